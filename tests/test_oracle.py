@@ -1,0 +1,187 @@
+"""CPU: the oracle (oracle/*.py) against the golden vectors generated from the
+reference itself (oracle/make_golden.py), plus independent-formulation checks of
+the complexPyTorch restatement (parity unpinned there: SURVEY.md §8c)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpt_oracle as cpt
+from oracle import nf_oracle as nf
+from oracle.cnet_oracle import C_NETWORK_Oracle
+from oracle.seeded_state import fill_state
+
+torch.set_num_threads(1)
+
+
+@pytest.fixture(scope='module')
+def nfv(golden_dir):
+    return np.load(os.path.join(golden_dir, 'nf_vectors.npz'))
+
+
+@pytest.fixture(scope='module')
+def cnv(golden_dir):
+    return np.load(os.path.join(golden_dir, 'cnet_vectors.npz'))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize('tag', ['small', 'mid'])
+def test_nf_elementwise_bit_exact(nfv, tag):
+    M, Y, S = _t(nfv[f'{tag}_M']), _t(nfv[f'{tag}_Y']), _t(nfv[f'{tag}_S'])
+    b1 = nf.bound_cRM(M)
+    b2 = nf.bound_cRM(b1)
+    # same torch ops in the same order on the same build: bit-exact
+    assert torch.equal(b1, _t(nfv[f'{tag}_bound1']))
+    assert torch.equal(b2, _t(nfv[f'{tag}_bound2']))
+    assert torch.equal(nf.cRM(S, Y), _t(nfv[f'{tag}_cRM']))
+    m, nhat, shat = nf.mask_apply_subtract(Y, b1)
+    assert torch.equal(m, b2)
+    assert torch.equal(nhat, _t(nfv[f'{tag}_nhat']))
+    assert torch.equal(shat, _t(nfv[f'{tag}_shat']))
+    assert torch.equal(nf.complex_lrelu(M), _t(nfv[f'{tag}_lrelu']))
+    assert torch.equal(nf.complex_sigmoid(M), _t(nfv[f'{tag}_sigmoid']))
+    B, F, T = M.shape
+    x4 = M.view(B, 2, F // 2, T)
+    assert torch.equal(nf.complex_adaptive_avg_pool2d(x4, 1), _t(nfv[f'{tag}_avgpool']))
+    # the reference's "max" pool is an average pool (network_functions.py:135-138)
+    assert torch.equal(nf.complex_adaptive_max_pool2d(x4, 1), _t(nfv[f'{tag}_maxpool']))
+    assert torch.equal(_t(nfv[f'{tag}_maxpool']), _t(nfv[f'{tag}_avgpool']))
+    a, b = torch.view_as_real(S).reshape(B, -1), torch.view_as_real(Y).reshape(B, -1)
+    assert torch.allclose(nf.si_snr(a, b), _t(nfv[f'{tag}_sisnr']), rtol=1e-6, atol=1e-6)
+
+
+def test_bound_is_bounded_and_double_bound_is_tanh_tanh(nfv):
+    M = _t(nfv['mid_M'])
+    b2 = _t(nfv['mid_bound2'])
+    assert float(b2.abs().max()) < 1.0
+    assert torch.allclose(b2.abs(), torch.tanh(torch.tanh(M.abs())), atol=2e-6)
+
+
+@pytest.mark.parametrize('tag,B,T,seed', [('b2t32', 2, 32, 0), ('b1t16', 1, 16, 1), ('b3t8', 3, 8, 2)])
+def test_cnet_wiring_against_reference(cnv, tag, B, T, seed):
+    net = fill_state(C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), seed)
+    x = _t(cnv[f'{tag}_x'])
+    assert tuple(x.shape) == (B, 256, T)
+    net.eval()
+    with torch.no_grad():
+        ev = net(x)
+    want = _t(cnv[f'{tag}_eval'])
+    assert ev.shape == want.shape                      # B==1: batch dim squeezed (c_network.py:224)
+    assert torch.allclose(ev, want, rtol=1e-5, atol=1e-6), float((ev - want).abs().max())
+    net.train()
+    tr = net(x)
+    want = _t(cnv[f'{tag}_train'])
+    assert torch.allclose(tr, want, rtol=1e-5, atol=1e-6), float((tr - want).abs().max())
+    sd = net.state_dict()
+    for k in ('initial_batchnorm.running_mean', 'initial_batchnorm.running_covar', 'encoder.3.1.running_mean',
+              'encoder.3.1.running_covar', 'decoder.2.1.running_mean', 'decoder.2.1.running_covar'):
+        assert torch.allclose(sd[k], _t(cnv[f'{tag}_after_{k}']), rtol=1e-5, atol=1e-6), k
+
+
+def _bias_before_bn(n):
+    return n.endswith('.bias') and (('.0.conv_r' in n or '.0.conv_i' in n) and n.startswith('encoder')
+                                    or ('.0.conv_tran_' in n and n.startswith('decoder')))
+
+
+def test_cnet_gradients_against_reference(cnv):
+    tag = 'b2t32'
+    net = fill_state(C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), 0)
+    net.train()
+    out = net(_t(cnv[f'{tag}_x']))
+    w = _t(cnv[f'{tag}_loss_w'])
+    loss = (w * (out.real ** 2 + 0.5 * out.imag ** 2 + 0.25 * out.real * out.imag)).sum()
+    loss.backward()
+    assert torch.allclose(loss.detach(), _t(cnv[f'{tag}_loss']), rtol=1e-5)
+    names = [str(n) for n in cnv[f'{tag}_grad_names']]
+    norms = cnv[f'{tag}_grad_norms']
+    pd = dict(net.named_parameters())
+    assert sorted(names) == sorted(pd.keys())          # state_dict / parameter names are the contract
+    for n, want in zip(names, norms):
+        g = pd[n].grad
+        if want < 0:                                   # decoder_attention.12/.13 never run -> grad None
+            assert g is None, n
+            assert n.startswith('decoder_attention.12') or n.startswith('decoder_attention.13')
+        elif _bias_before_bn(n):
+            # BN removes the mean, so this gradient is analytically zero: both sides are rounding noise
+            assert float(g.norm()) < 1e-3 and want < 1e-3, (n, float(g.norm()), want)
+        else:
+            assert abs(float(g.norm()) - want) <= 2e-4 * want + 1e-7, (n, float(g.norm()), want)
+    for k in cnv.files:
+        if k.startswith(f'{tag}_grad_') and k not in (f'{tag}_grad_names', f'{tag}_grad_norms'):
+            n = k[len(f'{tag}_grad_'):]
+            if _bias_before_bn(n):
+                continue
+            want = _t(cnv[k])
+            assert torch.allclose(pd[n].grad, want, rtol=2e-4, atol=1e-6 + 2e-4 * float(want.abs().max())), n
+
+
+# ---- independent formulations for the (unpinned) complexPyTorch restatement ----
+
+def test_complex_conv_equals_native_complex_conv():
+    torch.manual_seed(0)
+    m = cpt.ComplexConv2d(3, 5, 5, stride=(2, 1), padding=2)
+    x = torch.randn(2, 3, 12, 9, dtype=torch.complex64)
+    w = torch.complex(m.conv_r.weight, m.conv_i.weight)
+    b = torch.complex(m.conv_r.bias - m.conv_i.bias, m.conv_r.bias + m.conv_i.bias)   # two biases: SURVEY §8a a2
+    want = torch.nn.functional.conv2d(x, w, b, stride=(2, 1), padding=2)
+    assert torch.allclose(m(x), want, rtol=1e-4, atol=1e-5)
+
+
+def test_complex_convT_equals_flipped_correlation():
+    torch.manual_seed(1)
+    m = cpt.ComplexConvTranspose2d(4, 3, 3, stride=1, padding=1)
+    x = torch.randn(2, 4, 6, 7, dtype=torch.complex64)
+    w = torch.complex(m.conv_tran_r.weight, m.conv_tran_i.weight)          # [Cin,Cout,k,k]
+    wc = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+    b = torch.complex(m.conv_tran_r.bias - m.conv_tran_i.bias, m.conv_tran_r.bias + m.conv_tran_i.bias)
+    want = torch.nn.functional.conv2d(x, wc, b, padding=1)
+    assert torch.allclose(m(x), want, rtol=1e-4, atol=1e-5)
+
+
+def test_cbn_whitens_and_tracks_running_stats():
+    torch.manual_seed(2)
+    bn = cpt.ComplexBatchNorm2d(4)
+    A = torch.randn(2, 2)
+    z = torch.randn(8, 4, 10, 6, 2) @ A.T + torch.tensor([0.3, -0.7])
+    x = torch.view_as_complex(z.contiguous())
+    bn.train()
+    with torch.no_grad():
+        bn.weight[:, 0] = 1.0
+        bn.weight[:, 1] = 1.0
+        bn.weight[:, 2] = 0.0
+    y = bn(x)
+    yr = torch.view_as_real(y)
+    n = 8 * 10 * 6
+    mean = yr.mean(dim=(0, 2, 3))
+    assert float(mean.abs().max()) < 1e-5
+    yc = yr - mean[None, :, None, None, :]
+    cov = torch.einsum('bcftp,bcftq->cpq', yc, yc) / n
+    eye = torch.eye(2).expand(4, 2, 2)
+    assert torch.allclose(cov, eye, atol=2e-4)          # R C R = I (eps=1e-5)
+    xr = torch.view_as_real(x)
+    mu = xr.mean(dim=(0, 2, 3))
+    assert torch.allclose(torch.view_as_real(bn.running_mean), 0.1 * mu, atol=1e-6)
+    var_r = ((xr[..., 0] - mu[None, :, None, None, 0]) ** 2).mean(dim=(0, 2, 3)) + bn.eps
+    want = 0.9 * cpt.SQRT2 + 0.1 * var_r * n / (n - 1)
+    assert torch.allclose(bn.running_covar[:, 0], want, rtol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+    bn.eval()
+    y2 = bn(x)
+    assert y2.shape == x.shape and not torch.allclose(y2, y)
+
+
+def test_state_dict_contract():
+    net = C_NETWORK_Oracle()
+    keys = set(net.state_dict().keys())
+    for k in ('encoder.0.0.conv_r.weight', 'encoder.6.0.conv_i.bias', 'encoder.2.1.running_covar',
+              'encoder.2.1.running_mean', 'encoder.2.1.num_batches_tracked', 'initial_batchnorm.weight',
+              'lstm.real_lstm.weight_ih_l0', 'lstm.imag_lstm.weight_hh_l1_reverse', 'fc.fc_r.weight', 'fc.fc_i.bias',
+              'decoder.0.0.conv_tran_r.weight', 'decoder.6.conv_tran_i.bias', 'decoder.5.1.bias',
+              'skip_attention.0.fc.0.conv_r.weight', 'skip_attention.1.conv1.conv_i.weight',
+              'decoder_attention.12.fc.2.conv_r.weight', 'decoder_attention.13.conv1.conv_r.weight'):
+        assert k in keys, k
+    n_train = sum(p.numel() for p in net.parameters())
+    assert n_train == 2912707
