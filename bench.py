@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the DCS-Net hot path on MI355X, one JSON line on rank 0.
+
+  python bench.py --gpus N --steps K --warmup W [--mode infer|train]
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
+  infer  BASELINE.json configs[1]: C_NETWORK.eval() forward + bound/mask-apply/subtract,
+         complex64 [16,256,2000] per GPU (4 s of 16 kHz audio per utterance = 2000 STFT frames)
+  train  BASELINE.json configs[2]: forward + backward + Adam on [32,256,256] per GPU
+Utterances are independent, so ranks shard the batch with no data-path collective in `infer`
+(weak scaling: per-GPU work fixed) and one flat-bucket gradient all-reduce in `train`.
+
+Besides the contract fields the line carries
+  roofline      the dominant kernel (complex conv) timed live with HIP events inside the timed
+                region: algorithmic FLOPs of every launch / summed launch duration
+  cpu_baseline  the CPU oracle (oracle/cnet_oracle.py, a port: the reference's Python never
+                travels) timed on this box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'dcs-net_amd'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* = 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_stft_batch(B, T, device, seed=0):
+    """Audio-like synthetic batch: clean = 0.1 randn, noise = 0.05 randn, STFT
+    n_fft 512 / hop 32 / hann / normalized, bins 1..256 (data.py:112-118).  samples = T*hop - hop."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    n = T * 32 - 32
+    clean = 0.1 * torch.randn(B, n, generator=g)
+    noise = 0.05 * torch.randn(B, n, generator=g)
+    win = torch.hann_window(512)
+    st = lambda a: torch.stft(a, n_fft=512, hop_length=32, win_length=512, window=win, return_complex=True,
+                              normalized=True)[:, 1:257, :]
+    out = [st(noise), st(clean + noise), st(clean)]
+    assert out[0].shape == (B, 256, T), out[0].shape
+    return [o.contiguous().to(device) for o in out]
+
+
+class ConvTimer:
+    """HIP-event timing of every dcs_cconv2d_fwd launch inside the timed region (events are
+    recorded on the stream the kernel is launched on: torch's current stream)."""
+
+    def __init__(self):
+        self.events, self.flops, self.active = [], 0.0, False
+
+    def begin(self, flops):
+        if not self.active:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.flops += flops
+        return e0
+
+    def end(self, e0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.events.append((e0, e1))
+
+    def summary(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        return ms, len(self.events)
+
+
+def cpu_baseline(T, iters=2):
+    from oracle.cnet_oracle import C_NETWORK_Oracle
+    from oracle.nf_oracle import mask_apply_subtract
+    from oracle.seeded_state import fill_state, seeded_input
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = fill_state(C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), 0).eval()
+    B = 1
+    x = seeded_input(B, 256, T, seed=0, scale=0.1)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        mask_apply_subtract(x, net(x))
+        first = time.perf_counter() - t0
+        n = max(1, min(iters, int(20.0 / max(first, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            mask_apply_subtract(x, net(x))
+        dt = (time.perf_counter() - t0) / n
+    return {'value': B * T / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'oracle C_NETWORK eval forward + mask apply, B={B}, T={T}, {n} timed passes after 1 warm-up'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--mode', default='infer', choices=['infer'])
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
+    ap.add_argument('--frames', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from dcsnet import _lib, ops
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet import functional as F
+    _lib.load()
+
+    B = args.batch or 16
+    T = args.frames or 2000
+    torch.manual_seed(0)
+    net = C_NETWORK(config, hparams, 0).to(dev).eval()
+    noise, noisy, clean = synthetic_stft_batch(B, T, dev, seed=rank)
+
+    timer = ConvTimer()
+    ops.CONV_TIMER = timer
+
+    def step():
+        with torch.no_grad():
+            m_raw = net(noisy)
+            return F.bound_mask_apply_complex(noisy, m_raw, hparams['atan2_eps'])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.active = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.active = False
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        frames = B * T * world * args.steps
+        conv_ms, n_launch = timer.summary()
+        achieved = timer.flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        line = {
+            'metric': 'STFT frames/sec (forward-only inference: C_NETWORK forward + bound/mask-apply/subtract)',
+            'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: DCS-Net forward-only inference, complex64 [16,256,2000] per GPU '
+                                   '(4 s / 16 kHz STFT, n_fft 512 hop 32, bins 1..256), random-init weights seed 0',
+                       'per_gpu_batch': B, 'frames_per_utterance': T, 'global_batch': B * world,
+                       'frames_per_step': B * T * world, 'parallelism': f'dp{world} (utterance sharding, no collective)'},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'kernel': 'complex conv / convT (dcs_cconv2d_fwd), all launches of the timed region',
+                         'launches': n_launch, 'kernel_ms_per_step': conv_ms / args.steps,
+                         'algorithmic_gflop_per_step': timer.flops / args.steps / 1e9},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(T)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

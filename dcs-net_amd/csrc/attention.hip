@@ -1,0 +1,244 @@
+// attention.hip — the CBAM-style complex attentions of the skip and decoder paths
+// (c_network.py:53-84, applied at c_network.py:208-211 and :219-220), channels-last complex64.
+//
+// All HBM-bound.  The reference streams each activation ~8 times per attention pair (2 pools,
+// 2 broadcasts-multiplies, mean, 2 maxes, cat, final multiply).  Here:
+//   ca_pool_kernel        1 read  of x      -> per-sample channel sums (fp64 slabs, no atomics)
+//   ca_fc_kernel          tiny: slab sum, 1x1 conv, CReLU, 1x1 conv, x2 ("max" == avg quirk), sigmoid
+//   spatial_pool_kernel   1 read  of x      -> [mean_c, max_c] of ca*x per pixel (ca*x never stored)
+//   (7x7 2->1 conv + sigmoid: conv_direct.hip)
+//   attention_apply_kernel 1 read + 1 write -> sa * (ca * x), dropout fused
+// A lane group of G = C/2 lanes owns one pixel (one float4 = 2 complex channels per lane), so
+// per-pixel channel reductions are wavefront shuffles and every global access is a contiguous
+// 16-byte-per-lane stream.
+#include "dcs_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxChunks = 64;
+
+inline bool att_geom(int C, int* G) {
+    if (C < 2 || (C & 1)) return false;
+    int g = C / 2;
+    if (g > 64 || (g & (g - 1)) != 0) return false;   // lane group must sit inside one wave
+    *G = g;
+    return true;
+}
+
+inline int ca_chunks(long HW, int G) {
+    const int rows_per_iter = kThreads / G;
+    long it = (HW + rows_per_iter - 1) / rows_per_iter;
+    long nb = (it + 7) / 8;
+    return (int)(nb < 1 ? 1 : (nb > kMaxChunks ? kMaxChunks : nb));
+}
+
+// part[b][chunk][C][2] (double): sum over this chunk's pixels of x[b][p][c]
+__global__ __launch_bounds__(kThreads) void ca_pool_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                            long HW, int C, int G) {
+    __shared__ double red[kThreads * 4];
+    const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
+    const int b = blockIdx.y;
+    const float4* x4 = reinterpret_cast<const float4*>(x) + (long)b * HW * G;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (long r = (long)blockIdx.x * rpi + r0; r < HW; r += (long)gridDim.x * rpi) {
+        const float4 v = x4[r * G + g];
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    red[t * 4 + 0] = s0; red[t * 4 + 1] = s1; red[t * 4 + 2] = s2; red[t * 4 + 3] = s3;
+    __syncthreads();
+    for (int o = t; o < G * 4; o += kThreads) {
+        const int gg = o / 4, i = o % 4;
+        double a = 0;
+        for (int r = 0; r < rpi; ++r) a += red[(r * G + gg) * 4 + i];
+        part[(((long)b * gridDim.x + blockIdx.x) * C + 2 * gg) * 2 + i] = a;   // (c=2gg+(i>>1), ri=i&1)
+    }
+}
+
+// one workgroup per sample
+__global__ __launch_bounds__(kThreads) void ca_fc_kernel(const double* __restrict__ part, int nchunks,
+                                                          const float2* __restrict__ w1, const float2* __restrict__ w2,
+                                                          float2* __restrict__ ca_out, float2* __restrict__ pooled_out,
+                                                          float2* __restrict__ hidden_out, long HW, int C, int Ch) {
+    __shared__ float2 pooled[128];
+    __shared__ float2 hid[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int c = t; c < C; c += kThreads) {
+        double sr = 0, si = 0;
+        for (int k = 0; k < nchunks; ++k) {
+            const double* p = part + (((long)b * nchunks + k) * C + c) * 2;
+            sr += p[0]; si += p[1];
+        }
+        const float2 m = make_float2((float)(sr / (double)HW), (float)(si / (double)HW));
+        pooled[c] = m;
+        pooled_out[(long)b * C + c] = m;
+    }
+    __syncthreads();
+    for (int h = t; h < Ch; h += kThreads) {
+        float ar = 0.f, ai = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float2 w = w1[c * Ch + h], p = pooled[c];
+            ar = fmaf(w.x, p.x, ar); ar = fmaf(-w.y, p.y, ar);
+            ai = fmaf(w.x, p.y, ai); ai = fmaf(w.y, p.x, ai);
+        }
+        hidden_out[(long)b * Ch + h] = make_float2(ar, ai);
+        hid[h] = make_float2(ar > 0.f ? ar : 0.f, ai > 0.f ? ai : 0.f);
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += kThreads) {
+        float ar = 0.f, ai = 0.f;
+        for (int h = 0; h < Ch; ++h) {
+            const float2 w = w2[h * C + c], p = hid[h];
+            ar = fmaf(w.x, p.x, ar); ar = fmaf(-w.y, p.y, ar);
+            ai = fmaf(w.x, p.y, ai); ai = fmaf(w.y, p.x, ai);
+        }
+        // avg branch + "max" branch (an average, network_functions.py:135-138) = o + o
+        ar += ar; ai += ai;
+        ca_out[(long)b * C + c] = make_float2(1.f / (1.f + expf(-ar)), 1.f / (1.f + expf(-ai)));
+    }
+}
+
+__device__ __forceinline__ float group_sum(float v, int G) {
+    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float group_max(float v, int G) {
+    for (int o = G >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// pooled[b][p] = { mean_c z , max_c Re z + j max_c Im z },  z = ca[b][c] * x[b][p][c]
+__global__ __launch_bounds__(kThreads) void spatial_pool_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ ca,
+                                                                 float4* __restrict__ pooled, long HW, int C, int G) {
+    const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
+    const int b = blockIdx.y;
+    const float4* x4 = reinterpret_cast<const float4*>(x) + (long)b * HW * G;
+    float4 a = make_float4(1.f, 0.f, 1.f, 0.f);
+    if (ca) a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
+    const float invC = 1.f / (float)C;
+    // every lane of a group runs the same trip count, so the shuffles are convergent
+    const long iters = (HW + (long)gridDim.x * rpi - 1) / ((long)gridDim.x * rpi);
+    for (long k = 0; k < iters; ++k) {
+        const long r = (k * gridDim.x + blockIdx.x) * rpi + r0;
+        const bool ok = r < HW;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = x4[r * G + g];
+        const float z0r = a.x * v.x - a.y * v.y, z0i = a.x * v.y + a.y * v.x;
+        const float z1r = a.z * v.z - a.w * v.w, z1i = a.z * v.w + a.w * v.z;
+        const float sr = group_sum(z0r + z1r, G), si = group_sum(z0i + z1i, G);
+        const float mr = group_max(fmaxf(z0r, z1r), G), mi = group_max(fmaxf(z0i, z1i), G);
+        if (ok && g == 0) pooled[(long)b * HW + r] = make_float4(sr * invC, si * invC, mr, mi);
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(kThreads) void attention_apply_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ ca,
+                                                                    const float2* __restrict__ sa, float* __restrict__ y,
+                                                                    long HW, int C, int G, float drop_p, uint64_t seed) {
+    const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
+    const int b = blockIdx.y;
+    const long base = (long)b * HW * G;
+    const float4* x4 = reinterpret_cast<const float4*>(x) + base;
+    float4* y4 = reinterpret_cast<float4*>(y) + base;
+    float4 a = make_float4(1.f, 0.f, 1.f, 0.f);
+    if (ca) a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
+    const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
+    for (long r = (long)blockIdx.x * rpi + r0; r < HW; r += (long)gridDim.x * rpi) {
+        const float4 v = x4[r * G + g];
+        float2 s = make_float2(1.f, 0.f);
+        if (sa) s = sa[(long)b * HW + r];
+        const float z0r = a.x * v.x - a.y * v.y, z0i = a.x * v.y + a.y * v.x;
+        const float z1r = a.z * v.z - a.w * v.w, z1i = a.z * v.w + a.w * v.z;
+        float4 o;
+        o.x = s.x * z0r - s.y * z0i; o.y = s.x * z0i + s.y * z0r;
+        o.z = s.x * z1r - s.y * z1i; o.w = s.x * z1i + s.y * z1r;
+        if (DROP) {
+            const uint64_t e = (uint64_t)(base + r * G + g) * 4;
+            o.x *= dcs_keep_scale(seed, e, drop_p, inv_keep);
+            o.y *= dcs_keep_scale(seed, e + 1, drop_p, inv_keep);
+            o.z *= dcs_keep_scale(seed, e + 2, drop_p, inv_keep);
+            o.w *= dcs_keep_scale(seed, e + 3, drop_p, inv_keep);
+        }
+        y4[r * G + g] = o;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                            float drop_p, uint64_t seed) {
+    const float inv_keep = 1.f / (1.f - drop_p);
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads)
+        y[i] = x[i] * (drop_p > 0.f ? dcs_keep_scale(seed, (uint64_t)i, drop_p, inv_keep) : 1.f);
+}
+
+inline int stream_grid(long HW, int G, int B) {
+    const int rpi = kThreads / G;
+    long it = (HW + rpi - 1) / rpi;
+    long nb = (it + 3) / 4;
+    long cap = 2048 / (B > 0 ? B : 1);
+    if (cap < 1) cap = 1;
+    return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
+}
+
+}  // namespace
+
+extern "C" long dcs_ca_workspace_bytes(int B, long HW, int C) {
+    int G;
+    if (B <= 0 || HW <= 0 || !att_geom(C, &G)) return -1;
+    return (long)B * ca_chunks(HW, G) * C * 2 * (long)sizeof(double);
+}
+
+extern "C" int dcs_channel_attention_fwd(const float* x, const float* w1, const float* w2, float* ca_out,
+                                         float* pooled_out, float* hidden_out, void* workspace, long workspace_bytes,
+                                         int B, long HW, int C, int Ch, dcs_stream_t stream) {
+    int G;
+    if (!x || !w1 || !w2 || !ca_out || !pooled_out || !hidden_out || !workspace) return DCS_ERR_BADARG;
+    if (B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G) || Ch <= 0 || Ch > 64) return DCS_ERR_BADARG;
+    const int nch = ca_chunks(HW, G);
+    if (workspace_bytes < (long)B * nch * C * 2 * (long)sizeof(double)) return DCS_ERR_WORKSPACE;
+    hipStream_t s = dcs_stream(stream);
+    hipLaunchKernelGGL(ca_pool_kernel, dim3(nch, B), dim3(kThreads), 0, s, x, (double*)workspace, HW, C, G);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ca_fc_kernel, dim3(B), dim3(kThreads), 0, s, (const double*)workspace, nch, (const float2*)w1,
+                       (const float2*)w2, (float2*)ca_out, (float2*)pooled_out, (float2*)hidden_out, HW, C, Ch);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_spatial_pool_fwd(const float* x, const float* ca, float* pooled, int B, long HW, int C,
+                                    dcs_stream_t stream) {
+    int G;
+    if (!x || !pooled || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(spatial_pool_kernel, dim3(stream_grid(HW, G, B), B), dim3(kThreads), 0, dcs_stream(stream), x,
+                       ca, (float4*)pooled, HW, C, G);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, float* y, int B, long HW,
+                                       int C, float drop_p, unsigned long long seed, dcs_stream_t stream) {
+    int G;
+    if (!x || !y || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
+    dim3 grid(stream_grid(HW, G, B), B);
+    if (drop_p > 0.f)
+        hipLaunchKernelGGL(attention_apply_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), x, ca,
+                           (const float2*)sa, y, HW, C, G, drop_p, (uint64_t)seed);
+    else
+        hipLaunchKernelGGL(attention_apply_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), x, ca,
+                           (const float2*)sa, y, HW, C, G, drop_p, (uint64_t)seed);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_dropout_fwd(const float* x, float* y, long n, float drop_p, unsigned long long seed,
+                               dcs_stream_t stream) {
+    if (!x || !y || n <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
+    long nb = (n + kThreads * 4 - 1) / (kThreads * 4);
+    const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid), dim3(kThreads), 0, dcs_stream(stream), x, y, n, drop_p,
+                       (uint64_t)seed);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

@@ -1,0 +1,285 @@
+// cbn.hip — ComplexBatchNorm2d (complexPyTorch 0.3 semantics) for channels-last complex64.
+//
+// Replaces the ~12 reduction / element-wise ATen launches per CBN of the reference
+// (c_network.py:101,113,148) with:
+//   cbn_stats_kernel     one coalesced streaming read, per-thread fp32 partials around a
+//                        per-channel pivot, fp64 combine through LDS, one [C][5] fp64 slab
+//                        per workgroup (no atomics: bitwise reproducible)
+//   cbn_finalize_kernel  C threads: slab sum, covariance, closed-form inverse square root,
+//                        running-stat update, 2x2 affine folded to 6 coefficients / channel
+//   cbn_apply_kernel     y = act(A x + c) (+ dropout), float4 streaming, coefficients in VGPRs
+// HBM-bound: algorithmic bytes per pixel-channel = 8 (stats read) + 8 + 8 (apply read + write).
+#include "dcs_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 512;
+
+struct CbnGeom {
+    int vec_per_row;   // float4 groups per pixel row (C/2), or 0 for the C == 1 layout
+    int rows_per_iter; // pixel rows covered by one workgroup iteration
+    int nblocks;
+};
+
+inline bool cbn_geom(long P, int C, CbnGeom* g) {
+    if (P <= 0 || C <= 0) return false;
+    if (C == 1) {
+        long nvec = P / 2;
+        long it = (nvec + kThreads - 1) / kThreads;
+        long nb = (it + 7) / 8;
+        g->vec_per_row = 0;
+        g->rows_per_iter = 0;
+        g->nblocks = (int)(nb < 1 ? 1 : (nb > kMaxBlocks ? kMaxBlocks : nb));
+        return true;
+    }
+    if (C & 1) return false;
+    int G = C / 2;
+    if (G > kThreads || (kThreads % G) != 0) return false;
+    g->vec_per_row = G;
+    g->rows_per_iter = kThreads / G;
+    long it = (P + g->rows_per_iter - 1) / g->rows_per_iter;
+    long nb = (it + 7) / 8;
+    g->nblocks = (int)(nb < 1 ? 1 : (nb > kMaxBlocks ? kMaxBlocks : nb));
+    return true;
+}
+
+// partial slab layout: double part[nblocks][C][5] = {S_r, S_i, S_rr, S_ii, S_ri} of (x - pivot)
+__global__ __launch_bounds__(kThreads) void cbn_stats_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                              long P, int C, int G, int rows_per_iter) {
+    __shared__ double red[kThreads * 10];
+    const int t = threadIdx.x;
+    float s[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s[i] = 0.f;
+
+    if (C == 1) {
+        const float kr = x[0], ki = x[1];
+        const long nvec = P / 2;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (long i = (long)blockIdx.x * kThreads + t; i < nvec; i += (long)gridDim.x * kThreads) {
+            float4 v = x4[i];
+            float ar = v.x - kr, ai = v.y - ki, br = v.z - kr, bi = v.w - ki;
+            s[0] += ar + br;
+            s[1] += ai + bi;
+            s[2] = fmaf(ar, ar, fmaf(br, br, s[2]));
+            s[3] = fmaf(ai, ai, fmaf(bi, bi, s[3]));
+            s[4] = fmaf(ar, ai, fmaf(br, bi, s[4]));
+        }
+        if ((P & 1) && blockIdx.x == 0 && t == 0) {
+            float ar = x[2 * (P - 1)] - kr, ai = x[2 * (P - 1) + 1] - ki;
+            s[0] += ar; s[1] += ai; s[2] += ar * ar; s[3] += ai * ai; s[4] += ar * ai;
+        }
+        // all threads hold channel 0
+        double d[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) d[i] = dcs_wave_sum_d((double)s[i]);
+        const int wave = t >> 6, lane = t & 63;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) red[wave * 5 + i] = d[i];
+        }
+        __syncthreads();
+        if (t < 5) {
+            double a = 0;
+            for (int w = 0; w < kThreads / 64; ++w) a += red[w * 5 + t];
+            part[(long)blockIdx.x * 5 + t] = a;
+        }
+        return;
+    }
+
+    const int g = t % G;      // float4 group = complex channels 2g, 2g+1
+    const int r0 = t / G;
+    const float4 piv = reinterpret_cast<const float4*>(x)[g];   // row 0 of this channel pair
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
+        float4 v = x4[r * G + g];
+        float ar = v.x - piv.x, ai = v.y - piv.y, br = v.z - piv.z, bi = v.w - piv.w;
+        s[0] += ar; s[1] += ai;
+        s[2] = fmaf(ar, ar, s[2]); s[3] = fmaf(ai, ai, s[3]); s[4] = fmaf(ar, ai, s[4]);
+        s[5] += br; s[6] += bi;
+        s[7] = fmaf(br, br, s[7]); s[8] = fmaf(bi, bi, s[8]); s[9] = fmaf(br, bi, s[9]);
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) red[t * 10 + i] = (double)s[i];
+    __syncthreads();
+    // threads 0..G*10-1 each own one (g, i) column and sum over the rows_per_iter copies
+    for (int o = t; o < G * 10; o += kThreads) {
+        const int gg = o / 10, i = o % 10;
+        double a = 0;
+        for (int r = 0; r < rows_per_iter; ++r) a += red[(r * G + gg) * 10 + i];
+        const int c = 2 * gg + (i >= 5);
+        part[((long)blockIdx.x * C + c) * 5 + (i % 5)] = a;
+    }
+}
+
+__global__ void cbn_finalize_kernel(const float* __restrict__ x, const double* __restrict__ part, int nblocks,
+                                    const float* __restrict__ weight, const float* __restrict__ bias,
+                                    float* __restrict__ running_mean, float* __restrict__ running_covar,
+                                    float* __restrict__ stats_out, float* __restrict__ coef_out,
+                                    long P, int C, float eps, float momentum, int use_batch_stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mr, mi, Crr, Cii, Cri;
+    if (use_batch_stats) {
+        double S[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < nblocks; ++b) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) S[i] += part[((long)b * C + c) * 5 + i];
+        }
+        const double n = (double)P;
+        const double kr = (double)x[2 * c], ki = (double)x[2 * c + 1];   // pivot = pixel 0
+        const double dr = S[0] / n, di = S[1] / n;
+        mr = (float)(kr + dr);
+        mi = (float)(ki + di);
+        Crr = (float)(S[2] / n - dr * dr) + eps;
+        Cii = (float)(S[3] / n - di * di) + eps;
+        Cri = (float)(S[4] / n - dr * di);
+        if (momentum >= 0.f && running_mean != nullptr) {
+            const float f = momentum;
+            const float unb = P > 1 ? (float)(n / (n - 1.0)) : 1.f;
+            running_mean[2 * c] = f * mr + (1.f - f) * running_mean[2 * c];
+            running_mean[2 * c + 1] = f * mi + (1.f - f) * running_mean[2 * c + 1];
+            running_covar[3 * c + 0] = f * Crr * unb + (1.f - f) * running_covar[3 * c + 0];
+            running_covar[3 * c + 1] = f * Cii * unb + (1.f - f) * running_covar[3 * c + 1];
+            running_covar[3 * c + 2] = f * Cri * unb + (1.f - f) * running_covar[3 * c + 2];
+        }
+    } else {
+        mr = running_mean[2 * c];
+        mi = running_mean[2 * c + 1];
+        Crr = running_covar[3 * c + 0] + eps;
+        Cii = running_covar[3 * c + 1] + eps;
+        Cri = running_covar[3 * c + 2];
+    }
+    const float det = Crr * Cii - Cri * Cri;
+    const float s = sqrtf(det);
+    const float tt = sqrtf(Cii + Crr + 2.f * s);
+    const float ist = 1.0f / (s * tt);
+    const float Rrr = (Cii + s) * ist, Rii = (Crr + s) * ist, Rri = -Cri * ist;
+    float W0 = 1.f, W1 = 1.f, W2 = 0.f, b0 = 0.f, b1 = 0.f;
+    if (weight != nullptr) {
+        W0 = weight[3 * c]; W1 = weight[3 * c + 1]; W2 = weight[3 * c + 2];
+        b0 = bias[2 * c]; b1 = bias[2 * c + 1];
+    }
+    const float a0 = W0 * Rrr + W2 * Rri, a1 = W0 * Rri + W2 * Rii;
+    const float a2 = W2 * Rrr + W1 * Rri, a3 = W2 * Rri + W1 * Rii;
+    float* st = stats_out + 8 * c;
+    st[0] = mr; st[1] = mi; st[2] = Rrr; st[3] = Rii; st[4] = Rri; st[5] = Crr; st[6] = Cii; st[7] = Cri;
+    float* co = coef_out + 6 * c;
+    co[0] = a0; co[1] = a1; co[2] = a2; co[3] = a3;
+    co[4] = b0 - a0 * mr - a1 * mi;
+    co[5] = b1 - a2 * mr - a3 * mi;
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_t(float v) {
+    if (ACT == DCS_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == DCS_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+    return v;
+}
+
+// y = act(A x + c); thread keeps the coefficients of its fixed channel pair in registers.
+template <int ACT, bool DROP>
+__global__ __launch_bounds__(kThreads) void cbn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              const float* __restrict__ coef, long P, int C, int G,
+                                                              int rows_per_iter, float drop_p, uint64_t seed) {
+    const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
+    const int t = threadIdx.x;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    if (C == 1) {
+        const float a0 = coef[0], a1 = coef[1], a2 = coef[2], a3 = coef[3], c0 = coef[4], c1 = coef[5];
+        const long nvec = P / 2;
+        for (long i = (long)blockIdx.x * kThreads + t; i < nvec; i += (long)gridDim.x * kThreads) {
+            float4 v = x4[i], o;
+            o.x = act_t<ACT>(fmaf(a0, v.x, fmaf(a1, v.y, c0)));
+            o.y = act_t<ACT>(fmaf(a2, v.x, fmaf(a3, v.y, c1)));
+            o.z = act_t<ACT>(fmaf(a0, v.z, fmaf(a1, v.w, c0)));
+            o.w = act_t<ACT>(fmaf(a2, v.z, fmaf(a3, v.w, c1)));
+            if (DROP) {
+                const uint64_t e = (uint64_t)i * 4;
+                o.x *= dcs_keep_scale(seed, e, drop_p, inv_keep);
+                o.y *= dcs_keep_scale(seed, e + 1, drop_p, inv_keep);
+                o.z *= dcs_keep_scale(seed, e + 2, drop_p, inv_keep);
+                o.w *= dcs_keep_scale(seed, e + 3, drop_p, inv_keep);
+            }
+            y4[i] = o;
+        }
+        if ((P & 1) && blockIdx.x == 0 && t == 0) {
+            const float xr = x[2 * (P - 1)], xi = x[2 * (P - 1) + 1];
+            float yr = act_t<ACT>(fmaf(a0, xr, fmaf(a1, xi, c0)));
+            float yi = act_t<ACT>(fmaf(a2, xr, fmaf(a3, xi, c1)));
+            if (DROP) {
+                yr *= dcs_keep_scale(seed, (uint64_t)2 * (P - 1), drop_p, inv_keep);
+                yi *= dcs_keep_scale(seed, (uint64_t)2 * (P - 1) + 1, drop_p, inv_keep);
+            }
+            y[2 * (P - 1)] = yr;
+            y[2 * (P - 1) + 1] = yi;
+        }
+        return;
+    }
+    const int g = t % G, r0 = t / G;
+    const float* ca = coef + 12 * g;   // channels 2g and 2g+1, 6 floats each
+    const float a0 = ca[0], a1 = ca[1], a2 = ca[2], a3 = ca[3], c0 = ca[4], c1 = ca[5];
+    const float e0 = ca[6], e1 = ca[7], e2 = ca[8], e3 = ca[9], f0 = ca[10], f1 = ca[11];
+    for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
+        float4 v = x4[r * G + g], o;
+        o.x = act_t<ACT>(fmaf(a0, v.x, fmaf(a1, v.y, c0)));
+        o.y = act_t<ACT>(fmaf(a2, v.x, fmaf(a3, v.y, c1)));
+        o.z = act_t<ACT>(fmaf(e0, v.z, fmaf(e1, v.w, f0)));
+        o.w = act_t<ACT>(fmaf(e2, v.z, fmaf(e3, v.w, f1)));
+        if (DROP) {
+            const uint64_t e = (uint64_t)(r * G + g) * 4;
+            o.x *= dcs_keep_scale(seed, e, drop_p, inv_keep);
+            o.y *= dcs_keep_scale(seed, e + 1, drop_p, inv_keep);
+            o.z *= dcs_keep_scale(seed, e + 2, drop_p, inv_keep);
+            o.w *= dcs_keep_scale(seed, e + 3, drop_p, inv_keep);
+        }
+        y4[r * G + g] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" long dcs_cbn_workspace_bytes(long P, int C) {
+    CbnGeom g;
+    if (!cbn_geom(P, C, &g)) return -1;
+    return (long)g.nblocks * C * 5 * (long)sizeof(double);
+}
+
+extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
+                           float* running_covar, float* stats_out, float* coef_out, void* workspace,
+                           long workspace_bytes, long P, int C, float eps, float momentum, int use_batch_stats,
+                           int act, float drop_p, unsigned long long seed, dcs_stream_t stream) {
+    CbnGeom g;
+    if (!x || !y || !stats_out || !coef_out || !cbn_geom(P, C, &g)) return DCS_ERR_BADARG;
+    if ((weight == nullptr) != (bias == nullptr)) return DCS_ERR_BADARG;
+    if (!use_batch_stats && (!running_mean || !running_covar)) return DCS_ERR_BADARG;
+    if (act != DCS_ACT_NONE && act != DCS_ACT_RELU && act != DCS_ACT_LRELU) return DCS_ERR_BADARG;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
+    hipStream_t s = dcs_stream(stream);
+    if (use_batch_stats) {
+        if (!workspace || workspace_bytes < (long)g.nblocks * C * 5 * (long)sizeof(double)) return DCS_ERR_WORKSPACE;
+        hipLaunchKernelGGL(cbn_stats_kernel, dim3(g.nblocks), dim3(kThreads), 0, s, x, (double*)workspace, P, C,
+                           g.vec_per_row, g.rows_per_iter);
+        DCS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(cbn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, x, (const double*)workspace,
+                       g.nblocks, weight, bias, running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum,
+                       use_batch_stats);
+    DCS_CHECK_LAUNCH();
+    // apply: ~4 float4 per thread per workgroup pass, capped at 2048 workgroups
+    long iters = (C == 1) ? (P / 2 + kThreads - 1) / kThreads : (P + g.rows_per_iter - 1) / g.rows_per_iter;
+    long nb = (iters + 3) / 4;
+    int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+#define DCS_CBN_APPLY(A, D)                                                                                   \
+    hipLaunchKernelGGL((cbn_apply_kernel<A, D>), dim3(grid), dim3(kThreads), 0, s, x, y, coef_out, P, C,         \
+                       g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed)
+    const bool drop = drop_p > 0.f;
+    if (act == DCS_ACT_RELU) { if (drop) DCS_CBN_APPLY(DCS_ACT_RELU, true); else DCS_CBN_APPLY(DCS_ACT_RELU, false); }
+    else if (act == DCS_ACT_LRELU) { if (drop) DCS_CBN_APPLY(DCS_ACT_LRELU, true); else DCS_CBN_APPLY(DCS_ACT_LRELU, false); }
+    else { if (drop) DCS_CBN_APPLY(DCS_ACT_NONE, true); else DCS_CBN_APPLY(DCS_ACT_NONE, false); }
+#undef DCS_CBN_APPLY
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

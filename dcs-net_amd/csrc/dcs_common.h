@@ -1,0 +1,57 @@
+// dcs_common.h — shared helpers for the gfx950 kernels behind include/dcsnet_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dcsnet_hip.h"
+
+#define DCS_WAVE 64
+
+#define DCS_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return DCS_ERR_LAUNCH;        \
+    } while (0)
+
+static inline hipStream_t dcs_stream(dcs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ float dcs_act(float v, int act) {
+    if (act == DCS_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DCS_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+    if (act == DCS_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+
+// wave64 butterfly sum (every lane ends with the total)
+__device__ __forceinline__ float dcs_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double dcs_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float dcs_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Counter-based dropout RNG: one 32-bit hash per real element (re and im are
+// dropped independently, c_network.py:195-196).  Regenerated in backward from
+// (seed, element index); never stored.
+__device__ __forceinline__ uint32_t dcs_hash32(uint64_t seed, uint64_t idx) {
+    uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float dcs_keep_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    // uniform in [0,1): drop when u < p
+    float u = (float)(dcs_hash32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+    return u < p ? 0.f : inv_keep;
+}
+
+static inline int dcs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,81 @@
+"""ctypes binding of libdcsnet_hip.so (C ABI: include/dcsnet_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent this module
+raises, and every op built on it fails loudly.  PyTorch only owns device memory and streams;
+device pointers are borrowed for the duration of one call.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libdcsnet_hip.so')
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_long
+_F = ctypes.c_float
+_U64 = ctypes.c_ulonglong
+
+# name -> (restype, argtypes); must mirror include/dcsnet_hip.h exactly
+SIGNATURES = {
+    'dcs_abi_version': (_I, []),
+    'dcs_error_string': (ctypes.c_char_p, [_I]),
+    'dcs_pack_conv_weight': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'dcs_cconv2d_fwd': (_I, [_P, _P, _P, _P, _P] + [_I] * 15 + [_P]),
+    'dcs_cbn_workspace_bytes': (_L, [_L, _I]),
+    'dcs_cbn_fwd': (_I, [_P] * 9 + [_L, _L, _I, _F, _F, _I, _I, _F, _U64, _P]),
+    'dcs_ca_workspace_bytes': (_L, [_I, _L, _I]),
+    'dcs_channel_attention_fwd': (_I, [_P] * 7 + [_L, _I, _L, _I, _I, _P]),
+    'dcs_spatial_pool_fwd': (_I, [_P, _P, _P, _I, _L, _I, _P]),
+    'dcs_attention_apply_fwd': (_I, [_P, _P, _P, _P, _I, _L, _I, _F, _U64, _P]),
+    'dcs_dropout_fwd': (_I, [_P, _P, _L, _F, _U64, _P]),
+    'dcs_complex_act_fwd': (_I, [_P, _P, _L, _I, _P]),
+    'dcs_complex_upsample_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'dcs_bound_crm_fwd': (_I, [_P, _P, _L, _F, _P]),
+    'dcs_bound_mask_apply_fwd': (_I, [_P, _P, _P, _P, _P, _L, _F, _P]),
+    'dcs_crm_fwd': (_I, [_P, _P, _P, _L, _F, _P]),
+}
+
+_lib = None
+
+
+class DcsHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raises if it has not been built (python dcs-net_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DcsHipError(f'{LIB_PATH} not found: build it with `python dcs-net_amd/build.py` '
+                          '(there is no CPU or eager fallback)')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DcsHipError(f'{LIB_PATH} does not export {name}; rebuild it') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().dcs_error_string(code).decode()
+        raise DcsHipError(f'{what}: {msg} (code {code})')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def cur_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,304 @@
+"""DCS-Net's complex encoder / decoder behind the reference's ``c_network`` surface
+(c_network.py:12-416): same class names, constructor ``C_NETWORK(config, hparams, seed)``,
+sub-module names and registration order (=> same state_dict keys), same ``forward(x)`` contract
+(complex64 ``[B,256,T]`` in, bounded complex mask out, batch dimension squeezed when ``B == 1``),
+same trainer hook names — so the reference's ``train.py`` / ``test.py`` drive it unchanged.
+
+What differs is underneath: ``forward`` does not walk the module tree.  It runs the path as a
+sequence of fused HIP kernels on channels-last interleaved-complex activations
+(libdcsnet_hip.so, include/dcsnet_hip.h):
+
+  encoder stage   conv (LDS-tiled / MFMA)  ->  CBN statistics  ->  CBN apply + CReLU + dropout
+  skip attention  channel pool + FC  ->  per-pixel channel pool of ca*x  ->  7x7 conv + sigmoid
+  decoder stage   convT whose input gather performs  cat(d, sa*ca*skip)  and the nearest upsample
+                  -> CBN + CLReLU -> decoder attention (+ dropout)
+  output          bound_cRM
+
+The sub-modules (``ComplexConv2d`` ...) are the parameter containers and remain individually
+callable (layer-by-layer drop-in surface, dcsnet/complexLayers.py).
+"""
+import sys
+
+import torch
+
+from . import functional as F
+from ._pl_compat import LightningModule, seed_everything
+from .complexLayers import (ComplexConv2d, ComplexConvTranspose2d, ComplexBatchNorm2d,   # noqa: F401
+                            ComplexLinear, ComplexReLU)
+from .complexFunctions import complex_upsample, complex_relu                               # noqa: F401
+from .network_functions import *                                                           # noqa: F401,F403
+from .network_functions import (ComplexAdaptiveAvgPool2d, ComplexAdaptiveMaxPool2d, ComplexSigmoid,
+                                train_batch_2_loss, val_batch_2_metric_loss, test_batch_2_metric_loss,
+                                epoch_end, _mode)
+
+
+class ComplexLSTM(torch.nn.Module):
+    """c_network.py:12-51.  Two real 2-layer bidirectional LSTMs (MIOpen through PyTorch-ROCm:
+    latency-bound, 2.8 % of the forward FLOPs — SURVEY.md §7), combined as a complex product."""
+
+    def __init__(self, input_size, hidden_size, num_layers, bidirectional, batch_first, projection_dim=None):
+        super().__init__()
+        self.input_dim, self.rnn_units = input_size, hidden_size
+        kw = dict(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                  bidirectional=bidirectional, batch_first=batch_first)
+        self.real_lstm = torch.nn.LSTM(**kw)
+        self.imag_lstm = torch.nn.LSTM(**kw)
+        self.projection_dim = projection_dim
+        if projection_dim is not None:
+            width = hidden_size * (2 if bidirectional else 1)
+            self.r_trans = torch.nn.Linear(width, projection_dim)
+            self.i_trans = torch.nn.Linear(width, projection_dim)
+
+    def forward(self, inputs):
+        re, im = inputs.real.contiguous(), inputs.imag.contiguous()
+        rr, ri = self.real_lstm(re)[0], self.imag_lstm(re)[0]
+        ir, ii = self.real_lstm(im)[0], self.imag_lstm(im)[0]
+        out_r, out_i = rr - ii, ir + ri
+        if self.projection_dim is not None:
+            out_r, out_i = self.r_trans(out_r), self.i_trans(out_i)
+        return torch.complex(out_r, out_i)
+
+    def flatten_parameters(self):
+        self.imag_lstm.flatten_parameters()
+        self.real_lstm.flatten_parameters()
+
+
+class ComplexChannelAttention(torch.nn.Module):
+    """c_network.py:53-69."""
+
+    def __init__(self, no_channels, reduction_ratio):
+        super().__init__()
+        hidden = max(no_channels // reduction_ratio, 1)
+        self.avg_pool = ComplexAdaptiveAvgPool2d(1)
+        self.max_pool = ComplexAdaptiveMaxPool2d(1)
+        self.fc = torch.nn.Sequential(ComplexConv2d(no_channels, hidden, kernel_size=1, bias=False),
+                                      ComplexReLU(),
+                                      ComplexConv2d(hidden, no_channels, kernel_size=1, bias=False))
+        self.sigmoid = ComplexSigmoid()
+
+    def hip(self, x):
+        """x: float [B,H,W,C,2] -> ca float [B,C,2]."""
+        return F.channel_attention(x, self.fc[0].conv_r.weight, self.fc[0].conv_i.weight,
+                                   self.fc[2].conv_r.weight, self.fc[2].conv_i.weight)
+
+    def forward(self, x):
+        B, C = x.shape[0], x.shape[1]
+        return torch.view_as_complex(self.hip(F.to_nhwc(x))).view(B, C, 1, 1)
+
+
+class ComplexSpatialAttention(torch.nn.Module):
+    """c_network.py:71-84."""
+
+    def __init__(self, kernel_size):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.conv1 = ComplexConv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
+        self.sigmoid = ComplexSigmoid()
+
+    def hip(self, x, ca=None):
+        """sa float [B,H,W,1,2] of z = ca*x (ca=None: of x)."""
+        return F.spatial_attention(x, ca, self.conv1.conv_r.weight, self.conv1.conv_i.weight, self.kernel_size)
+
+    def forward(self, x):
+        return F.from_nhwc(self.hip(F.to_nhwc(x)))
+
+
+class C_NETWORK(LightningModule):
+    def __init__(self, config, hparams, seed):
+        super().__init__()
+        seed_everything(seed)
+        self.config = config
+        self.hparams.update(hparams)
+        self.save_hyperparameters(self.hparams)
+        hp = self.hparams
+        ch, L = hp['channels'], hp['no_of_layers']
+
+        # registration order is part of the checkpoint contract (c_network.py:95-98)
+        self.encoder = torch.nn.ModuleList()
+        self.decoder = torch.nn.ModuleList()
+        self.decoder_attention = torch.nn.ModuleList()
+        self.skip_attention = torch.nn.ModuleList()
+
+        self.initial_batchnorm = ComplexBatchNorm2d(max(ch[0] // 2, 1))
+        for i in range(L):
+            cin = 1 if i == 0 else ch[i] // 2
+            cout = ch[i + 1] // 2
+            self.encoder.append(torch.nn.Sequential(
+                ComplexConv2d(cin, cout, kernel_size=config.kernel_sizeE[i], stride=config.strideE[i],
+                              padding=config.paddingE[i]),
+                ComplexBatchNorm2d(cout),
+                config.CactivationE()))
+
+        self.lstm = ComplexLSTM(input_size=ch[4], hidden_size=ch[4] // 2, num_layers=hp['lstm_layers'],
+                                bidirectional=hp['lstm_bidir'], batch_first=True)
+        self.fc = ComplexLinear(ch[5] // 2, ch[5] // 2)
+
+        ratio, sk = hp['channel_attention_reduction_ratio'], hp['spatial_attention_kernel_size']
+        for i in range(L):
+            both = ch[L - i]
+            cout = max(ch[L - 1 - i] // 2, 1)
+            convt = ComplexConvTranspose2d(both, cout, kernel_size=config.kernel_sizeD[i], stride=config.strideD,
+                                           padding=config.paddingD[i])
+            if i == L - 1:
+                self.decoder.append(convt)
+            else:
+                self.decoder.append(torch.nn.Sequential(convt, ComplexBatchNorm2d(cout), config.CactivationD()))
+            self.skip_attention.append(ComplexChannelAttention(both // 2, ratio))
+            self.skip_attention.append(ComplexSpatialAttention(sk))
+            self.decoder_attention.append(ComplexChannelAttention(cout, ratio))
+            self.decoder_attention.append(ComplexSpatialAttention(sk))
+
+        self.dropout_conv = torch.nn.Dropout(hp['dropout_conv'])
+        self.dropout_fc = torch.nn.Dropout(hp['dropout_fc'])
+        self._drop_calls = 0
+        self.weights_init()
+
+    def weights_init(self):
+        init = self.hparams['initialisation_distribution']
+        for m in self.modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.Linear)):
+                init(m.weight)
+
+    # ---- fused HIP forward ------------------------------------------------------------------
+
+    def _drop(self, p):
+        """(p, seed) for the next fused dropout site; p = 0 in eval like nn.Dropout."""
+        if not self.training or p <= 0.0:
+            return 0.0, 0
+        self._drop_calls += 1
+        return p, (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77) & 0x7FFFFFFFFFFFFFFF
+
+    def _bn(self, bn, x, act, p=0.0):
+        dp, seed = self._drop(p)
+        return bn._hip_forward(x, act, dp, seed)
+
+    def forward(self, x):
+        hp, cfg = self.hparams, self.config
+        L = hp['no_of_layers']
+        p_conv, p_fc = self.dropout_conv.p, self.dropout_fc.p
+        if x.dim() != 3 or x.dtype != torch.complex64:
+            raise F.DcsHipError(f'C_NETWORK.forward expects complex64 [B,F,T], got {x.dtype} {tuple(x.shape)}')
+        B, Fbins, T = x.shape
+        if Fbins % (1 << L) or T % 8:
+            raise F.DcsHipError(f'F must be a multiple of {1 << L} and T of 8 (config.py:99,105); got F={Fbins}, T={T}')
+
+        # [B,F,T] complex IS channels-last with C = 1 (c_network.py:190)
+        e = torch.view_as_real(x.contiguous()).view(B, Fbins, T, 1, 2)
+        enc = [self._bn(self.initial_batchnorm, e, F.ACT_NONE)]
+        for i in range(L):                                   # c_network.py:193-197
+            conv, bn = self.encoder[i][0], self.encoder[i][1]
+            c = F.cconv2d(enc[i], None, conv.conv_r.weight, conv.conv_i.weight, conv.conv_r.bias, conv.conv_i.bias,
+                          False, conv.kernel_size, conv.stride, conv.padding)
+            enc.append(self._bn(bn, c, F.ACT_RELU, p_conv))
+
+        # latent (c_network.py:199-205): channels-last [B,F7,T7,C] is already [B, seq, C]
+        lat = enc[L]
+        _, F7, T7, C7, _ = lat.shape
+        z = self.fc(self.lstm(torch.view_as_complex(lat).view(B, F7 * T7, C7)))
+        zr = torch.view_as_real(z.contiguous())
+        dp, seed = self._drop(p_fc)
+        if dp > 0:
+            zr = F.dropout(zr, dp, seed)
+        d = zr.view(B, F7, T7, C7, 2)
+
+        for i in range(L):                                   # c_network.py:207-222
+            skip = enc[L - i]
+            ca_m, sa_m = self.skip_attention[2 * i], self.skip_attention[2 * i + 1]
+            ca = ca_m.hip(skip)
+            sa = sa_m.hip(skip, ca)
+            skip = F.attention_apply(skip, ca, sa)
+            stage = self.decoder[i]
+            convt = stage if i == L - 1 else stage[0]
+            y = F.cconv2d(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight, convt.conv_tran_r.bias,
+                          convt.conv_tran_i.bias, True, convt.kernel_size, (1, 1), convt.corr_padding,
+                          tuple(cfg.upsample_scale_factor[i]))
+            if i != L - 1:
+                a = self._bn(stage[1], y, F.ACT_LRELU)
+                ca_m, sa_m = self.decoder_attention[2 * i], self.decoder_attention[2 * i + 1]
+                ca = ca_m.hip(a)
+                sa = sa_m.hip(a, ca)
+                dp, seed = self._drop(p_conv)
+                d = F.attention_apply(a, ca, sa, dp, seed)
+            else:
+                dp, seed = self._drop(p_conv)
+                d = F.dropout(y, dp, seed) if dp > 0 else y
+
+        net_out = F.ops.bound_crm(d.view(B, Fbins, T, 2), hp['atan2_eps'])
+        return torch.squeeze(torch.view_as_complex(net_out))          # c_network.py:224
+
+    # ---- trainer hooks (c_network.py:229-416) -------------------------------------------------
+
+    def configure_optimizers(self):
+        hp = self.hparams
+        optimiser = torch.optim.Adam(self.parameters(), lr=hp['lr'], eps=hp['optim_eps'],
+                                     weight_decay=hp['optim_weight_decay'], amsgrad=hp['optim_amsgrad'])
+        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimiser, patience=10)
+        return {'optimizer': optimiser, 'lr_scheduler': scheduler,
+                'monitor': 'val_loss' if _mode() in ('dcs', 'drs') else 'speech_loss'}
+
+    def training_step(self, train_batch, batch_idx):
+        out = train_batch_2_loss(self, train_batch, batch_idx, dtype='complex')
+        if _mode() in ('dcs', 'drs'):
+            noise_loss, speech_loss, loss = out
+            metrics = {'train_loss': loss.detach(), 'noise_loss': noise_loss.detach(),
+                       'speech_loss': speech_loss.detach()}
+        else:
+            loss = out
+            metrics = {'speech_loss': loss.detach()}
+        self.log_dict(metrics, on_epoch=True)
+        if torch.any(torch.isnan(loss)):
+            print('found NaN in C train loss!')
+            return None
+        return loss
+
+    def _eval_step(self, fn, batch, idx, prefix):
+        out = fn(self, batch, idx, dtype='complex')
+        if _mode() in ('dcs', 'drs'):
+            noise_loss, speech_loss, loss, pesq_av, stoi_av, n_hat, s_hat, noise, noisy, clean = out[:10]
+            metrics = {f'{prefix}_loss': loss.detach(), f'{prefix}_noise_loss': noise_loss.detach(),
+                       f'{prefix}_speech_loss': speech_loss.detach(),
+                       f'{prefix}_pesq': torch.tensor(pesq_av), f'{prefix}_stoi': torch.tensor(stoi_av)}
+            audio = {'clean': clean, 'predict_clean': s_hat, 'noise': noise, 'predict_noise': n_hat, 'noisy': noisy}
+        else:
+            speech_loss, pesq_av, stoi_av, s_hat, noise, noisy, clean = out[:7]
+            loss = speech_loss
+            metrics = {f'{prefix}_speech_loss': speech_loss.detach(),
+                       f'{prefix}_pesq': torch.tensor(pesq_av), f'{prefix}_stoi': torch.tensor(stoi_av)}
+            audio = {'clean': clean, 'predict_clean': s_hat, 'noise': noise, 'noisy': noisy}
+        return loss, {k: v.detach().cpu().numpy() for k, v in audio.items()}, metrics
+
+    def validation_step(self, val_batch, val_idx):
+        loss, audio, metrics = self._eval_step(val_batch_2_metric_loss, val_batch, val_idx, 'val')
+        if torch.any(torch.isnan(loss)):
+            print('found a NaN in C val loss!')
+            return None
+        return audio, metrics
+
+    def test_step(self, test_batch, test_idx):
+        _, audio, metrics = self._eval_step(test_batch_2_metric_loss, test_batch, test_idx, 'test')
+        return audio, metrics
+
+    def _epoch_end(self, step_outputs, prefix):
+        step_outputs = [o for o in step_outputs if o is not None]
+        audio = [o[0] for o in step_outputs]
+        keys = step_outputs[0][1].keys() if step_outputs else []
+        metrics = {k: torch.stack([torch.as_tensor(o[1][k]).float() for o in step_outputs]).mean() for k in keys}
+        metrics['step'] = self.current_epoch
+        epoch_end(self, audio, prefix)
+        self.log_dict(metrics, on_epoch=True)
+        return metrics
+
+    def validation_epoch_end(self, validation_step_outputs):
+        return self._epoch_end(validation_step_outputs, 'val')
+
+    def test_epoch_end(self, test_step_outputs):
+        return self._epoch_end(test_step_outputs, 'test')
+
+    def on_after_backward(self):
+        trainer = getattr(self, 'trainer', None)
+        if trainer is None or trainer.global_step % 25 != 0 or getattr(self, 'logger', None) is None:
+            return
+        grads = [p.grad.flatten() if p.grad is not None else p.new_zeros(1) for p in self.parameters()]
+        vals = torch.cat(grads)
+        self.logger.experiment.add_scalar('grad val avg', vals.mean(), global_step=trainer.global_step)
+        self.logger.experiment.add_scalar('grad norm', torch.linalg.norm(vals), global_step=trainer.global_step)

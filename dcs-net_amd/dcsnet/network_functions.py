@@ -1,0 +1,233 @@
+"""Mask math, complex element-wise layers and step functions around the hot path, with the
+names and argument meaning of the reference's ``network_functions.py`` so ``c_network`` /
+``train.py`` / ``test.py`` find what they star-import.
+
+On the hot path (HIP, libdcsnet_hip.so):  bound_cRM (:77-88), cRM (:62-75), the bound + complex
+multiply + subtract of the step functions (:240-243), complex_lrelu / complex_sigmoid
+(:98-112).  Plumbing that stays on PyTorch-ROCm (SURVEY.md §8f "next"): torch.istft, SiSNR,
+loss assembly.
+"""
+import sys
+
+import torch
+
+from . import functional as F
+
+try:                                     # metric packages are absent from this image
+    from pypesq import pesq
+except ImportError:                      # pragma: no cover
+    pesq = None
+try:
+    from pystoi import stoi
+except ImportError:                      # pragma: no cover
+    stoi = None
+
+
+def _mode():
+    """The reference reads the network choice from sys.argv[1] deep inside the model code
+    (network_functions.py:170,223); default to 'dcs' when a harness has not set it."""
+    return sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ('dcs', 'drs', 'dc', 'dr') else 'dcs'
+
+
+def check_inf_neginf_nan(tensor, error_msg):
+    t = torch.view_as_real(tensor) if tensor.is_complex() else tensor
+    assert bool(torch.isfinite(t).all()), error_msg
+
+
+class SiSNR(object):
+    """network_functions.py:30-42."""
+
+    def __call__(self, clean, estimate, eps=1e-8):
+        dot = torch.sum(estimate * clean, -1, keepdim=True)
+        energy = torch.sum(clean * clean, -1, keepdim=True)
+        target = dot * clean / (energy + eps)
+        resid = estimate - target
+        t = torch.sum(target * target, -1, keepdim=True)
+        r = torch.sum(resid * resid, -1, keepdim=True)
+        return torch.mean(10 * torch.log10(t / (r + eps) + eps))
+
+
+class wSDR(object):
+    """network_functions.py:45-60."""
+
+    def __call__(self, mixed, clean, clean_est, eps=2e-8):
+        def neg_cos(a, b):
+            return -(a * b).sum(1) / (torch.norm(a, p=2, dim=1) * torch.norm(b, p=2, dim=1) + eps)
+
+        noise, noise_est = mixed - clean, mixed - clean_est
+        e_c, e_n = (clean ** 2).sum(1), (noise ** 2).sum(1)
+        alpha = e_c / (e_c + e_n + eps)
+        return torch.mean(alpha * neg_cos(clean, clean_est) + (1 - alpha) * neg_cos(noise, noise_est))
+
+
+# ---- hot-path element-wise math: HIP ----------------------------------------------------------
+
+def cRM(S, Y, eps=1e-8):
+    return F.crm_complex(S, Y, eps)
+
+
+def bound_cRM(cRM, hparams):
+    return F.bound_crm_complex(cRM, hparams['atan2_eps'])
+
+
+def complex_mat_mult(A, B):
+    """Element-wise complex product (network_functions.py:90-96).  The step functions below do
+    not call this: they use the fused bound + multiply + subtract kernel."""
+    return A * B
+
+
+def bound_mask_apply(noisy_data, mask_out, hparams):
+    """network_functions.py:240-243 in one kernel: returns (bounded mask, Y (.) M, Y - Y (.) M)."""
+    return F.bound_mask_apply_complex(noisy_data, mask_out, hparams['atan2_eps'])
+
+
+def complex_lrelu(input):
+    return F.complex_lrelu(input)
+
+
+def complex_sigmoid(input):
+    return F.complex_sigmoid(input)
+
+
+class ComplexLReLU(torch.nn.Module):
+    def forward(self, input):
+        return complex_lrelu(input)
+
+
+class ComplexSigmoid(torch.nn.Module):
+    def forward(self, input):
+        return complex_sigmoid(input)
+
+
+def complex_adaptive_avg_pool2d(input, output_size=1):
+    if output_size not in (1, (1, 1)):
+        raise NotImplementedError('only the global pool the reference uses (c_network.py:56-57)')
+    return torch.view_as_complex(torch.view_as_real(input).mean(dim=(2, 3), keepdim=True))
+
+
+def complex_adaptive_max_pool2d(input, output_size=1):
+    """The reference's "max" pool is an average pool (network_functions.py:135-138)."""
+    return complex_adaptive_avg_pool2d(input, output_size)
+
+
+class ComplexAdaptiveAvgPool2d(torch.nn.Module):
+    def __init__(self, output_size):
+        super().__init__()
+        self.output_size = output_size
+
+    def forward(self, input):
+        return complex_adaptive_avg_pool2d(input, self.output_size)
+
+
+class ComplexAdaptiveMaxPool2d(torch.nn.Module):
+    def __init__(self, output_size):
+        super().__init__()
+        self.output_size = output_size
+
+    def forward(self, input):
+        return complex_adaptive_max_pool2d(input, self.output_size)
+
+
+# ---- step functions (plumbing on PyTorch-ROCm around the HIP path) ------------------------------
+
+def mag_phase_2_wave(mag, phase, config):
+    """network_functions.py:140-150; the window follows the tensor's device instead of the
+    reference's hard-coded cuda index (:147)."""
+    comp = torch.complex(mag * torch.cos(phase), mag * torch.sin(phase))
+    comp = torch.nn.functional.pad(comp, (0, 0, 0, 1))
+    return torch.istft(comp, n_fft=config.fft_size, hop_length=config.hop_length, win_length=config.window_length,
+                       window=config.window.to(comp.device), normalized=config.normalise_stft)
+
+
+def _polar_wave(z, eps, config):
+    return mag_phase_2_wave(torch.abs(z), torch.atan2(z.imag, z.real + eps), config)
+
+
+def calc_metric(clean_audio, predict_audio, config, metric):
+    if metric is None:
+        return float('nan')
+    vals = []
+    for i in range(predict_audio.shape[0]):
+        v = metric(clean_audio[i, :].cpu().numpy(), predict_audio[i, :].cpu().numpy(), config.sr)
+        if v == v:
+            vals.append(v)
+    return float(sum(vals)) / max(len(vals), 1)
+
+
+def calc_loss(self, **kw):
+    """network_functions.py:168-208 for the loss types the reference configures
+    (noise_loss_type 6, speech_loss_type 0: config.py:38-39)."""
+    mode = _mode()
+    alpha = self.hparams['speech_alpha']
+    speech_loss = alpha * (-self.config.SiSNR(kw['clean_audio'], kw['predict_clean_audio']))
+    if mode in ('dc', 'dr'):
+        return speech_loss
+    t = self.hparams['noise_loss_type']
+    if t == 6:
+        raw = -self.config.SiSNR(kw['noise_audio'], kw['predict_noise_audio'])
+    elif t == 1:
+        raw = self.config.wSDR(kw['noisy_audio'], kw['noise_audio'], kw['predict_noise_audio'])
+    elif t == 0:
+        raw = self.config.L1(torch.view_as_real(kw['target_noise_mask']), torch.view_as_real(kw['predict_noise_mask']))
+    else:
+        raise NotImplementedError(f'noise_loss_type {t}')
+    noise_loss = 1 - alpha * raw                       # QUIRK kept: network_functions.py:196
+    return noise_loss, speech_loss, noise_loss + speech_loss
+
+
+def _complex_step(self, noise_data, noisy_data, clean_data):
+    eps = self.hparams['atan2_eps']
+    cfg = self.config
+    audio = {'noise_audio': _polar_wave(noise_data, eps, cfg), 'noisy_audio': _polar_wave(noisy_data, eps, cfg),
+             'clean_audio': _polar_wave(clean_data, eps, cfg)}
+    mask_out = self(noisy_data)
+    if _mode() in ('dcs', 'drs'):
+        audio['target_noise_mask'] = bound_cRM(cRM(noise_data, noisy_data), self.hparams)
+        mask, noise_hat, clean_hat = bound_mask_apply(noisy_data, mask_out, self.hparams)
+        audio['predict_noise_mask'] = mask
+        audio['predict_noise_audio'] = _polar_wave(noise_hat, eps, cfg)
+        audio['predict_clean_audio'] = _polar_wave(clean_hat, eps, cfg)
+    else:                                               # 'dc': the mask is applied, not subtracted
+        _, clean_hat, _ = bound_mask_apply(noisy_data, mask_out, self.hparams)
+        audio['predict_clean_audio'] = _polar_wave(clean_hat, eps, cfg)
+    return audio
+
+
+def train_batch_2_loss(self, train_batch, batch_idx, dtype):
+    noise_data, noisy_data, clean_data = train_batch[:3]
+    if dtype != 'complex':
+        raise NotImplementedError('the HIP build covers the complex network (DCS/DC-Net)')
+    return calc_loss(self, **_complex_step(self, noise_data, noisy_data, clean_data))
+
+
+def val_batch_2_metric_loss(self, val_batch, val_idx, dtype):
+    noise_data, noisy_data, clean_data = val_batch[:3]
+    if dtype != 'complex':
+        raise NotImplementedError('the HIP build covers the complex network (DCS/DC-Net)')
+    a = _complex_step(self, noise_data, noisy_data, clean_data)
+    pesq_av = calc_metric(a['clean_audio'], a['predict_clean_audio'], self.config, pesq)
+    stoi_av = calc_metric(a['clean_audio'], a['predict_clean_audio'], self.config, stoi)
+    losses = calc_loss(self, **a)
+    if _mode() in ('dcs', 'drs'):
+        return (*losses, pesq_av, stoi_av, a['predict_noise_audio'], a['predict_clean_audio'],
+                a['noise_audio'], a['noisy_audio'], a['clean_audio'])
+    return losses, pesq_av, stoi_av, a['predict_clean_audio'], a['noise_audio'], a['noisy_audio'], a['clean_audio']
+
+
+def test_batch_2_metric_loss(self, test_batch, test_idx, dtype):
+    out = val_batch_2_metric_loss(self, test_batch[:4], test_idx, dtype)
+    if _mode() in ('dcs', 'drs'):
+        return (*out, test_batch[3], test_batch[4])
+    return out
+
+
+def epoch_end(self, outputs, type):
+    """Audio-sample logging (network_functions.py:450-498) needs the trainer's TensorBoard
+    logger; without one there is nothing to write."""
+    logger = getattr(self, 'logger', None)
+    if logger is None or not outputs:
+        return
+    exp = logger.experiment
+    last = outputs[-1]
+    for name, wav in last.items():
+        exp.add_audio(f'{type}_{name}', torch.as_tensor(wav[0]).unsqueeze(0), self.current_epoch, self.config.sr)

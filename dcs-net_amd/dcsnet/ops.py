@@ -1,0 +1,216 @@
+"""Tensor-level wrappers over the C ABI (include/dcsnet_hip.h).
+
+Activations are float32 CUDA tensors of shape [B, H, W, C, 2] — channels-last interleaved
+complex, the memory of a torch complex64 [B, C, H, W] tensor in channels_last format.  Every
+function validates device / dtype / contiguity and raises on a non-zero return code; there is
+no eager or CPU fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, check, ptr, cur_stream  # noqa: F401
+
+
+def _chk(t, name, dims=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.DcsHipError(f'{name}: expected a CUDA (HIP) tensor; the HIP path has no CPU fallback')
+    if t.dtype != torch.float32:
+        raise _lib.DcsHipError(f'{name}: expected float32, got {t.dtype}')
+    if not t.is_contiguous():
+        raise _lib.DcsHipError(f'{name}: expected a contiguous tensor')
+    if dims is not None and t.dim() != dims:
+        raise _lib.DcsHipError(f'{name}: expected {dims} dims, got shape {tuple(t.shape)}')
+
+
+CONV_TIMER = None        # set by bench.py: object with begin(flops) -> token / end(token)
+
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream); reused across calls on the same stream."""
+    key = (device.index, cur_stream())
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def pack_conv_weight(w_r, w_i, b_r=None, b_i=None, transposed=False):
+    """(conv_r.weight, conv_i.weight[, biases]) -> (wp [k*k,Cin,Cout,2], bias [Cout,2])."""
+    for n, t in (('w_r', w_r), ('w_i', w_i), ('b_r', b_r), ('b_i', b_i)):
+        _chk(t, n)
+    if transposed:
+        Cin, Cout, kh, kw = w_r.shape
+    else:
+        Cout, Cin, kh, kw = w_r.shape
+    wp = torch.empty((kh * kw, Cin, Cout, 2), dtype=torch.float32, device=w_r.device)
+    bias = torch.empty((Cout, 2), dtype=torch.float32, device=w_r.device)
+    lib = _lib.load()
+    check(lib.dcs_pack_conv_weight(ptr(w_r), ptr(w_i), ptr(b_r), ptr(b_i), ptr(wp), ptr(bias),
+                                   Cout, Cin, kh, kw, int(bool(transposed)), cur_stream()), 'dcs_pack_conv_weight')
+    return wp, bias
+
+
+def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=ACT_NONE):
+    """Complex correlation over the virtual input upsample(cat(x1, x2)); see dcs_cconv2d_fwd."""
+    _chk(x1, 'x1', 5)
+    _chk(x2, 'x2', 5)
+    _chk(wp, 'wp', 4)
+    _chk(bias, 'bias', 2)
+    B, Hin, Win, C1, _ = x1.shape
+    C2 = 0
+    if x2 is not None:
+        if x2.shape[:3] != x1.shape[:3]:
+            raise _lib.DcsHipError(f'cconv2d: x1 {tuple(x1.shape)} and x2 {tuple(x2.shape)} differ in B/H/W')
+        C2 = x2.shape[3]
+    kh, kw = ksize
+    if wp.shape[0] != kh * kw or wp.shape[1] != C1 + C2:
+        raise _lib.DcsHipError(f'cconv2d: packed weight {tuple(wp.shape)} does not match k={ksize}, Cin={C1 + C2}')
+    Cout = wp.shape[2]
+    Hout = (Hin * up[0] + 2 * pad[0] - kh) // stride[0] + 1
+    Wout = (Win * up[1] + 2 * pad[1] - kw) // stride[1] + 1
+    y = torch.empty((B, Hout, Wout, Cout, 2), dtype=torch.float32, device=x1.device)
+    lib = _lib.load()
+    # bench.py's live roofline probe: 8 real flops per complex MAC
+    ev = CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw) if CONV_TIMER is not None else None
+    check(lib.dcs_cconv2d_fwd(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(y), B, Hin, Win, C1, C2, up[0], up[1],
+                              Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], act, cur_stream()),
+          'dcs_cconv2d_fwd')
+    if ev is not None:
+        CONV_TIMER.end(ev)
+    return y
+
+
+def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, use_batch_stats=True,
+        act=ACT_NONE, drop_p=0.0, seed=0, out=None):
+    """ComplexBatchNorm2d (+act +dropout).  running_mean: float [C,2] view of the complex buffer.
+    Returns (y, stats [C,8], coef [C,6])."""
+    _chk(x, 'x', 5)
+    for n, t in (('weight', weight), ('bias', bias), ('running_mean', running_mean), ('running_covar', running_covar)):
+        _chk(t, n)
+    B, H, W, C, _ = x.shape
+    P = B * H * W
+    y = torch.empty_like(x) if out is None else out
+    stats = torch.empty((C, 8), dtype=torch.float32, device=x.device)
+    coef = torch.empty((C, 6), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.dcs_cbn_workspace_bytes(P, C)
+    if nbytes < 0:
+        raise _lib.DcsHipError(f'cbn: unsupported channel count C={C}')
+    ws = _workspace(nbytes, x.device)
+    check(lib.dcs_cbn_fwd(ptr(x), ptr(y), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_covar),
+                          ptr(stats), ptr(coef), ptr(ws), ws.numel(), P, C, eps,
+                          -1.0 if momentum is None else momentum, int(bool(use_batch_stats)), act,
+                          float(drop_p), int(seed), cur_stream()), 'dcs_cbn_fwd')
+    return y, stats, coef
+
+
+def channel_attention(x, w1, w2):
+    """x [B,H,W,C,2]; w1 packed [1,C,Ch,2]; w2 packed [1,Ch,C,2] -> (ca [B,C,2], pooled, hidden)."""
+    _chk(x, 'x', 5)
+    _chk(w1, 'w1')
+    _chk(w2, 'w2')
+    B, H, W, C, _ = x.shape
+    Ch = w1.shape[-2]
+    ca = torch.empty((B, C, 2), dtype=torch.float32, device=x.device)
+    pooled = torch.empty((B, C, 2), dtype=torch.float32, device=x.device)
+    hidden = torch.empty((B, Ch, 2), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.dcs_ca_workspace_bytes(B, H * W, C)
+    if nbytes < 0:
+        raise _lib.DcsHipError(f'channel_attention: unsupported channel count C={C}')
+    ws = _workspace(nbytes, x.device)
+    check(lib.dcs_channel_attention_fwd(ptr(x), ptr(w1), ptr(w2), ptr(ca), ptr(pooled), ptr(hidden), ptr(ws),
+                                        ws.numel(), B, H * W, C, Ch, cur_stream()), 'dcs_channel_attention_fwd')
+    return ca, pooled, hidden
+
+
+def spatial_pool(x, ca=None):
+    _chk(x, 'x', 5)
+    _chk(ca, 'ca', 3)
+    B, H, W, C, _ = x.shape
+    pooled = torch.empty((B, H, W, 2, 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().dcs_spatial_pool_fwd(ptr(x), ptr(ca), ptr(pooled), B, H * W, C, cur_stream()),
+          'dcs_spatial_pool_fwd')
+    return pooled
+
+
+def attention_apply(x, ca=None, sa=None, drop_p=0.0, seed=0, out=None):
+    _chk(x, 'x', 5)
+    _chk(ca, 'ca', 3)
+    _chk(sa, 'sa')
+    B, H, W, C, _ = x.shape
+    y = torch.empty_like(x) if out is None else out
+    check(_lib.load().dcs_attention_apply_fwd(ptr(x), ptr(ca), ptr(sa), ptr(y), B, H * W, C, float(drop_p),
+                                              int(seed), cur_stream()), 'dcs_attention_apply_fwd')
+    return y
+
+
+def dropout(x, drop_p, seed, out=None):
+    _chk(x, 'x')
+    y = torch.empty_like(x) if out is None else out
+    check(_lib.load().dcs_dropout_fwd(ptr(x), ptr(y), x.numel(), float(drop_p), int(seed), cur_stream()),
+          'dcs_dropout_fwd')
+    return y
+
+
+def complex_act(x, act, out=None):
+    _chk(x, 'x')
+    y = torch.empty_like(x) if out is None else out
+    check(_lib.load().dcs_complex_act_fwd(ptr(x), ptr(y), x.numel(), act, cur_stream()), 'dcs_complex_act_fwd')
+    return y
+
+
+def complex_upsample(x, up):
+    _chk(x, 'x', 5)
+    B, H, W, C, _ = x.shape
+    y = torch.empty((B, H * up[0], W * up[1], C, 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().dcs_complex_upsample_fwd(ptr(x), ptr(y), B, H, W, C, up[0], up[1], cur_stream()),
+          'dcs_complex_upsample_fwd')
+    return y
+
+
+def bound_crm(M, eps=10e-7, out=None):
+    """M: float [..., 2] interleaved complex."""
+    _chk(M, 'M')
+    y = torch.empty_like(M) if out is None else out
+    check(_lib.load().dcs_bound_crm_fwd(ptr(M), ptr(y), M.numel() // 2, eps, cur_stream()), 'dcs_bound_crm_fwd')
+    return y
+
+
+def bound_mask_apply(Y, M_in, eps=10e-7):
+    _chk(Y, 'Y')
+    _chk(M_in, 'M_in')
+    if Y.shape != M_in.shape:
+        raise _lib.DcsHipError(f'bound_mask_apply: Y {tuple(Y.shape)} vs M {tuple(M_in.shape)}')
+    M, N, S = torch.empty_like(Y), torch.empty_like(Y), torch.empty_like(Y)
+    check(_lib.load().dcs_bound_mask_apply_fwd(ptr(Y), ptr(M_in), ptr(M), ptr(N), ptr(S), Y.numel() // 2, eps,
+                                               cur_stream()), 'dcs_bound_mask_apply_fwd')
+    return M, N, S
+
+
+def crm(S, Y, eps=1e-8):
+    _chk(S, 'S')
+    _chk(Y, 'Y')
+    M = torch.empty_like(S)
+    check(_lib.load().dcs_crm_fwd(ptr(S), ptr(Y), ptr(M), S.numel() // 2, eps, cur_stream()), 'dcs_crm_fwd')
+    return M
+
+
+# ---- complex <-> channels-last float views -------------------------------------------------
+
+def to_nhwc(z):
+    """complex64 [B,C,H,W] (any strides) -> float32 [B,H,W,C,2] contiguous (no copy if the input
+    is already in channels_last memory format)."""
+    if z.dtype != torch.complex64:
+        raise _lib.DcsHipError(f'expected complex64, got {z.dtype}')
+    return torch.view_as_real(z.permute(0, 2, 3, 1).contiguous())
+
+
+def from_nhwc(x):
+    """float32 [B,H,W,C,2] -> complex64 logical [B,C,H,W] in channels_last memory (a view)."""
+    return torch.view_as_complex(x).permute(0, 3, 1, 2)

@@ -1,0 +1,187 @@
+/*
+ * dcsnet_hip.h — C ABI of libdcsnet_hip.so: the MI355X (gfx950) implementation of the
+ * DCS-Net complex encoder/decoder hot path.
+ *
+ * The reference (jackhwalters/DCS-Net) is pure Python; it has no FFI of its own.  Every
+ * entry point below replaces a group of implicit ATen/cuDNN dispatches that the
+ * reference issues from Python, and cites the reference call site it stands in for.
+ * The reference-side binding (a ctypes stub a maintainer would add) is in INTEGRATION.md;
+ * this repo's own binding is dcs-net_amd/dcsnet/_lib.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and ints.  No torch / HIP types in any signature:
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - Every pointer is a DEVICE pointer BORROWED from the caller.  The library never
+ *     allocates, frees or retains caller memory; workspaces are passed in.
+ *   - Kernels are enqueued on `stream`; no call synchronises.  No global mutable state.
+ *   - Return value: 0 = enqueued; <0 = error (DCS_ERR_*), nothing was enqueued.
+ *   - Complex tensors are interleaved (re, im) fp32 pairs — the memory of a torch
+ *     complex64 tensor.  Activations are CHANNELS-LAST: x[b][f][t][c] complex,
+ *     i.e. float[B][F][T][C][2]  (a torch complex64 [B,C,F,T] tensor in
+ *     torch.channels_last memory format).  "pixel" = one (b,f,t) position.
+ *   - Parameters keep the reference's checkpoint layout (complexPyTorch 0.3):
+ *     conv_r/conv_i weight float[Cout][Cin][kh][kw]; conv_tran_r/_i weight
+ *     float[Cin][Cout][kh][kw]; CBN weight float[C][3], bias float[C][2],
+ *     running_mean complex[C], running_covar float[C][3].
+ */
+#ifndef DCSNET_HIP_H
+#define DCSNET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dcs_stream_t;
+
+#define DCS_OK              0
+#define DCS_ERR_BADARG     (-1)   /* null pointer, non-positive dim, unsupported geometry */
+#define DCS_ERR_LAUNCH     (-2)   /* hipLaunch reported an error */
+#define DCS_ERR_WORKSPACE  (-3)   /* workspace too small */
+
+/* activation codes shared by several entry points */
+#define DCS_ACT_NONE   0
+#define DCS_ACT_RELU   1   /* complexPyTorch complex_relu: relu on re and on im (config.py:103) */
+#define DCS_ACT_LRELU  2   /* network_functions.py:103-105, slope 0.01 (config.py:104)          */
+#define DCS_ACT_SIGMOID 3  /* network_functions.py:111-112                                       */
+
+int         dcs_abi_version(void);            /* bumps when a signature changes */
+const char* dcs_error_string(int code);
+
+/* ------------------------------------------------------------------------------------
+ * Weight packing.  Replaces nothing in the reference (it keeps two real layers per
+ * complex layer, c_network.py:107-112 / :135-147); this turns the pair (w_r, w_i) into
+ * ONE correlation weight the conv kernels consume:
+ *     wp[tap][ci][co] = (w_r + j w_i)           complex, tap = dy*kw + dx
+ * transposed != 0: the inputs are ConvTranspose2d weights [Cin][Cout][kh][kw]; for the
+ * stride-1 transposed convs of the decoder (config.py:84,92-100) the equivalent
+ * correlation kernel is the spatially flipped, in/out-swapped one, which this writes.
+ * bias_out[co] = (b_r - b_i) + j (b_r + b_i)   — both real layers carry a bias
+ * (SURVEY.md §8a a2); b_r/b_i may be NULL (bias=False: attention convs c_network.py:58-60,74).
+ * wp: complex[kh*kw][Cin][Cout]; bias_out: complex[Cout] (always written, zeros if no bias).
+ */
+int dcs_pack_conv_weight(const float* w_r, const float* w_i, const float* b_r, const float* b_i,
+                         float* wp, float* bias_out,
+                         int Cout, int Cin, int kh, int kw, int transposed, dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * ComplexConv2d / ComplexConvTranspose2d forward (apply_complex of complexPyTorch 0.3).
+ * Replaces: c_network.py:107-112 via encoder[i][0] (c_network.py:194), the decoder's
+ * conv_tran at c_network.py:135-147 via decoder[i] (c_network.py:217) TOGETHER WITH the
+ * torch.cat at c_network.py:214 and complex_upsample at c_network.py:215-216, and the
+ * attention convs at c_network.py:58-60,74.
+ *
+ * The logical input is X[b][iy][ix][ci], ci in [0, C1+C2):
+ *     ci <  C1 : x1[b][iy/up_f][ix/up_t][ci]          (decoder path "d")
+ *     ci >= C1 : x2[b][iy/up_f][ix/up_t][ci-C1]       (skip path; x2 may be NULL iff C2==0)
+ * with x1: complex[B][Hin][Win][C1], x2: complex[B][Hin][Win][C2], nearest-neighbour
+ * upsampling by (up_f, up_t) >= 1.  Output y: complex[B][Hout][Wout][Cout],
+ *     Hout = (Hin*up_f + 2*pad_f - kh)/sf + 1,  Wout likewise,
+ *     y[b,oy,ox,co] = bias[co] + sum_{dy,dx,ci} wp[dy*kw+dx][ci][co] * X[b, oy*sf-pad_f+dy, ox*st-pad_t+dx, ci]
+ * (complex product; X is zero outside its bounds).  act: DCS_ACT_* applied to re and im.
+ * wp/bias as written by dcs_pack_conv_weight.
+ */
+int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const float* bias, float* y,
+                    int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                    int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
+                    dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * ComplexBatchNorm2d forward (complexPyTorch 0.3), fused with the activation and the
+ * dropout that follow it in the reference.
+ * Replaces: c_network.py:101 (initial_batchnorm, :190), :113-114 (encoder CBN + CReLU),
+ * :148-150 (decoder CBN + CLReLU), and dropout_conv on the real view (:195-196).
+ *
+ * Training (use_batch_stats != 0): per-channel complex mean and biased 2x2 covariance over
+ * all B*F*T pixels, eps added to Crr and Cii; running_mean / running_covar updated with
+ * `momentum` and the n/(n-1) factor (skipped when momentum < 0).  Eval: running stats.
+ * Then whiten with the closed-form inverse matrix square root and apply the symmetric
+ * affine weight [C][3] and bias [C][2]; y = act(.) (DCS_ACT_NONE/RELU/LRELU), then inverted
+ * dropout (keep 1-drop_p, independent on re and im, mask = hash(seed, float index)) if drop_p > 0.
+ *   x, y        complex[P][C], P = B*F*T pixels   (y may alias x)
+ *   stats_out   float[C][8]: mean_r, mean_i, Rrr, Rii, Rri, Crr, Cii, Cri (saved for backward)
+ *   coef_out    float[C][6]: y_r = a0 x_r + a1 x_i + c0 ; y_i = a2 x_r + a3 x_i + c1, then act
+ *   workspace   >= dcs_cbn_workspace_bytes(P, C) bytes, 16-byte aligned
+ */
+long dcs_cbn_workspace_bytes(long P, int C);
+int  dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bias,
+                 float* running_mean, float* running_covar,
+                 float* stats_out, float* coef_out, void* workspace, long workspace_bytes,
+                 long P, int C, float eps, float momentum, int use_batch_stats, int act,
+                 float drop_p, unsigned long long seed, dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * ComplexChannelAttention (c_network.py:53-69): per sample, mean over (F,T) of every
+ * channel, the two bias-free 1x1 complex convs with CReLU between, and the complex sigmoid.
+ * QUIRK kept: the "max" branch is an average pool (network_functions.py:135-138), so the
+ * result is sigmoid_c(fc(avg) + fc(avg)).
+ *   x        complex[B][HW][C]
+ *   w1       complex[C][Ch]   packed 1x1 weight of fc.0 (dcs_pack_conv_weight, tap dim = 1)
+ *   w2       complex[Ch][C]   packed 1x1 weight of fc.2
+ *   ca_out   complex[B][C]
+ *   pooled_out complex[B][C]  (saved for backward), hidden_out complex[B][Ch] (pre-ReLU, saved)
+ *   workspace >= dcs_ca_workspace_bytes(B, HW, C)
+ */
+long dcs_ca_workspace_bytes(int B, long HW, int C);
+int  dcs_channel_attention_fwd(const float* x, const float* w1, const float* w2,
+                               float* ca_out, float* pooled_out, float* hidden_out,
+                               void* workspace, long workspace_bytes,
+                               int B, long HW, int C, int Ch, dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * ComplexSpatialAttention, first half (c_network.py:77-82): with z = ca[b,c] * x[p,c]
+ * (complex product; ca may be NULL = 1), per pixel
+ *     pooled[p][0] = mean_c z ;  pooled[p][1] = max_c Re z + j max_c Im z
+ * The 7x7 2->1 conv + sigmoid of c_network.py:83-84 is dcs_cconv2d_fwd(act=SIGMOID).
+ *   x complex[B][HW][C]; ca complex[B][C]; pooled complex[B][HW][2]
+ */
+int dcs_spatial_pool_fwd(const float* x, const float* ca, float* pooled,
+                         int B, long HW, int C, dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Attention application (c_network.py:209,211 and :219-220) fused with dropout_conv
+ * (:221-222):  y[p][c] = sa[p] * (ca[b][c] * x[p][c])   (two true complex products),
+ * then inverted dropout with keep probability 1-p independently on re and im when p > 0
+ * (mask = hash(seed, element index); regenerated, not stored).  y may alias x.
+ */
+int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, float* y,
+                            int B, long HW, int C, float drop_p, unsigned long long seed,
+                            dcs_stream_t stream);
+
+/* Stand-alone inverted dropout on a real view (c_network.py:203-204 dropout_fc after the
+ * ComplexLinear; c_network.py:221-222 on the last decoder stage, which has no attention to
+ * fuse it into).  n floats; same mask rule as above; y may alias x; drop_p == 0 copies. */
+int dcs_dropout_fwd(const float* x, float* y, long n, float drop_p, unsigned long long seed,
+                    dcs_stream_t stream);
+
+/* Stand-alone complexPyTorch surface used only by the layer-by-layer drop-in modules
+ * (ComplexReLU config.py:103 / complex_relu, ComplexLReLU, ComplexSigmoid; complex_upsample
+ * c_network.py:215).  C_NETWORK.forward fuses both into their producers / consumers instead.
+ *   dcs_complex_act_fwd:      y = act(x) on n_floats floats (re and im alike); y may alias x.
+ *   dcs_complex_upsample_fwd: x complex[B][H][W][C] -> y complex[B][H*up_f][W*up_t][C], nearest. */
+int dcs_complex_act_fwd(const float* x, float* y, long n_floats, int act, dcs_stream_t stream);
+int dcs_complex_upsample_fwd(const float* x, float* y, int B, int H, int W, int C, int up_f, int up_t,
+                             dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * bound_cRM (network_functions.py:77-88), as called at c_network.py:225:
+ *     m = tanh|M| ; phi1 = atan2(Mi, Mr+eps) ; phi2 = atan2(m sin phi1, m cos phi1 + eps)
+ *     out = m cos phi2 + j m sin phi2
+ * n complex elements; out may alias in.
+ */
+int dcs_bound_crm_fwd(const float* M_raw, float* M_out, long n, float eps, dcs_stream_t stream);
+
+/* The "complex subtractive mask application" of the step functions
+ * (network_functions.py:240-243 train, :313-316 val, :394-397 test):
+ *     M = bound_cRM(M_in) ; N_hat = Y (.) M (complex_mat_mult, element-wise) ; S_hat = Y - N_hat
+ * Y, M_in: complex[n]; M_out, N_hat, S_hat: complex[n] (M_out may alias M_in).
+ */
+int dcs_bound_mask_apply_fwd(const float* Y, const float* M_in, float* M_out, float* N_hat, float* S_hat,
+                             long n, float eps, dcs_stream_t stream);
+
+/* cRM target mask (network_functions.py:62-75): M = S conj(Y) / (|Y|^2 + 1e-8). */
+int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCSNET_HIP_H */

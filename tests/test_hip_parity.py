@@ -1,0 +1,318 @@
+"""GPU parity: every HIP entry point (called through the C ABI via dcsnet.ops) against the CPU
+oracle on the same seeded inputs, and against the golden vectors generated from the reference.
+
+Tolerances (fp32 path, stated per the north star): element-wise mask math 2e-6 absolute on a
+mask of modulus < 1; convolutions / batch-norm 2e-5 relative to the tensor's max-abs (fp32
+accumulation order differs from the CPU's); whole network 2e-4 absolute on the bounded mask.
+"""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpt_oracle as cpt          # noqa: E402
+from oracle import nf_oracle as nf            # noqa: E402
+from oracle import cnet_oracle as cno         # noqa: E402
+from oracle.seeded_state import fill_state, seeded_input   # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from dcsnet import _lib
+    _lib.load()                                   # fail loudly if the HIP library is missing
+    return torch.device('cuda:0')
+
+
+def rand_c(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.complex(torch.randn(shape, generator=g) * scale, torch.randn(shape, generator=g) * scale)
+
+
+def nhwc(z, dev):
+    from dcsnet import ops
+    return ops.to_nhwc(z.to(dev))
+
+
+def back(x):
+    from dcsnet import ops
+    return ops.from_nhwc(x).cpu()
+
+
+def close(got, want, rel=2e-5, abs_=0.0):
+    got, want = got.detach().cpu(), want.detach().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = float(want.abs().max()) if want.numel() else 1.0
+    err = float((got - want).abs().max()) if want.numel() else 0.0
+    assert err <= rel * scale + abs_, f'max err {err:.3e} vs scale {scale:.3e}'
+
+
+# --------------------------------------------------------------------------------- convolution
+
+ENC = [(1, 8, 7, (2, 2)), (8, 16, 7, (2, 2)), (16, 32, 5, (2, 2)), (32, 64, 5, (2, 1)),
+       (64, 128, 3, (2, 1)), (128, 128, 3, (2, 1))]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride', ENC)
+def test_complex_conv2d_encoder_geometries(dev, cin, cout, k, stride):
+    from dcsnet import functional as F
+    torch.manual_seed(cin * 7 + k)
+    m = cpt.ComplexConv2d(cin, cout, k, stride, k // 2)
+    H, W = (36, 24) if cin <= 16 else (12, 16)
+    x = rand_c((2, cin, H, W), 11)
+    want = m(x)
+    p = lambda t: t.detach().to(dev)
+    y = F.cconv2d(nhwc(x, dev), None, p(m.conv_r.weight), p(m.conv_i.weight), p(m.conv_r.bias), p(m.conv_i.bias),
+                  False, (k, k), stride, (k // 2, k // 2))
+    close(back(y), want)
+
+
+@pytest.mark.parametrize('c1,c2,cout,up', [(128, 128, 128, (2, 1)), (32, 32, 16, (2, 2)), (8, 8, 1, (2, 2)),
+                                            (16, 0, 8, (1, 1))])
+def test_complex_convtranspose_with_fused_cat_upsample(dev, c1, c2, cout, up):
+    from dcsnet import functional as F
+    torch.manual_seed(c1 + cout)
+    m = cpt.ComplexConvTranspose2d(c1 + c2, cout, 3, 1, 1)
+    d = rand_c((2, c1, 6, 10), 3)
+    s = rand_c((2, c2, 6, 10), 4) if c2 else None
+    cat = torch.cat((d, s), dim=1) if c2 else d
+    want = m(cpt.complex_upsample(cat, scale_factor=up, mode='nearest'))
+    p = lambda t: t.detach().to(dev)
+    y = F.cconv2d(nhwc(d, dev), nhwc(s, dev) if c2 else None, p(m.conv_tran_r.weight), p(m.conv_tran_i.weight),
+                  p(m.conv_tran_r.bias), p(m.conv_tran_i.bias), True, (3, 3), (1, 1), (1, 1), up)
+    close(back(y), want)
+
+
+def test_conv_edge_shapes_ragged_tiles_and_1x1(dev):
+    from dcsnet import functional as F
+    torch.manual_seed(5)
+    p = lambda t: t.detach().to(dev)
+    # output 19x5: not a multiple of the 16x16 tile; batch 1
+    m = cpt.ComplexConv2d(4, 2, 3, (1, 2), 1)
+    x = rand_c((1, 4, 19, 9), 8)
+    y = F.cconv2d(nhwc(x, dev), None, p(m.conv_r.weight), p(m.conv_i.weight), p(m.conv_r.bias), p(m.conv_i.bias),
+                  False, (3, 3), (1, 2), (1, 1))
+    close(back(y), m(x))
+    # bias-free 1x1 (channel-attention FC shape) on a 1x1 map
+    m = cpt.ComplexConv2d(16, 1, 1, bias=False)
+    x = rand_c((3, 16, 1, 1), 9)
+    y = F.cconv2d(nhwc(x, dev), None, p(m.conv_r.weight), p(m.conv_i.weight), None, None, False, (1, 1), (1, 1), (0, 0))
+    close(back(y), m(x))
+
+
+def test_complex_linear(dev):
+    from dcsnet import functional as F
+    torch.manual_seed(6)
+    m = cpt.ComplexLinear(128, 128)
+    z = rand_c((2, 24, 128), 2)
+    p = lambda t: t.detach().to(dev)
+    y = F.complex_linear(z.to(dev), p(m.fc_r.weight), p(m.fc_i.weight), p(m.fc_r.bias), p(m.fc_i.bias))
+    close(y, m(z))
+
+
+# --------------------------------------------------------------------------------- batch norm
+
+@pytest.mark.parametrize('C,shape', [(1, (2, 16, 24)), (1, (1, 3, 5)), (8, (2, 12, 10)), (64, (3, 6, 8)), (128, (2, 4, 8))])
+@pytest.mark.parametrize('act', ['none', 'relu', 'lrelu'])
+def test_cbn_train_and_eval(dev, C, shape, act):
+    from dcsnet import ops
+    B, H, W = shape
+    bn = cpt.ComplexBatchNorm2d(C)
+    fill_state(bn, seed=C)
+    x = rand_c((B, C, H, W), C + 1, 1.3) + (0.4 - 0.2j)
+    rm0, rc0 = bn.running_mean.clone(), bn.running_covar.clone()
+    post = {'none': lambda z: z, 'relu': cpt.complex_relu, 'lrelu': nf.complex_lrelu}[act]
+    code = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'lrelu': ops.ACT_LRELU}[act]
+    bn.train()
+    want_tr = post(bn(x))
+    bn.eval()
+    want_ev = post(bn(x))          # with the UPDATED running stats
+    p = lambda t: t.detach().to(dev).contiguous()
+    rm = torch.view_as_real(rm0).to(dev).contiguous()
+    rc = rc0.to(dev).contiguous()
+    y, stats, coef = ops.cbn(nhwc(x, dev), p(bn.weight), p(bn.bias), rm, rc, bn.eps, bn.momentum, True, code)
+    close(back(y), want_tr, rel=3e-5)
+    close(torch.view_as_complex(rm.cpu()), bn.running_mean, rel=1e-5, abs_=1e-7)
+    close(rc, bn.running_covar, rel=1e-5)
+    y2, _, _ = ops.cbn(nhwc(x, dev), p(bn.weight), p(bn.bias), rm, rc, bn.eps, bn.momentum, False, code)
+    close(back(y2), want_ev, rel=3e-5)
+
+
+def test_cbn_large_offset_is_stable(dev):
+    """mean >> std: the pivoted one-pass statistics must not cancel catastrophically."""
+    from dcsnet import ops
+    C = 8
+    bn = cpt.ComplexBatchNorm2d(C)
+    x = rand_c((4, C, 32, 32), 3, 0.05) + (30.0 - 20.0j)
+    bn.train()
+    want = bn(x)
+    p = lambda t: t.detach().to(dev).contiguous()
+    rm = torch.zeros(C, 2, device=dev)
+    rc = torch.ones(C, 3, device=dev)
+    y, _, _ = ops.cbn(nhwc(x, dev), p(bn.weight), p(bn.bias), rm, rc, bn.eps, 0.1, True, ops.ACT_NONE)
+    close(back(y), want, rel=2e-3)       # the CPU two-pass result itself carries ~1e-3 here
+
+
+def test_dropout_keep_rate_and_scale(dev):
+    from dcsnet import ops
+    x = torch.ones(1 << 20, device=dev)
+    y = ops.dropout(x, 0.1, 1234)
+    kept = float((y != 0).float().mean())
+    assert abs(kept - 0.9) < 3e-3
+    vals = torch.unique(y)
+    assert torch.allclose(vals, torch.tensor([0.0, 1 / 0.9], device=dev))
+    assert torch.equal(y, ops.dropout(x, 0.1, 1234))          # regenerated, not random
+    assert not torch.equal(y, ops.dropout(x, 0.1, 1235))
+    assert torch.equal(ops.dropout(x, 0.0, 1), x)
+
+
+# --------------------------------------------------------------------------------- attention
+
+@pytest.mark.parametrize('C,hw', [(8, (20, 12)), (64, (6, 10)), (128, (2, 8))])
+def test_channel_and_spatial_attention(dev, C, hw):
+    from dcsnet import functional as F
+    torch.manual_seed(C)
+    ca_m = cno.ComplexChannelAttention(C, 16)
+    sa_m = cno.ComplexSpatialAttention(7)
+    x = rand_c((3, C, *hw), C + 2)
+    want_ca = ca_m(x)
+    z = want_ca * x
+    want_sa = sa_m(z)
+    want_out = want_sa * z
+    p = lambda t: t.detach().to(dev)
+    xn = nhwc(x, dev)
+    ca = F.channel_attention(xn, p(ca_m.fc[0].conv_r.weight), p(ca_m.fc[0].conv_i.weight),
+                             p(ca_m.fc[2].conv_r.weight), p(ca_m.fc[2].conv_i.weight))
+    close(torch.view_as_complex(ca.cpu()), want_ca.view(3, C), rel=2e-5)
+    sa = F.spatial_attention(xn, ca, p(sa_m.conv1.conv_r.weight), p(sa_m.conv1.conv_i.weight), 7)
+    close(back(sa), want_sa, rel=2e-5)
+    out = F.attention_apply(xn, ca, sa)
+    close(back(out), want_out, rel=2e-5)
+    # identity attention operands
+    close(back(F.attention_apply(xn, None, None)), x, rel=0, abs_=0)
+
+
+# --------------------------------------------------------------------------------- mask math
+
+@pytest.fixture(scope='module')
+def nfv(golden_dir):
+    return np.load(os.path.join(golden_dir, 'nf_vectors.npz'))
+
+
+@pytest.mark.parametrize('tag', ['small', 'mid'])
+def test_mask_math_against_reference_vectors(dev, nfv, tag):
+    from dcsnet import functional as F
+    t = lambda k: torch.from_numpy(nfv[f'{tag}_{k}'])
+    M, Y, S = t('M'), t('Y'), t('S')
+    b1 = F.bound_crm_complex(M.to(dev))
+    close(b1, t('bound1'), rel=0, abs_=2e-6)
+    m2, nhat, shat = F.bound_mask_apply_complex(Y.to(dev), b1)
+    close(m2, t('bound2'), rel=0, abs_=2e-6)
+    close(nhat, t('nhat'), rel=0, abs_=2e-6 * float(Y.abs().max()))
+    close(shat, t('shat'), rel=0, abs_=2e-6 * float(Y.abs().max()))
+    # cRM divides by |Y|^2 + 1e-8: compare relative to each element's own magnitude
+    got, want = F.crm_complex(S.to(dev), Y.to(dev)).cpu(), t('cRM')
+    assert float(((got - want).abs() / (want.abs() + 1e-3)).max()) < 1e-5
+    close(F.complex_lrelu(M.to(dev)), t('lrelu'), rel=0, abs_=0)
+    close(F.complex_sigmoid(M.to(dev)), t('sigmoid'), rel=0, abs_=3e-7)
+
+
+def test_mask_apply_properties_full_size(dev):
+    """BASELINE config-2 size [16,256,2000]: size-independent properties of the subtractive step."""
+    from dcsnet import functional as F
+    g = torch.Generator(device='cpu').manual_seed(0)
+    Y = torch.complex(torch.randn(16, 256, 2000, generator=g), torch.randn(16, 256, 2000, generator=g)).to(dev)
+    M = torch.complex(torch.randn(16, 256, 2000, generator=g), torch.randn(16, 256, 2000, generator=g)).to(dev) * 2
+    m, nhat, shat = F.bound_mask_apply_complex(Y, M)
+    assert float(m.abs().max()) < 1.0                                   # bounded
+    assert torch.allclose(m.abs(), torch.tanh(M.abs()), atol=2e-6)      # modulus is tanh|M|
+    assert torch.equal(nhat + shat, Y) or float((nhat + shat - Y).abs().max()) < 1e-6   # S = Y - N
+    assert torch.allclose(nhat, Y * m, atol=1e-5)
+    # idempotence of the direction: bounding a bounded mask keeps its phase
+    m2 = F.bound_crm_complex(m)
+    ang = torch.angle(m2 * torch.conj(m))
+    assert float(ang.abs().max()) < 1e-4
+
+
+# --------------------------------------------------------------------------------- whole network
+
+@pytest.fixture(scope='module')
+def cnv(golden_dir):
+    return np.load(os.path.join(golden_dir, 'cnet_vectors.npz'))
+
+
+def _hip_net(dev, seed, dropout=False):
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    hp = dict(hparams)
+    if not dropout:
+        hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    net = C_NETWORK(config, hp, seed)
+    fill_state(net, seed)
+    return net.to(dev)
+
+
+@pytest.mark.parametrize('tag,seed', [('b2t32', 0), ('b1t16', 1), ('b3t8', 2)])
+def test_network_forward_against_reference_vectors(dev, cnv, tag, seed):
+    net = _hip_net(dev, seed)
+    x = torch.from_numpy(cnv[f'{tag}_x']).to(dev)
+    net.eval()
+    with torch.no_grad():
+        ev = net(x)
+    close(ev, torch.from_numpy(cnv[f'{tag}_eval']), rel=0, abs_=2e-4)
+    net.train()
+    with torch.no_grad():
+        tr = net(x)
+    close(tr, torch.from_numpy(cnv[f'{tag}_train']), rel=0, abs_=2e-4)
+    sd = net.state_dict()
+    for k in ('initial_batchnorm.running_mean', 'initial_batchnorm.running_covar', 'encoder.3.1.running_mean',
+              'encoder.3.1.running_covar', 'decoder.2.1.running_mean', 'decoder.2.1.running_covar'):
+        close(sd[k], torch.from_numpy(cnv[f'{tag}_after_{k}']), rel=1e-4, abs_=1e-6)
+    assert int(sd['encoder.0.1.num_batches_tracked']) == 1
+
+
+def test_network_forward_against_oracle_t256(dev):
+    """Native patch size [2,256,256] (config.py:72-75), oracle run here on the host cores."""
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    seed = 5
+    oracle = fill_state(cno.C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), seed).eval()
+    net = _hip_net(dev, seed).eval()
+    x = seeded_input(2, 256, 256, seed=seed)
+    with torch.no_grad():
+        want, inter = oracle(x, return_intermediates=True)
+        got = net(x.to(dev))
+    close(got, want, rel=0, abs_=2e-4)
+
+
+def test_layerwise_dropin_modules(dev):
+    """The complexPyTorch-surface modules, called one by one on NCHW complex tensors."""
+    from dcsnet import complexLayers as L
+    from dcsnet import complexFunctions as CF
+    torch.manual_seed(3)
+    x = rand_c((2, 8, 12, 10), 1)
+    ref = cpt.ComplexConv2d(8, 16, 5, (2, 1), 2)
+    mod = L.ComplexConv2d(8, 16, 5, (2, 1), 2)
+    mod.load_state_dict(ref.state_dict())
+    y = mod.to(dev)(x.to(dev))
+    assert y.shape == (2, 16, 6, 10)
+    close(y, ref(x))
+    rbn, mbn = cpt.ComplexBatchNorm2d(16), L.ComplexBatchNorm2d(16)
+    fill_state(rbn, 4)
+    mbn.load_state_dict(rbn.state_dict())
+    mbn.to(dev).train()
+    rbn.train()
+    close(mbn(y), rbn(ref(x)), rel=5e-5)
+    close(mbn.running_covar, rbn.running_covar, rel=1e-5)
+    close(CF.complex_relu(y), cpt.complex_relu(ref(x)))
+    close(CF.complex_upsample(y, scale_factor=(2, 1)), cpt.complex_upsample(ref(x), scale_factor=(2, 1)))
+    rt, mt = cpt.ComplexConvTranspose2d(16, 4, 3, 1, 1), L.ComplexConvTranspose2d(16, 4, 3, 1, 1)
+    mt.load_state_dict(rt.state_dict())
+    close(mt.to(dev)(y), rt(ref(x)))
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from dcsnet import ops, DcsHipError
+    with pytest.raises(DcsHipError):
+        ops.bound_crm(torch.zeros(4, 2))

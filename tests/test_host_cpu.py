@@ -1,0 +1,135 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/dcsnet_hip.h declares, the
+ctypes signatures cover exactly those symbols, and the host-side mirror of the reference's
+surface (module names, state_dict keys, config literals, argument checks) is intact.
+No compute call is made here — there is no GPU."""
+import os
+import re
+import ctypes
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, 'include', 'dcsnet_hip.h')
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(dcs_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dcsnet import _lib
+    assert os.path.exists(_lib.LIB_PATH), 'build the library first: python dcs-net_amd/build.py'
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/dcsnet_hip.h but not exported'
+
+
+def test_ctypes_signatures_cover_the_header():
+    from dcsnet import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.load()
+    assert lib.dcs_abi_version() >= 1
+    assert lib.dcs_error_string(0) == b'ok'
+    assert b'workspace' in lib.dcs_error_string(-3)
+
+
+def test_host_side_geometry_queries():
+    """The two workspace-size entry points are pure host arithmetic: callable without a GPU."""
+    from dcsnet import _lib
+    lib = _lib.load()
+    assert lib.dcs_cbn_workspace_bytes(32 * 128 * 128, 8) > 0
+    assert lib.dcs_cbn_workspace_bytes(100, 1) > 0
+    assert lib.dcs_cbn_workspace_bytes(100, 3) < 0          # odd channel counts are not on the path
+    assert lib.dcs_ca_workspace_bytes(4, 1000, 128) > 0
+    assert lib.dcs_ca_workspace_bytes(4, 1000, 1) < 0
+
+
+def test_null_and_bad_arguments_are_rejected_before_any_launch():
+    from dcsnet import _lib
+    lib = _lib.load()
+    assert lib.dcs_bound_crm_fwd(None, None, 10, 1e-6, None) == -1
+    assert lib.dcs_cconv2d_fwd(None, None, None, None, None, 1, 1, 1, 1, 0, 1, 1, 1, 3, 3, 1, 1, 1, 1, 0, None) == -1
+    assert lib.dcs_dropout_fwd(None, None, 0, 0.1, 1, None) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    from dcsnet import ops, DcsHipError
+    with pytest.raises(DcsHipError, match='no CPU fallback'):
+        ops.bound_crm(torch.zeros(8, 2))
+    with pytest.raises(DcsHipError):
+        ops.cbn(torch.zeros(1, 2, 2, 8, 2), None, None, None, None)
+
+
+def test_c_network_surface_matches_reference_contract():
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK, ComplexLSTM, ComplexChannelAttention, ComplexSpatialAttention  # noqa
+    from oracle.cnet_oracle import C_NETWORK_Oracle
+    net = C_NETWORK(config, hparams, 0)
+    assert list(net.state_dict().keys()) == list(C_NETWORK_Oracle().state_dict().keys())
+    assert sum(p.numel() for p in net.parameters()) == 2912707
+    kids = [n for n, _ in net.named_children()]
+    assert kids[:4] == ['encoder', 'decoder', 'decoder_attention', 'skip_attention']   # c_network.py:95-98
+    for hook in ('forward', 'configure_optimizers', 'training_step', 'validation_step', 'validation_epoch_end',
+                 'test_step', 'test_epoch_end', 'on_after_backward', 'weights_init'):
+        assert callable(getattr(net, hook))
+    sd = net.state_dict()
+    assert sd['encoder.0.1.running_mean'].dtype == torch.complex64
+    assert sd['encoder.0.1.running_covar'].shape == (8, 3)
+    assert sd['decoder.0.0.conv_tran_r.weight'].shape == (256, 128, 3, 3)
+    assert sd['skip_attention.0.fc.0.conv_r.weight'].shape == (8, 128, 1, 1)
+    assert torch.allclose(sd['encoder.2.1.weight'][:, :2], torch.full((32, 2), 2 ** 0.5))
+    opt = net.configure_optimizers()
+    adam = opt['optimizer']
+    g = adam.param_groups[0]
+    assert (g['lr'], g['eps'], g['weight_decay'], g['amsgrad']) == (1e-4, 1e-6, 1e-4, True)   # config.py:31,44-47
+
+
+def test_state_dict_round_trip_with_oracle():
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from oracle.cnet_oracle import C_NETWORK_Oracle
+    from oracle.seeded_state import fill_state
+    o = fill_state(C_NETWORK_Oracle(), 3)
+    net = C_NETWORK(config, hparams, 0)
+    net.load_state_dict(o.state_dict())                 # the reference's checkpoint layout loads as is
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, o.state_dict()[k]), k
+
+
+def test_forward_validates_input():
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet import DcsHipError
+    net = C_NETWORK(config, hparams, 0)
+    with pytest.raises(DcsHipError):
+        net(torch.zeros(2, 256, 12, dtype=torch.complex64))      # T % 8 != 0
+    with pytest.raises(DcsHipError):
+        net(torch.zeros(2, 256, 16))                             # not complex
+
+
+def test_dropin_names_resolve():
+    import sys
+    d = os.path.join(REPO, 'dcs-net_amd', 'dropin')
+    sys.path.insert(0, d)
+    try:
+        for m in ('c_network', 'network_functions', 'config', 'complexPyTorch.complexLayers',
+                  'complexPyTorch.complexFunctions'):
+            sys.modules.pop(m, None)
+        import c_network as cn
+        import config as cfg
+        from complexPyTorch.complexLayers import ComplexConv2d, ComplexBatchNorm2d    # noqa: F401
+        from complexPyTorch.complexFunctions import complex_upsample, complex_relu      # noqa: F401
+        assert cfg.hparams['channels'] == [1, 16, 32, 64, 128, 256, 256, 256]
+        assert cfg.config.strideE[3] == (2, 1) and cfg.config.upsample_scale_factor[4] == (2, 2)
+        for name in ('C_NETWORK', 'ComplexLSTM', 'bound_cRM', 'cRM', 'complex_mat_mult', 'SiSNR',
+                     'train_batch_2_loss', 'ComplexConv2d', 'complex_upsample', 'torch'):
+            assert hasattr(cn, name), name
+    finally:
+        sys.path.remove(d)
+        for m in ('c_network', 'network_functions', 'config', 'complexPyTorch', 'complexPyTorch.complexLayers',
+                  'complexPyTorch.complexFunctions'):
+            sys.modules.pop(m, None)
