@@ -126,6 +126,10 @@ def main():
     from dcsnet import functional as F
     _lib.load()
 
+    def log(msg):
+        if rank == 0:
+            print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
     B = args.batch or 16
     T = args.frames or 2000
     torch.manual_seed(0)
@@ -140,9 +144,11 @@ def main():
             m_raw = net(noisy)
             return F.bound_mask_apply_complex(noisy, m_raw, hparams['atan2_eps'])
 
-    for _ in range(args.warmup):
+    log(f'inputs ready: B={B} T={T}')
+    for i in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        log(f'warmup {i} done')
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -161,6 +167,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step')
     if rank == 0:
         frames = B * T * world * args.steps
         conv_ms, n_launch = timer.summary()

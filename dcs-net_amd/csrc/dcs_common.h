@@ -12,7 +12,12 @@
         if (e__ != hipSuccess) return DCS_ERR_LAUNCH;        \
     } while (0)
 
-static inline hipStream_t dcs_stream(dcs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// hipGetLastError() is per-thread and sticky across unrelated HIP calls made by the host
+// framework; clear it before our launches so DCS_CHECK_LAUNCH reports only our own failures.
+static inline hipStream_t dcs_stream(dcs_stream_t s) {
+    (void)hipGetLastError();
+    return reinterpret_cast<hipStream_t>(s);
+}
 
 __device__ __forceinline__ float dcs_act(float v, int act) {
     if (act == DCS_ACT_RELU) return v > 0.f ? v : 0.f;

@@ -50,6 +50,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the HIP runtime already in the
+    # process when our library's DT_NEEDED entry of the same soname is resolved, otherwise two
+    # runtimes coexist and launches on torch's streams fail.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DcsHipError(f'{LIB_PATH} not found: build it with `python dcs-net_amd/build.py` '
                           '(there is no CPU or eager fallback)')

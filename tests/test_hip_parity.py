@@ -226,14 +226,15 @@ def test_mask_apply_properties_full_size(dev):
     Y = torch.complex(torch.randn(16, 256, 2000, generator=g), torch.randn(16, 256, 2000, generator=g)).to(dev)
     M = torch.complex(torch.randn(16, 256, 2000, generator=g), torch.randn(16, 256, 2000, generator=g)).to(dev) * 2
     m, nhat, shat = F.bound_mask_apply_complex(Y, M)
-    assert float(m.abs().max()) < 1.0                                   # bounded
+    assert float(m.abs().max()) <= 1.0 + 2e-7                           # bounded (fp32 tanh saturates at 1.0)
     assert torch.allclose(m.abs(), torch.tanh(M.abs()), atol=2e-6)      # modulus is tanh|M|
     assert torch.equal(nhat + shat, Y) or float((nhat + shat - Y).abs().max()) < 1e-6   # S = Y - N
     assert torch.allclose(nhat, Y * m, atol=1e-5)
     # idempotence of the direction: bounding a bounded mask keeps its phase
     m2 = F.bound_crm_complex(m)
     ang = torch.angle(m2 * torch.conj(m))
-    assert float(ang.abs().max()) < 1e-4
+    big = m.abs() > 0.1                       # eps = 1e-6 on the real part rotates tiny masks by ~eps/|m|
+    assert float(ang[big].abs().max()) < 1e-4
 
 
 # --------------------------------------------------------------------------------- whole network
