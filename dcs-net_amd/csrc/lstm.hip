@@ -1,0 +1,101 @@
+// lstm.hip — the recurrent half of ComplexLSTM (c_network.py:12-51) as ONE persistent launch per
+// layer.
+//
+// The reference runs four cuDNN/MIOpen LSTM passes (two weight sets x {re, im} inputs); on
+// MI355X that is 2 small launches per time step per layer per direction per pass — 16,000
+// launches per forward at T=2000 (seq 500), 77 % of the step (profiles/r01_a_*).  The work is
+// latency-bound, not FLOP-bound (2.8 % of forward FLOPs), so:
+//   * the input projection x_t W_ih^T + b_ih + b_hh of ALL time steps is one plain GEMM done by the
+//     caller (rocBLAS through PyTorch) -> `gx`;
+//   * this kernel walks the sequence with one 256-thread workgroup per (sequence, direction):
+//     thread j owns gate column j (PyTorch order i,f,g,o, H = 64 each) with its W_hh row in 64
+//     VGPRs, h_{t-1} lives in LDS (broadcast reads), c in a register; two barriers per step;
+//     next step's gx is prefetched under the FMAs.
+// All four passes of a layer (both weight sets, re and im inputs, both directions) run in the
+// same launch: 8*B independent workgroups.
+#include "dcs_common.h"
+
+namespace {
+
+constexpr int H = 64;
+constexpr int G4 = 4 * H;
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+template <bool SAVE>
+__global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                           float* __restrict__ out, float* __restrict__ gates_save,
+                                                           float* __restrict__ c_save, int S, int seqs_per_set,
+                                                           long stride_set, long stride_n, long stride_t) {
+    __shared__ __attribute__((aligned(16))) float h_s[H];
+    __shared__ float g_s[G4];
+    const int j = threadIdx.x;
+    const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int set = n / seqs_per_set, ns = n % seqs_per_set;
+
+    float w[H];
+    {
+        const float4* wr = reinterpret_cast<const float4*>(whh + ((long)(set * 2 + dir) * G4 + j) * H);
+#pragma unroll
+        for (int k = 0; k < H / 4; ++k) {
+            const float4 v = wr[k];
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+    }
+    const float* gxp = gx + set * stride_set + ns * stride_n + dir * G4 + j;
+    const int t0 = dir ? S - 1 : 0, dt = dir ? -1 : 1;
+    float c = 0.f;
+    if (j < H) h_s[j] = 0.f;
+    float pre = gxp[(long)t0 * stride_t];
+    __syncthreads();
+    const bool is_g = (j >> 6) == 2;
+    for (int s = 0; s < S; ++s) {
+        const int t = t0 + s * dt;
+        float nxt = 0.f;
+        if (s + 1 < S) nxt = gxp[(long)(t + dt) * stride_t];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float4* h4 = reinterpret_cast<const float4*>(h_s);
+#pragma unroll
+        for (int k = 0; k < H / 4; ++k) {
+            const float4 hv = h4[k];
+            a0 = fmaf(w[4 * k], hv.x, a0);
+            a1 = fmaf(w[4 * k + 1], hv.y, a1);
+            a2 = fmaf(w[4 * k + 2], hv.z, a2);
+            a3 = fmaf(w[4 * k + 3], hv.w, a3);
+        }
+        const float a = pre + ((a0 + a1) + (a2 + a3));
+        const float act = is_g ? tanhf(a) : sigmoidf_(a);
+        g_s[j] = act;
+        if (SAVE) gates_save[(((long)n * S + t) * 2 + dir) * G4 + j] = act;
+        __syncthreads();
+        if (j < H) {
+            const float ig = g_s[j], fg = g_s[H + j], gg = g_s[2 * H + j], og = g_s[3 * H + j];
+            c = fmaf(fg, c, ig * gg);
+            const float h = og * tanhf(c);
+            h_s[j] = h;
+            out[((long)n * S + t) * (2 * H) + dir * H + j] = h;
+            if (SAVE) c_save[(((long)n * S + t) * 2 + dir) * H + j] = c;
+        }
+        __syncthreads();
+        pre = nxt;
+    }
+}
+
+}  // namespace
+
+extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
+                                  int n_sets, int seqs_per_set, int S, int Hdim, long stride_set, long stride_n,
+                                  long stride_t, dcs_stream_t stream) {
+    if (!gx || !w_hh || !out || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || Hdim != H) return DCS_ERR_BADARG;
+    if ((gates_save == nullptr) != (c_save == nullptr)) return DCS_ERR_BADARG;
+    const int NS = n_sets * seqs_per_set;
+    dim3 grid(NS * 2);
+    if (gates_save)
+        hipLaunchKernelGGL(lstm_rec_fwd_kernel<true>, grid, dim3(G4), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
+                           c_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+    else
+        hipLaunchKernelGGL(lstm_rec_fwd_kernel<false>, grid, dim3(G4), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
+                           c_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

@@ -30,6 +30,7 @@ SIGNATURES = {
     'dcs_channel_attention_fwd': (_I, [_P] * 7 + [_L, _I, _L, _I, _I, _P]),
     'dcs_spatial_pool_fwd': (_I, [_P, _P, _P, _I, _L, _I, _P]),
     'dcs_attention_apply_fwd': (_I, [_P, _P, _P, _P, _I, _L, _I, _F, _U64, _P]),
+    'dcs_lstm_layer_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P]),
     'dcs_dropout_fwd': (_I, [_P, _P, _L, _F, _U64, _P]),
     'dcs_complex_act_fwd': (_I, [_P, _P, _L, _I, _P]),
     'dcs_complex_upsample_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -50,13 +50,10 @@ class ComplexLSTM(torch.nn.Module):
             self.i_trans = torch.nn.Linear(width, projection_dim)
 
     def forward(self, inputs):
-        re, im = inputs.real.contiguous(), inputs.imag.contiguous()
-        rr, ri = self.real_lstm(re)[0], self.imag_lstm(re)[0]
-        ir, ii = self.real_lstm(im)[0], self.imag_lstm(im)[0]
-        out_r, out_i = rr - ii, ir + ri
-        if self.projection_dim is not None:
-            out_r, out_i = self.r_trans(out_r), self.i_trans(out_i)
-        return torch.complex(out_r, out_i)
+        out = F.complex_lstm(inputs, self.real_lstm, self.imag_lstm)
+        if self.projection_dim is not None:          # unused by C_NETWORK (c_network.py:118-123)
+            out = torch.complex(self.r_trans(out.real), self.i_trans(out.imag))
+        return out
 
     def flatten_parameters(self):
         self.imag_lstm.flatten_parameters()

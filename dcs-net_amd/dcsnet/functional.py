@@ -127,6 +127,40 @@ def complex_linear(z, w_r, w_i, b_r, b_i):
     return torch.view_as_complex(y.view(N, -1, 2)).view(*lead, -1)
 
 
+def complex_lstm(z, real_lstm, imag_lstm, save=False):
+    """ComplexLSTM.forward (c_network.py:33-47) for two bidirectional batch_first nn.LSTM
+    parameter containers.  Per layer: one input-projection GEMM for all time steps (rocBLAS via
+    torch) + one persistent HIP launch for the recurrence of all 4 passes x 2 directions."""
+    if not (real_lstm.bidirectional and real_lstm.batch_first and real_lstm.hidden_size == 64):
+        raise DcsHipError('complex_lstm: the HIP path implements the reference geometry '
+                          '(bidirectional, batch_first, hidden 64: c_network.py:118-123)')
+    B, S, I = z.shape
+    sets = (real_lstm, imag_lstm)
+    # rows 0..B-1: real parts, rows B..2B-1: imaginary parts
+    x = torch.view_as_real(z).permute(3, 0, 1, 2).reshape(2 * B, S, I)
+    inp = None
+    for layer in range(real_lstm.num_layers):
+        names = [f'_l{layer}', f'_l{layer}_reverse']
+        w_ih = [torch.cat([getattr(m, 'weight_ih' + n) for n in names]).detach() for m in sets]          # [8H, in]
+        bias = [torch.cat([getattr(m, 'bias_ih' + n) + getattr(m, 'bias_hh' + n) for n in names]).detach()
+                for m in sets]
+        w_hh = torch.stack([torch.stack([getattr(m, 'weight_hh' + n) for n in names]) for m in sets]).detach()
+        w_hh = w_hh.contiguous()
+        G = w_ih[0].shape[0]                                    # 2 dirs * 4H
+        if layer == 0:
+            gx = torch.addmm(torch.cat(bias), x.reshape(2 * B * S, I), torch.cat(w_ih).t())    # (n, t, set, dir, 4H)
+            strides = (G, S * 2 * G, 2 * G)
+        else:
+            gx = torch.baddbmm(torch.stack(bias).unsqueeze(1), inp.reshape(2, 2 * B * S, -1),
+                               torch.stack(w_ih).transpose(1, 2))                               # (set, n, t, dir, 4H)
+            strides = (2 * B * S * G, S * G, G)
+        out, _, _ = ops.lstm_layer(gx.contiguous(), w_hh, 2, 2 * B, S, strides, save)
+        inp = out.view(2, 2 * B, S, -1)
+    rr, ir = inp[0, :B], inp[0, B:]        # real_lstm(re), real_lstm(im)
+    ri, ii = inp[1, :B], inp[1, B:]        # imag_lstm(re), imag_lstm(im)
+    return torch.complex(rr - ii, ir + ri)
+
+
 def bound_crm_complex(M, eps=10e-7):
     x = torch.view_as_real(M.contiguous())
     return torch.view_as_complex(ops.bound_crm(x, eps))

@@ -150,6 +150,22 @@ def attention_apply(x, ca=None, sa=None, drop_p=0.0, seed=0, out=None):
     return y
 
 
+def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False):
+    """Recurrent half of one LSTM layer for every (set, sequence, direction); see dcs_lstm_layer_fwd.
+    gx: float pre-activations addressed by `strides` = (stride_set, stride_n, stride_t) in floats;
+    w_hh: float [n_sets, 2, 4H, H].  Returns (out [n_sets*seqs_per_set, S, 2H], gates, c)."""
+    _chk(gx, 'gx')
+    _chk(w_hh, 'w_hh', 4)
+    H = w_hh.shape[-1]
+    NS = n_sets * seqs_per_set
+    out = torch.empty((NS, S, 2 * H), dtype=torch.float32, device=gx.device)
+    gates = torch.empty((NS, S, 2, 4 * H), dtype=torch.float32, device=gx.device) if save else None
+    c = torch.empty((NS, S, 2, H), dtype=torch.float32, device=gx.device) if save else None
+    check(_lib.load().dcs_lstm_layer_fwd(ptr(gx), ptr(w_hh), ptr(out), ptr(gates), ptr(c), n_sets, seqs_per_set, S, H,
+                                         strides[0], strides[1], strides[2], cur_stream()), 'dcs_lstm_layer_fwd')
+    return out, gates, c
+
+
 def dropout(x, drop_p, seed, out=None):
     _chk(x, 'x')
     y = torch.empty_like(x) if out is None else out

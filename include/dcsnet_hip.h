@@ -147,6 +147,22 @@ int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, fl
                             int B, long HW, int C, float drop_p, unsigned long long seed,
                             dcs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * ComplexLSTM, recurrent half (c_network.py:12-51; built :118-123, called :201).
+ * One launch walks every sequence of one LSTM layer: both weight sets (real_lstm, imag_lstm),
+ * both inputs (re, im) and both directions.  PyTorch LSTM semantics: gate order i,f,g,o,
+ * c_t = f c_{t-1} + i g, h_t = o tanh(c_t), zero initial state, reverse direction walks t = S-1..0.
+ *   gx     pre-activations of the INPUT projection, x_t W_ih^T + b_ih + b_hh, computed by the caller
+ *          (one plain GEMM): element (set, n, t, dir, j) at gx[set*stride_set + n*stride_n + t*stride_t + dir*4H + j]
+ *   w_hh   float[n_sets][2 dirs][4H][H]   (weight_hh_l{k}, weight_hh_l{k}_reverse)
+ *   out    float[n_sets*seqs_per_set][S][2H]   ([.., dir*H + u]: forward half then reverse half)
+ *   gates_save / c_save  NULL for inference; else float[NS][S][2][4H] (post-activation gates) and
+ *          float[NS][S][2][H] (cell state) saved for dcs_lstm_layer_bwd.
+ * H must be 64 (hparams channels[4]//2, config.py:35). */
+int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
+                       int n_sets, int seqs_per_set, int S, int H, long stride_set, long stride_n, long stride_t,
+                       dcs_stream_t stream);
+
 /* Stand-alone inverted dropout on a real view (c_network.py:203-204 dropout_fc after the
  * ComplexLinear; c_network.py:221-222 on the last decoder stage, which has no attention to
  * fuse it into).  n floats; same mask rule as above; y may alias x; drop_p == 0 copies. */

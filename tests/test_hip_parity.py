@@ -112,6 +112,20 @@ def test_complex_linear(dev):
     close(y, m(z))
 
 
+@pytest.mark.parametrize('B,S', [(2, 8), (3, 64), (1, 1)])
+def test_complex_lstm_persistent_kernel(dev, B, S):
+    from dcsnet.c_network import ComplexLSTM
+    torch.manual_seed(B * 100 + S)
+    ref = cno.ComplexLSTM(128, 64, 2, True)
+    mod = ComplexLSTM(128, 64, 2, True, True)
+    mod.load_state_dict(ref.state_dict())
+    z = rand_c((B, S, 128), 4, 0.8)
+    with torch.no_grad():
+        want = ref(z)
+        got = mod.to(dev)(z.to(dev))
+    close(got, want, rel=2e-5, abs_=1e-6)
+
+
 # --------------------------------------------------------------------------------- batch norm
 
 @pytest.mark.parametrize('C,shape', [(1, (2, 16, 24)), (1, (1, 3, 5)), (8, (2, 12, 10)), (64, (3, 6, 8)), (128, (2, 4, 8))])
