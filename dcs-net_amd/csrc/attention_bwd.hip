@@ -1,0 +1,305 @@
+// attention_bwd.hip — backward of the fused attention block
+//     out = dropout( sa (.) ca (.) x ),   ca = sigmoid_c(2 fc2(relu_c(fc1(mean_p x)))),
+//     sa = sigmoid_c(conv7x7([mean_c z, max_c Re z + j max_c Im z])),   z = ca (.) x
+// (c_network.py:53-84 applied at :208-211 / :219-222).  Autograd in the reference walks ~25
+// element-wise / reduction nodes per attention pair, each streaming the activation.  Here the
+// activation-sized work is three streaming passes:
+//   att_bwd_sa_kernel   reads x, g_out            -> g_pre[p] = sigmoid'(sa) * sum_c g_o conj(z)
+//   (7x7 conv data / weight gradients: conv_direct.hip)
+//   att_bwd_x_kernel    reads x, g_out, writes g_x -> g_z = conj(sa) g_o + pool gradients (mean, arg-max
+//                       recomputed with wavefront shuffles), g_x = conj(ca) g_z, and the per-sample
+//                       partial sums of g_ca = sum_p g_z conj(x)   (fp64 slabs, no atomics)
+//   ca_bwd_kernel       one workgroup: sigmoid', both 1x1 convs, CReLU mask, weight gradients in the
+//                       reference's layout, and g_pooled
+//   att_bwd_pool_kernel g_x += g_pooled[b][c] / HW
+// z, the masks and the arg-max indices are recomputed, never stored.
+#include "dcs_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxChunks = 64;
+
+inline bool att_geom(int C, int* G) {
+    if (C < 2 || (C & 1)) return false;
+    int g = C / 2;
+    if (g > 64 || (g & (g - 1)) != 0) return false;
+    *G = g;
+    return true;
+}
+inline int chunks_for(long HW, int G) {
+    const int rpi = kThreads / G;
+    long it = (HW + rpi - 1) / rpi;
+    long nb = (it + 7) / 8;
+    return (int)(nb < 1 ? 1 : (nb > kMaxChunks ? kMaxChunks : nb));
+}
+
+__device__ __forceinline__ float gsum(float v, int G) {
+    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float gmax(float v, int G) {
+    for (int o = G >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int gmin_i(int v, int G) {
+    for (int o = G >> 1; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <bool DROP>
+__device__ __forceinline__ float4 masked(float4 g, uint64_t seed, uint64_t e, float p, float inv_keep) {
+    if (DROP) {
+        g.x *= dcs_keep_scale(seed, e, p, inv_keep);
+        g.y *= dcs_keep_scale(seed, e + 1, p, inv_keep);
+        g.z *= dcs_keep_scale(seed, e + 2, p, inv_keep);
+        g.w *= dcs_keep_scale(seed, e + 3, p, inv_keep);
+    }
+    return g;
+}
+
+// g_pre[b][p] = sigmoid'(sa[p]) (.) sum_c g_o[p][c] conj(ca[c] x[p][c])
+template <bool DROP>
+__global__ __launch_bounds__(kThreads) void att_bwd_sa_kernel(const float* __restrict__ x, const float* __restrict__ go,
+                                                               const float* __restrict__ ca,
+                                                               const float2* __restrict__ sa, float2* __restrict__ gpre,
+                                                               long HW, int G, float drop_p, uint64_t seed) {
+    const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
+    const int b = blockIdx.y;
+    const long base = (long)b * HW * G;
+    const float4* x4 = reinterpret_cast<const float4*>(x) + base;
+    const float4* g4 = reinterpret_cast<const float4*>(go) + base;
+    const float4 a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
+    const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
+    const long iters = (HW + (long)gridDim.x * rpi - 1) / ((long)gridDim.x * rpi);
+    for (long k = 0; k < iters; ++k) {
+        const long r = (k * gridDim.x + blockIdx.x) * rpi + r0;
+        const bool ok = r < HW;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), gg = v;
+        if (ok) {
+            v = x4[r * G + g];
+            gg = masked<DROP>(g4[r * G + g], seed, (uint64_t)(base + r * G + g) * 4, drop_p, inv_keep);
+        }
+        const float z0r = a.x * v.x - a.y * v.y, z0i = a.x * v.y + a.y * v.x;
+        const float z1r = a.z * v.z - a.w * v.w, z1i = a.z * v.w + a.w * v.z;
+        // g conj(z)
+        float sr = gg.x * z0r + gg.y * z0i + gg.z * z1r + gg.w * z1i;
+        float si = gg.y * z0r - gg.x * z0i + gg.w * z1r - gg.z * z1i;
+        sr = gsum(sr, G); si = gsum(si, G);
+        if (ok && g == 0) {
+            const float2 s = sa[(long)b * HW + r];
+            gpre[(long)b * HW + r] = make_float2(sr * s.x * (1.f - s.x), si * s.y * (1.f - s.y));
+        }
+    }
+}
+
+// g_x = conj(ca) g_z ; part[b][chunk][C][2] = sum_p g_z conj(x)
+template <bool DROP>
+__global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ go,
+                                                              const float* __restrict__ ca, const float2* __restrict__ sa,
+                                                              const float4* __restrict__ gsp, float* __restrict__ gx,
+                                                              double* __restrict__ part, long HW, int C, int G,
+                                                              float drop_p, uint64_t seed) {
+    __shared__ double red[kThreads * 4];
+    const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
+    const int b = blockIdx.y;
+    const long base = (long)b * HW * G;
+    const float4* x4 = reinterpret_cast<const float4*>(x) + base;
+    const float4* g4 = reinterpret_cast<const float4*>(go) + base;
+    float4* o4 = reinterpret_cast<float4*>(gx) + base;
+    const float4 a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
+    const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
+    const float invC = 1.f / (float)C;
+    float c0r = 0.f, c0i = 0.f, c1r = 0.f, c1i = 0.f;
+    const long iters = (HW + (long)gridDim.x * rpi - 1) / ((long)gridDim.x * rpi);
+    for (long k = 0; k < iters; ++k) {
+        const long r = (k * gridDim.x + blockIdx.x) * rpi + r0;
+        const bool ok = r < HW;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), gg = v, gp = v;
+        float2 s = make_float2(0.f, 0.f);
+        if (ok) {
+            v = x4[r * G + g];
+            gg = masked<DROP>(g4[r * G + g], seed, (uint64_t)(base + r * G + g) * 4, drop_p, inv_keep);
+            s = sa[(long)b * HW + r];
+            gp = gsp[(long)b * HW + r];          // (g_mean.re, g_mean.im, g_max.re, g_max.im)
+        }
+        const float z0r = a.x * v.x - a.y * v.y, z0i = a.x * v.y + a.y * v.x;
+        const float z1r = a.z * v.z - a.w * v.w, z1i = a.z * v.w + a.w * v.z;
+        // arg-max over channels, first index on ties (torch.max on the CPU oracle)
+        const float mr = gmax(fmaxf(z0r, z1r), G), mi = gmax(fmaxf(z0i, z1i), G);
+        const int big = 1 << 30;
+        const int ir = gmin_i(z0r == mr ? 2 * g : (z1r == mr ? 2 * g + 1 : big), G);
+        const int ii = gmin_i(z0i == mi ? 2 * g : (z1i == mi ? 2 * g + 1 : big), G);
+        // g_z = conj(sa) g_o + g_mean / C + one-hot(arg-max) g_max
+        float t0r = s.x * gg.x + s.y * gg.y + gp.x * invC + (ir == 2 * g ? gp.z : 0.f);
+        float t0i = s.x * gg.y - s.y * gg.x + gp.y * invC + (ii == 2 * g ? gp.w : 0.f);
+        float t1r = s.x * gg.z + s.y * gg.w + gp.x * invC + (ir == 2 * g + 1 ? gp.z : 0.f);
+        float t1i = s.x * gg.w - s.y * gg.z + gp.y * invC + (ii == 2 * g + 1 ? gp.w : 0.f);
+        if (ok) {
+            // g_x = conj(ca) g_z
+            o4[r * G + g] = make_float4(a.x * t0r + a.y * t0i, a.x * t0i - a.y * t0r,
+                                        a.z * t1r + a.w * t1i, a.z * t1i - a.w * t1r);
+            // g_ca += g_z conj(x)
+            c0r += t0r * v.x + t0i * v.y; c0i += t0i * v.x - t0r * v.y;
+            c1r += t1r * v.z + t1i * v.w; c1i += t1i * v.z - t1r * v.w;
+        }
+    }
+    red[t * 4 + 0] = c0r; red[t * 4 + 1] = c0i; red[t * 4 + 2] = c1r; red[t * 4 + 3] = c1i;
+    __syncthreads();
+    for (int o = t; o < G * 4; o += kThreads) {
+        const int gg = o / 4, i = o % 4;
+        double acc = 0;
+        for (int r = 0; r < rpi; ++r) acc += red[(r * G + gg) * 4 + i];
+        part[(((long)b * gridDim.x + blockIdx.x) * C + 2 * gg) * 2 + i] = acc;
+    }
+}
+
+// One workgroup.  scratch: float2 go[B][C], gh[B][Ch]
+__global__ __launch_bounds__(kThreads) void ca_bwd_kernel(const double* __restrict__ part, int nchunks,
+                                                           const float2* __restrict__ ca,
+                                                           const float2* __restrict__ pooled,
+                                                           const float2* __restrict__ hidden,
+                                                           const float2* __restrict__ w1, const float2* __restrict__ w2,
+                                                           float2* __restrict__ go, float2* __restrict__ gh,
+                                                           float2* __restrict__ gpooled, float* __restrict__ g_fc0_r,
+                                                           float* __restrict__ g_fc0_i, float* __restrict__ g_fc2_r,
+                                                           float* __restrict__ g_fc2_i, int B, int C, int Ch) {
+    const int t = threadIdx.x;
+    for (int i = t; i < B * C; i += kThreads) {               // g_o = 2 sigmoid'(.) g_ca
+        const int b = i / C, c = i % C;
+        double sr = 0, si = 0;
+        for (int k = 0; k < nchunks; ++k) {
+            const double* p = part + (((long)b * nchunks + k) * C + c) * 2;
+            sr += p[0]; si += p[1];
+        }
+        const float2 s = ca[i];
+        go[i] = make_float2(2.f * (float)sr * s.x * (1.f - s.x), 2.f * (float)si * s.y * (1.f - s.y));
+    }
+    __syncthreads();
+    for (int i = t; i < B * Ch; i += kThreads) {              // g_h = relu'(h) (.) sum_c conj(w2[h][c]) g_o
+        const int b = i / Ch, h = i % Ch;
+        float ar = 0.f, ai = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float2 w = w2[h * C + c], g = go[b * C + c];
+            ar += w.x * g.x + w.y * g.y; ai += w.x * g.y - w.y * g.x;
+        }
+        const float2 hv = hidden[i];
+        gh[i] = make_float2(hv.x > 0.f ? ar : 0.f, hv.y > 0.f ? ai : 0.f);
+    }
+    for (int i = t; i < Ch * C; i += kThreads) {              // g_w2[h][c] = sum_b g_o conj(relu(h))
+        const int h = i / C, c = i % C;
+        float ar = 0.f, ai = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float2 g = go[b * C + c];
+            float2 hv = hidden[b * Ch + h];
+            hv.x = hv.x > 0.f ? hv.x : 0.f; hv.y = hv.y > 0.f ? hv.y : 0.f;
+            ar += g.x * hv.x + g.y * hv.y; ai += g.y * hv.x - g.x * hv.y;
+        }
+        g_fc2_r[c * Ch + h] = ar;                             // fc.2 weight [C][Ch][1][1]
+        g_fc2_i[c * Ch + h] = ai;
+    }
+    __syncthreads();
+    for (int i = t; i < C * Ch; i += kThreads) {              // g_w1[c][h] = sum_b g_h conj(pooled)
+        const int c = i / Ch, h = i % Ch;
+        float ar = 0.f, ai = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float2 g = gh[b * Ch + h], p = pooled[b * C + c];
+            ar += g.x * p.x + g.y * p.y; ai += g.y * p.x - g.x * p.y;
+        }
+        g_fc0_r[h * C + c] = ar;                              // fc.0 weight [Ch][C][1][1]
+        g_fc0_i[h * C + c] = ai;
+    }
+    for (int i = t; i < B * C; i += kThreads) {               // g_pooled = sum_h conj(w1[c][h]) g_h
+        const int b = i / C, c = i % C;
+        float ar = 0.f, ai = 0.f;
+        for (int h = 0; h < Ch; ++h) {
+            const float2 w = w1[c * Ch + h], g = gh[b * Ch + h];
+            ar += w.x * g.x + w.y * g.y; ai += w.x * g.y - w.y * g.x;
+        }
+        gpooled[i] = make_float2(ar, ai);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void att_bwd_pool_kernel(float* __restrict__ gx, const float* __restrict__ gpooled,
+                                                                 long HW, int G, float inv_hw) {
+    const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
+    const int b = blockIdx.y;
+    float4* o4 = reinterpret_cast<float4*>(gx) + (long)b * HW * G;
+    float4 p = reinterpret_cast<const float4*>(gpooled)[(long)b * G + g];
+    p.x *= inv_hw; p.y *= inv_hw; p.z *= inv_hw; p.w *= inv_hw;
+    for (long r = (long)blockIdx.x * rpi + r0; r < HW; r += (long)gridDim.x * rpi) {
+        float4 v = o4[r * G + g];
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        o4[r * G + g] = v;
+    }
+}
+
+inline int stream_grid(long HW, int G, int B) {
+    const int rpi = kThreads / G;
+    long it = (HW + rpi - 1) / rpi;
+    long nb = (it + 3) / 4;
+    long cap = 2048 / (B > 0 ? B : 1);
+    if (cap < 1) cap = 1;
+    return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
+}
+
+}  // namespace
+
+extern "C" int dcs_attention_bwd_sa(const float* x, const float* g_out, const float* ca, const float* sa, float* g_pre,
+                                    int B, long HW, int C, float drop_p, unsigned long long seed, dcs_stream_t stream) {
+    int G;
+    if (!x || !g_out || !ca || !sa || !g_pre || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
+    dim3 grid(stream_grid(HW, G, B), B);
+    if (drop_p > 0.f)
+        hipLaunchKernelGGL(att_bwd_sa_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), x, g_out, ca,
+                           (const float2*)sa, (float2*)g_pre, HW, G, drop_p, (uint64_t)seed);
+    else
+        hipLaunchKernelGGL(att_bwd_sa_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), x, g_out, ca,
+                           (const float2*)sa, (float2*)g_pre, HW, G, drop_p, (uint64_t)seed);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" long dcs_attention_bwd_workspace_bytes(int B, long HW, int C, int Ch) {
+    int G;
+    if (B <= 0 || HW <= 0 || Ch <= 0 || !att_geom(C, &G)) return -1;
+    return (long)B * chunks_for(HW, G) * C * 2 * (long)sizeof(double) + ((long)B * C + (long)B * Ch) * 8 + 64;
+}
+
+extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, const float* sa,
+                                   const float* g_sp, const float* pooled, const float* hidden, const float* w1,
+                                   const float* w2, float* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r,
+                                   float* g_fc2_i, void* workspace, long workspace_bytes, int B, long HW, int C, int Ch,
+                                   float drop_p, unsigned long long seed, dcs_stream_t stream) {
+    int G;
+    if (!x || !g_out || !ca || !sa || !g_sp || !pooled || !hidden || !w1 || !w2 || !g_x || !g_fc0_r || !g_fc0_i ||
+        !g_fc2_r || !g_fc2_i || !workspace)
+        return DCS_ERR_BADARG;
+    if (B <= 0 || B > 65535 || HW <= 0 || Ch <= 0 || Ch > 64 || !att_geom(C, &G)) return DCS_ERR_BADARG;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
+    const int nch = chunks_for(HW, G);
+    const long part_bytes = (long)B * nch * C * 2 * (long)sizeof(double);
+    if (workspace_bytes < part_bytes + ((long)B * C + (long)B * Ch) * 8 + 64) return DCS_ERR_WORKSPACE;
+    double* part = (double*)workspace;
+    float2* go = (float2*)((char*)workspace + part_bytes);
+    float2* gh = go + (long)B * C;
+    float2* gpooled = go;   // ca_bwd's last phase reads gh / w1 / pooled only, so it may overwrite go
+    hipStream_t s = dcs_stream(stream);
+    dim3 grid(nch, B);
+    if (drop_p > 0.f)
+        hipLaunchKernelGGL(att_bwd_x_kernel<true>, grid, dim3(kThreads), 0, s, x, g_out, ca, (const float2*)sa,
+                           (const float4*)g_sp, g_x, part, HW, C, G, drop_p, (uint64_t)seed);
+    else
+        hipLaunchKernelGGL(att_bwd_x_kernel<false>, grid, dim3(kThreads), 0, s, x, g_out, ca, (const float2*)sa,
+                           (const float4*)g_sp, g_x, part, HW, C, G, drop_p, (uint64_t)seed);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ca_bwd_kernel, dim3(1), dim3(kThreads), 0, s, (const double*)part, nch, (const float2*)ca,
+                       (const float2*)pooled, (const float2*)hidden, (const float2*)w1, (const float2*)w2, go, gh,
+                       gpooled, g_fc0_r, g_fc0_i, g_fc2_r, g_fc2_i, B, C, Ch);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(att_bwd_pool_kernel, dim3(stream_grid(HW, G, B), B), dim3(kThreads), 0, s, g_x,
+                       (const float*)gpooled, HW, G, 1.f / (float)HW);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

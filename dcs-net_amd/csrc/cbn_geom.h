@@ -1,0 +1,44 @@
+// cbn_geom.h — thread/row mapping shared by the CBN forward (cbn.hip) and backward (cbn_bwd.hip)
+// kernels: a 256-thread workgroup covers rows_per_iter pixels x (C/2) float4 column groups per
+// pass, so a thread keeps ONE channel pair for the whole kernel (statistics and coefficients
+// stay in registers) and every global access is a contiguous 16-byte-per-lane stream.
+#pragma once
+
+namespace cbn {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 512;
+
+struct Geom {
+    int vec_per_row;   // float4 groups per pixel row (C/2), or 0 for the C == 1 layout
+    int rows_per_iter; // pixel rows covered by one workgroup iteration
+    int nblocks;       // reduction workgroups (one partial slab each)
+};
+
+inline bool geom(long P, int C, Geom* g) {
+    if (P <= 0 || C <= 0) return false;
+    long it;
+    if (C == 1) {
+        g->vec_per_row = 0;
+        g->rows_per_iter = 0;
+        it = (P / 2 + kThreads - 1) / kThreads;
+    } else {
+        if (C & 1) return false;
+        const int G = C / 2;
+        if (G > kThreads || (kThreads % G) != 0) return false;
+        g->vec_per_row = G;
+        g->rows_per_iter = kThreads / G;
+        it = (P + g->rows_per_iter - 1) / g->rows_per_iter;
+    }
+    const long nb = (it + 7) / 8;
+    g->nblocks = (int)(nb < 1 ? 1 : (nb > kMaxBlocks ? kMaxBlocks : nb));
+    return true;
+}
+
+inline int stream_grid(long P, int C, const Geom& g) {
+    const long iters = (C == 1) ? (P / 2 + kThreads - 1) / kThreads : (P + g.rows_per_iter - 1) / g.rows_per_iter;
+    const long nb = (iters + 3) / 4;
+    return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+}
+
+}  // namespace cbn

@@ -1,15 +1,22 @@
-// conv_direct.hip — direct (non-GEMM) complex correlation for the small-channel ends of the
-// network, and the weight packer.
+// conv_direct.hip — direct (non-GEMM) complex correlation, its data / weight gradients, and the
+// weight packers.
 //
-// Used for enc0 (Cin=1, K=98: SURVEY.md §7 "small-channel ends"), dec6 (Cout=1), the 7x7 2->1
-// spatial-attention conv (c_network.py:74) and as the generic fallback for any geometry the
-// MFMA implicit-GEMM kernel (conv_mfma.hip) does not take.  These stages are HBM-bound
-// (SURVEY.md §8d): the kernel stages one haloed input tile per workgroup in LDS (each input
-// element is read from HBM once per tile), keeps COB output channels per thread in VGPRs and
-// takes its weights through the scalar cache (wave-uniform addresses).
+// Forward use: enc0 (Cin=1, K=98: SURVEY.md §7 "small-channel ends"), dec6 (Cout=1), the 7x7 2->1
+// spatial-attention conv (c_network.py:74), and the generic fallback for any geometry the MFMA
+// implicit-GEMM kernel (conv_mfma.hip) does not take.  These stages are HBM-bound (SURVEY.md
+// §8d): one haloed input tile per workgroup is staged in LDS (each input element is read from
+// HBM once per tile), COB output channels per thread live in VGPRs, weights come through the
+// scalar cache (wave-uniform addresses).
 //
 // The virtual input (nearest upsample of cat(x1, x2): c_network.py:214-216) is resolved in the
 // LDS gather, so neither the concatenated nor the upsampled tensor ever exists in HBM.
+//
+// Backward (what autograd does for the reference through 4 real convs per complex conv):
+//   data   g_X = conj(W) (*)^T g_Y : the SAME kernel run on g_Y with zero-insertion (stride) in the
+//          gather and the flipped / conjugated / in-out-swapped weight (dcs_pack_conv_weight_bwd)
+//   weight g_W[tap,ci,co] = sum_p g_Y[p,co] conj(X[p*s-pad+tap, ci]) : per-tile partial slabs
+//          (no atomics: bitwise reproducible) + a reduce that writes the reference's parameter
+//          layout (conv_r / conv_i or conv_tran_r / conv_tran_i, and the two biases).
 #include "dcs_common.h"
 
 namespace {
@@ -19,9 +26,17 @@ constexpr int CHUNK = 8;             // input channels staged per LDS pass
 
 struct ConvArgs {
     const float2* x1; const float2* x2; const float2* wp; const float2* bias; float2* y;
-    int B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t, act;
-    int Hout, Wout, tiles_w, rows, cols, colsp, plane;
+    int B, Hin, Win, C1, C2, up_f, up_t, zero_ins, Cout, kh, kw, sf, st, pad_f, pad_t, act;
+    int Hv, Wv, Hout, Wout, tiles_w, tiles_h, rows, cols, colsp, plane;
 };
+
+// virtual input element (b, vy, vx, c); zero outside, and between samples in zero-insert mode
+__device__ __forceinline__ float2 gather(const ConvArgs& a, int b, int vy, int vx, int c) {
+    if (vy < 0 || vy >= a.Hv || vx < 0 || vx >= a.Wv) return make_float2(0.f, 0.f);
+    if (a.zero_ins && ((vy % a.up_f) != 0 || (vx % a.up_t) != 0)) return make_float2(0.f, 0.f);
+    const long sp = ((long)b * a.Hin + vy / a.up_f) * a.Win + vx / a.up_t;
+    return (c < a.C1) ? a.x1[sp * a.C1 + c] : a.x2[sp * a.C2 + (c - a.C1)];
+}
 
 template <int COB>
 __global__ __launch_bounds__(TH * TW) void cconv_direct_kernel(ConvArgs a) {
@@ -33,7 +48,6 @@ __global__ __launch_bounds__(TH * TW) void cconv_direct_kernel(ConvArgs a) {
     const int co0 = blockIdx.y * COB;
     const int b = blockIdx.z;
     const int Cin = a.C1 + a.C2;
-    const int Hv = a.Hin * a.up_f, Wv = a.Win * a.up_t;       // virtual (upsampled) input extent
     const int vy0 = oy0 * a.sf - a.pad_f, vx0 = ox0 * a.st - a.pad_t;
 
     float accr[COB], acci[COB];
@@ -48,14 +62,7 @@ __global__ __launch_bounds__(TH * TW) void cconv_direct_kernel(ConvArgs a) {
             const int ci = idx % nc;
             const int px = idx / nc;
             const int ix = px % a.cols, iy = px / a.cols;
-            const int vy = vy0 + iy, vx = vx0 + ix;
-            float2 v = make_float2(0.f, 0.f);
-            if (vy >= 0 && vy < Hv && vx >= 0 && vx < Wv) {
-                const long sp = ((long)b * a.Hin + vy / a.up_f) * a.Win + vx / a.up_t;
-                const int c = c0 + ci;
-                v = (c < a.C1) ? a.x1[sp * a.C1 + c] : a.x2[sp * a.C2 + (c - a.C1)];
-            }
-            tile[ci * a.plane + iy * a.colsp + ix] = v;
+            tile[ci * a.plane + iy * a.colsp + ix] = gather(a, b, vy0 + iy, vx0 + ix, c0 + ci);
         }
         __syncthreads();
         for (int ci = 0; ci < nc; ++ci) {
@@ -81,12 +88,134 @@ __global__ __launch_bounds__(TH * TW) void cconv_direct_kernel(ConvArgs a) {
         float2* out = a.y + (((long)b * a.Hout + oy) * a.Wout + ox) * a.Cout + co0;
 #pragma unroll
         for (int i = 0; i < COB; ++i) {
-            const float2 bv = a.bias[co0 + i];
+            const float2 bv = a.bias ? a.bias[co0 + i] : make_float2(0.f, 0.f);
             out[i] = make_float2(dcs_act(accr[i] + bv.x, a.act), dcs_act(acci[i] + bv.y, a.act));
         }
     }
 }
 
+// ---- weight gradient ---------------------------------------------------------------------------
+constexpr int WG_CO = 8;             // output channels per workgroup (g_Y tile columns)
+constexpr int WG_TAPS = 13;          // taps per thread: ceil(49 / 4) covers k = 7
+
+struct WgradArgs {
+    const float2* x1; const float2* x2; const float2* gy; float2* slab_w; float2* slab_b;
+    int n_slabs, total_tiles, n_co_chunks;
+    ConvArgs c;                      // forward geometry (y/wp/bias unused)
+};
+
+// grid: (n_slabs, ci_chunks * co_chunks).  Thread = (ci_l, co_l) pair x tap group.
+__global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const ConvArgs& a = w.c;
+    float2* tile = lds;                                   // [CHUNK][plane]
+    float2* gt = lds + CHUNK * a.plane;                   // [TH*TW][WG_CO]
+    const int t = threadIdx.x;
+    const int pair = t & 63, tg = t >> 6;
+    const int ci_l = pair >> 3, co_l = pair & 7;
+    const int ci0 = (blockIdx.y / w.n_co_chunks) * CHUNK, co0 = (blockIdx.y % w.n_co_chunks) * WG_CO;
+    const int Cin = a.C1 + a.C2;
+    const int ntaps = a.kh * a.kw;
+    const int tiles_per_img = a.tiles_w * a.tiles_h;
+
+    float accr[WG_TAPS], acci[WG_TAPS];
+#pragma unroll
+    for (int i = 0; i < WG_TAPS; ++i) { accr[i] = 0.f; acci[i] = 0.f; }
+    float br = 0.f, bi = 0.f;
+    int toff[WG_TAPS];                                    // LDS offset of each of my taps
+#pragma unroll
+    for (int i = 0; i < WG_TAPS; ++i) {
+        const int tap = tg + 4 * i;
+        toff[i] = tap < ntaps ? (tap / a.kw) * a.colsp + (tap % a.kw) : 0;
+    }
+
+    for (int tl = blockIdx.x; tl < w.total_tiles; tl += w.n_slabs) {
+        const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
+        const int oy0 = (tile_id / a.tiles_w) * TH, ox0 = (tile_id % a.tiles_w) * TW;
+        const int vy0 = oy0 * a.sf - a.pad_f, vx0 = ox0 * a.st - a.pad_t;
+        __syncthreads();
+        const int nc = min(CHUNK, Cin - ci0);
+        const int total = a.rows * a.cols * nc;
+        for (int idx = t; idx < total; idx += TH * TW) {
+            const int ci = idx % nc, px = idx / nc;
+            const int ix = px % a.cols, iy = px / a.cols;
+            tile[ci * a.plane + iy * a.colsp + ix] = gather(a, b, vy0 + iy, vx0 + ix, ci0 + ci);
+        }
+        for (int idx = t; idx < TH * TW * WG_CO; idx += TH * TW) {
+            const int co = idx % WG_CO, p = idx / WG_CO;
+            const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+            float2 v = make_float2(0.f, 0.f);
+            if (oy < a.Hout && ox < a.Wout && co0 + co < a.Cout)
+                v = w.gy[(((long)b * a.Hout + oy) * a.Wout + ox) * a.Cout + co0 + co];
+            gt[p * WG_CO + co] = v;
+        }
+        __syncthreads();
+        if (ci_l < nc) {
+            const float2* pl = tile + ci_l * a.plane;
+            for (int p = 0; p < TH * TW; ++p) {
+                const float2 g = gt[p * WG_CO + co_l];
+                const float2* xp = pl + ((p / TW) * a.sf) * a.colsp + (p % TW) * a.st;
+#pragma unroll
+                for (int i = 0; i < WG_TAPS; ++i) {
+                    if (tg + 4 * i < ntaps) {
+                        const float2 xv = xp[toff[i]];
+                        // g * conj(x)
+                        accr[i] = fmaf(g.x, xv.x, accr[i]);
+                        accr[i] = fmaf(g.y, xv.y, accr[i]);
+                        acci[i] = fmaf(g.y, xv.x, acci[i]);
+                        acci[i] = fmaf(-g.x, xv.y, acci[i]);
+                    }
+                }
+            }
+        }
+        if (ci0 == 0 && t < WG_CO) {                      // bias: column sums of g_Y, once per co chunk
+            for (int p = 0; p < TH * TW; ++p) {
+                const float2 g = gt[p * WG_CO + t];
+                br += g.x; bi += g.y;
+            }
+        }
+    }
+    const long wsz = (long)ntaps * Cin * a.Cout;
+    if (ci_l < min(CHUNK, Cin - ci0) && co0 + co_l < a.Cout) {
+#pragma unroll
+        for (int i = 0; i < WG_TAPS; ++i) {
+            const int tap = tg + 4 * i;
+            if (tap < ntaps)
+                w.slab_w[(long)blockIdx.x * wsz + ((long)tap * Cin + ci0 + ci_l) * a.Cout + co0 + co_l] =
+                    make_float2(accr[i], acci[i]);
+        }
+    }
+    if (ci0 == 0 && t < WG_CO && co0 + t < a.Cout) w.slab_b[(long)blockIdx.x * a.Cout + co0 + t] = make_float2(br, bi);
+}
+
+// sum the slabs and scatter into the reference's parameter layout
+__global__ void cconv_wgrad_reduce_kernel(const float2* __restrict__ slab_w, const float2* __restrict__ slab_b,
+                                          int n_slabs, float* __restrict__ gw_r, float* __restrict__ gw_i,
+                                          float* __restrict__ gb_r, float* __restrict__ gb_i, int Cout, int Cin,
+                                          int kh, int kw, int transposed) {
+    const long n = (long)kh * kw * Cin * Cout;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Cout && gb_r != nullptr) {
+        float sr = 0.f, si = 0.f;
+        for (int s = 0; s < n_slabs; ++s) { const float2 v = slab_b[(long)s * Cout + i]; sr += v.x; si += v.y; }
+        gb_r[i] = sr + si;          // bias = (b_r - b_i) + j (b_r + b_i)
+        gb_i[i] = si - sr;
+    }
+    if (i >= n) return;
+    float sr = 0.f, si = 0.f;
+    for (int s = 0; s < n_slabs; ++s) { const float2 v = slab_w[(long)s * n + i]; sr += v.x; si += v.y; }
+    const int co = (int)(i % Cout);
+    const int ci = (int)((i / Cout) % Cin);
+    const int tap = (int)(i / ((long)Cout * Cin));
+    const int dy = tap / kw, dx = tap % kw;
+    long dst;
+    if (transposed) dst = (((long)ci * Cout + co) * kh + (kh - 1 - dy)) * kw + (kw - 1 - dx);
+    else            dst = (((long)co * Cin + ci) * kh + dy) * kw + dx;
+    gw_r[dst] = sr;
+    gw_i[dst] = si;
+}
+
+// ---- packers ------------------------------------------------------------------------------------
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w_r, const float* __restrict__ w_i,
                                         const float* __restrict__ b_r, const float* __restrict__ b_i,
                                         float2* __restrict__ wp, float2* __restrict__ bias_out, int Cout, int Cin,
@@ -110,6 +239,110 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w_r, const flo
     wp[i] = make_float2(w_r[src], w_i[src]);
 }
 
+// wp_bwd[tap'][co][ci] = conj(wp[ntaps-1-tap'][ci][co])
+__global__ void pack_conv_weight_bwd_kernel(const float2* __restrict__ wp, float2* __restrict__ wpb, int Cout, int Cin,
+                                            int ntaps) {
+    const long n = (long)ntaps * Cin * Cout;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int tp = (int)(i / ((long)Cout * Cin));
+    const float2 v = wp[((long)(ntaps - 1 - tp) * Cin + ci) * Cout + co];
+    wpb[i] = make_float2(v.x, -v.y);
+}
+
+// g_x1[b][y][x][c] = sum over the up_f x up_t block of g_Xv[b][..][..][c]; channels >= C1 go to g_x2
+__global__ void upsample_cat_bwd_kernel(const float2* __restrict__ gxv, float2* __restrict__ gx1,
+                                        float2* __restrict__ gx2, int B, int Hin, int Win, int C1, int C2, int up_f,
+                                        int up_t) {
+    const int C = C1 + C2;
+    const long n = (long)B * Hin * Win * C;
+    const int Wv = Win * up_t, Hv = Hin * up_f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long p = i / C;
+        const int x = (int)(p % Win); p /= Win;
+        const int y = (int)(p % Hin);
+        const int b = (int)(p / Hin);
+        float sr = 0.f, si = 0.f;
+        for (int dy = 0; dy < up_f; ++dy)
+            for (int dx = 0; dx < up_t; ++dx) {
+                const float2 v = gxv[(((long)b * Hv + y * up_f + dy) * Wv + x * up_t + dx) * C + c];
+                sr += v.x; si += v.y;
+            }
+        const long sp = ((long)b * Hin + y) * Win + x;
+        if (c < C1) gx1[sp * C1 + c] = make_float2(sr, si);
+        else        gx2[sp * C2 + (c - C1)] = make_float2(sr, si);
+    }
+}
+
+bool conv_geometry(ConvArgs& a) {
+    if (a.Hout <= 0 || a.Wout <= 0) return false;
+    a.tiles_w = (a.Wout + TW - 1) / TW;
+    a.tiles_h = (a.Hout + TH - 1) / TH;
+    a.rows = (TH - 1) * a.sf + a.kh;
+    a.cols = (TW - 1) * a.st + a.kw;
+    a.colsp = a.cols | 1;                       // odd row pitch (in float2) spreads LDS banks
+    a.plane = a.rows * a.colsp + 1;
+    return true;
+}
+
+int launch_direct(ConvArgs& a, hipStream_t stream) {
+    if (!conv_geometry(a)) return DCS_ERR_BADARG;
+    const int Cin = a.C1 + a.C2;
+    const size_t lds = (size_t)(Cin < CHUNK ? Cin : CHUNK) * a.plane * sizeof(float2);
+    if (lds > 150 * 1024) return DCS_ERR_BADARG;
+    const int Cout = a.Cout;
+    int cob = (Cout % 8 == 0) ? 8 : (Cout % 4 == 0) ? 4 : (Cout % 2 == 0) ? 2 : 1;
+    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it for this instantiation
+        const void* fn = cob == 8 ? (const void*)cconv_direct_kernel<8> : cob == 4 ? (const void*)cconv_direct_kernel<4>
+                       : cob == 2 ? (const void*)cconv_direct_kernel<2> : (const void*)cconv_direct_kernel<1>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return DCS_ERR_LAUNCH;
+    }
+    dim3 grid(a.tiles_w * a.tiles_h, Cout / cob, a.B);
+    if (grid.y > 65535 || grid.z > 65535) return DCS_ERR_BADARG;
+    switch (cob) {
+        case 8: hipLaunchKernelGGL(cconv_direct_kernel<8>, grid, dim3(TH * TW), lds, stream, a); break;
+        case 4: hipLaunchKernelGGL(cconv_direct_kernel<4>, grid, dim3(TH * TW), lds, stream, a); break;
+        case 2: hipLaunchKernelGGL(cconv_direct_kernel<2>, grid, dim3(TH * TW), lds, stream, a); break;
+        default: hipLaunchKernelGGL(cconv_direct_kernel<1>, grid, dim3(TH * TW), lds, stream, a); break;
+    }
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+ConvArgs fwd_args(const float* x1, const float* x2, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                  int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t) {
+    ConvArgs a{};
+    a.x1 = (const float2*)x1; a.x2 = (const float2*)x2;
+    a.B = B; a.Hin = Hin; a.Win = Win; a.C1 = C1; a.C2 = C2; a.up_f = up_f; a.up_t = up_t; a.zero_ins = 0;
+    a.Cout = Cout; a.kh = kh; a.kw = kw; a.sf = sf; a.st = st; a.pad_f = pad_f; a.pad_t = pad_t; a.act = DCS_ACT_NONE;
+    a.Hv = Hin * up_f; a.Wv = Win * up_t;
+    a.Hout = (a.Hv + 2 * pad_f - kh) / sf + 1;
+    a.Wout = (a.Wv + 2 * pad_t - kw) / st + 1;
+    return a;
+}
+
+bool fwd_geom_ok(const void* x1, const void* x2, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout,
+                 int kh, int kw, int sf, int st, int pad_f, int pad_t) {
+    if (!x1 || B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0) return false;
+    if ((C2 > 0) != (x2 != nullptr)) return false;
+    if (up_f < 1 || up_t < 1 || kh < 1 || kw < 1 || sf < 1 || st < 1 || pad_f < 0 || pad_t < 0) return false;
+    return true;
+}
+
+int wgrad_slabs(const ConvArgs& a, long* wsz_out) {
+    const long wsz = (long)a.kh * a.kw * (a.C1 + a.C2) * a.Cout;
+    const long total_tiles = (long)a.tiles_w * a.tiles_h * a.B;
+    long cap = (32L << 20) / (wsz * (long)sizeof(float2));
+    if (cap < 1) cap = 1;
+    if (cap > 1024) cap = 1024;
+    *wsz_out = wsz;
+    return (int)(total_tiles < cap ? total_tiles : cap);
+}
+
 }  // namespace
 
 extern "C" int dcs_pack_conv_weight(const float* w_r, const float* w_i, const float* b_r, const float* b_i, float* wp,
@@ -125,54 +358,112 @@ extern "C" int dcs_pack_conv_weight(const float* w_r, const float* w_i, const fl
     return DCS_OK;
 }
 
+extern "C" int dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout, int Cin, int kh, int kw,
+                                        dcs_stream_t stream) {
+    if (!wp || !wp_bwd || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0) return DCS_ERR_BADARG;
+    const long n = (long)kh * kw * Cin * Cout;
+    hipLaunchKernelGGL(pack_conv_weight_bwd_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, dcs_stream(stream),
+                       (const float2*)wp, (float2*)wp_bwd, Cout, Cin, kh * kw);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
 // shared with conv_mfma.hip's dispatcher
 int dcs_cconv2d_direct(const float* x1, const float* x2, const float* wp, const float* bias, float* y, int B, int Hin,
                        int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh, int kw, int sf, int st, int pad_f,
                        int pad_t, int act, hipStream_t stream) {
-    ConvArgs a;
-    a.x1 = (const float2*)x1; a.x2 = (const float2*)x2; a.wp = (const float2*)wp; a.bias = (const float2*)bias;
-    a.y = (float2*)y;
-    a.B = B; a.Hin = Hin; a.Win = Win; a.C1 = C1; a.C2 = C2; a.up_f = up_f; a.up_t = up_t; a.Cout = Cout;
-    a.kh = kh; a.kw = kw; a.sf = sf; a.st = st; a.pad_f = pad_f; a.pad_t = pad_t; a.act = act;
-    a.Hout = (Hin * up_f + 2 * pad_f - kh) / sf + 1;
-    a.Wout = (Win * up_t + 2 * pad_t - kw) / st + 1;
-    if (a.Hout <= 0 || a.Wout <= 0) return DCS_ERR_BADARG;
-    a.tiles_w = (a.Wout + TW - 1) / TW;
-    const int tiles_h = (a.Hout + TH - 1) / TH;
-    a.rows = (TH - 1) * sf + kh;
-    a.cols = (TW - 1) * st + kw;
-    a.colsp = a.cols | 1;                       // odd row pitch (in float2) spreads LDS banks
-    a.plane = a.rows * a.colsp + 1;
-    const int Cin = C1 + C2;
-    const size_t lds = (size_t)(Cin < CHUNK ? Cin : CHUNK) * a.plane * sizeof(float2);
-    if (lds > 150 * 1024) return DCS_ERR_BADARG;
-    int cob = (Cout % 8 == 0) ? 8 : (Cout % 4 == 0) ? 4 : (Cout % 2 == 0) ? 2 : 1;
-    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it for this instantiation
-        const void* fn = cob == 8 ? (const void*)cconv_direct_kernel<8> : cob == 4 ? (const void*)cconv_direct_kernel<4>
-                       : cob == 2 ? (const void*)cconv_direct_kernel<2> : (const void*)cconv_direct_kernel<1>;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DCS_ERR_LAUNCH;
-    }
-    dim3 grid(a.tiles_w * tiles_h, Cout / cob, B);
-    if (grid.y > 65535 || grid.z > 65535) return DCS_ERR_BADARG;
-    switch (cob) {
-        case 8: hipLaunchKernelGGL(cconv_direct_kernel<8>, grid, dim3(TH * TW), lds, stream, a); break;
-        case 4: hipLaunchKernelGGL(cconv_direct_kernel<4>, grid, dim3(TH * TW), lds, stream, a); break;
-        case 2: hipLaunchKernelGGL(cconv_direct_kernel<2>, grid, dim3(TH * TW), lds, stream, a); break;
-        default: hipLaunchKernelGGL(cconv_direct_kernel<1>, grid, dim3(TH * TW), lds, stream, a); break;
-    }
-    DCS_CHECK_LAUNCH();
-    return DCS_OK;
+    ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    a.wp = (const float2*)wp; a.bias = (const float2*)bias; a.y = (float2*)y; a.act = act;
+    return launch_direct(a, stream);
 }
 
 extern "C" int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const float* bias, float* y, int B,
                                int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh, int kw, int sf,
                                int st, int pad_f, int pad_t, int act, dcs_stream_t stream) {
-    if (!x1 || !wp || !bias || !y) return DCS_ERR_BADARG;
-    if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0) return DCS_ERR_BADARG;
-    if ((C2 > 0) != (x2 != nullptr)) return DCS_ERR_BADARG;
-    if (up_f < 1 || up_t < 1 || kh < 1 || kw < 1 || sf < 1 || st < 1 || pad_f < 0 || pad_t < 0) return DCS_ERR_BADARG;
+    if (!wp || !bias || !y) return DCS_ERR_BADARG;
+    if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t)) return DCS_ERR_BADARG;
     if (act < DCS_ACT_NONE || act > DCS_ACT_SIGMOID) return DCS_ERR_BADARG;
     return dcs_cconv2d_direct(x1, x2, wp, bias, y, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t,
                               act, dcs_stream(stream));
+}
+
+extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float* gxv, int B, int Hout, int Wout,
+                                    int Cout, int Hv, int Wv, int Cin, int kh, int kw, int sf, int st, int pad_f,
+                                    int pad_t, dcs_stream_t stream) {
+    if (!gy || !wp_bwd || !gxv || B <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0 || Hv <= 0 || Wv <= 0 || Cin <= 0)
+        return DCS_ERR_BADARG;
+    if (kh < 1 || kw < 1 || sf < 1 || st < 1 || pad_f < 0 || pad_t < 0 || pad_f > kh - 1 || pad_t > kw - 1)
+        return DCS_ERR_BADARG;
+    ConvArgs a{};
+    a.x1 = (const float2*)gy; a.x2 = nullptr; a.wp = (const float2*)wp_bwd; a.bias = nullptr; a.y = (float2*)gxv;
+    a.B = B; a.Hin = Hout; a.Win = Wout; a.C1 = Cout; a.C2 = 0; a.up_f = sf; a.up_t = st; a.zero_ins = 1;
+    a.Cout = Cin; a.kh = kh; a.kw = kw; a.sf = 1; a.st = 1; a.pad_f = kh - 1 - pad_f; a.pad_t = kw - 1 - pad_t;
+    a.act = DCS_ACT_NONE;
+    a.Hv = (Hout - 1) * sf + 1; a.Wv = (Wout - 1) * st + 1;
+    a.Hout = Hv; a.Wout = Wv;                          // explicit: rows past the last tap get zeros
+    return launch_direct(a, dcs_stream(stream));
+}
+
+extern "C" long dcs_cconv2d_bwd_weight_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                                                       int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t) {
+    if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || kh < 1 || kw < 1 || sf < 1 || st < 1 ||
+        up_f < 1 || up_t < 1)
+        return -1;
+    ConvArgs a = fwd_args(nullptr, nullptr, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    if (!conv_geometry(a)) return -1;
+    long wsz;
+    const int ns = wgrad_slabs(a, &wsz);
+    return (long)ns * (wsz + Cout) * (long)sizeof(float2);
+}
+
+extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const float* gy, float* gw_r, float* gw_i,
+                                      float* gb_r, float* gb_i, void* workspace, long workspace_bytes, int B, int Hin,
+                                      int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh, int kw, int sf,
+                                      int st, int pad_f, int pad_t, int transposed, dcs_stream_t stream) {
+    if (!gy || !gw_r || !gw_i || !workspace) return DCS_ERR_BADARG;
+    if ((gb_r == nullptr) != (gb_i == nullptr)) return DCS_ERR_BADARG;
+    if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t)) return DCS_ERR_BADARG;
+    if (kh * kw > 4 * WG_TAPS) return DCS_ERR_BADARG;
+    WgradArgs w{};
+    w.c = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    if (!conv_geometry(w.c)) return DCS_ERR_BADARG;
+    long wsz;
+    w.n_slabs = wgrad_slabs(w.c, &wsz);
+    if (workspace_bytes < (long)w.n_slabs * (wsz + Cout) * (long)sizeof(float2)) return DCS_ERR_WORKSPACE;
+    w.x1 = (const float2*)x1; w.x2 = (const float2*)x2; w.gy = (const float2*)gy;
+    w.slab_w = (float2*)workspace;
+    w.slab_b = w.slab_w + (long)w.n_slabs * wsz;
+    w.total_tiles = w.c.tiles_w * w.c.tiles_h * B;
+    const int Cin = C1 + C2;
+    const int n_ci = (Cin + CHUNK - 1) / CHUNK;
+    w.n_co_chunks = (Cout + WG_CO - 1) / WG_CO;
+    const size_t lds = ((size_t)CHUNK * w.c.plane + (size_t)TH * TW * WG_CO) * sizeof(float2);
+    if (lds > 150 * 1024) return DCS_ERR_BADARG;
+    hipStream_t s = dcs_stream(stream);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)cconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+        return DCS_ERR_LAUNCH;
+    dim3 grid(w.n_slabs, n_ci * w.n_co_chunks);
+    if (grid.y > 65535) return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(cconv_wgrad_kernel, grid, dim3(TH * TW), lds, s, w);
+    DCS_CHECK_LAUNCH();
+    long n = wsz < Cout ? Cout : wsz;
+    hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, s, w.slab_w, w.slab_b,
+                       w.n_slabs, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_upsample_cat_bwd(const float* gxv, float* gx1, float* gx2, int B, int Hin, int Win, int C1, int C2,
+                                    int up_f, int up_t, dcs_stream_t stream) {
+    if (!gxv || !gx1 || B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || up_f < 1 || up_t < 1) return DCS_ERR_BADARG;
+    if ((C2 > 0) != (gx2 != nullptr)) return DCS_ERR_BADARG;
+    const long n = (long)B * Hin * Win * (C1 + C2);
+    long nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(upsample_cat_bwd_kernel, dim3((int)nb), dim3(256), 0, dcs_stream(stream), (const float2*)gxv,
+                       (float2*)gx1, (float2*)gx2, B, Hin, Win, C1, C2, up_f, up_t);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
 }

@@ -81,7 +81,81 @@ __global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restric
     }
 }
 
+// Backward through time for one (sequence, direction) per workgroup.  Threads u < H turn the
+// cotangent of h_t (from the layer above + from step t+1) into the four pre-activation
+// cotangents; then all 256 threads (k = t/4, quarter = t%4) form g_h_{t-1} = W_hh^T g_pre with the
+// W_hh column quarter held in 64 VGPRs and a 4-lane shuffle reduction.  g_pre is written out for
+// the caller's weight / input GEMMs.
+__global__ __launch_bounds__(G4) void lstm_rec_bwd_kernel(const float* __restrict__ g_out,
+                                                           const float* __restrict__ gates, const float* __restrict__ cs,
+                                                           const float* __restrict__ whh, float* __restrict__ g_pre,
+                                                           int S, int seqs_per_set) {
+    __shared__ float gp_s[G4];
+    __shared__ float gh_s[H];
+    const int j = threadIdx.x;
+    const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int set = n / seqs_per_set;
+    const int k = j >> 2, part = j & 3;
+
+    float w[H];      // W_hh[part*64 + jj][k]
+    {
+        const float* wb = whh + ((long)(set * 2 + dir) * G4 + part * H) * H + k;
+#pragma unroll
+        for (int jj = 0; jj < H; ++jj) w[jj] = wb[(long)jj * H];
+    }
+    const int t0 = dir ? S - 1 : 0, dt = dir ? -1 : 1;
+    float gc_rec = 0.f;
+    if (j < H) gh_s[j] = 0.f;
+    __syncthreads();
+    for (int s = S - 1; s >= 0; --s) {
+        const int t = t0 + s * dt;
+        if (j < H) {
+            const long gb = (((long)n * S + t) * 2 + dir) * G4;
+            const float ig = gates[gb + j], fg = gates[gb + H + j], gg = gates[gb + 2 * H + j], og = gates[gb + 3 * H + j];
+            const float c = cs[(((long)n * S + t) * 2 + dir) * H + j];
+            const float cp = s > 0 ? cs[(((long)n * S + (t - dt)) * 2 + dir) * H + j] : 0.f;
+            const float tc = tanhf(c);
+            const float gh = g_out[((long)n * S + t) * (2 * H) + dir * H + j] + gh_s[j];
+            const float gc = gh * og * (1.f - tc * tc) + gc_rec;
+            const float pi = gc * gg * ig * (1.f - ig);
+            const float pf = gc * cp * fg * (1.f - fg);
+            const float pg = gc * ig * (1.f - gg * gg);
+            const float po = gh * tc * og * (1.f - og);
+            gc_rec = gc * fg;
+            gp_s[j] = pi; gp_s[H + j] = pf; gp_s[2 * H + j] = pg; gp_s[3 * H + j] = po;
+            g_pre[gb + j] = pi; g_pre[gb + H + j] = pf; g_pre[gb + 2 * H + j] = pg; g_pre[gb + 3 * H + j] = po;
+        }
+        __syncthreads();
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float4* g4 = reinterpret_cast<const float4*>(gp_s + part * H);
+#pragma unroll
+        for (int q = 0; q < H / 4; ++q) {
+            const float4 gv = g4[q];
+            a0 = fmaf(w[4 * q], gv.x, a0);
+            a1 = fmaf(w[4 * q + 1], gv.y, a1);
+            a2 = fmaf(w[4 * q + 2], gv.z, a2);
+            a3 = fmaf(w[4 * q + 3], gv.w, a3);
+        }
+        float a = (a0 + a1) + (a2 + a3);
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        // gh_s of this step was consumed before the barrier above, so it may be overwritten now
+        if (part == 0) gh_s[k] = a;
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+extern "C" int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_save, const float* w_hh,
+                                  float* g_pre, int n_sets, int seqs_per_set, int S, int Hdim, dcs_stream_t stream) {
+    if (!g_out || !gates || !c_save || !w_hh || !g_pre || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || Hdim != H)
+        return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(lstm_rec_bwd_kernel, dim3(n_sets * seqs_per_set * 2), dim3(G4), 0, dcs_stream(stream), g_out,
+                       gates, c_save, w_hh, g_pre, S, seqs_per_set);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
 
 extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
                                   int n_sets, int seqs_per_set, int S, int Hdim, long stride_set, long stride_n,

@@ -59,6 +59,54 @@ __global__ __launch_bounds__(kThreads) void crm_kernel(const float2* __restrict_
     }
 }
 
+// d unit_dir(v) / dv applied to a cotangent: (g - u (u.g)) / |v|   (0 at the singular point)
+__device__ __forceinline__ float2 unit_dir_bwd(float x, float y, float2 g) {
+    const float h = hypotf(x, y);
+    if (h == 0.f) return make_float2(0.f, 0.f);
+    const float ux = x / h, uy = y / h;
+    const float d = ux * g.x + uy * g.y;
+    return make_float2((g.x - ux * d) / h, (g.y - uy * d) / h);
+}
+
+// cotangent of bound_one's input given the cotangent g of its output
+__device__ __forceinline__ float2 bound_one_bwd(float mr, float mi, float eps, float2 g) {
+    const float r = hypotf(mr, mi);
+    const float m = tanhf(r);
+    const float2 d1 = unit_dir(mr + eps, mi);
+    const float v2x = m * d1.x + eps, v2y = m * d1.y;
+    const float2 d2 = unit_dir(v2x, v2y);
+    float gm = g.x * d2.x + g.y * d2.y;                                  // out = m d2
+    const float2 gv2 = unit_dir_bwd(v2x, v2y, make_float2(m * g.x, m * g.y));
+    gm += gv2.x * d1.x + gv2.y * d1.y;                                   // v2 = m d1 + (eps, 0)
+    const float2 gv1 = unit_dir_bwd(mr + eps, mi, make_float2(m * gv2.x, m * gv2.y));
+    const float gr = gm * (1.f - m * m);                                 // m = tanh r
+    float2 out = gv1;
+    if (r > 0.f) { out.x += gr * mr / r; out.y += gr * mi / r; }         // r = |M|
+    return out;
+}
+
+// g_Min for M = bound(M_in), N = Y M, S = Y - N with optional cotangents gM, gN, gS (Y may be NULL
+// when only gM is given: plain bound_cRM backward)
+__global__ __launch_bounds__(kThreads) void bound_mask_apply_bwd_kernel(const float2* __restrict__ Y,
+                                                                         const float2* __restrict__ Min,
+                                                                         const float2* __restrict__ gM,
+                                                                         const float2* __restrict__ gN,
+                                                                         const float2* __restrict__ gS,
+                                                                         float2* __restrict__ gMin, long n, float eps) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+        float2 g = gM ? gM[i] : make_float2(0.f, 0.f);
+        if (Y && (gN || gS)) {
+            float2 t = gN ? gN[i] : make_float2(0.f, 0.f);
+            if (gS) { const float2 s = gS[i]; t.x -= s.x; t.y -= s.y; }
+            const float2 y = Y[i];                                       // conj(Y) t
+            g.x += y.x * t.x + y.y * t.y;
+            g.y += y.x * t.y - y.y * t.x;
+        }
+        const float2 v = Min[i];
+        gMin[i] = bound_one_bwd(v.x, v.y, eps, g);
+    }
+}
+
 inline int ew_grid(long n) {
     long nb = (n + kThreads * 4 - 1) / (kThreads * 4);
     return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
@@ -79,6 +127,17 @@ extern "C" int dcs_bound_mask_apply_fwd(const float* Y, const float* M_in, float
     if (!Y || !M_in || !M_out || !N_hat || !S_hat || n <= 0) return DCS_ERR_BADARG;
     hipLaunchKernelGGL(bound_mask_apply_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
                        (const float2*)Y, (const float2*)M_in, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const float* g_M, const float* g_N,
+                                        const float* g_S, float* g_Min, long n, float eps, dcs_stream_t stream) {
+    if (!M_in || !g_Min || n <= 0) return DCS_ERR_BADARG;
+    if ((g_N || g_S) && !Y) return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(bound_mask_apply_bwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                       (const float2*)Y, (const float2*)M_in, (const float2*)g_M, (const float2*)g_N,
+                       (const float2*)g_S, (float2*)g_Min, n, eps);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

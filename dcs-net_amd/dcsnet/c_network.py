@@ -199,29 +199,28 @@ class C_NETWORK(LightningModule):
         d = zr.view(B, F7, T7, C7, 2)
 
         for i in range(L):                                   # c_network.py:207-222
-            skip = enc[L - i]
-            ca_m, sa_m = self.skip_attention[2 * i], self.skip_attention[2 * i + 1]
-            ca = ca_m.hip(skip)
-            sa = sa_m.hip(skip, ca)
-            skip = F.attention_apply(skip, ca, sa)
+            skip = self._attend(self.skip_attention[2 * i], self.skip_attention[2 * i + 1], enc[L - i])
             stage = self.decoder[i]
             convt = stage if i == L - 1 else stage[0]
             y = F.cconv2d(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight, convt.conv_tran_r.bias,
                           convt.conv_tran_i.bias, True, convt.kernel_size, (1, 1), convt.corr_padding,
                           tuple(cfg.upsample_scale_factor[i]))
+            dp, seed = self._drop(p_conv)
             if i != L - 1:
                 a = self._bn(stage[1], y, F.ACT_LRELU)
-                ca_m, sa_m = self.decoder_attention[2 * i], self.decoder_attention[2 * i + 1]
-                ca = ca_m.hip(a)
-                sa = sa_m.hip(a, ca)
-                dp, seed = self._drop(p_conv)
-                d = F.attention_apply(a, ca, sa, dp, seed)
+                d = self._attend(self.decoder_attention[2 * i], self.decoder_attention[2 * i + 1], a, dp, seed)
             else:
-                dp, seed = self._drop(p_conv)
                 d = F.dropout(y, dp, seed) if dp > 0 else y
 
-        net_out = F.ops.bound_crm(d.view(B, Fbins, T, 2), hp['atan2_eps'])
+        net_out = F.bound_crm(d.view(B, Fbins, T, 2), hp['atan2_eps'])
         return torch.squeeze(torch.view_as_complex(net_out))          # c_network.py:224
+
+    @staticmethod
+    def _attend(ca_m, sa_m, x, drop_p=0.0, seed=0):
+        """sa (.) ca (.) x with both attentions computed from x (c_network.py:208-211 / :219-220)."""
+        fc0, fc2, c1 = ca_m.fc[0], ca_m.fc[2], sa_m.conv1
+        return F.attention_block(x, fc0.conv_r.weight, fc0.conv_i.weight, fc2.conv_r.weight, fc2.conv_i.weight,
+                                 c1.conv_r.weight, c1.conv_i.weight, sa_m.kernel_size, drop_p, seed)
 
     # ---- trainer hooks (c_network.py:229-416) -------------------------------------------------
 

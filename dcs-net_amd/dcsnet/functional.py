@@ -37,17 +37,68 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed):
     return packed
 
 
+class _CConv2dFn(torch.autograd.Function):
+    """dcs_cconv2d_fwd with its hand-written data / weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up, act):
+        wp, bias = packed_weight(w_r, w_i, b_r, b_i, transposed)
+        y = ops.cconv2d(x1, x2, wp, bias, ksize, stride, pad, up, act)
+        ctx.geom = (transposed, tuple(ksize), tuple(stride), tuple(pad), tuple(up), act, tuple(w_r.shape),
+                    b_r is not None)
+        ctx.save_for_backward(x1, x2, wp, y if act == ACT_SIGMOID else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, wp, y = ctx.saved_tensors
+        transposed, ksize, stride, pad, up, act, w_shape, has_bias = ctx.geom
+        gy = gy.contiguous()
+        if act == ACT_SIGMOID:
+            gy = gy * y * (1.0 - y)
+        elif act != ACT_NONE:
+            raise DcsHipError('cconv2d backward: only ACT_NONE / ACT_SIGMOID epilogues are differentiable here')
+        gx1 = gx2 = gw_r = gw_i = gb_r = gb_i = None
+        need = ctx.needs_input_grad
+        if need[0] or need[1]:
+            C1 = x1.shape[3]
+            Cin = C1 + (x2.shape[3] if x2 is not None else 0)
+            gx1, gx2 = ops.cconv2d_bwd_data(gy, ops.pack_conv_weight_bwd(wp), (x1.shape[1], x1.shape[2], Cin),
+                                            ksize, stride, pad, up, C1)
+        if need[2] or need[3] or need[4] or need[5]:
+            gw_r, gw_i, gb_r, gb_i = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up,
+                                                           transposed)
+        return gx1, gx2, gw_r, gw_i, gb_r, gb_i, None, None, None, None, None, None
+
+
 def cconv2d(x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up=(1, 1), act=ACT_NONE):
-    wp, bias = packed_weight(w_r, w_i, b_r, b_i, transposed)
-    return ops.cconv2d(x1, x2, wp, bias, ksize, stride, pad, up, act)
+    return _CConv2dFn.apply(x1, x2, w_r, w_i, b_r, b_i, transposed, tuple(ksize), tuple(stride), tuple(pad),
+                            tuple(up), act)
+
+
+class _CbnFn(torch.autograd.Function):
+    """dcs_cbn_fwd / dcs_cbn_bwd.  Saves only x and 14 floats per channel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, drop_p, seed):
+        y, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats,
+                                 act, drop_p, seed)
+        ctx.cfg = (bool(use_batch_stats), act, float(drop_p), int(seed), weight is not None)
+        ctx.save_for_backward(x, weight, stats, coef)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, weight, stats, coef = ctx.saved_tensors
+        use_batch, act, drop_p, seed, affine = ctx.cfg
+        g_x, g_w, g_b = ops.cbn_bwd(x, g_out.contiguous(), weight, stats, coef, use_batch, act, drop_p, seed, affine)
+        return g_x, g_w, g_b, None, None, None, None, None, None, None, None
 
 
 def cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act=ACT_NONE,
         drop_p=0.0, seed=0):
-    d = lambda t: None if t is None else t.detach()
-    y, _, _ = ops.cbn(x, d(weight), d(bias), running_mean, running_covar, eps, momentum, use_batch_stats,
-                      act, drop_p, seed)
-    return y
+    return _CbnFn.apply(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
+                        drop_p, seed)
 
 
 def channel_attention(x, fc0_r, fc0_i, fc2_r, fc2_i):
@@ -70,8 +121,34 @@ def attention_apply(x, ca, sa, drop_p=0.0, seed=0):
     return ops.attention_apply(x, ca, sa, drop_p, seed)
 
 
-def dropout(x, drop_p, seed):
-    return ops.dropout(x, drop_p, seed)
+class _AttentionFn(torch.autograd.Function):
+    """out = dropout(sa (.) ca (.) x): channel attention -> spatial attention -> apply, fused
+    (c_network.py:208-211 / :219-222), with the hand-written backward of attention_bwd.hip."""
+
+    @staticmethod
+    def forward(ctx, x, fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed):
+        w1, _ = packed_weight(fc0_r, fc0_i, None, None, False)
+        w2, _ = packed_weight(fc2_r, fc2_i, None, None, False)
+        wsa, zero_bias = packed_weight(c1_r, c1_i, None, None, False)
+        ca, pooled, hidden = ops.channel_attention(x, w1, w2)
+        sp = ops.spatial_pool(x, ca)
+        sa = ops.cconv2d(sp, None, wsa, zero_bias, (ksize, ksize), (1, 1), (ksize // 2, ksize // 2), (1, 1),
+                         ACT_SIGMOID)
+        out = ops.attention_apply(x, ca, sa, drop_p, seed)
+        ctx.cfg = (ksize, float(drop_p), int(seed))
+        ctx.save_for_backward(x, ca, sa, sp, pooled, hidden, w1, w2, wsa)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, ca, sa, sp, pooled, hidden, w1, w2, wsa = ctx.saved_tensors
+        ksize, drop_p, seed = ctx.cfg
+        g = ops.attention_bwd(x, g_out.contiguous(), ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p, seed)
+        return (*g, None, None, None)
+
+
+def attention_block(x, fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p=0.0, seed=0):
+    return _AttentionFn.apply(x, fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed)
 
 
 # ---- complex-tensor conveniences for the drop-in layer surface ---------------------------------
@@ -127,49 +204,124 @@ def complex_linear(z, w_r, w_i, b_r, b_i):
     return torch.view_as_complex(y.view(N, -1, 2)).view(*lead, -1)
 
 
-def complex_lstm(z, real_lstm, imag_lstm, save=False):
+class _LstmRecFn(torch.autograd.Function):
+    """Recurrent half of one LSTM layer (dcs_lstm_layer_fwd / _bwd).  gx: [sets, seqs, S, 2, 4H]
+    pre-activations of the input projection; w_hh: [sets, 2, 4H, H]."""
+
+    @staticmethod
+    def forward(ctx, gx, w_hh):
+        n_sets, seqs, S, _, G4 = gx.shape
+        need = gx.requires_grad or w_hh.requires_grad
+        out, gates, c = ops.lstm_layer(gx, w_hh, n_sets, seqs, S, (seqs * S * 2 * G4, S * 2 * G4, 2 * G4), need)
+        ctx.dims = (n_sets, seqs, S)
+        if need:
+            ctx.save_for_backward(out, gates, c, w_hh)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        out, gates, c, w_hh = ctx.saved_tensors
+        n_sets, seqs, S = ctx.dims
+        H = w_hh.shape[-1]
+        g_pre = ops.lstm_layer_bwd(g_out.contiguous(), gates, c, w_hh, n_sets, seqs, S)
+        g_pre5 = g_pre.view(n_sets, seqs, S, 2, 4 * H)
+        g_whh = None
+        if ctx.needs_input_grad[1]:
+            o = out.view(n_sets, seqs, S, 2, H)
+            h_prev = torch.zeros_like(o)
+            h_prev[:, :, 1:, 0] = o[:, :, :-1, 0]           # forward direction: h_{t-1}
+            h_prev[:, :, :-1, 1] = o[:, :, 1:, 1]           # reverse direction: h_{t+1}
+            g_whh = torch.einsum('sntdj,sntdk->sdjk', g_pre5, h_prev)
+        return g_pre5, g_whh
+
+
+def complex_lstm(z, real_lstm, imag_lstm):
     """ComplexLSTM.forward (c_network.py:33-47) for two bidirectional batch_first nn.LSTM
-    parameter containers.  Per layer: one input-projection GEMM for all time steps (rocBLAS via
-    torch) + one persistent HIP launch for the recurrence of all 4 passes x 2 directions."""
+    parameter containers.  Per layer: one batched input-projection GEMM for all time steps
+    (rocBLAS via torch, differentiated by autograd) + one persistent HIP launch for the recurrence
+    of all 4 passes x 2 directions (hand-written BPTT)."""
     if not (real_lstm.bidirectional and real_lstm.batch_first and real_lstm.hidden_size == 64):
         raise DcsHipError('complex_lstm: the HIP path implements the reference geometry '
                           '(bidirectional, batch_first, hidden 64: c_network.py:118-123)')
     B, S, I = z.shape
     sets = (real_lstm, imag_lstm)
-    # rows 0..B-1: real parts, rows B..2B-1: imaginary parts
-    x = torch.view_as_real(z).permute(3, 0, 1, 2).reshape(2 * B, S, I)
-    inp = None
+    # rows 0..B-1: real parts, rows B..2B-1: imaginary parts; both weight sets see the same input
+    x = torch.view_as_real(z).permute(3, 0, 1, 2).reshape(1, 2 * B * S, I)
+    inp = x.expand(2, -1, -1)
     for layer in range(real_lstm.num_layers):
         names = [f'_l{layer}', f'_l{layer}_reverse']
-        w_ih = [torch.cat([getattr(m, 'weight_ih' + n) for n in names]).detach() for m in sets]          # [8H, in]
-        bias = [torch.cat([getattr(m, 'bias_ih' + n) + getattr(m, 'bias_hh' + n) for n in names]).detach()
-                for m in sets]
-        w_hh = torch.stack([torch.stack([getattr(m, 'weight_hh' + n) for n in names]) for m in sets]).detach()
-        w_hh = w_hh.contiguous()
-        G = w_ih[0].shape[0]                                    # 2 dirs * 4H
-        if layer == 0:
-            gx = torch.addmm(torch.cat(bias), x.reshape(2 * B * S, I), torch.cat(w_ih).t())    # (n, t, set, dir, 4H)
-            strides = (G, S * 2 * G, 2 * G)
-        else:
-            gx = torch.baddbmm(torch.stack(bias).unsqueeze(1), inp.reshape(2, 2 * B * S, -1),
-                               torch.stack(w_ih).transpose(1, 2))                               # (set, n, t, dir, 4H)
-            strides = (2 * B * S * G, S * G, G)
-        out, _, _ = ops.lstm_layer(gx.contiguous(), w_hh, 2, 2 * B, S, strides, save)
-        inp = out.view(2, 2 * B, S, -1)
-    rr, ir = inp[0, :B], inp[0, B:]        # real_lstm(re), real_lstm(im)
-    ri, ii = inp[1, :B], inp[1, B:]        # imag_lstm(re), imag_lstm(im)
+        w_ih = torch.stack([torch.cat([getattr(m, 'weight_ih' + n) for n in names]) for m in sets])      # [2, 8H, in]
+        bias = torch.stack([torch.cat([getattr(m, 'bias_ih' + n) + getattr(m, 'bias_hh' + n) for n in names])
+                            for m in sets])                                                                # [2, 8H]
+        w_hh = torch.stack([torch.stack([getattr(m, 'weight_hh' + n) for n in names]) for m in sets])     # [2,2,4H,H]
+        gx = torch.baddbmm(bias.unsqueeze(1), inp, w_ih.transpose(1, 2))          # (set, n*t, dir*4H)
+        out = _LstmRecFn.apply(gx.view(2, 2 * B, S, 2, -1), w_hh.contiguous())    # [2*2B, S, 2H]
+        inp = out.view(2, 2 * B * S, -1)
+    o = inp.view(2, 2 * B, S, -1)
+    rr, ir = o[0, :B], o[0, B:]            # real_lstm(re), real_lstm(im)
+    ri, ii = o[1, :B], o[1, B:]            # imag_lstm(re), imag_lstm(im)
     return torch.complex(rr - ii, ir + ri)
 
 
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, drop_p, seed):
+        ctx.cfg = (float(drop_p), int(seed))
+        return ops.dropout(x, drop_p, seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.dropout(g.contiguous(), *ctx.cfg), None, None
+
+
+def dropout(x, drop_p, seed):
+    return _DropoutFn.apply(x, drop_p, seed)
+
+
+class _BoundCrmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, M, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(M)
+        return ops.bound_crm(M, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        (M,) = ctx.saved_tensors
+        return ops.bound_mask_apply_bwd(None, M, g.contiguous(), None, None, ctx.eps), None
+
+
+def bound_crm(M, eps=10e-7):
+    """bound_cRM on an interleaved float view [..., 2]."""
+    return _BoundCrmFn.apply(M, eps)
+
+
+class _BoundMaskApplyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, M_in, eps):
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(Y, M_in)
+        return ops.bound_mask_apply(Y, M_in, eps)
+
+    @staticmethod
+    def backward(ctx, gM, gN, gS):
+        Y, M_in = ctx.saved_tensors
+        c = lambda t: None if t is None else t.contiguous()
+        if gM is None and gN is None and gS is None:
+            return None, None, None
+        return None, ops.bound_mask_apply_bwd(Y, M_in, c(gM), c(gN), c(gS), ctx.eps), None
+
+
 def bound_crm_complex(M, eps=10e-7):
-    x = torch.view_as_real(M.contiguous())
-    return torch.view_as_complex(ops.bound_crm(x, eps))
+    return torch.view_as_complex(bound_crm(torch.view_as_real(M.contiguous()), eps))
 
 
 def bound_mask_apply_complex(Y, M_in, eps=10e-7):
+    """(bound_cRM(M_in), Y (.) M, Y - Y (.) M) in one kernel; differentiable w.r.t. M_in."""
     y = torch.view_as_real(Y.contiguous())
     m = torch.view_as_real(M_in.contiguous())
-    M, N, S = ops.bound_mask_apply(y, m, eps)
+    M, N, S = _BoundMaskApplyFn.apply(y, m, eps)
     return torch.view_as_complex(M), torch.view_as_complex(N), torch.view_as_complex(S)
 
 

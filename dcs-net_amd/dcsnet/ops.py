@@ -85,6 +85,63 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     return y
 
 
+def pack_conv_weight_bwd(wp):
+    """Forward packed weight [taps,Cin,Cout,2] -> data-gradient weight [taps,Cout,Cin,2]."""
+    _chk(wp, 'wp', 4)
+    taps, Cin, Cout, _ = wp.shape
+    wpb = torch.empty((taps, Cout, Cin, 2), dtype=torch.float32, device=wp.device)
+    check(_lib.load().dcs_pack_conv_weight_bwd(ptr(wp), ptr(wpb), Cout, Cin, taps, 1, cur_stream()),
+          'dcs_pack_conv_weight_bwd')
+    return wpb
+
+
+def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=None):
+    """gy [B,Hout,Wout,Cout,2] -> (g_x1, g_x2) for the forward call with x1 [B,Hin,Win,C1,2] (+ x2).
+    in_shape = (Hin, Win, Cin_total)."""
+    _chk(gy, 'gy', 5)
+    _chk(wp_bwd, 'wp_bwd', 4)
+    B, Hout, Wout, Cout, _ = gy.shape
+    Hin, Win, Cin = in_shape
+    C1 = Cin if C1 is None else C1
+    C2 = Cin - C1
+    Hv, Wv = Hin * up[0], Win * up[1]
+    gxv = torch.empty((B, Hv, Wv, Cin, 2), dtype=torch.float32, device=gy.device)
+    lib = _lib.load()
+    check(lib.dcs_cconv2d_bwd_data(ptr(gy), ptr(wp_bwd), ptr(gxv), B, Hout, Wout, Cout, Hv, Wv, Cin, ksize[0], ksize[1],
+                                   stride[0], stride[1], pad[0], pad[1], cur_stream()), 'dcs_cconv2d_bwd_data')
+    if up == (1, 1) and C2 == 0:
+        return gxv, None
+    gx1 = torch.empty((B, Hin, Win, C1, 2), dtype=torch.float32, device=gy.device)
+    gx2 = torch.empty((B, Hin, Win, C2, 2), dtype=torch.float32, device=gy.device) if C2 else None
+    check(lib.dcs_upsample_cat_bwd(ptr(gxv), ptr(gx1), ptr(gx2), B, Hin, Win, C1, C2, up[0], up[1], cur_stream()),
+          'dcs_upsample_cat_bwd')
+    return gx1, gx2
+
+
+def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1, 1), transposed=False):
+    """Gradients in the reference's parameter layout: (gw_r, gw_i, gb_r, gb_i)."""
+    _chk(x1, 'x1', 5)
+    _chk(x2, 'x2', 5)
+    _chk(gy, 'gy', 5)
+    B, Hin, Win, C1, _ = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    Cout = gy.shape[3]
+    dev = gy.device
+    gw_r = torch.empty(w_shape, dtype=torch.float32, device=dev)
+    gw_i = torch.empty(w_shape, dtype=torch.float32, device=dev)
+    gb_r = torch.empty(Cout, dtype=torch.float32, device=dev) if has_bias else None
+    gb_i = torch.empty(Cout, dtype=torch.float32, device=dev) if has_bias else None
+    lib = _lib.load()
+    geo = (B, Hin, Win, C1, C2, up[0], up[1], Cout, ksize[0], ksize[1], stride[0], stride[1], pad[0], pad[1])
+    nbytes = lib.dcs_cconv2d_bwd_weight_workspace_bytes(*geo)
+    if nbytes < 0:
+        raise _lib.DcsHipError(f'cconv2d_bwd_weight: unsupported geometry {geo}')
+    ws = _workspace(nbytes, dev)
+    check(lib.dcs_cconv2d_bwd_weight(ptr(x1), ptr(x2), ptr(gy), ptr(gw_r), ptr(gw_i), ptr(gb_r), ptr(gb_i), ptr(ws),
+                                     ws.numel(), *geo, int(bool(transposed)), cur_stream()), 'dcs_cconv2d_bwd_weight')
+    return gw_r, gw_i, gb_r, gb_i
+
+
 def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, use_batch_stats=True,
         act=ACT_NONE, drop_p=0.0, seed=0, out=None):
     """ComplexBatchNorm2d (+act +dropout).  running_mean: float [C,2] view of the complex buffer.
@@ -107,6 +164,26 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
                           -1.0 if momentum is None else momentum, int(bool(use_batch_stats)), act,
                           float(drop_p), int(seed), cur_stream()), 'dcs_cbn_fwd')
     return y, stats, coef
+
+
+def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, seed=0, affine=True):
+    """Backward of cbn(): returns (g_x, g_weight [C,3], g_bias [C,2])."""
+    _chk(x, 'x', 5)
+    _chk(g_out, 'g_out', 5)
+    B, H, W, C, _ = x.shape
+    P = B * H * W
+    g_x = torch.empty_like(x)
+    g_w = torch.empty((C, 3), dtype=torch.float32, device=x.device) if affine else None
+    g_b = torch.empty((C, 2), dtype=torch.float32, device=x.device) if affine else None
+    lib = _lib.load()
+    nbytes = lib.dcs_cbn_bwd_workspace_bytes(P, C)
+    if nbytes < 0:
+        raise _lib.DcsHipError(f'cbn_bwd: unsupported channel count C={C}')
+    ws = _workspace(nbytes, x.device)
+    check(lib.dcs_cbn_bwd(ptr(x), ptr(g_out), ptr(g_x), ptr(weight), ptr(stats), ptr(coef), ptr(g_w), ptr(g_b),
+                          ptr(ws), ws.numel(), P, C, int(bool(use_batch_stats)), act, float(drop_p), int(seed),
+                          cur_stream()), 'dcs_cbn_bwd')
+    return g_x, g_w, g_b
 
 
 def channel_attention(x, w1, w2):
@@ -150,6 +227,37 @@ def attention_apply(x, ca=None, sa=None, drop_p=0.0, seed=0, out=None):
     return y
 
 
+def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p=0.0, seed=0):
+    """Backward of the fused attention block.  Returns (g_x, g_fc0_r, g_fc0_i, g_fc2_r, g_fc2_i,
+    g_conv1_r, g_conv1_i) with the weight gradients in the reference's parameter layout."""
+    _chk(x, 'x', 5)
+    _chk(g_out, 'g_out', 5)
+    B, H, W, C, _ = x.shape
+    HW = H * W
+    Ch = hidden.shape[1]
+    dev = x.device
+    lib = _lib.load()
+    g_pre = torch.empty((B, H, W, 1, 2), dtype=torch.float32, device=dev)
+    check(lib.dcs_attention_bwd_sa(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_pre), B, HW, C, float(drop_p),
+                                   int(seed), cur_stream()), 'dcs_attention_bwd_sa')
+    k, pad = (ksize, ksize), (ksize // 2, ksize // 2)
+    g_sp, _ = cconv2d_bwd_data(g_pre, pack_conv_weight_bwd(wsa), (H, W, 2), k, (1, 1), pad)
+    g_c1r, g_c1i, _, _ = cconv2d_bwd_weight(sp, None, g_pre, (1, 2, ksize, ksize), False, k, (1, 1), pad)
+    g_x = torch.empty_like(x)
+    g0r = torch.empty((Ch, C, 1, 1), dtype=torch.float32, device=dev)
+    g0i = torch.empty_like(g0r)
+    g2r = torch.empty((C, Ch, 1, 1), dtype=torch.float32, device=dev)
+    g2i = torch.empty_like(g2r)
+    nbytes = lib.dcs_attention_bwd_workspace_bytes(B, HW, C, Ch)
+    if nbytes < 0:
+        raise _lib.DcsHipError(f'attention_bwd: unsupported channel count C={C}')
+    ws = _workspace(nbytes, dev)
+    check(lib.dcs_attention_bwd_x(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_sp), ptr(pooled), ptr(hidden), ptr(w1),
+                                  ptr(w2), ptr(g_x), ptr(g0r), ptr(g0i), ptr(g2r), ptr(g2i), ptr(ws), ws.numel(),
+                                  B, HW, C, Ch, float(drop_p), int(seed), cur_stream()), 'dcs_attention_bwd_x')
+    return g_x, g0r, g0i, g2r, g2i, g_c1r, g_c1i
+
+
 def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False):
     """Recurrent half of one LSTM layer for every (set, sequence, direction); see dcs_lstm_layer_fwd.
     gx: float pre-activations addressed by `strides` = (stride_set, stride_n, stride_t) in floats;
@@ -164,6 +272,17 @@ def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False):
     check(_lib.load().dcs_lstm_layer_fwd(ptr(gx), ptr(w_hh), ptr(out), ptr(gates), ptr(c), n_sets, seqs_per_set, S, H,
                                          strides[0], strides[1], strides[2], cur_stream()), 'dcs_lstm_layer_fwd')
     return out, gates, c
+
+
+def lstm_layer_bwd(g_out, gates, c, w_hh, n_sets, seqs_per_set, S):
+    _chk(g_out, 'g_out', 3)
+    _chk(gates, 'gates', 4)
+    _chk(c, 'c', 4)
+    _chk(w_hh, 'w_hh', 4)
+    g_pre = torch.empty_like(gates)
+    check(_lib.load().dcs_lstm_layer_bwd(ptr(g_out), ptr(gates), ptr(c), ptr(w_hh), ptr(g_pre), n_sets, seqs_per_set, S,
+                                         w_hh.shape[-1], cur_stream()), 'dcs_lstm_layer_bwd')
+    return g_pre
 
 
 def dropout(x, drop_p, seed, out=None):
@@ -207,6 +326,17 @@ def bound_mask_apply(Y, M_in, eps=10e-7):
     check(_lib.load().dcs_bound_mask_apply_fwd(ptr(Y), ptr(M_in), ptr(M), ptr(N), ptr(S), Y.numel() // 2, eps,
                                                cur_stream()), 'dcs_bound_mask_apply_fwd')
     return M, N, S
+
+
+def bound_mask_apply_bwd(Y, M_in, g_M, g_N, g_S, eps=10e-7):
+    """Cotangent of M_in; any of g_M / g_N / g_S (and Y when only g_M is given) may be None."""
+    _chk(M_in, 'M_in')
+    for n, t in (('Y', Y), ('g_M', g_M), ('g_N', g_N), ('g_S', g_S)):
+        _chk(t, n)
+    g = torch.empty_like(M_in)
+    check(_lib.load().dcs_bound_mask_apply_bwd(ptr(Y), ptr(M_in), ptr(g_M), ptr(g_N), ptr(g_S), ptr(g),
+                                               M_in.numel() // 2, eps, cur_stream()), 'dcs_bound_mask_apply_bwd')
+    return g
 
 
 def crm(S, Y, eps=1e-8):

@@ -86,6 +86,34 @@ int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const flo
                     dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Gradients of dcs_cconv2d_fwd (what torch.autograd derives for the reference through the four
+ * real convolutions of apply_complex; gradients of complex tensors are dL/dRe + j dL/dIm).
+ *
+ * dcs_pack_conv_weight_bwd: wp_bwd[tap'][co][ci] = conj(wp[ntaps-1-tap'][ci][co]).
+ * dcs_cconv2d_bwd_data:  g_Xv[b,vy,vx,ci] = sum_{p,tap,co} conj(wp[tap][ci][co]) g_Y[p,co] over
+ *     p*s - pad + tap = (vy,vx); g_Xv is the gradient of the VIRTUAL input complex[B][Hv][Wv][Cin]
+ *     (Hv = Hin*up_f ...).  Without upsample/cat it IS g_x1.
+ * dcs_upsample_cat_bwd:  g_x1 / g_x2 = block sums of g_Xv over (up_f, up_t), split at channel C1.
+ * dcs_cconv2d_bwd_weight: gradients of the reference's parameters, in THEIR layout:
+ *     gw_r, gw_i: float[Cout][Cin][kh][kw] (transposed=0) or float[Cin][Cout][kh][kw] (transposed=1)
+ *     gb_r, gb_i: float[Cout] (NULL for bias-free layers).  x1/x2/geometry as in the forward call.
+ *     workspace >= dcs_cconv2d_bwd_weight_workspace_bytes(...) (partial slabs; no atomics). */
+int  dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout, int Cin, int kh, int kw, dcs_stream_t stream);
+int  dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float* gxv,
+                          int B, int Hout, int Wout, int Cout, int Hv, int Wv, int Cin,
+                          int kh, int kw, int sf, int st, int pad_f, int pad_t, dcs_stream_t stream);
+int  dcs_upsample_cat_bwd(const float* gxv, float* gx1, float* gx2, int B, int Hin, int Win, int C1, int C2,
+                          int up_f, int up_t, dcs_stream_t stream);
+long dcs_cconv2d_bwd_weight_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                                            int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t);
+int  dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const float* gy,
+                            float* gw_r, float* gw_i, float* gb_r, float* gb_i,
+                            void* workspace, long workspace_bytes,
+                            int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                            int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int transposed,
+                            dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * ComplexBatchNorm2d forward (complexPyTorch 0.3), fused with the activation and the
  * dropout that follow it in the reference.
  * Replaces: c_network.py:101 (initial_batchnorm, :190), :113-114 (encoder CBN + CReLU),
@@ -107,6 +135,17 @@ int  dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bia
                  float* running_mean, float* running_covar,
                  float* stats_out, float* coef_out, void* workspace, long workspace_bytes,
                  long P, int C, float eps, float momentum, int use_batch_stats, int act,
+                 float drop_p, unsigned long long seed, dcs_stream_t stream);
+
+/* Backward of dcs_cbn_fwd (closed form of what autograd derives through complexPyTorch's CBN,
+ * the activation and the dropout).  g_out: gradient w.r.t. y; g_x: gradient w.r.t. x (may alias
+ * g_out); stats/coef: as written by the forward call; g_weight float[C][3], g_bias float[C][2]
+ * (both NULL for affine=False); same act / drop_p / seed as the forward call.
+ * use_batch_stats = 0 differentiates the eval-mode (running statistics) normalisation. */
+long dcs_cbn_bwd_workspace_bytes(long P, int C);
+int  dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const float* weight,
+                 const float* stats, const float* coef, float* g_weight, float* g_bias,
+                 void* workspace, long workspace_bytes, long P, int C, int use_batch_stats, int act,
                  float drop_p, unsigned long long seed, dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -148,6 +187,27 @@ int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, fl
                             dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Backward of the fused attention block  out = dropout(sa (.) ca (.) x)  built from the four
+ * forward entry points above (channel attention -> spatial pool -> 7x7 conv + sigmoid -> apply).
+ * Step 1  dcs_attention_bwd_sa: g_pre[b][p] = sigmoid'(sa) (.) sum_c g_o conj(ca x)   (complex[B][HW]);
+ *         the caller then runs the 7x7 conv's data / weight gradients on g_pre
+ *         (dcs_cconv2d_bwd_data / _bwd_weight) to get g_sp complex[B][HW][2].
+ * Step 2  dcs_attention_bwd_x: g_x (complex[B][HW][C]) including the paths through the spatial pool
+ *         (mean and first-index arg-max over channels), through ca's global average pool and both
+ *         1x1 convs; writes the gradients of fc.0 / fc.2 conv_r / conv_i in the reference's layout
+ *         ([Ch][C][1][1] and [C][Ch][1][1]).  pooled / hidden / ca as saved by
+ *         dcs_channel_attention_fwd; w1 / w2 the packed 1x1 weights.  g_out is the gradient of the
+ *         block's output; same drop_p / seed as dcs_attention_apply_fwd. */
+int  dcs_attention_bwd_sa(const float* x, const float* g_out, const float* ca, const float* sa, float* g_pre,
+                          int B, long HW, int C, float drop_p, unsigned long long seed, dcs_stream_t stream);
+long dcs_attention_bwd_workspace_bytes(int B, long HW, int C, int Ch);
+int  dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, const float* sa, const float* g_sp,
+                         const float* pooled, const float* hidden, const float* w1, const float* w2,
+                         float* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r, float* g_fc2_i,
+                         void* workspace, long workspace_bytes, int B, long HW, int C, int Ch,
+                         float drop_p, unsigned long long seed, dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * ComplexLSTM, recurrent half (c_network.py:12-51; built :118-123, called :201).
  * One launch walks every sequence of one LSTM layer: both weight sets (real_lstm, imag_lstm),
  * both inputs (re, im) and both directions.  PyTorch LSTM semantics: gate order i,f,g,o,
@@ -162,6 +222,12 @@ int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, fl
 int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
                        int n_sets, int seqs_per_set, int S, int H, long stride_set, long stride_n, long stride_t,
                        dcs_stream_t stream);
+
+/* Backward through time of dcs_lstm_layer_fwd: from g_out float[NS][S][2H] (cotangent of `out`) and
+ * the saved gates / cell states, writes the pre-activation cotangents g_pre float[NS][S][2][4H].
+ * The caller's plain GEMMs turn g_pre into the gradients of x, W_ih, both biases and W_hh. */
+int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_save, const float* w_hh,
+                       float* g_pre, int n_sets, int seqs_per_set, int S, int H, dcs_stream_t stream);
 
 /* Stand-alone inverted dropout on a real view (c_network.py:203-204 dropout_fc after the
  * ComplexLinear; c_network.py:221-222 on the last decoder stage, which has no attention to
@@ -193,6 +259,13 @@ int dcs_bound_crm_fwd(const float* M_raw, float* M_out, long n, float eps, dcs_s
  */
 int dcs_bound_mask_apply_fwd(const float* Y, const float* M_in, float* M_out, float* N_hat, float* S_hat,
                              long n, float eps, dcs_stream_t stream);
+
+/* Backward of dcs_bound_crm_fwd / dcs_bound_mask_apply_fwd w.r.t. the unbounded mask M_in:
+ * g_M, g_N, g_S are the cotangents of M, N_hat, S_hat (each may be NULL = zero); Y may be NULL when
+ * only g_M is given (plain bound_cRM backward).  g_Min may alias any cotangent.  The noisy input Y
+ * is data and receives no gradient. */
+int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const float* g_M, const float* g_N,
+                             const float* g_S, float* g_Min, long n, float eps, dcs_stream_t stream);
 
 /* cRM target mask (network_functions.py:62-75): M = S conj(Y) / (|Y|^2 + 1e-8). */
 int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs_stream_t stream);

@@ -1,0 +1,281 @@
+"""GPU parity of the hand-written backward kernels: every differentiable op (through the C ABI)
+against torch.autograd on the CPU oracle, and the whole network against the gradient vectors
+generated from the reference's own c_network.py (tests/golden/cnet_vectors.npz).
+
+Tolerance: 1e-4 relative to each gradient tensor's max-abs (fp32; accumulation orders differ).
+"""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpt_oracle as cpt          # noqa: E402
+from oracle import nf_oracle as nf            # noqa: E402
+from oracle import cnet_oracle as cno         # noqa: E402
+from oracle.seeded_state import fill_state    # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    from dcsnet import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def rand_c(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.complex(torch.randn(shape, generator=g) * scale, torch.randn(shape, generator=g) * scale)
+
+
+def weights_like(t, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(t.shape, generator=g) - 0.3
+
+
+def functional_loss(out, seed):
+    """A fixed real functional of a complex tensor."""
+    w = weights_like(out.real, seed).to(out.device)
+    return (w * (out.real ** 2 + 0.5 * out.imag ** 2 + 0.25 * out.real * out.imag + 0.3 * out.imag)).sum()
+
+
+def nhwc_leaf(z, dev):
+    from dcsnet import ops
+    return ops.to_nhwc(z.to(dev)).detach().requires_grad_(True)
+
+
+def cgrad(x_nhwc):
+    """float NHWC leaf's grad -> complex NCHW on the CPU."""
+    return torch.view_as_complex(x_nhwc.grad.cpu()).permute(0, 3, 1, 2)
+
+
+def close(got, want, rel=1e-4, abs_=0.0, what=''):
+    got, want = got.detach().cpu(), want.detach().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    assert err <= rel * scale + abs_, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+def dev_params(mod, dev):
+    return {n: p.detach().to(dev).requires_grad_(True) for n, p in mod.named_parameters()}
+
+
+# --------------------------------------------------------------------------------- convolution
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw', [(1, 8, 7, (2, 2), (40, 36)), (8, 16, 7, (2, 2), (20, 24)),
+                                                   (16, 32, 5, (2, 1), (12, 9)), (64, 128, 3, (2, 1), (8, 16)),
+                                                   (4, 2, 3, (1, 2), (19, 9))])
+def test_conv2d_backward(dev, cin, cout, k, stride, hw):
+    from dcsnet import functional as F
+    torch.manual_seed(cin + k)
+    m = cpt.ComplexConv2d(cin, cout, k, stride, k // 2)
+    x = rand_c((2, cin, *hw), 5).requires_grad_(True)
+    functional_loss(m(x), 1).backward()
+    p = dev_params(m, dev)
+    xn = nhwc_leaf(x.detach(), dev)
+    y = F.cconv2d(xn, None, p['conv_r.weight'], p['conv_i.weight'], p['conv_r.bias'], p['conv_i.bias'], False,
+                  (k, k), stride, (k // 2, k // 2))
+    functional_loss(F.from_nhwc(y), 1).backward()
+    close(cgrad(xn), x.grad, what='g_x')
+    for n, q in m.named_parameters():
+        close(p[n].grad, q.grad, what=n)
+
+
+@pytest.mark.parametrize('c1,c2,cout,up', [(128, 128, 64, (2, 1)), (16, 16, 8, (2, 2)), (8, 8, 1, (2, 2)), (16, 0, 8, (1, 1))])
+def test_convtranspose_cat_upsample_backward(dev, c1, c2, cout, up):
+    from dcsnet import functional as F
+    torch.manual_seed(c1 + cout)
+    m = cpt.ComplexConvTranspose2d(c1 + c2, cout, 3, 1, 1)
+    d = rand_c((2, c1, 5, 9), 3).requires_grad_(True)
+    s = rand_c((2, c2, 5, 9), 4).requires_grad_(True) if c2 else None
+    cat = torch.cat((d, s), dim=1) if c2 else d
+    functional_loss(m(cpt.complex_upsample(cat, scale_factor=up, mode='nearest')), 2).backward()
+    p = dev_params(m, dev)
+    dn = nhwc_leaf(d.detach(), dev)
+    sn = nhwc_leaf(s.detach(), dev) if c2 else None
+    y = F.cconv2d(dn, sn, p['conv_tran_r.weight'], p['conv_tran_i.weight'], p['conv_tran_r.bias'],
+                  p['conv_tran_i.bias'], True, (3, 3), (1, 1), (1, 1), up)
+    functional_loss(F.from_nhwc(y), 2).backward()
+    close(cgrad(dn), d.grad, what='g_d')
+    if c2:
+        close(cgrad(sn), s.grad, what='g_skip')
+    for n, q in m.named_parameters():
+        close(p[n].grad, q.grad, what=n)
+
+
+def test_complex_linear_backward(dev):
+    from dcsnet import functional as F
+    torch.manual_seed(8)
+    m = cpt.ComplexLinear(128, 128)
+    z = rand_c((2, 24, 128), 2).requires_grad_(True)
+    functional_loss(m(z), 3).backward()
+    p = dev_params(m, dev)
+    zd = z.detach().to(dev).requires_grad_(True)
+    y = F.complex_linear(zd, p['fc_r.weight'], p['fc_i.weight'], p['fc_r.bias'], p['fc_i.bias'])
+    functional_loss(y, 3).backward()
+    close(zd.grad, z.grad, what='g_z')
+    for n, q in m.named_parameters():
+        close(p[n].grad, q.grad, what=n)
+
+
+# --------------------------------------------------------------------------------- batch norm
+
+@pytest.mark.parametrize('C,shape', [(1, (2, 16, 24)), (1, (1, 3, 5)), (8, (2, 12, 10)), (64, (3, 6, 8)), (128, (2, 4, 8))])
+@pytest.mark.parametrize('act', ['none', 'relu', 'lrelu'])
+@pytest.mark.parametrize('training', [True, False])
+def test_cbn_backward(dev, C, shape, act, training):
+    from dcsnet import functional as F
+    B, H, W = shape
+    bn = fill_state(cpt.ComplexBatchNorm2d(C), seed=C + 1)
+    bn.train(training)
+    post = {'none': lambda z: z, 'relu': cpt.complex_relu, 'lrelu': nf.complex_lrelu}[act]
+    code = {'none': F.ACT_NONE, 'relu': F.ACT_RELU, 'lrelu': F.ACT_LRELU}[act]
+    x = (rand_c((B, C, H, W), C + 2, 1.2) + (0.3 - 0.5j)).requires_grad_(True)
+    rm = torch.view_as_real(bn.running_mean.clone()).to(dev).contiguous()
+    rc = bn.running_covar.clone().to(dev).contiguous()
+    functional_loss(post(bn(x)), 4).backward()
+    p = dev_params(bn, dev)
+    xn = nhwc_leaf(x.detach(), dev)
+    y = F.cbn(xn, p['weight'], p['bias'], rm, rc, bn.eps, 0.1 if training else -1.0, training, code)
+    functional_loss(F.from_nhwc(y), 4).backward()
+    close(cgrad(xn), x.grad, rel=2e-4, what='g_x')
+    close(p['weight'].grad, bn.weight.grad, rel=2e-4, what='g_weight')
+    close(p['bias'].grad, bn.bias.grad, rel=2e-4, what='g_bias')
+
+
+def test_dropout_backward_uses_the_same_mask(dev):
+    from dcsnet import functional as F
+    x = torch.randn(1 << 16, device=dev, requires_grad=True)
+    y = F.dropout(x, 0.2, 99)
+    y.sum().backward()
+    assert torch.equal(x.grad, (y.detach() != 0).float() / 0.8)
+    # fused in CBN: gradient is zero exactly where the output was dropped
+    bn = fill_state(cpt.ComplexBatchNorm2d(8), 1)
+    xn = torch.randn(2, 6, 6, 8, 2, device=dev, requires_grad=True)
+    p = dev_params(bn, dev)
+    rm, rc = torch.zeros(8, 2, device=dev), torch.ones(8, 3, device=dev)
+    y = F.cbn(xn, p['weight'], p['bias'], rm, rc, 1e-5, 0.1, False, F.ACT_NONE, 0.5, 7)
+    y0 = F.cbn(xn, p['weight'], p['bias'], rm, rc, 1e-5, 0.1, False, F.ACT_NONE, 0.0, 7)
+    keep = (y.detach() != 0)
+    assert 0.35 < float(keep.float().mean()) < 0.65
+    assert torch.allclose(y.detach()[keep], 2 * y0.detach()[keep])
+    g = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, xn, g)
+    (gx0,) = torch.autograd.grad(y0, xn, g * keep * 2)
+    assert torch.allclose(gx, gx0, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------- attention
+
+@pytest.mark.parametrize('C,hw,relu_in', [(8, (20, 12), True), (64, (6, 10), False), (128, (2, 8), True)])
+def test_attention_block_backward(dev, C, hw, relu_in):
+    from dcsnet import functional as F
+    torch.manual_seed(C)
+    ca_m, sa_m = cno.ComplexChannelAttention(C, 16), cno.ComplexSpatialAttention(7)
+    x0 = rand_c((3, C, *hw), C + 2)
+    if relu_in:                         # exact zeros (ReLU outputs) create ties in the channel arg-max
+        x0 = cpt.complex_relu(x0)
+    x = x0.clone().requires_grad_(True)
+    z = ca_m(x) * x
+    out = sa_m(z) * z
+    functional_loss(out, 5).backward()
+    pc, ps = dev_params(ca_m, dev), dev_params(sa_m, dev)
+    xn = nhwc_leaf(x0, dev)
+    y = F.attention_block(xn, pc['fc.0.conv_r.weight'], pc['fc.0.conv_i.weight'], pc['fc.2.conv_r.weight'],
+                          pc['fc.2.conv_i.weight'], ps['conv1.conv_r.weight'], ps['conv1.conv_i.weight'], 7)
+    close(F.from_nhwc(y), out, rel=2e-5, what='forward')
+    functional_loss(F.from_nhwc(y), 5).backward()
+    close(cgrad(xn), x.grad, rel=2e-4, what='g_x')
+    for n, q in ca_m.named_parameters():
+        close(pc[n].grad, q.grad, rel=2e-4, what=n)
+    for n, q in sa_m.named_parameters():
+        close(ps[n].grad, q.grad, rel=2e-4, what=n)
+
+
+# --------------------------------------------------------------------------------- LSTM, mask
+
+@pytest.mark.parametrize('B,S', [(2, 8), (3, 40), (1, 1)])
+def test_complex_lstm_backward(dev, B, S):
+    from dcsnet.c_network import ComplexLSTM
+    torch.manual_seed(B * 10 + S)
+    ref = cno.ComplexLSTM(128, 64, 2, True)
+    mod = ComplexLSTM(128, 64, 2, True, True)
+    mod.load_state_dict(ref.state_dict())
+    mod.to(dev)
+    z = rand_c((B, S, 128), 4, 0.8).requires_grad_(True)
+    functional_loss(ref(z), 6).backward()
+    zd = z.detach().to(dev).requires_grad_(True)
+    out = mod(zd)
+    functional_loss(out, 6).backward()
+    close(zd.grad, z.grad, rel=2e-4, what='g_z')
+    got = dict(mod.named_parameters())
+    for n, q in ref.named_parameters():
+        close(got[n].grad, q.grad, rel=2e-4, abs_=1e-7, what=n)
+
+
+def test_bound_and_mask_apply_backward(dev):
+    from dcsnet import functional as F
+    M = rand_c((2, 64, 32), 1, 1.5)
+    M.view(-1)[:4] = torch.tensor([0 + 0j, -1 + 0j, 50 - 70j, 1e-3 + 1e-3j])
+    Y = rand_c((2, 64, 32), 2, 0.7)
+    Mo = M.clone().requires_grad_(True)
+    m, nhat, shat = nf.mask_apply_subtract(Y, Mo)
+    (functional_loss(m, 1) + functional_loss(nhat, 2) + 2 * functional_loss(shat, 3)).backward()
+    Md = M.to(dev).requires_grad_(True)
+    m2, n2, s2 = F.bound_mask_apply_complex(Y.to(dev), Md)
+    (functional_loss(m2, 1) + functional_loss(n2, 2) + 2 * functional_loss(s2, 3)).backward()
+    ok = torch.ones(M.shape, dtype=torch.bool)
+    ok.view(-1)[:2] = False              # the origin and the branch cut are singular for atan2
+    close(Md.grad.cpu()[ok], Mo.grad[ok], rel=2e-4, what='g_M_in')
+    assert torch.isfinite(torch.view_as_real(Md.grad)).all()
+    # only one output used; plain bound_cRM
+    Mo.grad = None
+    functional_loss(nf.bound_cRM(Mo), 4).backward()
+    Md.grad = None
+    functional_loss(F.bound_crm_complex(Md), 4).backward()
+    close(Md.grad.cpu()[ok], Mo.grad[ok], rel=2e-4, what='g_M (bound only)')
+
+
+# --------------------------------------------------------------------------------- whole network
+
+def _hip_net(dev, seed):
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    return fill_state(C_NETWORK(config, hp, seed), seed).to(dev)
+
+
+def _bias_before_bn(n):
+    return n.endswith('.bias') and (('.0.conv_r' in n or '.0.conv_i' in n) and n.startswith('encoder')
+                                    or ('.0.conv_tran_' in n and n.startswith('decoder')))
+
+
+def test_network_gradients_against_reference_vectors(dev, golden_dir):
+    cnv = np.load(os.path.join(golden_dir, 'cnet_vectors.npz'))
+    tag = 'b2t32'
+    net = _hip_net(dev, 0).train()
+    out = net(torch.from_numpy(cnv[f'{tag}_x']).to(dev))
+    w = torch.from_numpy(cnv[f'{tag}_loss_w']).to(dev)
+    loss = (w * (out.real ** 2 + 0.5 * out.imag ** 2 + 0.25 * out.real * out.imag)).sum()
+    loss.backward()
+    assert abs(float(loss) - float(cnv[f'{tag}_loss'])) <= 1e-4 * abs(float(cnv[f'{tag}_loss']))
+    pd = dict(net.named_parameters())
+    names = [str(n) for n in cnv[f'{tag}_grad_names']]
+    assert sorted(names) == sorted(pd.keys())
+    for n, want in zip(names, cnv[f'{tag}_grad_norms']):
+        g = pd[n].grad
+        if want < 0:                                   # decoder_attention.12 / .13 are never run
+            assert g is None, n
+        elif _bias_before_bn(n):                       # analytically zero: both sides are rounding noise
+            assert float(g.norm()) < 2e-3, n
+        else:
+            assert abs(float(g.norm()) - want) <= 2e-3 * want + 1e-6, (n, float(g.norm()), want)
+    for k in cnv.files:
+        if k.startswith(f'{tag}_grad_') and k not in (f'{tag}_grad_names', f'{tag}_grad_norms'):
+            n = k[len(f'{tag}_grad_'):]
+            if not _bias_before_bn(n):
+                close(pd[n].grad, torch.from_numpy(cnv[k]), rel=2e-3, abs_=1e-6, what=n)
