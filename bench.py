@@ -98,12 +98,44 @@ def cpu_baseline(T, iters=2):
             'sample': f'oracle C_NETWORK eval forward + mask apply, B={B}, T={T}, {n} timed passes after 1 warm-up'}
 
 
+def cpu_baseline_train(B, T):
+    """Oracle train step (forward, SiSNR losses, backward, clip, Adam/AMSGrad) on the host cores."""
+    from oracle.cnet_oracle import C_NETWORK_Oracle
+    from oracle.nf_oracle import dcs_train_losses
+    from oracle.seeded_state import fill_state, seeded_input
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = fill_state(C_NETWORK_Oracle(), 0).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, eps=1e-6, weight_decay=1e-4, amsgrad=True)
+    Bs = min(B, 4)
+    clean, noise = seeded_input(Bs, 256, T, 1, 0.1), seeded_input(Bs, 256, T, 2, 0.05)
+    noisy = clean + noise
+
+    def one():
+        opt.zero_grad()
+        loss = dcs_train_losses(net, noise, noisy, clean)[2]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 100.0)
+        opt.step()
+
+    t0 = time.perf_counter()
+    one()
+    first = time.perf_counter() - t0
+    n = max(1, min(3, int(20.0 / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    dt = (time.perf_counter() - t0) / n
+    return {'value': Bs * T / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'oracle C_NETWORK train step (fwd + losses + bwd + clip + Adam), B={Bs}, T={T}, '
+                      f'{n} timed steps after 1 warm-up'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--mode', default='infer', choices=['infer'])
+    ap.add_argument('--mode', default='train', choices=['infer', 'train'])
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -130,19 +162,31 @@ def main():
         if rank == 0:
             print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
-    B = args.batch or 16
-    T = args.frames or 2000
+    train = args.mode == 'train'
+    B = args.batch or (32 if train else 16)
+    T = args.frames or (256 if train else 2000)
     torch.manual_seed(0)
-    net = C_NETWORK(config, hparams, 0).to(dev).eval()
+    net = C_NETWORK(config, hparams, 0).to(dev)
     noise, noisy, clean = synthetic_stft_batch(B, T, dev, seed=rank)
 
     timer = ConvTimer()
     ops.CONV_TIMER = timer
 
-    def step():
-        with torch.no_grad():
-            m_raw = net(noisy)
-            return F.bound_mask_apply_complex(noisy, m_raw, hparams['atan2_eps'])
+    if train:
+        from dcsnet.dp import TrainStep
+        net.train()                       # reference dropout (0.1 / 0.2) and batch statistics
+        ts = TrainStep(net)               # flat bucket + fused HIP Adam/AMSGrad + clip 100 + all-reduce
+        batch = (noise, noisy, clean, list(range(B)))
+
+        def step():
+            return ts(batch)
+    else:
+        net.eval()
+
+        def step():
+            with torch.no_grad():
+                m_raw = net(noisy)
+                return F.bound_mask_apply_complex(noisy, m_raw, hparams['atan2_eps'])
 
     log(f'inputs ready: B={B} T={T}')
     for i in range(args.warmup):
@@ -173,22 +217,29 @@ def main():
         conv_ms, n_launch = timer.summary()
         achieved = timer.flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         line = {
-            'metric': 'STFT frames/sec (forward-only inference: C_NETWORK forward + bound/mask-apply/subtract)',
+            'metric': ('STFT frames/sec (train fwd+bwd+Adam)' if train else
+                       'STFT frames/sec (forward-only inference: C_NETWORK forward + bound/mask-apply/subtract)'),
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: DCS-Net forward-only inference, complex64 [16,256,2000] per GPU '
-                                   '(4 s / 16 kHz STFT, n_fft 512 hop 32, bins 1..256), random-init weights seed 0',
+            'config': {'workload': ('BASELINE configs[2]/[3]: DCS-Net full train step (fwd + SiSNR losses + bwd + grad '
+                                    'all-reduce + clip 100 + Adam/AMSGrad), complex64 [32,256,256] x (noise, noisy, clean) '
+                                    'per GPU, dropout 0.1/0.2, batch-statistics CBN, random-init weights seed 0'
+                                    if train else
+                                    'BASELINE configs[1]: DCS-Net forward-only inference, complex64 [16,256,2000] per GPU '
+                                    '(4 s / 16 kHz STFT, n_fft 512 hop 32, bins 1..256), random-init weights seed 0'),
                        'per_gpu_batch': B, 'frames_per_utterance': T, 'global_batch': B * world,
-                       'frames_per_step': B * T * world, 'parallelism': f'dp{world} (utterance sharding, no collective)'},
+                       'frames_per_step': B * T * world, 'parallelism': (f'dp{world} (utterance sharding, one flat-bucket gradient all-reduce)' if train
+                                       else f'dp{world} (utterance sharding, no collective)')},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-                         'kernel': 'complex conv / convT (dcs_cconv2d_fwd), all launches of the timed region',
+                         'kernel': 'complex conv / convT (dcs_cconv2d_fwd' + (', _bwd_data, _bwd_weight' if train else '')
+                                   + '), all launches of the timed region',
                          'launches': n_launch, 'kernel_ms_per_step': conv_ms / args.steps,
                          'algorithmic_gflop_per_step': timer.flops / args.steps / 1e9},
         }
         if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(T)
+            line['cpu_baseline'] = cpu_baseline_train(B, T) if train else cpu_baseline(T)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)

@@ -1,0 +1,71 @@
+// adam.hip — one fused launch for the optimizer step of the reference's training recipe:
+// gradient all-reduce averaging, clip-by-global-norm (Trainer gradient_clip_val=100, "norm":
+// config.py:48-49, train.py:145-146) and Adam with L2 weight decay and AMSGrad
+// (c_network.py:229-234; lr 1e-4, eps 1e-6, wd 1e-4: config.py:31,44-47), over ONE flat fp32
+// parameter bucket (2.9 M floats).  torch.optim.Adam semantics:
+//     g = scale * g ;  g *= min(1, max_norm / (||g|| + 1e-6)) ;  g += wd * p
+//     m = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2 ;  vmax = max(vmax, v)
+//     p -= lr / (1-b1^t) * m / (sqrt(vmax) / sqrt(1-b2^t) + eps)
+// HBM-bound: 5 streams read, 4 written = 36 B per parameter; the global norm comes from the caller
+// as a DEVICE scalar (no host synchronisation in the step).
+#include "dcs_common.h"
+
+namespace {
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void adam_amsgrad_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                                 float4* __restrict__ m, float4* __restrict__ v,
+                                                                 float4* __restrict__ vmax,
+                                                                 const float* __restrict__ grad_norm, float max_norm,
+                                                                 float grad_scale, long n4, long n, float lr, float b1,
+                                                                 float b2, float eps, float wd, float bc1, float bc2s) {
+    float clip = grad_scale;
+    if (grad_norm != nullptr && max_norm > 0.f) {
+        const float c = max_norm / (grad_scale * grad_norm[0] + 1e-6f);
+        clip *= c < 1.f ? c : 1.f;
+    }
+    const float step = lr / bc1;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv, float& vm) {
+        gg = fmaf(wd, pp, gg * clip);
+        mm = fmaf(b1, mm, (1.f - b1) * gg);
+        vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
+        vm = fmaxf(vm, vv);
+        pp -= step * mm / (sqrtf(vm) / bc2s + eps);
+    };
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long)gridDim.x * kThreads) {
+        float4 pp = p[i], mm = m[i], vv = v[i], vm = vmax[i];
+        const float4 gg = g[i];
+        upd(pp.x, gg.x, mm.x, vv.x, vm.x);
+        upd(pp.y, gg.y, mm.y, vv.y, vm.y);
+        upd(pp.z, gg.z, mm.z, vv.z, vm.z);
+        upd(pp.w, gg.w, mm.w, vv.w, vm.w);
+        p[i] = pp; m[i] = mm; v[i] = vv; vmax[i] = vm;
+    }
+    // tail (n not a multiple of 4)
+    if (blockIdx.x == 0) {
+        float* ps = reinterpret_cast<float*>(p);
+        const float* gs = reinterpret_cast<const float*>(g);
+        float* ms = reinterpret_cast<float*>(m);
+        float* vs = reinterpret_cast<float*>(v);
+        float* vx = reinterpret_cast<float*>(vmax);
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += kThreads) upd(ps[i], gs[i], ms[i], vs[i], vx[i]);
+    }
+}
+}  // namespace
+
+extern "C" int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, const float* grad_norm,
+                                     float max_norm, float grad_scale, long n, float lr, float beta1, float beta2,
+                                     float eps, float weight_decay, int step, dcs_stream_t stream) {
+    if (!p || !g || !m || !v || !vmax || n <= 0 || step < 1) return DCS_ERR_BADARG;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return DCS_ERR_BADARG;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    const long n4 = n / 4;
+    long nb = (n4 + kThreads * 2 - 1) / (kThreads * 2);
+    const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+    hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid), dim3(kThreads), 0, dcs_stream(stream), (float4*)p,
+                       (const float4*)g, (float4*)m, (float4*)v, (float4*)vmax, grad_norm, max_norm, grad_scale, n4, n,
+                       lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

@@ -1,0 +1,132 @@
+"""Utterance-level data parallelism for DCS-Net training — NEW relative to the
+reference, whose DDP lines are commented out (train.py:62-65,138-139).
+
+One process per GPU, identical weights, the minibatch sharded along B.  The model is 11.65 MB:
+nothing is split, and the only exchange per step is ONE sum-all-reduce of ONE flat fp32 gradient
+bucket (RCCL over xGMI with backend "nccl"; gloo in the CPU tests).  At 8 GPUs a ring moves
+2*(7/8)*11.65 MB = 20 MB through a ~150 GB/s link (~0.13 ms) — latency-trivial next to the step,
+so there is no bucketing or overlap machinery.  BatchNorm statistics stay LOCAL: with 32
+utterances per GPU every rank reproduces the reference's batch-32 semantics (config.py:43).
+
+  FlatBucket      re-homes the parameters that are on the forward path into one contiguous buffer
+                  (p.data become views; gradients accumulate straight into a second flat buffer),
+                  so the all-reduce and the fused optimizer kernel each touch ONE tensor
+  TrainStep       zero-grad -> loss.backward() -> all-reduce -> device-side global norm ->
+                  dcs_adam_amsgrad_step (averaging + clip + Adam/AMSGrad in one HIP launch)
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check, ptr, cur_stream
+
+# built by the reference but never run (c_network.py:160-163 vs :218): their .grad stays None and
+# torch.optim skips them, so they must not be decayed or averaged either
+UNUSED_PREFIXES = ('decoder_attention.12.', 'decoder_attention.13.')
+
+
+def hot_parameters(net):
+    return [(n, p) for n, p in net.named_parameters() if p.requires_grad and not n.startswith(UNUSED_PREFIXES)]
+
+
+class FlatBucket:
+    def __init__(self, net):
+        named = hot_parameters(net)
+        if not named:
+            raise ValueError('no trainable parameters')
+        dev, dtype = named[0][1].device, named[0][1].dtype
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        # 4-float alignment of every slice keeps float4 access legal for any parameter shape
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.numel = total
+        self.flat = torch.zeros(total, dtype=dtype, device=dev)
+        self.grad = torch.zeros(total, dtype=dtype, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                n = p.numel()
+                self.flat[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
+        self.offsets = offs
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):        # re-attach if something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def allreduce(self):
+        """Sum over ranks, in place; the 1/world factor is folded into the optimizer kernel."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+            return dist.get_world_size()
+        return 1
+
+
+class FusedAdam:
+    """dcs_adam_amsgrad_step over a FlatBucket (HIP; no fallback)."""
+
+    def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0):
+        self.b = bucket
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.m = torch.zeros_like(bucket.flat)
+        self.v = torch.zeros_like(bucket.flat)
+        self.vmax = torch.zeros_like(bucket.flat)
+        self.t = 0
+
+    def step(self, world=1):
+        b = self.b
+        if not b.flat.is_cuda:
+            raise _lib.DcsHipError('FusedAdam: expected CUDA (HIP) parameters; the HIP path has no CPU fallback')
+        self.t += 1
+        norm = torch.linalg.vector_norm(b.grad).reshape(1) if self.max_norm > 0 else None
+        check(_lib.load().dcs_adam_amsgrad_step(ptr(b.flat), ptr(b.grad), ptr(self.m), ptr(self.v), ptr(self.vmax),
+                                                ptr(norm), float(self.max_norm), 1.0 / world, b.numel, self.lr,
+                                                self.betas[0], self.betas[1], self.eps, self.wd, self.t, cur_stream()),
+              'dcs_adam_amsgrad_step')
+        # the kernel rewrote the parameters behind torch's version counters: invalidate packed weights
+        from . import functional
+        functional.bump_param_generation()
+
+
+class TorchAdam:
+    """Reference optimizer on the same flat bucket (torch.optim.Adam + clip_grad_norm_): what the
+    reference's Trainer does.  Used by the CPU (gloo) data-parallel tests and as the parity
+    reference of FusedAdam; never on the product path."""
+
+    def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0):
+        self.b, self.max_norm = bucket, max_norm
+        self.opt = torch.optim.Adam(bucket.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                    amsgrad=True)
+
+    def step(self, world=1):
+        if world > 1:
+            self.b.grad.div_(world)
+        if self.max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.b.params, self.max_norm)
+        self.opt.step()
+
+
+class TrainStep:
+    """One optimisation step of the reference's recipe over a (possibly sharded) minibatch."""
+
+    def __init__(self, net, optimizer_cls=FusedAdam):
+        hp = net.hparams
+        self.net = net
+        self.bucket = FlatBucket(net)
+        self.opt = optimizer_cls(self.bucket, lr=hp['lr'], eps=hp['optim_eps'], weight_decay=hp['optim_weight_decay'],
+                                 max_norm=hp.get('gradient_clip_val', 0.0) or 0.0)
+
+    def __call__(self, batch, batch_idx=0):
+        self.bucket.zero_grad()
+        loss = self.net.training_step(batch, batch_idx)
+        if loss is None:                       # NaN guard of the reference (c_network.py:257-261)
+            return None
+        loss.backward()
+        world = self.bucket.allreduce()
+        self.opt.step(world)
+        return loss.detach()

@@ -15,6 +15,17 @@ from ._lib import DcsHipError
 _pack_cache = {}
 
 
+_param_generation = 0
+
+
+def bump_param_generation():
+    """Called by optimizers that update parameters outside torch's version counters (the fused
+    HIP Adam): every packed weight becomes stale."""
+    global _param_generation
+    _param_generation += 1
+    _pack_cache.clear()
+
+
 def _ver(t):
     return (0, 0) if t is None else (id(t), t._version)
 

@@ -107,8 +107,11 @@ def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=Non
     Hv, Wv = Hin * up[0], Win * up[1]
     gxv = torch.empty((B, Hv, Wv, Cin, 2), dtype=torch.float32, device=gy.device)
     lib = _lib.load()
+    ev = CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * Cin * ksize[0] * ksize[1]) if CONV_TIMER is not None else None
     check(lib.dcs_cconv2d_bwd_data(ptr(gy), ptr(wp_bwd), ptr(gxv), B, Hout, Wout, Cout, Hv, Wv, Cin, ksize[0], ksize[1],
                                    stride[0], stride[1], pad[0], pad[1], cur_stream()), 'dcs_cconv2d_bwd_data')
+    if ev is not None:
+        CONV_TIMER.end(ev)
     if up == (1, 1) and C2 == 0:
         return gxv, None
     gx1 = torch.empty((B, Hin, Win, C1, 2), dtype=torch.float32, device=gy.device)
@@ -137,8 +140,13 @@ def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1,
     if nbytes < 0:
         raise _lib.DcsHipError(f'cconv2d_bwd_weight: unsupported geometry {geo}')
     ws = _workspace(nbytes, dev)
+    ev = None
+    if CONV_TIMER is not None:
+        ev = CONV_TIMER.begin(8.0 * B * gy.shape[1] * gy.shape[2] * Cout * (C1 + C2) * ksize[0] * ksize[1])
     check(lib.dcs_cconv2d_bwd_weight(ptr(x1), ptr(x2), ptr(gy), ptr(gw_r), ptr(gw_i), ptr(gb_r), ptr(gb_i), ptr(ws),
                                      ws.numel(), *geo, int(bool(transposed)), cur_stream()), 'dcs_cconv2d_bwd_weight')
+    if ev is not None:
+        CONV_TIMER.end(ev)
     return gw_r, gw_i, gb_r, gb_i
 
 

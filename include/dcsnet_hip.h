@@ -270,6 +270,18 @@ int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const float* g_M
 /* cRM target mask (network_functions.py:62-75): M = S conj(Y) / (|Y|^2 + 1e-8). */
 int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Optimizer step of the reference's recipe, fused over one flat fp32 bucket of n parameters:
+ * data-parallel averaging (grad_scale = 1/world), Trainer clip-by-global-norm
+ * (gradient_clip_val 100, train.py:145-146; `grad_norm` = DEVICE scalar holding the 2-norm of the
+ * UNSCALED bucket, NULL or max_norm <= 0 disables clipping) and torch.optim.Adam with L2 weight
+ * decay and amsgrad (c_network.py:229-234).  step = 1-based update count.  All buffers 16-byte
+ * aligned, float[n]. */
+int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
+                          const float* grad_norm, float max_norm, float grad_scale, long n,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                          dcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

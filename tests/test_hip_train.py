@@ -1,0 +1,98 @@
+"""GPU: the optimizer kernel against torch.optim.Adam(amsgrad) + clip_grad_norm_, and the full
+train step (config-3 recipe) against the CPU oracle's step on the same seeded state and batch."""
+import os
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.cnet_oracle import C_NETWORK_Oracle      # noqa: E402
+from oracle.nf_oracle import dcs_train_losses         # noqa: E402
+from oracle.seeded_state import fill_state, seeded_input   # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    from dcsnet import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.a = torch.nn.Parameter(torch.randn(37, 5, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(1001, generator=g))
+        self.c = torch.nn.Parameter(torch.randn(3, generator=g))
+        self.hparams = {'lr': 1e-2, 'optim_eps': 1e-6, 'optim_weight_decay': 1e-3, 'gradient_clip_val': 0.5}
+
+
+@pytest.mark.parametrize('world', [1, 4])
+def test_fused_adam_matches_torch_adam_amsgrad_with_clipping(dev, world):
+    from dcsnet.dp import FlatBucket, FusedAdam, TorchAdam
+    m1, m2 = _Toy().to(dev), _Toy().to(dev)
+    b1, b2 = FlatBucket(m1), FlatBucket(m2)
+    kw = dict(lr=1e-2, eps=1e-6, weight_decay=1e-3, max_norm=0.5)
+    o1, o2 = FusedAdam(b1, **kw), TorchAdam(b2, **kw)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    for it in range(5):
+        grad = (torch.randn(b1.numel, generator=g) * (3.0 if it % 2 else 0.01)).to(dev)   # clipped / not clipped
+        for b in (b1, b2):
+            b.zero_grad()
+            for p, o in zip(b.params, b.offsets):
+                p.grad.copy_(grad[o:o + p.numel()].view(p.shape))
+        o1.step(world)
+        o2.step(world)
+        for p, q in zip(b1.params, b2.params):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), it
+    assert o1.t == 5
+
+
+def test_train_step_tracks_the_oracle(dev):
+    """Three optimisation steps, dropout off: the loss trajectory of the HIP path follows the CPU
+    oracle's.  (Parameters are not compared element-wise: Adam's first update is lr * sign(g), so
+    weights whose gradient is rounding noise — e.g. biases in front of a batch norm — legitimately
+    move in either direction.)"""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    net = fill_state(C_NETWORK(config, hp, 0), 2).to(dev).train()
+    ref = fill_state(C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), 2).train()
+    clean, noise = seeded_input(2, 256, 32, 1, 0.1), seeded_input(2, 256, 32, 2, 0.05)
+    noisy = clean + noise
+    ts = TrainStep(net)
+    opt = torch.optim.Adam(ref.parameters(), lr=hp['lr'], eps=hp['optim_eps'], weight_decay=hp['optim_weight_decay'],
+                           amsgrad=True)
+    batch = (noise.to(dev), noisy.to(dev), clean.to(dev), [0, 1])
+    got, want = [], []
+    for _ in range(3):
+        got.append(float(ts(batch)))
+        opt.zero_grad()
+        loss = dcs_train_losses(ref, noise, noisy, clean)[2]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 100.0)
+        opt.step()
+        want.append(float(loss))
+    for a, b in zip(got, want):
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-3, (got, want)
+    assert net.decoder_attention[12].fc[0].conv_r.weight.grad is None       # never run, never updated
+    sd = net.state_dict()
+    assert int(sd['encoder.0.1.num_batches_tracked']) == 3
+
+
+def test_train_step_with_reference_dropout_runs_and_is_finite(dev):
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    net = C_NETWORK(config, hparams, 0).to(dev).train()
+    clean, noise = seeded_input(4, 256, 64, 1, 0.1), seeded_input(4, 256, 64, 2, 0.05)
+    batch = (noise.to(dev), (clean + noise).to(dev), clean.to(dev), [0, 1, 2, 3])
+    ts = TrainStep(net)
+    losses = [float(ts(batch)) for _ in range(4)]
+    assert all(l == l and abs(l) < 1e4 for l in losses), losses
+    assert torch.isfinite(ts.bucket.flat).all()
