@@ -1,0 +1,39 @@
+// conv_common.h — geometry and the virtual-input gather shared by the direct (conv_direct.hip) and
+// MFMA implicit-GEMM (conv_mfma.hip) complex convolution kernels.
+#pragma once
+#include "dcs_common.h"
+
+namespace conv {
+
+struct Args {
+    const float2* x1; const float2* x2; const float2* wp; const float2* bias; float2* y;
+    int B, Hin, Win, C1, C2, up_f, up_t, zero_ins, Cout, kh, kw, sf, st, pad_f, pad_t, act;
+    int Hv, Wv, Hout, Wout, tiles_w, tiles_h, rows, cols, colsp, plane;
+};
+
+// Element (b, vy, vx, c) of the virtual input: nearest upsample of cat(x1, x2) (c_network.py:214-216),
+// or — for data gradients — g_Y with (up_f-1, up_t-1) zeros inserted between samples.  Zero outside.
+__device__ __forceinline__ bool src_pixel(const Args& a, int b, int vy, int vx, long* sp) {
+    if (vy < 0 || vy >= a.Hv || vx < 0 || vx >= a.Wv) return false;
+    if (a.zero_ins && ((vy % a.up_f) != 0 || (vx % a.up_t) != 0)) return false;
+    *sp = ((long)b * a.Hin + vy / a.up_f) * a.Win + vx / a.up_t;
+    return true;
+}
+
+__device__ __forceinline__ float2 gather(const Args& a, int b, int vy, int vx, int c) {
+    long sp;
+    if (!src_pixel(a, b, vy, vx, &sp)) return make_float2(0.f, 0.f);
+    return (c < a.C1) ? a.x1[sp * a.C1 + c] : a.x2[sp * a.C2 + (c - a.C1)];
+}
+
+// MFMA eligibility of a (Cin, Cout) pair: K groups of 4 complex input channels staged 8 at a time,
+// N = 2*Cout real columns in tiles of 32.
+inline bool mfma_ok(int Cin, int Cout) { return (Cin % 8) == 0 && ((2 * Cout) % 32) == 0; }
+inline long direct_floats(int Cout, int Cin, int taps) { return (long)taps * Cin * Cout * 2; }
+inline long mfma_floats(int Cout, int Cin, int taps) { return mfma_ok(Cin, Cout) ? (long)taps * Cin * Cout * 4 : 0; }
+
+}  // namespace conv
+
+// conv_mfma.hip
+int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);
+int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream);

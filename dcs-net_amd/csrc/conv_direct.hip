@@ -17,26 +17,15 @@
 //   weight g_W[tap,ci,co] = sum_p g_Y[p,co] conj(X[p*s-pad+tap, ci]) : per-tile partial slabs
 //          (no atomics: bitwise reproducible) + a reduce that writes the reference's parameter
 //          layout (conv_r / conv_i or conv_tran_r / conv_tran_i, and the two biases).
-#include "dcs_common.h"
+#include "conv_common.h"
 
 namespace {
 
 constexpr int TH = 16, TW = 16;      // output tile (pixels) per workgroup
 constexpr int CHUNK = 8;             // input channels staged per LDS pass
 
-struct ConvArgs {
-    const float2* x1; const float2* x2; const float2* wp; const float2* bias; float2* y;
-    int B, Hin, Win, C1, C2, up_f, up_t, zero_ins, Cout, kh, kw, sf, st, pad_f, pad_t, act;
-    int Hv, Wv, Hout, Wout, tiles_w, tiles_h, rows, cols, colsp, plane;
-};
-
-// virtual input element (b, vy, vx, c); zero outside, and between samples in zero-insert mode
-__device__ __forceinline__ float2 gather(const ConvArgs& a, int b, int vy, int vx, int c) {
-    if (vy < 0 || vy >= a.Hv || vx < 0 || vx >= a.Wv) return make_float2(0.f, 0.f);
-    if (a.zero_ins && ((vy % a.up_f) != 0 || (vx % a.up_t) != 0)) return make_float2(0.f, 0.f);
-    const long sp = ((long)b * a.Hin + vy / a.up_f) * a.Win + vx / a.up_t;
-    return (c < a.C1) ? a.x1[sp * a.C1 + c] : a.x2[sp * a.C2 + (c - a.C1)];
-}
+using ConvArgs = conv::Args;
+using conv::gather;
 
 template <int COB>
 __global__ __launch_bounds__(TH * TW) void cconv_direct_kernel(ConvArgs a) {
@@ -355,7 +344,15 @@ extern "C" int dcs_pack_conv_weight(const float* w_r, const float* w_i, const fl
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, dcs_stream(stream), w_r, w_i,
                        b_r, b_i, (float2*)wp, (float2*)bias_out, Cout, Cin, kh, kw, transposed);
     DCS_CHECK_LAUNCH();
+    if (conv::mfma_ok(Cin, Cout))      // second panel: MFMA fragment order (conv_mfma.hip)
+        return dcs_conv_mfma_pack(wp, wp + conv::direct_floats(Cout, Cin, kh * kw), Cout, Cin, kh * kw,
+                                  dcs_stream(stream));
     return DCS_OK;
+}
+
+extern "C" long dcs_packed_weight_floats(int Cout, int Cin, int kh, int kw) {
+    if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0) return -1;
+    return conv::direct_floats(Cout, Cin, kh * kw) + conv::mfma_floats(Cout, Cin, kh * kw);
 }
 
 extern "C" int dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout, int Cin, int kh, int kw,
@@ -365,6 +362,10 @@ extern "C" int dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout
     hipLaunchKernelGGL(pack_conv_weight_bwd_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, dcs_stream(stream),
                        (const float2*)wp, (float2*)wp_bwd, Cout, Cin, kh * kw);
     DCS_CHECK_LAUNCH();
+    // in the data-gradient GEMM the roles swap: K runs over the forward Cout, N over the forward Cin
+    if (conv::mfma_ok(Cout, Cin))
+        return dcs_conv_mfma_pack(wp_bwd, wp_bwd + conv::direct_floats(Cin, Cout, kh * kw), Cin, Cout, kh * kw,
+                                  dcs_stream(stream));
     return DCS_OK;
 }
 
@@ -383,6 +384,11 @@ extern "C" int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp
     if (!wp || !bias || !y) return DCS_ERR_BADARG;
     if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t)) return DCS_ERR_BADARG;
     if (act < DCS_ACT_NONE || act > DCS_ACT_SIGMOID) return DCS_ERR_BADARG;
+    if (conv::mfma_ok(C1 + C2, Cout) && !(C1 & 1)) {
+        ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+        a.wp = (const float2*)wp; a.bias = (const float2*)bias; a.y = (float2*)y; a.act = act;
+        return dcs_conv_mfma_launch(a, wp + conv::direct_floats(Cout, C1 + C2, kh * kw), dcs_stream(stream));
+    }
     return dcs_cconv2d_direct(x1, x2, wp, bias, y, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t,
                               act, dcs_stream(stream));
 }
@@ -401,6 +407,8 @@ extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float*
     a.act = DCS_ACT_NONE;
     a.Hv = (Hout - 1) * sf + 1; a.Wv = (Wout - 1) * st + 1;
     a.Hout = Hv; a.Wout = Wv;                          // explicit: rows past the last tap get zeros
+    if (conv::mfma_ok(Cout, Cin))
+        return dcs_conv_mfma_launch(a, wp_bwd + conv::direct_floats(Cin, Cout, kh * kw), dcs_stream(stream));
     return launch_direct(a, dcs_stream(stream));
 }
 

@@ -1,0 +1,207 @@
+// conv_mfma.hip — complex convolution as an fp32 MFMA implicit GEMM (gfx950).
+//
+// The reference runs four real cuDNN convolutions per complex conv (c_network.py:107-112,
+// :135-147).  Here ONE real GEMM does the whole complex product through the 2x2 real embedding
+//     D[p][(co,re|im)] = sum_{tap,ci} [x_r x_i] . [[w_r  w_i], [-w_i  w_r]]
+//   M = output pixels, N = 2*Cout, K = taps * 2*Cin  — exactly 8 real flops per complex MAC.
+// Interleaved (re,im) activations make the K axis contiguous: one ds_read_b128 per lane feeds
+// four v_mfma_f32_32x32x2_f32 (k order permuted identically in the pre-packed B panel).
+//
+//   A (activations)  a 128-pixel output tile's haloed input patch, 8 complex channels at a time, is
+//                    gathered into LDS once (cat / nearest-upsample / zero-insertion resolved in
+//                    the gather; pixel pitch 20 floats keeps ds_read_b128 conflict-free) and reused
+//                    by every tap and every output channel
+//   B (weights)      pre-packed per (tap, k-group, 32-column tile) as 1 KiB wave-fragments; read
+//                    straight from L2 with one coalesced 16-B-per-lane load per four MFMAs,
+//                    prefetched one step ahead
+//   C                4 waves x (WM x WN) 32x32 fp32 accumulators; columns = channels on the lanes, so
+//                    the epilogue adds the bias per lane and stores 128-B row segments
+// fp32-input MFMA is exact fp32 (bit-for-bit an fmaf chain), 157 TFLOP/s peak: the same numerics
+// as the direct kernel at ~6x its VALU rate.
+#include "conv_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;        // output pixels per workgroup
+constexpr int CHUNK = 8;       // complex input channels staged per LDS pass (= 2 k-groups of 4)
+constexpr int PIX = 20;        // LDS floats per patch pixel: 16 + 4 pad
+
+struct MArgs {
+    conv::Args c;
+    const float* bm;
+    int TH, TW, N, KG, NT;     // tile shape (TH*TW = 128), N = 2*Cout, KG = Cin/4, NT = N/32
+};
+
+// wave grid: WAVES_N waves along N, 4/WAVES_N along M; each wave owns WM x WN tiles of 32x32
+template <int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
+    const conv::Args& a = m.c;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    static_assert(WAVES_M * WM * 32 == BM, "tile");
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int kk = lane >> 5, li = lane & 31;
+
+    const int tiles_per_img = a.tiles_w * a.tiles_h;
+    const int b = blockIdx.x / tiles_per_img, tile_id = blockIdx.x % tiles_per_img;
+    const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
+    const int vy0 = oy0 * a.sf - a.pad_f, vx0 = ox0 * a.st - a.pad_t;
+    const int nt0 = (blockIdx.y * WAVES_N + wn) * WN;                  // first 32-column tile of this wave
+    const int Cin = a.C1 + a.C2;
+    const int ntaps = a.kh * a.kw;
+
+    // LDS float offset of this lane's pixel for each of its m-tiles (tap (0,0), k-group 0)
+    int pixoff[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int pi = (wm * WM + i) * 32 + li;
+        pixoff[i] = (((pi / m.TW) * a.sf) * a.cols + (pi % m.TW) * a.st) * PIX + kk * 4;
+    }
+    const float* bbase = m.bm + ((long)nt0 * 64 + lane) * 4;
+    const long b_tap_stride = (long)m.KG * m.NT * 256, b_kg_stride = (long)m.NT * 256;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int n_chunks = Cin / CHUNK;
+    const int npix = a.rows * a.cols;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        __syncthreads();                                               // previous chunk fully consumed
+        for (int idx = t; idx < npix * 4; idx += 256) {                // 4 float4 (2 complex each) per pixel
+            const int q = idx & 3, px = idx >> 2;
+            const int ix = px % a.cols, iy = px / a.cols;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            long sp;
+            if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
+                const int c = ch * CHUNK + 2 * q;
+                const float2* src = (c < a.C1) ? a.x1 + sp * a.C1 + c : a.x2 + sp * a.C2 + (c - a.C1);
+                v = *reinterpret_cast<const float4*>(src);
+            }
+            *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v;
+        }
+        __syncthreads();
+        const int iters = ntaps * 2;                                   // (tap, k-group within chunk)
+        float4 bn[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            bn[j] = *reinterpret_cast<const float4*>(bbase + (long)(ch * 2) * b_kg_stride + j * 256);
+        for (int it = 0; it < iters; ++it) {
+            const int tap = it >> 1, g = it & 1;
+            float4 bf[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = bn[j];
+            if (it + 1 < iters) {                                      // prefetch the next B fragments
+                const int tap2 = (it + 1) >> 1, g2 = (it + 1) & 1;
+                const float* bp = bbase + tap2 * b_tap_stride + (long)(ch * 2 + g2) * b_kg_stride;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bn[j] = *reinterpret_cast<const float4*>(bp + j * 256);
+            }
+            const int tapoff = ((tap / a.kw) * a.cols + (tap % a.kw)) * PIX + g * 8;
+            float4 af[WM];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const float* biasf = reinterpret_cast<const float*>(a.bias);
+    float* yf = reinterpret_cast<float*>(a.y);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = (nt0 + j) * 32 + li;
+        const float bv = biasf ? biasf[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int pi = (wm * WM + i) * 32 + row;
+                const int oy = oy0 + pi / m.TW, ox = ox0 + pi % m.TW;
+                if (oy < a.Hout && ox < a.Wout)
+                    yf[(((long)b * a.Hout + oy) * a.Wout + ox) * m.N + n] = dcs_act(acc[i][j][r] + bv, a.act);
+            }
+        }
+    }
+}
+
+// bm[tap][kg][nt][kk][j][e]: e = 0..3 -> (ci = 4kg+2kk, re), (.., im), (ci+1, re), (ci+1, im); column n = nt*32+j
+__global__ void pack_mfma_kernel(const float2* __restrict__ wp, float4* __restrict__ bm, int Cout, int Cin, int taps) {
+    const int KG = Cin / 4, NT = (2 * Cout) / 32;
+    const long total = (long)taps * KG * NT * 64;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 31), kk = (int)((i >> 5) & 1);
+    long r = i >> 6;
+    const int nt = (int)(r % NT); r /= NT;
+    const int kg = (int)(r % KG);
+    const int tap = (int)(r / KG);
+    const int n = nt * 32 + j, co = n >> 1, im = n & 1;
+    const int ci = 4 * kg + 2 * kk;
+    const float2 w0 = wp[((long)tap * Cin + ci) * Cout + co], w1 = wp[((long)tap * Cin + ci + 1) * Cout + co];
+    // column (co, re): [ w_r, -w_i ] ; column (co, im): [ w_i, w_r ]
+    bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
+}
+
+template <int WAVES_N, int WM, int WN>
+int launch(MArgs& m, hipStream_t stream) {
+    const conv::Args& a = m.c;
+    const size_t lds = (size_t)a.rows * a.cols * PIX * sizeof(float);
+    if (lds > 150 * 1024) return DCS_ERR_BADARG;
+    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DCS_ERR_LAUNCH;
+    dim3 grid(a.tiles_w * a.tiles_h * a.B, m.NT / (WAVES_N * WN));
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+}  // namespace
+
+int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream) {
+    if (!conv::mfma_ok(Cin, Cout)) return DCS_ERR_BADARG;
+    const long total = (long)taps * (Cin / 4) * ((2 * Cout) / 32) * 64;
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(dcs_cdiv(total, 256)), dim3(256), 0, stream, (const float2*)wp_direct,
+                       (float4*)bm, Cout, Cin, taps);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// a: forward geometry with Hout/Wout set; bm: MFMA panel of the packed weight
+int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream) {
+    const int Cin = a.C1 + a.C2;
+    if (!conv::mfma_ok(Cin, a.Cout) || (a.C1 & 1) || a.Hout <= 0 || a.Wout <= 0) return DCS_ERR_BADARG;
+    MArgs m;
+    m.c = a;
+    m.bm = bm;
+    m.N = 2 * a.Cout; m.KG = Cin / 4; m.NT = m.N / 32;
+    // 128-pixel tile: wide and flat for the shallow deep-layer maps, 8x16 otherwise
+    if (a.Hout >= 8) { m.TH = 8; m.TW = 16; }
+    else if (a.Hout >= 4) { m.TH = 4; m.TW = 32; }
+    else { m.TH = 2; m.TW = 64; }
+    m.c.tiles_w = (a.Wout + m.TW - 1) / m.TW;
+    m.c.tiles_h = (a.Hout + m.TH - 1) / m.TH;
+    m.c.rows = (m.TH - 1) * a.sf + a.kh;
+    m.c.cols = (m.TW - 1) * a.st + a.kw;
+    if (m.NT % 4 == 0) return launch<2, 2, 2>(m, stream);      // 128 x 128
+    if (m.NT % 2 == 0) return launch<2, 2, 1>(m, stream);      // 128 x 64
+    return launch<1, 1, 1>(m, stream);                         // 128 x 32
+}

@@ -24,6 +24,7 @@ SIGNATURES = {
     'dcs_error_string': (ctypes.c_char_p, [_I]),
     'dcs_pack_conv_weight': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'dcs_cconv2d_fwd': (_I, [_P, _P, _P, _P, _P] + [_I] * 15 + [_P]),
+    'dcs_packed_weight_floats': (_L, [_I, _I, _I, _I]),
     'dcs_pack_conv_weight_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'dcs_cconv2d_bwd_data': (_I, [_P, _P, _P] + [_I] * 13 + [_P]),
     'dcs_upsample_cat_bwd': (_I, [_P, _P, _P] + [_I] * 7 + [_P]),

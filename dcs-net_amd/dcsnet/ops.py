@@ -47,9 +47,13 @@ def pack_conv_weight(w_r, w_i, b_r=None, b_i=None, transposed=False):
         Cin, Cout, kh, kw = w_r.shape
     else:
         Cout, Cin, kh, kw = w_r.shape
-    wp = torch.empty((kh * kw, Cin, Cout, 2), dtype=torch.float32, device=w_r.device)
-    bias = torch.empty((Cout, 2), dtype=torch.float32, device=w_r.device)
     lib = _lib.load()
+    # one buffer, two panels: [taps,Cin,Cout] complex for the direct kernels, then (when the shape is
+    # MFMA-eligible) the fragment-ordered real-embedded panel; `wp` views the first, the library
+    # finds the second behind it
+    buf = torch.empty(lib.dcs_packed_weight_floats(Cout, Cin, kh, kw), dtype=torch.float32, device=w_r.device)
+    wp = buf[:kh * kw * Cin * Cout * 2].view(kh * kw, Cin, Cout, 2)
+    bias = torch.empty((Cout, 2), dtype=torch.float32, device=w_r.device)
     check(lib.dcs_pack_conv_weight(ptr(w_r), ptr(w_i), ptr(b_r), ptr(b_i), ptr(wp), ptr(bias),
                                    Cout, Cin, kh, kw, int(bool(transposed)), cur_stream()), 'dcs_pack_conv_weight')
     return wp, bias
@@ -89,7 +93,8 @@ def pack_conv_weight_bwd(wp):
     """Forward packed weight [taps,Cin,Cout,2] -> data-gradient weight [taps,Cout,Cin,2]."""
     _chk(wp, 'wp', 4)
     taps, Cin, Cout, _ = wp.shape
-    wpb = torch.empty((taps, Cout, Cin, 2), dtype=torch.float32, device=wp.device)
+    buf = torch.empty(_lib.load().dcs_packed_weight_floats(Cin, Cout, taps, 1), dtype=torch.float32, device=wp.device)
+    wpb = buf[:taps * Cin * Cout * 2].view(taps, Cout, Cin, 2)
     check(_lib.load().dcs_pack_conv_weight_bwd(ptr(wp), ptr(wpb), Cout, Cin, taps, 1, cur_stream()),
           'dcs_pack_conv_weight_bwd')
     return wpb
