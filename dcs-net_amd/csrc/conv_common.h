@@ -34,6 +34,12 @@ inline long mfma_floats(int Cout, int Cin, int taps) { return mfma_ok(Cin, Cout)
 
 }  // namespace conv
 
+// conv_wgrad_mfma.hip
+bool dcs_conv_wgrad_mfma_ok(int Cin, int Cout, int kh, int kw, int C1);
+int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW);
+int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, float* slab_b, int n_slabs,
+                               hipStream_t stream);
+
 // conv_mfma.hip
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);
 int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream);

@@ -177,31 +177,54 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
     if (ci0 == 0 && t < WG_CO && co0 + t < a.Cout) w.slab_b[(long)blockIdx.x * a.Cout + co0 + t] = make_float2(br, bi);
 }
 
-// sum the slabs and scatter into the reference's parameter layout
-__global__ void cconv_wgrad_reduce_kernel(const float2* __restrict__ slab_w, const float2* __restrict__ slab_b,
-                                          int n_slabs, float* __restrict__ gw_r, float* __restrict__ gw_i,
-                                          float* __restrict__ gb_r, float* __restrict__ gb_i, int Cout, int Cin,
-                                          int kh, int kw, int transposed) {
+// sum the slabs and scatter into the reference's parameter layout.  256 threads = 32 elements x 8
+// slab groups (coalesced 256-B rows per slab, 8 slabs in flight), LDS combine.
+__global__ __launch_bounds__(256) void cconv_wgrad_reduce_kernel(const float2* __restrict__ slab_w,
+                                                                  const float2* __restrict__ slab_b, int n_slabs,
+                                                                  float* __restrict__ gw_r, float* __restrict__ gw_i,
+                                                                  float* __restrict__ gb_r, float* __restrict__ gb_i,
+                                                                  int Cout, int Cin, int kh, int kw, int transposed) {
+    __shared__ float2 red[256];
     const long n = (long)kh * kw * Cin * Cout;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < Cout && gb_r != nullptr) {
-        float sr = 0.f, si = 0.f;
-        for (int s = 0; s < n_slabs; ++s) { const float2 v = slab_b[(long)s * Cout + i]; sr += v.x; si += v.y; }
-        gb_r[i] = sr + si;          // bias = (b_r - b_i) + j (b_r + b_i)
-        gb_i[i] = si - sr;
-    }
-    if (i >= n) return;
+    const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + e;
+    const long nb = (n + 31) / 32;                          // workgroups [0, nb): weights; [nb, ..): bias
+    const bool is_bias = blockIdx.x >= nb;
+    const long j = is_bias ? (long)(blockIdx.x - nb) * 32 + e : i;
+    const long lim = is_bias ? Cout : n;
+    const float2* src = is_bias ? slab_b : slab_w;
     float sr = 0.f, si = 0.f;
-    for (int s = 0; s < n_slabs; ++s) { const float2 v = slab_w[(long)s * n + i]; sr += v.x; si += v.y; }
-    const int co = (int)(i % Cout);
-    const int ci = (int)((i / Cout) % Cin);
-    const int tap = (int)(i / ((long)Cout * Cin));
+    if (j < lim)
+        for (int s = sg; s < n_slabs; s += 8) { const float2 v = src[(long)s * lim + j]; sr += v.x; si += v.y; }
+    red[threadIdx.x] = make_float2(sr, si);
+    __syncthreads();
+    if (sg != 0 || j >= lim) return;
+#pragma unroll
+    for (int g = 1; g < 8; ++g) { const float2 v = red[g * 32 + e]; sr += v.x; si += v.y; }
+    if (is_bias) {
+        gb_r[j] = sr + si;          // bias = (b_r - b_i) + j (b_r + b_i)
+        gb_i[j] = si - sr;
+        return;
+    }
+    const int co = (int)(j % Cout);
+    const int ci = (int)((j / Cout) % Cin);
+    const int tap = (int)(j / ((long)Cout * Cin));
     const int dy = tap / kw, dx = tap % kw;
     long dst;
     if (transposed) dst = (((long)ci * Cout + co) * kh + (kh - 1 - dy)) * kw + (kw - 1 - dx);
     else            dst = (((long)co * Cin + ci) * kh + dy) * kw + dx;
     gw_r[dst] = sr;
     gw_i[dst] = si;
+}
+
+int launch_wgrad_reduce(const float2* slab_w, const float2* slab_b, int n_slabs, float* gw_r, float* gw_i, float* gb_r,
+                        float* gb_i, int Cout, int Cin, int kh, int kw, int transposed, hipStream_t s) {
+    const long n = (long)kh * kw * Cin * Cout;
+    const long nb = (n + 31) / 32, nbb = gb_r ? (Cout + 31) / 32 : 0;
+    hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3((unsigned)(nb + nbb)), dim3(256), 0, s, slab_w, slab_b, n_slabs,
+                       gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
 }
 
 // ---- packers ------------------------------------------------------------------------------------
@@ -420,7 +443,12 @@ extern "C" long dcs_cconv2d_bwd_weight_workspace_bytes(int B, int Hin, int Win, 
     ConvArgs a = fwd_args(nullptr, nullptr, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
     if (!conv_geometry(a)) return -1;
     long wsz;
-    const int ns = wgrad_slabs(a, &wsz);
+    int ns = wgrad_slabs(a, &wsz);
+    if (dcs_conv_wgrad_mfma_ok(C1 + C2, Cout, kh, kw, C1)) {
+        int th, tw;
+        const int nm = dcs_conv_wgrad_mfma_slabs(a, &th, &tw);
+        if (nm > ns) ns = nm;
+    }
     return (long)ns * (wsz + Cout) * (long)sizeof(float2);
 }
 
@@ -432,6 +460,20 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     if ((gb_r == nullptr) != (gb_i == nullptr)) return DCS_ERR_BADARG;
     if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t)) return DCS_ERR_BADARG;
     if (kh * kw > 4 * WG_TAPS) return DCS_ERR_BADARG;
+    if (dcs_conv_wgrad_mfma_ok(C1 + C2, Cout, kh, kw, C1)) {          // MFMA GEMM over the pixel axis
+        ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+        if (a.Hout <= 0 || a.Wout <= 0) return DCS_ERR_BADARG;
+        int th, tw;
+        const int ns = dcs_conv_wgrad_mfma_slabs(a, &th, &tw);
+        const long wsz = (long)kh * kw * (C1 + C2) * Cout;
+        if (workspace_bytes < (long)ns * (wsz + Cout) * (long)sizeof(float2)) return DCS_ERR_WORKSPACE;
+        float2* slab_w = (float2*)workspace;
+        float2* slab_b = slab_w + (long)ns * wsz;
+        hipStream_t s = dcs_stream(stream);
+        const int rc = dcs_conv_wgrad_mfma_launch(a, gy, slab_w, (float*)slab_b, ns, s);
+        if (rc != DCS_OK) return rc;
+        return launch_wgrad_reduce(slab_w, slab_b, ns, gw_r, gw_i, gb_r, gb_i, Cout, C1 + C2, kh, kw, transposed, s);
+    }
     WgradArgs w{};
     w.c = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
     if (!conv_geometry(w.c)) return DCS_ERR_BADARG;
@@ -456,11 +498,7 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     if (grid.y > 65535) return DCS_ERR_BADARG;
     hipLaunchKernelGGL(cconv_wgrad_kernel, grid, dim3(TH * TW), lds, s, w);
     DCS_CHECK_LAUNCH();
-    long n = wsz < Cout ? Cout : wsz;
-    hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, s, w.slab_w, w.slab_b,
-                       w.n_slabs, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed);
-    DCS_CHECK_LAUNCH();
-    return DCS_OK;
+    return launch_wgrad_reduce(w.slab_w, w.slab_b, w.n_slabs, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed, s);
 }
 
 extern "C" int dcs_upsample_cat_bwd(const float* gxv, float* gx1, float* gx2, int B, int Hin, int Win, int C1, int C2,
