@@ -118,15 +118,18 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ x, const double* _
                                     float* __restrict__ running_mean, float* __restrict__ running_covar,
                                     float* __restrict__ stats_out, float* __restrict__ coef_out,
                                     long P, int C, float eps, float momentum, int use_batch_stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one wavefront per channel: lanes stride over the partial slabs, fp64 butterfly, lane 0 finishes
+    const int c = blockIdx.x, lane = threadIdx.x;
     float mr, mi, Crr, Cii, Cri;
     if (use_batch_stats) {
         double S[5] = {0, 0, 0, 0, 0};
-        for (int b = 0; b < nblocks; ++b) {
+        for (int b = lane; b < nblocks; b += 64) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) S[i] += part[((long)b * C + c) * 5 + i];
         }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) S[i] = dcs_wave_sum_d(S[i]);
+        if (lane != 0) return;
         const double n = (double)P;
         const double kr = (double)x[2 * c], ki = (double)x[2 * c + 1];   // pivot = pixel 0
         const double dr = S[0] / n, di = S[1] / n;
@@ -145,6 +148,7 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ x, const double* _
             running_covar[3 * c + 2] = f * Cri * unb + (1.f - f) * running_covar[3 * c + 2];
         }
     } else {
+        if (lane != 0) return;
         mr = running_mean[2 * c];
         mi = running_mean[2 * c + 1];
         Crr = running_covar[3 * c + 0] + eps;
@@ -264,7 +268,7 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
                            g.vec_per_row, g.rows_per_iter);
         DCS_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(cbn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, x, (const double*)workspace,
+    hipLaunchKernelGGL(cbn_finalize_kernel, dim3(C), dim3(64), 0, s, x, (const double*)workspace,
                        g.nblocks, weight, bias, running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum,
                        use_batch_stats);
     DCS_CHECK_LAUNCH();

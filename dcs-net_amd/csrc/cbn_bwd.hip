@@ -130,13 +130,16 @@ __global__ void cbn_bwd_finalize_kernel(const double* __restrict__ part, int nbl
                                         const float* __restrict__ coef, float* __restrict__ g_weight,
                                         float* __restrict__ g_bias, float* __restrict__ bcoef, long P, int C,
                                         int use_batch_stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one wavefront per channel: lanes stride over the partial slabs, fp64 butterfly, lane 0 finishes
+    const int c = blockIdx.x, lane = threadIdx.x;
     double S[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = lane; b < nblocks; b += 64) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) S[i] += part[((long)b * C + c) * 6 + i];
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S[i] = dcs_wave_sum_d(S[i]);
+    if (lane != 0) return;
     const double sgr = S[0], sgi = S[1], N00 = S[2], N01 = S[3], N10 = S[4], N11 = S[5];
     const float* st = stats + 8 * c;
     const double mr = st[0], mi = st[1], Rrr = st[2], Rii = st[3], Rri = st[4], Crr = st[5], Cii = st[6], Cri = st[7];
@@ -269,7 +272,7 @@ extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const
     do {                                                                                                           \
         hipLaunchKernelGGL((cbn_bwd_reduce_kernel<A, D>), dim3(g.nblocks), dim3(kThreads), 0, s, x, g_out, coef,    \
                            stats, part, P, C, g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed);             \
-        hipLaunchKernelGGL(cbn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const double*)part,      \
+        hipLaunchKernelGGL(cbn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part,      \
                            g.nblocks, weight, stats, coef, g_weight, g_bias, bcoef, P, C, use_batch_stats);        \
         hipLaunchKernelGGL((cbn_bwd_apply_kernel<A, D>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef,    \
                            stats, (const float*)bcoef, P, C, g.vec_per_row, g.rows_per_iter, drop_p,               \

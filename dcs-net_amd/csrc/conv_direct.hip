@@ -93,37 +93,39 @@ struct WgradArgs {
     ConvArgs c;                      // forward geometry (y/wp/bias unused)
 };
 
-// grid: (n_slabs, ci_chunks * co_chunks).  Thread = (ci_l, co_l) pair x tap group.
+// grid: (n_slabs, ci_chunks * co_chunks).  The (tap, ci, co) outputs of the workgroup's chunk pair are
+// flattened over the 256 threads (<= WG_TAPS each), so the small-channel layers this kernel serves
+// (enc0: 49x1x8, dec6: 9x16x1, the 7x7 2->1 attention convs: 49x2x1) keep most lanes busy.
 __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const ConvArgs& a = w.c;
     float2* tile = lds;                                   // [CHUNK][plane]
     float2* gt = lds + CHUNK * a.plane;                   // [TH*TW][WG_CO]
     const int t = threadIdx.x;
-    const int pair = t & 63, tg = t >> 6;
-    const int ci_l = pair >> 3, co_l = pair & 7;
     const int ci0 = (blockIdx.y / w.n_co_chunks) * CHUNK, co0 = (blockIdx.y % w.n_co_chunks) * WG_CO;
     const int Cin = a.C1 + a.C2;
     const int ntaps = a.kh * a.kw;
     const int tiles_per_img = a.tiles_w * a.tiles_h;
+    const int nc = min(CHUNK, Cin - ci0), nco = min(WG_CO, a.Cout - co0);
+    const int per_tap = nc * nco, n_out = ntaps * per_tap;
 
     float accr[WG_TAPS], acci[WG_TAPS];
-#pragma unroll
-    for (int i = 0; i < WG_TAPS; ++i) { accr[i] = 0.f; acci[i] = 0.f; }
-    float br = 0.f, bi = 0.f;
-    int toff[WG_TAPS];                                    // LDS offset of each of my taps
+    int xoff[WG_TAPS], goff[WG_TAPS];
 #pragma unroll
     for (int i = 0; i < WG_TAPS; ++i) {
-        const int tap = tg + 4 * i;
-        toff[i] = tap < ntaps ? (tap / a.kw) * a.colsp + (tap % a.kw) : 0;
+        accr[i] = 0.f; acci[i] = 0.f;
+        const int o = t + TH * TW * i;
+        const int tap = o < n_out ? o / per_tap : 0, r = o < n_out ? o % per_tap : 0;
+        xoff[i] = (r / nco) * a.plane + (tap / a.kw) * a.colsp + (tap % a.kw);
+        goff[i] = r % nco;
     }
+    float br = 0.f, bi = 0.f;
 
     for (int tl = blockIdx.x; tl < w.total_tiles; tl += w.n_slabs) {
         const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
         const int oy0 = (tile_id / a.tiles_w) * TH, ox0 = (tile_id % a.tiles_w) * TW;
         const int vy0 = oy0 * a.sf - a.pad_f, vx0 = ox0 * a.st - a.pad_t;
         __syncthreads();
-        const int nc = min(CHUNK, Cin - ci0);
         const int total = a.rows * a.cols * nc;
         for (int idx = t; idx < total; idx += TH * TW) {
             const int ci = idx % nc, px = idx / nc;
@@ -139,21 +141,18 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
             gt[p * WG_CO + co] = v;
         }
         __syncthreads();
-        if (ci_l < nc) {
-            const float2* pl = tile + ci_l * a.plane;
-            for (int p = 0; p < TH * TW; ++p) {
-                const float2 g = gt[p * WG_CO + co_l];
-                const float2* xp = pl + ((p / TW) * a.sf) * a.colsp + (p % TW) * a.st;
+        for (int p = 0; p < TH * TW; ++p) {
+            const int base = ((p / TW) * a.sf) * a.colsp + (p % TW) * a.st;
 #pragma unroll
-                for (int i = 0; i < WG_TAPS; ++i) {
-                    if (tg + 4 * i < ntaps) {
-                        const float2 xv = xp[toff[i]];
-                        // g * conj(x)
-                        accr[i] = fmaf(g.x, xv.x, accr[i]);
-                        accr[i] = fmaf(g.y, xv.y, accr[i]);
-                        acci[i] = fmaf(g.y, xv.x, acci[i]);
-                        acci[i] = fmaf(-g.x, xv.y, acci[i]);
-                    }
+            for (int i = 0; i < WG_TAPS; ++i) {
+                if (t + TH * TW * i < n_out) {
+                    const float2 g = gt[p * WG_CO + goff[i]];
+                    const float2 xv = tile[xoff[i] + base];
+                    // g * conj(x)
+                    accr[i] = fmaf(g.x, xv.x, accr[i]);
+                    accr[i] = fmaf(g.y, xv.y, accr[i]);
+                    acci[i] = fmaf(g.y, xv.x, acci[i]);
+                    acci[i] = fmaf(-g.x, xv.y, acci[i]);
                 }
             }
         }
@@ -165,13 +164,13 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
         }
     }
     const long wsz = (long)ntaps * Cin * a.Cout;
-    if (ci_l < min(CHUNK, Cin - ci0) && co0 + co_l < a.Cout) {
 #pragma unroll
-        for (int i = 0; i < WG_TAPS; ++i) {
-            const int tap = tg + 4 * i;
-            if (tap < ntaps)
-                w.slab_w[(long)blockIdx.x * wsz + ((long)tap * Cin + ci0 + ci_l) * a.Cout + co0 + co_l] =
-                    make_float2(accr[i], acci[i]);
+    for (int i = 0; i < WG_TAPS; ++i) {
+        const int o = t + TH * TW * i;
+        if (o < n_out) {
+            const int tap = o / per_tap, r = o % per_tap;
+            w.slab_w[(long)blockIdx.x * wsz + ((long)tap * Cin + ci0 + r / nco) * a.Cout + co0 + r % nco] =
+                make_float2(accr[i], acci[i]);
         }
     }
     if (ci0 == 0 && t < WG_CO && co0 + t < a.Cout) w.slab_b[(long)blockIdx.x * a.Cout + co0 + t] = make_float2(br, bi);

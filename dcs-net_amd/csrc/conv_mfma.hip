@@ -201,7 +201,9 @@ int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream) {
     m.c.tiles_h = (a.Hout + m.TH - 1) / m.TH;
     m.c.rows = (m.TH - 1) * a.sf + a.kh;
     m.c.cols = (m.TW - 1) * a.st + a.kw;
-    if (m.NT % 4 == 0) return launch<2, 2, 2>(m, stream);      // 128 x 128
+    // 128x128 tiles unless that leaves most of the 256 CUs idle (deep layers at small batch)
+    const long blocks128 = (long)m.c.tiles_w * m.c.tiles_h * a.B * (m.NT / 4);
+    if (m.NT % 4 == 0 && blocks128 >= 200) return launch<2, 2, 2>(m, stream);      // 128 x 128
     if (m.NT % 2 == 0) return launch<2, 2, 1>(m, stream);      // 128 x 64
     return launch<1, 1, 1>(m, stream);                         // 128 x 32
 }

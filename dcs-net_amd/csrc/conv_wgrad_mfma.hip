@@ -76,18 +76,28 @@ __global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
             *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v;
         }
         __syncthreads();
+        // gY fragments come from L2 with ~1-2 us latency and this kernel runs one wave per SIMD:
+        // keep the next k-step's loads in flight under the current step's MFMAs
+        float afn[MT];
+        auto load_g = [&](int ks, float* dst) {
+            const int p = ks * 4 + lk;
+            const int oy = oy0 + (p >> w.twshift), ox = ox0 + (p & (w.TW - 1));
+            const bool inb = oy < a.Hout && ox < a.Wout;
+            const float* gp = w.gy + (((long)b * a.Hout + (inb ? oy : 0)) * a.Wout + (inb ? ox : 0)) * N1;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) dst[i] = (inb && colok[i]) ? gp[gcol[i]] : 0.f;
+        };
+        load_g(0, afn);
         for (int ks = 0; ks < BMP / 4; ++ks) {
             const int p = ks * 4 + lk;                                 // this lane's pixel of the k-step
             const int py = p >> w.twshift, pxx = p & (w.TW - 1);
-            const int oy = oy0 + py, ox = ox0 + pxx;
-            const bool inb = oy < a.Hout && ox < a.Wout;
             float af[MT];
-            const float* gp = w.gy + (((long)b * a.Hout + oy) * a.Wout + ox) * N1;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                af[i] = (inb && colok[i]) ? gp[gcol[i]] : 0.f;
+                af[i] = afn[i];
                 bsum[i] += af[i];
             }
+            if (ks + 1 < BMP / 4) load_g(ks + 1, afn);
             const float* xp = patch + ((py * a.sf) * a.cols + pxx * a.st) * PIX + li;
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp) {
@@ -162,7 +172,7 @@ int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW) {
     else { *TH = 2; *TW = 64; }
     const long tiles = (long)((a.Wout + *TW - 1) / *TW) * ((a.Hout + *TH - 1) / *TH) * a.B;
     const long wsz = (long)a.kh * a.kw * (a.C1 + a.C2) * a.Cout;
-    long cap = (32L << 20) / (wsz * (long)sizeof(float2));
+    long cap = (96L << 20) / (wsz * (long)sizeof(float2));
     if (cap < 1) cap = 1;
     if (cap > 1024) cap = 1024;
     return (int)(tiles < cap ? tiles : cap);
