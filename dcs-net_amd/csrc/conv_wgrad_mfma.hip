@@ -27,15 +27,20 @@ struct WArgs {
     int n_slabs, total_tiles, co_blocks, TH, TW, twshift;
 };
 
-template <int KS, int MT>
+// MT row tiles (8 output channels each) per wave; WS waves split the tile's PIXELS (k-steps) and
+// 4/WS waves split the output channels, so layers with few output channels still fill all four
+// SIMDs: the pixel partials are combined through LDS once, after the last tile.
+template <int KS, int MT, int WS>
 __global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
     constexpr int TAPS = KS * KS;
+    constexpr int WCO = 4 / WS;
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     const conv::Args& a = w.c;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int ci0 = (blockIdx.y / w.co_blocks) * CHUNK;
-    const int co0 = (blockIdx.y % w.co_blocks) * (4 * MT * 8) + wave * (MT * 8);   // first output channel of this wave
+    const int part = wave % WS;                                       // which share of the pixels
+    const int co0 = (blockIdx.y % w.co_blocks) * (WCO * MT * 8) + (wave / WS) * (MT * 8);   // first output channel
     const int N1 = 2 * a.Cout;                                        // floats per gY pixel
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int npix = a.rows * a.cols;
@@ -87,8 +92,8 @@ __global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) dst[i] = (inb && colok[i]) ? gp[gcol[i]] : 0.f;
         };
-        load_g(0, afn);
-        for (int ks = 0; ks < BMP / 4; ++ks) {
+        load_g(part, afn);
+        for (int ks = part; ks < BMP / 4; ks += WS) {
             const int p = ks * 4 + lk;                                 // this lane's pixel of the k-step
             const int py = p >> w.twshift, pxx = p & (w.TW - 1);
             float af[MT];
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
                 af[i] = afn[i];
                 bsum[i] += af[i];
             }
-            if (ks + 1 < BMP / 4) load_g(ks + 1, afn);
+            if (ks + WS < BMP / 4) load_g(ks + WS, afn);
             const float* xp = patch + ((py * a.sf) * a.cols + pxx * a.st) * PIX + li;
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp) {
@@ -105,6 +110,37 @@ __global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
                     acc[i][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][tp], 0, 0, 0);
+            }
+        }
+    }
+
+    if (WS > 1) {                      // combine the pixel shares: waves with part > 0 hand over through LDS
+        __syncthreads();
+        float* red = patch;            // reused: [(WS-1) * WCO][MT*TAPS*4 + MT][64]
+        constexpr int PER = MT * TAPS * 4 + MT;
+        if (part > 0) {
+            float* dst = red + ((long)((part - 1) * WCO + wave / WS) * PER) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((i * TAPS + tp) * 4 + r) * 64] = acc[i][tp][r];
+                dst[(MT * TAPS * 4 + i) * 64] = bsum[i];
+            }
+        }
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int q = 1; q < WS; ++q) {
+            const float* src = red + ((long)((q - 1) * WCO + wave / WS) * PER) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][tp][r] += src[((i * TAPS + tp) * 4 + r) * 64];
+                bsum[i] += src[(MT * TAPS * 4 + i) * 64];
             }
         }
     }
@@ -141,16 +177,18 @@ __global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
     }
 }
 
-template <int KS, int MT>
+template <int KS, int MT, int WS>
 int launch(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
-    const size_t lds = (size_t)a.rows * a.cols * PIX * sizeof(float);
+    size_t lds = (size_t)a.rows * a.cols * PIX * sizeof(float);
+    const size_t red = (size_t)(WS - 1) * (4 / WS) * (MT * KS * KS * 4 + MT) * 64 * sizeof(float);
+    if (red > lds) lds = red;
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
-    auto fn = cconv_wgrad_mfma_kernel<KS, MT>;
+    auto fn = cconv_wgrad_mfma_kernel<KS, MT, WS>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DCS_ERR_LAUNCH;
-    const int co_per_block = 4 * MT * 8;
+    const int co_per_block = (4 / WS) * MT * 8;
     w.co_blocks = (a.Cout + co_per_block - 1) / co_per_block;
     dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks);
     if (grid.y > 65535) return DCS_ERR_BADARG;
@@ -194,11 +232,30 @@ int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, f
     w.c.cols = (TW - 1) * a.st + a.kw;
     w.total_tiles = w.c.tiles_w * w.c.tiles_h * a.B;
     const int Cin = a.C1 + a.C2;
+    // pick (MT, WS) so that the 4 waves cover min(Cout, 128) output channels without idle lanes
+    const int co = a.Cout;
     switch (a.kh) {
-        case 1: return launch<1, 4>(w, Cin, stream);
-        case 3: return launch<3, 4>(w, Cin, stream);
-        case 5: return launch<5, 2>(w, Cin, stream);
-        case 7: return launch<7, 1>(w, Cin, stream);
+        case 1:
+            if (co >= 128) return launch<1, 4, 1>(w, Cin, stream);
+            if (co >= 64) return launch<1, 2, 1>(w, Cin, stream);
+            if (co >= 32) return launch<1, 1, 1>(w, Cin, stream);
+            if (co >= 16) return launch<1, 1, 2>(w, Cin, stream);
+            return launch<1, 1, 4>(w, Cin, stream);
+        case 3:
+            if (co >= 128) return launch<3, 4, 1>(w, Cin, stream);
+            if (co >= 64) return launch<3, 2, 1>(w, Cin, stream);
+            if (co >= 32) return launch<3, 1, 1>(w, Cin, stream);
+            if (co >= 16) return launch<3, 1, 2>(w, Cin, stream);
+            return launch<3, 1, 4>(w, Cin, stream);
+        case 5:
+            if (co >= 64) return launch<5, 2, 1>(w, Cin, stream);
+            if (co >= 32) return launch<5, 1, 1>(w, Cin, stream);
+            if (co >= 16) return launch<5, 1, 2>(w, Cin, stream);
+            return launch<5, 1, 4>(w, Cin, stream);
+        case 7:
+            if (co >= 32) return launch<7, 1, 1>(w, Cin, stream);
+            if (co >= 16) return launch<7, 1, 2>(w, Cin, stream);
+            return launch<7, 1, 4>(w, Cin, stream);
         default: return DCS_ERR_BADARG;
     }
 }
