@@ -76,19 +76,34 @@ class ConvTimer:
         return ms, len(self.events)
 
 
+def host_cores():
+    """Cores this process may actually use: the scheduler affinity / cgroup share, not the machine's
+    core count (a GPU box exposes hundreds of cores but grants ~16 per GPU; asking torch for all of them
+    oversubscribes and stalls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(T, iters=2):
     from oracle.cnet_oracle import C_NETWORK_Oracle
     from oracle.nf_oracle import mask_apply_subtract
     from oracle.seeded_state import fill_state, seeded_input
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(host_cores())
     net = fill_state(C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), 0).eval()
     B = 1
     x = seeded_input(B, 256, T, seed=0, scale=0.1)
+    print(f'[bench] cpu baseline: oracle forward on {torch.get_num_threads()} threads ...', file=sys.stderr, flush=True)
     with torch.no_grad():
         t0 = time.perf_counter()
         mask_apply_subtract(x, net(x))
         first = time.perf_counter() - t0
+        print(f'[bench] cpu baseline: first pass {first:.1f} s', file=sys.stderr, flush=True)
         n = max(1, min(iters, int(20.0 / max(first, 1e-3))))
         t0 = time.perf_counter()
         for _ in range(n):
@@ -103,10 +118,10 @@ def cpu_baseline_train(B, T):
     from oracle.cnet_oracle import C_NETWORK_Oracle
     from oracle.nf_oracle import dcs_train_losses
     from oracle.seeded_state import fill_state, seeded_input
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     net = fill_state(C_NETWORK_Oracle(), 0).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, eps=1e-6, weight_decay=1e-4, amsgrad=True)
-    Bs = min(B, 4)
+    Bs = min(B, 2)
     clean, noise = seeded_input(Bs, 256, T, 1, 0.1), seeded_input(Bs, 256, T, 2, 0.05)
     noisy = clean + noise
 
@@ -117,9 +132,11 @@ def cpu_baseline_train(B, T):
         torch.nn.utils.clip_grad_norm_(net.parameters(), 100.0)
         opt.step()
 
+    print(f'[bench] cpu baseline: oracle train step on {torch.get_num_threads()} threads ...', file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     one()
     first = time.perf_counter() - t0
+    print(f'[bench] cpu baseline: first step {first:.1f} s', file=sys.stderr, flush=True)
     n = max(1, min(3, int(20.0 / max(first, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(n):
