@@ -154,70 +154,77 @@ __global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(const float* __rest
     }
 }
 
-// One workgroup.  scratch: float2 go[B][C], gh[B][Ch]
-__global__ __launch_bounds__(kThreads) void ca_bwd_kernel(const double* __restrict__ part, int nchunks,
-                                                           const float2* __restrict__ ca,
-                                                           const float2* __restrict__ pooled,
-                                                           const float2* __restrict__ hidden,
-                                                           const float2* __restrict__ w1, const float2* __restrict__ w2,
-                                                           float2* __restrict__ go, float2* __restrict__ gh,
-                                                           float2* __restrict__ gpooled, float* __restrict__ g_fc0_r,
-                                                           float* __restrict__ g_fc0_i, float* __restrict__ g_fc2_r,
-                                                           float* __restrict__ g_fc2_i, int B, int C, int Ch) {
-    const int t = threadIdx.x;
-    for (int i = t; i < B * C; i += kThreads) {               // g_o = 2 sigmoid'(.) g_ca
-        const int b = i / C, c = i % C;
+// Per-sample half (grid = B): slab sum -> g_o = 2 sigmoid'(.) g_ca ; g_h = relu'(h) (.) W2^H g_o ;
+// g_pooled = W1^H g_h.  scratch: float2 go[B][C], gh[B][Ch], gpooled[B][C]
+__global__ __launch_bounds__(kThreads) void ca_bwd_sample_kernel(const double* __restrict__ part, int nchunks,
+                                                                  const float2* __restrict__ ca,
+                                                                  const float2* __restrict__ hidden,
+                                                                  const float2* __restrict__ w1,
+                                                                  const float2* __restrict__ w2, float2* __restrict__ go,
+                                                                  float2* __restrict__ gh, float2* __restrict__ gpooled,
+                                                                  int C, int Ch) {
+    __shared__ float2 go_s[128];
+    __shared__ float2 gh_s[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int c = t; c < C; c += kThreads) {
         double sr = 0, si = 0;
         for (int k = 0; k < nchunks; ++k) {
             const double* p = part + (((long)b * nchunks + k) * C + c) * 2;
             sr += p[0]; si += p[1];
         }
-        const float2 s = ca[i];
-        go[i] = make_float2(2.f * (float)sr * s.x * (1.f - s.x), 2.f * (float)si * s.y * (1.f - s.y));
+        const float2 s = ca[(long)b * C + c];
+        const float2 g = make_float2(2.f * (float)sr * s.x * (1.f - s.x), 2.f * (float)si * s.y * (1.f - s.y));
+        go_s[c] = g;
+        go[(long)b * C + c] = g;
     }
     __syncthreads();
-    for (int i = t; i < B * Ch; i += kThreads) {              // g_h = relu'(h) (.) sum_c conj(w2[h][c]) g_o
-        const int b = i / Ch, h = i % Ch;
+    for (int h = t; h < Ch; h += kThreads) {
         float ar = 0.f, ai = 0.f;
         for (int c = 0; c < C; ++c) {
-            const float2 w = w2[h * C + c], g = go[b * C + c];
+            const float2 w = w2[h * C + c], g = go_s[c];
             ar += w.x * g.x + w.y * g.y; ai += w.x * g.y - w.y * g.x;
         }
-        const float2 hv = hidden[i];
-        gh[i] = make_float2(hv.x > 0.f ? ar : 0.f, hv.y > 0.f ? ai : 0.f);
-    }
-    for (int i = t; i < Ch * C; i += kThreads) {              // g_w2[h][c] = sum_b g_o conj(relu(h))
-        const int h = i / C, c = i % C;
-        float ar = 0.f, ai = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float2 g = go[b * C + c];
-            float2 hv = hidden[b * Ch + h];
-            hv.x = hv.x > 0.f ? hv.x : 0.f; hv.y = hv.y > 0.f ? hv.y : 0.f;
-            ar += g.x * hv.x + g.y * hv.y; ai += g.y * hv.x - g.x * hv.y;
-        }
-        g_fc2_r[c * Ch + h] = ar;                             // fc.2 weight [C][Ch][1][1]
-        g_fc2_i[c * Ch + h] = ai;
+        const float2 hv = hidden[(long)b * Ch + h];
+        const float2 g = make_float2(hv.x > 0.f ? ar : 0.f, hv.y > 0.f ? ai : 0.f);
+        gh_s[h] = g;
+        gh[(long)b * Ch + h] = g;
     }
     __syncthreads();
-    for (int i = t; i < C * Ch; i += kThreads) {              // g_w1[c][h] = sum_b g_h conj(pooled)
-        const int c = i / Ch, h = i % Ch;
-        float ar = 0.f, ai = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float2 g = gh[b * Ch + h], p = pooled[b * C + c];
-            ar += g.x * p.x + g.y * p.y; ai += g.y * p.x - g.x * p.y;
-        }
-        g_fc0_r[h * C + c] = ar;                              // fc.0 weight [Ch][C][1][1]
-        g_fc0_i[h * C + c] = ai;
-    }
-    for (int i = t; i < B * C; i += kThreads) {               // g_pooled = sum_h conj(w1[c][h]) g_h
-        const int b = i / C, c = i % C;
+    for (int c = t; c < C; c += kThreads) {
         float ar = 0.f, ai = 0.f;
         for (int h = 0; h < Ch; ++h) {
-            const float2 w = w1[c * Ch + h], g = gh[b * Ch + h];
+            const float2 w = w1[c * Ch + h], g = gh_s[h];
             ar += w.x * g.x + w.y * g.y; ai += w.x * g.y - w.y * g.x;
         }
-        gpooled[i] = make_float2(ar, ai);
+        gpooled[(long)b * C + c] = make_float2(ar, ai);
     }
+}
+
+// Weight half (one thread per weight element, sums over the batch):
+//   g_w2[h][c] = sum_b g_o conj(relu(h)) ;  g_w1[c][h] = sum_b g_h conj(pooled)
+__global__ __launch_bounds__(kThreads) void ca_bwd_weight_kernel(const float2* __restrict__ go,
+                                                                  const float2* __restrict__ gh,
+                                                                  const float2* __restrict__ pooled,
+                                                                  const float2* __restrict__ hidden,
+                                                                  float* __restrict__ g_fc0_r, float* __restrict__ g_fc0_i,
+                                                                  float* __restrict__ g_fc2_r, float* __restrict__ g_fc2_i,
+                                                                  int B, int C, int Ch) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= C * Ch) return;
+    const int c = i / Ch, h = i % Ch;
+    float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float2 g = go[(long)b * C + c];
+        float2 hv = hidden[(long)b * Ch + h];
+        hv.x = hv.x > 0.f ? hv.x : 0.f; hv.y = hv.y > 0.f ? hv.y : 0.f;
+        ar += g.x * hv.x + g.y * hv.y; ai += g.y * hv.x - g.x * hv.y;
+        const float2 q = gh[(long)b * Ch + h], p = pooled[(long)b * C + c];
+        br += q.x * p.x + q.y * p.y; bi += q.y * p.x - q.x * p.y;
+    }
+    g_fc2_r[c * Ch + h] = ar;                                 // fc.2 weight [C][Ch][1][1]
+    g_fc2_i[c * Ch + h] = ai;
+    g_fc0_r[h * C + c] = br;                                  // fc.0 weight [Ch][C][1][1]
+    g_fc0_i[h * C + c] = bi;
 }
 
 __global__ __launch_bounds__(kThreads) void att_bwd_pool_kernel(float* __restrict__ gx, const float* __restrict__ gpooled,
@@ -264,7 +271,7 @@ extern "C" int dcs_attention_bwd_sa(const float* x, const float* g_out, const fl
 extern "C" long dcs_attention_bwd_workspace_bytes(int B, long HW, int C, int Ch) {
     int G;
     if (B <= 0 || HW <= 0 || Ch <= 0 || !att_geom(C, &G)) return -1;
-    return (long)B * chunks_for(HW, G) * C * 2 * (long)sizeof(double) + ((long)B * C + (long)B * Ch) * 8 + 64;
+    return (long)B * chunks_for(HW, G) * C * 2 * (long)sizeof(double) + (2L * B * C + (long)B * Ch) * 8 + 64;
 }
 
 extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, const float* sa,
@@ -276,15 +283,15 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
     if (!x || !g_out || !ca || !sa || !g_sp || !pooled || !hidden || !w1 || !w2 || !g_x || !g_fc0_r || !g_fc0_i ||
         !g_fc2_r || !g_fc2_i || !workspace)
         return DCS_ERR_BADARG;
-    if (B <= 0 || B > 65535 || HW <= 0 || Ch <= 0 || Ch > 64 || !att_geom(C, &G)) return DCS_ERR_BADARG;
+    if (B <= 0 || B > 65535 || HW <= 0 || Ch <= 0 || Ch > 64 || C > 128 || !att_geom(C, &G)) return DCS_ERR_BADARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
     const int nch = chunks_for(HW, G);
     const long part_bytes = (long)B * nch * C * 2 * (long)sizeof(double);
-    if (workspace_bytes < part_bytes + ((long)B * C + (long)B * Ch) * 8 + 64) return DCS_ERR_WORKSPACE;
+    if (workspace_bytes < part_bytes + (2L * B * C + (long)B * Ch) * 8 + 64) return DCS_ERR_WORKSPACE;
     double* part = (double*)workspace;
     float2* go = (float2*)((char*)workspace + part_bytes);
     float2* gh = go + (long)B * C;
-    float2* gpooled = go;   // ca_bwd's last phase reads gh / w1 / pooled only, so it may overwrite go
+    float2* gpooled = gh + (long)B * Ch;
     hipStream_t s = dcs_stream(stream);
     dim3 grid(nch, B);
     if (drop_p > 0.f)
@@ -294,9 +301,13 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
         hipLaunchKernelGGL(att_bwd_x_kernel<false>, grid, dim3(kThreads), 0, s, x, g_out, ca, (const float2*)sa,
                            (const float4*)g_sp, g_x, part, HW, C, G, drop_p, (uint64_t)seed);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ca_bwd_kernel, dim3(1), dim3(kThreads), 0, s, (const double*)part, nch, (const float2*)ca,
-                       (const float2*)pooled, (const float2*)hidden, (const float2*)w1, (const float2*)w2, go, gh,
-                       gpooled, g_fc0_r, g_fc0_i, g_fc2_r, g_fc2_i, B, C, Ch);
+    hipLaunchKernelGGL(ca_bwd_sample_kernel, dim3(B), dim3(kThreads), 0, s, (const double*)part, nch,
+                       (const float2*)ca, (const float2*)hidden, (const float2*)w1, (const float2*)w2, go, gh, gpooled,
+                       C, Ch);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ca_bwd_weight_kernel, dim3((C * Ch + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
+                       (const float2*)go, (const float2*)gh, (const float2*)pooled, (const float2*)hidden, g_fc0_r,
+                       g_fc0_i, g_fc2_r, g_fc2_i, B, C, Ch);
     DCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(att_bwd_pool_kernel, dim3(stream_grid(HW, G, B), B), dim3(kThreads), 0, s, g_x,
                        (const float*)gpooled, HW, G, 1.f / (float)HW);

@@ -96,6 +96,7 @@ struct WgradArgs {
 // grid: (n_slabs, ci_chunks * co_chunks).  The (tap, ci, co) outputs of the workgroup's chunk pair are
 // flattened over the 256 threads (<= WG_TAPS each), so the small-channel layers this kernel serves
 // (enc0: 49x1x8, dec6: 9x16x1, the 7x7 2->1 attention convs: 49x2x1) keep most lanes busy.
+template <int SLOTS>
 __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const ConvArgs& a = w.c;
@@ -109,10 +110,10 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
     const int nc = min(CHUNK, Cin - ci0), nco = min(WG_CO, a.Cout - co0);
     const int per_tap = nc * nco, n_out = ntaps * per_tap;
 
-    float accr[WG_TAPS], acci[WG_TAPS];
-    int xoff[WG_TAPS], goff[WG_TAPS];
+    float accr[SLOTS], acci[SLOTS];
+    int xoff[SLOTS], goff[SLOTS];
 #pragma unroll
-    for (int i = 0; i < WG_TAPS; ++i) {
+    for (int i = 0; i < SLOTS; ++i) {
         accr[i] = 0.f; acci[i] = 0.f;
         const int o = t + TH * TW * i;
         const int tap = o < n_out ? o / per_tap : 0, r = o < n_out ? o % per_tap : 0;
@@ -141,10 +142,11 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
             gt[p * WG_CO + co] = v;
         }
         __syncthreads();
+#pragma unroll 4
         for (int p = 0; p < TH * TW; ++p) {
             const int base = ((p / TW) * a.sf) * a.colsp + (p % TW) * a.st;
 #pragma unroll
-            for (int i = 0; i < WG_TAPS; ++i) {
+            for (int i = 0; i < SLOTS; ++i) {
                 if (t + TH * TW * i < n_out) {
                     const float2 g = gt[p * WG_CO + goff[i]];
                     const float2 xv = tile[xoff[i] + base];
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
     }
     const long wsz = (long)ntaps * Cin * a.Cout;
 #pragma unroll
-    for (int i = 0; i < WG_TAPS; ++i) {
+    for (int i = 0; i < SLOTS; ++i) {
         const int o = t + TH * TW * i;
         if (o < n_out) {
             const int tap = o / per_tap, r = o % per_tap;
@@ -489,13 +491,17 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     const size_t lds = ((size_t)CHUNK * w.c.plane + (size_t)TH * TW * WG_CO) * sizeof(float2);
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
     hipStream_t s = dcs_stream(stream);
+    // outputs per thread: taps * min(Cin,8) * min(Cout,8) spread over 256 threads
+    const int n_out = kh * kw * (Cin < CHUNK ? Cin : CHUNK) * (Cout < WG_CO ? Cout : WG_CO);
+    const int slots = (n_out + TH * TW - 1) / (TH * TW);
+    auto fn = slots <= 1 ? cconv_wgrad_kernel<1> : slots <= 2 ? cconv_wgrad_kernel<2>
+            : slots <= 4 ? cconv_wgrad_kernel<4> : cconv_wgrad_kernel<WG_TAPS>;
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)cconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
+        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DCS_ERR_LAUNCH;
     dim3 grid(w.n_slabs, n_ci * w.n_co_chunks);
     if (grid.y > 65535) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(cconv_wgrad_kernel, grid, dim3(TH * TW), lds, s, w);
+    hipLaunchKernelGGL(fn, grid, dim3(TH * TW), lds, s, w);
     DCS_CHECK_LAUNCH();
     return launch_wgrad_reduce(w.slab_w, w.slab_b, w.n_slabs, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed, s);
 }
