@@ -147,6 +147,18 @@ def cpu_baseline_train(B, T):
                       f'{n} timed steps after 1 warm-up'}
 
 
+def pmc_traffic(mode, B, T):
+    """HBM bytes per step of the conv kernel family from the committed PMC passes (profiles/), or None when
+    the workload differs from the one that was profiled.  PMC counters cannot be read live from here."""
+    try:
+        d = json.load(open(os.path.join(REPO, 'profiles', 'traffic.json')))[mode]
+    except (OSError, KeyError, ValueError):
+        return None
+    if (mode == 'train' and (B, T) == (32, 256)) or (mode == 'infer' and (B, T) == (16, 2000)):
+        return d['conv_family_hbm_bytes_per_step']
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -249,7 +261,7 @@ def main():
                        'frames_per_step': B * T * world, 'parallelism': (f'dp{world} (utterance sharding, one flat-bucket gradient all-reduce)' if train
                                        else f'dp{world} (utterance sharding, no collective)')},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(args.mode, B, T),
                          'kernel': 'complex conv / convT (dcs_cconv2d_fwd' + (', _bwd_data, _bwd_weight' if train else '')
                                    + '), all launches of the timed region',
                          'launches': n_launch, 'kernel_ms_per_step': conv_ms / args.steps,
