@@ -27,10 +27,12 @@ __device__ __forceinline__ float2 gather(const Args& a, int b, int vy, int vx, i
 }
 
 // MFMA eligibility of a (Cin, Cout) pair: K groups of 4 complex input channels staged 8 at a time,
-// N = 2*Cout real columns in tiles of 32.
-inline bool mfma_ok(int Cin, int Cout) { return (Cin % 8) == 0 && ((2 * Cout) % 32) == 0; }
+// N = 2*Cout real columns in tiles of 32 (a 16-wide remainder is zero-padded).
+inline bool mfma_ok(int Cin, int Cout) { return (Cin % 8) == 0 && (Cout % 8) == 0; }
 inline long direct_floats(int Cout, int Cin, int taps) { return (long)taps * Cin * Cout * 2; }
-inline long mfma_floats(int Cout, int Cin, int taps) { return mfma_ok(Cin, Cout) ? (long)taps * Cin * Cout * 4 : 0; }
+inline long mfma_floats(int Cout, int Cin, int taps) {      // N = 2*Cout padded to whole 32-column tiles
+    return mfma_ok(Cin, Cout) ? (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 256 : 0;
+}
 
 }  // namespace conv
 

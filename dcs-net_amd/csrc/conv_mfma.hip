@@ -24,14 +24,13 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;        // output pixels per workgroup
 constexpr int CHUNK = 8;       // complex input channels staged per LDS pass (= 2 k-groups of 4)
 constexpr int PIX = 20;        // LDS floats per patch pixel: 16 + 4 pad
 
 struct MArgs {
     conv::Args c;
     const float* bm;
-    int TH, TW, N, KG, NT;     // tile shape (TH*TW = 128), N = 2*Cout, KG = Cin/4, NT = N/32
+    int TH, TW, N, KG, NT;     // tile shape (TH*TW = pixels per WG), N = 2*Cout, KG = Cin/4, NT = ceil(N/32)
 };
 
 // wave grid: WAVES_N waves along N, 4/WAVES_N along M; each wave owns WM x WN tiles of 32x32
@@ -39,8 +38,7 @@ template <int WAVES_N, int WM, int WN>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     const conv::Args& a = m.c;
-    constexpr int WAVES_M = 4 / WAVES_N;
-    static_assert(WAVES_M * WM * 32 == BM, "tile");
+    // pixels per workgroup = (4 / WAVES_N) * WM * 32 = TH * TW
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int kk = lane >> 5, li = lane & 31;
@@ -126,6 +124,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int n = (nt0 + j) * 32 + li;
+        if (n >= m.N) continue;                                        // zero-padded columns of a 16-wide N
         const float bv = biasf ? biasf[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 
 // bm[tap][kg][nt][kk][j][e]: e = 0..3 -> (ci = 4kg+2kk, re), (.., im), (ci+1, re), (ci+1, im); column n = nt*32+j
 __global__ void pack_mfma_kernel(const float2* __restrict__ wp, float4* __restrict__ bm, int Cout, int Cin, int taps) {
-    const int KG = Cin / 4, NT = (2 * Cout) / 32;
+    const int KG = Cin / 4, NT = (2 * Cout + 31) / 32;
     const long total = (long)taps * KG * NT * 64;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -153,6 +152,7 @@ __global__ void pack_mfma_kernel(const float2* __restrict__ wp, float4* __restri
     const int kg = (int)(r % KG);
     const int tap = (int)(r / KG);
     const int n = nt * 32 + j, co = n >> 1, im = n & 1;
+    if (co >= Cout) { bm[i] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
     const int ci = 4 * kg + 2 * kk;
     const float2 w0 = wp[((long)tap * Cin + ci) * Cout + co], w1 = wp[((long)tap * Cin + ci + 1) * Cout + co];
     // column (co, re): [ w_r, -w_i ] ; column (co, im): [ w_i, w_r ]
@@ -178,7 +178,7 @@ int launch(MArgs& m, hipStream_t stream) {
 
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream) {
     if (!conv::mfma_ok(Cin, Cout)) return DCS_ERR_BADARG;
-    const long total = (long)taps * (Cin / 4) * ((2 * Cout) / 32) * 64;
+    const long total = (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 64;
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(dcs_cdiv(total, 256)), dim3(256), 0, stream, (const float2*)wp_direct,
                        (float4*)bm, Cout, Cin, taps);
     DCS_CHECK_LAUNCH();
@@ -192,18 +192,33 @@ int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream) {
     MArgs m;
     m.c = a;
     m.bm = bm;
-    m.N = 2 * a.Cout; m.KG = Cin / 4; m.NT = m.N / 32;
-    // 128-pixel tile: wide and flat for the shallow deep-layer maps, 8x16 otherwise
-    if (a.Hout >= 8) { m.TH = 8; m.TW = 16; }
-    else if (a.Hout >= 4) { m.TH = 4; m.TW = 32; }
-    else { m.TH = 2; m.TW = 64; }
+    m.N = 2 * a.Cout; m.KG = Cin / 4; m.NT = (m.N + 31) / 32;
+    // candidate workgroup tiles (pixels x columns); take the largest that still yields >= 256 workgroups
+    // (one per CU), else the one with the most workgroups: deep layers at small batch have few pixels
+    struct Cand { int bm, bn; };
+    const Cand cands[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+    int best = -1; long best_blocks = -1;
+    for (int i = 0; i < 4; ++i) {
+        if (m.NT % (cands[i].bn / 32) != 0) continue;
+        int th, tw;
+        if (cands[i].bm == 128) { if (a.Hout >= 8) { th = 8; tw = 16; } else if (a.Hout >= 4) { th = 4; tw = 32; } else { th = 2; tw = 64; } }
+        else { if (a.Hout >= 4) { th = 4; tw = 16; } else { th = 2; tw = 32; } }
+        const long blocks = (long)((a.Wout + tw - 1) / tw) * ((a.Hout + th - 1) / th) * a.B * (m.NT / (cands[i].bn / 32));
+        if (blocks >= 256) { best = i; break; }
+        if (blocks > best_blocks) { best_blocks = blocks; best = i; }
+    }
+    if (best < 0) return DCS_ERR_BADARG;
+    const int bmp = cands[best].bm;
+    if (bmp == 128) { if (a.Hout >= 8) { m.TH = 8; m.TW = 16; } else if (a.Hout >= 4) { m.TH = 4; m.TW = 32; } else { m.TH = 2; m.TW = 64; } }
+    else { if (a.Hout >= 4) { m.TH = 4; m.TW = 16; } else { m.TH = 2; m.TW = 32; } }
     m.c.tiles_w = (a.Wout + m.TW - 1) / m.TW;
     m.c.tiles_h = (a.Hout + m.TH - 1) / m.TH;
     m.c.rows = (m.TH - 1) * a.sf + a.kh;
     m.c.cols = (m.TW - 1) * a.st + a.kw;
-    // 128x128 tiles unless that leaves most of the 256 CUs idle (deep layers at small batch)
-    const long blocks128 = (long)m.c.tiles_w * m.c.tiles_h * a.B * (m.NT / 4);
-    if (m.NT % 4 == 0 && blocks128 >= 200) return launch<2, 2, 2>(m, stream);      // 128 x 128
-    if (m.NT % 2 == 0) return launch<2, 2, 1>(m, stream);      // 128 x 64
-    return launch<1, 1, 1>(m, stream);                         // 128 x 32
+    switch (best) {
+        case 0: return launch<2, 2, 2>(m, stream);      // 128 x 128
+        case 1: return launch<2, 2, 1>(m, stream);      // 128 x 64
+        case 2: return launch<2, 1, 1>(m, stream);      //  64 x 64
+        default: return launch<1, 1, 1>(m, stream);     // 128 x 32
+    }
 }

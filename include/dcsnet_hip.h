@@ -58,7 +58,7 @@ const char* dcs_error_string(int code);
  * bias_out[co] = (b_r - b_i) + j (b_r + b_i)   — both real layers carry a bias
  * (SURVEY.md §8a a2); b_r/b_i may be NULL (bias=False: attention convs c_network.py:58-60,74).
  * wp: complex[kh*kw][Cin][Cout]; bias_out: complex[Cout] (always written, zeros if no bias).
- * When Cin % 8 == 0 and Cout % 16 == 0 a second panel follows in the same buffer: the 2x2
+ * When Cin % 8 == 0 and Cout % 8 == 0 a second panel follows in the same buffer: the 2x2
  * real-embedded weight in MFMA fragment order for the implicit-GEMM kernel.  Allocate
  * dcs_packed_weight_floats(Cout, Cin, kh, kw) floats for wp (same for wp_bwd with Cout/Cin swapped);
  * the conv entry points find the second panel themselves.
