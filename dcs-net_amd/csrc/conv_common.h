@@ -11,6 +11,13 @@ struct Args {
     int Hv, Wv, Hout, Wout, tiles_w, tiles_h, rows, cols, colsp, plane;
 };
 
+// One output-parity class of a decomposed convolution (conv_mfma.hip): its own sub-kernel, padding,
+// extent and weight panel; its pixel (oy, ox) lands at (oy*os + oo) of the full output.
+struct Cls {
+    int kh, kw, pad_f, pad_t, oo_f, oo_t, Hc, Wc;
+    long bm_off;              // float offset of this class's MFMA panel from the `bm` passed to the launch
+};
+
 // Element (b, vy, vx, c) of the virtual input: nearest upsample of cat(x1, x2) (c_network.py:214-216),
 // or — for data gradients — g_Y with (up_f-1, up_t-1) zeros inserted between samples.  Zero outside.
 __device__ __forceinline__ bool src_pixel(const Args& a, int b, int vy, int vx, long* sp) {
@@ -34,6 +41,21 @@ inline long mfma_floats(int Cout, int Cin, int taps) {      // N = 2*Cout padded
     return mfma_ok(Cin, Cout) ? (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 256 : 0;
 }
 
+// conv_pack.hip: derived panels (upsample fold, its data gradient, strided data gradient)
+struct Axis { int first, count, pad, n; };
+bool fold_ok(int Cin, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int up_f, int up_t);
+long fold_floats(int Cout, int Cin, int up_f, int up_t);
+int pack_fold(const float* wp, float* region, int Cout, int Cin, int up_f, int up_t, hipStream_t s);
+void fold_classes(int Cout, int Cin, int up_f, int up_t, int Hin, int Win, Cls* cls);
+long upfold_bwd_floats(int Cout, int Cin, int up_f, int up_t);
+int pack_upfold_bwd(const float* wp, float* region, int Cout, int Cin, int up_f, int up_t, hipStream_t s);
+Axis stride_axis(int k, int s, int pad, int r, int full);
+bool stride_ok(int Cin, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t);
+long stride_bwd_floats(int Cout, int Cin, int kh, int kw, int sf, int st, int pad_f, int pad_t);
+int pack_stride_bwd(const float* wp_bwd, float* region, int Cout, int Cin, int kh, int kw, int sf, int st, int pad_f,
+                    int pad_t, hipStream_t s);
+void stride_classes(int Cout, int Cin, int kh, int kw, int sf, int st, int pad_f, int pad_t, int Hv, int Wv, Cls* cls);
+
 }  // namespace conv
 
 // conv_wgrad_mfma.hip
@@ -45,3 +67,5 @@ int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, f
 // conv_mfma.hip
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);
 int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream);
+int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const conv::Cls* cls, int os_f, int os_t,
+                                 float* y2, int nsplit, hipStream_t stream);

@@ -290,6 +290,11 @@ __global__ void upsample_cat_bwd_kernel(const float2* __restrict__ gxv, float2* 
     }
 }
 
+// direct + MFMA panels of a (CoutRole, CinRole) weight
+long base_floats(int CoutRole, int CinRole, int taps) {
+    return conv::direct_floats(CoutRole, CinRole, taps) + conv::mfma_floats(CoutRole, CinRole, taps);
+}
+
 bool conv_geometry(ConvArgs& a) {
     if (a.Hout <= 0 || a.Wout <= 0) return false;
     a.tiles_w = (a.Wout + TW - 1) / TW;
@@ -359,8 +364,9 @@ int wgrad_slabs(const ConvArgs& a, long* wsz_out) {
 }  // namespace
 
 extern "C" int dcs_pack_conv_weight(const float* w_r, const float* w_i, const float* b_r, const float* b_i, float* wp,
-                                    float* bias_out, int Cout, int Cin, int kh, int kw, int transposed,
-                                    dcs_stream_t stream) {
+                                    float* bias_out, int Cout, int Cin, int kh, int kw, int transposed, int up_f,
+                                    int up_t, dcs_stream_t stream) {
+    if (up_f < 1 || up_t < 1) return DCS_ERR_BADARG;
     if (!w_r || !w_i || !wp || !bias_out || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0) return DCS_ERR_BADARG;
     if ((b_r == nullptr) != (b_i == nullptr)) return DCS_ERR_BADARG;
     long n = (long)kh * kw * Cin * Cout;
@@ -368,28 +374,52 @@ extern "C" int dcs_pack_conv_weight(const float* w_r, const float* w_i, const fl
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, dcs_stream(stream), w_r, w_i,
                        b_r, b_i, (float2*)wp, (float2*)bias_out, Cout, Cin, kh, kw, transposed);
     DCS_CHECK_LAUNCH();
-    if (conv::mfma_ok(Cin, Cout))      // second panel: MFMA fragment order (conv_mfma.hip)
-        return dcs_conv_mfma_pack(wp, wp + conv::direct_floats(Cout, Cin, kh * kw), Cout, Cin, kh * kw,
-                                  dcs_stream(stream));
+    if (conv::mfma_ok(Cin, Cout)) {    // second panel: MFMA fragment order (conv_mfma.hip)
+        const int rc = dcs_conv_mfma_pack(wp, wp + conv::direct_floats(Cout, Cin, kh * kw), Cout, Cin, kh * kw,
+                                          dcs_stream(stream));
+        if (rc != DCS_OK) return rc;
+    }
+    if (conv::fold_ok(Cin, Cout, kh, kw, 1, 1, 1, 1, up_f, up_t))   // third: per-parity folded sub-kernels (conv_pack.hip)
+        return conv::pack_fold(wp, wp + base_floats(Cout, Cin, kh * kw), Cout, Cin, up_f, up_t, dcs_stream(stream));
     return DCS_OK;
 }
 
-extern "C" long dcs_packed_weight_floats(int Cout, int Cin, int kh, int kw) {
-    if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0) return -1;
-    return conv::direct_floats(Cout, Cin, kh * kw) + conv::mfma_floats(Cout, Cin, kh * kw);
+extern "C" long dcs_packed_weight_floats(int Cout, int Cin, int kh, int kw, int up_f, int up_t) {
+    if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || up_f < 1 || up_t < 1) return -1;
+    long n = base_floats(Cout, Cin, kh * kw);
+    if (conv::fold_ok(Cin, Cout, kh, kw, 1, 1, 1, 1, up_f, up_t)) n += conv::fold_floats(Cout, Cin, up_f, up_t);
+    return n;
 }
 
-extern "C" int dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout, int Cin, int kh, int kw,
-                                        dcs_stream_t stream) {
-    if (!wp || !wp_bwd || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0) return DCS_ERR_BADARG;
+extern "C" long dcs_packed_weight_bwd_floats(int Cout, int Cin, int kh, int kw, int sf, int st, int pad_f, int pad_t,
+                                             int up_f, int up_t) {
+    if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || sf < 1 || st < 1 || up_f < 1 || up_t < 1) return -1;
+    long n = base_floats(Cin, Cout, kh * kw);
+    if (conv::fold_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) n += conv::upfold_bwd_floats(Cout, Cin, up_f, up_t);
+    else if (up_f * up_t == 1 && conv::stride_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t))
+        n += conv::stride_bwd_floats(Cout, Cin, kh, kw, sf, st, pad_f, pad_t);
+    return n;
+}
+
+extern "C" int dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout, int Cin, int kh, int kw, int sf,
+                                        int st, int pad_f, int pad_t, int up_f, int up_t, dcs_stream_t stream) {
+    if (!wp || !wp_bwd || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || sf < 1 || st < 1 || up_f < 1 || up_t < 1)
+        return DCS_ERR_BADARG;
     const long n = (long)kh * kw * Cin * Cout;
-    hipLaunchKernelGGL(pack_conv_weight_bwd_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, dcs_stream(stream),
-                       (const float2*)wp, (float2*)wp_bwd, Cout, Cin, kh * kw);
+    hipStream_t s = dcs_stream(stream);
+    hipLaunchKernelGGL(pack_conv_weight_bwd_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, s, (const float2*)wp,
+                       (float2*)wp_bwd, Cout, Cin, kh * kw);
     DCS_CHECK_LAUNCH();
     // in the data-gradient GEMM the roles swap: K runs over the forward Cout, N over the forward Cin
-    if (conv::mfma_ok(Cout, Cin))
-        return dcs_conv_mfma_pack(wp_bwd, wp_bwd + conv::direct_floats(Cin, Cout, kh * kw), Cin, Cout, kh * kw,
-                                  dcs_stream(stream));
+    if (conv::mfma_ok(Cout, Cin)) {
+        const int rc = dcs_conv_mfma_pack(wp_bwd, wp_bwd + conv::direct_floats(Cin, Cout, kh * kw), Cin, Cout, kh * kw, s);
+        if (rc != DCS_OK) return rc;
+    }
+    float* extra = wp_bwd + base_floats(Cin, Cout, kh * kw);
+    if (conv::fold_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t))
+        return conv::pack_upfold_bwd(wp, extra, Cout, Cin, up_f, up_t, s);
+    if (up_f * up_t == 1 && conv::stride_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t))
+        return conv::pack_stride_bwd(wp_bwd, extra, Cout, Cin, kh, kw, sf, st, pad_f, pad_t, s);
     return DCS_OK;
 }
 
@@ -408,6 +438,16 @@ extern "C" int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp
     if (!wp || !bias || !y) return DCS_ERR_BADARG;
     if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t)) return DCS_ERR_BADARG;
     if (act < DCS_ACT_NONE || act > DCS_ACT_SIGMOID) return DCS_ERR_BADARG;
+    if (!(C1 & 1) && conv::fold_ok(C1 + C2, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) {
+        // nearest upsample folded into per-parity sub-kernels on the SOURCE tensors (conv_pack.hip)
+        ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1, C2, 1, 1, Cout, kh, kw, 1, 1, pad_f, pad_t);
+        a.bias = (const float2*)bias; a.y = (float2*)y; a.act = act;
+        a.Hout = Hin * up_f; a.Wout = Win * up_t;
+        conv::Cls cls[4];
+        conv::fold_classes(Cout, C1 + C2, up_f, up_t, Hin, Win, cls);
+        return dcs_conv_mfma_launch_classes(a, wp + base_floats(Cout, C1 + C2, kh * kw), up_f * up_t, cls, up_f, up_t,
+                                            nullptr, 0, dcs_stream(stream));
+    }
     if (conv::mfma_ok(C1 + C2, Cout) && !(C1 & 1)) {
         ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
         a.wp = (const float2*)wp; a.bias = (const float2*)bias; a.y = (float2*)y; a.act = act;
@@ -417,23 +457,79 @@ extern "C" int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp
                               act, dcs_stream(stream));
 }
 
-extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float* gxv, int B, int Hout, int Wout,
-                                    int Cout, int Hv, int Wv, int Cin, int kh, int kw, int sf, int st, int pad_f,
-                                    int pad_t, dcs_stream_t stream) {
-    if (!gy || !wp_bwd || !gxv || B <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0 || Hv <= 0 || Wv <= 0 || Cin <= 0)
+extern "C" long dcs_cconv2d_bwd_data_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                                                     int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t) {
+    if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || up_f < 1 || up_t < 1) return -1;
+    const int Cin = C1 + C2;
+    if (up_f * up_t == 1 && C2 == 0) return 0;                                       // written straight into g_x1
+    if (!(C1 & 1) && conv::fold_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) return 0;
+    return (long)B * Hin * up_f * Win * up_t * Cin * (long)sizeof(float2);           // g_Xv of the virtual input
+}
+
+extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float* gx1, float* gx2, void* workspace,
+                                    long workspace_bytes, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                                    int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t,
+                                    dcs_stream_t stream) {
+    if (!gy || !wp_bwd || !gx1 || B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0) return DCS_ERR_BADARG;
+    if ((C2 > 0) != (gx2 != nullptr)) return DCS_ERR_BADARG;
+    if (kh < 1 || kw < 1 || sf < 1 || st < 1 || up_f < 1 || up_t < 1 || pad_f < 0 || pad_t < 0 || pad_f > kh - 1 ||
+        pad_t > kw - 1)
         return DCS_ERR_BADARG;
-    if (kh < 1 || kw < 1 || sf < 1 || st < 1 || pad_f < 0 || pad_t < 0 || pad_f > kh - 1 || pad_t > kw - 1)
-        return DCS_ERR_BADARG;
+    const int Cin = C1 + C2, taps = kh * kw;
+    const int Hv = Hin * up_f, Wv = Win * up_t;
+    const int Hout = (Hv + 2 * pad_f - kh) / sf + 1, Wout = (Wv + 2 * pad_t - kw) / st + 1;
+    if (Hout <= 0 || Wout <= 0) return DCS_ERR_BADARG;
+    hipStream_t s = dcs_stream(stream);
+    const float* extra = wp_bwd + base_floats(Cin, Cout, taps);
+
     ConvArgs a{};
-    a.x1 = (const float2*)gy; a.x2 = nullptr; a.wp = (const float2*)wp_bwd; a.bias = nullptr; a.y = (float2*)gxv;
-    a.B = B; a.Hin = Hout; a.Win = Wout; a.C1 = Cout; a.C2 = 0; a.up_f = sf; a.up_t = st; a.zero_ins = 1;
-    a.Cout = Cin; a.kh = kh; a.kw = kw; a.sf = 1; a.st = 1; a.pad_f = kh - 1 - pad_f; a.pad_t = kw - 1 - pad_t;
-    a.act = DCS_ACT_NONE;
-    a.Hv = (Hout - 1) * sf + 1; a.Wv = (Wout - 1) * st + 1;
-    a.Hout = Hv; a.Wout = Wv;                          // explicit: rows past the last tap get zeros
-    if (conv::mfma_ok(Cout, Cin))
-        return dcs_conv_mfma_launch(a, wp_bwd + conv::direct_floats(Cin, Cout, kh * kw), dcs_stream(stream));
-    return launch_direct(a, dcs_stream(stream));
+    a.x1 = (const float2*)gy; a.x2 = nullptr; a.bias = nullptr; a.y = (float2*)gx1;
+    a.B = B; a.Hin = Hout; a.Win = Wout; a.C1 = Cout; a.C2 = 0; a.Cout = Cin; a.act = DCS_ACT_NONE;
+
+    if (!(C1 & 1) && conv::fold_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) {
+        // gradient w.r.t. the SOURCE of the upsampled conv: stride-up correlation over g_Y with the effective
+        // 4-tap kernel; columns split into g_x1 | g_x2 in the epilogue (no g_Xv, no block-sum pass)
+        a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Hv = Hout; a.Wv = Wout;
+        a.kh = up_f == 2 ? 4 : 3; a.kw = up_t == 2 ? 4 : 3; a.sf = up_f; a.st = up_t; a.pad_f = 1; a.pad_t = 1;
+        a.Hout = Hin; a.Wout = Win;
+        conv::Cls c;
+        c.kh = a.kh; c.kw = a.kw; c.pad_f = 1; c.pad_t = 1; c.oo_f = 0; c.oo_t = 0; c.Hc = Hin; c.Wc = Win;
+        c.bm_off = conv::direct_floats(Cin, Cout, a.kh * a.kw);
+        return dcs_conv_mfma_launch_classes(a, extra, 1, &c, 1, 1, C2 ? gx2 : nullptr, 2 * C1, s);
+    }
+
+    float* gxv = gx1;
+    if (up_f * up_t > 1 || C2 > 0) {                        // generic: gradient of the virtual input, then fold it
+        if (!workspace || workspace_bytes < (long)B * Hv * Wv * Cin * (long)sizeof(float2)) return DCS_ERR_WORKSPACE;
+        gxv = (float*)workspace;
+    }
+    a.y = (float2*)gxv;
+    int rc;
+    if (conv::stride_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t)) {
+        // one compact sub-kernel per residue class of the input pixel instead of zero insertion
+        a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Hv = Hout; a.Wv = Wout;
+        a.kh = kh; a.kw = kw; a.sf = 1; a.st = 1; a.pad_f = 0; a.pad_t = 0;
+        a.Hout = Hv; a.Wout = Wv;
+        conv::Cls cls[4];
+        conv::stride_classes(Cout, Cin, kh, kw, sf, st, pad_f, pad_t, Hv, Wv, cls);
+        rc = dcs_conv_mfma_launch_classes(a, extra, sf * st, cls, sf, st, nullptr, 0, s);
+    } else {
+        a.wp = (const float2*)wp_bwd;
+        a.up_f = sf; a.up_t = st; a.zero_ins = 1;
+        a.kh = kh; a.kw = kw; a.sf = 1; a.st = 1; a.pad_f = kh - 1 - pad_f; a.pad_t = kw - 1 - pad_t;
+        a.Hv = (Hout - 1) * sf + 1; a.Wv = (Wout - 1) * st + 1;
+        a.Hout = Hv; a.Wout = Wv;                          // explicit: rows past the last tap get zeros
+        rc = conv::mfma_ok(Cout, Cin) ? dcs_conv_mfma_launch(a, wp_bwd + conv::direct_floats(Cin, Cout, taps), s)
+                                      : launch_direct(a, s);
+    }
+    if (rc != DCS_OK || gxv == gx1) return rc;
+    const long n = (long)B * Hin * Win * Cin;
+    long nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(upsample_cat_bwd_kernel, dim3((int)nb), dim3(256), 0, s, (const float2*)gxv, (float2*)gx1,
+                       (float2*)gx2, B, Hin, Win, C1, C2, up_f, up_t);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
 }
 
 extern "C" long dcs_cconv2d_bwd_weight_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,

@@ -28,9 +28,13 @@ constexpr int CHUNK = 8;       // complex input channels staged per LDS pass (= 
 constexpr int PIX = 20;        // LDS floats per patch pixel: 16 + 4 pad
 
 struct MArgs {
-    conv::Args c;
+    conv::Args c;              // c.Hout / c.Wout: FULL output extent (addressing); c.sf / c.st: stride in class space
     const float* bm;
+    float* y2;                 // optional second output: columns >= nsplit go here (g_x1 | g_x2 of a cat)
+    int nsplit;
     int TH, TW, N, KG, NT;     // tile shape (TH*TW = pixels per WG), N = 2*Cout, KG = Cin/4, NT = ceil(N/32)
+    int ncls, os_f, os_t;      // output-parity classes (blockIdx.z): pixel (oy, ox) of class c is stored at
+    conv::Cls cls[4];          //   (oy*os_f + oo_f, ox*os_t + oo_t) and has its own sub-kernel / padding / panel
 };
 
 // wave grid: WAVES_N waves along N, 4/WAVES_N along M; each wave owns WM x WN tiles of 32x32
@@ -38,6 +42,7 @@ template <int WAVES_N, int WM, int WN>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     const conv::Args& a = m.c;
+    const conv::Cls& k = m.cls[blockIdx.z];
     // pixels per workgroup = (4 / WAVES_N) * WM * 32 = TH * TW
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -46,19 +51,21 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int b = blockIdx.x / tiles_per_img, tile_id = blockIdx.x % tiles_per_img;
     const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
-    const int vy0 = oy0 * a.sf - a.pad_f, vx0 = ox0 * a.st - a.pad_t;
+    if (oy0 >= k.Hc || ox0 >= k.Wc) return;                           // tile outside this (smaller) class
+    const int vy0 = oy0 * a.sf - k.pad_f, vx0 = ox0 * a.st - k.pad_t;
     const int nt0 = (blockIdx.y * WAVES_N + wn) * WN;                  // first 32-column tile of this wave
     const int Cin = a.C1 + a.C2;
-    const int ntaps = a.kh * a.kw;
+    const int ntaps = k.kh * k.kw;
+    const int cols = (m.TW - 1) * a.st + k.kw, rows = (m.TH - 1) * a.sf + k.kh;
 
     // LDS float offset of this lane's pixel for each of its m-tiles (tap (0,0), k-group 0)
     int pixoff[WM];
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int pi = (wm * WM + i) * 32 + li;
-        pixoff[i] = (((pi / m.TW) * a.sf) * a.cols + (pi % m.TW) * a.st) * PIX + kk * 4;
+        pixoff[i] = (((pi / m.TW) * a.sf) * cols + (pi % m.TW) * a.st) * PIX + kk * 4;
     }
-    const float* bbase = m.bm + ((long)nt0 * 64 + lane) * 4;
+    const float* bbase = m.bm + k.bm_off + ((long)nt0 * 64 + lane) * 4;
     const long b_tap_stride = (long)m.KG * m.NT * 256, b_kg_stride = (long)m.NT * 256;
 
     f32x16 acc[WM][WN];
@@ -70,12 +77,12 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int n_chunks = Cin / CHUNK;
-    const int npix = a.rows * a.cols;
+    const int npix = rows * cols;
     for (int ch = 0; ch < n_chunks; ++ch) {
         __syncthreads();                                               // previous chunk fully consumed
         for (int idx = t; idx < npix * 4; idx += 256) {                // 4 float4 (2 complex each) per pixel
             const int q = idx & 3, px = idx >> 2;
-            const int ix = px % a.cols, iy = px / a.cols;
+            const int ix = px % cols, iy = px / cols;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             long sp;
             if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
                 for (int j = 0; j < WN; ++j) bn[j] = *reinterpret_cast<const float4*>(bp + j * 256);
             }
-            const int tapoff = ((tap / a.kw) * a.cols + (tap % a.kw)) * PIX + g * 8;
+            const int tapoff = ((tap / k.kw) * cols + (tap % k.kw)) * PIX + g * 8;
             float4 af[WM];
 #pragma unroll
             for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff);
@@ -120,12 +127,16 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 
     // epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const float* biasf = reinterpret_cast<const float*>(a.bias);
-    float* yf = reinterpret_cast<float*>(a.y);
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int n = (nt0 + j) * 32 + li;
         if (n >= m.N) continue;                                        // zero-padded columns of a 16-wide N
         const float bv = biasf ? biasf[n] : 0.f;
+        // columns >= nsplit belong to the second tensor of a concatenation
+        const bool second = m.y2 != nullptr && n >= m.nsplit;
+        float* yf = second ? m.y2 : reinterpret_cast<float*>(a.y);
+        const int width = m.y2 == nullptr ? m.N : (second ? m.N - m.nsplit : m.nsplit);
+        const int col = second ? n - m.nsplit : n;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -133,8 +144,9 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
                 const int pi = (wm * WM + i) * 32 + row;
                 const int oy = oy0 + pi / m.TW, ox = ox0 + pi % m.TW;
-                if (oy < a.Hout && ox < a.Wout)
-                    yf[(((long)b * a.Hout + oy) * a.Wout + ox) * m.N + n] = dcs_act(acc[i][j][r] + bv, a.act);
+                if (oy < k.Hc && ox < k.Wc)
+                    yf[(((long)b * a.Hout + oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] =
+                        dcs_act(acc[i][j][r] + bv, a.act);
             }
         }
     }
@@ -162,13 +174,15 @@ __global__ void pack_mfma_kernel(const float2* __restrict__ wp, float4* __restri
 template <int WAVES_N, int WM, int WN>
 int launch(MArgs& m, hipStream_t stream) {
     const conv::Args& a = m.c;
-    const size_t lds = (size_t)a.rows * a.cols * PIX * sizeof(float);
+    int kh = 0, kw = 0;
+    for (int c = 0; c < m.ncls; ++c) { kh = m.cls[c].kh > kh ? m.cls[c].kh : kh; kw = m.cls[c].kw > kw ? m.cls[c].kw : kw; }
+    const size_t lds = (size_t)((m.TH - 1) * a.sf + kh) * ((m.TW - 1) * a.st + kw) * PIX * sizeof(float);
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
     auto fn = cconv_mfma_kernel<WAVES_N, WM, WN>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DCS_ERR_LAUNCH;
-    dim3 grid(a.tiles_w * a.tiles_h * a.B, m.NT / (WAVES_N * WN));
+    dim3 grid(a.tiles_w * a.tiles_h * a.B, m.NT / (WAVES_N * WN), m.ncls);
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -185,40 +199,59 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     return DCS_OK;
 }
 
-// a: forward geometry with Hout/Wout set; bm: MFMA panel of the packed weight
-int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream) {
+// a: geometry with the FULL output extent in Hout/Wout; cls[0..ncls): output-parity classes (class-space
+// extent Hc x Wc, sub-kernel size, padding, panel offset); y2/nsplit: optional column split of the output
+int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const conv::Cls* cls, int os_f, int os_t,
+                                 float* y2, int nsplit, hipStream_t stream) {
     const int Cin = a.C1 + a.C2;
-    if (!conv::mfma_ok(Cin, a.Cout) || (a.C1 & 1) || a.Hout <= 0 || a.Wout <= 0) return DCS_ERR_BADARG;
+    if (!conv::mfma_ok(Cin, a.Cout) || (a.C1 & 1) || a.Hout <= 0 || a.Wout <= 0 || ncls < 1 || ncls > 4)
+        return DCS_ERR_BADARG;
     MArgs m;
     m.c = a;
     m.bm = bm;
+    m.y2 = y2; m.nsplit = nsplit;
+    m.ncls = ncls; m.os_f = os_f; m.os_t = os_t;
+    int Hc = 0, Wc = 0;
+    for (int c = 0; c < ncls; ++c) {
+        m.cls[c] = cls[c];
+        Hc = cls[c].Hc > Hc ? cls[c].Hc : Hc;
+        Wc = cls[c].Wc > Wc ? cls[c].Wc : Wc;
+    }
+    if (Hc <= 0 || Wc <= 0) return DCS_ERR_BADARG;
     m.N = 2 * a.Cout; m.KG = Cin / 4; m.NT = (m.N + 31) / 32;
     // candidate workgroup tiles (pixels x columns); take the largest that still yields >= 256 workgroups
     // (one per CU), else the one with the most workgroups: deep layers at small batch have few pixels
     struct Cand { int bm, bn; };
     const Cand cands[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+    auto shape = [&](int bmp, int* th, int* tw) {
+        if (bmp == 128) { if (Hc >= 8) { *th = 8; *tw = 16; } else if (Hc >= 4) { *th = 4; *tw = 32; } else { *th = 2; *tw = 64; } }
+        else { if (Hc >= 4) { *th = 4; *tw = 16; } else { *th = 2; *tw = 32; } }
+    };
     int best = -1; long best_blocks = -1;
     for (int i = 0; i < 4; ++i) {
         if (m.NT % (cands[i].bn / 32) != 0) continue;
         int th, tw;
-        if (cands[i].bm == 128) { if (a.Hout >= 8) { th = 8; tw = 16; } else if (a.Hout >= 4) { th = 4; tw = 32; } else { th = 2; tw = 64; } }
-        else { if (a.Hout >= 4) { th = 4; tw = 16; } else { th = 2; tw = 32; } }
-        const long blocks = (long)((a.Wout + tw - 1) / tw) * ((a.Hout + th - 1) / th) * a.B * (m.NT / (cands[i].bn / 32));
+        shape(cands[i].bm, &th, &tw);
+        const long blocks = (long)((Wc + tw - 1) / tw) * ((Hc + th - 1) / th) * a.B * (m.NT / (cands[i].bn / 32)) * ncls;
         if (blocks >= 256) { best = i; break; }
         if (blocks > best_blocks) { best_blocks = blocks; best = i; }
     }
     if (best < 0) return DCS_ERR_BADARG;
-    const int bmp = cands[best].bm;
-    if (bmp == 128) { if (a.Hout >= 8) { m.TH = 8; m.TW = 16; } else if (a.Hout >= 4) { m.TH = 4; m.TW = 32; } else { m.TH = 2; m.TW = 64; } }
-    else { if (a.Hout >= 4) { m.TH = 4; m.TW = 16; } else { m.TH = 2; m.TW = 32; } }
-    m.c.tiles_w = (a.Wout + m.TW - 1) / m.TW;
-    m.c.tiles_h = (a.Hout + m.TH - 1) / m.TH;
-    m.c.rows = (m.TH - 1) * a.sf + a.kh;
-    m.c.cols = (m.TW - 1) * a.st + a.kw;
+    shape(cands[best].bm, &m.TH, &m.TW);
+    m.c.tiles_w = (Wc + m.TW - 1) / m.TW;
+    m.c.tiles_h = (Hc + m.TH - 1) / m.TH;
     switch (best) {
         case 0: return launch<2, 2, 2>(m, stream);      // 128 x 128
         case 1: return launch<2, 2, 1>(m, stream);      // 128 x 64
         case 2: return launch<2, 1, 1>(m, stream);      //  64 x 64
         default: return launch<1, 1, 1>(m, stream);     // 128 x 32
     }
+}
+
+// single class: the plain convolution described by `a` (Hout/Wout set)
+int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream) {
+    conv::Cls c;
+    c.kh = a.kh; c.kw = a.kw; c.pad_f = a.pad_f; c.pad_t = a.pad_t; c.oo_f = 0; c.oo_t = 0;
+    c.Hc = a.Hout; c.Wc = a.Wout; c.bm_off = 0;
+    return dcs_conv_mfma_launch_classes(a, bm, 1, &c, 1, 1, nullptr, 0, stream);
 }

@@ -30,10 +30,11 @@ def _ver(t):
     return (0, 0) if t is None else (id(t), t._version)
 
 
-def packed_weight(w_r, w_i, b_r, b_i, transposed):
+def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1)):
     """Packed (wp, bias) for a weight pair; cached per tensor OBJECT and version (the weakrefs
-    guard against a recycled id()).  1x1 / Linear weights may be passed 2-D."""
-    key = (_ver(w_r), _ver(w_i), _ver(b_r), _ver(b_i), bool(transposed))
+    guard against a recycled id()).  1x1 / Linear weights may be passed 2-D.  `up`: upsample factors
+    of the conv call the weight is for."""
+    key = (_ver(w_r), _ver(w_i), _ver(b_r), _ver(b_i), bool(transposed), tuple(up))
     hit = _pack_cache.get(key)
     if hit is not None and hit[0]() is w_r and hit[1]() is w_i:
         return hit[2]
@@ -43,7 +44,7 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed):
     wr, wi = d(w_r), d(w_i)
     if wr.dim() == 2:
         wr, wi = wr.view(*wr.shape, 1, 1), wi.view(*wi.shape, 1, 1)
-    packed = ops.pack_conv_weight(wr, wi, d(b_r), d(b_i), transposed)
+    packed = ops.pack_conv_weight(wr, wi, d(b_r), d(b_i), transposed, tuple(up))
     _pack_cache[key] = (weakref.ref(w_r), weakref.ref(w_i), packed)
     return packed
 
@@ -53,7 +54,7 @@ class _CConv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up, act):
-        wp, bias = packed_weight(w_r, w_i, b_r, b_i, transposed)
+        wp, bias = packed_weight(w_r, w_i, b_r, b_i, transposed, up)
         y = ops.cconv2d(x1, x2, wp, bias, ksize, stride, pad, up, act)
         ctx.geom = (transposed, tuple(ksize), tuple(stride), tuple(pad), tuple(up), act, tuple(w_r.shape),
                     b_r is not None)
@@ -74,8 +75,8 @@ class _CConv2dFn(torch.autograd.Function):
         if need[0] or need[1]:
             C1 = x1.shape[3]
             Cin = C1 + (x2.shape[3] if x2 is not None else 0)
-            gx1, gx2 = ops.cconv2d_bwd_data(gy, ops.pack_conv_weight_bwd(wp), (x1.shape[1], x1.shape[2], Cin),
-                                            ksize, stride, pad, up, C1)
+            gx1, gx2 = ops.cconv2d_bwd_data(gy, ops.pack_conv_weight_bwd(wp, ksize, stride, pad, up),
+                                            (x1.shape[1], x1.shape[2], Cin), ksize, stride, pad, up, C1)
         if need[2] or need[3] or need[4] or need[5]:
             gw_r, gw_i, gb_r, gb_i = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up,
                                                            transposed)

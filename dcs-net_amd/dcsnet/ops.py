@@ -39,8 +39,9 @@ def _workspace(nbytes, device):
     return buf
 
 
-def pack_conv_weight(w_r, w_i, b_r=None, b_i=None, transposed=False):
-    """(conv_r.weight, conv_i.weight[, biases]) -> (wp [k*k,Cin,Cout,2], bias [Cout,2])."""
+def pack_conv_weight(w_r, w_i, b_r=None, b_i=None, transposed=False, up=(1, 1)):
+    """(conv_r.weight, conv_i.weight[, biases]) -> (wp [k*k,Cin,Cout,2], bias [Cout,2]).
+    `up`: the upsample factors of the cconv2d call the weight is for (adds the folded panels)."""
     for n, t in (('w_r', w_r), ('w_i', w_i), ('b_r', b_r), ('b_i', b_i)):
         _chk(t, n)
     if transposed:
@@ -48,14 +49,16 @@ def pack_conv_weight(w_r, w_i, b_r=None, b_i=None, transposed=False):
     else:
         Cout, Cin, kh, kw = w_r.shape
     lib = _lib.load()
-    # one buffer, two panels: [taps,Cin,Cout] complex for the direct kernels, then (when the shape is
-    # MFMA-eligible) the fragment-ordered real-embedded panel; `wp` views the first, the library
-    # finds the second behind it
-    buf = torch.empty(lib.dcs_packed_weight_floats(Cout, Cin, kh, kw), dtype=torch.float32, device=w_r.device)
+    # one buffer, several panels: [taps,Cin,Cout] complex for the direct kernels, then (when the shape is
+    # MFMA-eligible) the fragment-ordered real-embedded panel and the upsample-folded sub-kernels; `wp`
+    # views the first, the library finds the others behind it
+    buf = torch.empty(lib.dcs_packed_weight_floats(Cout, Cin, kh, kw, up[0], up[1]), dtype=torch.float32,
+                      device=w_r.device)
     wp = buf[:kh * kw * Cin * Cout * 2].view(kh * kw, Cin, Cout, 2)
     bias = torch.empty((Cout, 2), dtype=torch.float32, device=w_r.device)
     check(lib.dcs_pack_conv_weight(ptr(w_r), ptr(w_i), ptr(b_r), ptr(b_i), ptr(wp), ptr(bias),
-                                   Cout, Cin, kh, kw, int(bool(transposed)), cur_stream()), 'dcs_pack_conv_weight')
+                                   Cout, Cin, kh, kw, int(bool(transposed)), up[0], up[1], cur_stream()),
+          'dcs_pack_conv_weight')
     return wp, bias
 
 
@@ -89,40 +92,42 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     return y
 
 
-def pack_conv_weight_bwd(wp):
-    """Forward packed weight [taps,Cin,Cout,2] -> data-gradient weight [taps,Cout,Cin,2]."""
+def pack_conv_weight_bwd(wp, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1)):
+    """Forward packed weight [taps,Cin,Cout,2] -> data-gradient weight [taps,Cout,Cin,2] (+ derived panels
+    for the forward geometry it will be used with)."""
     _chk(wp, 'wp', 4)
     taps, Cin, Cout, _ = wp.shape
-    buf = torch.empty(_lib.load().dcs_packed_weight_floats(Cin, Cout, taps, 1), dtype=torch.float32, device=wp.device)
+    kh, kw = ksize
+    lib = _lib.load()
+    geo = (Cout, Cin, kh, kw, stride[0], stride[1], pad[0], pad[1], up[0], up[1])
+    buf = torch.empty(lib.dcs_packed_weight_bwd_floats(*geo), dtype=torch.float32, device=wp.device)
     wpb = buf[:taps * Cin * Cout * 2].view(taps, Cout, Cin, 2)
-    check(_lib.load().dcs_pack_conv_weight_bwd(ptr(wp), ptr(wpb), Cout, Cin, taps, 1, cur_stream()),
-          'dcs_pack_conv_weight_bwd')
+    check(lib.dcs_pack_conv_weight_bwd(ptr(wp), ptr(wpb), *geo, cur_stream()), 'dcs_pack_conv_weight_bwd')
     return wpb
 
 
 def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=None):
     """gy [B,Hout,Wout,Cout,2] -> (g_x1, g_x2) for the forward call with x1 [B,Hin,Win,C1,2] (+ x2).
-    in_shape = (Hin, Win, Cin_total)."""
+    in_shape = (Hin, Win, Cin_total); wp_bwd from pack_conv_weight_bwd with the same geometry."""
     _chk(gy, 'gy', 5)
     _chk(wp_bwd, 'wp_bwd', 4)
     B, Hout, Wout, Cout, _ = gy.shape
     Hin, Win, Cin = in_shape
     C1 = Cin if C1 is None else C1
     C2 = Cin - C1
-    Hv, Wv = Hin * up[0], Win * up[1]
-    gxv = torch.empty((B, Hv, Wv, Cin, 2), dtype=torch.float32, device=gy.device)
-    lib = _lib.load()
-    ev = CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * Cin * ksize[0] * ksize[1]) if CONV_TIMER is not None else None
-    check(lib.dcs_cconv2d_bwd_data(ptr(gy), ptr(wp_bwd), ptr(gxv), B, Hout, Wout, Cout, Hv, Wv, Cin, ksize[0], ksize[1],
-                                   stride[0], stride[1], pad[0], pad[1], cur_stream()), 'dcs_cconv2d_bwd_data')
-    if ev is not None:
-        CONV_TIMER.end(ev)
-    if up == (1, 1) and C2 == 0:
-        return gxv, None
     gx1 = torch.empty((B, Hin, Win, C1, 2), dtype=torch.float32, device=gy.device)
     gx2 = torch.empty((B, Hin, Win, C2, 2), dtype=torch.float32, device=gy.device) if C2 else None
-    check(lib.dcs_upsample_cat_bwd(ptr(gxv), ptr(gx1), ptr(gx2), B, Hin, Win, C1, C2, up[0], up[1], cur_stream()),
-          'dcs_upsample_cat_bwd')
+    lib = _lib.load()
+    geo = (B, Hin, Win, C1, C2, up[0], up[1], Cout, ksize[0], ksize[1], stride[0], stride[1], pad[0], pad[1])
+    nbytes = lib.dcs_cconv2d_bwd_data_workspace_bytes(*geo)
+    if nbytes < 0:
+        raise _lib.DcsHipError(f'cconv2d_bwd_data: unsupported geometry {geo}')
+    ws = _workspace(nbytes, gy.device) if nbytes else None
+    ev = CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * Cin * ksize[0] * ksize[1]) if CONV_TIMER is not None else None
+    check(lib.dcs_cconv2d_bwd_data(ptr(gy), ptr(wp_bwd), ptr(gx1), ptr(gx2), ptr(ws), ws.numel() if ws is not None else 0,
+                                   *geo, cur_stream()), 'dcs_cconv2d_bwd_data')
+    if ev is not None:
+        CONV_TIMER.end(ev)
     return gx1, gx2
 
 
@@ -254,7 +259,7 @@ def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop
     check(lib.dcs_attention_bwd_sa(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_pre), B, HW, C, float(drop_p),
                                    int(seed), cur_stream()), 'dcs_attention_bwd_sa')
     k, pad = (ksize, ksize), (ksize // 2, ksize // 2)
-    g_sp, _ = cconv2d_bwd_data(g_pre, pack_conv_weight_bwd(wsa), (H, W, 2), k, (1, 1), pad)
+    g_sp, _ = cconv2d_bwd_data(g_pre, pack_conv_weight_bwd(wsa, k, (1, 1), pad), (H, W, 2), k, (1, 1), pad)
     g_c1r, g_c1i, _, _ = cconv2d_bwd_weight(sp, None, g_pre, (1, 2, ksize, ksize), False, k, (1, 1), pad)
     g_x = torch.empty_like(x)
     g0r = torch.empty((Ch, C, 1, 1), dtype=torch.float32, device=dev)

@@ -62,11 +62,18 @@ const char* dcs_error_string(int code);
  * real-embedded weight in MFMA fragment order for the implicit-GEMM kernel.  Allocate
  * dcs_packed_weight_floats(Cout, Cin, kh, kw) floats for wp (same for wp_bwd with Cout/Cin swapped);
  * the conv entry points find the second panel themselves.
+ * (up_f, up_t): the nearest-upsample factors of the dcs_cconv2d_fwd call this weight will be used with
+ * (1,1 = none).  For a 3x3 / stride-1 / pad-1 conv behind a x2 upsample a third panel is appended: the
+ * upsample FOLDED into per-output-parity sub-kernels with pre-summed taps (y[2m] = W0 x[m-1] + (W1+W2) x[m],
+ * y[2m+1] = (W0+W1) x[m] + W2 x[m+1]), which dcs_cconv2d_fwd then runs on the source tensors.  A weight
+ * must be used with the same (up_f, up_t) it was packed for.
  */
-long dcs_packed_weight_floats(int Cout, int Cin, int kh, int kw);
+long dcs_packed_weight_floats(int Cout, int Cin, int kh, int kw, int up_f, int up_t);
 int dcs_pack_conv_weight(const float* w_r, const float* w_i, const float* b_r, const float* b_i,
                          float* wp, float* bias_out,
-                         int Cout, int Cin, int kh, int kw, int transposed, dcs_stream_t stream);
+                         int Cout, int Cin, int kh, int kw, int transposed, int up_f, int up_t,
+                         dcs_stream_t stream);
+/*
 
 /* ------------------------------------------------------------------------------------
  * ComplexConv2d / ComplexConvTranspose2d forward (apply_complex of complexPyTorch 0.3).
@@ -94,19 +101,31 @@ int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const flo
  * Gradients of dcs_cconv2d_fwd (what torch.autograd derives for the reference through the four
  * real convolutions of apply_complex; gradients of complex tensors are dL/dRe + j dL/dIm).
  *
- * dcs_pack_conv_weight_bwd: wp_bwd[tap'][co][ci] = conj(wp[ntaps-1-tap'][ci][co]).
- * dcs_cconv2d_bwd_data:  g_Xv[b,vy,vx,ci] = sum_{p,tap,co} conj(wp[tap][ci][co]) g_Y[p,co] over
- *     p*s - pad + tap = (vy,vx); g_Xv is the gradient of the VIRTUAL input complex[B][Hv][Wv][Cin]
- *     (Hv = Hin*up_f ...).  Without upsample/cat it IS g_x1.
- * dcs_upsample_cat_bwd:  g_x1 / g_x2 = block sums of g_Xv over (up_f, up_t), split at channel C1.
+ * dcs_pack_conv_weight_bwd: wp_bwd[tap'][co][ci] = conj(wp[ntaps-1-tap'][ci][co]), its MFMA panel, and — given
+ *     the forward geometry — the derived panels that skip structurally zero work: one compact sub-kernel per
+ *     input-pixel residue class for a strided conv (instead of zero insertion), or the effective 4-tap
+ *     stride-2 kernel conj[W2, W1+W2, W0+W1, W0] for the conv behind a x2 nearest upsample.
+ *     Allocate dcs_packed_weight_bwd_floats(...) floats.
+ * dcs_cconv2d_bwd_data:  g_x1 (complex[B][Hin][Win][C1]) and g_x2 (complex[B][Hin][Win][C2], NULL iff C2 == 0):
+ *     gradients of the two inputs of the forward call with the same geometry arguments,
+ *       g_Xv[b,vy,vx,ci] = sum_{p,tap,co} conj(wp[tap][ci][co]) g_Y[p,co]   over p*s - pad + tap = (vy,vx),
+ *     block-summed over the upsample factors and split at channel C1.  workspace: see
+ *     dcs_cconv2d_bwd_data_workspace_bytes (0 on the fused paths).
+ * dcs_upsample_cat_bwd:  the stand-alone block sum / channel split of a virtual-input gradient.
  * dcs_cconv2d_bwd_weight: gradients of the reference's parameters, in THEIR layout:
  *     gw_r, gw_i: float[Cout][Cin][kh][kw] (transposed=0) or float[Cin][Cout][kh][kw] (transposed=1)
  *     gb_r, gb_i: float[Cout] (NULL for bias-free layers).  x1/x2/geometry as in the forward call.
  *     workspace >= dcs_cconv2d_bwd_weight_workspace_bytes(...) (partial slabs; no atomics). */
-int  dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout, int Cin, int kh, int kw, dcs_stream_t stream);
-int  dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float* gxv,
-                          int B, int Hout, int Wout, int Cout, int Hv, int Wv, int Cin,
-                          int kh, int kw, int sf, int st, int pad_f, int pad_t, dcs_stream_t stream);
+long dcs_packed_weight_bwd_floats(int Cout, int Cin, int kh, int kw, int sf, int st, int pad_f, int pad_t,
+                                  int up_f, int up_t);
+int  dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout, int Cin, int kh, int kw,
+                              int sf, int st, int pad_f, int pad_t, int up_f, int up_t, dcs_stream_t stream);
+long dcs_cconv2d_bwd_data_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                                          int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t);
+int  dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float* gx1, float* gx2,
+                          void* workspace, long workspace_bytes,
+                          int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                          int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, dcs_stream_t stream);
 int  dcs_upsample_cat_bwd(const float* gxv, float* gx1, float* gx2, int B, int Hin, int Win, int C1, int C2,
                           int up_f, int up_t, dcs_stream_t stream);
 long dcs_cconv2d_bwd_weight_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
