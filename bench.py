@@ -168,6 +168,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a hipGraph')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -204,18 +205,40 @@ def main():
     if train:
         from dcsnet.dp import TrainStep
         net.train()                       # reference dropout (0.1 / 0.2) and batch statistics
-        ts = TrainStep(net)               # flat bucket + fused HIP Adam/AMSGrad + clip 100 + all-reduce
+        # flat bucket + fused HIP Adam/AMSGrad + clip 100 + all-reduce; fwd+bwd(+optimizer) replayed as one hipGraph
+        ts = TrainStep(net, use_graph=not args.no_graph)
         batch = (noise, noisy, clean, list(range(B)))
 
         def step():
             return ts(batch)
+
+        def eager_step():
+            return ts._eager(batch, 0)
+        setup_steps = ts.graph_warmup + 1 if ts.use_graph else 0
     else:
         net.eval()
 
-        def step():
+        def eager_step():
             with torch.no_grad():
                 m_raw = net(noisy)
                 return F.bound_mask_apply_complex(noisy, m_raw, hparams['atan2_eps'])
+        step, setup_steps = eager_step, 0
+        if not args.no_graph:
+            for _ in range(2):
+                eager_step()
+            torch.cuda.synchronize()
+            try:
+                infer_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(infer_graph):
+                    static_out = eager_step()
+                step = infer_graph.replay
+            except Exception as e:                      # noqa: BLE001
+                log(f'hipGraph capture failed ({type(e).__name__}: {e}); running eagerly')
+                torch.cuda.synchronize()
+
+    for _ in range(setup_steps):          # eager steps + the capture itself: setup, neither warm-up nor timed
+        step()
+    torch.cuda.synchronize()
 
     log(f'inputs ready: B={B} T={T}')
     for i in range(args.warmup):
@@ -225,7 +248,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.active = True
+    graphed = (train and ts.use_graph) or (not train and step is not eager_step)
+    timer.active = not graphed
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -235,6 +259,14 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.active = False
+    if graphed and rank == 0:
+        # kernels inside a hipGraph replay cannot be bracketed by events: time the conv family in an
+        # instrumented EAGER pass of the same K steps, right after (and outside) the timed region
+        timer.active = True
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize()
+        timer.active = False
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -258,13 +290,16 @@ def main():
                                     'BASELINE configs[1]: DCS-Net forward-only inference, complex64 [16,256,2000] per GPU '
                                     '(4 s / 16 kHz STFT, n_fft 512 hop 32, bins 1..256), random-init weights seed 0'),
                        'per_gpu_batch': B, 'frames_per_utterance': T, 'global_batch': B * world,
-                       'frames_per_step': B * T * world, 'parallelism': (f'dp{world} (utterance sharding, one flat-bucket gradient all-reduce)' if train
+                       'frames_per_step': B * T * world, 'hip_graph': bool(graphed), 'parallelism': (f'dp{world} (utterance sharding, one flat-bucket gradient all-reduce)' if train
                                        else f'dp{world} (utterance sharding, no collective)')},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(args.mode, B, T),
                          'kernel': 'complex conv / convT (dcs_cconv2d_fwd' + (', _bwd_data, _bwd_weight' if train else '')
                                    + '), all launches of the timed region',
                          'launches': n_launch, 'kernel_ms_per_step': conv_ms / args.steps,
+                         'measured': ('HIP events around every launch in an instrumented eager pass of the same K steps '
+                                      'right after the timed region (the timed steps replay a hipGraph)' if graphed else
+                                      'HIP events around every launch inside the timed region'),
                          'algorithmic_gflop_per_step': timer.flops / args.steps / 1e9},
         }
         if not args.no_cpu_baseline and world == 1:

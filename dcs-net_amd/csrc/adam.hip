@@ -18,7 +18,13 @@ __global__ __launch_bounds__(kThreads) void adam_amsgrad_kernel(float4* __restri
                                                                  float4* __restrict__ vmax,
                                                                  const float* __restrict__ grad_norm, float max_norm,
                                                                  float grad_scale, long n4, long n, float lr, float b1,
-                                                                 float b2, float eps, float wd, float bc1, float bc2s) {
+                                                                 float b2, float eps, float wd, float bc1, float bc2s,
+                                                                 const int* __restrict__ step_dev) {
+    if (step_dev) {                       // update count kept on the device (hipGraph replay safe)
+        const float t = (float)step_dev[0];
+        bc1 = 1.f - powf(b1, t);
+        bc2s = sqrtf(1.f - powf(b2, t));
+    }
     float clip = grad_scale;
     if (grad_norm != nullptr && max_norm > 0.f) {
         const float c = max_norm / (grad_scale * grad_norm[0] + 1e-6f);
@@ -55,17 +61,18 @@ __global__ __launch_bounds__(kThreads) void adam_amsgrad_kernel(float4* __restri
 
 extern "C" int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, const float* grad_norm,
                                      float max_norm, float grad_scale, long n, float lr, float beta1, float beta2,
-                                     float eps, float weight_decay, int step, dcs_stream_t stream) {
-    if (!p || !g || !m || !v || !vmax || n <= 0 || step < 1) return DCS_ERR_BADARG;
+                                     float eps, float weight_decay, int step, const int* step_dev,
+                                     dcs_stream_t stream) {
+    if (!p || !g || !m || !v || !vmax || n <= 0 || (step < 1 && !step_dev)) return DCS_ERR_BADARG;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return DCS_ERR_BADARG;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    const float bc1 = 1.f - powf(beta1, (float)(step < 1 ? 1 : step));
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)(step < 1 ? 1 : step)));
     const long n4 = n / 4;
     long nb = (n4 + kThreads * 2 - 1) / (kThreads * 2);
     const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
     hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid), dim3(kThreads), 0, dcs_stream(stream), (float4*)p,
                        (const float4*)g, (float4*)m, (float4*)v, (float4*)vmax, grad_norm, max_norm, grad_scale, n4, n,
-                       lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+                       lr, beta1, beta2, eps, weight_decay, bc1, bc2s, step_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

@@ -12,3 +12,20 @@ extern "C" const char* dcs_error_string(int code) {
         default: return "unknown error";
     }
 }
+
+hipError_t dcs_ensure_dynamic_lds(const void* fn, size_t bytes) {
+    struct Entry { const void* fn; size_t bytes; };
+    static Entry table[64];
+    static int n = 0;
+    if (bytes <= 64 * 1024) return hipSuccess;
+    for (int i = 0; i < n; ++i)
+        if (table[i].fn == fn) {
+            if (table[i].bytes >= bytes) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) table[i].bytes = bytes;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && n < 64) { table[n].fn = fn; table[n].bytes = bytes; ++n; }
+    return e;
+}

@@ -136,7 +136,8 @@ template <bool DROP>
 __global__ __launch_bounds__(kThreads) void attention_apply_kernel(const float* __restrict__ x,
                                                                     const float* __restrict__ ca,
                                                                     const float2* __restrict__ sa, float* __restrict__ y,
-                                                                    long HW, int C, int G, float drop_p, uint64_t seed) {
+                                                                    long HW, int C, int G, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = blockIdx.y;
     const long base = (long)b * HW * G;
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(kThreads) void attention_apply_kernel(const float* 
 }
 
 __global__ __launch_bounds__(kThreads) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
-                                                            float drop_p, uint64_t seed) {
+                                                            float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const float inv_keep = 1.f / (1.f - drop_p);
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads)
         y[i] = x[i] * (drop_p > 0.f ? dcs_keep_scale(seed, (uint64_t)i, drop_p, inv_keep) : 1.f);
@@ -217,28 +219,28 @@ extern "C" int dcs_spatial_pool_fwd(const float* x, const float* ca, float* pool
 }
 
 extern "C" int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, float* y, int B, long HW,
-                                       int C, float drop_p, unsigned long long seed, dcs_stream_t stream) {
+                                       int C, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
     int G;
     if (!x || !y || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
     dim3 grid(stream_grid(HW, G, B), B);
     if (drop_p > 0.f)
         hipLaunchKernelGGL(attention_apply_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), x, ca,
-                           (const float2*)sa, y, HW, C, G, drop_p, (uint64_t)seed);
+                           (const float2*)sa, y, HW, C, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     else
         hipLaunchKernelGGL(attention_apply_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), x, ca,
-                           (const float2*)sa, y, HW, C, G, drop_p, (uint64_t)seed);
+                           (const float2*)sa, y, HW, C, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
 
 extern "C" int dcs_dropout_fwd(const float* x, float* y, long n, float drop_p, unsigned long long seed,
-                               dcs_stream_t stream) {
+                               const unsigned long long* seed_dev, dcs_stream_t stream) {
     if (!x || !y || n <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
     long nb = (n + kThreads * 4 - 1) / (kThreads * 4);
     const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
     hipLaunchKernelGGL(dropout_kernel, dim3(grid), dim3(kThreads), 0, dcs_stream(stream), x, y, n, drop_p,
-                       (uint64_t)seed);
+                       (uint64_t)seed, (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

@@ -63,7 +63,8 @@ template <bool DROP>
 __global__ __launch_bounds__(kThreads) void att_bwd_sa_kernel(const float* __restrict__ x, const float* __restrict__ go,
                                                                const float* __restrict__ ca,
                                                                const float2* __restrict__ sa, float2* __restrict__ gpre,
-                                                               long HW, int G, float drop_p, uint64_t seed) {
+                                                               long HW, int G, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = blockIdx.y;
     const long base = (long)b * HW * G;
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(const float* __rest
                                                               const float* __restrict__ ca, const float2* __restrict__ sa,
                                                               const float4* __restrict__ gsp, float* __restrict__ gx,
                                                               double* __restrict__ part, long HW, int C, int G,
-                                                              float drop_p, uint64_t seed) {
+                                                              float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     __shared__ double red[kThreads * 4];
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = blockIdx.y;
@@ -253,17 +255,17 @@ inline int stream_grid(long HW, int G, int B) {
 }  // namespace
 
 extern "C" int dcs_attention_bwd_sa(const float* x, const float* g_out, const float* ca, const float* sa, float* g_pre,
-                                    int B, long HW, int C, float drop_p, unsigned long long seed, dcs_stream_t stream) {
+                                    int B, long HW, int C, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
     int G;
     if (!x || !g_out || !ca || !sa || !g_pre || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
     dim3 grid(stream_grid(HW, G, B), B);
     if (drop_p > 0.f)
         hipLaunchKernelGGL(att_bwd_sa_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), x, g_out, ca,
-                           (const float2*)sa, (float2*)g_pre, HW, G, drop_p, (uint64_t)seed);
+                           (const float2*)sa, (float2*)g_pre, HW, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     else
         hipLaunchKernelGGL(att_bwd_sa_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), x, g_out, ca,
-                           (const float2*)sa, (float2*)g_pre, HW, G, drop_p, (uint64_t)seed);
+                           (const float2*)sa, (float2*)g_pre, HW, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -278,7 +280,7 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
                                    const float* g_sp, const float* pooled, const float* hidden, const float* w1,
                                    const float* w2, float* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r,
                                    float* g_fc2_i, void* workspace, long workspace_bytes, int B, long HW, int C, int Ch,
-                                   float drop_p, unsigned long long seed, dcs_stream_t stream) {
+                                   float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
     int G;
     if (!x || !g_out || !ca || !sa || !g_sp || !pooled || !hidden || !w1 || !w2 || !g_x || !g_fc0_r || !g_fc0_i ||
         !g_fc2_r || !g_fc2_i || !workspace)
@@ -296,10 +298,10 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
     dim3 grid(nch, B);
     if (drop_p > 0.f)
         hipLaunchKernelGGL(att_bwd_x_kernel<true>, grid, dim3(kThreads), 0, s, x, g_out, ca, (const float2*)sa,
-                           (const float4*)g_sp, g_x, part, HW, C, G, drop_p, (uint64_t)seed);
+                           (const float4*)g_sp, g_x, part, HW, C, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     else
         hipLaunchKernelGGL(att_bwd_x_kernel<false>, grid, dim3(kThreads), 0, s, x, g_out, ca, (const float2*)sa,
-                           (const float4*)g_sp, g_x, part, HW, C, G, drop_p, (uint64_t)seed);
+                           (const float4*)g_sp, g_x, part, HW, C, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
     hipLaunchKernelGGL(ca_bwd_sample_kernel, dim3(B), dim3(kThreads), 0, s, (const double*)part, nch,
                        (const float2*)ca, (const float2*)hidden, (const float2*)w1, (const float2*)w2, go, gh, gpooled,

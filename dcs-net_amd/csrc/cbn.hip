@@ -186,7 +186,8 @@ __device__ __forceinline__ float act_t(float v) {
 template <int ACT, bool DROP>
 __global__ __launch_bounds__(kThreads) void cbn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               const float* __restrict__ coef, long P, int C, int G,
-                                                              int rows_per_iter, float drop_p, uint64_t seed) {
+                                                              int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
     const int t = threadIdx.x;
     const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -254,7 +255,7 @@ extern "C" long dcs_cbn_workspace_bytes(long P, int C) {
 extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
                            float* running_covar, float* stats_out, float* coef_out, void* workspace,
                            long workspace_bytes, long P, int C, float eps, float momentum, int use_batch_stats,
-                           int act, float drop_p, unsigned long long seed, dcs_stream_t stream) {
+                           int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
     CbnGeom g;
     if (!x || !y || !stats_out || !coef_out || !cbn_geom(P, C, &g)) return DCS_ERR_BADARG;
     if ((weight == nullptr) != (bias == nullptr)) return DCS_ERR_BADARG;
@@ -278,7 +279,7 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
     int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
 #define DCS_CBN_APPLY(A, D)                                                                                   \
     hipLaunchKernelGGL((cbn_apply_kernel<A, D>), dim3(grid), dim3(kThreads), 0, s, x, y, coef_out, P, C,         \
-                       g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed)
+                       g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev)
     const bool drop = drop_p > 0.f;
     if (act == DCS_ACT_RELU) { if (drop) DCS_CBN_APPLY(DCS_ACT_RELU, true); else DCS_CBN_APPLY(DCS_ACT_RELU, false); }
     else if (act == DCS_ACT_LRELU) { if (drop) DCS_CBN_APPLY(DCS_ACT_LRELU, true); else DCS_CBN_APPLY(DCS_ACT_LRELU, false); }

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
                                                                    const float* __restrict__ coef,
                                                                    const float* __restrict__ stats,
                                                                    double* __restrict__ part, long P, int C, int G,
-                                                                   int rows_per_iter, float drop_p, uint64_t seed) {
+                                                                   int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     __shared__ double red[kThreads * 12];
     const int t = threadIdx.x;
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
                                                                   const float* __restrict__ coef,
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ bcoef, long P, int C, int G,
-                                                                  int rows_per_iter, float drop_p, uint64_t seed) {
+                                                                  int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x;
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
     const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -255,7 +257,7 @@ extern "C" long dcs_cbn_bwd_workspace_bytes(long P, int C) {
 extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const float* weight, const float* stats,
                            const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
                            long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
-                           dcs_stream_t stream) {
+                           const unsigned long long* seed_dev, dcs_stream_t stream) {
     cbn::Geom g;
     if (!x || !g_out || !g_x || !stats || !coef || !workspace || !cbn::geom(P, C, &g)) return DCS_ERR_BADARG;
     if ((g_weight == nullptr) != (g_bias == nullptr)) return DCS_ERR_BADARG;
@@ -271,12 +273,12 @@ extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const
 #define DCS_CBN_BWD(A, D)                                                                                          \
     do {                                                                                                           \
         hipLaunchKernelGGL((cbn_bwd_reduce_kernel<A, D>), dim3(g.nblocks), dim3(kThreads), 0, s, x, g_out, coef,    \
-                           stats, part, P, C, g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed);             \
+                           stats, part, P, C, g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);             \
         hipLaunchKernelGGL(cbn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part,      \
                            g.nblocks, weight, stats, coef, g_weight, g_bias, bcoef, P, C, use_batch_stats);        \
         hipLaunchKernelGGL((cbn_bwd_apply_kernel<A, D>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef,    \
                            stats, (const float*)bcoef, P, C, g.vec_per_row, g.rows_per_iter, drop_p,               \
-                           (uint64_t)seed);                                                                        \
+                           (uint64_t)seed, (const uint64_t*)seed_dev);                                                                        \
     } while (0)
     if (act == DCS_ACT_RELU) { if (drop) DCS_CBN_BWD(DCS_ACT_RELU, true); else DCS_CBN_BWD(DCS_ACT_RELU, false); }
     else if (act == DCS_ACT_LRELU) { if (drop) DCS_CBN_BWD(DCS_ACT_LRELU, true); else DCS_CBN_BWD(DCS_ACT_LRELU, false); }

@@ -316,8 +316,7 @@ int launch_direct(ConvArgs& a, hipStream_t stream) {
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it for this instantiation
         const void* fn = cob == 8 ? (const void*)cconv_direct_kernel<8> : cob == 4 ? (const void*)cconv_direct_kernel<4>
                        : cob == 2 ? (const void*)cconv_direct_kernel<2> : (const void*)cconv_direct_kernel<1>;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DCS_ERR_LAUNCH;
+        if (dcs_ensure_dynamic_lds(fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     }
     dim3 grid(a.tiles_w * a.tiles_h, Cout / cob, a.B);
     if (grid.y > 65535 || grid.z > 65535) return DCS_ERR_BADARG;
@@ -592,9 +591,7 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     const int slots = (n_out + TH * TW - 1) / (TH * TW);
     auto fn = slots <= 1 ? cconv_wgrad_kernel<1> : slots <= 2 ? cconv_wgrad_kernel<2>
             : slots <= 4 ? cconv_wgrad_kernel<4> : cconv_wgrad_kernel<WG_TAPS>;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return DCS_ERR_LAUNCH;
+    if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(w.n_slabs, n_ci * w.n_co_chunks);
     if (grid.y > 65535) return DCS_ERR_BADARG;
     hipLaunchKernelGGL(fn, grid, dim3(TH * TW), lds, s, w);

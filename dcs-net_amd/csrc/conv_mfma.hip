@@ -179,9 +179,7 @@ int launch(MArgs& m, hipStream_t stream) {
     const size_t lds = (size_t)((m.TH - 1) * a.sf + kh) * ((m.TW - 1) * a.st + kw) * PIX * sizeof(float);
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
     auto fn = cconv_mfma_kernel<WAVES_N, WM, WN>;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return DCS_ERR_LAUNCH;
+    if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, m.NT / (WAVES_N * WN), m.ncls);
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
     DCS_CHECK_LAUNCH();

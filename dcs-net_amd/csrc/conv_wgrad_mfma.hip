@@ -185,9 +185,7 @@ int launch(WArgs& w, int Cin, hipStream_t stream) {
     if (red > lds) lds = red;
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
     auto fn = cconv_wgrad_mfma_kernel<KS, MT, WS>;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return DCS_ERR_LAUNCH;
+    if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     const int co_per_block = (4 / WS) * MT * 8;
     w.co_blocks = (a.Cout + co_per_block - 1) / co_per_block;
     dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks);

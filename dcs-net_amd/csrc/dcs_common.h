@@ -60,3 +60,8 @@ __device__ __forceinline__ float dcs_keep_scale(uint64_t seed, uint64_t idx, flo
 }
 
 static inline int dcs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Raise a kernel's dynamic-LDS limit (> 64 KiB) once per (kernel, size high-water mark).  The table makes the
+// call idempotent, so steady-state launches issue no attribute call at all — hipFuncSetAttribute is not
+// permitted while a stream is being captured into a hipGraph, and the eager warm-up steps have already made it.
+hipError_t dcs_ensure_dynamic_lds(const void* fn, size_t bytes);

@@ -33,26 +33,26 @@ SIGNATURES = {
     'dcs_cconv2d_bwd_weight_workspace_bytes': (_L, [_I] * 14),
     'dcs_cconv2d_bwd_weight': (_I, [_P] * 8 + [_L] + [_I] * 15 + [_P]),
     'dcs_cbn_workspace_bytes': (_L, [_L, _I]),
-    'dcs_cbn_fwd': (_I, [_P] * 9 + [_L, _L, _I, _F, _F, _I, _I, _F, _U64, _P]),
+    'dcs_cbn_fwd': (_I, [_P] * 9 + [_L, _L, _I, _F, _F, _I, _I, _F, _U64, _P, _P]),
     'dcs_cbn_bwd_workspace_bytes': (_L, [_L, _I]),
-    'dcs_cbn_bwd': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P]),
+    'dcs_cbn_bwd': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P]),
     'dcs_ca_workspace_bytes': (_L, [_I, _L, _I]),
     'dcs_channel_attention_fwd': (_I, [_P] * 7 + [_L, _I, _L, _I, _I, _P]),
     'dcs_spatial_pool_fwd': (_I, [_P, _P, _P, _I, _L, _I, _P]),
-    'dcs_attention_apply_fwd': (_I, [_P, _P, _P, _P, _I, _L, _I, _F, _U64, _P]),
-    'dcs_attention_bwd_sa': (_I, [_P] * 5 + [_I, _L, _I, _F, _U64, _P]),
+    'dcs_attention_apply_fwd': (_I, [_P, _P, _P, _P, _I, _L, _I, _F, _U64, _P, _P]),
+    'dcs_attention_bwd_sa': (_I, [_P] * 5 + [_I, _L, _I, _F, _U64, _P, _P]),
     'dcs_attention_bwd_workspace_bytes': (_L, [_I, _L, _I, _I]),
-    'dcs_attention_bwd_x': (_I, [_P] * 15 + [_L, _I, _L, _I, _I, _F, _U64, _P]),
+    'dcs_attention_bwd_x': (_I, [_P] * 15 + [_L, _I, _L, _I, _I, _F, _U64, _P, _P]),
     'dcs_lstm_layer_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P]),
     'dcs_lstm_layer_bwd': (_I, [_P] * 5 + [_I] * 4 + [_P]),
-    'dcs_dropout_fwd': (_I, [_P, _P, _L, _F, _U64, _P]),
+    'dcs_dropout_fwd': (_I, [_P, _P, _L, _F, _U64, _P, _P]),
     'dcs_complex_act_fwd': (_I, [_P, _P, _L, _I, _P]),
     'dcs_complex_upsample_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'dcs_bound_crm_fwd': (_I, [_P, _P, _L, _F, _P]),
     'dcs_bound_mask_apply_fwd': (_I, [_P, _P, _P, _P, _P, _L, _F, _P]),
     'dcs_bound_mask_apply_bwd': (_I, [_P] * 6 + [_L, _F, _P]),
     'dcs_crm_fwd': (_I, [_P, _P, _P, _L, _F, _P]),
-    'dcs_adam_amsgrad_step': (_I, [_P] * 6 + [_F, _F, _L, _F, _F, _F, _F, _F, _I, _P]),
+    'dcs_adam_amsgrad_step': (_I, [_P] * 6 + [_F, _F, _L, _F, _F, _F, _F, _F, _I, _P, _P]),
 }
 
 _lib = None

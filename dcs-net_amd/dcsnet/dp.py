@@ -68,7 +68,8 @@ class FlatBucket:
 
 
 class FusedAdam:
-    """dcs_adam_amsgrad_step over a FlatBucket (HIP; no fallback)."""
+    """dcs_adam_amsgrad_step over a FlatBucket (HIP; no fallback).  The update count also lives on the
+    device so that a captured hipGraph can be replayed while the bias corrections advance."""
 
     def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0):
         self.b = bucket
@@ -77,17 +78,19 @@ class FusedAdam:
         self.v = torch.zeros_like(bucket.flat)
         self.vmax = torch.zeros_like(bucket.flat)
         self.t = 0
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=bucket.flat.device)
 
     def step(self, world=1):
         b = self.b
         if not b.flat.is_cuda:
             raise _lib.DcsHipError('FusedAdam: expected CUDA (HIP) parameters; the HIP path has no CPU fallback')
         self.t += 1
+        self.t_dev += 1
         norm = torch.linalg.vector_norm(b.grad).reshape(1) if self.max_norm > 0 else None
         check(_lib.load().dcs_adam_amsgrad_step(ptr(b.flat), ptr(b.grad), ptr(self.m), ptr(self.v), ptr(self.vmax),
                                                 ptr(norm), float(self.max_norm), 1.0 / world, b.numel, self.lr,
-                                                self.betas[0], self.betas[1], self.eps, self.wd, self.t, cur_stream()),
-              'dcs_adam_amsgrad_step')
+                                                self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                                ptr(self.t_dev), cur_stream()), 'dcs_adam_amsgrad_step')
         # the kernel rewrote the parameters behind torch's version counters: invalidate packed weights
         from . import functional
         functional.bump_param_generation()
@@ -112,16 +115,31 @@ class TorchAdam:
 
 
 class TrainStep:
-    """One optimisation step of the reference's recipe over a (possibly sharded) minibatch."""
+    """One optimisation step of the reference's recipe over a (possibly sharded) minibatch.
 
-    def __init__(self, net, optimizer_cls=FusedAdam):
+    use_graph=True captures forward + losses + backward (+ the fused optimizer when single-process) into
+    ONE hipGraph after `graph_warmup` eager steps and replays it afterwards: ~1.3 k launches per step
+    become one submission.  Per-step state that must advance under replay lives on the device: the
+    dropout seed offset (ops.SEED_STATE) and Adam's update count.  The batch is copied into static
+    buffers before each replay.  Any capture failure falls back to eager execution, loudly."""
+
+    def __init__(self, net, optimizer_cls=FusedAdam, use_graph=False, graph_warmup=3):
         hp = net.hparams
         self.net = net
         self.bucket = FlatBucket(net)
         self.opt = optimizer_cls(self.bucket, lr=hp['lr'], eps=hp['optim_eps'], weight_decay=hp['optim_weight_decay'],
                                  max_norm=hp.get('gradient_clip_val', 0.0) or 0.0)
+        self.use_graph = bool(use_graph) and self.bucket.flat.is_cuda
+        self.graph_warmup = graph_warmup
+        self.seed_state = None
+        if self.bucket.flat.is_cuda:
+            from . import ops
+            self.seed_state = torch.zeros(1, dtype=torch.int64, device=self.bucket.flat.device)
+            ops.SEED_STATE = self.seed_state
+        self._graph = self._static_batch = self._static_loss = None
+        self._calls = 0
 
-    def __call__(self, batch, batch_idx=0):
+    def _eager(self, batch, batch_idx):
         self.bucket.zero_grad()
         loss = self.net.training_step(batch, batch_idx)
         if loss is None:                       # NaN guard of the reference (c_network.py:257-261)
@@ -129,4 +147,53 @@ class TrainStep:
         loss.backward()
         world = self.bucket.allreduce()
         self.opt.step(world)
+        if self.seed_state is not None:
+            self.seed_state += 1
         return loss.detach()
+
+    def _loss_no_sync(self, batch, batch_idx):
+        """training_step without its NaN test (a host synchronisation, illegal under capture)."""
+        from .network_functions import train_batch_2_loss
+        out = train_batch_2_loss(self.net, batch, batch_idx, dtype='complex')
+        return out[2] if isinstance(out, tuple) else out
+
+    def _capture(self, batch):
+        from . import functional
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        functional.bump_param_generation()                 # packed weights must be re-made INSIDE the graph
+        self._static_batch = [t.clone() for t in batch[:3]]
+        static = (*self._static_batch, *batch[3:])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.bucket.zero_grad()
+            loss = self._loss_no_sync(static, 0)
+            loss.backward()
+            if world == 1:                                 # collectives stay outside the graph
+                self.opt.step(1)
+                self.seed_state += 1
+        functional.bump_param_generation()                 # cache entries made during capture live in its pool
+        self._graph, self._static_loss, self._graph_world = g, loss.detach(), world
+
+    def __call__(self, batch, batch_idx=0):
+        if not self.use_graph:
+            return self._eager(batch, batch_idx)
+        self._calls += 1
+        if self._graph is None:
+            if self._calls <= self.graph_warmup:
+                return self._eager(batch, batch_idx)
+            try:
+                self._capture(batch)
+            except Exception as e:                          # noqa: BLE001 - report and keep training eagerly
+                import warnings
+                warnings.warn(f'TrainStep: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly')
+                self.use_graph = False
+                torch.cuda.synchronize()
+                return self._eager(batch, batch_idx)
+        for s, b in zip(self._static_batch, batch[:3]):
+            if s is not b:
+                s.copy_(b)
+        self._graph.replay()
+        if self._graph_world > 1:
+            self.opt.step(self.bucket.allreduce())
+            self.seed_state += 1
+        return self._static_loss

@@ -130,13 +130,50 @@ class ComplexAdaptiveMaxPool2d(torch.nn.Module):
 
 # ---- step functions (plumbing on PyTorch-ROCm around the HIP path) ------------------------------
 
+_windows = {}
+
+
+def _window_on(config, device):
+    """The synthesis window on `device`, uploaded once (a per-call host-to-device copy would also be illegal
+    inside a hipGraph capture)."""
+    key = (id(config.window), device)
+    w = _windows.get(key)
+    if w is None:
+        w = _windows[key] = config.window.to(device)
+    return w
+
+
+_envelopes = {}
+
+
+def istft(comp, n_fft, hop, window, normalized):
+    """torch.istft(center=True, onesided, length=None) spelled out — irfft, synthesis window, overlap-add,
+    division by the squared-window envelope, trim n_fft/2 at both ends — WITHOUT torch.istft's NOLA check,
+    which reads the envelope minimum back to the host (a synchronisation per call, and illegal inside a
+    hipGraph capture).  The envelope depends only on (window, frame count) and is cached."""
+    B, _, T = comp.shape
+    if normalized:
+        comp = comp * (float(n_fft) ** 0.5)
+    frames = torch.fft.irfft(comp, n=n_fft, dim=1).transpose(1, 2) * window          # [B, T, n_fft]
+    L = n_fft + hop * (T - 1)
+    # overlap-add = the adjoint of Tensor.unfold (what torch.istft itself uses; F.fold's backward is an im2col
+    # that is ~20x slower for a 512-wide kernel)
+    ola = lambda fr: torch.ops.aten.unfold_backward(fr, [fr.shape[0], L], 1, n_fft, hop)
+    key = (window.data_ptr(), T, hop, comp.device)
+    env = _envelopes.get(key)
+    if env is None:
+        env = ola((window * window)[None, None, :].expand(1, T, n_fft).contiguous()).reshape(L)
+        env = _envelopes[key] = env[n_fft // 2: L - n_fft // 2].clone()
+    y = ola(frames.contiguous())[:, n_fft // 2: L - n_fft // 2]
+    return y / env
+
+
 def mag_phase_2_wave(mag, phase, config):
     """network_functions.py:140-150; the window follows the tensor's device instead of the
     reference's hard-coded cuda index (:147)."""
     comp = torch.complex(mag * torch.cos(phase), mag * torch.sin(phase))
     comp = torch.nn.functional.pad(comp, (0, 0, 0, 1))
-    return torch.istft(comp, n_fft=config.fft_size, hop_length=config.hop_length, win_length=config.window_length,
-                       window=config.window.to(comp.device), normalized=config.normalise_stft)
+    return istft(comp, config.fft_size, config.hop_length, _window_on(config, comp.device), config.normalise_stft)
 
 
 def _polar_wave(z, eps, config):

@@ -26,6 +26,11 @@ def _chk(t, name, dims=None):
 
 CONV_TIMER = None        # set by bench.py: object with begin(flops) -> token / end(token)
 
+# Device-side dropout seed offset (int64 tensor with one element, or None).  Every dropout-capable
+# kernel adds it to its by-value seed, so a captured hipGraph draws a fresh mask per replay once the
+# owner (dp.TrainStep) increments it in-graph.  Forward and backward of a step see the same value.
+SEED_STATE = None
+
 _workspaces = {}
 
 
@@ -180,7 +185,7 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
     check(lib.dcs_cbn_fwd(ptr(x), ptr(y), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_covar),
                           ptr(stats), ptr(coef), ptr(ws), ws.numel(), P, C, eps,
                           -1.0 if momentum is None else momentum, int(bool(use_batch_stats)), act,
-                          float(drop_p), int(seed), cur_stream()), 'dcs_cbn_fwd')
+                          float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_cbn_fwd')
     return y, stats, coef
 
 
@@ -200,7 +205,7 @@ def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, see
     ws = _workspace(nbytes, x.device)
     check(lib.dcs_cbn_bwd(ptr(x), ptr(g_out), ptr(g_x), ptr(weight), ptr(stats), ptr(coef), ptr(g_w), ptr(g_b),
                           ptr(ws), ws.numel(), P, C, int(bool(use_batch_stats)), act, float(drop_p), int(seed),
-                          cur_stream()), 'dcs_cbn_bwd')
+                          ptr(SEED_STATE), cur_stream()), 'dcs_cbn_bwd')
     return g_x, g_w, g_b
 
 
@@ -241,7 +246,7 @@ def attention_apply(x, ca=None, sa=None, drop_p=0.0, seed=0, out=None):
     B, H, W, C, _ = x.shape
     y = torch.empty_like(x) if out is None else out
     check(_lib.load().dcs_attention_apply_fwd(ptr(x), ptr(ca), ptr(sa), ptr(y), B, H * W, C, float(drop_p),
-                                              int(seed), cur_stream()), 'dcs_attention_apply_fwd')
+                                              int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_attention_apply_fwd')
     return y
 
 
@@ -257,7 +262,7 @@ def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop
     lib = _lib.load()
     g_pre = torch.empty((B, H, W, 1, 2), dtype=torch.float32, device=dev)
     check(lib.dcs_attention_bwd_sa(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_pre), B, HW, C, float(drop_p),
-                                   int(seed), cur_stream()), 'dcs_attention_bwd_sa')
+                                   int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_attention_bwd_sa')
     k, pad = (ksize, ksize), (ksize // 2, ksize // 2)
     g_sp, _ = cconv2d_bwd_data(g_pre, pack_conv_weight_bwd(wsa, k, (1, 1), pad), (H, W, 2), k, (1, 1), pad)
     g_c1r, g_c1i, _, _ = cconv2d_bwd_weight(sp, None, g_pre, (1, 2, ksize, ksize), False, k, (1, 1), pad)
@@ -272,7 +277,7 @@ def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop
     ws = _workspace(nbytes, dev)
     check(lib.dcs_attention_bwd_x(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_sp), ptr(pooled), ptr(hidden), ptr(w1),
                                   ptr(w2), ptr(g_x), ptr(g0r), ptr(g0i), ptr(g2r), ptr(g2i), ptr(ws), ws.numel(),
-                                  B, HW, C, Ch, float(drop_p), int(seed), cur_stream()), 'dcs_attention_bwd_x')
+                                  B, HW, C, Ch, float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_attention_bwd_x')
     return g_x, g0r, g0i, g2r, g2i, g_c1r, g_c1i
 
 
@@ -306,7 +311,7 @@ def lstm_layer_bwd(g_out, gates, c, w_hh, n_sets, seqs_per_set, S):
 def dropout(x, drop_p, seed, out=None):
     _chk(x, 'x')
     y = torch.empty_like(x) if out is None else out
-    check(_lib.load().dcs_dropout_fwd(ptr(x), ptr(y), x.numel(), float(drop_p), int(seed), cur_stream()),
+    check(_lib.load().dcs_dropout_fwd(ptr(x), ptr(y), x.numel(), float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()),
           'dcs_dropout_fwd')
     return y
 

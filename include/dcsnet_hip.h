@@ -15,6 +15,8 @@
  *     allocates, frees or retains caller memory; workspaces are passed in.
  *   - Kernels are enqueued on `stream`; no call synchronises.  No global mutable state.
  *   - Return value: 0 = enqueued; <0 = error (DCS_ERR_*), nothing was enqueued.
+ *   - Dropout: mask = hash(seed + *seed_dev, element index); `seed_dev` (device uint64, may be NULL) lets
+ *     a captured hipGraph be replayed with a fresh mask every step.  Backward calls take the same pair.
  *   - Complex tensors are interleaved (re, im) fp32 pairs — the memory of a torch
  *     complex64 tensor.  Activations are CHANNELS-LAST: x[b][f][t][c] complex,
  *     i.e. float[B][F][T][C][2]  (a torch complex64 [B,C,F,T] tensor in
@@ -159,7 +161,7 @@ int  dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bia
                  float* running_mean, float* running_covar,
                  float* stats_out, float* coef_out, void* workspace, long workspace_bytes,
                  long P, int C, float eps, float momentum, int use_batch_stats, int act,
-                 float drop_p, unsigned long long seed, dcs_stream_t stream);
+                 float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
 
 /* Backward of dcs_cbn_fwd (closed form of what autograd derives through complexPyTorch's CBN,
  * the activation and the dropout).  g_out: gradient w.r.t. y; g_x: gradient w.r.t. x (may alias
@@ -170,7 +172,7 @@ long dcs_cbn_bwd_workspace_bytes(long P, int C);
 int  dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const float* weight,
                  const float* stats, const float* coef, float* g_weight, float* g_bias,
                  void* workspace, long workspace_bytes, long P, int C, int use_batch_stats, int act,
-                 float drop_p, unsigned long long seed, dcs_stream_t stream);
+                 float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * ComplexChannelAttention (c_network.py:53-69): per sample, mean over (F,T) of every
@@ -208,7 +210,7 @@ int dcs_spatial_pool_fwd(const float* x, const float* ca, float* pooled,
  */
 int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, float* y,
                             int B, long HW, int C, float drop_p, unsigned long long seed,
-                            dcs_stream_t stream);
+                            const unsigned long long* seed_dev, dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward of the fused attention block  out = dropout(sa (.) ca (.) x)  built from the four
@@ -223,13 +225,13 @@ int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, fl
  *         dcs_channel_attention_fwd; w1 / w2 the packed 1x1 weights.  g_out is the gradient of the
  *         block's output; same drop_p / seed as dcs_attention_apply_fwd. */
 int  dcs_attention_bwd_sa(const float* x, const float* g_out, const float* ca, const float* sa, float* g_pre,
-                          int B, long HW, int C, float drop_p, unsigned long long seed, dcs_stream_t stream);
+                          int B, long HW, int C, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
 long dcs_attention_bwd_workspace_bytes(int B, long HW, int C, int Ch);
 int  dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, const float* sa, const float* g_sp,
                          const float* pooled, const float* hidden, const float* w1, const float* w2,
                          float* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r, float* g_fc2_i,
                          void* workspace, long workspace_bytes, int B, long HW, int C, int Ch,
-                         float drop_p, unsigned long long seed, dcs_stream_t stream);
+                         float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * ComplexLSTM, recurrent half (c_network.py:12-51; built :118-123, called :201).
@@ -257,7 +259,7 @@ int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_sa
  * ComplexLinear; c_network.py:221-222 on the last decoder stage, which has no attention to
  * fuse it into).  n floats; same mask rule as above; y may alias x; drop_p == 0 copies. */
 int dcs_dropout_fwd(const float* x, float* y, long n, float drop_p, unsigned long long seed,
-                    dcs_stream_t stream);
+                    const unsigned long long* seed_dev, dcs_stream_t stream);
 
 /* Stand-alone complexPyTorch surface used only by the layer-by-layer drop-in modules
  * (ComplexReLU config.py:103 / complex_relu, ComplexLReLU, ComplexSigmoid; complex_upsample
@@ -299,12 +301,13 @@ int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs
  * data-parallel averaging (grad_scale = 1/world), Trainer clip-by-global-norm
  * (gradient_clip_val 100, train.py:145-146; `grad_norm` = DEVICE scalar holding the 2-norm of the
  * UNSCALED bucket, NULL or max_norm <= 0 disables clipping) and torch.optim.Adam with L2 weight
- * decay and amsgrad (c_network.py:229-234).  step = 1-based update count.  All buffers 16-byte
- * aligned, float[n]. */
+ * decay and amsgrad (c_network.py:229-234).  step = 1-based update count, or — when step_dev != NULL —
+ * read from that device int (so a captured hipGraph can be replayed while the count advances).  All
+ * buffers 16-byte aligned, float[n]. */
 int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
                           const float* grad_norm, float max_norm, float grad_scale, long n,
                           float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                          dcs_stream_t stream);
+                          const int* step_dev, dcs_stream_t stream);
 
 #ifdef __cplusplus
 }

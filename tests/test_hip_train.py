@@ -96,3 +96,51 @@ def test_train_step_with_reference_dropout_runs_and_is_finite(dev):
     losses = [float(ts(batch)) for _ in range(4)]
     assert all(l == l and abs(l) < 1e4 for l in losses), losses
     assert torch.isfinite(ts.bucket.flat).all()
+
+
+def test_graph_replayed_train_step_matches_eager(dev):
+    """hipGraph capture of forward + losses + backward + fused optimizer: same loss trajectory as eager
+    launches (dropout off), update count and dropout seed advance on the device under replay."""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    clean, noise = seeded_input(2, 256, 32, 1, 0.1), seeded_input(2, 256, 32, 2, 0.05)
+    batch = (noise.to(dev), (clean + noise).to(dev), clean.to(dev), [0, 1])
+    runs = []
+    for use_graph in (False, True):
+        net = fill_state(C_NETWORK(config, hp, 0), 2).to(dev).train()
+        ts = TrainStep(net, use_graph=use_graph, graph_warmup=2)
+        losses = [float(ts(batch)) for _ in range(6)]
+        runs.append((losses, ts))
+    (eager, ts_e), (graph, ts_g) = runs
+    assert ts_g._graph is not None, 'capture did not happen (fell back to eager)'
+    for a, b in zip(eager, graph):
+        assert abs(a - b) <= 1e-3 * abs(a) + 1e-3, (eager, graph)
+    assert int(ts_g.opt.t_dev) == 6 and int(ts_e.opt.t_dev) == 6
+    assert int(ts_g.seed_state) == 6
+    assert torch.allclose(ts_g.bucket.flat, ts_e.bucket.flat, atol=5e-4)
+
+
+def test_graph_replay_draws_fresh_dropout_masks(dev):
+    from dcsnet import ops
+    x = torch.ones(1 << 16, device=dev)
+    state = torch.zeros(1, dtype=torch.int64, device=dev)
+    old = ops.SEED_STATE
+    ops.SEED_STATE = state
+    try:
+        ops.dropout(x, 0.5, 3)                       # warm-up outside capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = ops.dropout(x, 0.5, 3)
+            state += 1
+        g.replay()
+        a = y.clone()
+        g.replay()
+        b = y.clone()
+        assert not torch.equal(a, b)                 # the device-side seed offset advanced
+        assert abs(float((a != 0).float().mean()) - 0.5) < 0.02
+    finally:
+        ops.SEED_STATE = old

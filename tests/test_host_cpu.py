@@ -53,7 +53,7 @@ def test_null_and_bad_arguments_are_rejected_before_any_launch():
     lib = _lib.load()
     assert lib.dcs_bound_crm_fwd(None, None, 10, 1e-6, None) == -1
     assert lib.dcs_cconv2d_fwd(None, None, None, None, None, 1, 1, 1, 1, 0, 1, 1, 1, 3, 3, 1, 1, 1, 1, 0, None) == -1
-    assert lib.dcs_dropout_fwd(None, None, 0, 0.1, 1, None) == -1
+    assert lib.dcs_dropout_fwd(None, None, 0, 0.1, 1, None, None) == -1
 
 
 def test_ops_refuse_cpu_tensors():
@@ -133,3 +133,20 @@ def test_dropin_names_resolve():
         for m in ('c_network', 'network_functions', 'config', 'complexPyTorch', 'complexPyTorch.complexLayers',
                   'complexPyTorch.complexFunctions'):
             sys.modules.pop(m, None)
+
+
+def test_capturable_istft_equals_torch_istft():
+    """network_functions.istft (no host-synchronising NOLA check) reproduces torch.istft and inverts the
+    reference's STFT (n_fft 512, hop 32, hann, normalized: data.py:112-118)."""
+    from dcsnet.network_functions import istft
+    torch.manual_seed(0)
+    w = torch.hann_window(512)
+    for T in (16, 256):
+        x = torch.randn(2, 32 * T - 32)
+        X = torch.stft(x, 512, 32, 512, w, return_complex=True, normalized=True)
+        assert X.shape[-1] == T
+        want = torch.istft(X, 512, 32, 512, w, normalized=True)
+        got = istft(X, 512, 32, w, True)
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) < 5e-6
+        assert float((got - x).abs().max()) < 5e-6
