@@ -51,6 +51,7 @@ class FlatBucket:
                 self.flat[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
+                p._dcs_grad_sink = p.grad        # backward kernels write here directly (functional._sink)
         self.offsets = offs
 
     def zero_grad(self):
@@ -58,6 +59,7 @@ class FlatBucket:
         for p, o in zip(self.params, self.offsets):        # re-attach if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p._dcs_grad_sink = p.grad
 
     def allreduce(self):
         """Sum over ranks, in place; the 1/world factor is folded into the optimizer kernel."""

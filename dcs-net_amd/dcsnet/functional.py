@@ -49,6 +49,23 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1)):
     return packed
 
 
+sink_hits = 0          # diagnostics: how many parameter gradients were routed to a sink
+
+
+def _sink(p):
+    """Destination registered by dp.FlatBucket for this parameter's gradient (a view of the flat gradient
+    bucket that IS p.grad), or None.  Backward kernels then write there directly and return None to
+    autograd: no temporary, no per-parameter accumulate kernel (~200 tiny launches per step)."""
+    if p is None or not p.requires_grad:
+        return None
+    s = getattr(p, '_dcs_grad_sink', None)
+    if s is None or p.grad is None or p.grad.data_ptr() != s.data_ptr():
+        return None
+    global sink_hits
+    sink_hits += 1
+    return s
+
+
 class _CConv2dFn(torch.autograd.Function):
     """dcs_cconv2d_fwd with its hand-written data / weight gradients."""
 
@@ -58,6 +75,7 @@ class _CConv2dFn(torch.autograd.Function):
         y = ops.cconv2d(x1, x2, wp, bias, ksize, stride, pad, up, act)
         ctx.geom = (transposed, tuple(ksize), tuple(stride), tuple(pad), tuple(up), act, tuple(w_r.shape),
                     b_r is not None)
+        ctx.sinks = (_sink(w_r), _sink(w_i), _sink(b_r), _sink(b_i))
         ctx.save_for_backward(x1, x2, wp, y if act == ACT_SIGMOID else None)
         return y
 
@@ -78,8 +96,9 @@ class _CConv2dFn(torch.autograd.Function):
             gx1, gx2 = ops.cconv2d_bwd_data(gy, ops.pack_conv_weight_bwd(wp, ksize, stride, pad, up),
                                             (x1.shape[1], x1.shape[2], Cin), ksize, stride, pad, up, C1)
         if need[2] or need[3] or need[4] or need[5]:
-            gw_r, gw_i, gb_r, gb_i = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up,
-                                                           transposed)
+            g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks)
+            # gradients written straight into their sink are not handed back to autograd
+            gw_r, gw_i, gb_r, gb_i = (None if sk is not None else t for t, sk in zip(g, ctx.sinks))
         return gx1, gx2, gw_r, gw_i, gb_r, gb_i, None, None, None, None, None, None
 
 
@@ -96,6 +115,7 @@ class _CbnFn(torch.autograd.Function):
         y, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats,
                                  act, drop_p, seed)
         ctx.cfg = (bool(use_batch_stats), act, float(drop_p), int(seed), weight is not None)
+        ctx.sinks = (_sink(weight), _sink(bias))
         ctx.save_for_backward(x, weight, stats, coef)
         return y
 
@@ -103,7 +123,10 @@ class _CbnFn(torch.autograd.Function):
     def backward(ctx, g_out):
         x, weight, stats, coef = ctx.saved_tensors
         use_batch, act, drop_p, seed, affine = ctx.cfg
-        g_x, g_w, g_b = ops.cbn_bwd(x, g_out.contiguous(), weight, stats, coef, use_batch, act, drop_p, seed, affine)
+        g_x, g_w, g_b = ops.cbn_bwd(x, g_out.contiguous(), weight, stats, coef, use_batch, act, drop_p, seed, affine,
+                                    ctx.sinks)
+        g_w = None if ctx.sinks[0] is not None else g_w
+        g_b = None if ctx.sinks[1] is not None else g_b
         return g_x, g_w, g_b, None, None, None, None, None, None, None, None
 
 
@@ -148,6 +171,7 @@ class _AttentionFn(torch.autograd.Function):
                          ACT_SIGMOID)
         out = ops.attention_apply(x, ca, sa, drop_p, seed)
         ctx.cfg = (ksize, float(drop_p), int(seed))
+        ctx.sinks = tuple(_sink(t) for t in (fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i))
         ctx.save_for_backward(x, ca, sa, sp, pooled, hidden, w1, w2, wsa)
         return out
 
@@ -155,8 +179,10 @@ class _AttentionFn(torch.autograd.Function):
     def backward(ctx, g_out):
         x, ca, sa, sp, pooled, hidden, w1, w2, wsa = ctx.saved_tensors
         ksize, drop_p, seed = ctx.cfg
-        g = ops.attention_bwd(x, g_out.contiguous(), ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p, seed)
-        return (*g, None, None, None)
+        g = ops.attention_bwd(x, g_out.contiguous(), ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p, seed,
+                              ctx.sinks)
+        gw = tuple(None if sk is not None else t for t, sk in zip(g[1:], ctx.sinks))
+        return (g[0], *gw, None, None, None)
 
 
 def attention_block(x, fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p=0.0, seed=0):

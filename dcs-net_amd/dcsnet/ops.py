@@ -136,8 +136,9 @@ def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=Non
     return gx1, gx2
 
 
-def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1, 1), transposed=False):
-    """Gradients in the reference's parameter layout: (gw_r, gw_i, gb_r, gb_i)."""
+def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1, 1), transposed=False, outs=None):
+    """Gradients in the reference's parameter layout: (gw_r, gw_i, gb_r, gb_i).  `outs`: optional
+    pre-existing destinations (e.g. views of a flat gradient bucket) for any of the four."""
     _chk(x1, 'x1', 5)
     _chk(x2, 'x2', 5)
     _chk(gy, 'gy', 5)
@@ -145,10 +146,13 @@ def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1,
     C2 = 0 if x2 is None else x2.shape[3]
     Cout = gy.shape[3]
     dev = gy.device
-    gw_r = torch.empty(w_shape, dtype=torch.float32, device=dev)
-    gw_i = torch.empty(w_shape, dtype=torch.float32, device=dev)
-    gb_r = torch.empty(Cout, dtype=torch.float32, device=dev) if has_bias else None
-    gb_i = torch.empty(Cout, dtype=torch.float32, device=dev) if has_bias else None
+    o = outs or (None, None, None, None)
+    gw_r = o[0] if o[0] is not None else torch.empty(w_shape, dtype=torch.float32, device=dev)
+    gw_i = o[1] if o[1] is not None else torch.empty(w_shape, dtype=torch.float32, device=dev)
+    gb_r = (o[2] if o[2] is not None else torch.empty(Cout, dtype=torch.float32, device=dev)) if has_bias else None
+    gb_i = (o[3] if o[3] is not None else torch.empty(Cout, dtype=torch.float32, device=dev)) if has_bias else None
+    for n, t in (('gw_r', gw_r), ('gw_i', gw_i), ('gb_r', gb_r), ('gb_i', gb_i)):
+        _chk(t, n)
     lib = _lib.load()
     geo = (B, Hin, Win, C1, C2, up[0], up[1], Cout, ksize[0], ksize[1], stride[0], stride[1], pad[0], pad[1])
     nbytes = lib.dcs_cconv2d_bwd_weight_workspace_bytes(*geo)
@@ -189,15 +193,17 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
     return y, stats, coef
 
 
-def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, seed=0, affine=True):
-    """Backward of cbn(): returns (g_x, g_weight [C,3], g_bias [C,2])."""
+def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, seed=0, affine=True, outs=None):
+    """Backward of cbn(): returns (g_x, g_weight [C,3], g_bias [C,2]).  `outs`: optional destinations for
+    (g_weight, g_bias)."""
     _chk(x, 'x', 5)
     _chk(g_out, 'g_out', 5)
     B, H, W, C, _ = x.shape
     P = B * H * W
     g_x = torch.empty_like(x)
-    g_w = torch.empty((C, 3), dtype=torch.float32, device=x.device) if affine else None
-    g_b = torch.empty((C, 2), dtype=torch.float32, device=x.device) if affine else None
+    o = outs or (None, None)
+    g_w = (o[0] if o[0] is not None else torch.empty((C, 3), dtype=torch.float32, device=x.device)) if affine else None
+    g_b = (o[1] if o[1] is not None else torch.empty((C, 2), dtype=torch.float32, device=x.device)) if affine else None
     lib = _lib.load()
     nbytes = lib.dcs_cbn_bwd_workspace_bytes(P, C)
     if nbytes < 0:
@@ -250,7 +256,7 @@ def attention_apply(x, ca=None, sa=None, drop_p=0.0, seed=0, out=None):
     return y
 
 
-def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p=0.0, seed=0):
+def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p=0.0, seed=0, outs=None):
     """Backward of the fused attention block.  Returns (g_x, g_fc0_r, g_fc0_i, g_fc2_r, g_fc2_i,
     g_conv1_r, g_conv1_i) with the weight gradients in the reference's parameter layout."""
     _chk(x, 'x', 5)
@@ -265,12 +271,15 @@ def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop
                                    int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_attention_bwd_sa')
     k, pad = (ksize, ksize), (ksize // 2, ksize // 2)
     g_sp, _ = cconv2d_bwd_data(g_pre, pack_conv_weight_bwd(wsa, k, (1, 1), pad), (H, W, 2), k, (1, 1), pad)
-    g_c1r, g_c1i, _, _ = cconv2d_bwd_weight(sp, None, g_pre, (1, 2, ksize, ksize), False, k, (1, 1), pad)
+    o = outs or (None,) * 6
+    g_c1r, g_c1i, _, _ = cconv2d_bwd_weight(sp, None, g_pre, (1, 2, ksize, ksize), False, k, (1, 1), pad,
+                                            outs=(o[4], o[5], None, None))
     g_x = torch.empty_like(x)
-    g0r = torch.empty((Ch, C, 1, 1), dtype=torch.float32, device=dev)
-    g0i = torch.empty_like(g0r)
-    g2r = torch.empty((C, Ch, 1, 1), dtype=torch.float32, device=dev)
-    g2i = torch.empty_like(g2r)
+    new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    g0r = o[0] if o[0] is not None else new((Ch, C, 1, 1))
+    g0i = o[1] if o[1] is not None else new((Ch, C, 1, 1))
+    g2r = o[2] if o[2] is not None else new((C, Ch, 1, 1))
+    g2i = o[3] if o[3] is not None else new((C, Ch, 1, 1))
     nbytes = lib.dcs_attention_bwd_workspace_bytes(B, HW, C, Ch)
     if nbytes < 0:
         raise _lib.DcsHipError(f'attention_bwd: unsupported channel count C={C}')

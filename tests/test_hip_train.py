@@ -144,3 +144,32 @@ def test_graph_replay_draws_fresh_dropout_masks(dev):
         assert abs(float((a != 0).float().mean()) - 0.5) < 0.02
     finally:
         ops.SEED_STATE = old
+
+
+def test_backward_kernels_write_into_the_flat_gradient_bucket(dev):
+    """With a FlatBucket attached, conv / CBN / attention backward write parameter gradients straight into
+    the bucket (no per-parameter accumulate kernels), and the result equals plain autograd accumulation."""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import FlatBucket
+    from dcsnet import functional
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    x = seeded_input(2, 256, 32, 3).to(dev)
+
+    def grads(with_bucket):
+        net = fill_state(C_NETWORK(config, hp, 0), 4).to(dev).train()
+        bucket = FlatBucket(net) if with_bucket else None
+        if bucket:
+            bucket.zero_grad()
+        out = net(x)
+        (out.real ** 2 + 0.3 * out.imag).sum().backward()
+        return {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    before = functional.sink_hits
+    a = grads(True)
+    assert functional.sink_hits - before > 150          # ~190 conv / CBN / attention parameter tensors
+    b = grads(False)
+    assert a.keys() == b.keys()
+    for n in a:
+        assert torch.allclose(a[n], b[n], rtol=1e-5, atol=1e-7), n
