@@ -185,6 +185,26 @@ def cnet_vectors(cn, nf):
     return res
 
 
+def rnet_vectors(rn, nf):
+    """BASELINE configs[0]: R_NETWORK (DR-Net), B=1, real magnitude input, CPU."""
+    from oracle.seeded_state import seeded_input, fill_state_stream
+    cfg = _ref_config(nf)
+    cfg.RactivationE, cfg.RactivationD = torch.nn.ReLU, torch.nn.LeakyReLU
+    res = {}
+    for tag, (B, T) in (('b1t256', (1, 256)), ('b2t32', (2, 32))):
+        net = rn.R_NETWORK(cfg, _ref_hparams(dropout=False), 0)
+        fill_state_stream(net, 5)
+        x = seeded_input(B, 256, T, seed=9).abs()
+        res[f'{tag}_x'] = _c(x)
+        net.eval()
+        with torch.no_grad():
+            res[f'{tag}_eval'] = _c(net(x))
+        net.train()
+        with torch.no_grad():
+            res[f'{tag}_train'] = _c(net(x))
+    return res
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit('reference not mounted: fixtures can only be generated in the build container')
@@ -195,11 +215,13 @@ def main():
     sys.argv = ['train.py', 'dcs', '0']          # network_functions.py / c_network.py read sys.argv[1]
     import network_functions as nf
     import c_network as cn
+    import r_network as rn
     sys.argv = argv
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)                      # bit-stable reductions
     np.savez_compressed(os.path.join(OUT, 'nf_vectors.npz'), **nf_vectors(nf))
     np.savez_compressed(os.path.join(OUT, 'cnet_vectors.npz'), **cnet_vectors(cn, nf))
+    np.savez_compressed(os.path.join(OUT, 'rnet_vectors.npz'), **rnet_vectors(rn, nf))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -72,3 +72,19 @@ def seeded_input(B, F, T, seed=0, scale=1.0):
     re = torch.randn((B, F, T), generator=g) * scale
     im = torch.randn((B, F, T), generator=g) * scale
     return torch.complex(re, im)
+
+
+@torch.no_grad()
+def fill_state_stream(module, seed=5):
+    """Stock torch.nn models (the real-valued R_NETWORK): every parameter / buffer drawn from ONE seeded
+    stream in sorted-key order; running variances kept positive."""
+    g = torch.Generator().manual_seed(seed)
+    for k, v in sorted(module.state_dict().items()):
+        if k.endswith('num_batches_tracked'):
+            continue
+        if k.endswith('running_var'):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        else:
+            fan = v[0].numel() if v.dim() > 1 else 16
+            v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * (1.5 / max(fan, 1)) ** 0.5)
+    return module

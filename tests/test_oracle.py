@@ -185,3 +185,27 @@ def test_state_dict_contract():
         assert k in keys, k
     n_train = sum(p.numel() for p in net.parameters())
     assert n_train == 2912707
+
+
+# ---- BASELINE configs[0]: DR-Net (r_network.py), CPU plumbing --------------------------------------
+
+@pytest.mark.parametrize('tag,B,T', [('b1t256', 1, 256), ('b2t32', 2, 32)])
+def test_rnetwork_oracle_against_reference(golden_dir, tag, B, T):
+    from oracle.rnet_oracle import R_NETWORK_Oracle
+    from oracle.seeded_state import fill_state_stream
+    v = np.load(os.path.join(golden_dir, 'rnet_vectors.npz'))
+    net = fill_state_stream(R_NETWORK_Oracle(dropout_conv=0.0, dropout_fc=0.0), 5)
+    assert sum(p.numel() for p in net.parameters()) == 5808753
+    x = _t(v[f'{tag}_x'])
+    assert tuple(x.shape) == (B, 256, T) and x.dtype == torch.float32
+    net.eval()
+    with torch.no_grad():
+        ev = net(x)
+    want = _t(v[f'{tag}_eval'])
+    assert ev.shape == want.shape                                         # [256, T] when B == 1
+    assert torch.allclose(ev, want, rtol=1e-5, atol=1e-6), float((ev - want).abs().max())
+    net.train()
+    with torch.no_grad():
+        tr = net(x)
+    assert torch.allclose(tr, _t(v[f'{tag}_train']), rtol=1e-5, atol=1e-6)
+    assert float(ev.min()) >= 0.0 and float(ev.max()) <= 1.0              # sigmoid magnitude mask
