@@ -110,12 +110,21 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
     const int nc = min(CHUNK, Cin - ci0), nco = min(WG_CO, a.Cout - co0);
     const int per_tap = nc * nco, n_out = ntaps * per_tap;
 
+    // few outputs (Cout = 1 layers: 72..98): Q thread groups take every Q-th pixel of a tile each and are
+    // combined through LDS once, after the last tile, so all 256 lanes work
+    int Q = 1, q = 0, o0 = t;
+    if (SLOTS == 1 && 2 * n_out <= TH * TW) {
+        Q = (TH * TW) / n_out;
+        q = t / n_out;
+        o0 = q < Q ? t % n_out : n_out;                   // lanes beyond Q * n_out stay idle
+    }
+
     float accr[SLOTS], acci[SLOTS];
     int xoff[SLOTS], goff[SLOTS];
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
         accr[i] = 0.f; acci[i] = 0.f;
-        const int o = t + TH * TW * i;
+        const int o = o0 + TH * TW * i;
         const int tap = o < n_out ? o / per_tap : 0, r = o < n_out ? o % per_tap : 0;
         xoff[i] = (r / nco) * a.plane + (tap / a.kw) * a.colsp + (tap % a.kw);
         goff[i] = r % nco;
@@ -143,11 +152,11 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
         }
         __syncthreads();
 #pragma unroll 4
-        for (int p = 0; p < TH * TW; ++p) {
+        for (int p = q; p < TH * TW; p += Q) {
             const int base = ((p / TW) * a.sf) * a.colsp + (p % TW) * a.st;
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i) {
-                if (t + TH * TW * i < n_out) {
+                if (o0 + TH * TW * i < n_out) {
                     const float2 g = gt[p * WG_CO + goff[i]];
                     const float2 xv = tile[xoff[i] + base];
                     // g * conj(x)
@@ -166,9 +175,19 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
         }
     }
     const long wsz = (long)ntaps * Cin * a.Cout;
+    if (Q > 1) {                                          // combine the pixel shares (SLOTS == 1 here)
+        __syncthreads();
+        if (o0 < n_out) lds[q * n_out + o0] = make_float2(accr[0], acci[0]);
+        __syncthreads();
+        if (q == 0) {
+            for (int k = 1; k < Q; ++k) { const float2 v = lds[k * n_out + o0]; accr[0] += v.x; acci[0] += v.y; }
+        } else {
+            o0 = n_out;                                   // only group 0 writes the slab
+        }
+    }
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
-        const int o = t + TH * TW * i;
+        const int o = o0 + TH * TW * i;
         if (o < n_out) {
             const int tap = o / per_tap, r = o % per_tap;
             w.slab_w[(long)blockIdx.x * wsz + ((long)tap * Cin + ci0 + r / nco) * a.Cout + co0 + r % nco] =
