@@ -51,3 +51,89 @@ extern "C" int dcs_complex_upsample_fwd(const float* x, float* y, int B, int H, 
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
+
+// ---- tap-sum: the spatial half of a Cout = 1 convolution ---------------------------------------------
+// For a conv with ONE output channel (dec6: ComplexConvTranspose2d 16 -> 1, c_network.py:135-141) the channel
+// contraction and the spatial gather commute:  y[o] = sum_tap ( sum_ci W[tap][ci] x[src(o,tap)][ci] ).
+// The inner sum is a 1x1 conv 16 -> 9 "tap channels" on the SOURCE-resolution tensor — an MFMA GEMM with full
+// lanes (K = 32, N = 18) instead of an N = 2 one — and this kernel is the outer sum: 9 shifted loads per
+// output pixel (nearest upsample resolved in the index).  Both passes are HBM-bound.
+namespace {
+// y[b][oy][ox] = sum_{dy,dx} z[b][(oy-pad_f+dy)/up_f][(ox-pad_t+dx)/up_t][dy*kw+dx]
+__global__ __launch_bounds__(kThreads) void tapsum_fwd_kernel(const float2* __restrict__ z, float2* __restrict__ y,
+                                                               int B, int Hs, int Ws, int CT, int kh, int kw, int up_f,
+                                                               int up_t, int pad_f, int pad_t) {
+    const int Ho = Hs * up_f, Wo = Ws * up_t;
+    const long n = (long)B * Ho * Wo;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+        const int ox = (int)(i % Wo);
+        long r = i / Wo;
+        const int oy = (int)(r % Ho), b = (int)(r / Ho);
+        float sr = 0.f, si = 0.f;
+        for (int dy = 0; dy < kh; ++dy) {
+            const int vy = oy - pad_f + dy;
+            if (vy < 0 || vy >= Ho) continue;
+            for (int dx = 0; dx < kw; ++dx) {
+                const int vx = ox - pad_t + dx;
+                if (vx < 0 || vx >= Wo) continue;
+                const float2 v = z[(((long)b * Hs + vy / up_f) * Ws + vx / up_t) * CT + dy * kw + dx];
+                sr += v.x; si += v.y;
+            }
+        }
+        y[i] = make_float2(sr, si);
+    }
+}
+
+// gz[b][my][mx][tap] = sum over the output pixels that read z[b][my][mx][tap] in the forward pass
+__global__ __launch_bounds__(kThreads) void tapsum_bwd_kernel(const float2* __restrict__ gy, float2* __restrict__ gz,
+                                                               int B, int Hs, int Ws, int CT, int kh, int kw, int up_f,
+                                                               int up_t, int pad_f, int pad_t) {
+    const int Ho = Hs * up_f, Wo = Ws * up_t;
+    const long n = (long)B * Hs * Ws * CT;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+        const int tap = (int)(i % CT);
+        long r = i / CT;
+        const int mx = (int)(r % Ws); r /= Ws;
+        const int my = (int)(r % Hs), b = (int)(r / Hs);
+        float sr = 0.f, si = 0.f;
+        if (tap < kh * kw) {
+            const int dy = tap / kw, dx = tap % kw;
+            for (int jy = 0; jy < up_f; ++jy) {
+                const int oy = up_f * my + pad_f - dy + jy;
+                if (oy < 0 || oy >= Ho) continue;
+                for (int jx = 0; jx < up_t; ++jx) {
+                    const int ox = up_t * mx + pad_t - dx + jx;
+                    if (ox < 0 || ox >= Wo) continue;
+                    const float2 v = gy[((long)b * Ho + oy) * Wo + ox];
+                    sr += v.x; si += v.y;
+                }
+            }
+        }
+        gz[i] = make_float2(sr, si);
+    }
+}
+}  // namespace
+
+extern "C" int dcs_tapsum_fwd(const float* z, float* y, int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t,
+                              int pad_f, int pad_t, dcs_stream_t stream) {
+    if (!z || !y || B <= 0 || Hs <= 0 || Ws <= 0 || kh < 1 || kw < 1 || CT < kh * kw || up_f < 1 || up_t < 1 ||
+        pad_f < 0 || pad_t < 0)
+        return DCS_ERR_BADARG;
+    const long n = (long)B * Hs * up_f * Ws * up_t;
+    hipLaunchKernelGGL(tapsum_fwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
+                       (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_tapsum_bwd(const float* gy, float* gz, int B, int Hs, int Ws, int CT, int kh, int kw, int up_f,
+                              int up_t, int pad_f, int pad_t, dcs_stream_t stream) {
+    if (!gy || !gz || B <= 0 || Hs <= 0 || Ws <= 0 || kh < 1 || kw < 1 || CT < kh * kw || up_f < 1 || up_t < 1 ||
+        pad_f < 0 || pad_t < 0)
+        return DCS_ERR_BADARG;
+    const long n = (long)B * Hs * Ws * CT;
+    hipLaunchKernelGGL(tapsum_bwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)gy,
+                       (float2*)gz, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

@@ -202,9 +202,14 @@ class C_NETWORK(LightningModule):
             skip = self._attend(self.skip_attention[2 * i], self.skip_attention[2 * i + 1], enc[L - i])
             stage = self.decoder[i]
             convt = stage if i == L - 1 else stage[0]
-            y = F.cconv2d(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight, convt.conv_tran_r.bias,
-                          convt.conv_tran_i.bias, True, convt.kernel_size, (1, 1), convt.corr_padding,
-                          tuple(cfg.upsample_scale_factor[i]))
+            up = tuple(cfg.upsample_scale_factor[i])
+            if convt.conv_tran_r.out_channels == 1 and (d.shape[3] + skip.shape[3]) % 8 == 0:
+                y = F.cconv_single_output(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight,
+                                          convt.conv_tran_r.bias, convt.conv_tran_i.bias, convt.kernel_size,
+                                          convt.corr_padding, up)
+            else:
+                y = F.cconv2d(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight, convt.conv_tran_r.bias,
+                              convt.conv_tran_i.bias, True, convt.kernel_size, (1, 1), convt.corr_padding, up)
             dp, seed = self._drop(p_conv)
             if i != L - 1:
                 a = self._bn(stage[1], y, F.ACT_LRELU)

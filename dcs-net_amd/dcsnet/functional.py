@@ -301,6 +301,40 @@ def complex_lstm(z, real_lstm, imag_lstm):
     return torch.complex(rr - ii, ir + ri)
 
 
+class _TapSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, ksize, up, pad):
+        ctx.cfg = (tuple(z.shape), tuple(ksize), tuple(up), tuple(pad))
+        return ops.tapsum(z, ksize, up, pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, ksize, up, pad = ctx.cfg
+        return ops.tapsum(shape, ksize, up, pad, backward=True, grad=g.contiguous()), None, None, None
+
+
+def cconv_single_output(x1, x2, w_r, w_i, b_r, b_i, ksize, pad, up):
+    """Stride-1 ComplexConvTranspose2d with ONE output channel over upsample(cat(x1, x2)) (the last decoder
+    stage).  Cout = 1 would leave the MFMA tile's N dimension 2 wide, so the stage is factored as
+        y = tapsum( conv1x1(cat(x1, x2): Cin -> kh*kw tap channels) ) + bias
+    where the 1x1 weight row `tap` is the (flipped) transposed-conv kernel at that tap: a full-lane MFMA GEMM
+    at SOURCE resolution plus an HBM-bound 9-load gather (elementwise.hip).  w_*: [Cin, 1, kh, kw]."""
+    kh, kw = ksize
+    taps = kh * kw
+    ct = (taps + 7) // 8 * 8                                   # tap channels, padded for the MFMA N tile
+
+    def tap_rows(w):                                           # [Cin,1,kh,kw] -> [ct, Cin, 1, 1], correlation order
+        rows = w[:, 0].flip(1, 2).reshape(w.shape[0], taps).t()
+        return torch.nn.functional.pad(rows, (0, 0, 0, ct - taps)).reshape(ct, w.shape[0], 1, 1).contiguous()
+
+    z = cconv2d(x1, x2, tap_rows(w_r), tap_rows(w_i), None, None, False, (1, 1), (1, 1), (0, 0))
+    # stride-1 transposed conv == correlation with padding k-1-p (already in `pad`)
+    y = _TapSumFn.apply(z, (kh, kw), tuple(up), tuple(pad))
+    if b_r is not None:
+        y = y + torch.stack((b_r - b_i, b_r + b_i), dim=-1).view(1, 1, 1, 1, 2)
+    return y
+
+
 class _DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, drop_p, seed):

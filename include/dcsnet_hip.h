@@ -270,6 +270,18 @@ int dcs_complex_act_fwd(const float* x, float* y, long n_floats, int act, dcs_st
 int dcs_complex_upsample_fwd(const float* x, float* y, int B, int H, int W, int C, int up_f, int up_t,
                              dcs_stream_t stream);
 
+/* Tap-sum: the spatial half of a convolution with ONE output channel (the last decoder stage,
+ * ComplexConvTranspose2d 16 -> 1 behind cat + x2 upsample: c_network.py:135-141, :214-217).  With Cout = 1 the
+ * channel contraction and the spatial gather commute, so the stage runs as a 1x1 complex conv 16 -> kh*kw "tap
+ * channels" on the SOURCE-resolution tensors (dcs_cconv2d_fwd: an MFMA GEMM with full lanes) followed by
+ *     y[b][oy][ox] = sum_{dy,dx} z[b][(oy - pad_f + dy)/up_f][(ox - pad_t + dx)/up_t][dy*kw + dx]
+ * z: complex[B][Hs][Ws][CT] (CT >= kh*kw tap channels, extra ones ignored); y: complex[B][Hs*up_f][Ws*up_t].
+ * dcs_tapsum_bwd is its adjoint: gz from gy (unused tap channels get zeros). */
+int dcs_tapsum_fwd(const float* z, float* y, int B, int Hs, int Ws, int CT, int kh, int kw,
+                   int up_f, int up_t, int pad_f, int pad_t, dcs_stream_t stream);
+int dcs_tapsum_bwd(const float* gy, float* gz, int B, int Hs, int Ws, int CT, int kh, int kw,
+                   int up_f, int up_t, int pad_f, int pad_t, dcs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * bound_cRM (network_functions.py:77-88), as called at c_network.py:225:
  *     m = tanh|M| ; phi1 = atan2(Mi, Mr+eps) ; phi2 = atan2(m sin phi1, m cos phi1 + eps)
