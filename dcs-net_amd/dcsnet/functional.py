@@ -385,6 +385,26 @@ class _BoundMaskApplyFn(torch.autograd.Function):
         return None, ops.bound_mask_apply_bwd(Y, M_in, c(gM), c(gN), c(gS), ctx.eps), None
 
 
+class _PolarPadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, Fp, eps):
+        ctx.cfg = (Fp, eps)
+        ctx.save_for_backward(z)
+        return ops.polar_pad(z, Fp, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        return ops.polar_pad(z, ctx.cfg[0], ctx.cfg[1], grad=g.contiguous()), None, None
+
+
+def polar_pad_complex(z, pad_bins=1, eps=10e-7):
+    """|z| (cos phi + j sin phi), phi = atan2(z_i, z_r + eps), with `pad_bins` zero bins appended on the
+    frequency axis: the spectrum mag_phase_2_wave hands to the iSTFT (network_functions.py:140-145)."""
+    zr = torch.view_as_real(z.contiguous())
+    return torch.view_as_complex(_PolarPadFn.apply(zr, z.shape[1] + pad_bins, eps))
+
+
 def bound_crm_complex(M, eps=10e-7):
     return torch.view_as_complex(bound_crm(torch.view_as_real(M.contiguous()), eps))
 

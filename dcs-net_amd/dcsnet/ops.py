@@ -390,6 +390,22 @@ def bound_mask_apply_bwd(Y, M_in, g_M, g_N, g_S, eps=10e-7):
     return g
 
 
+def polar_pad(z, Fp, eps=10e-7, grad=None):
+    """z: float [B,F,T,2].  Forward (grad None): [B,Fp,T,2] = |z| unit(z_r+eps, z_i), zero rows F..Fp-1.
+    With grad [B,Fp,T,2]: the cotangent of z."""
+    _chk(z, 'z', 4)
+    B, F, T, _ = z.shape
+    lib = _lib.load()
+    if grad is None:
+        out = torch.empty((B, Fp, T, 2), dtype=torch.float32, device=z.device)
+        check(lib.dcs_polar_pad_fwd(ptr(z), ptr(out), B, F, Fp, T, eps, cur_stream()), 'dcs_polar_pad_fwd')
+        return out
+    _chk(grad, 'grad', 4)
+    gz = torch.empty_like(z)
+    check(lib.dcs_polar_pad_bwd(ptr(z), ptr(grad), ptr(gz), B, F, Fp, T, eps, cur_stream()), 'dcs_polar_pad_bwd')
+    return gz
+
+
 def crm(S, Y, eps=1e-8):
     _chk(S, 'S')
     _chk(Y, 'Y')

@@ -305,6 +305,14 @@ int dcs_bound_mask_apply_fwd(const float* Y, const float* M_in, float* M_out, fl
 int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const float* g_M, const float* g_N,
                              const float* g_S, float* g_Min, long n, float eps, dcs_stream_t stream);
 
+/* Polar round trip + zero-bin pad in front of every iSTFT of the step functions
+ * (network_functions.py:140-145 via :213-221 and :244-247): out = |z| (cos phi + j sin phi), phi = atan2(z_i, z_r + eps),
+ * for bins f < F, zeros for the padded bins F..Fp-1.  z: complex[B][F][T]; out / g_out: complex[B][Fp][T].
+ * dcs_polar_pad_bwd: cotangent of z from the cotangent of out. */
+int dcs_polar_pad_fwd(const float* z, float* out, long B, int F, int Fp, int T, float eps, dcs_stream_t stream);
+int dcs_polar_pad_bwd(const float* z, const float* g_out, float* g_z, long B, int F, int Fp, int T, float eps,
+                      dcs_stream_t stream);
+
 /* cRM target mask (network_functions.py:62-75): M = S conj(Y) / (|Y|^2 + 1e-8). */
 int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs_stream_t stream);
 

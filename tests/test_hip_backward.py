@@ -279,3 +279,29 @@ def test_network_gradients_against_reference_vectors(dev, golden_dir):
             n = k[len(f'{tag}_grad_'):]
             if not _bias_before_bn(n):
                 close(pd[n].grad, torch.from_numpy(cnv[k]), rel=2e-3, abs_=1e-6, what=n)
+
+
+def test_polar_pad_forward_and_backward(dev):
+    """The fused polar round trip in front of the iSTFT vs the reference's op chain (network_functions.py:140-145,
+    :213-221): |z| cos/sin(atan2(z_i, z_r + eps)), one zero bin appended."""
+    from dcsnet import functional as F
+    eps = 10e-7
+    z0 = rand_c((2, 64, 24), 3, 0.8)
+    z0.view(-1)[:3] = torch.tensor([0 + 0j, -0.5 + 0j, 1e-4 - 2e-4j])
+
+    def ref(z):
+        mag, ph = torch.abs(z), torch.atan2(z.imag, z.real + eps)
+        return torch.nn.functional.pad(torch.complex(mag * torch.cos(ph), mag * torch.sin(ph)), (0, 0, 0, 1))
+
+    z = z0.clone().requires_grad_(True)
+    want = ref(z)
+    functional_loss(want, 7).backward()
+    zd = z0.to(dev).requires_grad_(True)
+    got = F.polar_pad_complex(zd, 1, eps)
+    assert got.shape == (2, 65, 24)
+    close(got, want, rel=0, abs_=2e-6, what='forward')
+    functional_loss(got, 7).backward()
+    ok = torch.ones(z0.shape, dtype=torch.bool)
+    ok.view(-1)[:2] = False                       # origin / branch cut: atan2 is singular there
+    close(zd.grad.cpu()[ok], z.grad[ok], rel=2e-4, what='g_z')
+    assert torch.isfinite(torch.view_as_real(zd.grad)).all()
