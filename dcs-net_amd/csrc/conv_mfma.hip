@@ -19,13 +19,12 @@
 // fp32-input MFMA is exact fp32 (bit-for-bit an fmaf chain), 157 TFLOP/s peak: the same numerics
 // as the direct kernel at ~6x its VALU rate.
 #include "conv_common.h"
+#include <cstdlib>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CHUNK = 8;       // complex input channels staged per LDS pass (= 2 k-groups of 4)
-constexpr int PIX = 20;        // LDS floats per patch pixel: 16 + 4 pad
 
 struct MArgs {
     conv::Args c;              // c.Hout / c.Wout: FULL output extent (addressing); c.sf / c.st: stride in class space
@@ -37,10 +36,17 @@ struct MArgs {
     conv::Cls cls[4];          //   (oy*os_f + oo_f, ox*os_t + oo_t) and has its own sub-kernel / padding / panel
 };
 
-// wave grid: WAVES_N waves along N, 4/WAVES_N along M; each wave owns WM x WN tiles of 32x32
-template <int WAVES_N, int WM, int WN>
+// wave grid: WAVES_N waves along N, 4/WAVES_N along M; each wave owns WM x WN tiles of 32x32.
+// CH complex input channels are staged per LDS pass (U = CH/4 k-groups per tap): the gather is latency- not
+// bandwidth-bound, so a deeper chunk amortises its two barriers and one memory round trip over U/2 x the MFMA work.
+// Software pipeline per wave, all register indices static (the tap loop body is unrolled over the U k-groups):
+//   B fragments  ring of R = min(U,4) slots, each refilled right after use with the fragment R iterations ahead
+//                (across tap and chunk boundaries; a short-tile iteration is ~256 cycles < one L2 round trip)
+//   A fragments  two register sets alternating by k-group parity, loaded one iteration ahead
+template <int WAVES_N, int WM, int WN, int CH>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
+    constexpr int U = CH / 4, R = U < 4 ? U : 4, PIX = 2 * CH + 4, Q = CH / 2;
     const conv::Args& a = m.c;
     const conv::Cls& k = m.cls[blockIdx.z];
     // pixels per workgroup = (4 / WAVES_N) * WM * 32 = TH * TW
@@ -76,52 +82,74 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int n_chunks = Cin / CHUNK;
-    const int npix = rows * cols;
+    const int n_chunks = Cin / CH;
+    const int nslots = rows * cols * Q;                                // float4 (2 complex) slots of one patch chunk
+
+    // fragment of (chunk c, tap tp, k-group g); past the last chunk: nothing to fetch
+    auto bload = [&](float4* dst, int c, int tp, int g) {
+        if (tp >= ntaps) { tp = 0; ++c; }
+        if (c < n_chunks) {
+            const float* bp = bbase + tp * b_tap_stride + (long)(c * U + g) * b_kg_stride;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) dst[j] = *reinterpret_cast<const float4*>(bp + j * 256);
+        }
+    };
+    float4 bring[R][WN];
+#pragma unroll
+    for (int g = 0; g < R; ++g) bload(bring[g], 0, 0, g);
+
     for (int ch = 0; ch < n_chunks; ++ch) {
         __syncthreads();                                               // previous chunk fully consumed
-        for (int idx = t; idx < npix * 4; idx += 256) {                // 4 float4 (2 complex each) per pixel
-            const int q = idx & 3, px = idx >> 2;
+        for (int idx = t; idx < nslots; idx += 256) {
+            const int q = idx % Q, px = idx / Q;
             const int ix = px % cols, iy = px / cols;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             long sp;
             if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
-                const int c = ch * CHUNK + 2 * q;
+                const int c = ch * CH + 2 * q;
                 const float2* src = (c < a.C1) ? a.x1 + sp * a.C1 + c : a.x2 + sp * a.C2 + (c - a.C1);
                 v = *reinterpret_cast<const float4*>(src);
             }
             *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v;
         }
         __syncthreads();
-        const int iters = ntaps * 2;                                   // (tap, k-group within chunk)
-        float4 bn[WN];
+        float4 af[2][WM];
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
-            bn[j] = *reinterpret_cast<const float4*>(bbase + (long)(ch * 2) * b_kg_stride + j * 256);
-        for (int it = 0; it < iters; ++it) {
-            const int tap = it >> 1, g = it & 1;
-            float4 bf[WN];
+        for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const float4*>(patch + pixoff[i]);
+        int tapoff = 0;                                                // LDS float offset of the current tap
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int tap2 = tap + 1;
+            const int tapoff2 = ((tap2 / k.kw) * cols + (tap2 % k.kw)) * PIX;
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = bn[j];
-            if (it + 1 < iters) {                                      // prefetch the next B fragments
-                const int tap2 = (it + 1) >> 1, g2 = (it + 1) & 1;
-                const float* bp = bbase + tap2 * b_tap_stride + (long)(ch * 2 + g2) * b_kg_stride;
+            for (int g = 0; g < U; ++g) {
+                float4 bf[WN];
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bn[j] = *reinterpret_cast<const float4*>(bp + j * 256);
-            }
-            const int tapoff = ((tap / k.kw) * cols + (tap % k.kw)) * PIX + g * 8;
-            float4 af[WM];
+                for (int j = 0; j < WN; ++j) bf[j] = bring[g % R][j];
+                // refill this slot with the fragment R iterations ahead
+                if (g + R < U) bload(bring[g % R], ch, tap, g + R);
+                else bload(bring[g % R], ch, tap2, g + R - U);
+                // A fragments of the next iteration
+                if (g + 1 < U) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff);
+                    for (int i = 0; i < WM; ++i)
+                        af[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff + (g + 1) * 8);
+                } else if (tap2 < ntaps) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < WM; ++i)
+                        af[0][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff2);
                 }
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const float4 av = af[g & 1][i];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            tapoff = tapoff2;
         }
     }
 
@@ -171,19 +199,32 @@ __global__ void pack_mfma_kernel(const float2* __restrict__ wp, float4* __restri
     bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
 }
 
-template <int WAVES_N, int WM, int WN>
-int launch(MArgs& m, hipStream_t stream) {
+template <int WAVES_N, int WM, int WN, int CH>
+int launch_ch(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    int kh = 0, kw = 0;
-    for (int c = 0; c < m.ncls; ++c) { kh = m.cls[c].kh > kh ? m.cls[c].kh : kh; kw = m.cls[c].kw > kw ? m.cls[c].kw : kw; }
-    const size_t lds = (size_t)((m.TH - 1) * a.sf + kh) * ((m.TW - 1) * a.st + kw) * PIX * sizeof(float);
-    if (lds > 150 * 1024) return DCS_ERR_BADARG;
-    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN>;
+    const size_t lds = (size_t)npix * (2 * CH + 4) * sizeof(float);
+    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, m.NT / (WAVES_N * WN), m.ncls);
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+template <int WAVES_N, int WM, int WN>
+int launch(MArgs& m, hipStream_t stream) {
+    const conv::Args& a = m.c;
+    int kh = 0, kw = 0;
+    for (int c = 0; c < m.ncls; ++c) { kh = m.cls[c].kh > kh ? m.cls[c].kh : kh; kw = m.cls[c].kw > kw ? m.cls[c].kw : kw; }
+    const long npix = (long)((m.TH - 1) * a.sf + kh) * ((m.TW - 1) * a.st + kw);
+    const int Cin = a.C1 + a.C2;
+    // chunk depth: 16 channels whenever the patch stays within ~1/3 of a CU's LDS (2-3 workgroups per CU overlap
+    // each other's gathers), 32 only for small patches (occupancy matters more than barrier count there)
+    static const long cap16 = [] { const char* e = getenv("DCS_MFMA_LDS_CAP"); return e ? atol(e) : 56L * 1024; }();
+    if (Cin % 32 == 0 && npix * 68 * 4 <= 32 * 1024) return launch_ch<WAVES_N, WM, WN, 32>(m, npix, stream);
+    if (Cin % 16 == 0 && npix * 36 * 4 <= cap16) return launch_ch<WAVES_N, WM, WN, 16>(m, npix, stream);
+    if (npix * 20 * 4 > 150 * 1024) return DCS_ERR_BADARG;
+    return launch_ch<WAVES_N, WM, WN, 8>(m, npix, stream);
 }
 
 }  // namespace
@@ -217,21 +258,32 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
     }
     if (Hc <= 0 || Wc <= 0) return DCS_ERR_BADARG;
     m.N = 2 * a.Cout; m.KG = Cin / 4; m.NT = (m.N + 31) / 32;
-    // candidate workgroup tiles (pixels x columns); take the largest that still yields >= 256 workgroups
-    // (one per CU), else the one with the most workgroups: deep layers at small batch have few pixels
+    // candidate workgroup tiles (pixels x columns); take the largest that still yields >= min_blocks workgroups
+    // (default 2 per CU, so one workgroup's MFMA phase hides the other's patch gather), else the one with the most
+    // workgroups: deep layers at small batch have few pixels
     struct Cand { int bm, bn; };
     const Cand cands[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+    int kh = 0, kw = 0;
+    for (int c = 0; c < ncls; ++c) { kh = cls[c].kh > kh ? cls[c].kh : kh; kw = cls[c].kw > kw ? cls[c].kw : kw; }
+    // tile shape th x tw = bmp pixels: least padding past the class extent first, then the smallest haloed patch
     auto shape = [&](int bmp, int* th, int* tw) {
-        if (bmp == 128) { if (Hc >= 8) { *th = 8; *tw = 16; } else if (Hc >= 4) { *th = 4; *tw = 32; } else { *th = 2; *tw = 64; } }
-        else { if (Hc >= 4) { *th = 4; *tw = 16; } else { *th = 2; *tw = 32; } }
+        long best_cost = -1;
+        for (int h = 2; h <= 16 && h <= bmp / 8; h *= 2) {
+            const int w = bmp / h;
+            const long padded = (long)((Hc + h - 1) / h) * h * ((Wc + w - 1) / w) * w;
+            const long patch = (long)((h - 1) * a.sf + kh) * ((w - 1) * a.st + kw);
+            const long cost = padded * 4096 + patch;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; *th = h; *tw = w; }
+        }
     };
+    static const long min_blocks = [] { const char* e = getenv("DCS_MFMA_MIN_BLOCKS"); return e ? atol(e) : 1024L; }();
     int best = -1; long best_blocks = -1;
     for (int i = 0; i < 4; ++i) {
         if (m.NT % (cands[i].bn / 32) != 0) continue;
         int th, tw;
         shape(cands[i].bm, &th, &tw);
         const long blocks = (long)((Wc + tw - 1) / tw) * ((Hc + th - 1) / th) * a.B * (m.NT / (cands[i].bn / 32)) * ncls;
-        if (blocks >= 256) { best = i; break; }
+        if (blocks >= min_blocks) { best = i; break; }
         if (blocks > best_blocks) { best_blocks = blocks; best = i; }
     }
     if (best < 0) return DCS_ERR_BADARG;

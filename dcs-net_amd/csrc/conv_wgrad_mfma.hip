@@ -12,6 +12,7 @@
 //   * workgroups stride over pixel tiles; one partial slab per workgroup row, reduced without atomics by
 //     cconv_wgrad_reduce_kernel (conv_direct.hip), which also writes the reference's parameter layout.
 #include "conv_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -30,8 +31,10 @@ struct WArgs {
 // MT row tiles (8 output channels each) per wave; WS waves split the tile's PIXELS (k-steps) and
 // 4/WS waves split the output channels, so layers with few output channels still fill all four
 // SIMDs: the pixel partials are combined through LDS once, after the last tile.
+// Two workgroups per CU (<= 256 VGPR + AGPR per lane) whenever the accumulator set allows it: one gathers while
+// the other runs its MFMAs.
 template <int KS, int MT, int WS>
-__global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
+__global__ __launch_bounds__(256, (MT * KS * KS * 4 <= 160 && !(KS == 5 && WS == 4) ? 2 : 1)) void cconv_wgrad_mfma_kernel(WArgs w) {
     constexpr int TAPS = KS * KS;
     constexpr int WCO = 4 / WS;
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
@@ -81,9 +84,10 @@ __global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
             *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v;
         }
         __syncthreads();
-        // gY fragments come from L2 with ~1-2 us latency and this kernel runs one wave per SIMD:
-        // keep the next k-step's loads in flight under the current step's MFMAs
-        float afn[MT];
+        // gY fragments come from L2 with ~1-2 us latency and a k-step is only MT*TAPS*32 cycles of MFMA: keep the
+        // next RING k-steps' loads in flight (static register ring; the k-step loop is unrolled over it)
+        constexpr int RING = MT >= 4 ? 2 : 4;                          // BMP/4/WS is 32, 16 or 8
+        float afr[RING][MT];
         auto load_g = [&](int ks, float* dst) {
             const int p = ks * 4 + lk;
             const int oy = oy0 + (p >> w.twshift), ox = ox0 + (p & (w.TW - 1));
@@ -92,24 +96,29 @@ __global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) dst[i] = (inb && colok[i]) ? gp[gcol[i]] : 0.f;
         };
-        load_g(part, afn);
-        for (int ks = part; ks < BMP / 4; ks += WS) {
-            const int p = ks * 4 + lk;                                 // this lane's pixel of the k-step
-            const int py = p >> w.twshift, pxx = p & (w.TW - 1);
-            float af[MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                af[i] = afn[i];
-                bsum[i] += af[i];
-            }
-            if (ks + WS < BMP / 4) load_g(ks + WS, afn);
-            const float* xp = patch + ((py * a.sf) * a.cols + pxx * a.st) * PIX + li;
+        for (int r = 0; r < RING; ++r) load_g(part + r * WS, afr[r]);
+        for (int ks0 = part; ks0 < BMP / 4; ks0 += WS * RING) {
 #pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) {
-                const float bf = xp[((tp / KS) * a.cols + (tp % KS)) * PIX];
+            for (int r = 0; r < RING; ++r) {
+                const int ks = ks0 + r * WS;
+                const int p = ks * 4 + lk;                             // this lane's pixel of the k-step
+                const int py = p >> w.twshift, pxx = p & (w.TW - 1);
+                float af[MT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    acc[i][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][tp], 0, 0, 0);
+                for (int i = 0; i < MT; ++i) {
+                    af[i] = afr[r][i];
+                    bsum[i] += af[i];
+                }
+                if (ks + WS * RING < BMP / 4) load_g(ks + WS * RING, afr[r]);
+                const float* xp = patch + ((py * a.sf) * a.cols + pxx * a.st) * PIX + li;
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp) {
+                    const float bf = xp[((tp / KS) * a.cols + (tp % KS)) * PIX];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        acc[i][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][tp], 0, 0, 0);
+                }
             }
         }
     }
@@ -177,16 +186,68 @@ __global__ __launch_bounds__(256) void cconv_wgrad_mfma_kernel(WArgs w) {
     }
 }
 
-template <int KS, int MT, int WS>
+template <int KS_, int MT_, int WS_> struct Variant { static constexpr int KS = KS_, MT = MT_, WS = WS_; };
+
+// (MT, WS) so that the 4 waves cover min(Cout, most-per-kernel-size) output channels without idle lanes
+template <class F>
+int dispatch(int k, int co, F&& f) {
+    switch (k) {
+        case 1:
+            if (co >= 128) return f(Variant<1, 4, 1>{});
+            if (co >= 64) return f(Variant<1, 2, 1>{});
+            if (co >= 32) return f(Variant<1, 1, 1>{});
+            if (co >= 16) return f(Variant<1, 1, 2>{});
+            return f(Variant<1, 1, 4>{});
+        case 3:
+            if (co >= 128) return f(Variant<3, 4, 1>{});
+            if (co >= 64) return f(Variant<3, 2, 1>{});
+            if (co >= 32) return f(Variant<3, 1, 1>{});
+            if (co >= 16) return f(Variant<3, 1, 2>{});
+            return f(Variant<3, 1, 4>{});
+        case 5:
+            if (co >= 64) return f(Variant<5, 2, 1>{});
+            if (co >= 32) return f(Variant<5, 1, 1>{});
+            if (co >= 16) return f(Variant<5, 1, 2>{});
+            return f(Variant<5, 1, 4>{});
+        case 7:
+            if (co >= 32) return f(Variant<7, 1, 1>{});
+            if (co >= 16) return f(Variant<7, 1, 2>{});
+            return f(Variant<7, 1, 4>{});
+        default: return DCS_ERR_BADARG;
+    }
+}
+
+template <class V>
+size_t lds_bytes(int rows, int cols) {
+    size_t lds = (size_t)rows * cols * PIX * sizeof(float);
+    const size_t red = (size_t)(V::WS - 1) * (4 / V::WS) * (V::MT * V::KS * V::KS * 4 + V::MT) * 64 * sizeof(float);
+    return red > lds ? red : lds;
+}
+
+// workgroups of this variant one CU holds at once (registers / LDS), queried once per variant
+template <class V>
+int resident_per_cu(size_t lds) {
+    static int cached = 0;
+    if (cached == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cconv_wgrad_mfma_kernel<V::KS, V::MT, V::WS>, 256, lds) !=
+                hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 1;
+        }
+        cached = n > 4 ? 4 : n;
+    }
+    return cached;
+}
+
+template <class V>
 int launch(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
-    size_t lds = (size_t)a.rows * a.cols * PIX * sizeof(float);
-    const size_t red = (size_t)(WS - 1) * (4 / WS) * (MT * KS * KS * 4 + MT) * 64 * sizeof(float);
-    if (red > lds) lds = red;
+    const size_t lds = lds_bytes<V>(a.rows, a.cols);
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
-    auto fn = cconv_wgrad_mfma_kernel<KS, MT, WS>;
+    auto fn = cconv_wgrad_mfma_kernel<V::KS, V::MT, V::WS>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
-    const int co_per_block = (4 / WS) * MT * 8;
+    const int co_per_block = (4 / V::WS) * V::MT * 8;
     w.co_blocks = (a.Cout + co_per_block - 1) / co_per_block;
     dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks);
     if (grid.y > 65535) return DCS_ERR_BADARG;
@@ -211,6 +272,22 @@ int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW) {
     long cap = (96L << 20) / (wsz * (long)sizeof(float2));
     if (cap < 1) cap = 1;
     if (cap > 1024) cap = 1024;
+    // A workgroup's epilogue writes its whole accumulator set (up to 147 KB), so give each one several pixel
+    // tiles rather than one — but keep every CU holding as many workgroups as the variant's registers allow
+    // (they overlap each other's gathers): target = 256 CUs x resident workgroups per CU.
+    const int rows = (*TH - 1) * a.sf + a.kh, cols = (*TW - 1) * a.st + a.kw;
+    int per_cu = 1, cpb = 8;
+    dispatch(a.kh, a.Cout, [&](auto v) {
+        using V = decltype(v);
+        per_cu = resident_per_cu<V>(lds_bytes<V>(rows, cols));
+        cpb = (4 / V::WS) * V::MT * 8;
+        return 0;
+    });
+    static const long scale = [] { const char* e = getenv("DCS_WGRAD_WGS_PER_SLOT"); return e ? atol(e) : 1L; }();
+    const long grid_y = (long)((a.C1 + a.C2) / CHUNK) * ((a.Cout + cpb - 1) / cpb);
+    long want = (256L * per_cu * scale + grid_y - 1) / grid_y;
+    if (want < 1) want = 1;
+    if (want < cap) cap = want;
     return (int)(tiles < cap ? tiles : cap);
 }
 
@@ -230,30 +307,5 @@ int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, f
     w.c.cols = (TW - 1) * a.st + a.kw;
     w.total_tiles = w.c.tiles_w * w.c.tiles_h * a.B;
     const int Cin = a.C1 + a.C2;
-    // pick (MT, WS) so that the 4 waves cover min(Cout, 128) output channels without idle lanes
-    const int co = a.Cout;
-    switch (a.kh) {
-        case 1:
-            if (co >= 128) return launch<1, 4, 1>(w, Cin, stream);
-            if (co >= 64) return launch<1, 2, 1>(w, Cin, stream);
-            if (co >= 32) return launch<1, 1, 1>(w, Cin, stream);
-            if (co >= 16) return launch<1, 1, 2>(w, Cin, stream);
-            return launch<1, 1, 4>(w, Cin, stream);
-        case 3:
-            if (co >= 128) return launch<3, 4, 1>(w, Cin, stream);
-            if (co >= 64) return launch<3, 2, 1>(w, Cin, stream);
-            if (co >= 32) return launch<3, 1, 1>(w, Cin, stream);
-            if (co >= 16) return launch<3, 1, 2>(w, Cin, stream);
-            return launch<3, 1, 4>(w, Cin, stream);
-        case 5:
-            if (co >= 64) return launch<5, 2, 1>(w, Cin, stream);
-            if (co >= 32) return launch<5, 1, 1>(w, Cin, stream);
-            if (co >= 16) return launch<5, 1, 2>(w, Cin, stream);
-            return launch<5, 1, 4>(w, Cin, stream);
-        case 7:
-            if (co >= 32) return launch<7, 1, 1>(w, Cin, stream);
-            if (co >= 16) return launch<7, 1, 2>(w, Cin, stream);
-            return launch<7, 1, 4>(w, Cin, stream);
-        default: return DCS_ERR_BADARG;
-    }
+    return dispatch(a.kh, a.Cout, [&](auto v) { return launch<decltype(v)>(w, Cin, stream); });
 }

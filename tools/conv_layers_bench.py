@@ -54,7 +54,7 @@ for name, H, W, C1, C2, Cout, k, st, up in L:
     d = timeit(lambda: ops.cconv2d_bwd_data(gy, wpb, (H, W, Cin), (k, k), st, pad, up, C1))
     w = timeit(lambda: ops.cconv2d_bwd_weight(x1, x2, gy, wshape, True, (k, k), st, pad, up, tr))
     tot['fwd'] += f; tot['dgrad'] += d; tot['wgrad'] += w; gf_tot += gflop
-    tf = lambda us: gflop / us * 1e-3
+    tf = lambda us: gflop / us * 1e3
     print(f'{name}: {gflop:7.2f} GF | fwd {f:7.1f} us {tf(f):6.1f} TF | dgrad {d:7.1f} us {tf(d):6.1f} TF | wgrad {w:7.1f} us {tf(w):6.1f} TF')
-print(f'total {gf_tot:.1f} GF: fwd {tot["fwd"]/1e3:.2f} ms ({gf_tot/tot["fwd"]*1e-3:.1f} TF), dgrad {tot["dgrad"]/1e3:.2f} ms '
-      f'({gf_tot/tot["dgrad"]*1e-3:.1f} TF), wgrad {tot["wgrad"]/1e3:.2f} ms ({gf_tot/tot["wgrad"]*1e-3:.1f} TF)')
+print(f'total {gf_tot:.1f} GF: fwd {tot["fwd"]/1e3:.2f} ms ({gf_tot/tot["fwd"]*1e3:.1f} TF), dgrad {tot["dgrad"]/1e3:.2f} ms '
+      f'({gf_tot/tot["dgrad"]*1e3:.1f} TF), wgrad {tot["wgrad"]/1e3:.2f} ms ({gf_tot/tot["wgrad"]*1e3:.1f} TF)')
