@@ -18,6 +18,7 @@
 //          (no atomics: bitwise reproducible) + a reduce that writes the reference's parameter
 //          layout (conv_r / conv_i or conv_tran_r / conv_tran_i, and the two biases).
 #include "conv_common.h"
+#include "pack_jobs.h"
 
 namespace {
 
@@ -248,41 +249,7 @@ int launch_wgrad_reduce(const float2* slab_w, const float2* slab_b, int n_slabs,
 }
 
 // ---- packers ------------------------------------------------------------------------------------
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w_r, const float* __restrict__ w_i,
-                                        const float* __restrict__ b_r, const float* __restrict__ b_i,
-                                        float2* __restrict__ wp, float2* __restrict__ bias_out, int Cout, int Cin,
-                                        int kh, int kw, int transposed) {
-    const long n = (long)kh * kw * Cin * Cout;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < Cout) {
-        const float br = b_r ? b_r[i] : 0.f, bi = b_i ? b_i[i] : 0.f;
-        bias_out[i] = make_float2(br - bi, br + bi);
-    }
-    if (i >= n) return;
-    const int co = (int)(i % Cout);
-    const int ci = (int)((i / Cout) % Cin);
-    const int tap = (int)(i / ((long)Cout * Cin));
-    const int dy = tap / kw, dx = tap % kw;
-    long src;
-    if (transposed)   // ConvTranspose2d weight [Cin][Cout][kh][kw], flipped
-        src = (((long)ci * Cout + co) * kh + (kh - 1 - dy)) * kw + (kw - 1 - dx);
-    else              // Conv2d weight [Cout][Cin][kh][kw]
-        src = (((long)co * Cin + ci) * kh + dy) * kw + dx;
-    wp[i] = make_float2(w_r[src], w_i[src]);
-}
-
-// wp_bwd[tap'][co][ci] = conj(wp[ntaps-1-tap'][ci][co])
-__global__ void pack_conv_weight_bwd_kernel(const float2* __restrict__ wp, float2* __restrict__ wpb, int Cout, int Cin,
-                                            int ntaps) {
-    const long n = (long)ntaps * Cin * Cout;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int ci = (int)(i % Cin);
-    const int co = (int)((i / Cin) % Cout);
-    const int tp = (int)(i / ((long)Cout * Cin));
-    const float2 v = wp[((long)(ntaps - 1 - tp) * Cin + ci) * Cout + co];
-    wpb[i] = make_float2(v.x, -v.y);
-}
+// (the re-layout kernels themselves live in pack_jobs.hip: packjob::DIRECT / packjob::BWD)
 
 // g_x1[b][y][x][c] = sum over the up_f x up_t block of g_Xv[b][..][..][c]; channels >= C1 go to g_x2
 __global__ void upsample_cat_bwd_kernel(const float2* __restrict__ gxv, float2* __restrict__ gx1,
@@ -389,9 +356,17 @@ extern "C" int dcs_pack_conv_weight(const float* w_r, const float* w_i, const fl
     if ((b_r == nullptr) != (b_i == nullptr)) return DCS_ERR_BADARG;
     long n = (long)kh * kw * Cin * Cout;
     if (n < Cout) n = Cout;
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, dcs_stream(stream), w_r, w_i,
-                       b_r, b_i, (float2*)wp, (float2*)bias_out, Cout, Cin, kh, kw, transposed);
-    DCS_CHECK_LAUNCH();
+    packjob::Job j{};
+    j.kind = packjob::DIRECT;
+    j.Cout = Cout; j.Cin = Cin; j.kh = kh; j.kw = kw; j.flag = transposed;
+    j.total = n;
+    j.dst_bytes = (long)kh * kw * Cin * Cout * (long)sizeof(float2);
+    j.src0 = w_r; j.src1 = w_i; j.src2 = b_r; j.src3 = b_i;
+    j.dst0 = wp; j.dst1 = bias_out;
+    {
+        const int rc = packjob::emit(j, dcs_stream(stream));
+        if (rc != DCS_OK) return rc;
+    }
     if (conv::mfma_ok(Cin, Cout)) {    // second panel: MFMA fragment order (conv_mfma.hip)
         const int rc = dcs_conv_mfma_pack(wp, wp + conv::direct_floats(Cout, Cin, kh * kw), Cout, Cin, kh * kw,
                                           dcs_stream(stream));
@@ -425,9 +400,16 @@ extern "C" int dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout
         return DCS_ERR_BADARG;
     const long n = (long)kh * kw * Cin * Cout;
     hipStream_t s = dcs_stream(stream);
-    hipLaunchKernelGGL(pack_conv_weight_bwd_kernel, dim3(dcs_cdiv(n, 256)), dim3(256), 0, s, (const float2*)wp,
-                       (float2*)wp_bwd, Cout, Cin, kh * kw);
-    DCS_CHECK_LAUNCH();
+    packjob::Job j{};
+    j.kind = packjob::BWD;
+    j.Cout = Cout; j.Cin = Cin; j.kh = kh * kw;
+    j.total = n;
+    j.dst_bytes = n * (long)sizeof(float2);
+    j.src0 = wp; j.dst0 = wp_bwd;
+    {
+        const int rc = packjob::emit(j, s);
+        if (rc != DCS_OK) return rc;
+    }
     // in the data-gradient GEMM the roles swap: K runs over the forward Cout, N over the forward Cin
     if (conv::mfma_ok(Cout, Cin)) {
         const int rc = dcs_conv_mfma_pack(wp_bwd, wp_bwd + conv::direct_floats(Cin, Cout, kh * kw), Cin, Cout, kh * kw, s);

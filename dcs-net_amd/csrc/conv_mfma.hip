@@ -19,6 +19,7 @@
 // fp32-input MFMA is exact fp32 (bit-for-bit an fmaf chain), 157 TFLOP/s peak: the same numerics
 // as the direct kernel at ~6x its VALU rate.
 #include "conv_common.h"
+#include "pack_jobs.h"
 #include <cstdlib>
 
 namespace {
@@ -180,24 +181,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     }
 }
 
-// bm[tap][kg][nt][kk][j][e]: e = 0..3 -> (ci = 4kg+2kk, re), (.., im), (ci+1, re), (ci+1, im); column n = nt*32+j
-__global__ void pack_mfma_kernel(const float2* __restrict__ wp, float4* __restrict__ bm, int Cout, int Cin, int taps) {
-    const int KG = Cin / 4, NT = (2 * Cout + 31) / 32;
-    const long total = (long)taps * KG * NT * 64;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int j = (int)(i & 31), kk = (int)((i >> 5) & 1);
-    long r = i >> 6;
-    const int nt = (int)(r % NT); r /= NT;
-    const int kg = (int)(r % KG);
-    const int tap = (int)(r / KG);
-    const int n = nt * 32 + j, co = n >> 1, im = n & 1;
-    if (co >= Cout) { bm[i] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
-    const int ci = 4 * kg + 2 * kk;
-    const float2 w0 = wp[((long)tap * Cin + ci) * Cout + co], w1 = wp[((long)tap * Cin + ci + 1) * Cout + co];
-    // column (co, re): [ w_r, -w_i ] ; column (co, im): [ w_i, w_r ]
-    bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
-}
+// (the B-panel re-layout kernel lives in pack_jobs.hip: packjob::MFMA)
 
 template <int WAVES_N, int WM, int WN, int CH>
 int launch_ch(MArgs& m, long npix, hipStream_t stream) {
@@ -231,11 +215,13 @@ int launch(MArgs& m, hipStream_t stream) {
 
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream) {
     if (!conv::mfma_ok(Cin, Cout)) return DCS_ERR_BADARG;
-    const long total = (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 64;
-    hipLaunchKernelGGL(pack_mfma_kernel, dim3(dcs_cdiv(total, 256)), dim3(256), 0, stream, (const float2*)wp_direct,
-                       (float4*)bm, Cout, Cin, taps);
-    DCS_CHECK_LAUNCH();
-    return DCS_OK;
+    packjob::Job j{};
+    j.kind = packjob::MFMA;
+    j.Cout = Cout; j.Cin = Cin; j.kh = taps;
+    j.total = (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 64;      // float4 elements
+    j.dst_bytes = j.total * (long)sizeof(float4);
+    j.src0 = wp_direct; j.dst0 = bm;
+    return packjob::emit(j, stream);
 }
 
 // a: geometry with the FULL output extent in Hout/Wout; cls[0..ncls): output-parity classes (class-space

@@ -15,43 +15,28 @@
 //     the zero-inserted correlation whose MFMAs are 1 - 1/(s_f s_t) zeros.
 // All three are consumed by conv_mfma.hip's class launches (dcs_conv_mfma_launch_classes).
 #include "conv_common.h"
+#include "pack_jobs.h"
 
 namespace {
 
 struct AxisMap { int n; int lo[8]; int hi[8]; };      // destination tap j sums source taps lo[j]..hi[j]
 
-// dst[(jy*nx + jx)][e'] = (conj?) sum_{dy in Y[jy]} sum_{dx in X[jx]} src[(dy*skw + dx)][e]
+// dst[(jy*nx + jx)][e'] = (conj?) sum_{dy in Y[jy]} sum_{dx in X[jx]} src[(dy*skw + dx)][e]   (packjob::FOLD)
 // elements: src [A][B] complex per tap; swap -> dst [B][A] (in/out channel swap)
-__global__ void fold_taps_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int A, int Bc, int skw,
-                                 AxisMap Y, AxisMap X, int swap_conj) {
-    const long per = (long)A * Bc;
-    const long total = (long)Y.n * X.n * per;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const long e = i % per;
-    const int tap = (int)(i / per);
-    const int jy = tap / X.n, jx = tap % X.n;
-    long se = e;
-    if (swap_conj) {                       // dst element (b, a) <- src element (a, b)
-        const int b = (int)(e / A), a = (int)(e % A);
-        se = (long)a * Bc + b;
-    }
-    float sr = 0.f, si = 0.f;
-    for (int dy = Y.lo[jy]; dy <= Y.hi[jy]; ++dy)
-        for (int dx = X.lo[jx]; dx <= X.hi[jx]; ++dx) {
-            const float2 v = src[(long)(dy * skw + dx) * per + se];
-            sr += v.x; si += v.y;
-        }
-    dst[i] = make_float2(sr, swap_conj ? -si : si);
-}
-
 int fold(const float* src, float* dst, int A, int Bc, int skw, const AxisMap& Y, const AxisMap& X, int swap_conj,
          hipStream_t s) {
-    const long total = (long)Y.n * X.n * A * Bc;
-    hipLaunchKernelGGL(fold_taps_kernel, dim3(dcs_cdiv(total, 256)), dim3(256), 0, s, (const float2*)src, (float2*)dst,
-                       A, Bc, skw, Y, X, swap_conj);
-    DCS_CHECK_LAUNCH();
-    return DCS_OK;
+    packjob::Job j{};
+    j.kind = packjob::FOLD;
+    j.Cout = A; j.Cin = Bc; j.kw = skw; j.flag = swap_conj;
+    j.yn = Y.n; j.xn = X.n;
+    for (int q = 0; q < 8; ++q) {
+        j.ylo[q] = (signed char)Y.lo[q]; j.yhi[q] = (signed char)Y.hi[q];
+        j.xlo[q] = (signed char)X.lo[q]; j.xhi[q] = (signed char)X.hi[q];
+    }
+    j.total = (long)Y.n * X.n * A * Bc;
+    j.dst_bytes = j.total * (long)sizeof(float2);
+    j.src0 = src; j.dst0 = dst;
+    return packjob::emit(j, s);
 }
 
 AxisMap identity_axis(int k) {

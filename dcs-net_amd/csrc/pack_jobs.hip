@@ -1,0 +1,236 @@
+// pack_jobs.hip — the weight re-layout kernels (one element per thread) behind a job table, and the pack plan.
+//
+// The reference has no counterpart: cuDNN consumes the nn.Parameter layout directly (c_network.py:107-147).
+// Here the hot kernels read pre-packed panels (conv_direct.hip / conv_mfma.hip / conv_pack.hip), so a training
+// step has to re-derive them from the updated parameters; the plan turns that from ~200 serial 4-us launches
+// into one launch per dependency level.
+#include "pack_jobs.h"
+
+#include <mutex>
+#include <vector>
+
+namespace packjob {
+namespace {
+
+__device__ __forceinline__ void run_direct(const Job& j, long i) {
+    const float* w_r = (const float*)j.src0; const float* w_i = (const float*)j.src1;
+    const float* b_r = (const float*)j.src2; const float* b_i = (const float*)j.src3;
+    float2* wp = (float2*)j.dst0; float2* bias_out = (float2*)j.dst1;
+    const int Cout = j.Cout, Cin = j.Cin, kh = j.kh, kw = j.kw;
+    const long n = (long)kh * kw * Cin * Cout;
+    if (i < Cout) {
+        const float br = b_r ? b_r[i] : 0.f, bi = b_i ? b_i[i] : 0.f;
+        bias_out[i] = make_float2(br - bi, br + bi);
+    }
+    if (i >= n) return;
+    const int co = (int)(i % Cout);
+    const int ci = (int)((i / Cout) % Cin);
+    const int tap = (int)(i / ((long)Cout * Cin));
+    const int dy = tap / kw, dx = tap % kw;
+    long src;
+    if (j.flag)       // ConvTranspose2d weight [Cin][Cout][kh][kw], flipped
+        src = (((long)ci * Cout + co) * kh + (kh - 1 - dy)) * kw + (kw - 1 - dx);
+    else              // Conv2d weight [Cout][Cin][kh][kw]
+        src = (((long)co * Cin + ci) * kh + dy) * kw + dx;
+    wp[i] = make_float2(w_r[src], w_i[src]);
+}
+
+// wp_bwd[tap'][co][ci] = conj(wp[ntaps-1-tap'][ci][co])
+__device__ __forceinline__ void run_bwd(const Job& j, long i) {
+    const float2* wp = (const float2*)j.src0; float2* wpb = (float2*)j.dst0;
+    const int Cout = j.Cout, Cin = j.Cin, ntaps = j.kh;
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int tp = (int)(i / ((long)Cout * Cin));
+    const float2 v = wp[((long)(ntaps - 1 - tp) * Cin + ci) * Cout + co];
+    wpb[i] = make_float2(v.x, -v.y);
+}
+
+// dst[(jy*nx + jx)][e'] = (conj?) sum_{dy in Y[jy]} sum_{dx in X[jx]} src[(dy*skw + dx)][e]
+// elements: src [A][B] complex per tap; swap -> dst [B][A] (in/out channel swap)
+__device__ __forceinline__ void run_fold(const Job& j, long i) {
+    const float2* src = (const float2*)j.src0; float2* dst = (float2*)j.dst0;
+    const int A = j.Cout, Bc = j.Cin, skw = j.kw;
+    const long per = (long)A * Bc;
+    const long e = i % per;
+    const int tap = (int)(i / per);
+    const int jy = tap / j.xn, jx = tap % j.xn;
+    long se = e;
+    if (j.flag) {                          // dst element (b, a) <- src element (a, b)
+        const int b = (int)(e / A), a = (int)(e % A);
+        se = (long)a * Bc + b;
+    }
+    float sr = 0.f, si = 0.f;
+    for (int dy = j.ylo[jy]; dy <= j.yhi[jy]; ++dy)
+        for (int dx = j.xlo[jx]; dx <= j.xhi[jx]; ++dx) {
+            const float2 v = src[(long)(dy * skw + dx) * per + se];
+            sr += v.x; si += v.y;
+        }
+    dst[i] = make_float2(sr, j.flag ? -si : si);
+}
+
+// bm[tap][kg][nt][kk][j][e]: e = 0..3 -> (ci = 4kg+2kk, re), (.., im), (ci+1, re), (ci+1, im); column n = nt*32+j
+__device__ __forceinline__ void run_mfma(const Job& jb, long i) {
+    const float2* wp = (const float2*)jb.src0; float4* bm = (float4*)jb.dst0;
+    const int Cout = jb.Cout, Cin = jb.Cin;
+    const int KG = Cin / 4, NT = (2 * Cout + 31) / 32;
+    const int j = (int)(i & 31), kk = (int)((i >> 5) & 1);
+    long r = i >> 6;
+    const int nt = (int)(r % NT); r /= NT;
+    const int kg = (int)(r % KG);
+    const int tap = (int)(r / KG);
+    const int n = nt * 32 + j, co = n >> 1, im = n & 1;
+    if (co >= Cout) { bm[i] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const int ci = 4 * kg + 2 * kk;
+    const float2 w0 = wp[((long)tap * Cin + ci) * Cout + co], w1 = wp[((long)tap * Cin + ci + 1) * Cout + co];
+    // column (co, re): [ w_r, -w_i ] ; column (co, im): [ w_i, w_r ]
+    bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
+}
+
+__device__ __forceinline__ void run(const Job& j, long i) {
+    if (i >= j.total) return;
+    switch (j.kind) {
+        case DIRECT: run_direct(j, i); break;
+        case BWD: run_bwd(j, i); break;
+        case FOLD: run_fold(j, i); break;
+        default: run_mfma(j, i); break;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_one_kernel(Job j) { run(j, (long)blockIdx.x * 256 + threadIdx.x); }
+
+// blk0[k] = first block of job k (ascending; blk0[nj] = grid size)
+__global__ __launch_bounds__(256) void pack_multi_kernel(const Job* __restrict__ jobs, const int* __restrict__ blk0, int nj) {
+    int lo = 0, hi = nj - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blk0[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    run(jobs[lo], (long)(b - blk0[lo]) * 256 + threadIdx.x);
+}
+
+struct Level { Job* d_jobs = nullptr; int* d_blk0 = nullptr; int nj = 0, nblocks = 0; };
+struct Plan { std::vector<Level> levels; int njobs = 0; };
+
+struct Recorder { std::vector<Job> jobs; std::vector<int> level; };
+// process-wide, not thread-local: torch.autograd runs backward (and its packs) on its own worker thread
+Recorder* g_rec = nullptr;
+std::mutex g_rec_mutex;
+
+bool inside(const void* p, const Job& q) {
+    const char* c = (const char*)p;
+    return p != nullptr && c >= (const char*)q.dst0 && c < (const char*)q.dst0 + q.dst_bytes;
+}
+
+// dependency level = 1 + the deepest recorded job whose output this one reads
+void record(const Job& j) {
+    int lvl = 0;
+    for (size_t k = 0; k < g_rec->jobs.size(); ++k) {
+        const Job& q = g_rec->jobs[k];
+        if (inside(j.src0, q) || inside(j.src1, q) || inside(j.src2, q) || inside(j.src3, q))
+            lvl = g_rec->level[k] + 1 > lvl ? g_rec->level[k] + 1 : lvl;
+    }
+    g_rec->jobs.push_back(j);
+    g_rec->level.push_back(lvl);
+}
+
+}  // namespace
+
+int emit(const Job& j, hipStream_t s) {
+    if (j.total <= 0) return DCS_ERR_BADARG;
+    {
+        std::lock_guard<std::mutex> lock(g_rec_mutex);
+        if (g_rec) record(j);
+    }
+    hipLaunchKernelGGL(pack_one_kernel, dim3((unsigned)dcs_cdiv(j.total, 256)), dim3(256), 0, s, j);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+}  // namespace packjob
+
+using packjob::Plan;
+using packjob::Level;
+
+extern "C" int dcs_pack_plan_begin(void) {
+    std::lock_guard<std::mutex> lock(packjob::g_rec_mutex);
+    if (packjob::g_rec) return DCS_ERR_BADARG;
+    packjob::g_rec = new packjob::Recorder();
+    return DCS_OK;
+}
+
+extern "C" int dcs_pack_plan_end(void** plan_out) {
+    packjob::Recorder* rec;
+    {
+        std::lock_guard<std::mutex> lock(packjob::g_rec_mutex);
+        rec = packjob::g_rec;
+        packjob::g_rec = nullptr;
+    }
+    if (!rec) return DCS_ERR_BADARG;
+    if (!plan_out) { delete rec; return DCS_ERR_BADARG; }
+    int nlev = 0;
+    for (int l : rec->level) nlev = l + 1 > nlev ? l + 1 : nlev;
+    Plan* plan = new Plan();
+    plan->njobs = (int)rec->jobs.size();
+    int rc = DCS_OK;
+    for (int l = 0; l < nlev && rc == DCS_OK; ++l) {
+        std::vector<packjob::Job> jobs;
+        std::vector<int> blk0;
+        long nb = 0;
+        for (size_t k = 0; k < rec->jobs.size(); ++k)
+            if (rec->level[k] == l) {
+                jobs.push_back(rec->jobs[k]);
+                blk0.push_back((int)nb);
+                nb += dcs_cdiv(rec->jobs[k].total, 256);
+            }
+        blk0.push_back((int)nb);
+        if (jobs.empty() || nb > 0x7fffffffL) { rc = DCS_ERR_BADARG; break; }
+        Level lv;
+        lv.nj = (int)jobs.size(); lv.nblocks = (int)nb;
+        if (hipMalloc((void**)&lv.d_jobs, jobs.size() * sizeof(packjob::Job)) != hipSuccess ||
+            hipMalloc((void**)&lv.d_blk0, blk0.size() * sizeof(int)) != hipSuccess ||
+            hipMemcpy(lv.d_jobs, jobs.data(), jobs.size() * sizeof(packjob::Job), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(lv.d_blk0, blk0.data(), blk0.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            rc = DCS_ERR_LAUNCH;
+        }
+        plan->levels.push_back(lv);
+    }
+    delete rec;
+    if (rc != DCS_OK) {
+        for (Level& lv : plan->levels) { (void)hipFree(lv.d_jobs); (void)hipFree(lv.d_blk0); }
+        delete plan;
+        return rc;
+    }
+    *plan_out = plan;
+    return DCS_OK;
+}
+
+extern "C" int dcs_pack_plan_jobs(const void* plan, int* n_jobs, int* n_launches) {
+    if (!plan) return DCS_ERR_BADARG;
+    const Plan* p = (const Plan*)plan;
+    if (n_jobs) *n_jobs = p->njobs;
+    if (n_launches) *n_launches = (int)p->levels.size();
+    return DCS_OK;
+}
+
+extern "C" int dcs_pack_plan_run(const void* plan, dcs_stream_t stream) {
+    if (!plan) return DCS_ERR_BADARG;
+    const Plan* p = (const Plan*)plan;
+    hipStream_t s = dcs_stream(stream);
+    for (const Level& lv : p->levels) {
+        hipLaunchKernelGGL(packjob::pack_multi_kernel, dim3((unsigned)lv.nblocks), dim3(256), 0, s, lv.d_jobs, lv.d_blk0,
+                           lv.nj);
+        DCS_CHECK_LAUNCH();
+    }
+    return DCS_OK;
+}
+
+extern "C" int dcs_pack_plan_destroy(void* plan) {
+    if (!plan) return DCS_ERR_BADARG;
+    Plan* p = (Plan*)plan;
+    for (Level& lv : p->levels) { (void)hipFree(lv.d_jobs); (void)hipFree(lv.d_blk0); }
+    delete p;
+    return DCS_OK;
+}

@@ -57,6 +57,11 @@ SIGNATURES = {
     'dcs_polar_pad_bwd': (_I, [_P, _P, _P, _L, _I, _I, _I, _F, _P]),
     'dcs_crm_fwd': (_I, [_P, _P, _P, _L, _F, _P]),
     'dcs_adam_amsgrad_step': (_I, [_P] * 6 + [_F, _F, _L, _F, _F, _F, _F, _F, _I, _P, _P]),
+    'dcs_pack_plan_begin': (_I, []),
+    'dcs_pack_plan_end': (_I, [_P]),
+    'dcs_pack_plan_jobs': (_I, [_P, _P, _P]),
+    'dcs_pack_plan_run': (_I, [_P, _P]),
+    'dcs_pack_plan_destroy': (_I, [_P]),
 }
 
 _lib = None

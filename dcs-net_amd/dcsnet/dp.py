@@ -125,7 +125,7 @@ class TrainStep:
     dropout seed offset (ops.SEED_STATE) and Adam's update count.  The batch is copied into static
     buffers before each replay.  Any capture failure falls back to eager execution, loudly."""
 
-    def __init__(self, net, optimizer_cls=FusedAdam, use_graph=False, graph_warmup=3):
+    def __init__(self, net, optimizer_cls=FusedAdam, use_graph=False, graph_warmup=3, use_pack_plan=True):
         hp = net.hparams
         self.net = net
         self.bucket = FlatBucket(net)
@@ -139,9 +139,10 @@ class TrainStep:
             self.seed_state = torch.zeros(1, dtype=torch.int64, device=self.bucket.flat.device)
             ops.SEED_STATE = self.seed_state
         self._graph = self._static_batch = self._static_loss = None
+        self.use_pack_plan, self._plan = bool(use_pack_plan), None
         self._calls = 0
 
-    def _eager(self, batch, batch_idx):
+    def _step_body(self, batch, batch_idx):
         self.bucket.zero_grad()
         loss = self.net.training_step(batch, batch_idx)
         if loss is None:                       # NaN guard of the reference (c_network.py:257-261)
@@ -152,6 +153,28 @@ class TrainStep:
         if self.seed_state is not None:
             self.seed_state += 1
         return loss.detach()
+
+    def _eager(self, batch, batch_idx):
+        """The first GPU step records every weight pack it makes into a pack plan (the packs still run); later
+        steps re-derive all packed weights up front with the plan's 4 launches instead of ~200."""
+        from . import functional
+        if not (self.use_pack_plan and self.bucket.flat.is_cuda):
+            return self._step_body(batch, batch_idx)
+        if self._plan is None:
+            functional.begin_pack_plan()
+            loss = None
+            try:
+                loss = self._step_body(batch, batch_idx)
+            finally:
+                plan = functional.end_pack_plan()
+            if loss is None:                   # skipped step: backward never packed, record again next time
+                from . import ops
+                ops.pack_plan_drop()
+            else:
+                self._plan = plan
+            return loss
+        functional.run_pack_plan(self._plan)
+        return self._step_body(batch, batch_idx)
 
     def _loss_no_sync(self, batch, batch_idx):
         """training_step without its NaN test (a host synchronisation, illegal under capture)."""
@@ -167,6 +190,8 @@ class TrainStep:
         static = (*self._static_batch, *batch[3:])
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
+            if self._plan is not None:
+                functional.run_pack_plan(self._plan)
             self.bucket.zero_grad()
             loss = self._loss_no_sync(static, 0)
             loss.backward()

@@ -24,6 +24,23 @@ def bump_param_generation():
     global _param_generation
     _param_generation += 1
     _pack_cache.clear()
+    ops.pack_plan_invalidate()
+
+
+def begin_pack_plan():
+    """Start recording every weight pack of the coming step (they still execute)."""
+    _pack_cache.clear()
+    return ops.pack_plan_begin()
+
+
+def end_pack_plan():
+    return ops.pack_plan_end()
+
+
+def run_pack_plan(plan):
+    """Re-derive every recorded packed weight from the current parameters (4 launches) and serve them to
+    packed_weight() / ops.pack_conv_weight_bwd until the next parameter update."""
+    ops.pack_plan_run(plan)
 
 
 def _ver(t):
@@ -34,6 +51,15 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1)):
     """Packed (wp, bias) for a weight pair; cached per tensor OBJECT and version (the weakrefs
     guard against a recycled id()).  1x1 / Linear weights may be passed 2-D.  `up`: upsample factors
     of the conv call the weight is for."""
+    plan = ops.PLAN
+    if plan is not None:
+        pkey = (id(w_r), id(w_i), id(b_r), id(b_i), bool(transposed), tuple(up))
+        if plan.valid and not plan.recording:
+            e = plan.fwd.get(pkey)
+            if e is not None and e[0][0]() is w_r and e[0][1]() is w_i and e[2] == (
+                    w_r._version, w_i._version, None if b_r is None else b_r._version,
+                    None if b_i is None else b_i._version):
+                return e[1]
     key = (_ver(w_r), _ver(w_i), _ver(b_r), _ver(b_i), bool(transposed), tuple(up))
     hit = _pack_cache.get(key)
     if hit is not None and hit[0]() is w_r and hit[1]() is w_i:
@@ -46,6 +72,9 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1)):
         wr, wi = wr.view(*wr.shape, 1, 1), wi.view(*wi.shape, 1, 1)
     packed = ops.pack_conv_weight(wr, wi, d(b_r), d(b_i), transposed, tuple(up))
     _pack_cache[key] = (weakref.ref(w_r), weakref.ref(w_i), packed)
+    if plan is not None and plan.recording:
+        wref = lambda t: None if t is None else weakref.ref(t)
+        plan.fwd[pkey] = [(wref(w_r), wref(w_i), wref(b_r), wref(b_i)), packed, None]
     return packed
 
 

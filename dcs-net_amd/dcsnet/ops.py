@@ -34,6 +34,74 @@ SEED_STATE = None
 _workspaces = {}
 
 
+class PackPlan:
+    """Python side of a dcs_pack_plan: owns the destination tensors the plan re-packs in place and serves
+    them to packed-weight lookups while `valid` (= dcs_pack_plan_run has run since the last parameter
+    update).  fwd: key -> [parameter weakrefs, (wp, bias), parameter versions]; bwd: key -> data-gradient weight."""
+
+    def __init__(self):
+        self.handle, self.recording, self.valid = None, True, False
+        self.fwd, self.bwd, self.keep = {}, {}, []
+
+    def stats(self):
+        import ctypes
+        nj, nl = ctypes.c_int(0), ctypes.c_int(0)
+        check(_lib.load().dcs_pack_plan_jobs(self.handle, ctypes.byref(nj), ctypes.byref(nl)), 'dcs_pack_plan_jobs')
+        return nj.value, nl.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().dcs_pack_plan_destroy(self.handle)
+        except Exception:      # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+PLAN = None                # the active PackPlan (dp.TrainStep owns it), or None
+
+
+def pack_plan_begin():
+    global PLAN
+    check(_lib.load().dcs_pack_plan_begin(), 'dcs_pack_plan_begin')
+    PLAN = PackPlan()
+    return PLAN
+
+
+def pack_plan_end():
+    import ctypes
+    h = ctypes.c_void_p()
+    plan = PLAN
+    check(_lib.load().dcs_pack_plan_end(ctypes.byref(h)), 'dcs_pack_plan_end')
+    plan.handle, plan.recording = h.value, False
+    _plan_snapshot(plan)
+    plan.valid = True          # everything recorded was also executed
+    return plan
+
+
+def _plan_snapshot(plan):
+    for e in plan.fwd.values():
+        e[2] = tuple(None if r is None or r() is None else r()._version for r in e[0])
+
+
+def pack_plan_run(plan):
+    global PLAN
+    PLAN = plan                # lookups consult the plan that ran last
+    check(_lib.load().dcs_pack_plan_run(plan.handle, cur_stream()), 'dcs_pack_plan_run')
+    _plan_snapshot(plan)
+    plan.valid = True
+
+
+def pack_plan_invalidate():
+    if PLAN is not None:
+        PLAN.valid = False
+
+
+def pack_plan_drop():
+    global PLAN
+    PLAN = None
+
+
+
 def _workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream); reused across calls on the same stream."""
     key = (device.index, cur_stream())
@@ -103,11 +171,20 @@ def pack_conv_weight_bwd(wp, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1)):
     _chk(wp, 'wp', 4)
     taps, Cin, Cout, _ = wp.shape
     kh, kw = ksize
+    plan = PLAN
+    key = (wp.data_ptr(), tuple(ksize), tuple(stride), tuple(pad), tuple(up))
+    if plan is not None and plan.valid and not plan.recording:
+        hit = plan.bwd.get(key)            # plan-owned wp: its address cannot be reused by another tensor
+        if hit is not None:
+            return hit
     lib = _lib.load()
     geo = (Cout, Cin, kh, kw, stride[0], stride[1], pad[0], pad[1], up[0], up[1])
     buf = torch.empty(lib.dcs_packed_weight_bwd_floats(*geo), dtype=torch.float32, device=wp.device)
     wpb = buf[:taps * Cin * Cout * 2].view(taps, Cout, Cin, 2)
     check(lib.dcs_pack_conv_weight_bwd(ptr(wp), ptr(wpb), *geo, cur_stream()), 'dcs_pack_conv_weight_bwd')
+    if plan is not None and plan.recording:
+        plan.bwd[key] = wpb
+        plan.keep.append((wp, buf))
     return wpb
 
 

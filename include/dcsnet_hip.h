@@ -329,6 +329,22 @@ int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* v
                           float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                           const int* step_dev, dcs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Pack plan: every weight re-layout of a training step in one launch per dependency level.
+ * No reference counterpart (cuDNN reads the nn.Parameter layout, c_network.py:107-147); the packed panels
+ * dcs_pack_conv_weight / dcs_pack_conv_weight_bwd produce must be re-derived after each optimizer update
+ * (~200 launches of 3-5 us).  Between dcs_pack_plan_begin() and dcs_pack_plan_end() every pack call made
+ * by the process (any thread: torch.autograd runs backward on its own) still executes AND is recorded
+ * with its source / destination pointers; dcs_pack_plan_run() later repeats all of them (one launch per
+ * dependency level, <= 4; capturable into a hipGraph).  The caller keeps every recorded source and
+ * destination buffer alive and in place for the life of the plan.  dcs_pack_plan_end / _destroy
+ * allocate / free device memory: not inside a stream capture. */
+int dcs_pack_plan_begin(void);
+int dcs_pack_plan_end(void** plan_out);
+int dcs_pack_plan_jobs(const void* plan, int* n_jobs, int* n_launches);
+int dcs_pack_plan_run(const void* plan, dcs_stream_t stream);
+int dcs_pack_plan_destroy(void* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -173,3 +173,28 @@ def test_backward_kernels_write_into_the_flat_gradient_bucket(dev):
     assert a.keys() == b.keys()
     for n in a:
         assert torch.allclose(a[n], b[n], rtol=1e-5, atol=1e-7), n
+
+
+def test_pack_plan_step_is_bit_identical_to_per_layer_packing(dev):
+    """dcs_pack_plan_*: every weight re-layout of a step replayed in one launch per dependency level gives
+    exactly the parameters the ~200 per-layer pack launches give (same kernels bodies, same inputs)."""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    clean, noise = seeded_input(2, 256, 32, 1, 0.1), seeded_input(2, 256, 32, 2, 0.05)
+    batch = (noise.to(dev), (clean + noise).to(dev), clean.to(dev), [0, 1])
+    runs = []
+    for use_plan in (False, True):
+        net = fill_state(C_NETWORK(config, hp, 0), 2).to(dev).train()
+        ts = TrainStep(net, use_graph=False, use_pack_plan=use_plan)
+        losses = [float(ts(batch)) for _ in range(4)]
+        runs.append((losses, ts))
+    (l0, ts0), (l1, ts1) = runs
+    assert ts0._plan is None and ts1._plan is not None
+    jobs, launches = ts1._plan.stats()
+    assert jobs > 80 and launches <= 6, (jobs, launches)
+    assert len(ts1._plan.fwd) > 40 and len(ts1._plan.bwd) > 20
+    assert l0 == l1
+    assert torch.equal(ts0.bucket.flat, ts1.bucket.flat)
