@@ -29,14 +29,41 @@ def hot_parameters(net):
     return [(n, p) for n, p in net.named_parameters() if p.requires_grad and not n.startswith(UNUSED_PREFIXES)]
 
 
+def _lstm_stack_groups(net):
+    """Parameter groups that functional._LstmLayerFn wants contiguous: for every ComplexLSTM-like module (two
+    bidirectional nn.LSTM named real_lstm / imag_lstm, c_network.py:26-31), per layer and kind the four tensors
+    (real fwd, real rev, imag fwd, imag rev) — stacked they are [2, 8H, in] / [2, 2, 4H, H] / [2, 8H]."""
+    groups = []
+    for mod in net.modules():
+        rl, il = getattr(mod, 'real_lstm', None), getattr(mod, 'imag_lstm', None)
+        if not (isinstance(rl, torch.nn.LSTM) and isinstance(il, torch.nn.LSTM)):
+            continue
+        if not (rl.bidirectional and il.bidirectional and rl.bias and il.bias and rl.num_layers == il.num_layers and
+                rl.hidden_size == il.hidden_size and rl.input_size == il.input_size and rl.proj_size == 0):
+            continue
+        for layer in range(rl.num_layers):
+            for kind in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                ps = [getattr(m, f'{kind}_l{layer}{suf}') for m in (rl, il) for suf in ('', '_reverse')]
+                groups.append((rl, layer, kind, ps))
+    return groups
+
+
 class FlatBucket:
     def __init__(self, net):
         named = hot_parameters(net)
         if not named:
             raise ValueError('no trainable parameters')
         dev, dtype = named[0][1].device, named[0][1].dtype
-        self.names = [n for n, _ in named]
-        self.params = [p for _, p in named]
+        # LSTM parameter groups first, each contiguous in stacking order; everything else in registration order
+        hot = {id(p) for _, p in named}
+        groups = [g for g in _lstm_stack_groups(net)
+                  if all(id(p) in hot and p.numel() % 4 == 0 and p.shape == g[3][0].shape for p in g[3])]
+        name_of = {id(p): n for n, p in named}
+        grouped = [p for g in groups for p in g[3]]
+        taken = {id(p) for p in grouped}
+        ordered = grouped + [p for _, p in named if id(p) not in taken]
+        self.names = [name_of[id(p)] for p in ordered]
+        self.params = ordered
         # 4-float alignment of every slice keeps float4 access legal for any parameter shape
         offs, total = [], 0
         for p in self.params:
@@ -53,6 +80,12 @@ class FlatBucket:
                 p.grad = self.grad[o:o + n].view(p.shape)
                 p._dcs_grad_sink = p.grad        # backward kernels write here directly (functional._sink)
         self.offsets = offs
+        off_of = {id(p): o for p, o in zip(self.params, offs)}
+        for rl, layer, kind, ps in groups:        # stacked views of value and gradient (functional._LstmLayerFn)
+            o, n = off_of[id(ps[0])], sum(p.numel() for p in ps)
+            shape = (2, 2, *ps[0].shape) if kind == 'weight_hh' else (2, 2 * ps[0].shape[0], *ps[0].shape[1:])
+            st = rl.__dict__.setdefault('_dcs_stacked', {})
+            st.setdefault(layer, {})[kind] = (self.flat[o:o + n].view(shape), self.grad[o:o + n].view(shape))
 
     def zero_grad(self):
         self.grad.zero_()

@@ -302,11 +302,68 @@ class _LstmRecFn(torch.autograd.Function):
         return g_pre5, g_whh
 
 
+class _LstmLayerFn(torch.autograd.Function):
+    """One bidirectional layer of both LSTM parameter sets over STACKED parameters that are views of a
+    dp.FlatBucket (st[kind] = (value view, gradient view); weight_ih [2, 8H, in], weight_hh [2, 2, 4H, H],
+    biases [2, 8H]): no per-parameter cat / stack in forward, and backward accumulates the four parameter
+    gradients straight into the bucket (returns None to autograd) — ~12 launches instead of ~60 per layer."""
+
+    @staticmethod
+    def forward(ctx, inp, anchor, st, B2, S):
+        w_ih, w_hh = st['weight_ih'][0], st['weight_hh'][0]
+        bias = st['bias_ih'][0] + st['bias_hh'][0]
+        gx = torch.baddbmm(bias.unsqueeze(1), inp, w_ih.transpose(1, 2))          # (set, n*t, dir*4H)
+        G4 = gx.shape[-1] // 2
+        need = inp.requires_grad or anchor.requires_grad
+        out, gates, c = ops.lstm_layer(gx, w_hh, 2, B2, S, (B2 * S * 2 * G4, S * 2 * G4, 2 * G4), need)
+        ctx.st, ctx.dims = st, (B2, S)
+        if need:
+            ctx.save_for_backward(inp, out, gates, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        global sink_hits
+        inp, out, gates, c = ctx.saved_tensors
+        st, (B2, S) = ctx.st, ctx.dims
+        w_ih, w_hh = st['weight_ih'][0], st['weight_hh'][0]
+        H = w_hh.shape[-1]
+        g_pre = ops.lstm_layer_bwd(g_out.contiguous(), gates, c, w_hh, 2, B2, S)
+        g_pre5 = g_pre.view(2, B2, S, 2, 4 * H)
+        o = out.view(2, B2, S, 2, H)
+        h_prev = torch.zeros_like(o)
+        h_prev[:, :, 1:, 0] = o[:, :, :-1, 0]               # forward direction: h_{t-1}
+        h_prev[:, :, :-1, 1] = o[:, :, 1:, 1]               # reverse direction: h_{t+1}
+        st['weight_hh'][1].add_(torch.einsum('sntdj,sntdk->sdjk', g_pre5, h_prev))
+        g_gx = g_pre.view(2, B2 * S, 8 * H)
+        g_b = g_gx.sum(1)
+        st['bias_ih'][1].add_(g_b)
+        st['bias_hh'][1].add_(g_b)
+        g_wih = st['weight_ih'][1]
+        torch.baddbmm(g_wih, g_gx.transpose(1, 2), inp, out=g_wih)      # accumulate in place
+        sink_hits += 16
+        g_inp = torch.bmm(g_gx, w_ih) if ctx.needs_input_grad[0] else None
+        return g_inp, None, None, None, None
+
+
+def _stacked_lstm(real_lstm):
+    """Stacked parameter views registered by dp.FlatBucket, if they still alias the live parameters and their
+    gradients (and autograd is going to need them)."""
+    st = getattr(real_lstm, '_dcs_stacked', None)
+    if not st:
+        return None
+    p = real_lstm.weight_ih_l0
+    v, g = st[0]['weight_ih']
+    if p.data_ptr() != v.data_ptr() or p.grad is None or p.grad.data_ptr() != g.data_ptr():
+        return None
+    return st
+
+
 def complex_lstm(z, real_lstm, imag_lstm):
     """ComplexLSTM.forward (c_network.py:33-47) for two bidirectional batch_first nn.LSTM
     parameter containers.  Per layer: one batched input-projection GEMM for all time steps
-    (rocBLAS via torch, differentiated by autograd) + one persistent HIP launch for the recurrence
-    of all 4 passes x 2 directions (hand-written BPTT)."""
+    (rocBLAS via torch) + one persistent HIP launch for the recurrence of all 4 passes x 2 directions
+    (hand-written BPTT)."""
     if not (real_lstm.bidirectional and real_lstm.batch_first and real_lstm.hidden_size == 64):
         raise DcsHipError('complex_lstm: the HIP path implements the reference geometry '
                           '(bidirectional, batch_first, hidden 64: c_network.py:118-123)')
@@ -315,7 +372,12 @@ def complex_lstm(z, real_lstm, imag_lstm):
     # rows 0..B-1: real parts, rows B..2B-1: imaginary parts; both weight sets see the same input
     x = torch.view_as_real(z).permute(3, 0, 1, 2).reshape(1, 2 * B * S, I)
     inp = x.expand(2, -1, -1)
+    stacked = _stacked_lstm(real_lstm) if torch.is_grad_enabled() else None
     for layer in range(real_lstm.num_layers):
+        if stacked is not None:
+            out = _LstmLayerFn.apply(inp, real_lstm.weight_ih_l0, stacked[layer], 2 * B, S)
+            inp = out.view(2, 2 * B * S, -1)
+            continue
         names = [f'_l{layer}', f'_l{layer}_reverse']
         w_ih = torch.stack([torch.cat([getattr(m, 'weight_ih' + n) for n in names]) for m in sets])      # [2, 8H, in]
         bias = torch.stack([torch.cat([getattr(m, 'bias_ih' + n) + getattr(m, 'bias_hh' + n) for n in names])
