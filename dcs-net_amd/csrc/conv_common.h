@@ -64,6 +64,16 @@ int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW);
 int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, float* slab_b, int n_slabs,
                                hipStream_t stream);
 
+// conv_wgrad_small.hip (a: forward geometry with conv_direct.hip's 16x16 tiling filled in)
+bool dcs_conv_wgrad_small_ok(const conv::Args& a);
+int dcs_conv_wgrad_small_launch(const conv::Args& a, const float* gy, float2* slab_w, float2* slab_b, int n_slabs,
+                                hipStream_t stream);
+
+// conv_small.hip: class-decomposed data gradient of the 1->8 stride-2 7x7 conv
+bool dcs_conv_small_dgrad_ok(int Cin, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int up_f, int up_t);
+int dcs_conv_small_dgrad_launch(const float* gy, const float* wp_bwd, float* gx, int B, int Hx, int Wx, int Hg, int Wg,
+                                int pad_f, int pad_t, hipStream_t stream);
+
 // conv_mfma.hip
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);
 int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream);

@@ -504,6 +504,8 @@ extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float*
         gxv = (float*)workspace;
     }
     a.y = (float2*)gxv;
+    if (C2 == 0 && dcs_conv_small_dgrad_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t))
+        return dcs_conv_small_dgrad_launch(gy, wp_bwd, gx1, B, Hv, Wv, Hout, Wout, pad_f, pad_t, s);   // enc0: conv_small.hip
     int rc;
     if (conv::stride_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t)) {
         // one compact sub-kernel per residue class of the input pixel instead of zero insertion
@@ -582,6 +584,13 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     w.slab_b = w.slab_w + (long)w.n_slabs * wsz;
     w.total_tiles = w.c.tiles_w * w.c.tiles_h * B;
     const int Cin = C1 + C2;
+    if (dcs_conv_wgrad_small_ok(w.c)) {          // 7x7 2->1 / 1->8: pixel-stationary kernel (conv_wgrad_small.hip)
+        hipStream_t s = dcs_stream(stream);
+        const int ns = w.n_slabs < 512 ? w.n_slabs : 512;       // two resident workgroups per CU
+        const int rc = dcs_conv_wgrad_small_launch(w.c, gy, w.slab_w, w.slab_b, ns, s);
+        if (rc != DCS_OK) return rc;
+        return launch_wgrad_reduce(w.slab_w, w.slab_b, ns, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed, s);
+    }
     const int n_ci = (Cin + CHUNK - 1) / CHUNK;
     w.n_co_chunks = (Cout + WG_CO - 1) / WG_CO;
     const size_t lds = ((size_t)CHUNK * w.c.plane + (size_t)TH * TW * WG_CO) * sizeof(float2);

@@ -1,0 +1,145 @@
+// conv_wgrad_small.hip — weight gradient of the two 7x7 small-channel convolutions of the network, pixel-stationary.
+//
+//   MODE 0  spatial-attention conv: 2 -> 1 channels, stride 1 (c_network.py:74-84): 98 complex outputs
+//   MODE 1  first encoder conv:     1 -> 8 channels, stride 2 (c_network.py:107-112, config.py:83-91): 392 outputs
+//
+// g_W[tap][ci][co] = sum_p g_Y[p][co] conj(X[p*s - pad + tap][ci]) has far fewer outputs than pixels, so the
+// generic output-stationary kernel (conv_direct.hip) re-reads both operands from LDS for every FMA quad.  Here a
+// thread owns PIXELS and keeps all 49 taps x 2 of the outputs in registers (196 VGPRs): g_Y comes from HBM once
+// per pixel, the haloed input tile is staged in LDS once per 16x16 tile, and each LDS read feeds 4-8 FMAs.
+//   MODE 0: the 256 threads take the 256 pixels of a tile; acc[tap][ci].
+//   MODE 1: wave w owns output channels (2w, 2w+1) and walks all 256 pixels of the tile in 4 passes; acc[tap][co&1].
+// The lanes are summed once per workgroup (DPP row shifts / broadcasts; cross-wave through LDS for MODE 0) into
+// one partial slab per workgroup — same slab layout and reduce kernel as the other weight-gradient paths, no atomics.
+#include "conv_common.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16, KS = 7, TAPS = KS * KS;
+
+struct SArgs {
+    conv::Args c;
+    const float2* gy; float2* slab_w; float2* slab_b;
+    int n_slabs, total_tiles;
+};
+
+template <int MODE, int S>
+__global__ __launch_bounds__(256, 2) void cconv_wgrad_small_kernel(SArgs w) {
+    constexpr int NC = MODE == 0 ? 2 : 1;
+    constexpr int ROWS = (TH - 1) * S + KS, COLS = (TW - 1) * S + KS, COLSP = COLS | 1, PLANE = ROWS * COLSP + 1;
+    __shared__ float2 tile[NC * PLANE];
+    __shared__ float2 red[4][2 * TAPS + 2];
+    const conv::Args& a = w.c;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tiles_per_img = a.tiles_w * a.tiles_h;
+
+    float ar[TAPS][2], ai[TAPS][2];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) { ar[tp][0] = ar[tp][1] = ai[tp][0] = ai[tp][1] = 0.f; }
+    float2 b0 = make_float2(0.f, 0.f), b1 = make_float2(0.f, 0.f);
+
+    for (int tl = blockIdx.x; tl < w.total_tiles; tl += w.n_slabs) {
+        const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
+        const int oy0 = (tile_id / a.tiles_w) * TH, ox0 = (tile_id % a.tiles_w) * TW;
+        const int vy0 = oy0 * S - a.pad_f, vx0 = ox0 * S - a.pad_t;
+        __syncthreads();
+        for (int idx = t; idx < ROWS * COLS * NC; idx += 256) {
+            const int ci = idx % NC, px = idx / NC;
+            const int ix = px % COLS, iy = px / COLS;
+            tile[ci * PLANE + iy * COLSP + ix] = conv::gather(a, b, vy0 + iy, vx0 + ix, ci);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int sub = 0; sub < (MODE == 0 ? 1 : 4); ++sub) {
+            const int p = MODE == 0 ? t : sub * 64 + lane;
+            const int py = p / TW, pxx = p % TW;
+            const int oy = oy0 + py, ox = ox0 + pxx;
+            float2 g0 = make_float2(0.f, 0.f), g1 = make_float2(0.f, 0.f);
+            if (oy < a.Hout && ox < a.Wout) {
+                const long o = ((long)b * a.Hout + oy) * a.Wout + ox;
+                if (MODE == 0) {
+                    g0 = w.gy[o];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(w.gy + o * 8 + 2 * wave);
+                    g0 = make_float2(v.x, v.y); g1 = make_float2(v.z, v.w);
+                }
+            }
+            b0.x += g0.x; b0.y += g0.y; b1.x += g1.x; b1.y += g1.y;
+            const float2* base = tile + (py * S) * COLSP + pxx * S;
+#pragma unroll
+            for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx) {
+                    const int tp = dy * KS + dx;
+                    const float2 x0 = base[dy * COLSP + dx];
+                    // g * conj(x)
+                    ar[tp][0] = fmaf(g0.x, x0.x, fmaf(g0.y, x0.y, ar[tp][0]));
+                    ai[tp][0] = fmaf(g0.y, x0.x, fmaf(-g0.x, x0.y, ai[tp][0]));
+                    if (MODE == 0) {
+                        const float2 x1 = base[PLANE + dy * COLSP + dx];
+                        ar[tp][1] = fmaf(g0.x, x1.x, fmaf(g0.y, x1.y, ar[tp][1]));
+                        ai[tp][1] = fmaf(g0.y, x1.x, fmaf(-g0.x, x1.y, ai[tp][1]));
+                    } else {
+                        ar[tp][1] = fmaf(g1.x, x0.x, fmaf(g1.y, x0.y, ar[tp][1]));
+                        ai[tp][1] = fmaf(g1.y, x0.x, fmaf(-g1.x, x0.y, ai[tp][1]));
+                    }
+                }
+        }
+    }
+
+    // lanes -> one value per output.  Output j = tap*2 + k: MODE 0 (tap, ci = k); MODE 1 (tap, co = 2*wave + k)
+    const long wsz = (long)TAPS * (MODE == 0 ? 2 : 8);
+    float2* slab = w.slab_w + (long)blockIdx.x * wsz;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float sr = dcs_wave_sum_lane63(ar[tp][k]), si = dcs_wave_sum_lane63(ai[tp][k]);
+            if (lane == 63) {
+                if (MODE == 0) red[wave][tp * 2 + k] = make_float2(sr, si);
+                else slab[tp * 8 + 2 * wave + k] = make_float2(sr, si);
+            }
+        }
+    const float2 s0 = make_float2(dcs_wave_sum_lane63(b0.x), dcs_wave_sum_lane63(b0.y));
+    const float2 s1 = make_float2(dcs_wave_sum_lane63(b1.x), dcs_wave_sum_lane63(b1.y));
+    if (MODE == 1) {
+        if (lane == 63) {
+            w.slab_b[(long)blockIdx.x * 8 + 2 * wave] = s0;
+            w.slab_b[(long)blockIdx.x * 8 + 2 * wave + 1] = s1;
+        }
+        return;
+    }
+    if (lane == 63) red[wave][2 * TAPS] = s0;
+    __syncthreads();
+    if (t <= 2 * TAPS) {
+        float2 v = red[0][t];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { v.x += red[q][t].x; v.y += red[q][t].y; }
+        if (t < 2 * TAPS) slab[t] = v;                     // [tap][ci][co = 0]
+        else w.slab_b[blockIdx.x] = v;
+    }
+}
+
+}  // namespace
+
+// forward geometry `a` (fwd_args + conv_geometry of conv_direct.hip: 16x16 tiles)
+bool dcs_conv_wgrad_small_ok(const conv::Args& a) {
+    if (a.kh != KS || a.kw != KS || a.up_f != 1 || a.up_t != 1 || a.C2 != 0 || a.sf != a.st) return false;
+    if (a.C1 == 2 && a.Cout == 1 && a.sf == 1) return true;
+    return a.C1 == 1 && a.Cout == 8 && a.sf == 2;
+}
+
+// slab_w: float2[n_slabs][49][Cin][Cout]; slab_b: float2[n_slabs][Cout]
+int dcs_conv_wgrad_small_launch(const conv::Args& a, const float* gy, float2* slab_w, float2* slab_b, int n_slabs,
+                                hipStream_t stream) {
+    if (!dcs_conv_wgrad_small_ok(a) || n_slabs < 1) return DCS_ERR_BADARG;
+    SArgs w;
+    w.c = a;
+    w.gy = (const float2*)gy; w.slab_w = slab_w; w.slab_b = slab_b;
+    w.n_slabs = n_slabs;
+    w.total_tiles = a.tiles_w * a.tiles_h * a.B;
+    if (a.C1 == 2) hipLaunchKernelGGL((cconv_wgrad_small_kernel<0, 1>), dim3(n_slabs), dim3(256), 0, stream, w);
+    else hipLaunchKernelGGL((cconv_wgrad_small_kernel<1, 2>), dim3(n_slabs), dim3(256), 0, stream, w);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

@@ -32,6 +32,22 @@ __device__ __forceinline__ float dcs_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// wave64 sum through DPP (no LDS crossbar traffic): 4 row shifts + 2 row broadcasts; the total is valid in
+// LANE 63 ONLY.  ~6 VALU instructions per value instead of 6 ds_bpermute round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dcs_dpp_term(float v) {
+    // lanes without a valid source (shifted in from outside the row, or masked rows) contribute 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float dcs_wave_sum_lane63(float v) {
+    v += dcs_dpp_term<0x111, 0xf>(v);        // row_shr:1
+    v += dcs_dpp_term<0x112, 0xf>(v);        // row_shr:2
+    v += dcs_dpp_term<0x114, 0xf>(v);        // row_shr:4
+    v += dcs_dpp_term<0x118, 0xf>(v);        // row_shr:8   -> lane 15 of each row holds the row sum
+    v += dcs_dpp_term<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    v += dcs_dpp_term<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ double dcs_wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
