@@ -149,66 +149,3 @@ extern "C" int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, flo
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
-
-// ---- polar round trip of the step functions (network_functions.py:213-221, :244-247) -----------------
-// mag_phase_2_wave(|z|, atan2(z_i, z_r + eps)) rebuilds mag*cos(phase) + j mag*sin(phase) and pads a zero bin
-// before the iSTFT: 9 element-wise launches per signal in the reference (abs, add, atan2, cos, sin, 2 mul,
-// complex, pad), 5 signals per step.  cos/sin(atan2(y, x)) = (x, y)/hypot(x, y), so it is one pass:
-//     out[b][f][t] = |z| * unit(z_r + eps, z_i)   for f < F,   0 for the padded bins F..Fp-1
-namespace {
-__global__ __launch_bounds__(kThreads) void polar_pad_fwd_kernel(const float2* __restrict__ z, float2* __restrict__ out,
-                                                                  long B, int F, int Fp, int T, float eps) {
-    const long n = B * Fp * T;
-    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-        const int t = (int)(i % T);
-        const long r = i / T;
-        const int f = (int)(r % Fp);
-        const long b = r / Fp;
-        float2 o = make_float2(0.f, 0.f);
-        if (f < F) {
-            const float2 v = z[(b * F + f) * T + t];
-            const float m = hypotf(v.x, v.y);
-            const float2 d = unit_dir(v.x + eps, v.y);
-            o = make_float2(m * d.x, m * d.y);
-        }
-        out[i] = o;
-    }
-}
-
-// g_z = (z/|z|) (u.g) + |z| (g - u (u.g)) / |v|,  u = unit(v), v = (z_r + eps, z_i)
-__global__ __launch_bounds__(kThreads) void polar_pad_bwd_kernel(const float2* __restrict__ z, const float2* __restrict__ g,
-                                                                  float2* __restrict__ gz, long B, int F, int Fp, int T,
-                                                                  float eps) {
-    const long n = B * F * T;
-    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-        const int t = (int)(i % T);
-        const long r = i / T;
-        const int f = (int)(r % F);
-        const long b = r / F;
-        const float2 v = z[i], go = g[(b * Fp + f) * T + t];
-        const float m = hypotf(v.x, v.y);
-        const float2 d = unit_dir(v.x + eps, v.y);
-        const float dot = d.x * go.x + d.y * go.y;
-        float2 o = unit_dir_bwd(v.x + eps, v.y, make_float2(m * go.x, m * go.y));
-        if (m > 0.f) { o.x += dot * v.x / m; o.y += dot * v.y / m; }
-        gz[i] = o;
-    }
-}
-}  // namespace
-
-extern "C" int dcs_polar_pad_fwd(const float* z, float* out, long B, int F, int Fp, int T, float eps, dcs_stream_t stream) {
-    if (!z || !out || B <= 0 || F <= 0 || Fp < F || T <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(polar_pad_fwd_kernel, dim3(ew_grid(B * Fp * T)), dim3(kThreads), 0, dcs_stream(stream),
-                       (const float2*)z, (float2*)out, B, F, Fp, T, eps);
-    DCS_CHECK_LAUNCH();
-    return DCS_OK;
-}
-
-extern "C" int dcs_polar_pad_bwd(const float* z, const float* g_out, float* g_z, long B, int F, int Fp, int T, float eps,
-                                 dcs_stream_t stream) {
-    if (!z || !g_out || !g_z || B <= 0 || F <= 0 || Fp < F || T <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(polar_pad_bwd_kernel, dim3(ew_grid(B * F * T)), dim3(kThreads), 0, dcs_stream(stream),
-                       (const float2*)z, (const float2*)g_out, (float2*)g_z, B, F, Fp, T, eps);
-    DCS_CHECK_LAUNCH();
-    return DCS_OK;
-}

@@ -1,0 +1,194 @@
+// synth.hip — the waveform-synthesis ends of the step functions (network_functions.py:140-150, :213-221, :244-247),
+// i.e. what surrounds the inverse FFT of mag_phase_2_wave / torch.istft:
+//
+//   dcs_polar_frames_fwd/_bwd   |z| (cos, sin)(atan2(z_i, z_r + eps)), zero-padded by the dropped bin and written
+//                               FRAME-MAJOR [B][T][Fp] (each STFT frame's bins contiguous), so the inverse real FFT
+//                               is one contiguous batched c2r transform instead of a strided one plus a transposed
+//                               copy.  The transpose goes through a 32x33 LDS tile: both sides stay coalesced.
+//   dcs_istft_envelope          1 / sum_f w^2 of torch.istft's window-envelope normalisation (depends on T only)
+//   dcs_istft_ola_fwd/_bwd      synthesis window, overlap-add, envelope division and the n_fft/2 trim of
+//                               torch.istft(center=True) in one pass: each output sample gathers its n_fft/hop frames
+//                               (backward: each frame element reads the one sample it fed).
+// All HBM-bound; they replace ~10 ATen launches per synthesised signal (complex mul, copies, window mul,
+// fill + arange + unfold_backward, slice, div) and their autograd counterparts.
+#include "dcs_common.h"
+
+namespace {
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float2 unit_dir(float x, float y) {
+    const float h = hypotf(x, y);
+    if (h == 0.f) return make_float2(1.f, 0.f);       // atan2(0, 0) = 0
+    return make_float2(x / h, y / h);
+}
+// d unit_dir(v) / dv applied to a cotangent: (g - u (u.g)) / |v|   (0 at the singular point)
+__device__ __forceinline__ float2 unit_dir_bwd(float x, float y, float2 g) {
+    const float h = hypotf(x, y);
+    if (h == 0.f) return make_float2(0.f, 0.f);
+    const float ux = x / h, uy = y / h;
+    const float d = ux * g.x + uy * g.y;
+    return make_float2((g.x - ux * d) / h, (g.y - uy * d) / h);
+}
+
+// grid (ceil(T/32), ceil(Fp/32), B); block 32 x 8
+__global__ __launch_bounds__(kThreads) void polar_frames_fwd_kernel(const float2* __restrict__ z, float2* __restrict__ out,
+                                                                     int F, int Fp, int T, float eps) {
+    __shared__ float2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+    const long b = blockIdx.z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + ty + 8 * r, t = t0 + tx;
+        float2 o = make_float2(0.f, 0.f);
+        if (f < F && t < T) {
+            const float2 v = z[(b * F + f) * T + t];
+            const float m = hypotf(v.x, v.y);
+            const float2 d = unit_dir(v.x + eps, v.y);
+            o = make_float2(m * d.x, m * d.y);
+        }
+        tile[ty + 8 * r][tx] = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r, f = f0 + tx;
+        if (t < T && f < Fp) out[(b * T + t) * Fp + f] = tile[tx][ty + 8 * r];
+    }
+}
+
+// g_z = (z/|z|) (u.g) + |z| (g - u (u.g)) / |v|,  u = unit(v), v = (z_r + eps, z_i);  g is frame-major
+__global__ __launch_bounds__(kThreads) void polar_frames_bwd_kernel(const float2* __restrict__ z, const float2* __restrict__ g,
+                                                                     float2* __restrict__ gz, int F, int Fp, int T,
+                                                                     float eps) {
+    __shared__ float2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+    const long b = blockIdx.z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r, f = f0 + tx;
+        tile[tx][ty + 8 * r] = (t < T && f < F) ? g[(b * T + t) * Fp + f] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + ty + 8 * r, t = t0 + tx;
+        if (f < F && t < T) {
+            const long i = (b * F + f) * T + t;
+            const float2 v = z[i], go = tile[ty + 8 * r][tx];
+            const float m = hypotf(v.x, v.y);
+            const float2 d = unit_dir(v.x + eps, v.y);
+            const float dot = d.x * go.x + d.y * go.y;
+            float2 o = unit_dir_bwd(v.x + eps, v.y, make_float2(m * go.x, m * go.y));
+            if (m > 0.f) { o.x += dot * v.x / m; o.y += dot * v.y / m; }
+            gz[i] = o;
+        }
+    }
+}
+
+// frames covering OLA position p: f in [max(0, ceil((p - n_fft + 1) / hop)), min(T - 1, p / hop)]
+__device__ __forceinline__ void frame_range(int p, int n_fft, int hop, int T, int* f_lo, int* f_hi) {
+    const int lo = p - n_fft + 1;
+    *f_lo = lo > 0 ? (lo + hop - 1) / hop : 0;
+    const int hi = p / hop;
+    *f_hi = hi < T - 1 ? hi : T - 1;
+}
+
+__global__ __launch_bounds__(kThreads) void istft_envelope_kernel(const float* __restrict__ w, float* __restrict__ inv_env,
+                                                                   int T, int n_fft, int hop, int Lout) {
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= Lout) return;
+    const int p = n + n_fft / 2;
+    int f_lo, f_hi;
+    frame_range(p, n_fft, hop, T, &f_lo, &f_hi);
+    float s = 0.f;
+    for (int f = f_lo; f <= f_hi; ++f) { const float v = w[p - f * hop]; s = fmaf(v, v, s); }
+    inv_env[n] = 1.f / s;
+}
+
+// y[b][n] = scale * inv_env[n] * sum_f w[p - f hop] frames[b][f][p - f hop],  p = n + n_fft/2
+__global__ __launch_bounds__(kThreads) void istft_ola_fwd_kernel(const float* __restrict__ frames, const float* __restrict__ w,
+                                                                  const float* __restrict__ inv_env, float* __restrict__ y,
+                                                                  int T, int n_fft, int hop, int Lout, float scale) {
+    const int n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= Lout) return;
+    const long b = blockIdx.y;
+    const int p = n + n_fft / 2;
+    int f_lo, f_hi;
+    frame_range(p, n_fft, hop, T, &f_lo, &f_hi);
+    const float* fr = frames + b * T * n_fft;
+    float s = 0.f;
+    for (int f = f_lo; f <= f_hi; ++f) {
+        const int k = p - f * hop;
+        s = fmaf(w[k], fr[(long)f * n_fft + k], s);
+    }
+    y[b * Lout + n] = scale * inv_env[n] * s;
+}
+
+// g_frames[b][f][k] = scale * w[k] * inv_env[n] * g_y[b][n],  n = f hop + k - n_fft/2 (0 outside the trimmed signal)
+__global__ __launch_bounds__(kThreads) void istft_ola_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                  const float* __restrict__ inv_env, float* __restrict__ gf,
+                                                                  int T, int n_fft, int hop, int Lout, float scale) {
+    const long i = (long)blockIdx.x * kThreads + threadIdx.x;        // (f, k) of one batch item
+    if (i >= (long)T * n_fft) return;
+    const long b = blockIdx.y;
+    const int k = (int)(i % n_fft), f = (int)(i / n_fft);
+    const int n = f * hop + k - n_fft / 2;
+    float v = 0.f;
+    if (n >= 0 && n < Lout) v = scale * w[k] * inv_env[n] * gy[b * Lout + n];
+    gf[b * T * n_fft + i] = v;
+}
+}  // namespace
+
+extern "C" int dcs_polar_frames_fwd(const float* z, float* out, int B, int F, int Fp, int T, float eps, dcs_stream_t stream) {
+    if (!z || !out || B <= 0 || B > 65535 || F <= 0 || Fp < F || T <= 0) return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(polar_frames_fwd_kernel, dim3((T + 31) / 32, (Fp + 31) / 32, B), dim3(kThreads), 0, dcs_stream(stream),
+                       (const float2*)z, (float2*)out, F, Fp, T, eps);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_polar_frames_bwd(const float* z, const float* g_out, float* g_z, int B, int F, int Fp, int T, float eps,
+                                    dcs_stream_t stream) {
+    if (!z || !g_out || !g_z || B <= 0 || B > 65535 || F <= 0 || Fp < F || T <= 0) return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(polar_frames_bwd_kernel, dim3((T + 31) / 32, (F + 31) / 32, B), dim3(kThreads), 0, dcs_stream(stream),
+                       (const float2*)z, (const float2*)g_out, (float2*)g_z, F, Fp, T, eps);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+static bool ola_ok(int B, int T, int n_fft, int hop) {
+    return B > 0 && B <= 65535 && T > 0 && n_fft > 1 && !(n_fft & 1) && hop > 0 && hop <= n_fft &&
+           (long)hop * (T - 1) > 0;
+}
+
+extern "C" int dcs_istft_envelope(const float* window, float* inv_env, int T, int n_fft, int hop, dcs_stream_t stream) {
+    if (!window || !inv_env || !ola_ok(1, T, n_fft, hop)) return DCS_ERR_BADARG;
+    const int Lout = hop * (T - 1);
+    hipLaunchKernelGGL(istft_envelope_kernel, dim3((Lout + kThreads - 1) / kThreads), dim3(kThreads), 0, dcs_stream(stream),
+                       window, inv_env, T, n_fft, hop, Lout);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_istft_ola_fwd(const float* frames, const float* window, const float* inv_env, float* y, int B, int T,
+                                 int n_fft, int hop, float scale, dcs_stream_t stream) {
+    if (!frames || !window || !inv_env || !y || !ola_ok(B, T, n_fft, hop)) return DCS_ERR_BADARG;
+    const int Lout = hop * (T - 1);
+    hipLaunchKernelGGL(istft_ola_fwd_kernel, dim3((Lout + kThreads - 1) / kThreads, B), dim3(kThreads), 0,
+                       dcs_stream(stream), frames, window, inv_env, y, T, n_fft, hop, Lout, scale);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_istft_ola_bwd(const float* g_y, const float* window, const float* inv_env, float* g_frames, int B, int T,
+                                 int n_fft, int hop, float scale, dcs_stream_t stream) {
+    if (!g_y || !window || !inv_env || !g_frames || !ola_ok(B, T, n_fft, hop)) return DCS_ERR_BADARG;
+    const int Lout = hop * (T - 1);
+    const long per = (long)T * n_fft;
+    hipLaunchKernelGGL(istft_ola_bwd_kernel, dim3((unsigned)((per + kThreads - 1) / kThreads), B), dim3(kThreads), 0,
+                       dcs_stream(stream), g_y, window, inv_env, g_frames, T, n_fft, hop, Lout, scale);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

@@ -53,8 +53,11 @@ SIGNATURES = {
     'dcs_bound_crm_fwd': (_I, [_P, _P, _L, _F, _P]),
     'dcs_bound_mask_apply_fwd': (_I, [_P, _P, _P, _P, _P, _L, _F, _P]),
     'dcs_bound_mask_apply_bwd': (_I, [_P] * 6 + [_L, _F, _P]),
-    'dcs_polar_pad_fwd': (_I, [_P, _P, _L, _I, _I, _I, _F, _P]),
-    'dcs_polar_pad_bwd': (_I, [_P, _P, _P, _L, _I, _I, _I, _F, _P]),
+    'dcs_polar_frames_fwd': (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
+    'dcs_polar_frames_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    'dcs_istft_envelope': (_I, [_P, _P, _I, _I, _I, _P]),
+    'dcs_istft_ola_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    'dcs_istft_ola_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     'dcs_crm_fwd': (_I, [_P, _P, _P, _L, _F, _P]),
     'dcs_adam_amsgrad_step': (_I, [_P] * 6 + [_F, _F, _L, _F, _F, _F, _F, _F, _I, _P, _P]),
     'dcs_pack_plan_begin': (_I, []),

@@ -148,6 +148,7 @@ class C_NETWORK(LightningModule):
         self.dropout_conv = torch.nn.Dropout(hp['dropout_conv'])
         self.dropout_fc = torch.nn.Dropout(hp['dropout_fc'])
         self._drop_calls = 0
+        self._counted = False
         self.weights_init()
 
     def weights_init(self):
@@ -167,7 +168,26 @@ class C_NETWORK(LightningModule):
 
     def _bn(self, bn, x, act, p=0.0):
         dp, seed = self._drop(p)
-        return bn._hip_forward(x, act, dp, seed)
+        return bn._hip_forward(x, act, dp, seed, count=not self._counted)
+
+    def _count_batches(self):
+        """num_batches_tracked += 1 for every CBN of the forward path as ONE launch: the 14 scalar buffers are
+        views of one int64 tensor (re-made whenever a buffer was replaced, e.g. by .to(device))."""
+        bns = [self.initial_batchnorm] + [st[1] for st in self.encoder] + [st[1] for st in self.decoder
+                                                                           if isinstance(st, torch.nn.Sequential)]
+        self._counted = False
+        if not (self.training and all(b.track_running_stats and b.momentum is not None for b in bns)):
+            return
+        shared = getattr(self, '_nbt_shared', None)
+        dev = bns[0].num_batches_tracked.device
+        if (shared is None or shared.device != dev or shared.numel() != len(bns) or
+                any(b.num_batches_tracked.data_ptr() != shared[i].data_ptr() for i, b in enumerate(bns))):
+            shared = torch.stack([b.num_batches_tracked.detach().to(torch.long) for b in bns])
+            for i, b in enumerate(bns):
+                b._buffers['num_batches_tracked'] = shared[i]
+            self.__dict__['_nbt_shared'] = shared
+        shared += 1
+        self._counted = True
 
     def forward(self, x):
         hp, cfg = self.hparams, self.config
@@ -181,6 +201,7 @@ class C_NETWORK(LightningModule):
 
         # [B,F,T] complex IS channels-last with C = 1 (c_network.py:190)
         e = torch.view_as_real(x.contiguous()).view(B, Fbins, T, 1, 2)
+        self._count_batches()
         enc = [self._bn(self.initial_batchnorm, e, F.ACT_NONE)]
         for i in range(L):                                   # c_network.py:193-197
             conv, bn = self.encoder[i][0], self.encoder[i][1]

@@ -119,12 +119,14 @@ class _ComplexBatchNorm(Module):
                 self.weight[:, 2] = 0
                 self.bias.zero_()
 
-    def _hip_forward(self, x_nhwc, act=F.ACT_NONE, drop_p=0.0, seed=0):
-        """x: float [B,H,W,C,2].  Shared with the fused C_NETWORK.forward."""
+    def _hip_forward(self, x_nhwc, act=F.ACT_NONE, drop_p=0.0, seed=0, count=True):
+        """x: float [B,H,W,C,2].  Shared with the fused C_NETWORK.forward (which advances all the
+        num_batches_tracked counters of the network with one launch and passes count=False)."""
         use_batch = self.training or not self.track_running_stats
         momentum = -1.0
         if self.training and self.track_running_stats:
-            self.num_batches_tracked += 1
+            if count or self.momentum is None:
+                self.num_batches_tracked += 1
             momentum = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
         rm = torch.view_as_real(self.running_mean) if self.track_running_stats else None
         return F.cbn(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,

@@ -476,24 +476,44 @@ class _BoundMaskApplyFn(torch.autograd.Function):
         return None, ops.bound_mask_apply_bwd(Y, M_in, c(gM), c(gN), c(gS), ctx.eps), None
 
 
-class _PolarPadFn(torch.autograd.Function):
+class _PolarFramesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, Fp, eps):
         ctx.cfg = (Fp, eps)
         ctx.save_for_backward(z)
-        return ops.polar_pad(z, Fp, eps)
+        return ops.polar_frames(z, Fp, eps)
 
     @staticmethod
     def backward(ctx, g):
         (z,) = ctx.saved_tensors
-        return ops.polar_pad(z, ctx.cfg[0], ctx.cfg[1], grad=g.contiguous()), None, None
+        return ops.polar_frames(z, ctx.cfg[0], ctx.cfg[1], grad=g.contiguous()), None, None
 
 
-def polar_pad_complex(z, pad_bins=1, eps=10e-7):
-    """|z| (cos phi + j sin phi), phi = atan2(z_i, z_r + eps), with `pad_bins` zero bins appended on the
-    frequency axis: the spectrum mag_phase_2_wave hands to the iSTFT (network_functions.py:140-145)."""
+def polar_frames_complex(z, pad_bins=1, eps=10e-7):
+    """|z| (cos phi + j sin phi), phi = atan2(z_i, z_r + eps), with `pad_bins` zero bins appended on the frequency
+    axis — the spectrum mag_phase_2_wave hands to the iSTFT (network_functions.py:140-145) — returned FRAME-MAJOR:
+    complex [B, T, F + pad_bins] for z complex [B, F, T]."""
     zr = torch.view_as_real(z.contiguous())
-    return torch.view_as_complex(_PolarPadFn.apply(zr, z.shape[1] + pad_bins, eps))
+    return torch.view_as_complex(_PolarFramesFn.apply(zr, z.shape[1] + pad_bins, eps))
+
+
+class _IstftOlaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, frames, window, inv_env, hop, scale):
+        ctx.cfg = (tuple(frames.shape), hop, scale)
+        ctx.save_for_backward(window, inv_env)
+        return ops.istft_ola(frames.contiguous(), window, inv_env, hop, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        window, inv_env = ctx.saved_tensors
+        shape, hop, scale = ctx.cfg
+        return ops.istft_ola(shape, window, inv_env, hop, scale, grad=g.contiguous()), None, None, None, None
+
+
+def istft_ola(frames, window, inv_env, hop, scale=1.0):
+    """Windowed overlap-add, envelope division and centre trim of torch.istft over irfft frames [B,T,n_fft]."""
+    return _IstftOlaFn.apply(frames, window, inv_env, hop, scale)
 
 
 def bound_crm_complex(M, eps=10e-7):

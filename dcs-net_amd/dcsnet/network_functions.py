@@ -4,14 +4,16 @@ names and argument meaning of the reference's ``network_functions.py`` so ``c_ne
 
 On the hot path (HIP, libdcsnet_hip.so):  bound_cRM (:77-88), cRM (:62-75), the bound + complex
 multiply + subtract of the step functions (:240-243), complex_lrelu / complex_sigmoid
-(:98-112).  Plumbing that stays on PyTorch-ROCm (SURVEY.md §8f "next"): torch.istft, SiSNR,
-loss assembly.
+(:98-112), and the waveform synthesis of mag_phase_2_wave around the inverse FFT (:140-150: polar
+spectrum, window / overlap-add / envelope).  Plumbing that stays on PyTorch-ROCm (SURVEY.md §8f
+"next"): the inverse FFT itself (rocFFT via torch.fft.irfft), SiSNR, loss assembly.
 """
 import sys
 
 import torch
 
 from . import functional as F
+from . import ops
 
 try:                                     # metric packages are absent from this image (SURVEY §0)
     from pypesq import pesq
@@ -146,26 +148,29 @@ def _window_on(config, device):
 _envelopes = {}
 
 
-def istft(comp, n_fft, hop, window, normalized):
-    """torch.istft(center=True, onesided, length=None) spelled out — irfft, synthesis window, overlap-add,
-    division by the squared-window envelope, trim n_fft/2 at both ends — WITHOUT torch.istft's NOLA check,
-    which reads the envelope minimum back to the host (a synchronisation per call, and illegal inside a
-    hipGraph capture).  The envelope depends only on (window, frame count) and is cached."""
-    B, _, T = comp.shape
-    if normalized:
-        comp = comp * (float(n_fft) ** 0.5)
-    frames = torch.fft.irfft(comp, n=n_fft, dim=1).transpose(1, 2) * window          # [B, T, n_fft]
-    L = n_fft + hop * (T - 1)
-    # overlap-add = the adjoint of Tensor.unfold (what torch.istft itself uses; F.fold's backward is an im2col
-    # that is ~20x slower for a 512-wide kernel)
-    ola = lambda fr: torch.ops.aten.unfold_backward(fr, [fr.shape[0], L], 1, n_fft, hop)
-    key = (window.data_ptr(), T, hop, comp.device)
+def _inv_envelope(window, T, hop):
+    """1 / squared-window envelope for T frames; depends only on (window, T, hop): computed once (HIP)."""
+    key = (window.data_ptr(), T, hop, window.device)
     env = _envelopes.get(key)
     if env is None:
-        env = ola((window * window)[None, None, :].expand(1, T, n_fft).contiguous()).reshape(L)
-        env = _envelopes[key] = env[n_fft // 2: L - n_fft // 2].clone()
-    y = ola(frames.contiguous())[:, n_fft // 2: L - n_fft // 2]
-    return y / env
+        env = _envelopes[key] = ops.istft_envelope(window, T, hop)
+    return env
+
+
+def _frames_to_wave(comp_t, n_fft, hop, window, normalized):
+    """comp_t: complex [B, T, n_fft/2 + 1] frame-major one-sided spectra -> waveform [B, hop (T-1)]: one contiguous
+    batched inverse real FFT, then window / overlap-add / envelope / centre trim in ONE HIP pass
+    (dcs_istft_ola_fwd).  torch.istft's NOLA check — a host read-back per call, illegal under hipGraph capture — is
+    not made: the configured Hann window at hop <= n_fft/2 satisfies it by construction."""
+    T = comp_t.shape[1]
+    frames = torch.fft.irfft(comp_t, n=n_fft, dim=-1)                                # [B, T, n_fft]
+    scale = float(n_fft) ** 0.5 if normalized else 1.0
+    return F.istft_ola(frames, window, _inv_envelope(window, T, hop), hop, scale)
+
+
+def istft(comp, n_fft, hop, window, normalized):
+    """torch.istft(comp [B, n_fft/2+1, T], center=True, onesided, length=None) on the HIP synthesis path."""
+    return _frames_to_wave(comp.transpose(1, 2).contiguous(), n_fft, hop, window, normalized)
 
 
 def mag_phase_2_wave(mag, phase, config):
@@ -178,9 +183,11 @@ def mag_phase_2_wave(mag, phase, config):
 
 def _polar_wave(z, eps, config):
     """mag_phase_2_wave(|z|, atan2(z_i, z_r + eps)) of the step functions (network_functions.py:213-221,
-    :244-247) with the nine element-wise ops in front of the iSTFT fused into one HIP pass."""
-    comp = F.polar_pad_complex(z, 1, eps)
-    return istft(comp, config.fft_size, config.hop_length, _window_on(config, comp.device), config.normalise_stft)
+    :244-247): polar round trip + zero bin + frame-major transpose in one HIP pass, contiguous irfft, fused
+    overlap-add."""
+    comp_t = F.polar_frames_complex(z, 1, eps)
+    return _frames_to_wave(comp_t, config.fft_size, config.hop_length, _window_on(config, comp_t.device),
+                           config.normalise_stft)
 
 
 def calc_metric(clean_audio, predict_audio, config, metric):
@@ -224,7 +231,9 @@ def _complex_step(self, noise_data, noisy_data, clean_data, need_noisy_audio=Fal
         audio['noisy_audio'] = _polar_wave(noisy_data, eps, cfg)
     mask_out = self(noisy_data)
     if _mode() in ('dcs', 'drs'):
-        audio['target_noise_mask'] = bound_cRM(cRM(noise_data, noisy_data), self.hparams)
+        if need_noisy_audio or self.hparams.get('noise_loss_type') == 0:
+            # only the L1 mask loss reads it (the reference always builds it: network_functions.py:237-239)
+            audio['target_noise_mask'] = bound_cRM(cRM(noise_data, noisy_data), self.hparams)
         mask, noise_hat, clean_hat = bound_mask_apply(noisy_data, mask_out, self.hparams)
         audio['predict_noise_mask'] = mask
         audio['predict_noise_audio'] = _polar_wave(noise_hat, eps, cfg)

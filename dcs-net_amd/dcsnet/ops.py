@@ -467,20 +467,52 @@ def bound_mask_apply_bwd(Y, M_in, g_M, g_N, g_S, eps=10e-7):
     return g
 
 
-def polar_pad(z, Fp, eps=10e-7, grad=None):
-    """z: float [B,F,T,2].  Forward (grad None): [B,Fp,T,2] = |z| unit(z_r+eps, z_i), zero rows F..Fp-1.
-    With grad [B,Fp,T,2]: the cotangent of z."""
+def polar_frames(z, Fp, eps=10e-7, grad=None):
+    """z: float [B,F,T,2].  Forward (grad None): FRAME-MAJOR [B,T,Fp,2] = |z| unit(z_r+eps, z_i), zero bins F..Fp-1.
+    With grad [B,T,Fp,2]: the cotangent of z."""
     _chk(z, 'z', 4)
     B, F, T, _ = z.shape
     lib = _lib.load()
     if grad is None:
-        out = torch.empty((B, Fp, T, 2), dtype=torch.float32, device=z.device)
-        check(lib.dcs_polar_pad_fwd(ptr(z), ptr(out), B, F, Fp, T, eps, cur_stream()), 'dcs_polar_pad_fwd')
+        out = torch.empty((B, T, Fp, 2), dtype=torch.float32, device=z.device)
+        check(lib.dcs_polar_frames_fwd(ptr(z), ptr(out), B, F, Fp, T, eps, cur_stream()), 'dcs_polar_frames_fwd')
         return out
     _chk(grad, 'grad', 4)
     gz = torch.empty_like(z)
-    check(lib.dcs_polar_pad_bwd(ptr(z), ptr(grad), ptr(gz), B, F, Fp, T, eps, cur_stream()), 'dcs_polar_pad_bwd')
+    check(lib.dcs_polar_frames_bwd(ptr(z), ptr(grad), ptr(gz), B, F, Fp, T, eps, cur_stream()), 'dcs_polar_frames_bwd')
     return gz
+
+
+def istft_envelope(window, T, hop):
+    """1 / (squared-window overlap-add envelope) of torch.istft(center=True) for T frames: float [hop*(T-1)]."""
+    _chk(window, 'window', 1)
+    n_fft = window.numel()
+    inv_env = torch.empty(hop * (T - 1), dtype=torch.float32, device=window.device)
+    check(_lib.load().dcs_istft_envelope(ptr(window), ptr(inv_env), T, n_fft, hop, cur_stream()), 'dcs_istft_envelope')
+    return inv_env
+
+
+def istft_ola(frames, window, inv_env, hop, scale=1.0, grad=None):
+    """frames: float [B,T,n_fft] (irfft output).  Forward: windowed overlap-add / envelope / trim -> [B, hop*(T-1)].
+    With grad [B, hop*(T-1)]: the cotangent of frames (pass the frames' shape via `frames`)."""
+    B, T, n_fft = frames if grad is not None else frames.shape
+    _chk(window, 'window', 1)
+    _chk(inv_env, 'inv_env', 1)
+    if window.numel() != n_fft or inv_env.numel() != hop * (T - 1):
+        raise _lib.DcsHipError(f'istft_ola: window {window.numel()} / envelope {inv_env.numel()} do not match '
+                               f'n_fft={n_fft}, T={T}, hop={hop}')
+    lib = _lib.load()
+    if grad is None:
+        _chk(frames, 'frames', 3)
+        y = torch.empty((B, hop * (T - 1)), dtype=torch.float32, device=frames.device)
+        check(lib.dcs_istft_ola_fwd(ptr(frames), ptr(window), ptr(inv_env), ptr(y), B, T, n_fft, hop, float(scale),
+                                    cur_stream()), 'dcs_istft_ola_fwd')
+        return y
+    _chk(grad, 'grad', 2)
+    gf = torch.empty((B, T, n_fft), dtype=torch.float32, device=grad.device)
+    check(lib.dcs_istft_ola_bwd(ptr(grad), ptr(window), ptr(inv_env), ptr(gf), B, T, n_fft, hop, float(scale),
+                                cur_stream()), 'dcs_istft_ola_bwd')
+    return gf
 
 
 def crm(S, Y, eps=1e-8):

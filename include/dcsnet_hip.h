@@ -305,13 +305,25 @@ int dcs_bound_mask_apply_fwd(const float* Y, const float* M_in, float* M_out, fl
 int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const float* g_M, const float* g_N,
                              const float* g_S, float* g_Min, long n, float eps, dcs_stream_t stream);
 
-/* Polar round trip + zero-bin pad in front of every iSTFT of the step functions
- * (network_functions.py:140-145 via :213-221 and :244-247): out = |z| (cos phi + j sin phi), phi = atan2(z_i, z_r + eps),
- * for bins f < F, zeros for the padded bins F..Fp-1.  z: complex[B][F][T]; out / g_out: complex[B][Fp][T].
- * dcs_polar_pad_bwd: cotangent of z from the cotangent of out. */
-int dcs_polar_pad_fwd(const float* z, float* out, long B, int F, int Fp, int T, float eps, dcs_stream_t stream);
-int dcs_polar_pad_bwd(const float* z, const float* g_out, float* g_z, long B, int F, int Fp, int T, float eps,
-                      dcs_stream_t stream);
+/* Waveform synthesis around the inverse FFT of mag_phase_2_wave / torch.istft (network_functions.py:140-150 via
+ * :213-221 and :244-247).
+ * dcs_polar_frames_fwd: out = |z| (cos phi + j sin phi), phi = atan2(z_i, z_r + eps), for bins f < F and zeros for
+ *   the padded bins F..Fp-1, written FRAME-MAJOR: z complex[B][F][T] -> out complex[B][T][Fp], so the inverse real
+ *   FFT runs over contiguous frames.  _bwd: cotangent of z from the (frame-major) cotangent of out.
+ * dcs_istft_envelope: inv_env[n] = 1 / sum_f window^2 of torch.istft(center=True), n in [0, hop (T-1)).
+ * dcs_istft_ola_fwd: y[b][n] = scale * inv_env[n] * sum_f window[k] frames[b][f][k], k = n + n_fft/2 - f hop:
+ *   synthesis window, overlap-add, envelope division and the n_fft/2 trim in one pass.  frames float[B][T][n_fft]
+ *   (irfft output), y float[B][hop (T-1)]; scale = sqrt(n_fft) for normalized=True.  No NOLA check (it is a host
+ *   read-back in torch.istft): the caller guarantees a non-vanishing envelope.
+ * dcs_istft_ola_bwd: g_frames from g_y (the adjoint gather). */
+int dcs_polar_frames_fwd(const float* z, float* out, int B, int F, int Fp, int T, float eps, dcs_stream_t stream);
+int dcs_polar_frames_bwd(const float* z, const float* g_out, float* g_z, int B, int F, int Fp, int T, float eps,
+                         dcs_stream_t stream);
+int dcs_istft_envelope(const float* window, float* inv_env, int T, int n_fft, int hop, dcs_stream_t stream);
+int dcs_istft_ola_fwd(const float* frames, const float* window, const float* inv_env, float* y, int B, int T,
+                      int n_fft, int hop, float scale, dcs_stream_t stream);
+int dcs_istft_ola_bwd(const float* g_y, const float* window, const float* inv_env, float* g_frames, int B, int T,
+                      int n_fft, int hop, float scale, dcs_stream_t stream);
 
 /* cRM target mask (network_functions.py:62-75): M = S conj(Y) / (|Y|^2 + 1e-8). */
 int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs_stream_t stream);

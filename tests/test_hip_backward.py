@@ -281,12 +281,12 @@ def test_network_gradients_against_reference_vectors(dev, golden_dir):
                 close(pd[n].grad, torch.from_numpy(cnv[k]), rel=2e-3, abs_=1e-6, what=n)
 
 
-def test_polar_pad_forward_and_backward(dev):
+def test_polar_frames_forward_and_backward(dev):
     """The fused polar round trip in front of the iSTFT vs the reference's op chain (network_functions.py:140-145,
-    :213-221): |z| cos/sin(atan2(z_i, z_r + eps)), one zero bin appended."""
+    :213-221): |z| cos/sin(atan2(z_i, z_r + eps)), one zero bin appended; HIP output is frame-major [B,T,F+1]."""
     from dcsnet import functional as F
     eps = 10e-7
-    z0 = rand_c((2, 64, 24), 3, 0.8)
+    z0 = rand_c((2, 70, 45), 3, 0.8)                  # not multiples of the 32x32 transpose tile
     z0.view(-1)[:3] = torch.tensor([0 + 0j, -0.5 + 0j, 1e-4 - 2e-4j])
 
     def ref(z):
@@ -294,14 +294,38 @@ def test_polar_pad_forward_and_backward(dev):
         return torch.nn.functional.pad(torch.complex(mag * torch.cos(ph), mag * torch.sin(ph)), (0, 0, 0, 1))
 
     z = z0.clone().requires_grad_(True)
-    want = ref(z)
+    want = ref(z).transpose(1, 2)
     functional_loss(want, 7).backward()
     zd = z0.to(dev).requires_grad_(True)
-    got = F.polar_pad_complex(zd, 1, eps)
-    assert got.shape == (2, 65, 24)
+    got = F.polar_frames_complex(zd, 1, eps)
+    assert got.shape == (2, 45, 71) and got.is_contiguous()
     close(got, want, rel=0, abs_=2e-6, what='forward')
     functional_loss(got, 7).backward()
     ok = torch.ones(z0.shape, dtype=torch.bool)
     ok.view(-1)[:2] = False                       # origin / branch cut: atan2 is singular there
     close(zd.grad.cpu()[ok], z.grad[ok], rel=2e-4, what='g_z')
     assert torch.isfinite(torch.view_as_real(zd.grad)).all()
+
+
+def test_hip_istft_equals_torch_istft_and_its_gradient(dev):
+    """network_functions.istft (contiguous irfft + dcs_istft_ola_fwd; no host-synchronising NOLA check) reproduces
+    torch.istft, inverts the reference's STFT (n_fft 512, hop 32, hann, normalized: data.py:112-118), and its
+    backward (dcs_istft_ola_bwd) matches autograd through torch.istft."""
+    from dcsnet.network_functions import istft
+    torch.manual_seed(0)
+    w = torch.hann_window(512)
+    for T in (16, 256):
+        x = torch.randn(2, 32 * T - 32)
+        X = torch.stft(x, 512, 32, 512, w, return_complex=True, normalized=True)
+        assert X.shape[-1] == T
+        Xc = X.clone().requires_grad_(True)
+        want = torch.istft(Xc, 512, 32, 512, w, normalized=True)
+        gw = torch.randn(want.shape, generator=torch.Generator().manual_seed(T))
+        (want * gw).sum().backward()
+        Xd = X.to(dev).requires_grad_(True)
+        got = istft(Xd, 512, 32, w.to(dev), True)
+        assert got.shape == want.shape
+        assert float((got.cpu() - want).abs().max()) < 5e-6
+        assert float((got.cpu() - x).abs().max()) < 5e-6
+        (got * gw.to(dev)).sum().backward()
+        close(Xd.grad.cpu(), Xc.grad, rel=1e-4, what=f'g_X T={T}')

@@ -133,20 +133,3 @@ def test_dropin_names_resolve():
         for m in ('c_network', 'network_functions', 'config', 'complexPyTorch', 'complexPyTorch.complexLayers',
                   'complexPyTorch.complexFunctions'):
             sys.modules.pop(m, None)
-
-
-def test_capturable_istft_equals_torch_istft():
-    """network_functions.istft (no host-synchronising NOLA check) reproduces torch.istft and inverts the
-    reference's STFT (n_fft 512, hop 32, hann, normalized: data.py:112-118)."""
-    from dcsnet.network_functions import istft
-    torch.manual_seed(0)
-    w = torch.hann_window(512)
-    for T in (16, 256):
-        x = torch.randn(2, 32 * T - 32)
-        X = torch.stft(x, 512, 32, 512, w, return_complex=True, normalized=True)
-        assert X.shape[-1] == T
-        want = torch.istft(X, 512, 32, 512, w, normalized=True)
-        got = istft(X, 512, 32, w, True)
-        assert got.shape == want.shape
-        assert float((got - want).abs().max()) < 5e-6
-        assert float((got - x).abs().max()) < 5e-6
