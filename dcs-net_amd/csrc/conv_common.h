@@ -64,6 +64,13 @@ int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW);
 int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, float* slab_b, int n_slabs,
                                hipStream_t stream);
 
+// conv_wgrad_mfma.hip: weight gradient of a 3x3 conv over an upsampled input in its folded (per-class, source-
+// resolution) form; kernel + reduce into the parameter layout
+bool dcs_conv_wgrad_fold_ok(const conv::Args& a);
+long dcs_conv_wgrad_fold_workspace_bytes(const conv::Args& a);
+int dcs_conv_wgrad_fold_run(const conv::Args& a, const float* gy, void* workspace, long workspace_bytes, float* gw_r,
+                            float* gw_i, float* gb_r, float* gb_i, int transposed, hipStream_t stream);
+
 // conv_wgrad_small.hip (a: forward geometry with conv_direct.hip's 16x16 tiling filled in)
 bool dcs_conv_wgrad_small_ok(const conv::Args& a);
 int dcs_conv_wgrad_small_launch(const conv::Args& a, const float* gy, float2* slab_w, float2* slab_b, int n_slabs,

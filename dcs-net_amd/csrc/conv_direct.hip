@@ -548,7 +548,12 @@ extern "C" long dcs_cconv2d_bwd_weight_workspace_bytes(int B, int Hin, int Win, 
         const int nm = dcs_conv_wgrad_mfma_slabs(a, &th, &tw);
         if (nm > ns) ns = nm;
     }
-    return (long)ns * (wsz + Cout) * (long)sizeof(float2);
+    long bytes = (long)ns * (wsz + Cout) * (long)sizeof(float2);
+    if (dcs_conv_wgrad_fold_ok(a)) {
+        const long fb = dcs_conv_wgrad_fold_workspace_bytes(a);
+        if (fb > bytes) bytes = fb;
+    }
+    return bytes;
 }
 
 extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const float* gy, float* gw_r, float* gw_i,
@@ -562,6 +567,9 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     if (dcs_conv_wgrad_mfma_ok(C1 + C2, Cout, kh, kw, C1)) {          // MFMA GEMM over the pixel axis
         ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
         if (a.Hout <= 0 || a.Wout <= 0) return DCS_ERR_BADARG;
+        if (dcs_conv_wgrad_fold_ok(a))                                 // decoder stages: per parity class, source resolution
+            return dcs_conv_wgrad_fold_run(a, gy, workspace, workspace_bytes, gw_r, gw_i, gb_r, gb_i, transposed,
+                                           dcs_stream(stream));
         int th, tw;
         const int ns = dcs_conv_wgrad_mfma_slabs(a, &th, &tw);
         const long wsz = (long)kh * kw * (C1 + C2) * Cout;

@@ -26,6 +26,12 @@ struct WArgs {
     conv::Args c;
     const float* gy; float2* slab_w; float* slab_b;
     int n_slabs, total_tiles, co_blocks, TH, TW, twshift;
+    // output-parity classes of an upsample-folded conv (blockIdx.z): class pixel (oy, ox) is g_Y pixel
+    // (oy*os_f + oo_f, ox*os_t + oo_t) and reads the SOURCE-resolution input with its own padding; one class = the
+    // plain convolution (os = 1, oo = 0, pad = c.pad).  c.Hout / c.Wout: class-space extent (tiling);
+    // Hy / Wy: full g_Y extent (addressing).
+    int ncls, os_f, os_t, Hy, Wy;
+    int pad_f[4], pad_t[4], oo_f[4], oo_t[4];
 };
 
 // MT row tiles (8 output channels each) per wave; WS waves split the tile's PIXELS (k-steps) and
@@ -33,9 +39,10 @@ struct WArgs {
 // SIMDs: the pixel partials are combined through LDS once, after the last tile.
 // Two workgroups per CU (<= 256 VGPR + AGPR per lane) whenever the accumulator set allows it: one gathers while
 // the other runs its MFMAs.
-template <int KS, int MT, int WS>
-__global__ __launch_bounds__(256, (MT * KS * KS * 4 <= 160 && !(KS == 5 && WS == 4) ? 2 : 1)) void cconv_wgrad_mfma_kernel(WArgs w) {
-    constexpr int TAPS = KS * KS;
+template <int KH, int KW, int MT, int WS>
+__global__ __launch_bounds__(256, (MT * KH * KW * 4 <= 160 && !(KH == 5 && WS == 4) ? 2 : 1)) void cconv_wgrad_mfma_kernel(WArgs w) {
+    constexpr int TAPS = KH * KW;
+    const int cls = blockIdx.z;
     constexpr int WCO = 4 / WS;
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     const conv::Args& a = w.c;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256, (MT * KS * KS * 4 <= 160 && !(KS == 5 && WS ==
     for (int tl = blockIdx.x; tl < w.total_tiles; tl += w.n_slabs) {
         const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
         const int oy0 = (tile_id / a.tiles_w) * w.TH, ox0 = (tile_id % a.tiles_w) * w.TW;
-        const int vy0 = oy0 * a.sf - a.pad_f, vx0 = ox0 * a.st - a.pad_t;
+        const int vy0 = oy0 * a.sf - w.pad_f[cls], vx0 = ox0 * a.st - w.pad_t[cls];
         __syncthreads();
         for (int idx = t; idx < npix * 4; idx += 256) {
             const int q = idx & 3, px = idx >> 2;
@@ -92,7 +99,8 @@ __global__ __launch_bounds__(256, (MT * KS * KS * 4 <= 160 && !(KS == 5 && WS ==
             const int p = ks * 4 + lk;
             const int oy = oy0 + (p >> w.twshift), ox = ox0 + (p & (w.TW - 1));
             const bool inb = oy < a.Hout && ox < a.Wout;
-            const float* gp = w.gy + (((long)b * a.Hout + (inb ? oy : 0)) * a.Wout + (inb ? ox : 0)) * N1;
+            const float* gp = w.gy + (((long)b * w.Hy + (inb ? oy * w.os_f + w.oo_f[cls] : 0)) * w.Wy +
+                                      (inb ? ox * w.os_t + w.oo_t[cls] : 0)) * N1;
 #pragma unroll
             for (int i = 0; i < MT; ++i) dst[i] = (inb && colok[i]) ? gp[gcol[i]] : 0.f;
         };
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256, (MT * KS * KS * 4 <= 160 && !(KS == 5 && WS ==
                 const float* xp = patch + ((py * a.sf) * a.cols + pxx * a.st) * PIX + li;
 #pragma unroll
                 for (int tp = 0; tp < TAPS; ++tp) {
-                    const float bf = xp[((tp / KS) * a.cols + (tp % KS)) * PIX];
+                    const float bf = xp[((tp / KW) * a.cols + (tp % KW)) * PIX];
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
                         acc[i][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][tp], 0, 0, 0);
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256, (MT * KS * KS * 4 <= 160 && !(KS == 5 && WS ==
     // C/D map: column j = lane&15 -> (ci = j>>1, re|im = j&1); row = (lane>>4)*4 + r -> (co = row>>1, re|im = r&1)
     const int Cin = a.C1 + a.C2;
     const long wsz = (long)TAPS * Cin * a.Cout;
-    float2* slab = w.slab_w + (long)blockIdx.x * wsz;
+    float2* slab = w.slab_w + ((long)blockIdx.x * w.ncls + cls) * wsz;
     const int ci = ci0 + (li >> 1);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -181,38 +189,50 @@ __global__ __launch_bounds__(256, (MT * KS * KS * 4 <= 160 && !(KS == 5 && WS ==
             float s = bsum[i];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            if (lk == 0 && colok[i]) w.slab_b[(long)blockIdx.x * N1 + gcol[i]] = s;
+            if (lk == 0 && colok[i]) w.slab_b[((long)blockIdx.x * w.ncls + cls) * N1 + gcol[i]] = s;
         }
     }
 }
 
-template <int KS_, int MT_, int WS_> struct Variant { static constexpr int KS = KS_, MT = MT_, WS = WS_; };
+template <int KH_, int KW_, int MT_, int WS_> struct Variant { static constexpr int KH = KH_, KW = KW_, MT = MT_, WS = WS_; };
 
 // (MT, WS) so that the 4 waves cover min(Cout, most-per-kernel-size) output channels without idle lanes
 template <class F>
-int dispatch(int k, int co, F&& f) {
-    switch (k) {
-        case 1:
-            if (co >= 128) return f(Variant<1, 4, 1>{});
-            if (co >= 64) return f(Variant<1, 2, 1>{});
-            if (co >= 32) return f(Variant<1, 1, 1>{});
-            if (co >= 16) return f(Variant<1, 1, 2>{});
-            return f(Variant<1, 1, 4>{});
-        case 3:
-            if (co >= 128) return f(Variant<3, 4, 1>{});
-            if (co >= 64) return f(Variant<3, 2, 1>{});
-            if (co >= 32) return f(Variant<3, 1, 1>{});
-            if (co >= 16) return f(Variant<3, 1, 2>{});
-            return f(Variant<3, 1, 4>{});
-        case 5:
-            if (co >= 64) return f(Variant<5, 2, 1>{});
-            if (co >= 32) return f(Variant<5, 1, 1>{});
-            if (co >= 16) return f(Variant<5, 1, 2>{});
-            return f(Variant<5, 1, 4>{});
-        case 7:
-            if (co >= 32) return f(Variant<7, 1, 1>{});
-            if (co >= 16) return f(Variant<7, 1, 2>{});
-            return f(Variant<7, 1, 4>{});
+int dispatch(int kh, int kw, int co, F&& f) {
+    switch (kh * 10 + kw) {
+        case 11:
+            if (co >= 128) return f(Variant<1, 1, 4, 1>{});
+            if (co >= 64) return f(Variant<1, 1, 2, 1>{});
+            if (co >= 32) return f(Variant<1, 1, 1, 1>{});
+            if (co >= 16) return f(Variant<1, 1, 1, 2>{});
+            return f(Variant<1, 1, 1, 4>{});
+        case 22:                                   // 3x3 folded over a (2,2) upsample
+            if (co >= 128) return f(Variant<2, 2, 4, 1>{});
+            if (co >= 64) return f(Variant<2, 2, 2, 1>{});
+            if (co >= 32) return f(Variant<2, 2, 1, 1>{});
+            if (co >= 16) return f(Variant<2, 2, 1, 2>{});
+            return f(Variant<2, 2, 1, 4>{});
+        case 23:                                   // 3x3 folded over a (2,1) upsample
+            if (co >= 128) return f(Variant<2, 3, 4, 1>{});
+            if (co >= 64) return f(Variant<2, 3, 2, 1>{});
+            if (co >= 32) return f(Variant<2, 3, 1, 1>{});
+            if (co >= 16) return f(Variant<2, 3, 1, 2>{});
+            return f(Variant<2, 3, 1, 4>{});
+        case 33:
+            if (co >= 128) return f(Variant<3, 3, 4, 1>{});
+            if (co >= 64) return f(Variant<3, 3, 2, 1>{});
+            if (co >= 32) return f(Variant<3, 3, 1, 1>{});
+            if (co >= 16) return f(Variant<3, 3, 1, 2>{});
+            return f(Variant<3, 3, 1, 4>{});
+        case 55:
+            if (co >= 64) return f(Variant<5, 5, 2, 1>{});
+            if (co >= 32) return f(Variant<5, 5, 1, 1>{});
+            if (co >= 16) return f(Variant<5, 5, 1, 2>{});
+            return f(Variant<5, 5, 1, 4>{});
+        case 77:
+            if (co >= 32) return f(Variant<7, 7, 1, 1>{});
+            if (co >= 16) return f(Variant<7, 7, 1, 2>{});
+            return f(Variant<7, 7, 1, 4>{});
         default: return DCS_ERR_BADARG;
     }
 }
@@ -220,7 +240,7 @@ int dispatch(int k, int co, F&& f) {
 template <class V>
 size_t lds_bytes(int rows, int cols) {
     size_t lds = (size_t)rows * cols * PIX * sizeof(float);
-    const size_t red = (size_t)(V::WS - 1) * (4 / V::WS) * (V::MT * V::KS * V::KS * 4 + V::MT) * 64 * sizeof(float);
+    const size_t red = (size_t)(V::WS - 1) * (4 / V::WS) * (V::MT * V::KH * V::KW * 4 + V::MT) * 64 * sizeof(float);
     return red > lds ? red : lds;
 }
 
@@ -230,7 +250,7 @@ int resident_per_cu(size_t lds) {
     static int cached = 0;
     if (cached == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cconv_wgrad_mfma_kernel<V::KS, V::MT, V::WS>, 256, lds) !=
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cconv_wgrad_mfma_kernel<V::KH, V::KW, V::MT, V::WS>, 256, lds) !=
                 hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 1;
@@ -245,15 +265,144 @@ int launch(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
     const size_t lds = lds_bytes<V>(a.rows, a.cols);
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
-    auto fn = cconv_wgrad_mfma_kernel<V::KS, V::MT, V::WS>;
+    auto fn = cconv_wgrad_mfma_kernel<V::KH, V::KW, V::MT, V::WS>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     const int co_per_block = (4 / V::WS) * V::MT * 8;
     w.co_blocks = (a.Cout + co_per_block - 1) / co_per_block;
-    dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks);
+    dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks, w.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, w);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+// ---- upsample-folded weight gradient ---------------------------------------------------------------
+// A 3x3 stride-1 conv over a nearest-upsampled input (every decoder stage, c_network.py:214-216) is, per output
+// parity class, a 2-tap (upsampled axis) x 3-tap conv over the SOURCE-resolution input with tap-summed weights
+// (conv_pack.hip).  Its weight gradient is taken in the same form — per class, over the un-upsampled input, 6/9
+// or 4/9 of the MACs — and mapped back: g_W[dy][dx] = sum over classes of g_Wfold_c[jy_c(dy)][jx_c(dx)].
+struct Fold {
+    int ncls, kh, kw, os_f, os_t;
+    int pad_f[4], pad_t[4], oo_f[4], oo_t[4];
+};
+
+Fold fold_of(const conv::Args& a) {
+    Fold f{};
+    f.kh = a.up_f == 2 ? 2 : 3; f.kw = a.up_t == 2 ? 2 : 3;
+    f.os_f = a.up_f; f.os_t = a.up_t; f.ncls = a.up_f * a.up_t;
+    for (int ry = 0; ry < a.up_f; ++ry)
+        for (int rx = 0; rx < a.up_t; ++rx) {
+            const int c = ry * a.up_t + rx;
+            f.pad_f[c] = a.up_f == 2 ? (ry == 0 ? 1 : 0) : 1;
+            f.pad_t[c] = a.up_t == 2 ? (rx == 0 ? 1 : 0) : 1;
+            f.oo_f[c] = ry; f.oo_t[c] = rx;
+        }
+    return f;
+}
+
+// class-space problem: source-resolution input, class extent = source extent, folded kernel size
+conv::Args class_args(const conv::Args& a, const Fold& f) {
+    conv::Args c = a;
+    c.up_f = 1; c.up_t = 1; c.zero_ins = 0; c.Hv = a.Hin; c.Wv = a.Win;
+    c.kh = f.kh; c.kw = f.kw; c.sf = 1; c.st = 1;
+    c.Hout = a.Hin; c.Wout = a.Win;
+    return c;
+}
+
+// destination tap index on one axis: which folded tap of residue class r contains original tap d
+__device__ __forceinline__ int fold_index(int up, int r, int d) {
+    if (up == 1) return d;
+    return r == 0 ? (d == 0 ? 0 : 1) : (d == 2 ? 1 : 0);
+}
+
+// slab_w: float2[n_slabs][ncls][kh_c*kw_c][Cin][Cout]; slab_b: float2[n_slabs][ncls][Cout].  One thread per element of
+// the 3x3 gradient (then per bias element), summing slabs in a fixed order: bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_unfold_reduce_kernel(const float2* __restrict__ slab_w,
+                                                                   const float2* __restrict__ slab_b, int n_slabs,
+                                                                   int up_f, int up_t, float* __restrict__ gw_r,
+                                                                   float* __restrict__ gw_i, float* __restrict__ gb_r,
+                                                                   float* __restrict__ gb_i, int Cout, int Cin,
+                                                                   int transposed) {
+    const int kh_c = up_f == 2 ? 2 : 3, kw_c = up_t == 2 ? 2 : 3, ncls = up_f * up_t;
+    const long per = (long)Cin * Cout, n = 9 * per, wsz_c = (long)kh_c * kw_c * per;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j < n) {
+        const int tap = (int)(j / per);
+        const long e = j % per;
+        const int dy = tap / 3, dx = tap % 3;
+        float sr = 0.f, si = 0.f;
+        for (int ry = 0; ry < up_f; ++ry)
+            for (int rx = 0; rx < up_t; ++rx) {
+                const int c = ry * up_t + rx;
+                const long off = (long)c * wsz_c + (long)(fold_index(up_f, ry, dy) * kw_c + fold_index(up_t, rx, dx)) * per + e;
+                for (int s = 0; s < n_slabs; ++s) {
+                    const float2 v = slab_w[(long)s * ncls * wsz_c + off];
+                    sr += v.x; si += v.y;
+                }
+            }
+        const int co = (int)(e % Cout), ci = (int)(e / Cout);
+        long dst;
+        if (transposed) dst = (((long)ci * Cout + co) * 3 + (2 - dy)) * 3 + (2 - dx);
+        else            dst = (((long)co * Cin + ci) * 3 + dy) * 3 + dx;
+        gw_r[dst] = sr;
+        gw_i[dst] = si;
+    } else if (gb_r != nullptr && j < n + Cout) {
+        const int co = (int)(j - n);
+        float sr = 0.f, si = 0.f;
+        for (int s = 0; s < n_slabs * ncls; ++s) { const float2 v = slab_b[(long)s * Cout + co]; sr += v.x; si += v.y; }
+        gb_r[co] = sr + si;          // bias = (b_r - b_i) + j (b_r + b_i)
+        gb_i[co] = si - sr;
+    }
+}
+
+// slabs per class for a class-space geometry `c` (tiling filled in), ncls classes
+int slabs_for(const conv::Args& c, int ncls, int TH, int TW) {
+    const long tiles = (long)((c.Wout + TW - 1) / TW) * ((c.Hout + TH - 1) / TH) * c.B;
+    const long wsz = (long)c.kh * c.kw * (c.C1 + c.C2) * c.Cout;
+    long cap = (96L << 20) / (wsz * ncls * (long)sizeof(float2));
+    if (cap < 1) cap = 1;
+    if (cap > 1024) cap = 1024;
+    // A workgroup's epilogue writes its whole accumulator set (up to 147 KB), so give each one several pixel
+    // tiles rather than one — but keep every CU holding as many workgroups as the variant's registers allow
+    // (they overlap each other's gathers): target = 256 CUs x resident workgroups per CU.
+    const int rows = (TH - 1) * c.sf + c.kh, cols = (TW - 1) * c.st + c.kw;
+    int per_cu = 1, cpb = 8;
+    dispatch(c.kh, c.kw, c.Cout, [&](auto v) {
+        using V = decltype(v);
+        per_cu = resident_per_cu<V>(lds_bytes<V>(rows, cols));
+        cpb = (4 / V::WS) * V::MT * 8;
+        return 0;
+    });
+    const long grid_y = (long)((c.C1 + c.C2) / CHUNK) * ((c.Cout + cpb - 1) / cpb) * ncls;
+    long want = (256L * per_cu + grid_y - 1) / grid_y;
+    if (want < 1) want = 1;
+    if (want < cap) cap = want;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+void tile_shape(int Hc, int* TH, int* TW) {
+    if (Hc >= 8) { *TH = 8; *TW = 16; }
+    else if (Hc >= 4) { *TH = 4; *TW = 32; }
+    else { *TH = 2; *TW = 64; }
+}
+
+// c: class-space geometry; f: classes; Hy x Wy: full g_Y extent
+int launch_classes(const conv::Args& c, const Fold& f, int Hy, int Wy, const float* gy, float2* slab_w, float* slab_b,
+                   int n_slabs, int TH, int TW, hipStream_t stream) {
+    WArgs w;
+    w.c = c;
+    w.gy = gy; w.slab_w = slab_w; w.slab_b = slab_b; w.n_slabs = n_slabs;
+    w.TH = TH; w.TW = TW;
+    w.twshift = TW == 16 ? 4 : (TW == 32 ? 5 : 6);
+    w.c.tiles_w = (c.Wout + TW - 1) / TW;
+    w.c.tiles_h = (c.Hout + TH - 1) / TH;
+    w.c.rows = (TH - 1) * c.sf + c.kh;
+    w.c.cols = (TW - 1) * c.st + c.kw;
+    w.total_tiles = w.c.tiles_w * w.c.tiles_h * c.B;
+    w.ncls = f.ncls; w.os_f = f.os_f; w.os_t = f.os_t; w.Hy = Hy; w.Wy = Wy;
+    for (int i = 0; i < 4; ++i) { w.pad_f[i] = f.pad_f[i]; w.pad_t[i] = f.pad_t[i]; w.oo_f[i] = f.oo_f[i]; w.oo_t[i] = f.oo_t[i]; }
+    const int Cin = c.C1 + c.C2;
+    return dispatch(c.kh, c.kw, c.Cout, [&](auto v) { return launch<decltype(v)>(w, Cin, stream); });
 }
 
 }  // namespace
@@ -264,48 +413,65 @@ bool dcs_conv_wgrad_mfma_ok(int Cin, int Cout, int kh, int kw, int C1) {
 
 // number of partial slabs and the tile shape for a forward geometry (a.Hout / a.Wout set)
 int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW) {
-    if (a.Hout >= 8) { *TH = 8; *TW = 16; }
-    else if (a.Hout >= 4) { *TH = 4; *TW = 32; }
-    else { *TH = 2; *TW = 64; }
-    const long tiles = (long)((a.Wout + *TW - 1) / *TW) * ((a.Hout + *TH - 1) / *TH) * a.B;
-    const long wsz = (long)a.kh * a.kw * (a.C1 + a.C2) * a.Cout;
-    long cap = (96L << 20) / (wsz * (long)sizeof(float2));
-    if (cap < 1) cap = 1;
-    if (cap > 1024) cap = 1024;
-    // A workgroup's epilogue writes its whole accumulator set (up to 147 KB), so give each one several pixel
-    // tiles rather than one — but keep every CU holding as many workgroups as the variant's registers allow
-    // (they overlap each other's gathers): target = 256 CUs x resident workgroups per CU.
-    const int rows = (*TH - 1) * a.sf + a.kh, cols = (*TW - 1) * a.st + a.kw;
-    int per_cu = 1, cpb = 8;
-    dispatch(a.kh, a.Cout, [&](auto v) {
-        using V = decltype(v);
-        per_cu = resident_per_cu<V>(lds_bytes<V>(rows, cols));
-        cpb = (4 / V::WS) * V::MT * 8;
-        return 0;
-    });
-    static const long scale = [] { const char* e = getenv("DCS_WGRAD_WGS_PER_SLOT"); return e ? atol(e) : 1L; }();
-    const long grid_y = (long)((a.C1 + a.C2) / CHUNK) * ((a.Cout + cpb - 1) / cpb);
-    long want = (256L * per_cu * scale + grid_y - 1) / grid_y;
-    if (want < 1) want = 1;
-    if (want < cap) cap = want;
-    return (int)(tiles < cap ? tiles : cap);
+    tile_shape(a.Hout, TH, TW);
+    return slabs_for(a, 1, *TH, *TW);
 }
 
 // slab_w: float2[n_slabs][taps][Cin][Cout]; slab_b: float[n_slabs][2*Cout]
 int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, float* slab_b, int n_slabs,
                                hipStream_t stream) {
-    WArgs w;
-    w.c = a;
-    w.gy = gy; w.slab_w = slab_w; w.slab_b = slab_b; w.n_slabs = n_slabs;
     int TH, TW;
-    dcs_conv_wgrad_mfma_slabs(a, &TH, &TW);
-    w.TH = TH; w.TW = TW;
-    w.twshift = TW == 16 ? 4 : (TW == 32 ? 5 : 6);
-    w.c.tiles_w = (a.Wout + TW - 1) / TW;
-    w.c.tiles_h = (a.Hout + TH - 1) / TH;
-    w.c.rows = (TH - 1) * a.sf + a.kh;
-    w.c.cols = (TW - 1) * a.st + a.kw;
-    w.total_tiles = w.c.tiles_w * w.c.tiles_h * a.B;
+    tile_shape(a.Hout, &TH, &TW);
+    Fold f{};
+    f.ncls = 1; f.kh = a.kh; f.kw = a.kw; f.os_f = 1; f.os_t = 1;
+    f.pad_f[0] = a.pad_f; f.pad_t[0] = a.pad_t;
+    return launch_classes(a, f, a.Hout, a.Wout, gy, slab_w, slab_b, n_slabs, TH, TW, stream);
+}
+
+// upsample-folded path: forward geometry `a` (a.Hout / a.Wout set) of a 3x3 stride-1 pad-1 conv over an upsampled input
+bool dcs_conv_wgrad_fold_ok(const conv::Args& a) {
     const int Cin = a.C1 + a.C2;
-    return dispatch(a.kh, a.Cout, [&](auto v) { return launch<decltype(v)>(w, Cin, stream); });
+    if (!(dcs_conv_wgrad_mfma_ok(Cin, a.Cout, a.kh, a.kw, a.C1) &&
+          conv::fold_ok(Cin, a.Cout, a.kh, a.kw, a.sf, a.st, a.pad_f, a.pad_t, a.up_f, a.up_t)))
+        return false;
+    // 128-pixel tiles x taps actually issued: a class of a very small source map (dec0: 2 x 32) can fill its tiles
+    // worse than the plain form does
+    const Fold f = fold_of(a);
+    int th, tw;
+    tile_shape(a.Hin, &th, &tw);
+    const long folded = (long)((a.Win + tw - 1) / tw) * ((a.Hin + th - 1) / th) * f.ncls * f.kh * f.kw;
+    tile_shape(a.Hout, &th, &tw);
+    const long plain = (long)((a.Wout + tw - 1) / tw) * ((a.Hout + th - 1) / th) * a.kh * a.kw;
+    return folded < plain;
+}
+
+long dcs_conv_wgrad_fold_workspace_bytes(const conv::Args& a) {
+    const Fold f = fold_of(a);
+    const conv::Args c = class_args(a, f);
+    int TH, TW;
+    tile_shape(c.Hout, &TH, &TW);
+    const long ns = slabs_for(c, f.ncls, TH, TW);
+    return ns * f.ncls * ((long)f.kh * f.kw * (a.C1 + a.C2) * a.Cout + a.Cout) * (long)sizeof(float2);
+}
+
+int dcs_conv_wgrad_fold_run(const conv::Args& a, const float* gy, void* workspace, long workspace_bytes, float* gw_r,
+                            float* gw_i, float* gb_r, float* gb_i, int transposed, hipStream_t stream) {
+    if (!dcs_conv_wgrad_fold_ok(a)) return DCS_ERR_BADARG;
+    const Fold f = fold_of(a);
+    const conv::Args c = class_args(a, f);
+    int TH, TW;
+    tile_shape(c.Hout, &TH, &TW);
+    const int ns = slabs_for(c, f.ncls, TH, TW);
+    const int Cin = a.C1 + a.C2;
+    const long wsz_c = (long)f.kh * f.kw * Cin * a.Cout;
+    if (workspace_bytes < (long)ns * f.ncls * (wsz_c + a.Cout) * (long)sizeof(float2)) return DCS_ERR_WORKSPACE;
+    float2* slab_w = (float2*)workspace;
+    float2* slab_b = slab_w + (long)ns * f.ncls * wsz_c;
+    const int rc = launch_classes(c, f, a.Hout, a.Wout, gy, slab_w, (float*)slab_b, ns, TH, TW, stream);
+    if (rc != DCS_OK) return rc;
+    const long n = 9L * Cin * a.Cout + (gb_r ? a.Cout : 0);
+    hipLaunchKernelGGL(wgrad_unfold_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slab_w, slab_b, ns,
+                       a.up_f, a.up_t, gw_r, gw_i, gb_r, gb_i, a.Cout, Cin, transposed);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
 }
