@@ -101,17 +101,30 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 
     for (int ch = 0; ch < n_chunks; ++ch) {
         __syncthreads();                                               // previous chunk fully consumed
-        for (int idx = t; idx < nslots; idx += 256) {
-            const int q = idx % Q, px = idx / Q;
-            const int ix = px % cols, iy = px / cols;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            long sp;
-            if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
-                const int c = ch * CH + 2 * q;
-                const float2* src = (c < a.C1) ? a.x1 + sp * a.C1 + c : a.x2 + sp * a.C2 + (c - a.C1);
-                v = *reinterpret_cast<const float4*>(src);
+        // gather in rounds of GU independent loads per thread (all in flight together), then the LDS stores
+        constexpr int GU = 4;
+        for (int base = t; base < nslots; base += 256 * GU) {
+            float4 v[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int idx = base + u * 256;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < nslots) {
+                    const int q = idx % Q, px = idx / Q;
+                    const int ix = px % cols, iy = px / cols;
+                    long sp;
+                    if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
+                        const int c = ch * CH + 2 * q;
+                        const float2* src = (c < a.C1) ? a.x1 + sp * a.C1 + c : a.x2 + sp * a.C2 + (c - a.C1);
+                        v[u] = *reinterpret_cast<const float4*>(src);
+                    }
+                }
             }
-            *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v;
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int idx = base + u * 256;
+                if (idx < nslots) *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
+            }
         }
         __syncthreads();
         float4 af[2][WM];
