@@ -44,6 +44,9 @@ __global__ __launch_bounds__(256, (MT * KH * KW * 4 <= 160 && !(KH == 5 && WS ==
     constexpr int TAPS = KH * KW;
     const int cls = blockIdx.z;
     constexpr int WCO = 4 / WS;
+    constexpr bool GL = MT == 1 && WS >= 2;             // g_Y tile through LDS (<= 16 output channels per workgroup)
+    constexpr int GQ = WCO * 4;                         // float4 per pixel of the g_Y block (WCO*8 channels x 2 floats)
+    constexpr int GP = WCO * 16 + (WCO == 1 ? 0 : 16);  // float pitch per pixel: pixel stride == 16 banks (mod 32)
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     const conv::Args& a = w.c;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -90,12 +93,32 @@ __global__ __launch_bounds__(256, (MT * KH * KW * 4 <= 160 && !(KH == 5 && WS ==
             }
             *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v;
         }
+        if (GL) {
+            // few output channels (<= 16 per workgroup): a k-step is only TAPS*32 cycles of MFMA, far less than the L2 round trip
+            // of its g_Y fragment — stage the tile's g_Y block [128 pixels][co_per_block*2] in LDS with coalesced
+            // 16-byte loads instead (zeros outside the map / beyond Cout), and feed the A fragments from there
+            float* gt = patch + npix * PIX;
+            const int cb0 = (blockIdx.y % w.co_blocks) * (WCO * 8);           // first output channel of the block
+            for (int idx = t; idx < BMP * GQ; idx += 256) {
+                const int q = idx % GQ, p = idx / GQ;
+                const int oy = oy0 + (p >> w.twshift), ox = ox0 + (p & (w.TW - 1));
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (oy < a.Hout && ox < a.Wout && 2 * cb0 + 4 * q < N1)
+                    v = *reinterpret_cast<const float4*>(w.gy + (((long)b * w.Hy + oy * w.os_f + w.oo_f[cls]) * w.Wy +
+                                                                 ox * w.os_t + w.oo_t[cls]) * N1 + 2 * cb0 + 4 * q);
+                *reinterpret_cast<float4*>(gt + p * GP + q * 4) = v;
+            }
+        }
         __syncthreads();
         // gY fragments come from L2 with ~1-2 us latency and a k-step is only MT*TAPS*32 cycles of MFMA: keep the
         // next RING k-steps' loads in flight (static register ring; the k-step loop is unrolled over it)
         constexpr int RING = MT >= 4 ? 2 : 4;                          // BMP/4/WS is 32, 16 or 8
         float afr[RING][MT];
         auto load_g = [&](int ks, float* dst) {
+            if (GL) {
+                dst[0] = patch[npix * PIX + (ks * 4 + lk) * GP + (wave / WS) * 16 + li];
+                return;
+            }
             const int p = ks * 4 + lk;
             const int oy = oy0 + (p >> w.twshift), ox = ox0 + (p & (w.TW - 1));
             const bool inb = oy < a.Hout && ox < a.Wout;
@@ -240,6 +263,7 @@ int dispatch(int kh, int kw, int co, F&& f) {
 template <class V>
 size_t lds_bytes(int rows, int cols) {
     size_t lds = (size_t)rows * cols * PIX * sizeof(float);
+    if (V::MT == 1 && V::WS >= 2) lds += (size_t)BMP * ((4 / V::WS) * 16 + (V::WS == 4 ? 0 : 16)) * sizeof(float);   // g_Y tile
     const size_t red = (size_t)(V::WS - 1) * (4 / V::WS) * (V::MT * V::KH * V::KW * 4 + V::MT) * 64 * sizeof(float);
     return red > lds ? red : lds;
 }
