@@ -516,6 +516,25 @@ def istft_ola(frames, window, inv_env, hop, scale=1.0):
     return _IstftOlaFn.apply(frames, window, inv_env, hop, scale)
 
 
+class _SiSNRFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clean, est, eps):
+        snr, coef = ops.sisnr(clean, est, eps)
+        ctx.save_for_backward(clean, est, coef)
+        return snr.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        clean, est, coef = ctx.saved_tensors
+        return None, ops.sisnr_bwd(clean, est, coef, g.contiguous(), 1.0 / est.shape[0]), None
+
+
+def sisnr_mean(clean, est, eps=1e-8):
+    """torch.mean over utterances of the SiSNR (network_functions.py:30-42); gradient to `est` only (the clean signal
+    is data).  float [B, L] inputs."""
+    return _SiSNRFn.apply(clean.detach().contiguous(), est.contiguous(), eps)
+
+
 def bound_crm_complex(M, eps=10e-7):
     return torch.view_as_complex(bound_crm(torch.view_as_real(M.contiguous()), eps))
 

@@ -37,9 +37,14 @@ def check_inf_neginf_nan(tensor, error_msg):
 
 
 class SiSNR(object):
-    """network_functions.py:30-42."""
+    """network_functions.py:30-42.  [B, L] float32 device signals take the fused HIP kernels (two launches forward
+    including the batch mean, one backward; gradient to the estimate — the clean signal is data in every call site of
+    the reference, :186-199); any other input runs the reference's formula as written."""
 
     def __call__(self, clean, estimate, eps=1e-8):
+        if (estimate.is_cuda and estimate.dim() == 2 and estimate.dtype == torch.float32 and clean.shape == estimate.shape
+                and not clean.requires_grad):
+            return F.sisnr_mean(clean, estimate, eps)
         dot = torch.sum(estimate * clean, -1, keepdim=True)
         energy = torch.sum(clean * clean, -1, keepdim=True)
         target = dot * clean / (energy + eps)

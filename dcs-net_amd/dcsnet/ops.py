@@ -515,6 +515,29 @@ def istft_ola(frames, window, inv_env, hop, scale=1.0, grad=None):
     return gf
 
 
+def sisnr(clean, est, eps=1e-8):
+    """Per-utterance SiSNR [B] of float [B,L] signals and the [B,2] coefficients its backward reads."""
+    _chk(clean, 'clean', 2)
+    _chk(est, 'est', 2)
+    if clean.shape != est.shape:
+        raise _lib.DcsHipError(f'sisnr: clean {tuple(clean.shape)} vs estimate {tuple(est.shape)}')
+    B, L = est.shape
+    snr = torch.empty(B, dtype=torch.float32, device=est.device)
+    coef = torch.empty((B, 2), dtype=torch.float32, device=est.device)
+    check(_lib.load().dcs_sisnr_fwd(ptr(clean), ptr(est), ptr(snr), ptr(coef), B, L, float(eps), cur_stream()), 'dcs_sisnr_fwd')
+    return snr, coef
+
+
+def sisnr_bwd(clean, est, coef, g, scale):
+    """g: 0-dim / 1-element float tensor on the device (upstream gradient of the batch mean)."""
+    B, L = est.shape
+    _chk(g, 'g')
+    g_est = torch.empty_like(est)
+    check(_lib.load().dcs_sisnr_bwd(ptr(clean), ptr(est), ptr(coef), ptr(g), float(scale), ptr(g_est), B, L, cur_stream()),
+          'dcs_sisnr_bwd')
+    return g_est
+
+
 def crm(S, Y, eps=1e-8):
     _chk(S, 'S')
     _chk(Y, 'Y')

@@ -325,6 +325,15 @@ int dcs_istft_ola_fwd(const float* frames, const float* window, const float* inv
 int dcs_istft_ola_bwd(const float* g_y, const float* window, const float* inv_env, float* g_frames, int B, int T,
                       int n_fft, int hop, float scale, dcs_stream_t stream);
 
+/* SiSNR (network_functions.py:30-42) of B utterances of L samples: snr[b] = 10 log10(|a c|^2 / (|e - a c|^2 + eps) + eps),
+ * a = <e,c> / (|c|^2 + eps), c = clean, e = estimate (float[B][L] each).  coef: float[B][2] scratch the backward reads.
+ * dcs_sisnr_bwd: g_est[b][n] = (*g) * scale * d snr[b] / d est[b][n]; g = DEVICE scalar (the upstream gradient of the
+ * batch mean), scale = 1/B for the reference's torch.mean.  The clean signal is data and receives no gradient. */
+int dcs_sisnr_fwd(const float* clean, const float* est, float* snr, float* coef, int B, int L, float eps,
+                  dcs_stream_t stream);
+int dcs_sisnr_bwd(const float* clean, const float* est, const float* coef, const float* g, float scale, float* g_est,
+                  int B, int L, dcs_stream_t stream);
+
 /* cRM target mask (network_functions.py:62-75): M = S conj(Y) / (|Y|^2 + 1e-8). */
 int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs_stream_t stream);
 

@@ -329,3 +329,19 @@ def test_hip_istft_equals_torch_istft_and_its_gradient(dev):
         assert float((got.cpu() - x).abs().max()) < 5e-6
         (got * gw.to(dev)).sum().backward()
         close(Xd.grad.cpu(), Xc.grad, rel=1e-4, what=f'g_X T={T}')
+
+
+def test_fused_sisnr_value_and_gradient(dev):
+    """dcs_sisnr_fwd/_bwd vs the reference's SiSNR formula (network_functions.py:30-42) and autograd through it."""
+    from dcsnet import functional as F
+    g = torch.Generator().manual_seed(5)
+    for B, L in ((3, 1000), (32, 8160)):
+        clean = torch.randn(B, L, generator=g) * 0.3
+        est = (clean + 0.2 * torch.randn(B, L, generator=g)).requires_grad_(True)
+        want = nf.si_snr(clean, est)
+        (-0.7 * want).backward()
+        ed = est.detach().to(dev).requires_grad_(True)
+        got = F.sisnr_mean(clean.to(dev), ed, 1e-8)
+        assert abs(float(got) - float(want)) <= 2e-5 * abs(float(want)) + 1e-5
+        (-0.7 * got).backward()
+        close(ed.grad, est.grad, rel=2e-4, what=f'g_est B={B}')
