@@ -204,39 +204,47 @@ __global__ __launch_bounds__(kThreads) void ca_bwd_sample_kernel(const double* _
 
 // Weight half (one thread per weight element, sums over the batch):
 //   g_w2[h][c] = sum_b g_o conj(relu(h)) ;  g_w1[c][h] = sum_b g_h conj(pooled)
-__global__ __launch_bounds__(kThreads) void ca_bwd_weight_kernel(const float2* __restrict__ go,
-                                                                  const float2* __restrict__ gh,
-                                                                  const float2* __restrict__ pooled,
-                                                                  const float2* __restrict__ hidden,
-                                                                  float* __restrict__ g_fc0_r, float* __restrict__ g_fc0_i,
-                                                                  float* __restrict__ g_fc2_r, float* __restrict__ g_fc2_i,
-                                                                  int B, int C, int Ch) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= C * Ch) return;
-    const int c = i / Ch, h = i % Ch;
+// The batch loop is unrolled so that its loads are issued together: a handful of threads on four dependent
+// loads per item is otherwise a chain of ~B memory round trips.
+struct CaWeightArgs {
+    const float2* go; const float2* gh; const float2* pooled; const float2* hidden;
+    float* g_fc0_r; float* g_fc0_i; float* g_fc2_r; float* g_fc2_i;
+    int B, C, Ch;
+};
+
+__device__ __forceinline__ void ca_bwd_weight_element(const CaWeightArgs& w, int i) {
+    const int c = i / w.Ch, h = i % w.Ch;
     float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float2 g = go[(long)b * C + c];
-        float2 hv = hidden[(long)b * Ch + h];
+#pragma unroll 8
+    for (int b = 0; b < w.B; ++b) {
+        const float2 g = w.go[(long)b * w.C + c];
+        float2 hv = w.hidden[(long)b * w.Ch + h];
         hv.x = hv.x > 0.f ? hv.x : 0.f; hv.y = hv.y > 0.f ? hv.y : 0.f;
         ar += g.x * hv.x + g.y * hv.y; ai += g.y * hv.x - g.x * hv.y;
-        const float2 q = gh[(long)b * Ch + h], p = pooled[(long)b * C + c];
+        const float2 q = w.gh[(long)b * w.Ch + h], p = w.pooled[(long)b * w.C + c];
         br += q.x * p.x + q.y * p.y; bi += q.y * p.x - q.x * p.y;
     }
-    g_fc2_r[c * Ch + h] = ar;                                 // fc.2 weight [C][Ch][1][1]
-    g_fc2_i[c * Ch + h] = ai;
-    g_fc0_r[h * C + c] = br;                                  // fc.0 weight [Ch][C][1][1]
-    g_fc0_i[h * C + c] = bi;
+    w.g_fc2_r[c * w.Ch + h] = ar;                             // fc.2 weight [C][Ch][1][1]
+    w.g_fc2_i[c * w.Ch + h] = ai;
+    w.g_fc0_r[h * w.C + c] = br;                              // fc.0 weight [Ch][C][1][1]
+    w.g_fc0_i[h * w.C + c] = bi;
 }
 
+// g_x += g_pooled / HW (broadcast over the sample's pixels).  Workgroups with blockIdx.x >= nx_pool of batch row 0 are
+// the FC weight-gradient half (nothing downstream waits for it, so it rides along instead of taking its own launch).
 __global__ __launch_bounds__(kThreads) void att_bwd_pool_kernel(float* __restrict__ gx, const float* __restrict__ gpooled,
-                                                                 long HW, int G, float inv_hw) {
+                                                                 long HW, int G, float inv_hw, int nx_pool, CaWeightArgs w) {
+    if ((int)blockIdx.x >= nx_pool) {
+        const int i = ((int)blockIdx.x - nx_pool) * kThreads + threadIdx.x;
+        if (blockIdx.y == 0 && i < w.C * w.Ch) ca_bwd_weight_element(w, i);
+        return;
+    }
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = blockIdx.y;
     float4* o4 = reinterpret_cast<float4*>(gx) + (long)b * HW * G;
     float4 p = reinterpret_cast<const float4*>(gpooled)[(long)b * G + g];
     p.x *= inv_hw; p.y *= inv_hw; p.z *= inv_hw; p.w *= inv_hw;
-    for (long r = (long)blockIdx.x * rpi + r0; r < HW; r += (long)gridDim.x * rpi) {
+    for (long r = (long)blockIdx.x * rpi + r0; r < HW; r += (long)nx_pool * rpi) {
         float4 v = o4[r * G + g];
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
         o4[r * G + g] = v;
@@ -307,12 +315,13 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
                        (const float2*)ca, (const float2*)hidden, (const float2*)w1, (const float2*)w2, go, gh, gpooled,
                        C, Ch);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ca_bwd_weight_kernel, dim3((C * Ch + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
-                       (const float2*)go, (const float2*)gh, (const float2*)pooled, (const float2*)hidden, g_fc0_r,
-                       g_fc0_i, g_fc2_r, g_fc2_i, B, C, Ch);
-    DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(att_bwd_pool_kernel, dim3(stream_grid(HW, G, B), B), dim3(kThreads), 0, s, g_x,
-                       (const float*)gpooled, HW, G, 1.f / (float)HW);
+    CaWeightArgs cw;
+    cw.go = go; cw.gh = gh; cw.pooled = (const float2*)pooled; cw.hidden = (const float2*)hidden;
+    cw.g_fc0_r = g_fc0_r; cw.g_fc0_i = g_fc0_i; cw.g_fc2_r = g_fc2_r; cw.g_fc2_i = g_fc2_i;
+    cw.B = B; cw.C = C; cw.Ch = Ch;
+    const int nx_pool = stream_grid(HW, G, B);
+    hipLaunchKernelGGL(att_bwd_pool_kernel, dim3(nx_pool + (C * Ch + kThreads - 1) / kThreads, B), dim3(kThreads), 0, s, g_x,
+                       (const float*)gpooled, HW, G, 1.f / (float)HW, nx_pool, cw);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
