@@ -222,7 +222,8 @@ class TrainStep:
         self._static_batch = [t.clone() for t in batch[:3]]
         static = (*self._static_batch, *batch[3:])
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: a collective backend's watchdog thread may touch the HIP runtime while this thread captures
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             if self._plan is not None:
                 functional.run_pack_plan(self._plan)
             self.bucket.zero_grad()
