@@ -86,14 +86,15 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     const int n_chunks = Cin / CH;
     const int nslots = rows * cols * Q;                                // float4 (2 complex) slots of one patch chunk
 
-    // fragment of (chunk c, tap tp, k-group g); past the last chunk: nothing to fetch
+    // fragment of (chunk c, tap tp, k-group g).  Always a load (past the end it re-reads the last chunk's fragment,
+    // which nobody consumes): the tap loop body stays free of branches, so s_waitcnt counts stay exact instead of
+    // draining to zero at every loop header.
     auto bload = [&](float4* dst, int c, int tp, int g) {
         if (tp >= ntaps) { tp = 0; ++c; }
-        if (c < n_chunks) {
-            const float* bp = bbase + tp * b_tap_stride + (long)(c * U + g) * b_kg_stride;
+        c = c < n_chunks ? c : n_chunks - 1;
+        const float* bp = bbase + tp * b_tap_stride + (long)(c * U + g) * b_kg_stride;
 #pragma unroll
-            for (int j = 0; j < WN; ++j) dst[j] = *reinterpret_cast<const float4*>(bp + j * 256);
-        }
+        for (int j = 0; j < WN; ++j) dst[j] = *reinterpret_cast<const float4*>(bp + j * 256);
     };
     float4 bring[R][WN];
 #pragma unroll
@@ -132,36 +133,33 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const float4*>(patch + pixoff[i]);
         int tapoff = 0;                                                // LDS float offset of the current tap
         for (int tap = 0; tap < ntaps; ++tap) {
-            const int tap2 = tap + 1;
+            const int tap2 = tap + 1 < ntaps ? tap + 1 : tap;          // clamped: the last prefetch re-reads this tap
             const int tapoff2 = ((tap2 / k.kw) * cols + (tap2 % k.kw)) * PIX;
 #pragma unroll
             for (int g = 0; g < U; ++g) {
-                float4 bf[WN];
+                // A fragments of the next iteration into the other register set
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bf[j] = bring[g % R][j];
-                // refill this slot with the fragment R iterations ahead
-                if (g + R < U) bload(bring[g % R], ch, tap, g + R);
-                else bload(bring[g % R], ch, tap2, g + R - U);
-                // A fragments of the next iteration
-                if (g + 1 < U) {
-#pragma unroll
-                    for (int i = 0; i < WM; ++i)
-                        af[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff + (g + 1) * 8);
-                } else if (tap2 < ntaps) {
-#pragma unroll
-                    for (int i = 0; i < WM; ++i)
-                        af[0][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff2);
-                }
+                for (int i = 0; i < WM; ++i)
+                    af[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(
+                        patch + pixoff[i] + (g + 1 < U ? tapoff + (g + 1) * 8 : tapoff2));
+                // MFMAs straight from the ring slot ...
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        const float4 av = af[g & 1][i];
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[j].w, acc[i][j], 0, 0, 0);
+                        const float4 av = af[g & 1][i], bv = bring[g % R][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
                     }
+                // ... which is then refilled with the fragment R iterations ahead (no register copy in between).  The
+                // scheduling barriers pin the load HERE: left alone, the machine scheduler sinks it to just before its
+                // use four iterations later (shorter live range) and the ring degenerates into load-wait-use.
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + R < U) bload(bring[g % R], ch, tap, g + R);
+                else bload(bring[g % R], ch, tap + 1, g + R - U);
+                __builtin_amdgcn_sched_barrier(0);
             }
             tapoff = tapoff2;
         }
