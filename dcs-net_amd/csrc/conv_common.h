@@ -83,6 +83,9 @@ int dcs_conv_small_dgrad_launch(const float* gy, const float* wp_bwd, float* gx,
 
 // conv_mfma.hip
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);
-int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream);
+// split-K scratch (bytes) the launch of this geometry would use; ws / ws_bytes below: that scratch (optional)
+long dcs_conv_mfma_workspace_bytes(const conv::Args& a, int ncls, const conv::Cls* cls);
+long dcs_conv_mfma_workspace_bytes_plain(const conv::Args& a);
+int dcs_conv_mfma_launch(conv::Args& a, const float* bm, void* ws, long ws_bytes, hipStream_t stream);
 int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const conv::Cls* cls, int os_f, int os_t,
-                                 float* y2, int nsplit, hipStream_t stream);
+                                 float* y2, int nsplit, void* ws, long ws_bytes, hipStream_t stream);

@@ -423,47 +423,124 @@ extern "C" int dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout
     return DCS_OK;
 }
 
-// shared with conv_mfma.hip's dispatcher
-int dcs_cconv2d_direct(const float* x1, const float* x2, const float* wp, const float* bias, float* y, int B, int Hin,
-                       int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh, int kw, int sf, int st, int pad_f,
-                       int pad_t, int act, hipStream_t stream) {
-    ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
-    a.wp = (const float2*)wp; a.bias = (const float2*)bias; a.y = (float2*)y; a.act = act;
-    return launch_direct(a, stream);
+// forward launch description shared by the workspace query and the launch itself
+struct FwdPlan { ConvArgs a; int path, ncls, os_f, os_t; conv::Cls cls[4]; };   // path 0: folded classes, 1: plain MFMA, 2: direct
+
+static FwdPlan fwd_plan(const float* x1, const float* x2, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                        int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t) {
+    FwdPlan p{};
+    if (!(C1 & 1) && conv::fold_ok(C1 + C2, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) {
+        // nearest upsample folded into per-parity sub-kernels on the SOURCE tensors (conv_pack.hip)
+        p.a = fwd_args(x1, x2, B, Hin, Win, C1, C2, 1, 1, Cout, kh, kw, 1, 1, pad_f, pad_t);
+        p.a.Hout = Hin * up_f; p.a.Wout = Win * up_t;
+        p.path = 0; p.ncls = up_f * up_t; p.os_f = up_f; p.os_t = up_t;
+        conv::fold_classes(Cout, C1 + C2, up_f, up_t, Hin, Win, p.cls);
+        return p;
+    }
+    p.a = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    p.path = (conv::mfma_ok(C1 + C2, Cout) && !(C1 & 1)) ? 1 : 2;
+    return p;
 }
 
-extern "C" int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const float* bias, float* y, int B,
-                               int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh, int kw, int sf,
-                               int st, int pad_f, int pad_t, int act, dcs_stream_t stream) {
+extern "C" long dcs_cconv2d_fwd_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout,
+                                                int kh, int kw, int sf, int st, int pad_f, int pad_t) {
+    if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || up_f < 1 || up_t < 1 || kh < 1 || kw < 1 ||
+        sf < 1 || st < 1 || pad_f < 0 || pad_t < 0)
+        return -1;
+    const FwdPlan p = fwd_plan(nullptr, nullptr, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    if (p.a.Hout <= 0 || p.a.Wout <= 0) return -1;
+    if (p.path == 0) return dcs_conv_mfma_workspace_bytes(p.a, p.ncls, p.cls);
+    if (p.path == 1) return dcs_conv_mfma_workspace_bytes_plain(p.a);
+    return 0;
+}
+
+extern "C" int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const float* bias, float* y,
+                               void* workspace, long workspace_bytes, int B, int Hin, int Win, int C1, int C2, int up_f,
+                               int up_t, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
+                               dcs_stream_t stream) {
     if (!wp || !bias || !y) return DCS_ERR_BADARG;
     if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t)) return DCS_ERR_BADARG;
     if (act < DCS_ACT_NONE || act > DCS_ACT_SIGMOID) return DCS_ERR_BADARG;
-    if (!(C1 & 1) && conv::fold_ok(C1 + C2, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) {
-        // nearest upsample folded into per-parity sub-kernels on the SOURCE tensors (conv_pack.hip)
-        ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1, C2, 1, 1, Cout, kh, kw, 1, 1, pad_f, pad_t);
-        a.bias = (const float2*)bias; a.y = (float2*)y; a.act = act;
-        a.Hout = Hin * up_f; a.Wout = Win * up_t;
-        conv::Cls cls[4];
-        conv::fold_classes(Cout, C1 + C2, up_f, up_t, Hin, Win, cls);
-        return dcs_conv_mfma_launch_classes(a, wp + base_floats(Cout, C1 + C2, kh * kw), up_f * up_t, cls, up_f, up_t,
-                                            nullptr, 0, dcs_stream(stream));
-    }
-    if (conv::mfma_ok(C1 + C2, Cout) && !(C1 & 1)) {
-        ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
-        a.wp = (const float2*)wp; a.bias = (const float2*)bias; a.y = (float2*)y; a.act = act;
-        return dcs_conv_mfma_launch(a, wp + conv::direct_floats(Cout, C1 + C2, kh * kw), dcs_stream(stream));
-    }
-    return dcs_cconv2d_direct(x1, x2, wp, bias, y, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t,
-                              act, dcs_stream(stream));
+    FwdPlan p = fwd_plan(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    p.a.wp = (const float2*)wp; p.a.bias = (const float2*)bias; p.a.y = (float2*)y; p.a.act = act;
+    if (p.path == 0)
+        return dcs_conv_mfma_launch_classes(p.a, wp + base_floats(Cout, C1 + C2, kh * kw), p.ncls, p.cls, p.os_f, p.os_t,
+                                            nullptr, 0, workspace, workspace_bytes, dcs_stream(stream));
+    if (p.path == 1)
+        return dcs_conv_mfma_launch(p.a, wp + conv::direct_floats(Cout, C1 + C2, kh * kw), workspace, workspace_bytes,
+                                    dcs_stream(stream));
+    return launch_direct(p.a, dcs_stream(stream));
 }
+
+// data-gradient launch description shared by the workspace query and the launch itself
+struct DgradPlan {
+    ConvArgs a;
+    int path;                  // 0: gradient of the upsample-folded conv, 1: enc0 class kernel, 2: stride classes (MFMA),
+                               // 3: zero-insertion MFMA, 4: zero-insertion direct
+    int ncls, os_f, os_t;
+    conv::Cls cls[4];
+    long gxv_bytes;            // gradient of the virtual (upsampled / concatenated) input, 0 when written straight to g_x1
+    int Hv, Wv, Hout, Wout;
+};
+
+static DgradPlan dgrad_plan(const float* gy, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh,
+                            int kw, int sf, int st, int pad_f, int pad_t) {
+    DgradPlan p{};
+    const int Cin = C1 + C2;
+    p.Hv = Hin * up_f; p.Wv = Win * up_t;
+    p.Hout = (p.Hv + 2 * pad_f - kh) / sf + 1; p.Wout = (p.Wv + 2 * pad_t - kw) / st + 1;
+    ConvArgs& a = p.a;
+    a.x1 = (const float2*)gy; a.x2 = nullptr; a.bias = nullptr;
+    a.B = B; a.Hin = p.Hout; a.Win = p.Wout; a.C1 = Cout; a.C2 = 0; a.Cout = Cin; a.act = DCS_ACT_NONE;
+    p.ncls = 1; p.os_f = 1; p.os_t = 1;
+    if (!(C1 & 1) && conv::fold_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) {
+        // gradient w.r.t. the SOURCE of the upsampled conv: stride-up correlation over g_Y with the effective
+        // 4-tap kernel; columns split into g_x1 | g_x2 in the epilogue (no g_Xv, no block-sum pass)
+        a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Hv = p.Hout; a.Wv = p.Wout;
+        a.kh = up_f == 2 ? 4 : 3; a.kw = up_t == 2 ? 4 : 3; a.sf = up_f; a.st = up_t; a.pad_f = 1; a.pad_t = 1;
+        a.Hout = Hin; a.Wout = Win;
+        conv::Cls& c = p.cls[0];
+        c.kh = a.kh; c.kw = a.kw; c.pad_f = 1; c.pad_t = 1; c.oo_f = 0; c.oo_t = 0; c.Hc = Hin; c.Wc = Win;
+        c.bm_off = conv::direct_floats(Cin, Cout, a.kh * a.kw);
+        p.path = 0;
+        return p;
+    }
+    if (up_f * up_t > 1 || C2 > 0) p.gxv_bytes = (long)B * p.Hv * p.Wv * Cin * (long)sizeof(float2);
+    if (C2 == 0 && dcs_conv_small_dgrad_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) { p.path = 1; return p; }
+    if (conv::stride_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t)) {
+        // one compact sub-kernel per residue class of the input pixel instead of zero insertion
+        a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Hv = p.Hout; a.Wv = p.Wout;
+        a.kh = kh; a.kw = kw; a.sf = 1; a.st = 1; a.pad_f = 0; a.pad_t = 0;
+        a.Hout = p.Hv; a.Wout = p.Wv;
+        conv::stride_classes(Cout, Cin, kh, kw, sf, st, pad_f, pad_t, p.Hv, p.Wv, p.cls);
+        p.ncls = sf * st; p.os_f = sf; p.os_t = st;
+        p.path = 2;
+        return p;
+    }
+    a.up_f = sf; a.up_t = st; a.zero_ins = 1;
+    a.kh = kh; a.kw = kw; a.sf = 1; a.st = 1; a.pad_f = kh - 1 - pad_f; a.pad_t = kw - 1 - pad_t;
+    a.Hv = (p.Hout - 1) * sf + 1; a.Wv = (p.Wout - 1) * st + 1;
+    a.Hout = p.Hv; a.Wout = p.Wv;                          // explicit: rows past the last tap get zeros
+    p.path = conv::mfma_ok(Cout, Cin) ? 3 : 4;
+    return p;
+}
+
+static long dgrad_split_bytes(const DgradPlan& p) {
+    if (p.path == 0 || p.path == 2) return dcs_conv_mfma_workspace_bytes(p.a, p.ncls, p.cls);
+    if (p.path == 3) return dcs_conv_mfma_workspace_bytes_plain(p.a);
+    return 0;
+}
+
+static long align256(long n) { return (n + 255) / 256 * 256; }
 
 extern "C" long dcs_cconv2d_bwd_data_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
                                                      int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t) {
-    if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || up_f < 1 || up_t < 1) return -1;
-    const int Cin = C1 + C2;
-    if (up_f * up_t == 1 && C2 == 0) return 0;                                       // written straight into g_x1
-    if (!(C1 & 1) && conv::fold_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) return 0;
-    return (long)B * Hin * up_f * Win * up_t * Cin * (long)sizeof(float2);           // g_Xv of the virtual input
+    if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || up_f < 1 || up_t < 1 || kh < 1 || kw < 1 ||
+        sf < 1 || st < 1 || pad_f < 0 || pad_t < 0 || pad_f > kh - 1 || pad_t > kw - 1)
+        return -1;
+    const DgradPlan p = dgrad_plan(nullptr, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    if (p.Hout <= 0 || p.Wout <= 0) return -1;
+    return align256(p.gxv_bytes) + dgrad_split_bytes(p);     // [g_Xv | split-K slices]
 }
 
 extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float* gx1, float* gx2, void* workspace,
@@ -476,53 +553,37 @@ extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float*
         pad_t > kw - 1)
         return DCS_ERR_BADARG;
     const int Cin = C1 + C2, taps = kh * kw;
-    const int Hv = Hin * up_f, Wv = Win * up_t;
-    const int Hout = (Hv + 2 * pad_f - kh) / sf + 1, Wout = (Wv + 2 * pad_t - kw) / st + 1;
-    if (Hout <= 0 || Wout <= 0) return DCS_ERR_BADARG;
+    DgradPlan p = dgrad_plan(gy, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    if (p.Hout <= 0 || p.Wout <= 0) return DCS_ERR_BADARG;
     hipStream_t s = dcs_stream(stream);
     const float* extra = wp_bwd + base_floats(Cin, Cout, taps);
-
-    ConvArgs a{};
-    a.x1 = (const float2*)gy; a.x2 = nullptr; a.bias = nullptr; a.y = (float2*)gx1;
-    a.B = B; a.Hin = Hout; a.Win = Wout; a.C1 = Cout; a.C2 = 0; a.Cout = Cin; a.act = DCS_ACT_NONE;
-
-    if (!(C1 & 1) && conv::fold_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) {
-        // gradient w.r.t. the SOURCE of the upsampled conv: stride-up correlation over g_Y with the effective
-        // 4-tap kernel; columns split into g_x1 | g_x2 in the epilogue (no g_Xv, no block-sum pass)
-        a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Hv = Hout; a.Wv = Wout;
-        a.kh = up_f == 2 ? 4 : 3; a.kw = up_t == 2 ? 4 : 3; a.sf = up_f; a.st = up_t; a.pad_f = 1; a.pad_t = 1;
-        a.Hout = Hin; a.Wout = Win;
-        conv::Cls c;
-        c.kh = a.kh; c.kw = a.kw; c.pad_f = 1; c.pad_t = 1; c.oo_f = 0; c.oo_t = 0; c.Hc = Hin; c.Wc = Win;
-        c.bm_off = conv::direct_floats(Cin, Cout, a.kh * a.kw);
-        return dcs_conv_mfma_launch_classes(a, extra, 1, &c, 1, 1, C2 ? gx2 : nullptr, 2 * C1, s);
-    }
-
     float* gxv = gx1;
-    if (up_f * up_t > 1 || C2 > 0) {                        // generic: gradient of the virtual input, then fold it
-        if (!workspace || workspace_bytes < (long)B * Hv * Wv * Cin * (long)sizeof(float2)) return DCS_ERR_WORKSPACE;
+    if (p.gxv_bytes > 0) {                                  // generic: gradient of the virtual input, then fold it
+        if (!workspace || workspace_bytes < p.gxv_bytes) return DCS_ERR_WORKSPACE;
         gxv = (float*)workspace;
     }
-    a.y = (float2*)gxv;
-    if (C2 == 0 && dcs_conv_small_dgrad_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t))
-        return dcs_conv_small_dgrad_launch(gy, wp_bwd, gx1, B, Hv, Wv, Hout, Wout, pad_f, pad_t, s);   // enc0: conv_small.hip
+    // whatever follows g_Xv in the workspace is split-K scratch (optional: too small just means no slicing)
+    const long used = align256(p.gxv_bytes);
+    void* ws2 = (workspace && workspace_bytes > used) ? (void*)((char*)workspace + used) : nullptr;
+    const long ws2_bytes = ws2 ? workspace_bytes - used : 0;
+    p.a.y = (float2*)gxv;
     int rc;
-    if (conv::stride_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t)) {
-        // one compact sub-kernel per residue class of the input pixel instead of zero insertion
-        a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Hv = Hout; a.Wv = Wout;
-        a.kh = kh; a.kw = kw; a.sf = 1; a.st = 1; a.pad_f = 0; a.pad_t = 0;
-        a.Hout = Hv; a.Wout = Wv;
-        conv::Cls cls[4];
-        conv::stride_classes(Cout, Cin, kh, kw, sf, st, pad_f, pad_t, Hv, Wv, cls);
-        rc = dcs_conv_mfma_launch_classes(a, extra, sf * st, cls, sf, st, nullptr, 0, s);
-    } else {
-        a.wp = (const float2*)wp_bwd;
-        a.up_f = sf; a.up_t = st; a.zero_ins = 1;
-        a.kh = kh; a.kw = kw; a.sf = 1; a.st = 1; a.pad_f = kh - 1 - pad_f; a.pad_t = kw - 1 - pad_t;
-        a.Hv = (Hout - 1) * sf + 1; a.Wv = (Wout - 1) * st + 1;
-        a.Hout = Hv; a.Wout = Wv;                          // explicit: rows past the last tap get zeros
-        rc = conv::mfma_ok(Cout, Cin) ? dcs_conv_mfma_launch(a, wp_bwd + conv::direct_floats(Cin, Cout, taps), s)
-                                      : launch_direct(a, s);
+    switch (p.path) {
+        case 0:
+            return dcs_conv_mfma_launch_classes(p.a, extra, 1, p.cls, 1, 1, C2 ? gx2 : nullptr, 2 * C1, ws2, ws2_bytes, s);
+        case 1:
+            return dcs_conv_small_dgrad_launch(gy, wp_bwd, gx1, B, p.Hv, p.Wv, p.Hout, p.Wout, pad_f, pad_t, s);   // enc0
+        case 2:
+            rc = dcs_conv_mfma_launch_classes(p.a, extra, p.ncls, p.cls, p.os_f, p.os_t, nullptr, 0, ws2, ws2_bytes, s);
+            break;
+        case 3:
+            p.a.wp = (const float2*)wp_bwd;
+            rc = dcs_conv_mfma_launch(p.a, wp_bwd + conv::direct_floats(Cin, Cout, taps), ws2, ws2_bytes, s);
+            break;
+        default:
+            p.a.wp = (const float2*)wp_bwd;
+            rc = launch_direct(p.a, s);
+            break;
     }
     if (rc != DCS_OK || gxv == gx1) return rc;
     const long n = (long)B * Hin * Win * Cin;

@@ -35,6 +35,12 @@ struct MArgs {
     int TH, TW, N, KG, NT;     // tile shape (TH*TW = pixels per WG), N = 2*Cout, KG = Cin/4, NT = ceil(N/32)
     int ncls, os_f, os_t;      // output-parity classes (blockIdx.z): pixel (oy, ox) of class c is stored at
     conv::Cls cls[4];          //   (oy*os_f + oo_f, ox*os_t + oo_t) and has its own sub-kernel / padding / panel
+    // split-K (layers whose pixel x column tiles alone leave most CUs idle): blockIdx.y also indexes ksplit slices of
+    // the input-channel chunks; each slice stores its raw partial tile into part[slice][pixel][N] and
+    // splitk_reduce_kernel adds the slices (+ bias, activation, cat split) in a fixed order
+    int ksplit, cps;           // slices, chunks per slice
+    float* part;
+    long slab_floats;          // B * Hout * Wout * N
 };
 
 // wave grid: WAVES_N waves along N, 4/WAVES_N along M; each wave owns WM x WN tiles of 32x32.
@@ -60,7 +66,9 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
     if (oy0 >= k.Hc || ox0 >= k.Wc) return;                           // tile outside this (smaller) class
     const int vy0 = oy0 * a.sf - k.pad_f, vx0 = ox0 * a.st - k.pad_t;
-    const int nt0 = (blockIdx.y * WAVES_N + wn) * WN;                  // first 32-column tile of this wave
+    const int ny = m.NT / (WAVES_N * WN);
+    const int kslice = blockIdx.y / ny;
+    const int nt0 = ((blockIdx.y % ny) * WAVES_N + wn) * WN;           // first 32-column tile of this wave
     const int Cin = a.C1 + a.C2;
     const int ntaps = k.kh * k.kw;
     const int cols = (m.TW - 1) * a.st + k.kw, rows = (m.TH - 1) * a.sf + k.kh;
@@ -83,7 +91,8 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int n_chunks = Cin / CH;
+    const int c_begin = kslice * m.cps;
+    const int n_chunks = (c_begin + m.cps) * CH < Cin ? c_begin + m.cps : Cin / CH;     // end of this slice's chunks
     const int nslots = rows * cols * Q;                                // float4 (2 complex) slots of one patch chunk
 
     // fragment of (chunk c, tap tp, k-group g).  Always a load (past the end it re-reads the last chunk's fragment,
@@ -98,9 +107,9 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     };
     float4 bring[R][WN];
 #pragma unroll
-    for (int g = 0; g < R; ++g) bload(bring[g], 0, 0, g);
+    for (int g = 0; g < R; ++g) bload(bring[g], c_begin, 0, g);
 
-    for (int ch = 0; ch < n_chunks; ++ch) {
+    for (int ch = c_begin; ch < n_chunks; ++ch) {
         __syncthreads();                                               // previous chunk fully consumed
         // gather in rounds of GU independent loads per thread (all in flight together), then the LDS stores
         constexpr int GU = 4;
@@ -166,6 +175,26 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     }
 
     // epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (m.ksplit > 1) {                                                // raw partial tile of this K slice
+        float* pf = m.part + (long)kslice * m.slab_floats;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = (nt0 + j) * 32 + li;
+            if (n >= m.N) continue;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    const int pi = (wm * WM + i) * 32 + row;
+                    const int oy = oy0 + pi / m.TW, ox = ox0 + pi % m.TW;
+                    if (oy < k.Hc && ox < k.Wc)
+                        pf[(((long)b * a.Hout + oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * m.N + n] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
     const float* biasf = reinterpret_cast<const float*>(a.bias);
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -192,7 +221,29 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     }
 }
 
+// y[p][n] = act(sum_s part[s][p][n] + bias[n]); columns >= nsplit of a cat split go to y2.  One float4 per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long slab_floats,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            float* __restrict__ y2, int nsplit, int N, int act) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 * 4 >= slab_floats) return;
+    float4 v = *reinterpret_cast<const float4*>(part + i4 * 4);
+    for (int s_ = 1; s_ < S; ++s_) {
+        const float4 u = *reinterpret_cast<const float4*>(part + (long)s_ * slab_floats + i4 * 4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const long p = (i4 * 4) / N;
+    const int n = (int)((i4 * 4) % N);
+    if (bias) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
+    v.x = dcs_act(v.x, act); v.y = dcs_act(v.y, act); v.z = dcs_act(v.z, act); v.w = dcs_act(v.w, act);
+    if (y2 == nullptr) *reinterpret_cast<float4*>(y + i4 * 4) = v;
+    else if (n < nsplit) *reinterpret_cast<float4*>(y + p * nsplit + n) = v;
+    else *reinterpret_cast<float4*>(y2 + p * (N - nsplit) + (n - nsplit)) = v;
+}
+
 // (the B-panel re-layout kernel lives in pack_jobs.hip: packjob::MFMA)
+
+struct Plan { int cand, TH, TW, CH, S, cps; long blocks; };
 
 template <int WAVES_N, int WM, int WN, int CH>
 int launch_ch(MArgs& m, long npix, hipStream_t stream) {
@@ -200,26 +251,101 @@ int launch_ch(MArgs& m, long npix, hipStream_t stream) {
     const size_t lds = (size_t)npix * (2 * CH + 4) * sizeof(float);
     auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
-    dim3 grid(a.tiles_w * a.tiles_h * a.B, m.NT / (WAVES_N * WN), m.ncls);
+    dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);
+    if (grid.y > 65535) return DCS_ERR_BADARG;
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
 
 template <int WAVES_N, int WM, int WN>
-int launch(MArgs& m, hipStream_t stream) {
-    const conv::Args& a = m.c;
-    int kh = 0, kw = 0;
-    for (int c = 0; c < m.ncls; ++c) { kh = m.cls[c].kh > kh ? m.cls[c].kh : kh; kw = m.cls[c].kw > kw ? m.cls[c].kw : kw; }
-    const long npix = (long)((m.TH - 1) * a.sf + kh) * ((m.TW - 1) * a.st + kw);
+int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
+    switch (p.CH) {
+        case 32: return launch_ch<WAVES_N, WM, WN, 32>(m, npix, stream);
+        case 16: return launch_ch<WAVES_N, WM, WN, 16>(m, npix, stream);
+        default: return launch_ch<WAVES_N, WM, WN, 8>(m, npix, stream);
+    }
+}
+
+struct Cand { int bm, bn; };
+constexpr Cand kCands[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+
+// tile, chunk depth and K slices for geometry `a` (FULL output extent in Hout/Wout) and its classes
+bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, long* npix_out) {
     const int Cin = a.C1 + a.C2;
+    if (!conv::mfma_ok(Cin, a.Cout) || (a.C1 & 1) || a.Hout <= 0 || a.Wout <= 0 || ncls < 1 || ncls > 4) return false;
+    int Hc = 0, Wc = 0, kh = 0, kw = 0;
+    for (int c = 0; c < ncls; ++c) {
+        Hc = cls[c].Hc > Hc ? cls[c].Hc : Hc; Wc = cls[c].Wc > Wc ? cls[c].Wc : Wc;
+        kh = cls[c].kh > kh ? cls[c].kh : kh; kw = cls[c].kw > kw ? cls[c].kw : kw;
+    }
+    if (Hc <= 0 || Wc <= 0) return false;
+    const int NT = (2 * a.Cout + 31) / 32;
+    // tile shape th x tw = bmp pixels: least padding past the class extent first, then the smallest haloed patch
+    auto shape = [&](int bmp, int* th, int* tw) {
+        long best_cost = -1;
+        for (int h = 2; h <= 16 && h <= bmp / 8; h *= 2) {
+            const int w = bmp / h;
+            const long padded = (long)((Hc + h - 1) / h) * h * ((Wc + w - 1) / w) * w;
+            const long patch = (long)((h - 1) * a.sf + kh) * ((w - 1) * a.st + kw);
+            const long cost = padded * 4096 + patch;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; *th = h; *tw = w; }
+        }
+    };
+    auto blocks_of = [&](int i, double* eff) {
+        int th, tw;
+        shape(kCands[i].bm, &th, &tw);
+        const long ty = (Hc + th - 1) / th, tx = (Wc + tw - 1) / tw;
+        *eff = (double)Hc * Wc / ((double)ty * th * tx * tw);             // share of the tiles' pixels that exist
+        return ty * tx * a.B * (NT / (kCands[i].bn / 32)) * ncls;
+    };
+    // candidate workgroup tiles (pixels x columns): the largest whose USEFUL workgroups (workgroups x the share of their
+    // pixels inside the map) number >= min_blocks — several per CU, so one workgroup's MFMA phase hides another's
+    // patch gather ...
+    static const long min_blocks = [] { const char* e = getenv("DCS_MFMA_MIN_BLOCKS"); return e ? atol(e) : 1024L; }();
+    static const long split_below = [] { const char* e = getenv("DCS_MFMA_SPLIT_BELOW"); return e ? atol(e) : 512L; }();
+    int best = -1; long best_blocks = -1; double best_useful = -1;
+    for (int i = 0; i < 4; ++i) {
+        if (NT % (kCands[i].bn / 32) != 0) continue;
+        double eff;
+        const long blocks = blocks_of(i, &eff);
+        if (blocks * eff >= min_blocks) { best = i; best_blocks = blocks; best_useful = blocks * eff; break; }
+        if (blocks * eff > best_useful) { best_useful = blocks * eff; best_blocks = blocks; best = i; }
+    }
+    if (best < 0) return false;
+    // ... and when even the best tile leaves CUs idle (deep layers at small batch: few pixels, long K), slice K
+    // instead: the tile with the best (pixel fit x operand reuse), times enough slices for ~4 workgroups per CU
+    int want_s = 1;
+    if (best_useful < split_below) {
+        const double reuse[4] = {1.0, 0.9, 0.8, 0.7};
+        double best_score = -1;
+        for (int i = 0; i < 4; ++i) {
+            if (NT % (kCands[i].bn / 32) != 0) continue;
+            double eff;
+            const long blocks = blocks_of(i, &eff);
+            if (blocks * 8 < split_below / 2) continue;                     // even 8 slices would not fill the chip
+            if (eff * reuse[i] > best_score) { best_score = eff * reuse[i]; best = i; best_blocks = blocks; }
+        }
+        want_s = (int)((min_blocks + best_blocks - 1) / best_blocks);
+    }
+    p->cand = best; p->blocks = best_blocks;
+    shape(kCands[best].bm, &p->TH, &p->TW);
+    const long npix = (long)((p->TH - 1) * a.sf + kh) * ((p->TW - 1) * a.st + kw);
     // chunk depth: 16 channels whenever the patch stays within ~1/3 of a CU's LDS (2-3 workgroups per CU overlap
     // each other's gathers), 32 only for small patches (occupancy matters more than barrier count there)
     static const long cap16 = [] { const char* e = getenv("DCS_MFMA_LDS_CAP"); return e ? atol(e) : 56L * 1024; }();
-    if (Cin % 32 == 0 && npix * 68 * 4 <= 32 * 1024) return launch_ch<WAVES_N, WM, WN, 32>(m, npix, stream);
-    if (Cin % 16 == 0 && npix * 36 * 4 <= cap16) return launch_ch<WAVES_N, WM, WN, 16>(m, npix, stream);
-    if (npix * 20 * 4 > 150 * 1024) return DCS_ERR_BADARG;
-    return launch_ch<WAVES_N, WM, WN, 8>(m, npix, stream);
+    if (Cin % 32 == 0 && npix * 68 * 4 <= 32 * 1024) p->CH = 32;
+    else if (Cin % 16 == 0 && npix * 36 * 4 <= cap16) p->CH = 16;
+    else if (npix * 20 * 4 <= 150 * 1024) p->CH = 8;
+    else return false;
+    const int n_chunks = Cin / p->CH;
+    int S = want_s < n_chunks ? want_s : n_chunks;
+    if (S > 8) S = 8;
+    if (S < 1) S = 1;
+    p->cps = (n_chunks + S - 1) / S;
+    p->S = (n_chunks + p->cps - 1) / p->cps;                 // no empty slice
+    *npix_out = npix;
+    return true;
 }
 
 }  // namespace
@@ -235,13 +361,23 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     return packjob::emit(j, stream);
 }
 
+// bytes of split-K scratch the launch of (a, classes) would use (0: the layer is not sliced)
+long dcs_conv_mfma_workspace_bytes(const conv::Args& a, int ncls, const conv::Cls* cls) {
+    Plan p;
+    long npix;
+    if (!make_plan(a, ncls, cls, &p, &npix) || p.S <= 1) return 0;
+    return (long)p.S * a.B * a.Hout * a.Wout * 2 * a.Cout * (long)sizeof(float);
+}
+
 // a: geometry with the FULL output extent in Hout/Wout; cls[0..ncls): output-parity classes (class-space
-// extent Hc x Wc, sub-kernel size, padding, panel offset); y2/nsplit: optional column split of the output
+// extent Hc x Wc, sub-kernel size, padding, panel offset); y2/nsplit: optional column split of the output;
+// ws / ws_bytes: optional split-K scratch (dcs_conv_mfma_workspace_bytes); too small or NULL: the layer runs unsliced
 int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const conv::Cls* cls, int os_f, int os_t,
-                                 float* y2, int nsplit, hipStream_t stream) {
+                                 float* y2, int nsplit, void* ws, long ws_bytes, hipStream_t stream) {
+    Plan p;
+    long npix;
+    if (!make_plan(a, ncls, cls, &p, &npix)) return DCS_ERR_BADARG;
     const int Cin = a.C1 + a.C2;
-    if (!conv::mfma_ok(Cin, a.Cout) || (a.C1 & 1) || a.Hout <= 0 || a.Wout <= 0 || ncls < 1 || ncls > 4)
-        return DCS_ERR_BADARG;
     MArgs m;
     m.c = a;
     m.bm = bm;
@@ -253,52 +389,45 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         Hc = cls[c].Hc > Hc ? cls[c].Hc : Hc;
         Wc = cls[c].Wc > Wc ? cls[c].Wc : Wc;
     }
-    if (Hc <= 0 || Wc <= 0) return DCS_ERR_BADARG;
     m.N = 2 * a.Cout; m.KG = Cin / 4; m.NT = (m.N + 31) / 32;
-    // candidate workgroup tiles (pixels x columns); take the largest that still yields >= min_blocks workgroups
-    // (default 2 per CU, so one workgroup's MFMA phase hides the other's patch gather), else the one with the most
-    // workgroups: deep layers at small batch have few pixels
-    struct Cand { int bm, bn; };
-    const Cand cands[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
-    int kh = 0, kw = 0;
-    for (int c = 0; c < ncls; ++c) { kh = cls[c].kh > kh ? cls[c].kh : kh; kw = cls[c].kw > kw ? cls[c].kw : kw; }
-    // tile shape th x tw = bmp pixels: least padding past the class extent first, then the smallest haloed patch
-    auto shape = [&](int bmp, int* th, int* tw) {
-        long best_cost = -1;
-        for (int h = 2; h <= 16 && h <= bmp / 8; h *= 2) {
-            const int w = bmp / h;
-            const long padded = (long)((Hc + h - 1) / h) * h * ((Wc + w - 1) / w) * w;
-            const long patch = (long)((h - 1) * a.sf + kh) * ((w - 1) * a.st + kw);
-            const long cost = padded * 4096 + patch;
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; *th = h; *tw = w; }
-        }
-    };
-    static const long min_blocks = [] { const char* e = getenv("DCS_MFMA_MIN_BLOCKS"); return e ? atol(e) : 1024L; }();
-    int best = -1; long best_blocks = -1;
-    for (int i = 0; i < 4; ++i) {
-        if (m.NT % (cands[i].bn / 32) != 0) continue;
-        int th, tw;
-        shape(cands[i].bm, &th, &tw);
-        const long blocks = (long)((Wc + tw - 1) / tw) * ((Hc + th - 1) / th) * a.B * (m.NT / (cands[i].bn / 32)) * ncls;
-        if (blocks >= min_blocks) { best = i; break; }
-        if (blocks > best_blocks) { best_blocks = blocks; best = i; }
-    }
-    if (best < 0) return DCS_ERR_BADARG;
-    shape(cands[best].bm, &m.TH, &m.TW);
+    m.TH = p.TH; m.TW = p.TW;
     m.c.tiles_w = (Wc + m.TW - 1) / m.TW;
     m.c.tiles_h = (Hc + m.TH - 1) / m.TH;
-    switch (best) {
-        case 0: return launch<2, 2, 2>(m, stream);      // 128 x 128
-        case 1: return launch<2, 2, 1>(m, stream);      // 128 x 64
-        case 2: return launch<2, 1, 1>(m, stream);      //  64 x 64
-        default: return launch<1, 1, 1>(m, stream);     // 128 x 32
+    m.slab_floats = (long)a.B * a.Hout * a.Wout * m.N;
+    m.ksplit = p.S; m.cps = p.cps; m.part = (float*)ws;
+    if (p.S > 1 && (!ws || ws_bytes < (long)p.S * m.slab_floats * (long)sizeof(float) || (m.N & 3) ||
+                    (y2 != nullptr && (nsplit & 3)))) {
+        m.ksplit = 1; m.cps = Cin / p.CH; m.part = nullptr;
     }
+    int rc;
+    switch (p.cand) {
+        case 0: rc = launch<2, 2, 2>(m, p, npix, stream); break;      // 128 x 128
+        case 1: rc = launch<2, 2, 1>(m, p, npix, stream); break;      // 128 x 64
+        case 2: rc = launch<2, 1, 1>(m, p, npix, stream); break;      //  64 x 64
+        default: rc = launch<1, 1, 1>(m, p, npix, stream); break;     // 128 x 32
+    }
+    if (rc != DCS_OK || m.ksplit <= 1) return rc;
+    const long n4 = m.slab_floats / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)m.part,
+                       m.ksplit, m.slab_floats, (const float*)a.bias, (float*)a.y, y2, nsplit, m.N, a.act);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
 }
 
 // single class: the plain convolution described by `a` (Hout/Wout set)
-int dcs_conv_mfma_launch(conv::Args& a, const float* bm, hipStream_t stream) {
+static conv::Cls plain_class(const conv::Args& a) {
     conv::Cls c;
     c.kh = a.kh; c.kw = a.kw; c.pad_f = a.pad_f; c.pad_t = a.pad_t; c.oo_f = 0; c.oo_t = 0;
     c.Hc = a.Hout; c.Wc = a.Wout; c.bm_off = 0;
-    return dcs_conv_mfma_launch_classes(a, bm, 1, &c, 1, 1, nullptr, 0, stream);
+    return c;
+}
+
+long dcs_conv_mfma_workspace_bytes_plain(const conv::Args& a) {
+    const conv::Cls c = plain_class(a);
+    return dcs_conv_mfma_workspace_bytes(a, 1, &c);
+}
+
+int dcs_conv_mfma_launch(conv::Args& a, const float* bm, void* ws, long ws_bytes, hipStream_t stream) {
+    const conv::Cls c = plain_class(a);
+    return dcs_conv_mfma_launch_classes(a, bm, 1, &c, 1, 1, nullptr, 0, ws, ws_bytes, stream);
 }

@@ -155,10 +155,15 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     Wout = (Win * up[1] + 2 * pad[1] - kw) // stride[1] + 1
     y = torch.empty((B, Hout, Wout, Cout, 2), dtype=torch.float32, device=x1.device)
     lib = _lib.load()
+    # split-K scratch for layers with too few output tiles to fill the chip (0 bytes for most geometries)
+    nbytes = lib.dcs_cconv2d_fwd_workspace_bytes(B, Hin, Win, C1, C2, up[0], up[1], Cout, kh, kw, stride[0], stride[1],
+                                                 pad[0], pad[1])
+    ws = _workspace(nbytes, x1.device) if nbytes > 0 else None
+    nbytes = max(nbytes, 0)
     # bench.py's live roofline probe: 8 real flops per complex MAC
     ev = CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw) if CONV_TIMER is not None else None
-    check(lib.dcs_cconv2d_fwd(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(y), B, Hin, Win, C1, C2, up[0], up[1],
-                              Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], act, cur_stream()),
+    check(lib.dcs_cconv2d_fwd(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(y), ptr(ws), nbytes, B, Hin, Win, C1, C2,
+                              up[0], up[1], Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], act, cur_stream()),
           'dcs_cconv2d_fwd')
     if ev is not None:
         CONV_TIMER.end(ev)

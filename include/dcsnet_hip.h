@@ -93,8 +93,15 @@ int dcs_pack_conv_weight(const float* w_r, const float* w_i, const float* b_r, c
  *     y[b,oy,ox,co] = bias[co] + sum_{dy,dx,ci} wp[dy*kw+dx][ci][co] * X[b, oy*sf-pad_f+dy, ox*st-pad_t+dx, ci]
  * (complex product; X is zero outside its bounds).  act: DCS_ACT_* applied to re and im.
  * wp/bias as written by dcs_pack_conv_weight.
+ * workspace: optional split-K scratch of dcs_cconv2d_fwd_workspace_bytes() bytes (0 for most geometries).  Deep
+ * layers at small batch have too few output tiles to fill 256 CUs; with the scratch their input-channel range is
+ * sliced over extra workgroups and a reduce pass adds the slices (+ bias, activation) in a fixed order.  NULL or too
+ * small: the layer simply runs unsliced.
  */
+long dcs_cconv2d_fwd_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                                     int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t);
 int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const float* bias, float* y,
+                    void* workspace, long workspace_bytes,
                     int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
                     int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
                     dcs_stream_t stream);
@@ -111,8 +118,10 @@ int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const flo
  * dcs_cconv2d_bwd_data:  g_x1 (complex[B][Hin][Win][C1]) and g_x2 (complex[B][Hin][Win][C2], NULL iff C2 == 0):
  *     gradients of the two inputs of the forward call with the same geometry arguments,
  *       g_Xv[b,vy,vx,ci] = sum_{p,tap,co} conj(wp[tap][ci][co]) g_Y[p,co]   over p*s - pad + tap = (vy,vx),
- *     block-summed over the upsample factors and split at channel C1.  workspace: see
- *     dcs_cconv2d_bwd_data_workspace_bytes (0 on the fused paths).
+ *     block-summed over the upsample factors and split at channel C1.  workspace: the first part (required when
+ *     the virtual-input gradient has to exist: cat or upsample on a non-folded geometry) holds g_Xv, the rest is the
+ *     optional split-K scratch of the deep few-pixel layers (as in dcs_cconv2d_fwd);
+ *     dcs_cconv2d_bwd_data_workspace_bytes returns the sum (0 for most geometries).
  * dcs_upsample_cat_bwd:  the stand-alone block sum / channel split of a virtual-input gradient.
  * dcs_cconv2d_bwd_weight: gradients of the reference's parameters, in THEIR layout:
  *     gw_r, gw_i: float[Cout][Cin][kh][kw] (transposed=0) or float[Cin][Cout][kh][kw] (transposed=1)

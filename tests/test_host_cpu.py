@@ -52,7 +52,7 @@ def test_null_and_bad_arguments_are_rejected_before_any_launch():
     from dcsnet import _lib
     lib = _lib.load()
     assert lib.dcs_bound_crm_fwd(None, None, 10, 1e-6, None) == -1
-    assert lib.dcs_cconv2d_fwd(None, None, None, None, None, 1, 1, 1, 1, 0, 1, 1, 1, 3, 3, 1, 1, 1, 1, 0, None) == -1
+    assert lib.dcs_cconv2d_fwd(None, None, None, None, None, None, 0, 1, 1, 1, 1, 0, 1, 1, 1, 3, 3, 1, 1, 1, 1, 0, None) == -1
     assert lib.dcs_dropout_fwd(None, None, 0, 0.1, 1, None, None) == -1
 
 
