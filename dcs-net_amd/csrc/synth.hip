@@ -249,6 +249,30 @@ __global__ __launch_bounds__(kThreads) void sisnr_bwd_kernel(const float* __rest
 }
 }  // namespace
 
+namespace {
+// the reference's loss assembly for noise_loss_type 6 / speech_loss_type 0 (network_functions.py:168-208) on the two
+// per-utterance SiSNR vectors: out = {noise_loss = 1 - alpha * (-mean snr_n), speech_loss = alpha * (-mean snr_s), sum}
+__global__ __launch_bounds__(64) void sisnr_losses_kernel(const float* __restrict__ snr_s, const float* __restrict__ snr_n,
+                                                           float* __restrict__ out, int B, float alpha) {
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < B; i += 64) { a += snr_s[i]; b += snr_n[i]; }
+    a = dcs_wave_sum(a) / (float)B;
+    b = dcs_wave_sum(b) / (float)B;
+    if (threadIdx.x == 0) {
+        const float noise_loss = 1.f - alpha * (-b), speech_loss = alpha * (-a);
+        out[0] = noise_loss; out[1] = speech_loss; out[2] = noise_loss + speech_loss;
+    }
+}
+}  // namespace
+
+extern "C" int dcs_sisnr_losses_fwd(const float* snr_speech, const float* snr_noise, float* out3, int B, float alpha,
+                                    dcs_stream_t stream) {
+    if (!snr_speech || !snr_noise || !out3 || B <= 0) return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(sisnr_losses_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), snr_speech, snr_noise, out3, B, alpha);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
 extern "C" int dcs_sisnr_fwd(const float* clean, const float* est, float* snr, float* coef, int B, int L, float eps,
                              dcs_stream_t stream) {
     if (!clean || !est || !snr || !coef || B <= 0 || L <= 0) return DCS_ERR_BADARG;

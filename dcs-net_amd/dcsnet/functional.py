@@ -535,6 +535,41 @@ def sisnr_mean(clean, est, eps=1e-8):
     return _SiSNRFn.apply(clean.detach().contiguous(), est.contiguous(), eps)
 
 
+class _SiSNRLossesFn(torch.autograd.Function):
+    """(noise_loss, speech_loss, total) of network_functions.py:168-208 for noise_loss_type 6 / speech_loss_type 0:
+    two dcs_sisnr_fwd + one combine launch forward, two dcs_sisnr_bwd backward — no scalar glue kernels."""
+
+    @staticmethod
+    def forward(ctx, clean, est_clean, noise, est_noise, alpha, eps):
+        snr_s, coef_s = ops.sisnr(clean, est_clean, eps)
+        snr_n, coef_n = ops.sisnr(noise, est_noise, eps)
+        out = ops.sisnr_losses(snr_s, snr_n, alpha)
+        ctx.save_for_backward(clean, est_clean, coef_s, noise, est_noise, coef_n)
+        ctx.alpha = float(alpha)
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_noise, g_speech, g_total):
+        clean, est_clean, coef_s, noise, est_noise, coef_n = ctx.saved_tensors
+        B = est_clean.shape[0]
+
+        def both(a, b):                                    # upstream gradients that reach one SiSNR
+            if a is None:
+                return b
+            return a if b is None else a + b
+        gs, gn = both(g_speech, g_total), both(g_noise, g_total)
+        # speech_loss = -alpha mean(snr_s);  noise_loss = 1 + alpha mean(snr_n)
+        g_ec = None if gs is None else ops.sisnr_bwd(clean, est_clean, coef_s, gs.contiguous(), -ctx.alpha / B)
+        g_en = None if gn is None else ops.sisnr_bwd(noise, est_noise, coef_n, gn.contiguous(), ctx.alpha / B)
+        return None, g_ec, None, g_en, None, None
+
+
+def sisnr_losses(clean, est_clean, noise, est_noise, alpha, eps=1e-8):
+    return _SiSNRLossesFn.apply(clean.detach().contiguous(), est_clean.contiguous(), noise.detach().contiguous(),
+                                est_noise.contiguous(), float(alpha), eps)
+
+
 def bound_crm_complex(M, eps=10e-7):
     return torch.view_as_complex(bound_crm(torch.view_as_real(M.contiguous()), eps))
 

@@ -211,6 +211,13 @@ def calc_loss(self, **kw):
     (noise_loss_type 6, speech_loss_type 0: config.py:38-39)."""
     mode = _mode()
     alpha = self.hparams['speech_alpha']
+    if (mode in ('dcs', 'drs') and self.hparams['noise_loss_type'] == 6 and isinstance(self.config.SiSNR, SiSNR) and
+            all(kw[k].is_cuda and kw[k].dim() == 2 and kw[k].dtype == torch.float32
+                for k in ('clean_audio', 'predict_clean_audio', 'noise_audio', 'predict_noise_audio')) and
+            not (kw['clean_audio'].requires_grad or kw['noise_audio'].requires_grad)):
+        # the configured pair of SiSNR losses and their assembly in five HIP launches (forward + backward)
+        return F.sisnr_losses(kw['clean_audio'], kw['predict_clean_audio'], kw['noise_audio'], kw['predict_noise_audio'],
+                              alpha)
     speech_loss = alpha * (-self.config.SiSNR(kw['clean_audio'], kw['predict_clean_audio']))
     if mode in ('dc', 'dr'):
         return speech_loss

@@ -533,6 +533,16 @@ def sisnr(clean, est, eps=1e-8):
     return snr, coef
 
 
+def sisnr_losses(snr_speech, snr_noise, alpha):
+    """[noise_loss, speech_loss, total] (float [3]) of the reference's SiSNR loss configuration."""
+    _chk(snr_speech, 'snr_speech', 1)
+    _chk(snr_noise, 'snr_noise', 1)
+    out = torch.empty(3, dtype=torch.float32, device=snr_speech.device)
+    check(_lib.load().dcs_sisnr_losses_fwd(ptr(snr_speech), ptr(snr_noise), ptr(out), snr_speech.numel(), float(alpha),
+                                           cur_stream()), 'dcs_sisnr_losses_fwd')
+    return out
+
+
 def sisnr_bwd(clean, est, coef, g, scale):
     """g: 0-dim / 1-element float tensor on the device (upstream gradient of the batch mean)."""
     B, L = est.shape

@@ -343,6 +343,12 @@ int dcs_sisnr_fwd(const float* clean, const float* est, float* snr, float* coef,
 int dcs_sisnr_bwd(const float* clean, const float* est, const float* coef, const float* g, float scale, float* g_est,
                   int B, int L, dcs_stream_t stream);
 
+/* Loss assembly of the reference's configuration (noise_loss_type 6, speech_loss_type 0: network_functions.py:168-208,
+ * config.py:38-39) from the two per-utterance SiSNR vectors of dcs_sisnr_fwd:
+ * out3 = { 1 - alpha * (-mean snr_noise), alpha * (-mean snr_speech), their sum } (the "1 -" quirk of :196 kept). */
+int dcs_sisnr_losses_fwd(const float* snr_speech, const float* snr_noise, float* out3, int B, float alpha,
+                         dcs_stream_t stream);
+
 /* cRM target mask (network_functions.py:62-75): M = S conj(Y) / (|Y|^2 + 1e-8). */
 int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs_stream_t stream);
 

@@ -345,3 +345,24 @@ def test_fused_sisnr_value_and_gradient(dev):
         assert abs(float(got) - float(want)) <= 2e-5 * abs(float(want)) + 1e-5
         (-0.7 * got).backward()
         close(ed.grad, est.grad, rel=2e-4, what=f'g_est B={B}')
+
+
+def test_fused_sisnr_loss_assembly(dev):
+    """dcs_sisnr_losses_fwd + the two dcs_sisnr_bwd launches vs the reference's loss assembly
+    (network_functions.py:168-208: speech = alpha (-SiSNR), noise = 1 - alpha (-SiSNR), total = sum)."""
+    from dcsnet import functional as F
+    g = torch.Generator().manual_seed(9)
+    B, L, alpha = 8, 4000, 0.7
+    clean, noise = torch.randn(B, L, generator=g) * 0.3, torch.randn(B, L, generator=g) * 0.1
+    ec = (clean + 0.1 * torch.randn(B, L, generator=g)).requires_grad_(True)
+    en = (noise + 0.05 * torch.randn(B, L, generator=g)).requires_grad_(True)
+    speech = alpha * (-nf.si_snr(clean, ec))
+    nl = 1 - alpha * (-nf.si_snr(noise, en))
+    (nl + speech).backward()
+    ecd, end_ = ec.detach().to(dev).requires_grad_(True), en.detach().to(dev).requires_grad_(True)
+    got = F.sisnr_losses(clean.to(dev), ecd, noise.to(dev), end_, alpha)
+    for a, b in zip(got, (nl, speech, nl + speech)):
+        assert abs(float(a) - float(b)) <= 2e-5 * abs(float(b)) + 2e-5
+    got[2].backward()
+    close(ecd.grad, ec.grad, rel=2e-4, what='g_est_clean')
+    close(end_.grad, en.grad, rel=2e-4, what='g_est_noise')
