@@ -14,6 +14,8 @@ enum Kind : int {
     BWD = 1,      // forward direct panel -> data-gradient panel complex[tap'][Cout][Cin] (flip, conj, swap)
     FOLD = 2,     // tap sums / tap subsets of a direct panel (upsample fold, stride classes), optional swap+conj
     MFMA = 3,     // direct panel -> v_mfma_f32_32x32x2_f32 B-fragment order
+    TAPROWS = 4,  // ConvTranspose2d weight [Cin][1][kh][kw] -> 1x1 panel complex[1][Cin][ct]: column `tap` = the flipped kernel
+                  // at that tap (the tap-sum factorisation of a Cout = 1 stage), zero columns beyond kh*kw, zero bias
 };
 
 struct Job {

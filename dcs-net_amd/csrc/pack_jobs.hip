@@ -87,12 +87,25 @@ __device__ __forceinline__ void run_mfma(const Job& jb, long i) {
     bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
 }
 
+// wp[0][ci][tap] = w[ci][0][kh-1-dy][kw-1-dx] (tap = dy*kw + dx), 0 for tap >= kh*kw; bias = 0.  Cout = ct columns.
+__device__ __forceinline__ void run_taprows(const Job& j, long i) {
+    const float* w_r = (const float*)j.src0; const float* w_i = (const float*)j.src1;
+    float2* wp = (float2*)j.dst0; float2* bias_out = (float2*)j.dst1;
+    const int ct = j.Cout, taps = j.kh * j.kw;
+    if (i < ct) bias_out[i] = make_float2(0.f, 0.f);
+    const int tap = (int)(i % ct), ci = (int)(i / ct);
+    float2 v = make_float2(0.f, 0.f);
+    if (tap < taps) { const long src = (long)ci * taps + (taps - 1 - tap); v = make_float2(w_r[src], w_i[src]); }
+    wp[i] = v;
+}
+
 __device__ __forceinline__ void run(const Job& j, long i) {
     if (i >= j.total) return;
     switch (j.kind) {
         case DIRECT: run_direct(j, i); break;
         case BWD: run_bwd(j, i); break;
         case FOLD: run_fold(j, i); break;
+        case TAPROWS: run_taprows(j, i); break;
         default: run_mfma(j, i); break;
     }
 }
@@ -152,6 +165,54 @@ int emit(const Job& j, hipStream_t s) {
 
 using packjob::Plan;
 using packjob::Level;
+
+namespace {
+// g_w[ci][0][dy][dx] (+)= g_rows[kh*kw - 1 - (dy*kw + dx)][ci]: the adjoint of packjob::TAPROWS on the 1x1 weight gradient
+__global__ __launch_bounds__(256) void tap_rows_scatter_kernel(const float* __restrict__ gt_r, const float* __restrict__ gt_i,
+                                                                float* __restrict__ gw_r, float* __restrict__ gw_i, int Cin,
+                                                                int taps, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cin * taps) return;
+    const int ci = i / taps, t = i % taps;
+    const long src = (long)(taps - 1 - t) * Cin + ci;
+    if (accumulate) { gw_r[i] += gt_r[src]; gw_i[i] += gt_i[src]; }
+    else { gw_r[i] = gt_r[src]; gw_i[i] = gt_i[src]; }
+}
+}  // namespace
+
+extern "C" int dcs_pack_tap_rows(const float* w_r, const float* w_i, float* wp, float* bias_out, int Cin, int kh, int kw,
+                                 int ct, dcs_stream_t stream) {
+    if (!w_r || !w_i || !wp || !bias_out || Cin <= 0 || kh < 1 || kw < 1 || ct < kh * kw) return DCS_ERR_BADARG;
+    packjob::Job j{};
+    j.kind = packjob::TAPROWS;
+    j.Cout = ct; j.Cin = Cin; j.kh = kh; j.kw = kw;
+    j.total = (long)Cin * ct;
+    if (j.total < ct) j.total = ct;
+    j.dst_bytes = (long)Cin * ct * (long)sizeof(float2);
+    j.src0 = w_r; j.src1 = w_i; j.dst0 = wp; j.dst1 = bias_out;
+    const int rc = packjob::emit(j, dcs_stream(stream));
+    if (rc != DCS_OK) return rc;
+    if ((Cin % 8) == 0 && (ct % 8) == 0) {                   // MFMA fragment panel behind the direct one (conv_mfma.hip)
+        packjob::Job m{};
+        m.kind = packjob::MFMA;
+        m.Cout = ct; m.Cin = Cin; m.kh = 1;
+        m.total = (long)(Cin / 4) * ((2 * ct + 31) / 32) * 64;
+        m.dst_bytes = m.total * (long)sizeof(float4);
+        m.src0 = wp; m.dst0 = wp + (long)Cin * ct * 2;
+        return packjob::emit(m, dcs_stream(stream));
+    }
+    return DCS_OK;
+}
+
+extern "C" int dcs_tap_rows_wgrad_scatter(const float* gt_r, const float* gt_i, float* gw_r, float* gw_i, int Cin, int kh,
+                                          int kw, int accumulate, dcs_stream_t stream) {
+    if (!gt_r || !gt_i || !gw_r || !gw_i || Cin <= 0 || kh < 1 || kw < 1) return DCS_ERR_BADARG;
+    const int n = Cin * kh * kw;
+    hipLaunchKernelGGL(tap_rows_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, dcs_stream(stream), gt_r, gt_i, gw_r, gw_i,
+                       Cin, kh * kw, accumulate);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
 
 extern "C" int dcs_pack_plan_begin(void) {
     std::lock_guard<std::mutex> lock(packjob::g_rec_mutex);

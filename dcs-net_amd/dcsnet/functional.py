@@ -47,20 +47,21 @@ def _ver(t):
     return (0, 0) if t is None else (id(t), t._version)
 
 
-def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1)):
+def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1), tap_rows=0):
     """Packed (wp, bias) for a weight pair; cached per tensor OBJECT and version (the weakrefs
     guard against a recycled id()).  1x1 / Linear weights may be passed 2-D.  `up`: upsample factors
-    of the conv call the weight is for."""
+    of the conv call the weight is for.  tap_rows = ct > 0: the 1x1 "tap channel" weight of the tap-sum factorisation
+    instead (ops.pack_tap_rows)."""
     plan = ops.PLAN
     if plan is not None:
-        pkey = (id(w_r), id(w_i), id(b_r), id(b_i), bool(transposed), tuple(up))
+        pkey = (id(w_r), id(w_i), id(b_r), id(b_i), bool(transposed), tuple(up), int(tap_rows))
         if plan.valid and not plan.recording:
             e = plan.fwd.get(pkey)
             if e is not None and e[0][0]() is w_r and e[0][1]() is w_i and e[2] == (
                     w_r._version, w_i._version, None if b_r is None else b_r._version,
                     None if b_i is None else b_i._version):
                 return e[1]
-    key = (_ver(w_r), _ver(w_i), _ver(b_r), _ver(b_i), bool(transposed), tuple(up))
+    key = (_ver(w_r), _ver(w_i), _ver(b_r), _ver(b_i), bool(transposed), tuple(up), int(tap_rows))
     hit = _pack_cache.get(key)
     if hit is not None and hit[0]() is w_r and hit[1]() is w_i:
         return hit[2]
@@ -70,7 +71,10 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1)):
     wr, wi = d(w_r), d(w_i)
     if wr.dim() == 2:
         wr, wi = wr.view(*wr.shape, 1, 1), wi.view(*wi.shape, 1, 1)
-    packed = ops.pack_conv_weight(wr, wi, d(b_r), d(b_i), transposed, tuple(up))
+    if tap_rows:
+        packed = ops.pack_tap_rows(wr, wi, int(tap_rows))
+    else:
+        packed = ops.pack_conv_weight(wr, wi, d(b_r), d(b_i), transposed, tuple(up))
     _pack_cache[key] = (weakref.ref(w_r), weakref.ref(w_i), packed)
     if plan is not None and plan.recording:
         wref = lambda t: None if t is None else weakref.ref(t)
@@ -404,6 +408,38 @@ class _TapSumFn(torch.autograd.Function):
         return ops.tapsum(shape, ksize, up, pad, backward=True, grad=g.contiguous()), None, None, None
 
 
+class _TapRowsConvFn(torch.autograd.Function):
+    """conv1x1(cat(x1, x2): Cin -> ct tap channels) whose weight rows are the flipped taps of a [Cin,1,kh,kw]
+    ConvTranspose2d weight: packed straight from the parameters (dcs_pack_tap_rows: no flip / pad / reshape kernels, and
+    the pack is part of the pack plan), weight gradient scattered straight back (dcs_tap_rows_wgrad_scatter)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w_r, w_i, ct):
+        wp, bias = packed_weight(w_r, w_i, None, None, False, (1, 1), tap_rows=ct)
+        z = ops.cconv2d(x1, x2, wp, bias, (1, 1), (1, 1), (0, 0), (1, 1), ACT_NONE)
+        ctx.ct, ctx.w_shape = ct, tuple(w_r.shape)
+        ctx.sinks = (_sink(w_r), _sink(w_i))
+        ctx.save_for_backward(x1, x2, wp)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x1, x2, wp = ctx.saved_tensors
+        gz = gz.contiguous()
+        C1 = x1.shape[3]
+        Cin = C1 + (x2.shape[3] if x2 is not None else 0)
+        gx1 = gx2 = gw_r = gw_i = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            gt_r, gt_i, _, _ = ops.cconv2d_bwd_weight(x1, x2, gz, (ctx.ct, Cin, 1, 1), False, (1, 1), (1, 1), (0, 0))
+            g = ops.tap_rows_scatter(gt_r, gt_i, ctx.w_shape, ctx.sinks)
+            if ctx.sinks[0] is None or ctx.sinks[1] is None:
+                gw_r, gw_i = g
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gx1, gx2 = ops.cconv2d_bwd_data(gz, ops.pack_conv_weight_bwd(wp, (1, 1)), (x1.shape[1], x1.shape[2], Cin),
+                                            (1, 1), (1, 1), (0, 0), (1, 1), C1)
+        return gx1, gx2, gw_r, gw_i, None
+
+
 def cconv_single_output(x1, x2, w_r, w_i, b_r, b_i, ksize, pad, up):
     """Stride-1 ComplexConvTranspose2d with ONE output channel over upsample(cat(x1, x2)) (the last decoder
     stage).  Cout = 1 would leave the MFMA tile's N dimension 2 wide, so the stage is factored as
@@ -411,14 +447,8 @@ def cconv_single_output(x1, x2, w_r, w_i, b_r, b_i, ksize, pad, up):
     where the 1x1 weight row `tap` is the (flipped) transposed-conv kernel at that tap: a full-lane MFMA GEMM
     at SOURCE resolution plus an HBM-bound 9-load gather (elementwise.hip).  w_*: [Cin, 1, kh, kw]."""
     kh, kw = ksize
-    taps = kh * kw
-    ct = (taps + 7) // 8 * 8                                   # tap channels, padded for the MFMA N tile
-
-    def tap_rows(w):                                           # [Cin,1,kh,kw] -> [ct, Cin, 1, 1], correlation order
-        rows = w[:, 0].flip(1, 2).reshape(w.shape[0], taps).t()
-        return torch.nn.functional.pad(rows, (0, 0, 0, ct - taps)).reshape(ct, w.shape[0], 1, 1).contiguous()
-
-    z = cconv2d(x1, x2, tap_rows(w_r), tap_rows(w_i), None, None, False, (1, 1), (1, 1), (0, 0))
+    ct = (kh * kw + 7) // 8 * 8                                # tap channels, padded for the MFMA N tile
+    z = _TapRowsConvFn.apply(x1, x2, w_r, w_i, ct)
     # stride-1 transposed conv == correlation with padding k-1-p (already in `pad`)
     y = _TapSumFn.apply(z, (kh, kw), tuple(up), tuple(pad))
     if b_r is not None:

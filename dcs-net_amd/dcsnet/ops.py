@@ -135,6 +135,34 @@ def pack_conv_weight(w_r, w_i, b_r=None, b_i=None, transposed=False, up=(1, 1)):
     return wp, bias
 
 
+def pack_tap_rows(w_r, w_i, ct):
+    """conv_tran_r / conv_tran_i.weight [Cin,1,kh,kw] -> the 1x1 packed weight (wp [1,Cin,ct,2], zero bias [ct,2]) of the
+    tap-sum factorisation (dcs_pack_tap_rows)."""
+    _chk(w_r, 'w_r', 4)
+    _chk(w_i, 'w_i', 4)
+    Cin, one, kh, kw = w_r.shape
+    if one != 1 or ct < kh * kw:
+        raise _lib.DcsHipError(f'pack_tap_rows: expected [Cin,1,kh,kw] and ct >= kh*kw, got {tuple(w_r.shape)}, ct={ct}')
+    lib = _lib.load()
+    buf = torch.empty(lib.dcs_packed_weight_floats(ct, Cin, 1, 1, 1, 1), dtype=torch.float32, device=w_r.device)
+    wp = buf[:Cin * ct * 2].view(1, Cin, ct, 2)
+    bias = torch.empty((ct, 2), dtype=torch.float32, device=w_r.device)
+    check(lib.dcs_pack_tap_rows(ptr(w_r), ptr(w_i), ptr(wp), ptr(bias), Cin, kh, kw, ct, cur_stream()), 'dcs_pack_tap_rows')
+    return wp, bias
+
+
+def tap_rows_scatter(gt_r, gt_i, w_shape, outs=None):
+    """Weight gradient of the 1x1 tap conv [ct,Cin,1,1] -> gradient of conv_tran_r/_i.weight [Cin,1,kh,kw]; `outs`:
+    optional (g_r, g_i) destinations that are ADDED to (gradient sinks)."""
+    Cin, _, kh, kw = w_shape
+    acc = outs is not None and outs[0] is not None and outs[1] is not None
+    g_r = outs[0] if acc else torch.empty(w_shape, dtype=torch.float32, device=gt_r.device)
+    g_i = outs[1] if acc else torch.empty(w_shape, dtype=torch.float32, device=gt_r.device)
+    check(_lib.load().dcs_tap_rows_wgrad_scatter(ptr(gt_r), ptr(gt_i), ptr(g_r), ptr(g_i), Cin, kh, kw, int(acc),
+                                                 cur_stream()), 'dcs_tap_rows_wgrad_scatter')
+    return g_r, g_i
+
+
 def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=ACT_NONE):
     """Complex correlation over the virtual input upsample(cat(x1, x2)); see dcs_cconv2d_fwd."""
     _chk(x1, 'x1', 5)

@@ -365,6 +365,19 @@ int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* v
                           float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                           const int* step_dev, dcs_stream_t stream);
 
+/* Tap-sum factorisation of a ONE-output-channel stride-1 ComplexConvTranspose2d (the last decoder stage,
+ * c_network.py:135-141): y = tapsum(conv1x1(x: Cin -> ct "tap channels")) (dcs_tapsum_fwd).
+ * dcs_pack_tap_rows: the 1x1 weight from the reference's conv_tran_r / conv_tran_i.weight (float[Cin][1][kh][kw]):
+ *   wp = complex[1][Cin][ct] with column `tap` = the flipped kernel at that tap and zero columns kh*kw..ct-1 (+ its MFMA
+ *   panel behind it when Cin, ct are multiples of 8), bias_out = complex[ct] zeros.  Allocate
+ *   dcs_packed_weight_floats(ct, Cin, 1, 1, 1, 1) floats.
+ * dcs_tap_rows_wgrad_scatter: the adjoint on the weight gradient — gt_r/gt_i float[ct][Cin] (what
+ *   dcs_cconv2d_bwd_weight writes for the 1x1 conv) -> gw_r/gw_i float[Cin][1][kh][kw] (added to when accumulate). */
+int dcs_pack_tap_rows(const float* w_r, const float* w_i, float* wp, float* bias_out, int Cin, int kh, int kw, int ct,
+                      dcs_stream_t stream);
+int dcs_tap_rows_wgrad_scatter(const float* gt_r, const float* gt_i, float* gw_r, float* gw_i, int Cin, int kh, int kw,
+                               int accumulate, dcs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Pack plan: every weight re-layout of a training step in one launch per dependency level.
  * No reference counterpart (cuDNN reads the nn.Parameter layout, c_network.py:107-147); the packed panels
