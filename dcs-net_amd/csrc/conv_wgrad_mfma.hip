@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void wgrad_unfold_reduce_kernel(const float2* 
             for (int rx = 0; rx < up_t; ++rx) {
                 const int c = ry * up_t + rx;
                 const long off = (long)c * wsz_c + (long)(fold_index(up_f, ry, dy) * kw_c + fold_index(up_t, rx, dx)) * per + e;
-                for (int s = 0; s < n_slabs; ++s) {
+#pragma unroll 8
+                for (int s = 0; s < n_slabs; ++s) {                      // unrolled: the loads go out together
                     const float2 v = slab_w[(long)s * ncls * wsz_c + off];
                     sr += v.x; si += v.y;
                 }
