@@ -221,6 +221,124 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     }
 }
 
+// ---- N = 16 (Cout = 8) variant ---------------------------------------------------------------------------
+// A 16-column GEMM leaves half of every 32x32 MFMA tile empty (dec5 forward, the data gradient of enc1).  Here the
+// instruction is v_mfma_f32_16x16x4_f32: a wave owns 32 pixels x 16 columns as two 16x16 tiles, and one ds_read_b128
+// per lane (4 consecutive reals of its pixel, lane group g = lane/16 picks which 4 of the 16 reals of an 8-channel
+// block) feeds four MFMAs per tile; the B panel is packed to match (packjob::MFMA with N = 16: [tap][kg8][64 lanes][4]).
+// Same LDS patch, gather, classes and B ring as the 32-wide kernel; no split-K (these layers have plenty of pixels).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int CH>
+__global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
+    constexpr int U8 = CH / 8, PIX = 2 * CH + 4, Q = CH / 2;
+    const conv::Args& a = m.c;
+    const conv::Cls& k = m.cls[blockIdx.z];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int g4 = lane >> 4, li = lane & 15;
+
+    const int tiles_per_img = a.tiles_w * a.tiles_h;
+    const int b = blockIdx.x / tiles_per_img, tile_id = blockIdx.x % tiles_per_img;
+    const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
+    if (oy0 >= k.Hc || ox0 >= k.Wc) return;
+    const int vy0 = oy0 * a.sf - k.pad_f, vx0 = ox0 * a.st - k.pad_t;
+    const int Cin = a.C1 + a.C2;
+    const int ntaps = k.kh * k.kw;
+    const int cols = (m.TW - 1) * a.st + k.kw, rows = (m.TH - 1) * a.sf + k.kh;
+
+    int pixoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pi = wave * 32 + i * 16 + li;
+        pixoff[i] = (((pi / m.TW) * a.sf) * cols + (pi % m.TW) * a.st) * PIX + g4 * 4;
+    }
+    const float* bbase = m.bm + k.bm_off + (long)lane * 4;
+    const long b_tap_stride = (long)(Cin / 8) * 256, b_kg_stride = 256;
+
+    f32x4v acc[2];
+    acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int n_chunks = Cin / CH;
+    const int nslots = rows * cols * Q;
+
+    auto bload = [&](int c, int tp, int g) -> float4 {
+        if (tp >= ntaps) { tp = 0; ++c; }
+        c = c < n_chunks ? c : n_chunks - 1;
+        return *reinterpret_cast<const float4*>(bbase + tp * b_tap_stride + (long)(c * U8 + g) * b_kg_stride);
+    };
+    float4 bring[U8];
+#pragma unroll
+    for (int g = 0; g < U8; ++g) bring[g] = bload(0, 0, g);
+
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        __syncthreads();
+        constexpr int GU = 4;
+        for (int base = t; base < nslots; base += 256 * GU) {
+            float4 v[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int idx = base + u * 256;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < nslots) {
+                    const int q = idx % Q, px = idx / Q;
+                    const int ix = px % cols, iy = px / cols;
+                    long sp;
+                    if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
+                        const int c = ch * CH + 2 * q;
+                        const float2* src = (c < a.C1) ? a.x1 + sp * a.C1 + c : a.x2 + sp * a.C2 + (c - a.C1);
+                        v[u] = *reinterpret_cast<const float4*>(src);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int idx = base + u * 256;
+                if (idx < nslots) *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
+            }
+        }
+        __syncthreads();
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int tapoff = ((tap / k.kw) * cols + (tap % k.kw)) * PIX;
+#pragma unroll
+            for (int g = 0; g < U8; ++g) {
+                const float4 a0 = *reinterpret_cast<const float4*>(patch + pixoff[0] + tapoff + g * 16);
+                const float4 a1 = *reinterpret_cast<const float4*>(patch + pixoff[1] + tapoff + g * 16);
+                const float4 bv = bring[g];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                bring[g] = bload(ch, tap + 1, g);                      // same slot, next tap (U8 iterations ahead)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // C/D map of 16x16x4: col = lane & 15, rows (lane >> 4) * 4 + r
+    const float* biasf = reinterpret_cast<const float*>(a.bias);
+    const int n = li;
+    const float bv = biasf ? biasf[n] : 0.f;
+    const bool second = m.y2 != nullptr && n >= m.nsplit;
+    float* yf = second ? m.y2 : reinterpret_cast<float*>(a.y);
+    const int width = m.y2 == nullptr ? 16 : (second ? 16 - m.nsplit : m.nsplit);
+    const int col = second ? n - m.nsplit : n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pi = wave * 32 + i * 16 + g4 * 4 + r;
+            const int oy = oy0 + pi / m.TW, ox = ox0 + pi % m.TW;
+            if (oy < k.Hc && ox < k.Wc)
+                yf[(((long)b * a.Hout + oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] =
+                    dcs_act(acc[i][r] + bv, a.act);
+        }
+}
+
 // y[p][n] = act(sum_s part[s][p][n] + bias[n]); columns >= nsplit of a cat split go to y2.  One float4 per thread.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long slab_floats,
                                                             const float* __restrict__ bias, float* __restrict__ y,
@@ -265,6 +383,18 @@ int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
         case 16: return launch_ch<WAVES_N, WM, WN, 16>(m, npix, stream);
         default: return launch_ch<WAVES_N, WM, WN, 8>(m, npix, stream);
     }
+}
+
+template <int CH>
+int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
+    const conv::Args& a = m.c;
+    const size_t lds = (size_t)npix * (2 * CH + 4) * sizeof(float);
+    auto fn = cconv_mfma16_kernel<CH>;
+    if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
+    dim3 grid(a.tiles_w * a.tiles_h * a.B, 1, m.ncls);
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
 }
 
 struct Cand { int bm, bn; };
@@ -339,6 +469,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     else if (npix * 20 * 4 <= 150 * 1024) p->CH = 8;
     else return false;
     const int n_chunks = Cin / p->CH;
+    if (2 * a.Cout == 16) want_s = 1;                        // the 16-column kernel does not slice K
     int S = want_s < n_chunks ? want_s : n_chunks;
     if (S > 8) S = 8;
     if (S < 1) S = 1;
@@ -355,7 +486,12 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     packjob::Job j{};
     j.kind = packjob::MFMA;
     j.Cout = Cout; j.Cin = Cin; j.kh = taps;
-    j.total = (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 64;      // float4 elements
+    if (2 * Cout == 16) {                                                // 16-column layout of cconv_mfma16_kernel (half the region)
+        j.flag = 16;
+        j.total = (long)taps * (Cin / 8) * 64;
+    } else {
+        j.total = (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 64;  // float4 elements
+    }
     j.dst_bytes = j.total * (long)sizeof(float4);
     j.src0 = wp_direct; j.dst0 = bm;
     return packjob::emit(j, stream);
@@ -398,6 +534,13 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
     if (p.S > 1 && (!ws || ws_bytes < (long)p.S * m.slab_floats * (long)sizeof(float) || (m.N & 3) ||
                     (y2 != nullptr && (nsplit & 3)))) {
         m.ksplit = 1; m.cps = Cin / p.CH; m.part = nullptr;
+    }
+    if (m.N == 16 && p.cand == 3) {                           // 128 pixels x 16 columns, v_mfma_f32_16x16x4_f32
+        switch (p.CH) {
+            case 32: return launch16_ch<32>(m, npix, stream);
+            case 16: return launch16_ch<16>(m, npix, stream);
+            default: return launch16_ch<8>(m, npix, stream);
+        }
     }
     int rc;
     switch (p.cand) {

@@ -5,6 +5,7 @@
 // step has to re-derive them from the updated parameters; the plan turns that from ~200 serial 4-us launches
 // into one launch per dependency level.
 #include "pack_jobs.h"
+#include "conv_common.h"
 
 #include <mutex>
 #include <vector>
@@ -70,7 +71,23 @@ __device__ __forceinline__ void run_fold(const Job& j, long i) {
 }
 
 // bm[tap][kg][nt][kk][j][e]: e = 0..3 -> (ci = 4kg+2kk, re), (.., im), (ci+1, re), (ci+1, im); column n = nt*32+j
+// N = 16 (flag == 16): bm[tap][kg8][lane][q]: lane = g*16 + col, real k index r = 4g + q of the 8-channel block kg8
+// (ci = 8 kg8 + r/2, re|im = r&1), column col = (co = col>>1, re|im = col&1)
+__device__ __forceinline__ void run_mfma16(const Job& jb, long i) {
+    const float2* wp = (const float2*)jb.src0; float4* bm = (float4*)jb.dst0;
+    const int Cout = jb.Cout, Cin = jb.Cin;
+    const int col = (int)(i & 15), g = (int)((i >> 4) & 3);
+    const long r = i >> 6;
+    const int kg8 = (int)(r % (Cin / 8)), tap = (int)(r / (Cin / 8));
+    const int co = col >> 1, im = col & 1;
+    const int ci = 8 * kg8 + 2 * g;
+    const float2 w0 = wp[((long)tap * Cin + ci) * Cout + co], w1 = wp[((long)tap * Cin + ci + 1) * Cout + co];
+    // k = (ci, re): [w_r | w_i];  k = (ci, im): [-w_i | w_r]  for columns (co, re) | (co, im)
+    bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
+}
+
 __device__ __forceinline__ void run_mfma(const Job& jb, long i) {
+    if (jb.flag == 16) { run_mfma16(jb, i); return; }
     const float2* wp = (const float2*)jb.src0; float4* bm = (float4*)jb.dst0;
     const int Cout = jb.Cout, Cin = jb.Cin;
     const int KG = Cin / 4, NT = (2 * Cout + 31) / 32;
@@ -192,15 +209,8 @@ extern "C" int dcs_pack_tap_rows(const float* w_r, const float* w_i, float* wp, 
     j.src0 = w_r; j.src1 = w_i; j.dst0 = wp; j.dst1 = bias_out;
     const int rc = packjob::emit(j, dcs_stream(stream));
     if (rc != DCS_OK) return rc;
-    if ((Cin % 8) == 0 && (ct % 8) == 0) {                   // MFMA fragment panel behind the direct one (conv_mfma.hip)
-        packjob::Job m{};
-        m.kind = packjob::MFMA;
-        m.Cout = ct; m.Cin = Cin; m.kh = 1;
-        m.total = (long)(Cin / 4) * ((2 * ct + 31) / 32) * 64;
-        m.dst_bytes = m.total * (long)sizeof(float4);
-        m.src0 = wp; m.dst0 = wp + (long)Cin * ct * 2;
-        return packjob::emit(m, dcs_stream(stream));
-    }
+    if ((Cin % 8) == 0 && (ct % 8) == 0)                     // MFMA fragment panel behind the direct one (conv_mfma.hip)
+        return dcs_conv_mfma_pack(wp, wp + (long)Cin * ct * 2, ct, Cin, 1, dcs_stream(stream));
     return DCS_OK;
 }
 
