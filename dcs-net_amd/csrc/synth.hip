@@ -289,3 +289,76 @@ extern "C" int dcs_sisnr_bwd(const float* clean, const float* est, const float* 
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
+
+// ---- on-device STFT front end (data.py:104-134) ------------------------------------------------------------
+// The reference's DataLoader workers run torch.stft three times per item on the CPU (clean, noise = noisy - clean,
+// noisy).  Here a batch of cropped waveforms already on the device becomes the three [B][256][T] complex inputs of the
+// train step in three launches around one batched real FFT:
+//   stft_frames_kernel   frames[s][b][t][k] = w[k] * x_s[b][reflect(t*hop + k - n_fft/2)]  (torch.stft center=True,
+//                        pad_mode='reflect'); s = 0 clean, 1 noise = noisy - clean (subtracted in the time domain, as
+//                        data.py:104 does), 2 noisy
+//   (rocFFT r2c over the contiguous frames)
+//   stft_bins_kernel     out[s][b][f][t] = scale * spec[s][b][t][f + 1], f = 0..n_fft/2-1: drops the DC bin
+//                        (data.py:118: [1 : n_fft/2 + 1]), applies normalized = 1/sqrt(n_fft) and transposes to the
+//                        network's [B][F][T] layout through a 32x33 LDS tile.
+namespace {
+__global__ __launch_bounds__(kThreads) void stft_frames_kernel(const float* __restrict__ clean, const float* __restrict__ noisy,
+                                                                const float* __restrict__ w, float* __restrict__ frames,
+                                                                int B, int L, int T, int n_fft, int hop) {
+    const long per = (long)B * T * n_fft;
+    const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= per) return;
+    const int k = (int)(i % n_fft);
+    const long r = i / n_fft;
+    const int t = (int)(r % T), b = (int)(r / T);
+    int n = t * hop + k - n_fft / 2;
+    if (n < 0) n = -n;                                   // reflect without repeating the edge sample
+    if (n >= L) n = 2 * (L - 1) - n;
+    const float c = clean[(long)b * L + n], y = noisy[(long)b * L + n], wk = w[k];
+    frames[i] = wk * c;
+    frames[per + i] = wk * (y - c);
+    frames[2 * per + i] = wk * y;
+}
+
+// grid (ceil(T/32), ceil(F/32), n_signals * B); spec: complex[SB][T][F + 1]; out: complex[SB][F][T]
+__global__ __launch_bounds__(kThreads) void stft_bins_kernel(const float2* __restrict__ spec, float2* __restrict__ out, int F,
+                                                              int T, float scale) {
+    __shared__ float2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+    const long sb = blockIdx.z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r, f = f0 + tx;
+        float2 v = make_float2(0.f, 0.f);
+        if (t < T && f < F) v = spec[(sb * T + t) * (F + 1) + f + 1];
+        tile[tx][ty + 8 * r] = make_float2(v.x * scale, v.y * scale);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + ty + 8 * r, t = t0 + tx;
+        if (f < F && t < T) out[(sb * F + f) * T + t] = tile[ty + 8 * r][tx];
+    }
+}
+}  // namespace
+
+extern "C" int dcs_stft_frames_fwd(const float* clean, const float* noisy, const float* window, float* frames, int B, int L,
+                                   int T, int n_fft, int hop, dcs_stream_t stream) {
+    if (!clean || !noisy || !window || !frames || B <= 0 || L <= n_fft / 2 || T <= 0 || n_fft < 2 || (n_fft & 1) || hop <= 0 ||
+        (long)(T - 1) * hop > L)
+        return DCS_ERR_BADARG;
+    const long per = (long)B * T * n_fft;
+    hipLaunchKernelGGL(stft_frames_kernel, dim3((unsigned)((per + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       dcs_stream(stream), clean, noisy, window, frames, B, L, T, n_fft, hop);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_stft_bins_fwd(const float* spec, float* out, int SB, int T, int F, float scale, dcs_stream_t stream) {
+    if (!spec || !out || SB <= 0 || SB > 65535 || T <= 0 || F <= 0) return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(stft_bins_kernel, dim3((T + 31) / 32, (F + 31) / 32, SB), dim3(kThreads), 0, dcs_stream(stream),
+                       (const float2*)spec, (float2*)out, F, T, scale);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

@@ -59,6 +59,8 @@ SIGNATURES = {
     'dcs_istft_envelope': (_I, [_P, _P, _I, _I, _I, _P]),
     'dcs_istft_ola_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     'dcs_istft_ola_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    'dcs_stft_frames_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'dcs_stft_bins_fwd': (_I, [_P, _P, _I, _I, _I, _F, _P]),
     'dcs_sisnr_fwd': (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     'dcs_sisnr_bwd': (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _P]),
     'dcs_sisnr_losses_fwd': (_I, [_P, _P, _P, _I, _F, _P]),

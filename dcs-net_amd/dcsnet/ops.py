@@ -548,6 +548,30 @@ def istft_ola(frames, window, inv_env, hop, scale=1.0, grad=None):
     return gf
 
 
+def stft_frames(clean, noisy, window, T, hop):
+    """Windowed, reflect-padded frames of (clean, noisy - clean, noisy): float [3,B,T,n_fft] (dcs_stft_frames_fwd)."""
+    _chk(clean, 'clean', 2)
+    _chk(noisy, 'noisy', 2)
+    _chk(window, 'window', 1)
+    if clean.shape != noisy.shape:
+        raise _lib.DcsHipError(f'stft_frames: clean {tuple(clean.shape)} vs noisy {tuple(noisy.shape)}')
+    B, L = clean.shape
+    n_fft = window.numel()
+    frames = torch.empty((3, B, T, n_fft), dtype=torch.float32, device=clean.device)
+    check(_lib.load().dcs_stft_frames_fwd(ptr(clean), ptr(noisy), ptr(window), ptr(frames), B, L, T, n_fft, hop, cur_stream()),
+          'dcs_stft_frames_fwd')
+    return frames
+
+
+def stft_bins(spec, scale):
+    """spec float [S,B,T,F+1,2] (rfft of the frames) -> float [S,B,F,T,2]: DC bin dropped, scaled, transposed."""
+    _chk(spec, 'spec', 5)
+    S, B, T, F1, _ = spec.shape
+    out = torch.empty((S, B, F1 - 1, T, 2), dtype=torch.float32, device=spec.device)
+    check(_lib.load().dcs_stft_bins_fwd(ptr(spec), ptr(out), S * B, T, F1 - 1, float(scale), cur_stream()), 'dcs_stft_bins_fwd')
+    return out
+
+
 def sisnr(clean, est, eps=1e-8):
     """Per-utterance SiSNR [B] of float [B,L] signals and the [B,2] coefficients its backward reads."""
     _chk(clean, 'clean', 2)

@@ -349,6 +349,17 @@ int dcs_sisnr_bwd(const float* clean, const float* est, const float* coef, const
 int dcs_sisnr_losses_fwd(const float* snr_speech, const float* snr_noise, float* out3, int B, float alpha,
                          dcs_stream_t stream);
 
+/* On-device STFT front end (data.py:104-134: noise = noisy - clean, then torch.stft(n_fft, hop, hann, center=True,
+ * normalized)[1 : n_fft/2 + 1] of clean, noise, noisy on the DataLoader's CPU workers).
+ * dcs_stft_frames_fwd: frames float[3][B][T][n_fft] = window[k] * x_s[b][reflect(t hop + k - n_fft/2)], s = clean,
+ *   noise (= noisy - clean), noisy; clean / noisy float[B][L] cropped waveforms with (T-1) hop <= L.  The caller runs one
+ *   contiguous batched real FFT over the last axis (rocFFT), giving spec complex[3][B][T][n_fft/2 + 1].
+ * dcs_stft_bins_fwd: out complex[SB][F][T] = scale * spec[SB][T][f + 1], f < F = n_fft/2 (DC bin dropped, transposed to
+ *   the network's layout); scale = 1/sqrt(n_fft) for normalized=True. */
+int dcs_stft_frames_fwd(const float* clean, const float* noisy, const float* window, float* frames, int B, int L, int T,
+                        int n_fft, int hop, dcs_stream_t stream);
+int dcs_stft_bins_fwd(const float* spec, float* out, int SB, int T, int F, float scale, dcs_stream_t stream);
+
 /* cRM target mask (network_functions.py:62-75): M = S conj(Y) / (|Y|^2 + 1e-8). */
 int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs_stream_t stream);
 

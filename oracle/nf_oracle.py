@@ -142,3 +142,16 @@ def dcs_train_losses(net, noise, noisy, clean, speech_alpha=0.7, eps=ATAN2_EPS):
     noise_loss = 1 - speech_alpha * (-si_snr(noise_audio, n_hat_audio))
     speech_loss = speech_alpha * (-si_snr(clean_audio, s_hat_audio))
     return noise_loss, speech_loss, noise_loss + speech_loss
+
+
+def stft_frontend(clean_wave, noisy_wave, n_fft=512, hop=32, window=None, normalized=True):
+    """data.py:104-134 for a batch of cropped [B, L] waveforms: noise = noisy - clean in the time domain, then
+    torch.stft (center=True, reflect padding) of clean, noise and noisy, keeping bins 1..n_fft/2.
+    Returns (noise, noisy, clean) complex64 [B, n_fft/2, T] — the order of the reference's batches."""
+    window = torch.hann_window(n_fft) if window is None else window
+
+    def one(x):
+        return torch.stft(x, n_fft=n_fft, hop_length=hop, win_length=n_fft, window=window, return_complex=True,
+                          normalized=normalized)[:, 1:n_fft // 2 + 1, :]
+    noise_wave = noisy_wave - clean_wave
+    return one(noise_wave), one(noisy_wave), one(clean_wave)

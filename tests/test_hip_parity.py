@@ -331,3 +331,21 @@ def test_ops_fail_loudly_on_cpu_tensors():
     from dcsnet import ops, DcsHipError
     with pytest.raises(DcsHipError):
         ops.bound_crm(torch.zeros(4, 2))
+
+
+def test_device_stft_front_end_matches_the_loader_side_stft(dev):
+    """dcsnet.frontend.stft_batch (HIP framing + rocFFT + HIP bin slice / transpose) vs the three torch.stft calls of
+    the reference's Dataset (data.py:104-134, restated in oracle.nf_oracle.stft_frontend)."""
+    from dcsnet.frontend import stft_batch
+    from dcsnet.config import config
+    g = torch.Generator().manual_seed(3)
+    for B, T in ((3, 16), (2, 256)):
+        L = 32 * (T - 1)
+        clean = 0.1 * torch.randn(B, L, generator=g)
+        noisy = clean + 0.05 * torch.randn(B, L, generator=g)
+        want = nf.stft_frontend(clean, noisy)
+        got = stft_batch(clean.to(dev), noisy.to(dev), config)
+        for name, a, b in zip(('noise', 'noisy', 'clean'), got, want):
+            assert a.shape == b.shape == (B, 256, T) and a.is_contiguous(), name
+            err = float((a.cpu() - b).abs().max())
+            assert err <= 1e-5 * float(b.abs().max()) + 1e-7, (name, T, err)

@@ -133,3 +133,20 @@ def test_dropin_names_resolve():
         for m in ('c_network', 'network_functions', 'config', 'complexPyTorch', 'complexPyTorch.complexLayers',
                   'complexPyTorch.complexFunctions'):
             sys.modules.pop(m, None)
+
+
+def test_crop_batch_follows_the_dataset_rule():
+    """dcsnet.frontend.crop_batch = data.py:87-104 per item: equal lengths enforced, short items zero-padded, otherwise
+    one random window shared by the clean and the noisy signal."""
+    from dcsnet.frontend import crop_batch
+    g = torch.Generator().manual_seed(0)
+    clean = [torch.arange(100.), torch.arange(40.), torch.arange(64.)]
+    noisy = [c + 1000 for c in clean]
+    c, n = crop_batch(clean, noisy, 64, generator=g)
+    assert c.shape == n.shape == (3, 64)
+    assert torch.equal(n[0] - c[0], torch.full((64,), 1000.)) and float(c[0][1] - c[0][0]) == 1.0
+    assert 0 <= float(c[0][0]) < 36
+    assert torch.equal(c[1][:40], torch.arange(40.)) and float(c[1][40:].abs().sum()) == 0 and float(n[1][40:].abs().sum()) == 0
+    assert torch.equal(c[2], torch.arange(64.))
+    with pytest.raises(Exception):
+        crop_batch([torch.zeros(10)], [torch.zeros(11)], 8)
