@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* = 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (same guide; AMD's headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -169,6 +170,9 @@ def main():
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a hipGraph')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='operand precision of the MFMA conv forward / data gradient (bf16 = BASELINE configs[4] mixed '
+                         'precision; NOT the headline: the reference computes in fp32)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -187,6 +191,7 @@ def main():
     from dcsnet.c_network import C_NETWORK
     from dcsnet import functional as F
     _lib.load()
+    ops.set_conv_precision(args.dtype)
 
     def log(msg):
         if rank == 0:
@@ -276,13 +281,16 @@ def main():
     if rank == 0:
         frames = B * T * world * args.steps
         conv_ms, n_launch = timer.summary()
+        # dense MFMA peak of the operand type (bf16 mode: forward / data gradient on bf16 MFMA, weight gradients still fp32)
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         achieved = timer.flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         line = {
             'metric': ('STFT frames/sec (train fwd+bwd+Adam)' if train else
                        'STFT frames/sec (forward-only inference: C_NETWORK forward + bound/mask-apply/subtract)'),
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if args.dtype == 'f32' else 'bf16 conv operands (forward + data gradient), f32 accumulate / weight gradients / storage',
+            'data': 'synthetic',
             'config': {'workload': ('BASELINE configs[2]/[3]: DCS-Net full train step (fwd + SiSNR losses + bwd + grad '
                                     'all-reduce + clip 100 + Adam/AMSGrad), complex64 [32,256,256] x (noise, noisy, clean) '
                                     'per GPU, dropout 0.1/0.2, batch-statistics CBN, random-init weights seed 0'
@@ -292,8 +300,8 @@ def main():
                        'per_gpu_batch': B, 'frames_per_utterance': T, 'global_batch': B * world,
                        'frames_per_step': B * T * world, 'hip_graph': bool(graphed), 'parallelism': (f'dp{world} (utterance sharding, one flat-bucket gradient all-reduce)' if train
                                        else f'dp{world} (utterance sharding, no collective)')},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(args.mode, B, T),
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': pmc_traffic(args.mode, B, T),
                          'kernel': 'complex conv / convT (dcs_cconv2d_fwd' + (', _bwd_data, _bwd_weight' if train else '')
                                    + '), all launches of the timed region',
                          'launches': n_launch, 'kernel_ms_per_step': conv_ms / args.steps,

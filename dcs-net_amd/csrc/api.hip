@@ -29,3 +29,15 @@ hipError_t dcs_ensure_dynamic_lds(const void* fn, size_t bytes) {
     if (e == hipSuccess && n < 64) { table[n].fn = fn; table[n].bytes = bytes; ++n; }
     return e;
 }
+
+namespace { int g_conv_precision = 0; }
+
+int dcs_conv_precision() { return g_conv_precision; }
+
+extern "C" int dcs_set_conv_precision(int mode) {
+    if (mode != 0 && mode != 1) return DCS_ERR_BADARG;
+    g_conv_precision = mode;
+    return DCS_OK;
+}
+
+extern "C" int dcs_get_conv_precision(void) { return g_conv_precision; }

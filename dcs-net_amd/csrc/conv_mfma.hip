@@ -25,6 +25,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 
 struct MArgs {
@@ -50,10 +51,14 @@ struct MArgs {
 //   B fragments  ring of R = min(U,4) slots, each refilled right after use with the fragment R iterations ahead
 //                (across tap and chunk boundaries; a short-tile iteration is ~256 cycles < one L2 round trip)
 //   A fragments  two register sets alternating by k-group parity, loaded one iteration ahead
-template <int WAVES_N, int WM, int WN, int CH>
+// BF = true: bf16 operands, fp32 accumulate (dcs_set_conv_precision(1); BASELINE configs[4]).  The gather rounds the
+// activations to bf16 on their way into LDS (half the patch), the B panel holds bf16 fragments, and one
+// v_mfma_f32_32x32x16_bf16 covers what eight fp32 MFMAs cover (8 complex channels of one tap).  Measured in float
+// units the fragment addresses are the same as in the fp32 form: a 16-byte read per lane either way.
+template <int WAVES_N, int WM, int WN, int CH, bool BF>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
-    constexpr int U = CH / 4, R = U < 4 ? U : 4, PIX = 2 * CH + 4, Q = CH / 2;
+    constexpr int U = BF ? CH / 8 : CH / 4, R = U < 4 ? U : 4, PIX = BF ? CH + 4 : 2 * CH + 4, Q = CH / 2;
     const conv::Args& a = m.c;
     const conv::Cls& k = m.cls[blockIdx.z];
     // pixels per workgroup = (4 / WAVES_N) * WM * 32 = TH * TW
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         pixoff[i] = (((pi / m.TW) * a.sf) * cols + (pi % m.TW) * a.st) * PIX + kk * 4;
     }
     const float* bbase = m.bm + k.bm_off + ((long)nt0 * 64 + lane) * 4;
-    const long b_tap_stride = (long)m.KG * m.NT * 256, b_kg_stride = (long)m.NT * 256;
+    const long b_tap_stride = (long)(BF ? m.KG / 2 : m.KG) * m.NT * 256, b_kg_stride = (long)m.NT * 256;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -133,7 +138,14 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int idx = base + u * 256;
-                if (idx < nslots) *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
+                if (idx >= nslots) continue;
+                if (BF) {                                              // 2 complex -> 4 bf16 (round to nearest even)
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    const bf16x4 h = {(__bf16)v[u].x, (__bf16)v[u].y, (__bf16)v[u].z, (__bf16)v[u].w};
+                    *reinterpret_cast<bf16x4*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = h;
+                } else {
+                    *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
+                }
             }
         }
         __syncthreads();
@@ -157,10 +169,15 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
                         const float4 av = af[g & 1][i], bv = bring[g % R][j];
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+                        if (BF) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                                __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
+                        }
                     }
                 // ... which is then refilled with the fragment R iterations ahead (no register copy in between).  The
                 // scheduling barriers pin the load HERE: left alone, the machine scheduler sinks it to just before its
@@ -169,6 +186,10 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 if (g + R < U) bload(bring[g % R], ch, tap, g + R);
                 else bload(bring[g % R], ch, tap + 1, g + R - U);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (U & 1) {                                               // odd U (bf16, CH = 8): the prefetch landed in set 1
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[0][i] = af[1][i];
             }
             tapoff = tapoff2;
         }
@@ -363,17 +384,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 struct Plan { int cand, TH, TW, CH, S, cps; long blocks; };
 
-template <int WAVES_N, int WM, int WN, int CH>
-int launch_ch(MArgs& m, long npix, hipStream_t stream) {
+template <int WAVES_N, int WM, int WN, int CH, bool BF>
+int launch_bf(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    const size_t lds = (size_t)npix * (2 * CH + 4) * sizeof(float);
-    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH>;
+    const size_t lds = (size_t)npix * (BF ? CH + 4 : 2 * CH + 4) * sizeof(float);
+    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, BF>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+template <int WAVES_N, int WM, int WN, int CH>
+int launch_ch(MArgs& m, long npix, hipStream_t stream) {
+    return dcs_conv_precision() == 1 ? launch_bf<WAVES_N, WM, WN, CH, true>(m, npix, stream)
+                                     : launch_bf<WAVES_N, WM, WN, CH, false>(m, npix, stream);
 }
 
 template <int WAVES_N, int WM, int WN>
@@ -489,6 +516,9 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     if (2 * Cout == 16) {                                                // 16-column layout of cconv_mfma16_kernel (half the region)
         j.flag = 16;
         j.total = (long)taps * (Cin / 8) * 64;
+    } else if (dcs_conv_precision() == 1) {                              // bf16 fragments: [tap][kg8][nt][64 lanes][8 bf16]
+        j.flag = 2;
+        j.total = (long)taps * (Cin / 8) * ((2 * Cout + 31) / 32) * 64;
     } else {
         j.total = (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 64;  // float4 elements
     }

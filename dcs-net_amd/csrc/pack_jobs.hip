@@ -86,8 +86,34 @@ __device__ __forceinline__ void run_mfma16(const Job& jb, long i) {
     bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
 }
 
+// bf16 (flag == 2): bm[tap][kg8][nt][lane][8 bf16]: lane = 32h + j, element e = real k index 8h + e of the 8-channel block
+// (ci = 8 kg8 + 4h + e/2, re|im = e&1), column n = nt*32 + j — the A/B lane map of v_mfma_f32_32x32x16_bf16
+__device__ __forceinline__ void run_mfma_bf16(const Job& jb, long i) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const float2* wp = (const float2*)jb.src0; bf16x8* bm = (bf16x8*)jb.dst0;
+    const int Cout = jb.Cout, Cin = jb.Cin;
+    const int KG8 = Cin / 8, NT = (2 * Cout + 31) / 32;
+    const int j = (int)(i & 31), h = (int)((i >> 5) & 1);
+    long r = i >> 6;
+    const int nt = (int)(r % NT); r /= NT;
+    const int kg8 = (int)(r % KG8);
+    const int tap = (int)(r / KG8);
+    const int n = nt * 32 + j, co = n >> 1, im = n & 1;
+    bf16x8 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float2 w = make_float2(0.f, 0.f);
+        if (co < Cout) w = wp[((long)tap * Cin + 8 * kg8 + 4 * h + q) * Cout + co];
+        // column (co, re): [ w_r, -w_i ] ; column (co, im): [ w_i, w_r ]   for k = (ci, re), (ci, im)
+        o[2 * q] = (__bf16)(im ? w.y : w.x);
+        o[2 * q + 1] = (__bf16)(im ? w.x : -w.y);
+    }
+    bm[i] = o;
+}
+
 __device__ __forceinline__ void run_mfma(const Job& jb, long i) {
     if (jb.flag == 16) { run_mfma16(jb, i); return; }
+    if (jb.flag == 2) { run_mfma_bf16(jb, i); return; }
     const float2* wp = (const float2*)jb.src0; float4* bm = (float4*)jb.dst0;
     const int Cout = jb.Cout, Cin = jb.Cin;
     const int KG = Cin / 4, NT = (2 * Cout + 31) / 32;

@@ -68,6 +68,8 @@ SIGNATURES = {
     'dcs_adam_amsgrad_step': (_I, [_P] * 6 + [_F, _F, _L, _F, _F, _F, _F, _F, _I, _P, _P]),
     'dcs_pack_tap_rows': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dcs_tap_rows_wgrad_scatter': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'dcs_set_conv_precision': (_I, [_I]),
+    'dcs_get_conv_precision': (_I, []),
     'dcs_pack_plan_begin': (_I, []),
     'dcs_pack_plan_end': (_I, [_P]),
     'dcs_pack_plan_jobs': (_I, [_P, _P, _P]),

@@ -34,6 +34,21 @@ SEED_STATE = None
 _workspaces = {}
 
 
+def set_conv_precision(mode):
+    """'f32' (default: exact fp32 MFMA) or 'bf16' (bf16 operands, fp32 accumulate, in the MFMA conv forward / data
+    gradient: dcs_set_conv_precision).  Every packed weight made under the other mode becomes invalid: the caches
+    are cleared here, a recorded pack plan must be re-recorded by its owner."""
+    code = {'f32': 0, 'fp32': 0, 'bf16': 1}[mode]
+    check(_lib.load().dcs_set_conv_precision(code), 'dcs_set_conv_precision')
+    from . import functional
+    functional._pack_cache.clear()
+    pack_plan_drop()
+
+
+def conv_precision():
+    return 'bf16' if _lib.load().dcs_get_conv_precision() == 1 else 'f32'
+
+
 class PackPlan:
     """Python side of a dcs_pack_plan: owns the destination tensors the plan re-packs in place and serves
     them to packed-weight lookups while `valid` (= dcs_pack_plan_run has run since the last parameter

@@ -389,6 +389,14 @@ int dcs_pack_tap_rows(const float* w_r, const float* w_i, float* wp, float* bias
 int dcs_tap_rows_wgrad_scatter(const float* gt_r, const float* gt_i, float* gw_r, float* gw_i, int Cin, int kh, int kw,
                                int accumulate, dcs_stream_t stream);
 
+/* Operand precision of the MFMA convolution GEMMs (forward and data gradient; BASELINE configs[4] "bf16 mixed
+ * precision"): 0 = fp32 operands (default, exact fp32), 1 = bf16 operands (activations rounded to nearest-even on
+ * their way into LDS, weights rounded at pack time), fp32 accumulate, fp32 storage everywhere.  Weight gradients,
+ * the 16-column and the small-channel kernels stay fp32.  Process-wide; weights packed under one mode are only valid
+ * under that mode (the caller re-packs after switching). */
+int dcs_set_conv_precision(int mode);
+int dcs_get_conv_precision(void);
+
 /* ------------------------------------------------------------------------------------
  * Pack plan: every weight re-layout of a training step in one launch per dependency level.
  * No reference counterpart (cuDNN reads the nn.Parameter layout, c_network.py:107-147); the packed panels

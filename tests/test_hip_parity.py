@@ -349,3 +349,89 @@ def test_device_stft_front_end_matches_the_loader_side_stft(dev):
             assert a.shape == b.shape == (B, 256, T) and a.is_contiguous(), name
             err = float((a.cpu() - b).abs().max())
             assert err <= 1e-5 * float(b.abs().max()) + 1e-7, (name, T, err)
+
+
+def _bias_before_bn(name):
+    """conv biases directly in front of a batch-statistics CBN have analytically zero gradients (noise only)"""
+    import re
+    return bool(re.match(r'(encoder\.\d+\.0|decoder\.[0-5]\.0)\..*bias$', name))
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def test_bf16_operand_mode_of_the_mfma_conv(dev):
+    """dcs_set_conv_precision(1): bf16 operands, fp32 accumulate (BASELINE configs[4]).  Against the fp32 oracle run on
+    bf16-ROUNDED inputs and weights the kernel must agree to fp32 accumulation order (the products of two bf16 numbers
+    are exact in fp32); against the unrounded oracle it is a bf16 computation: 2e-2 of the output's max-abs."""
+    from dcsnet import functional as F, ops
+    torch.manual_seed(11)
+    m = cpt.ComplexConv2d(32, 64, 3, (2, 1), 1)
+    x = rand_c((2, 32, 12, 20), 5)
+    mr = cpt.ComplexConv2d(32, 64, 3, (2, 1), 1)
+    with torch.no_grad():
+        for a, b in zip(mr.parameters(), m.parameters()):
+            a.copy_(_bf16_round(b) if b.dim() == 4 else b)                 # biases stay fp32 (added in the epilogue)
+        want_exact = mr(torch.complex(_bf16_round(x.real), _bf16_round(x.imag)))
+        want_f32 = m(x)
+    p = {n: q.detach().to(dev) for n, q in m.named_parameters()}
+    xn = ops.to_nhwc(x.to(dev))
+    assert ops.conv_precision() == 'f32'
+    try:
+        ops.set_conv_precision('bf16')
+        assert ops.conv_precision() == 'bf16'
+        y = F.from_nhwc(F.cconv2d(xn, None, p['conv_r.weight'], p['conv_i.weight'], p['conv_r.bias'], p['conv_i.bias'],
+                                  False, (3, 3), (2, 1), (1, 1))).cpu()
+    finally:
+        ops.set_conv_precision('f32')
+    scale = float(want_f32.abs().max())
+    assert float((y - want_exact).abs().max()) <= 2e-5 * scale
+    err = float((y - want_f32).abs().max())
+    assert 1e-6 * scale < err <= 2e-2 * scale          # genuinely a bf16 computation, within bf16 tolerance
+
+
+def test_bf16_mode_whole_network_and_gradients(dev):
+    """The whole network in bf16-operand mode (folded / strided class kernels, split-K, data gradients) against the fp32
+    oracle, as relative L2 error: train-mode mask 2e-2; gradients of all parameters together 3e-2, taken with running
+    statistics (eval) — through BATCH statistics of a 2-utterance, 32-frame batch the same 2^-8 operand rounding is
+    amplified to ~1e-1 (6e-2 at B=8, T=64: tools/bf16_grad_probe.py), which measures the batch, not the kernels."""
+    from dcsnet import ops
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    x = seeded_input(2, 256, 32, seed=4)
+    w = None
+
+    def rel_l2(a, b):
+        return float((a - b).abs().pow(2).sum().sqrt()) / (float(b.abs().pow(2).sum().sqrt()) + 1e-20)
+
+    def loss_of(out, w_):
+        return (w_ * (out.real ** 2 + 0.5 * out.imag ** 2)).sum()
+
+    with torch.no_grad():                                  # (its own instance: a train-mode forward moves the running stats)
+        mask_train = fill_state(cno.C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), 6).train()(x)
+    ref = fill_state(cno.C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), 6).eval()
+    out_r = ref(x)
+    w = torch.rand(out_r.shape, generator=torch.Generator().manual_seed(2))
+    loss_of(out_r, w).backward()
+    try:
+        ops.set_conv_precision('bf16')
+        net = fill_state(C_NETWORK(config, hp, 0), 6).to(dev)
+        net.train()
+        with torch.no_grad():
+            got_train = net(x.to(dev)).cpu()
+        net = fill_state(C_NETWORK(config, hp, 0), 6).to(dev).eval()
+        out = net(x.to(dev))
+        loss_of(out, w.to(dev)).backward()
+        grads = {n: p.grad.detach().cpu() for n, p in net.named_parameters() if p.grad is not None}
+    finally:
+        ops.set_conv_precision('f32')
+    e_mask = rel_l2(got_train, mask_train)
+    pr = dict(ref.named_parameters())
+    num = sum(float((g - pr[n].grad).pow(2).sum()) for n, g in grads.items()) ** 0.5
+    e_all = num / sum(float(pr[n].grad.pow(2).sum()) for n in grads) ** 0.5
+    print(f'bf16 mode: train-mode mask rel-L2 {e_mask:.3e}; eval-mode gradients rel-L2 {e_all:.3e}')
+    assert 1e-4 < e_mask <= 2e-2, e_mask
+    assert e_all <= 3e-2, e_all
