@@ -19,6 +19,7 @@
 //          layout (conv_r / conv_i or conv_tran_r / conv_tran_i, and the two biases).
 #include "conv_common.h"
 #include "pack_jobs.h"
+#include "wgrad_reduce.h"
 
 namespace {
 
@@ -198,54 +199,13 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
     if (ci0 == 0 && t < WG_CO && co0 + t < a.Cout) w.slab_b[(long)blockIdx.x * a.Cout + co0 + t] = make_float2(br, bi);
 }
 
-// sum the slabs and scatter into the reference's parameter layout.  256 threads = 32 elements x 8
-// slab groups (coalesced 256-B rows per slab, 8 slabs in flight), LDS combine.
-__global__ __launch_bounds__(256) void cconv_wgrad_reduce_kernel(const float2* __restrict__ slab_w,
-                                                                  const float2* __restrict__ slab_b, int n_slabs,
-                                                                  float* __restrict__ gw_r, float* __restrict__ gw_i,
-                                                                  float* __restrict__ gb_r, float* __restrict__ gb_i,
-                                                                  int Cout, int Cin, int kh, int kw, int transposed) {
-    __shared__ float2 red[256];
-    const long n = (long)kh * kw * Cin * Cout;
-    const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    const long i = (long)blockIdx.x * 32 + e;
-    const long nb = (n + 31) / 32;                          // workgroups [0, nb): weights; [nb, ..): bias
-    const bool is_bias = blockIdx.x >= nb;
-    const long j = is_bias ? (long)(blockIdx.x - nb) * 32 + e : i;
-    const long lim = is_bias ? Cout : n;
-    const float2* src = is_bias ? slab_b : slab_w;
-    float sr = 0.f, si = 0.f;
-    if (j < lim)
-        for (int s = sg; s < n_slabs; s += 8) { const float2 v = src[(long)s * lim + j]; sr += v.x; si += v.y; }
-    red[threadIdx.x] = make_float2(sr, si);
-    __syncthreads();
-    if (sg != 0 || j >= lim) return;
-#pragma unroll
-    for (int g = 1; g < 8; ++g) { const float2 v = red[g * 32 + e]; sr += v.x; si += v.y; }
-    if (is_bias) {
-        gb_r[j] = sr + si;          // bias = (b_r - b_i) + j (b_r + b_i)
-        gb_i[j] = si - sr;
-        return;
-    }
-    const int co = (int)(j % Cout);
-    const int ci = (int)((j / Cout) % Cin);
-    const int tap = (int)(j / ((long)Cout * Cin));
-    const int dy = tap / kw, dx = tap % kw;
-    long dst;
-    if (transposed) dst = (((long)ci * Cout + co) * kh + (kh - 1 - dy)) * kw + (kw - 1 - dx);
-    else            dst = (((long)co * Cin + ci) * kh + dy) * kw + dx;
-    gw_r[dst] = sr;
-    gw_i[dst] = si;
-}
-
+// sum the slabs and scatter into the reference's parameter layout (wgrad_reduce.hip: immediate, or deferred + batched)
 int launch_wgrad_reduce(const float2* slab_w, const float2* slab_b, int n_slabs, float* gw_r, float* gw_i, float* gb_r,
                         float* gb_i, int Cout, int Cin, int kh, int kw, int transposed, hipStream_t s) {
-    const long n = (long)kh * kw * Cin * Cout;
-    const long nb = (n + 31) / 32, nbb = gb_r ? (Cout + 31) / 32 : 0;
-    hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3((unsigned)(nb + nbb)), dim3(256), 0, s, slab_w, slab_b, n_slabs,
-                       gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed);
-    DCS_CHECK_LAUNCH();
-    return DCS_OK;
+    wreduce::Job j{};
+    j.slab_w = slab_w; j.slab_b = slab_b; j.gw_r = gw_r; j.gw_i = gw_i; j.gb_r = gb_r; j.gb_i = gb_i;
+    j.n_slabs = n_slabs; j.Cout = Cout; j.Cin = Cin; j.kh = kh; j.kw = kw; j.transposed = transposed;
+    return wreduce::emit(j, s);
 }
 
 // ---- packers ------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 //   * workgroups stride over pixel tiles; one partial slab per workgroup row, reduced without atomics by
 //     cconv_wgrad_reduce_kernel (conv_direct.hip), which also writes the reference's parameter layout.
 #include "conv_common.h"
+#include "wgrad_reduce.h"
 #include <cstdlib>
 
 namespace {
@@ -333,53 +334,6 @@ conv::Args class_args(const conv::Args& a, const Fold& f) {
     return c;
 }
 
-// destination tap index on one axis: which folded tap of residue class r contains original tap d
-__device__ __forceinline__ int fold_index(int up, int r, int d) {
-    if (up == 1) return d;
-    return r == 0 ? (d == 0 ? 0 : 1) : (d == 2 ? 1 : 0);
-}
-
-// slab_w: float2[n_slabs][ncls][kh_c*kw_c][Cin][Cout]; slab_b: float2[n_slabs][ncls][Cout].  One thread per element of
-// the 3x3 gradient (then per bias element), summing slabs in a fixed order: bitwise reproducible.
-__global__ __launch_bounds__(256) void wgrad_unfold_reduce_kernel(const float2* __restrict__ slab_w,
-                                                                   const float2* __restrict__ slab_b, int n_slabs,
-                                                                   int up_f, int up_t, float* __restrict__ gw_r,
-                                                                   float* __restrict__ gw_i, float* __restrict__ gb_r,
-                                                                   float* __restrict__ gb_i, int Cout, int Cin,
-                                                                   int transposed) {
-    const int kh_c = up_f == 2 ? 2 : 3, kw_c = up_t == 2 ? 2 : 3, ncls = up_f * up_t;
-    const long per = (long)Cin * Cout, n = 9 * per, wsz_c = (long)kh_c * kw_c * per;
-    const long j = (long)blockIdx.x * 256 + threadIdx.x;
-    if (j < n) {
-        const int tap = (int)(j / per);
-        const long e = j % per;
-        const int dy = tap / 3, dx = tap % 3;
-        float sr = 0.f, si = 0.f;
-        for (int ry = 0; ry < up_f; ++ry)
-            for (int rx = 0; rx < up_t; ++rx) {
-                const int c = ry * up_t + rx;
-                const long off = (long)c * wsz_c + (long)(fold_index(up_f, ry, dy) * kw_c + fold_index(up_t, rx, dx)) * per + e;
-#pragma unroll 8
-                for (int s = 0; s < n_slabs; ++s) {                      // unrolled: the loads go out together
-                    const float2 v = slab_w[(long)s * ncls * wsz_c + off];
-                    sr += v.x; si += v.y;
-                }
-            }
-        const int co = (int)(e % Cout), ci = (int)(e / Cout);
-        long dst;
-        if (transposed) dst = (((long)ci * Cout + co) * 3 + (2 - dy)) * 3 + (2 - dx);
-        else            dst = (((long)co * Cin + ci) * 3 + dy) * 3 + dx;
-        gw_r[dst] = sr;
-        gw_i[dst] = si;
-    } else if (gb_r != nullptr && j < n + Cout) {
-        const int co = (int)(j - n);
-        float sr = 0.f, si = 0.f;
-        for (int s = 0; s < n_slabs * ncls; ++s) { const float2 v = slab_b[(long)s * Cout + co]; sr += v.x; si += v.y; }
-        gb_r[co] = sr + si;          // bias = (b_r - b_i) + j (b_r + b_i)
-        gb_i[co] = si - sr;
-    }
-}
-
 // slabs per class for a class-space geometry `c` (tiling filled in), ncls classes
 int slabs_for(const conv::Args& c, int ncls, int TH, int TW) {
     const long tiles = (long)((c.Wout + TW - 1) / TW) * ((c.Hout + TH - 1) / TH) * c.B;
@@ -494,9 +448,10 @@ int dcs_conv_wgrad_fold_run(const conv::Args& a, const float* gy, void* workspac
     float2* slab_b = slab_w + (long)ns * f.ncls * wsz_c;
     const int rc = launch_classes(c, f, a.Hout, a.Wout, gy, slab_w, (float*)slab_b, ns, TH, TW, stream);
     if (rc != DCS_OK) return rc;
-    const long n = 9L * Cin * a.Cout + (gb_r ? a.Cout : 0);
-    hipLaunchKernelGGL(wgrad_unfold_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slab_w, slab_b, ns,
-                       a.up_f, a.up_t, gw_r, gw_i, gb_r, gb_i, a.Cout, Cin, transposed);
-    DCS_CHECK_LAUNCH();
+    wreduce::Job j{};                                     // class gradients -> 3x3 parameter (wgrad_reduce.hip)
+    j.slab_w = slab_w; j.slab_b = slab_b; j.gw_r = gw_r; j.gw_i = gw_i; j.gb_r = gb_r; j.gb_i = gb_i;
+    j.n_slabs = ns; j.Cout = a.Cout; j.Cin = Cin; j.kh = 3; j.kw = 3; j.transposed = transposed;
+    j.up_f = a.up_f; j.up_t = a.up_t;
+    return wreduce::emit(j, stream);
     return DCS_OK;
 }

@@ -1,0 +1,165 @@
+// wgrad_reduce.hip — slab reductions of the weight-gradient kernels: single launch, or deferred and batched.
+#include "wgrad_reduce.h"
+
+#include <mutex>
+#include <vector>
+
+namespace wreduce {
+namespace {
+
+// plain slabs: 256 threads = 32 elements x 8 slab groups (coalesced 256-B rows per slab, 8 slabs in flight), LDS combine
+__device__ __forceinline__ void reduce_plain(const Job& q, int bid, float2* red) {
+    const long n = (long)q.kh * q.kw * q.Cin * q.Cout;
+    const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const long nb = (n + 31) / 32;                          // blocks [0, nb): weights; [nb, ..): bias
+    const bool is_bias = bid >= nb;
+    const long j = is_bias ? (long)(bid - nb) * 32 + e : (long)bid * 32 + e;
+    const long lim = is_bias ? q.Cout : n;
+    const float2* src = is_bias ? q.slab_b : q.slab_w;
+    float sr = 0.f, si = 0.f;
+    if (j < lim)
+        for (int s = sg; s < q.n_slabs; s += 8) { const float2 v = src[(long)s * lim + j]; sr += v.x; si += v.y; }
+    red[threadIdx.x] = make_float2(sr, si);
+    __syncthreads();
+    if (sg != 0 || j >= lim) return;
+#pragma unroll
+    for (int g = 1; g < 8; ++g) { const float2 v = red[g * 32 + e]; sr += v.x; si += v.y; }
+    if (is_bias) {
+        q.gb_r[j] = sr + si;          // bias = (b_r - b_i) + j (b_r + b_i)
+        q.gb_i[j] = si - sr;
+        return;
+    }
+    const int co = (int)(j % q.Cout);
+    const int ci = (int)((j / q.Cout) % q.Cin);
+    const int tap = (int)(j / ((long)q.Cout * q.Cin));
+    const int dy = tap / q.kw, dx = tap % q.kw;
+    long dst;
+    if (q.transposed) dst = (((long)ci * q.Cout + co) * q.kh + (q.kh - 1 - dy)) * q.kw + (q.kw - 1 - dx);
+    else              dst = (((long)co * q.Cin + ci) * q.kh + dy) * q.kw + dx;
+    q.gw_r[dst] = sr;
+    q.gw_i[dst] = si;
+}
+
+// destination tap index on one axis: which folded tap of residue class r contains original tap d
+__device__ __forceinline__ int fold_index(int up, int r, int d) {
+    if (up == 1) return d;
+    return r == 0 ? (d == 0 ? 0 : 1) : (d == 2 ? 1 : 0);
+}
+
+// folded slabs -> 3x3 gradient: g_W[dy][dx] = sum over classes of g_Wfold_c[jy_c(dy)][jx_c(dx)]; one thread per element
+__device__ __forceinline__ void reduce_folded(const Job& q, int bid) {
+    const int up_f = q.up_f, up_t = q.up_t;
+    const int kh_c = up_f == 2 ? 2 : 3, kw_c = up_t == 2 ? 2 : 3, ncls = up_f * up_t;
+    const long per = (long)q.Cin * q.Cout, n = 9 * per, wsz_c = (long)kh_c * kw_c * per;
+    const long j = (long)bid * 256 + threadIdx.x;
+    if (j < n) {
+        const int tap = (int)(j / per);
+        const long e = j % per;
+        const int dy = tap / 3, dx = tap % 3;
+        float sr = 0.f, si = 0.f;
+        for (int ry = 0; ry < up_f; ++ry)
+            for (int rx = 0; rx < up_t; ++rx) {
+                const int c = ry * up_t + rx;
+                const long off = (long)c * wsz_c + (long)(fold_index(up_f, ry, dy) * kw_c + fold_index(up_t, rx, dx)) * per + e;
+#pragma unroll 8
+                for (int s = 0; s < q.n_slabs; ++s) {                    // unrolled: the loads go out together
+                    const float2 v = q.slab_w[(long)s * ncls * wsz_c + off];
+                    sr += v.x; si += v.y;
+                }
+            }
+        const int co = (int)(e % q.Cout), ci = (int)(e / q.Cout);
+        long dst;
+        if (q.transposed) dst = (((long)ci * q.Cout + co) * 3 + (2 - dy)) * 3 + (2 - dx);
+        else              dst = (((long)co * q.Cin + ci) * 3 + dy) * 3 + dx;
+        q.gw_r[dst] = sr;
+        q.gw_i[dst] = si;
+    } else if (q.gb_r != nullptr && j < n + q.Cout) {
+        const int co = (int)(j - n);
+        float sr = 0.f, si = 0.f;
+        for (int s = 0; s < q.n_slabs * ncls; ++s) { const float2 v = q.slab_b[(long)s * q.Cout + co]; sr += v.x; si += v.y; }
+        q.gb_r[co] = sr + si;
+        q.gb_i[co] = si - sr;
+    }
+}
+
+constexpr int kBatch = 24;                             // jobs per batched launch (kernel-argument table, ~2.3 KB)
+struct Table { int n; Job jobs[kBatch]; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(Job q) {
+    __shared__ float2 red[256];
+    if (q.up_f > 0) reduce_folded(q, blockIdx.x); else reduce_plain(q, blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(Table t) {
+    __shared__ float2 red[256];
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.jobs[k + 1].blk0) ++k;
+    const Job& q = t.jobs[k];
+    const int bid = blockIdx.x - q.blk0;
+    if (bid >= q.nblk) return;
+    if (q.up_f > 0) reduce_folded(q, bid); else reduce_plain(q, bid, red);
+}
+
+int blocks_of(const Job& q) {
+    if (q.up_f > 0) return (int)((9L * q.Cin * q.Cout + (q.gb_r ? q.Cout : 0) + 255) / 256);
+    const long n = (long)q.kh * q.kw * q.Cin * q.Cout;
+    return (int)((n + 31) / 32 + (q.gb_r ? (q.Cout + 31) / 32 : 0));
+}
+
+std::vector<Job>* g_deferred = nullptr;                // process-wide: autograd runs backward on its own thread
+std::mutex g_mutex;
+thread_local bool g_suspended = false;                 // this thread's next reductions run immediately (dcs_wgrad_defer_suspend)
+
+}  // namespace
+
+int emit(Job j, hipStream_t s) {
+    j.blk0 = 0; j.nblk = blocks_of(j);
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (g_deferred && !g_suspended) { g_deferred->push_back(j); return DCS_OK; }
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(j.nblk), dim3(256), 0, s, j);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+}  // namespace wreduce
+
+extern "C" int dcs_wgrad_defer_begin(void) {
+    std::lock_guard<std::mutex> lock(wreduce::g_mutex);
+    if (wreduce::g_deferred) return DCS_ERR_BADARG;
+    wreduce::g_deferred = new std::vector<wreduce::Job>();
+    return DCS_OK;
+}
+
+extern "C" int dcs_wgrad_defer_suspend(int suspended) {
+    wreduce::g_suspended = suspended != 0;
+    return DCS_OK;
+}
+
+extern "C" int dcs_wgrad_defer_flush(dcs_stream_t stream) {
+    std::vector<wreduce::Job>* jobs;
+    {
+        std::lock_guard<std::mutex> lock(wreduce::g_mutex);
+        jobs = wreduce::g_deferred;
+        wreduce::g_deferred = nullptr;
+    }
+    if (!jobs) return DCS_ERR_BADARG;
+    hipStream_t s = dcs_stream(stream);
+    int rc = DCS_OK;
+    for (size_t i0 = 0; i0 < jobs->size() && rc == DCS_OK; i0 += wreduce::kBatch) {
+        wreduce::Table t;
+        t.n = 0;
+        int nb = 0;
+        for (size_t i = i0; i < jobs->size() && t.n < wreduce::kBatch; ++i) {
+            wreduce::Job q = (*jobs)[i];
+            q.blk0 = nb;
+            nb += q.nblk;
+            t.jobs[t.n++] = q;
+        }
+        hipLaunchKernelGGL(wreduce::wgrad_reduce_multi_kernel, dim3(nb), dim3(256), 0, s, t);
+        if (hipGetLastError() != hipSuccess) rc = DCS_ERR_LAUNCH;
+    }
+    delete jobs;
+    return rc;
+}

@@ -180,12 +180,25 @@ class TrainStep:
         loss = self.net.training_step(batch, batch_idx)
         if loss is None:                       # NaN guard of the reference (c_network.py:257-261)
             return None
-        loss.backward()
+        self._backward(loss)
         world = self.bucket.allreduce()
         self.opt.step(world)
         if self.seed_state is not None:
             self.seed_state += 1
         return loss.detach()
+
+    def _backward(self, loss):
+        """loss.backward() with the ~28 weight-gradient slab reductions deferred and run as one batched launch at
+        the end (nothing reads a weight gradient before the all-reduce / optimizer)."""
+        if not self.bucket.flat.is_cuda:
+            loss.backward()
+            return
+        from . import ops
+        ops.wgrad_defer_begin()
+        try:
+            loss.backward()
+        finally:
+            ops.wgrad_defer_flush()
 
     def _eager(self, batch, batch_idx):
         """The first GPU step records every weight pack it makes into a pack plan (the packs still run); later
@@ -228,7 +241,7 @@ class TrainStep:
                 functional.run_pack_plan(self._plan)
             self.bucket.zero_grad()
             loss = self._loss_no_sync(static, 0)
-            loss.backward()
+            self._backward(loss)
             if world == 1:                                 # collectives stay outside the graph
                 self.opt.step(1)
                 self.seed_state += 1

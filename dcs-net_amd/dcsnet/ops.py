@@ -283,15 +283,53 @@ def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1,
     nbytes = lib.dcs_cconv2d_bwd_weight_workspace_bytes(*geo)
     if nbytes < 0:
         raise _lib.DcsHipError(f'cconv2d_bwd_weight: unsupported geometry {geo}')
-    ws = _workspace(nbytes, dev)
+    # Inside a deferred-reduce scope (wgrad_defer_begin) the slab reduce of this call is postponed to the flush when ALL
+    # its results land in caller-owned destinations (`outs`): the slabs then need their own buffer, kept until the flush.
+    # A call whose results are consumed right away suspends deferral for its duration.
+    scope = WGRAD_DEFER
+    all_out = outs is not None and o[0] is not None and o[1] is not None and (not has_bias or (o[2] is not None and o[3] is not None))
+    if scope is not None and all_out:
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        scope.append(ws)
+    else:
+        ws = _workspace(nbytes, dev)
+    suspend = scope is not None and not all_out
+    if suspend:
+        lib.dcs_wgrad_defer_suspend(1)
     ev = None
     if CONV_TIMER is not None:
         ev = CONV_TIMER.begin(8.0 * B * gy.shape[1] * gy.shape[2] * Cout * (C1 + C2) * ksize[0] * ksize[1])
-    check(lib.dcs_cconv2d_bwd_weight(ptr(x1), ptr(x2), ptr(gy), ptr(gw_r), ptr(gw_i), ptr(gb_r), ptr(gb_i), ptr(ws),
-                                     ws.numel(), *geo, int(bool(transposed)), cur_stream()), 'dcs_cconv2d_bwd_weight')
+    try:
+        check(lib.dcs_cconv2d_bwd_weight(ptr(x1), ptr(x2), ptr(gy), ptr(gw_r), ptr(gw_i), ptr(gb_r), ptr(gb_i), ptr(ws),
+                                         ws.numel(), *geo, int(bool(transposed)), cur_stream()), 'dcs_cconv2d_bwd_weight')
+    finally:
+        if suspend:
+            lib.dcs_wgrad_defer_suspend(0)
     if ev is not None:
         CONV_TIMER.end(ev)
     return gw_r, gw_i, gb_r, gb_i
+
+
+WGRAD_DEFER = None         # keep-alive list of slab workspaces while a deferred-reduce scope is open, else None
+
+
+def wgrad_defer_begin():
+    """Open a scope in which weight-gradient slab reductions are recorded instead of launched (dcs_wgrad_defer_begin)."""
+    global WGRAD_DEFER
+    check(_lib.load().dcs_wgrad_defer_begin(), 'dcs_wgrad_defer_begin')
+    WGRAD_DEFER = []
+
+
+def wgrad_defer_flush():
+    """Run every recorded reduction as one batched launch on the current stream and release the slabs."""
+    global WGRAD_DEFER
+    ev = CONV_TIMER.begin(0.0) if CONV_TIMER is not None else None     # the reduces belong to the conv family's time
+    try:
+        check(_lib.load().dcs_wgrad_defer_flush(cur_stream()), 'dcs_wgrad_defer_flush')
+    finally:
+        WGRAD_DEFER = None
+    if ev is not None:
+        CONV_TIMER.end(ev)
 
 
 def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, use_batch_stats=True,

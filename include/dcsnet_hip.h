@@ -397,6 +397,17 @@ int dcs_tap_rows_wgrad_scatter(const float* gt_r, const float* gt_i, float* gw_r
 int dcs_set_conv_precision(int mode);
 int dcs_get_conv_precision(void);
 
+/* Deferred weight-gradient reductions.  dcs_cconv2d_bwd_weight = a partial-slab kernel + a small reduce that writes the
+ * parameter layout; nothing reads a weight gradient before the optimizer, so between dcs_wgrad_defer_begin() and
+ * dcs_wgrad_defer_flush() the reduces are recorded instead of launched (process-wide: autograd's backward thread makes
+ * the calls) and the flush runs all of them as one batched launch per 24.  While a scope is open the caller gives
+ * every dcs_cconv2d_bwd_weight call its OWN workspace and keeps it, and the gradient destinations, alive until the
+ * flush.  dcs_wgrad_defer_suspend(1) makes the calling thread's next reductions immediate again (for a call whose
+ * result is consumed right away); (0) resumes deferral. */
+int dcs_wgrad_defer_begin(void);
+int dcs_wgrad_defer_suspend(int suspended);
+int dcs_wgrad_defer_flush(dcs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Pack plan: every weight re-layout of a training step in one launch per dependency level.
  * No reference counterpart (cuDNN reads the nn.Parameter layout, c_network.py:107-147); the packed panels
