@@ -12,6 +12,9 @@
 // The lanes are summed once per workgroup (DPP row shifts / broadcasts; cross-wave through LDS for MODE 0) into
 // one partial slab per workgroup — same slab layout and reduce kernel as the other weight-gradient paths, no atomics.
 #include "conv_common.h"
+#include "wgrad_reduce.h"
+
+#include <vector>
 
 namespace {
 
@@ -24,11 +27,21 @@ struct SArgs {
 };
 
 template <int MODE, int S>
-__global__ __launch_bounds__(256, 2) void cconv_wgrad_small_kernel(SArgs w) {
-    constexpr int NC = MODE == 0 ? 2 : 1;
-    constexpr int ROWS = (TH - 1) * S + KS, COLS = (TW - 1) * S + KS, COLSP = COLS | 1, PLANE = ROWS * COLSP + 1;
-    __shared__ float2 tile[NC * PLANE];
-    __shared__ float2 red[4][2 * TAPS + 2];
+struct SmallLds {
+    static constexpr int NC = MODE == 0 ? 2 : 1;
+    static constexpr int ROWS = (TH - 1) * S + KS, COLS = (TW - 1) * S + KS, COLSP = COLS | 1, PLANE = ROWS * COLSP + 1;
+    float2 tile[NC * PLANE];
+    float2 red[4][2 * TAPS + 2];
+};
+
+// `bid`: this workgroup's slab index inside problem `w` (blockIdx.x of a single launch)
+template <int MODE, int S>
+__device__ __forceinline__ void wgrad_small_body(const SArgs& w, int bid, SmallLds<MODE, S>& lds) {
+    constexpr int NC = SmallLds<MODE, S>::NC;
+    constexpr int ROWS = SmallLds<MODE, S>::ROWS, COLS = SmallLds<MODE, S>::COLS, COLSP = SmallLds<MODE, S>::COLSP,
+                  PLANE = SmallLds<MODE, S>::PLANE;
+    float2* tile = lds.tile;
+    float2 (*red)[2 * TAPS + 2] = lds.red;
     const conv::Args& a = w.c;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tiles_per_img = a.tiles_w * a.tiles_h;
@@ -38,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_small_kernel(SArgs w) {
     for (int tp = 0; tp < TAPS; ++tp) { ar[tp][0] = ar[tp][1] = ai[tp][0] = ai[tp][1] = 0.f; }
     float2 b0 = make_float2(0.f, 0.f), b1 = make_float2(0.f, 0.f);
 
-    for (int tl = blockIdx.x; tl < w.total_tiles; tl += w.n_slabs) {
+    for (int tl = bid; tl < w.total_tiles; tl += w.n_slabs) {
         const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
         const int oy0 = (tile_id / a.tiles_w) * TH, ox0 = (tile_id % a.tiles_w) * TW;
         const int vy0 = oy0 * S - a.pad_f, vx0 = ox0 * S - a.pad_t;
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_small_kernel(SArgs w) {
 
     // lanes -> one value per output.  Output j = tap*2 + k: MODE 0 (tap, ci = k); MODE 1 (tap, co = 2*wave + k)
     const long wsz = (long)TAPS * (MODE == 0 ? 2 : 8);
-    float2* slab = w.slab_w + (long)blockIdx.x * wsz;
+    float2* slab = w.slab_w + (long)bid * wsz;
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
@@ -104,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_small_kernel(SArgs w) {
     const float2 s1 = make_float2(dcs_wave_sum_lane63(b1.x), dcs_wave_sum_lane63(b1.y));
     if (MODE == 1) {
         if (lane == 63) {
-            w.slab_b[(long)blockIdx.x * 8 + 2 * wave] = s0;
-            w.slab_b[(long)blockIdx.x * 8 + 2 * wave + 1] = s1;
+            w.slab_b[(long)bid * 8 + 2 * wave] = s0;
+            w.slab_b[(long)bid * 8 + 2 * wave + 1] = s1;
         }
         return;
     }
@@ -116,9 +129,30 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_small_kernel(SArgs w) {
 #pragma unroll
         for (int q = 1; q < 4; ++q) { v.x += red[q][t].x; v.y += red[q][t].y; }
         if (t < 2 * TAPS) slab[t] = v;                     // [tap][ci][co = 0]
-        else w.slab_b[blockIdx.x] = v;
+        else w.slab_b[bid] = v;
     }
 }
+
+template <int MODE, int S>
+__global__ __launch_bounds__(256, 2) void cconv_wgrad_small_kernel(SArgs w) {
+    __shared__ SmallLds<MODE, S> lds;
+    wgrad_small_body<MODE, S>(w, blockIdx.x, lds);
+}
+
+// several independent 2 -> 1 problems (the 13 spatial-attention convs of a train step) in ONE launch: inside a
+// deferred-reduce scope (wgrad_reduce.h) nothing needs these gradients before the optimizer, so their launches are
+// recorded and the flush runs them together — 13 kernels of ~10-20 us, each mostly a fixed DPP-reduction tail, overlap
+constexpr int kSmallBatch = 16;
+struct SmallTable { int n; int blk0[kSmallBatch + 1]; SArgs p[kSmallBatch]; };
+
+__global__ __launch_bounds__(256, 2) void cconv_wgrad_small_multi_kernel(SmallTable t) {
+    __shared__ SmallLds<0, 1> lds;
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
+    wgrad_small_body<0, 1>(t.p[k], blockIdx.x - t.blk0[k], lds);
+}
+
+std::vector<SArgs>* g_small_deferred = nullptr;
 
 }  // namespace
 
@@ -138,8 +172,36 @@ int dcs_conv_wgrad_small_launch(const conv::Args& a, const float* gy, float2* sl
     w.gy = (const float2*)gy; w.slab_w = slab_w; w.slab_b = slab_b;
     w.n_slabs = n_slabs;
     w.total_tiles = a.tiles_w * a.tiles_h * a.B;
+    if (a.C1 == 2 && wreduce::deferring()) {                 // recorded; dcs_conv_wgrad_small_flush launches the batch
+        if (!g_small_deferred) g_small_deferred = new std::vector<SArgs>();
+        g_small_deferred->push_back(w);
+        return DCS_OK;
+    }
     if (a.C1 == 2) hipLaunchKernelGGL((cconv_wgrad_small_kernel<0, 1>), dim3(n_slabs), dim3(256), 0, stream, w);
     else hipLaunchKernelGGL((cconv_wgrad_small_kernel<1, 2>), dim3(n_slabs), dim3(256), 0, stream, w);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+// launch every recorded 2 -> 1 problem (called by dcs_wgrad_defer_flush before the batched reduces)
+int dcs_conv_wgrad_small_flush(hipStream_t stream) {
+    std::vector<SArgs>* jobs = g_small_deferred;
+    g_small_deferred = nullptr;
+    if (!jobs) return DCS_OK;
+    int rc = DCS_OK;
+    for (size_t i0 = 0; i0 < jobs->size() && rc == DCS_OK; i0 += kSmallBatch) {
+        SmallTable t;
+        t.n = 0;
+        int nb = 0;
+        for (size_t i = i0; i < jobs->size() && t.n < kSmallBatch; ++i) {
+            t.blk0[t.n] = nb;
+            t.p[t.n++] = (*jobs)[i];
+            nb += (*jobs)[i].n_slabs;
+        }
+        t.blk0[t.n] = nb;
+        hipLaunchKernelGGL(cconv_wgrad_small_multi_kernel, dim3(nb), dim3(256), 0, stream, t);
+        if (hipGetLastError() != hipSuccess) rc = DCS_ERR_LAUNCH;
+    }
+    delete jobs;
+    return rc;
 }

@@ -23,4 +23,10 @@ struct Job {
 // launch now, or record when a defer scope is open
 int emit(Job j, hipStream_t s);
 
+// true while the calling thread's weight-gradient work may be postponed to the flush
+bool deferring();
+
 }  // namespace wreduce
+
+// conv_wgrad_small.hip: the recorded 2 -> 1 weight-gradient kernels, launched as one batch before the reduces
+int dcs_conv_wgrad_small_flush(hipStream_t stream);

@@ -112,6 +112,11 @@ thread_local bool g_suspended = false;                 // this thread's next red
 
 }  // namespace
 
+bool deferring() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    return g_deferred != nullptr && !g_suspended;
+}
+
 int emit(Job j, hipStream_t s) {
     j.blk0 = 0; j.nblk = blocks_of(j);
     {
@@ -146,7 +151,7 @@ extern "C" int dcs_wgrad_defer_flush(dcs_stream_t stream) {
     }
     if (!jobs) return DCS_ERR_BADARG;
     hipStream_t s = dcs_stream(stream);
-    int rc = DCS_OK;
+    int rc = dcs_conv_wgrad_small_flush(s);               // recorded kernels first: the reduces read their slabs
     for (size_t i0 = 0; i0 < jobs->size() && rc == DCS_OK; i0 += wreduce::kBatch) {
         wreduce::Table t;
         t.n = 0;

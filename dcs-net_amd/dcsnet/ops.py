@@ -290,7 +290,7 @@ def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1,
     all_out = outs is not None and o[0] is not None and o[1] is not None and (not has_bias or (o[2] is not None and o[3] is not None))
     if scope is not None and all_out:
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-        scope.append(ws)
+        scope.append((ws, x1, x2, gy))                # a deferred KERNEL (the small-channel one) still reads its inputs at the flush
     else:
         ws = _workspace(nbytes, dev)
     suspend = scope is not None and not all_out
