@@ -11,7 +11,7 @@
 // A lane group of G = C/2 lanes owns one pixel (one float4 = 2 complex channels per lane), so
 // per-pixel channel reductions are wavefront shuffles and every global access is a contiguous
 // 16-byte-per-lane stream.
-#include "dcs_common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -34,14 +34,14 @@ inline int ca_chunks(long HW, int G) {
 }
 
 // part[b][chunk][C][2] (double): sum over this chunk's pixels of x[b][p][c]
-__global__ __launch_bounds__(kThreads) void ca_pool_kernel(const float* __restrict__ x, double* __restrict__ part,
-                                                            long HW, int C, int G) {
+__device__ __forceinline__ void ca_pool_kernel_body(const float* __restrict__ x, double* __restrict__ part,
+                                                            long HW, int C, int G, int bx, int by, int gx) {
     __shared__ double red[kThreads * 4];
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
-    const int b = blockIdx.y;
+    const int b = by;
     const float4* x4 = reinterpret_cast<const float4*>(x) + (long)b * HW * G;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (long r = (long)blockIdx.x * rpi + r0; r < HW; r += (long)gridDim.x * rpi) {
+    for (long r = (long)bx * rpi + r0; r < HW; r += (long)gx * rpi) {
         const float4 v = x4[r * G + g];
         s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
     }
@@ -51,18 +51,18 @@ __global__ __launch_bounds__(kThreads) void ca_pool_kernel(const float* __restri
         const int gg = o / 4, i = o % 4;
         double a = 0;
         for (int r = 0; r < rpi; ++r) a += red[(r * G + gg) * 4 + i];
-        part[(((long)b * gridDim.x + blockIdx.x) * C + 2 * gg) * 2 + i] = a;   // (c=2gg+(i>>1), ri=i&1)
+        part[(((long)b * gx + bx) * C + 2 * gg) * 2 + i] = a;   // (c=2gg+(i>>1), ri=i&1)
     }
 }
 
 // one workgroup per sample
-__global__ __launch_bounds__(kThreads) void ca_fc_kernel(const double* __restrict__ part, int nchunks,
+__device__ __forceinline__ void ca_fc_kernel_body(const double* __restrict__ part, int nchunks,
                                                           const float2* __restrict__ w1, const float2* __restrict__ w2,
                                                           float2* __restrict__ ca_out, float2* __restrict__ pooled_out,
-                                                          float2* __restrict__ hidden_out, long HW, int C, int Ch) {
+                                                          float2* __restrict__ hidden_out, long HW, int C, int Ch, int bx, int by, int gx) {
     __shared__ float2 pooled[128];
     __shared__ float2 hid[64];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = bx, t = threadIdx.x;
     for (int c = t; c < C; c += kThreads) {
         double sr = 0, si = 0;
         for (int k = 0; k < nchunks; ++k) {
@@ -108,19 +108,19 @@ __device__ __forceinline__ float group_max(float v, int G) {
 }
 
 // pooled[b][p] = { mean_c z , max_c Re z + j max_c Im z },  z = ca[b][c] * x[b][p][c]
-__global__ __launch_bounds__(kThreads) void spatial_pool_kernel(const float* __restrict__ x,
+__device__ __forceinline__ void spatial_pool_kernel_body(const float* __restrict__ x,
                                                                  const float* __restrict__ ca,
-                                                                 float4* __restrict__ pooled, long HW, int C, int G) {
+                                                                 float4* __restrict__ pooled, long HW, int C, int G, int bx, int by, int gx) {
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
-    const int b = blockIdx.y;
+    const int b = by;
     const float4* x4 = reinterpret_cast<const float4*>(x) + (long)b * HW * G;
     float4 a = make_float4(1.f, 0.f, 1.f, 0.f);
     if (ca) a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
     const float invC = 1.f / (float)C;
     // every lane of a group runs the same trip count, so the shuffles are convergent
-    const long iters = (HW + (long)gridDim.x * rpi - 1) / ((long)gridDim.x * rpi);
+    const long iters = (HW + (long)gx * rpi - 1) / ((long)gx * rpi);
     for (long k = 0; k < iters; ++k) {
-        const long r = (k * gridDim.x + blockIdx.x) * rpi + r0;
+        const long r = (k * gx + bx) * rpi + r0;
         const bool ok = r < HW;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) v = x4[r * G + g];
@@ -133,20 +133,20 @@ __global__ __launch_bounds__(kThreads) void spatial_pool_kernel(const float* __r
 }
 
 template <bool DROP>
-__global__ __launch_bounds__(kThreads) void attention_apply_kernel(const float* __restrict__ x,
+__device__ __forceinline__ void attention_apply_kernel_body(const float* __restrict__ x,
                                                                     const float* __restrict__ ca,
                                                                     const float2* __restrict__ sa, float* __restrict__ y,
-                                                                    long HW, int C, int G, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+                                                                    long HW, int C, int G, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev, int bx, int by, int gx) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
-    const int b = blockIdx.y;
+    const int b = by;
     const long base = (long)b * HW * G;
     const float4* x4 = reinterpret_cast<const float4*>(x) + base;
     float4* y4 = reinterpret_cast<float4*>(y) + base;
     float4 a = make_float4(1.f, 0.f, 1.f, 0.f);
     if (ca) a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
-    for (long r = (long)blockIdx.x * rpi + r0; r < HW; r += (long)gridDim.x * rpi) {
+    for (long r = (long)bx * rpi + r0; r < HW; r += (long)gx * rpi) {
         const float4 v = x4[r * G + g];
         float2 s = make_float2(1.f, 0.f);
         if (sa) s = sa[(long)b * HW + r];
@@ -164,6 +164,53 @@ __global__ __launch_bounds__(kThreads) void attention_apply_kernel(const float* 
         }
         y4[r * G + g] = o;
     }
+}
+
+// ---- launch forms: one problem per launch, or several problems (blockIdx.z) sharing one launch ---------------------
+// The seven skip attentions of the network depend only on encoder outputs, and their backward pass only on the
+// decoder's: run as 7 x 5 (x 6 backward) dependent launches of 5-10 us they cost more in launch boundaries than in
+// work.  Every kernel therefore also exists in a table form: problem = blockIdx.z, its own grid width p.nx (blocks
+// beyond it exit), same body.
+constexpr int kMaxBatch = 8;
+template <class P> struct Tbl { P p[kMaxBatch]; };
+
+struct CaPoolP { const float* x; double* part; long HW; int C, G, nx; };
+struct CaFcP { const double* part; int nchunks; const float2* w1; const float2* w2; float2* ca; float2* pooled; float2* hidden;
+               long HW; int C, Ch; };
+struct SpPoolP { const float* x; const float* ca; float4* pooled; long HW; int C, G, nx; };
+struct ApplyP { const float* x; const float* ca; const float2* sa; float* y; long HW; int C, G, nx; };
+
+__global__ __launch_bounds__(kThreads) void ca_pool_kernel(CaPoolP p) {
+    ca_pool_kernel_body(p.x, p.part, p.HW, p.C, p.G, blockIdx.x, blockIdx.y, gridDim.x);
+}
+__global__ __launch_bounds__(kThreads) void ca_pool_multi_kernel(Tbl<CaPoolP> t) {
+    const CaPoolP& p = t.p[blockIdx.z];
+    if ((int)blockIdx.x >= p.nx) return;
+    ca_pool_kernel_body(p.x, p.part, p.HW, p.C, p.G, blockIdx.x, blockIdx.y, p.nx);
+}
+__global__ __launch_bounds__(kThreads) void ca_fc_kernel(CaFcP p) {
+    ca_fc_kernel_body(p.part, p.nchunks, p.w1, p.w2, p.ca, p.pooled, p.hidden, p.HW, p.C, p.Ch, blockIdx.x, 0, 0);
+}
+__global__ __launch_bounds__(kThreads) void ca_fc_multi_kernel(Tbl<CaFcP> t) {
+    const CaFcP& p = t.p[blockIdx.z];
+    ca_fc_kernel_body(p.part, p.nchunks, p.w1, p.w2, p.ca, p.pooled, p.hidden, p.HW, p.C, p.Ch, blockIdx.x, 0, 0);
+}
+__global__ __launch_bounds__(kThreads) void spatial_pool_kernel(SpPoolP p) {
+    spatial_pool_kernel_body(p.x, p.ca, p.pooled, p.HW, p.C, p.G, blockIdx.x, blockIdx.y, gridDim.x);
+}
+__global__ __launch_bounds__(kThreads) void spatial_pool_multi_kernel(Tbl<SpPoolP> t) {
+    const SpPoolP& p = t.p[blockIdx.z];
+    if ((int)blockIdx.x >= p.nx) return;
+    spatial_pool_kernel_body(p.x, p.ca, p.pooled, p.HW, p.C, p.G, blockIdx.x, blockIdx.y, p.nx);
+}
+template <bool DROP>
+__global__ __launch_bounds__(kThreads) void attention_apply_kernel(ApplyP p, float drop_p, uint64_t seed, const uint64_t* seed_dev) {
+    attention_apply_kernel_body<DROP>(p.x, p.ca, p.sa, p.y, p.HW, p.C, p.G, drop_p, seed, seed_dev, blockIdx.x, blockIdx.y, gridDim.x);
+}
+__global__ __launch_bounds__(kThreads) void attention_apply_multi_kernel(Tbl<ApplyP> t) {      // no dropout on the skip path
+    const ApplyP& p = t.p[blockIdx.z];
+    if ((int)blockIdx.x >= p.nx) return;
+    attention_apply_kernel_body<false>(p.x, p.ca, p.sa, p.y, p.HW, p.C, p.G, 0.f, 0, nullptr, blockIdx.x, blockIdx.y, p.nx);
 }
 
 __global__ __launch_bounds__(kThreads) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
@@ -200,10 +247,12 @@ extern "C" int dcs_channel_attention_fwd(const float* x, const float* w1, const 
     const int nch = ca_chunks(HW, G);
     if (workspace_bytes < (long)B * nch * C * 2 * (long)sizeof(double)) return DCS_ERR_WORKSPACE;
     hipStream_t s = dcs_stream(stream);
-    hipLaunchKernelGGL(ca_pool_kernel, dim3(nch, B), dim3(kThreads), 0, s, x, (double*)workspace, HW, C, G);
+    const CaPoolP pp{x, (double*)workspace, HW, C, G, nch};
+    hipLaunchKernelGGL(ca_pool_kernel, dim3(nch, B), dim3(kThreads), 0, s, pp);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ca_fc_kernel, dim3(B), dim3(kThreads), 0, s, (const double*)workspace, nch, (const float2*)w1,
-                       (const float2*)w2, (float2*)ca_out, (float2*)pooled_out, (float2*)hidden_out, HW, C, Ch);
+    const CaFcP fp{(const double*)workspace, nch, (const float2*)w1, (const float2*)w2, (float2*)ca_out, (float2*)pooled_out,
+                   (float2*)hidden_out, HW, C, Ch};
+    hipLaunchKernelGGL(ca_fc_kernel, dim3(B), dim3(kThreads), 0, s, fp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -212,8 +261,9 @@ extern "C" int dcs_spatial_pool_fwd(const float* x, const float* ca, float* pool
                                     dcs_stream_t stream) {
     int G;
     if (!x || !pooled || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(spatial_pool_kernel, dim3(stream_grid(HW, G, B), B), dim3(kThreads), 0, dcs_stream(stream), x,
-                       ca, (float4*)pooled, HW, C, G);
+    const int nx = stream_grid(HW, G, B);
+    const SpPoolP sp{x, ca, (float4*)pooled, HW, C, G, nx};
+    hipLaunchKernelGGL(spatial_pool_kernel, dim3(nx, B), dim3(kThreads), 0, dcs_stream(stream), sp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -223,13 +273,77 @@ extern "C" int dcs_attention_apply_fwd(const float* x, const float* ca, const fl
     int G;
     if (!x || !y || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
-    dim3 grid(stream_grid(HW, G, B), B);
+    const int nx = stream_grid(HW, G, B);
+    dim3 grid(nx, B);
+    const ApplyP ap{x, ca, (const float2*)sa, y, HW, C, G, nx};
     if (drop_p > 0.f)
-        hipLaunchKernelGGL(attention_apply_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), x, ca,
-                           (const float2*)sa, y, HW, C, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+        hipLaunchKernelGGL(attention_apply_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), ap, drop_p,
+                           (uint64_t)seed, (const uint64_t*)seed_dev);
     else
-        hipLaunchKernelGGL(attention_apply_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), x, ca,
-                           (const float2*)sa, y, HW, C, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+        hipLaunchKernelGGL(attention_apply_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), ap, drop_p,
+                           (uint64_t)seed, (const uint64_t*)seed_dev);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// ---- several attention blocks in one set of launches (forward) ---------------------------------------------
+// items[i]: one block (the reference's skip_attention[2i], [2i+1] on encoder output i: c_network.py:208-211), no dropout.
+// Five launches for all n blocks: channel pooling, channel FCs, spatial pooling, the 7x7 2->1 conv + sigmoid
+// (conv_direct.hip), apply.  workspace: sum of the blocks' dcs_ca_workspace_bytes, each rounded up to 256 bytes.
+extern "C" long dcs_attention_fwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B) {
+    if (n < 1 || n > kMaxBatch || !items || B <= 0) return -1;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        int G;
+        if (!att_geom(items[i].C, &G)) return -1;
+        const long b = (long)B * ca_chunks((long)items[i].H * items[i].W, G) * items[i].C * 2 * (long)sizeof(double);
+        total += (b + 255) / 256 * 256;
+    }
+    return total;
+}
+
+extern "C" int dcs_attention_fwd_batched(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
+                                         dcs_stream_t stream) {
+    if (n < 1 || n > kMaxBatch || !items || !workspace || B <= 0 || B > 65535) return DCS_ERR_BADARG;
+    if (workspace_bytes < dcs_attention_fwd_batched_workspace_bytes(n, items, B)) return DCS_ERR_WORKSPACE;
+    Tbl<CaPoolP> tp; Tbl<CaFcP> tf; Tbl<SpPoolP> ts; Tbl<ApplyP> ta;
+    conv::Args ca_[kMaxBatch];
+    int nx_pool = 1, nx_stream = 1;
+    char* ws = (char*)workspace;
+    for (int i = 0; i < n; ++i) {
+        const dcs_attention_item& it = items[i];
+        int G;
+        if (!it.x || !it.w1 || !it.w2 || !it.wsa || !it.sa_bias || !it.ca || !it.pooled || !it.hidden || !it.sp || !it.sa ||
+            !it.y || it.H <= 0 || it.W <= 0 || it.Ch <= 0 || it.Ch > 64 || !att_geom(it.C, &G))
+            return DCS_ERR_BADARG;
+        const long HW = (long)it.H * it.W;
+        const int nch = ca_chunks(HW, G), nxs = stream_grid(HW, G, B);
+        tp.p[i] = CaPoolP{it.x, (double*)ws, HW, it.C, G, nch};
+        tf.p[i] = CaFcP{(const double*)ws, nch, (const float2*)it.w1, (const float2*)it.w2, (float2*)it.ca, (float2*)it.pooled,
+                        (float2*)it.hidden, HW, it.C, it.Ch};
+        ts.p[i] = SpPoolP{it.x, it.ca, (float4*)it.sp, HW, it.C, G, nxs};
+        ta.p[i] = ApplyP{it.x, it.ca, (const float2*)it.sa, it.y, HW, it.C, G, nxs};
+        ws += ((long)B * nch * it.C * 2 * (long)sizeof(double) + 255) / 256 * 256;
+        nx_pool = nch > nx_pool ? nch : nx_pool;
+        nx_stream = nxs > nx_stream ? nxs : nx_stream;
+        conv::Args& a = ca_[i];                           // sa = sigmoid(conv7x7(sp)): 2 -> 1 channels, pad 3
+        a = conv::Args{};
+        a.x1 = (const float2*)it.sp; a.x2 = nullptr; a.wp = (const float2*)it.wsa; a.bias = (const float2*)it.sa_bias;
+        a.y = (float2*)it.sa;
+        a.B = B; a.Hin = it.H; a.Win = it.W; a.C1 = 2; a.C2 = 0; a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Cout = 1;
+        a.kh = 7; a.kw = 7; a.sf = 1; a.st = 1; a.pad_f = 3; a.pad_t = 3; a.act = DCS_ACT_SIGMOID;
+        a.Hv = it.H; a.Wv = it.W; a.Hout = it.H; a.Wout = it.W;
+    }
+    hipStream_t s = dcs_stream(stream);
+    hipLaunchKernelGGL(ca_pool_multi_kernel, dim3(nx_pool, B, n), dim3(kThreads), 0, s, tp);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ca_fc_multi_kernel, dim3(B, 1, n), dim3(kThreads), 0, s, tf);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(spatial_pool_multi_kernel, dim3(nx_stream, B, n), dim3(kThreads), 0, s, ts);
+    DCS_CHECK_LAUNCH();
+    const int rc = dcs_conv_direct_multi(ca_, n, s);
+    if (rc != DCS_OK) return rc;
+    hipLaunchKernelGGL(attention_apply_multi_kernel, dim3(nx_stream, B, n), dim3(kThreads), 0, s, ta);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

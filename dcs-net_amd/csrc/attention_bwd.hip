@@ -13,7 +13,7 @@
 //                       reference's layout, and g_pooled
 //   att_bwd_pool_kernel g_x += g_pooled[b][c] / HW
 // z, the masks and the arg-max indices are recomputed, never stored.
-#include "dcs_common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -60,21 +60,21 @@ __device__ __forceinline__ float4 masked(float4 g, uint64_t seed, uint64_t e, fl
 
 // g_pre[b][p] = sigmoid'(sa[p]) (.) sum_c g_o[p][c] conj(ca[c] x[p][c])
 template <bool DROP>
-__global__ __launch_bounds__(kThreads) void att_bwd_sa_kernel(const float* __restrict__ x, const float* __restrict__ go,
+__device__ __forceinline__ void att_bwd_sa_kernel_body(const float* __restrict__ x, const float* __restrict__ go,
                                                                const float* __restrict__ ca,
                                                                const float2* __restrict__ sa, float2* __restrict__ gpre,
-                                                               long HW, int G, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+                                                               long HW, int G, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev, int vbx, int vby, int vgx) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
-    const int b = blockIdx.y;
+    const int b = vby;
     const long base = (long)b * HW * G;
     const float4* x4 = reinterpret_cast<const float4*>(x) + base;
     const float4* g4 = reinterpret_cast<const float4*>(go) + base;
     const float4 a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
-    const long iters = (HW + (long)gridDim.x * rpi - 1) / ((long)gridDim.x * rpi);
+    const long iters = (HW + (long)vgx * rpi - 1) / ((long)vgx * rpi);
     for (long k = 0; k < iters; ++k) {
-        const long r = (k * gridDim.x + blockIdx.x) * rpi + r0;
+        const long r = (k * vgx + vbx) * rpi + r0;
         const bool ok = r < HW;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f), gg = v;
         if (ok) {
@@ -96,15 +96,15 @@ __global__ __launch_bounds__(kThreads) void att_bwd_sa_kernel(const float* __res
 
 // g_x = conj(ca) g_z ; part[b][chunk][C][2] = sum_p g_z conj(x)
 template <bool DROP>
-__global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ go,
+__device__ __forceinline__ void att_bwd_x_kernel_body(const float* __restrict__ x, const float* __restrict__ go,
                                                               const float* __restrict__ ca, const float2* __restrict__ sa,
                                                               const float4* __restrict__ gsp, float* __restrict__ gx,
                                                               double* __restrict__ part, long HW, int C, int G,
-                                                              float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+                                                              float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev, int vbx, int vby, int vgx) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     __shared__ double red[kThreads * 4];
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
-    const int b = blockIdx.y;
+    const int b = vby;
     const long base = (long)b * HW * G;
     const float4* x4 = reinterpret_cast<const float4*>(x) + base;
     const float4* g4 = reinterpret_cast<const float4*>(go) + base;
@@ -113,9 +113,9 @@ __global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(const float* __rest
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
     const float invC = 1.f / (float)C;
     float c0r = 0.f, c0i = 0.f, c1r = 0.f, c1i = 0.f;
-    const long iters = (HW + (long)gridDim.x * rpi - 1) / ((long)gridDim.x * rpi);
+    const long iters = (HW + (long)vgx * rpi - 1) / ((long)vgx * rpi);
     for (long k = 0; k < iters; ++k) {
-        const long r = (k * gridDim.x + blockIdx.x) * rpi + r0;
+        const long r = (k * vgx + vbx) * rpi + r0;
         const bool ok = r < HW;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f), gg = v, gp = v;
         float2 s = make_float2(0.f, 0.f);
@@ -152,22 +152,22 @@ __global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(const float* __rest
         const int gg = o / 4, i = o % 4;
         double acc = 0;
         for (int r = 0; r < rpi; ++r) acc += red[(r * G + gg) * 4 + i];
-        part[(((long)b * gridDim.x + blockIdx.x) * C + 2 * gg) * 2 + i] = acc;
+        part[(((long)b * vgx + vbx) * C + 2 * gg) * 2 + i] = acc;
     }
 }
 
 // Per-sample half (grid = B): slab sum -> g_o = 2 sigmoid'(.) g_ca ; g_h = relu'(h) (.) W2^H g_o ;
 // g_pooled = W1^H g_h.  scratch: float2 go[B][C], gh[B][Ch], gpooled[B][C]
-__global__ __launch_bounds__(kThreads) void ca_bwd_sample_kernel(const double* __restrict__ part, int nchunks,
+__device__ __forceinline__ void ca_bwd_sample_kernel_body(const double* __restrict__ part, int nchunks,
                                                                   const float2* __restrict__ ca,
                                                                   const float2* __restrict__ hidden,
                                                                   const float2* __restrict__ w1,
                                                                   const float2* __restrict__ w2, float2* __restrict__ go,
                                                                   float2* __restrict__ gh, float2* __restrict__ gpooled,
-                                                                  int C, int Ch) {
+                                                                  int C, int Ch, int vbx, int vby, int vgx) {
     __shared__ float2 go_s[128];
     __shared__ float2 gh_s[64];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = vbx, t = threadIdx.x;
     for (int c = t; c < C; c += kThreads) {
         double sr = 0, si = 0;
         for (int k = 0; k < nchunks; ++k) {
@@ -232,23 +232,70 @@ __device__ __forceinline__ void ca_bwd_weight_element(const CaWeightArgs& w, int
 
 // g_x += g_pooled / HW (broadcast over the sample's pixels).  Workgroups with blockIdx.x >= nx_pool of batch row 0 are
 // the FC weight-gradient half (nothing downstream waits for it, so it rides along instead of taking its own launch).
-__global__ __launch_bounds__(kThreads) void att_bwd_pool_kernel(float* __restrict__ gx, const float* __restrict__ gpooled,
-                                                                 long HW, int G, float inv_hw, int nx_pool, CaWeightArgs w) {
-    if ((int)blockIdx.x >= nx_pool) {
-        const int i = ((int)blockIdx.x - nx_pool) * kThreads + threadIdx.x;
-        if (blockIdx.y == 0 && i < w.C * w.Ch) ca_bwd_weight_element(w, i);
+__device__ __forceinline__ void att_bwd_pool_kernel_body(float* __restrict__ gx, const float* __restrict__ gpooled,
+                                                                 long HW, int G, float inv_hw, int nx_pool, CaWeightArgs w, int vbx, int vby, int vgx) {
+    if ((int)vbx >= nx_pool) {
+        const int i = ((int)vbx - nx_pool) * kThreads + threadIdx.x;
+        if (vby == 0 && i < w.C * w.Ch) ca_bwd_weight_element(w, i);
         return;
     }
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
-    const int b = blockIdx.y;
+    const int b = vby;
     float4* o4 = reinterpret_cast<float4*>(gx) + (long)b * HW * G;
     float4 p = reinterpret_cast<const float4*>(gpooled)[(long)b * G + g];
     p.x *= inv_hw; p.y *= inv_hw; p.z *= inv_hw; p.w *= inv_hw;
-    for (long r = (long)blockIdx.x * rpi + r0; r < HW; r += (long)nx_pool * rpi) {
+    for (long r = (long)vbx * rpi + r0; r < HW; r += (long)nx_pool * rpi) {
         float4 v = o4[r * G + g];
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
         o4[r * G + g] = v;
     }
+}
+
+// ---- launch forms: one problem per launch, or several problems (blockIdx.z) sharing one launch (see attention.hip) ----
+constexpr int kMaxBatch = 8;
+template <class P> struct Tbl { P p[kMaxBatch]; };
+
+struct BwdSaP { const float* x; const float* go; const float* ca; const float2* sa; float2* gpre; long HW; int G, nx; };
+struct BwdXP { const float* x; const float* go; const float* ca; const float2* sa; const float4* gsp; float* gx; double* part;
+               long HW; int C, G, nx; };
+struct CaBwdP { const double* part; int nchunks; const float2* ca; const float2* hidden; const float2* w1; const float2* w2;
+                float2* go; float2* gh; float2* gpooled; int C, Ch; };
+struct PoolP { float* gx; const float* gpooled; long HW; int G; float inv_hw; int nx_pool, nx; CaWeightArgs w; };
+
+template <bool DROP>
+__global__ __launch_bounds__(kThreads) void att_bwd_sa_kernel(BwdSaP p, float drop_p, uint64_t seed, const uint64_t* seed_dev) {
+    att_bwd_sa_kernel_body<DROP>(p.x, p.go, p.ca, p.sa, p.gpre, p.HW, p.G, drop_p, seed, seed_dev, blockIdx.x, blockIdx.y, gridDim.x);
+}
+__global__ __launch_bounds__(kThreads) void att_bwd_sa_multi_kernel(Tbl<BwdSaP> t) {
+    const BwdSaP& p = t.p[blockIdx.z];
+    if ((int)blockIdx.x >= p.nx) return;
+    att_bwd_sa_kernel_body<false>(p.x, p.go, p.ca, p.sa, p.gpre, p.HW, p.G, 0.f, 0, nullptr, blockIdx.x, blockIdx.y, p.nx);
+}
+template <bool DROP>
+__global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(BwdXP p, float drop_p, uint64_t seed, const uint64_t* seed_dev) {
+    att_bwd_x_kernel_body<DROP>(p.x, p.go, p.ca, p.sa, p.gsp, p.gx, p.part, p.HW, p.C, p.G, drop_p, seed, seed_dev, blockIdx.x,
+                                blockIdx.y, gridDim.x);
+}
+__global__ __launch_bounds__(kThreads) void att_bwd_x_multi_kernel(Tbl<BwdXP> t) {
+    const BwdXP& p = t.p[blockIdx.z];
+    if ((int)blockIdx.x >= p.nx) return;
+    att_bwd_x_kernel_body<false>(p.x, p.go, p.ca, p.sa, p.gsp, p.gx, p.part, p.HW, p.C, p.G, 0.f, 0, nullptr, blockIdx.x, blockIdx.y,
+                                 p.nx);
+}
+__global__ __launch_bounds__(kThreads) void ca_bwd_sample_kernel(CaBwdP p) {
+    ca_bwd_sample_kernel_body(p.part, p.nchunks, p.ca, p.hidden, p.w1, p.w2, p.go, p.gh, p.gpooled, p.C, p.Ch, blockIdx.x, 0, 0);
+}
+__global__ __launch_bounds__(kThreads) void ca_bwd_sample_multi_kernel(Tbl<CaBwdP> t) {
+    const CaBwdP& p = t.p[blockIdx.z];
+    ca_bwd_sample_kernel_body(p.part, p.nchunks, p.ca, p.hidden, p.w1, p.w2, p.go, p.gh, p.gpooled, p.C, p.Ch, blockIdx.x, 0, 0);
+}
+__global__ __launch_bounds__(kThreads) void att_bwd_pool_kernel(PoolP p) {
+    att_bwd_pool_kernel_body(p.gx, p.gpooled, p.HW, p.G, p.inv_hw, p.nx_pool, p.w, blockIdx.x, blockIdx.y, gridDim.x);
+}
+__global__ __launch_bounds__(kThreads) void att_bwd_pool_multi_kernel(Tbl<PoolP> t) {
+    const PoolP& p = t.p[blockIdx.z];
+    if ((int)blockIdx.x >= p.nx) return;
+    att_bwd_pool_kernel_body(p.gx, p.gpooled, p.HW, p.G, p.inv_hw, p.nx_pool, p.w, blockIdx.x, blockIdx.y, p.nx);
 }
 
 inline int stream_grid(long HW, int G, int B) {
@@ -267,13 +314,15 @@ extern "C" int dcs_attention_bwd_sa(const float* x, const float* g_out, const fl
     int G;
     if (!x || !g_out || !ca || !sa || !g_pre || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
-    dim3 grid(stream_grid(HW, G, B), B);
+    const int nx = stream_grid(HW, G, B);
+    dim3 grid(nx, B);
+    const BwdSaP sp{x, g_out, ca, (const float2*)sa, (float2*)g_pre, HW, G, nx};
     if (drop_p > 0.f)
-        hipLaunchKernelGGL(att_bwd_sa_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), x, g_out, ca,
-                           (const float2*)sa, (float2*)g_pre, HW, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+        hipLaunchKernelGGL(att_bwd_sa_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), sp, drop_p, (uint64_t)seed,
+                           (const uint64_t*)seed_dev);
     else
-        hipLaunchKernelGGL(att_bwd_sa_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), x, g_out, ca,
-                           (const float2*)sa, (float2*)g_pre, HW, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+        hipLaunchKernelGGL(att_bwd_sa_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), sp, drop_p, (uint64_t)seed,
+                           (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -304,24 +353,99 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
     float2* gpooled = gh + (long)B * Ch;
     hipStream_t s = dcs_stream(stream);
     dim3 grid(nch, B);
+    const BwdXP xp{x, g_out, ca, (const float2*)sa, (const float4*)g_sp, g_x, part, HW, C, G, nch};
     if (drop_p > 0.f)
-        hipLaunchKernelGGL(att_bwd_x_kernel<true>, grid, dim3(kThreads), 0, s, x, g_out, ca, (const float2*)sa,
-                           (const float4*)g_sp, g_x, part, HW, C, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+        hipLaunchKernelGGL(att_bwd_x_kernel<true>, grid, dim3(kThreads), 0, s, xp, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     else
-        hipLaunchKernelGGL(att_bwd_x_kernel<false>, grid, dim3(kThreads), 0, s, x, g_out, ca, (const float2*)sa,
-                           (const float4*)g_sp, g_x, part, HW, C, G, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+        hipLaunchKernelGGL(att_bwd_x_kernel<false>, grid, dim3(kThreads), 0, s, xp, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ca_bwd_sample_kernel, dim3(B), dim3(kThreads), 0, s, (const double*)part, nch,
-                       (const float2*)ca, (const float2*)hidden, (const float2*)w1, (const float2*)w2, go, gh, gpooled,
-                       C, Ch);
+    const CaBwdP cp{(const double*)part, nch, (const float2*)ca, (const float2*)hidden, (const float2*)w1, (const float2*)w2, go, gh,
+                    gpooled, C, Ch};
+    hipLaunchKernelGGL(ca_bwd_sample_kernel, dim3(B), dim3(kThreads), 0, s, cp);
     DCS_CHECK_LAUNCH();
     CaWeightArgs cw;
     cw.go = go; cw.gh = gh; cw.pooled = (const float2*)pooled; cw.hidden = (const float2*)hidden;
     cw.g_fc0_r = g_fc0_r; cw.g_fc0_i = g_fc0_i; cw.g_fc2_r = g_fc2_r; cw.g_fc2_i = g_fc2_i;
     cw.B = B; cw.C = C; cw.Ch = Ch;
     const int nx_pool = stream_grid(HW, G, B);
-    hipLaunchKernelGGL(att_bwd_pool_kernel, dim3(nx_pool + (C * Ch + kThreads - 1) / kThreads, B), dim3(kThreads), 0, s, g_x,
-                       (const float*)gpooled, HW, G, 1.f / (float)HW, nx_pool, cw);
+    const int nxw = nx_pool + (C * Ch + kThreads - 1) / kThreads;
+    const PoolP pp{g_x, (const float*)gpooled, HW, G, 1.f / (float)HW, nx_pool, nxw, cw};
+    hipLaunchKernelGGL(att_bwd_pool_kernel, dim3(nxw, B), dim3(kThreads), 0, s, pp);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// ---- several attention blocks in one set of launches (backward; see dcs_attention_fwd_batched) ----------------
+static long bwd_item_bytes(const dcs_attention_item& it, int B, int G) {
+    const long HW = (long)it.H * it.W;
+    const long b = (long)B * chunks_for(HW, G) * it.C * 2 * (long)sizeof(double) + (2L * B * it.C + (long)B * it.Ch) * 8 + 64;
+    return (b + 255) / 256 * 256;
+}
+
+extern "C" long dcs_attention_bwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B) {
+    if (n < 1 || n > kMaxBatch || !items || B <= 0) return -1;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        int G;
+        if (!att_geom(items[i].C, &G) || items[i].Ch <= 0) return -1;
+        total += bwd_item_bytes(items[i], B, G);
+    }
+    return total;
+}
+
+extern "C" int dcs_attention_bwd_batched(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
+                                         dcs_stream_t stream) {
+    if (n < 1 || n > kMaxBatch || !items || !workspace || B <= 0 || B > 65535) return DCS_ERR_BADARG;
+    if (workspace_bytes < dcs_attention_bwd_batched_workspace_bytes(n, items, B)) return DCS_ERR_WORKSPACE;
+    Tbl<BwdSaP> tsa; Tbl<BwdXP> tx; Tbl<CaBwdP> tc; Tbl<PoolP> tp;
+    conv::Args dg[kMaxBatch];
+    int nx_sa = 1, nx_x = 1, nx_p = 1;
+    char* ws = (char*)workspace;
+    for (int i = 0; i < n; ++i) {
+        const dcs_attention_item& it = items[i];
+        int G;
+        if (!it.x || !it.w1 || !it.w2 || !it.ca || !it.pooled || !it.hidden || !it.sa || !it.g_out || !it.wsa_bwd || !it.g_pre ||
+            !it.g_sp || !it.g_x || !it.g_fc0_r || !it.g_fc0_i || !it.g_fc2_r || !it.g_fc2_i || it.H <= 0 || it.W <= 0 ||
+            it.Ch <= 0 || it.Ch > 64 || it.C > 128 || !att_geom(it.C, &G))
+            return DCS_ERR_BADARG;
+        const long HW = (long)it.H * it.W;
+        const int nch = chunks_for(HW, G), nxs = stream_grid(HW, G, B);
+        double* part = (double*)ws;
+        float2* go = (float2*)(ws + (long)B * nch * it.C * 2 * (long)sizeof(double));
+        float2* gh = go + (long)B * it.C;
+        float2* gpooled = gh + (long)B * it.Ch;
+        ws += bwd_item_bytes(it, B, G);
+        tsa.p[i] = BwdSaP{it.x, it.g_out, it.ca, (const float2*)it.sa, (float2*)it.g_pre, HW, G, nxs};
+        tx.p[i] = BwdXP{it.x, it.g_out, it.ca, (const float2*)it.sa, (const float4*)it.g_sp, it.g_x, part, HW, it.C, G, nch};
+        tc.p[i] = CaBwdP{(const double*)part, nch, (const float2*)it.ca, (const float2*)it.hidden, (const float2*)it.w1,
+                         (const float2*)it.w2, go, gh, gpooled, it.C, it.Ch};
+        CaWeightArgs cw;
+        cw.go = go; cw.gh = gh; cw.pooled = (const float2*)it.pooled; cw.hidden = (const float2*)it.hidden;
+        cw.g_fc0_r = it.g_fc0_r; cw.g_fc0_i = it.g_fc0_i; cw.g_fc2_r = it.g_fc2_r; cw.g_fc2_i = it.g_fc2_i;
+        cw.B = B; cw.C = it.C; cw.Ch = it.Ch;
+        const int nxw = nxs + (it.C * it.Ch + kThreads - 1) / kThreads;
+        tp.p[i] = PoolP{it.g_x, (const float*)gpooled, HW, G, 1.f / (float)HW, nxs, nxw, cw};
+        nx_sa = nxs > nx_sa ? nxs : nx_sa;
+        nx_x = nch > nx_x ? nch : nx_x;
+        nx_p = nxw > nx_p ? nxw : nx_p;
+        conv::Args& a = dg[i];                            // g_sp = data gradient of the 7x7 2->1 conv: 1 -> 2 over g_pre
+        a = conv::Args{};
+        a.x1 = (const float2*)it.g_pre; a.x2 = nullptr; a.wp = (const float2*)it.wsa_bwd; a.bias = nullptr;
+        a.y = (float2*)it.g_sp;
+        a.B = B; a.Hin = it.H; a.Win = it.W; a.C1 = 1; a.C2 = 0; a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Cout = 2;
+        a.kh = 7; a.kw = 7; a.sf = 1; a.st = 1; a.pad_f = 3; a.pad_t = 3; a.act = DCS_ACT_NONE;
+        a.Hv = it.H; a.Wv = it.W; a.Hout = it.H; a.Wout = it.W;
+    }
+    hipStream_t s = dcs_stream(stream);
+    hipLaunchKernelGGL(att_bwd_sa_multi_kernel, dim3(nx_sa, B, n), dim3(kThreads), 0, s, tsa);
+    DCS_CHECK_LAUNCH();
+    const int rc = dcs_conv_direct_multi(dg, n, s);
+    if (rc != DCS_OK) return rc;
+    hipLaunchKernelGGL(att_bwd_x_multi_kernel, dim3(nx_x, B, n), dim3(kThreads), 0, s, tx);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ca_bwd_sample_multi_kernel, dim3(B, 1, n), dim3(kThreads), 0, s, tc);
+    DCS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(att_bwd_pool_multi_kernel, dim3(nx_p, B, n), dim3(kThreads), 0, s, tp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

@@ -81,6 +81,9 @@ bool dcs_conv_small_dgrad_ok(int Cin, int Cout, int kh, int kw, int sf, int st, 
 int dcs_conv_small_dgrad_launch(const float* gy, const float* wp_bwd, float* gx, int B, int Hx, int Wx, int Hg, int Wg,
                                 int pad_f, int pad_t, hipStream_t stream);
 
+// conv_direct.hip: n small direct correlations (same batch, Cout 1 or 2) in one launch
+int dcs_conv_direct_multi(conv::Args* a, int n, hipStream_t stream);
+
 // conv_mfma.hip
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);
 // split-K scratch (bytes) the launch of this geometry would use; ws / ws_bytes below: that scratch (optional)

@@ -30,14 +30,11 @@ using ConvArgs = conv::Args;
 using conv::gather;
 
 template <int COB>
-__global__ __launch_bounds__(TH * TW) void cconv_direct_kernel(ConvArgs a) {
+__device__ __forceinline__ void cconv_direct_body(const ConvArgs& a, int tile_id, int co0, int b) {
     extern __shared__ __attribute__((aligned(16))) float2 tile[];   // [CHUNK][rows][colsp]
     const int t = threadIdx.x;
     const int tx = t % TW, ty = t / TW;
-    const int tile_id = blockIdx.x;
     const int oy0 = (tile_id / a.tiles_w) * TH, ox0 = (tile_id % a.tiles_w) * TW;
-    const int co0 = blockIdx.y * COB;
-    const int b = blockIdx.z;
     const int Cin = a.C1 + a.C2;
     const int vy0 = oy0 * a.sf - a.pad_f, vx0 = ox0 * a.st - a.pad_t;
 
@@ -83,6 +80,22 @@ __global__ __launch_bounds__(TH * TW) void cconv_direct_kernel(ConvArgs a) {
             out[i] = make_float2(dcs_act(accr[i] + bv.x, a.act), dcs_act(acci[i] + bv.y, a.act));
         }
     }
+}
+
+template <int COB>
+__global__ __launch_bounds__(TH * TW) void cconv_direct_kernel(ConvArgs a) {
+    cconv_direct_body<COB>(a, blockIdx.x, blockIdx.y * COB, blockIdx.z);
+}
+
+// several problems whose Cout == COB (one output-channel block each) in one launch: problem = blockIdx.y
+constexpr int kDirectBatch = 8;
+struct DirectTable { ConvArgs p[kDirectBatch]; };
+
+template <int COB>
+__global__ __launch_bounds__(TH * TW) void cconv_direct_multi_kernel(DirectTable t) {
+    const ConvArgs& a = t.p[blockIdx.y];
+    if ((int)blockIdx.x >= a.tiles_w * a.tiles_h) return;
+    cconv_direct_body<COB>(a, blockIdx.x, 0, blockIdx.z);
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------
@@ -252,6 +265,30 @@ bool conv_geometry(ConvArgs& a) {
     return true;
 }
 
+// n plain correlations with the same batch size and Cout in {1, 2} (the spatial-attention convs and their data
+// gradients) as one launch; `a`: geometry with Hout / Wout set (tiling is filled in here)
+int launch_direct_multi(ConvArgs* a, int n, hipStream_t stream) {
+    if (n < 1 || n > kDirectBatch) return DCS_ERR_BADARG;
+    DirectTable t;
+    size_t lds = 0;
+    int tiles = 0;
+    const int cob = a[0].Cout;
+    for (int i = 0; i < n; ++i) {
+        if (!conv_geometry(a[i]) || a[i].Cout != cob || a[i].B != a[0].B || (cob != 1 && cob != 2)) return DCS_ERR_BADARG;
+        const int Cin = a[i].C1 + a[i].C2;
+        const size_t l = (size_t)(Cin < CHUNK ? Cin : CHUNK) * a[i].plane * sizeof(float2);
+        lds = l > lds ? l : lds;
+        tiles = a[i].tiles_w * a[i].tiles_h > tiles ? a[i].tiles_w * a[i].tiles_h : tiles;
+        t.p[i] = a[i];
+    }
+    if (lds > 64 * 1024 || a[0].B > 65535) return DCS_ERR_BADARG;
+    dim3 grid(tiles, n, a[0].B);
+    if (cob == 1) hipLaunchKernelGGL(cconv_direct_multi_kernel<1>, grid, dim3(TH * TW), lds, stream, t);
+    else hipLaunchKernelGGL(cconv_direct_multi_kernel<2>, grid, dim3(TH * TW), lds, stream, t);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
 int launch_direct(ConvArgs& a, hipStream_t stream) {
     if (!conv_geometry(a)) return DCS_ERR_BADARG;
     const int Cin = a.C1 + a.C2;
@@ -307,6 +344,8 @@ int wgrad_slabs(const ConvArgs& a, long* wsz_out) {
 }
 
 }  // namespace
+
+int dcs_conv_direct_multi(conv::Args* a, int n, hipStream_t stream) { return launch_direct_multi(a, n, stream); }
 
 extern "C" int dcs_pack_conv_weight(const float* w_r, const float* w_i, const float* b_r, const float* b_i, float* wp,
                                     float* bias_out, int Cout, int Cin, int kh, int kw, int transposed, int up_f,

@@ -18,6 +18,15 @@ _L = ctypes.c_long
 _F = ctypes.c_float
 _U64 = ctypes.c_ulonglong
 
+
+
+class AttentionItem(ctypes.Structure):
+    """dcs_attention_item (include/dcsnet_hip.h): one attention block of a batched launch."""
+    _fields_ = [(n, _P) for n in ('x', 'w1', 'w2', 'wsa', 'sa_bias', 'ca', 'pooled', 'hidden', 'sp', 'sa', 'y', 'g_out',
+                                  'wsa_bwd', 'g_pre', 'g_sp', 'g_x', 'g_fc0_r', 'g_fc0_i', 'g_fc2_r', 'g_fc2_i')] + \
+               [(n, _I) for n in ('H', 'W', 'C', 'Ch')]
+
+
 # name -> (restype, argtypes); must mirror include/dcsnet_hip.h exactly
 SIGNATURES = {
     'dcs_abi_version': (_I, []),
@@ -44,6 +53,10 @@ SIGNATURES = {
     'dcs_attention_bwd_sa': (_I, [_P] * 5 + [_I, _L, _I, _F, _U64, _P, _P]),
     'dcs_attention_bwd_workspace_bytes': (_L, [_I, _L, _I, _I]),
     'dcs_attention_bwd_x': (_I, [_P] * 15 + [_L, _I, _L, _I, _I, _F, _U64, _P, _P]),
+    'dcs_attention_fwd_batched_workspace_bytes': (_L, [_I, _P, _I]),
+    'dcs_attention_fwd_batched': (_I, [_I, _P, _P, _L, _I, _P]),
+    'dcs_attention_bwd_batched_workspace_bytes': (_L, [_I, _P, _I]),
+    'dcs_attention_bwd_batched': (_I, [_I, _P, _P, _L, _I, _P]),
     'dcs_lstm_layer_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P]),
     'dcs_lstm_layer_bwd': (_I, [_P] * 5 + [_I] * 4 + [_P]),
     'dcs_dropout_fwd': (_I, [_P, _P, _L, _F, _U64, _P, _P]),

@@ -219,8 +219,9 @@ class C_NETWORK(LightningModule):
             zr = F.dropout(zr, dp, seed)
         d = zr.view(B, F7, T7, C7, 2)
 
+        skips = self._skip_attentions(enc)
         for i in range(L):                                   # c_network.py:207-222
-            skip = self._attend(self.skip_attention[2 * i], self.skip_attention[2 * i + 1], enc[L - i])
+            skip = skips[i]
             stage = self.decoder[i]
             convt = stage if i == L - 1 else stage[0]
             up = tuple(cfg.upsample_scale_factor[i])
@@ -240,6 +241,20 @@ class C_NETWORK(LightningModule):
 
         net_out = F.bound_crm(d.view(B, Fbins, T, 2), hp['atan2_eps'])
         return torch.squeeze(torch.view_as_complex(net_out))          # c_network.py:224
+
+    def _skip_attentions(self, enc):
+        """skip_i = sa_i (.) ca_i (.) enc[L - i] for every decoder stage (c_network.py:208-211).  Each depends on one
+        encoder output only, so all of them run as one batched set of launches (F.attention_blocks); blocks the batched
+        entry does not cover (spatial kernel != 7) fall back to one launch set per block — same HIP kernels."""
+        L = self.hparams['no_of_layers']
+        mods = [(self.skip_attention[2 * i], self.skip_attention[2 * i + 1]) for i in range(L)]
+        if L > F.ATTENTION_BATCH_MAX or any(sa_m.kernel_size != 7 for _, sa_m in mods) or not self.batch_skip_attention:
+            return [self._attend(ca_m, sa_m, enc[L - i]) for i, (ca_m, sa_m) in enumerate(mods)]
+        params = [(ca_m.fc[0].conv_r.weight, ca_m.fc[0].conv_i.weight, ca_m.fc[2].conv_r.weight, ca_m.fc[2].conv_i.weight,
+                   sa_m.conv1.conv_r.weight, sa_m.conv1.conv_i.weight) for ca_m, sa_m in mods]
+        return F.attention_blocks([enc[L - i] for i in range(L)], params, 7)
+
+    batch_skip_attention = True
 
     @staticmethod
     def _attend(ca_m, sa_m, x, drop_p=0.0, seed=0):

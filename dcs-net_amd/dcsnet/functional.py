@@ -82,6 +82,7 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1), tap_rows=0):
     return packed
 
 
+ATTENTION_BATCH_MAX = ops.ATTENTION_BATCH_MAX
 sink_hits = 0          # diagnostics: how many parameter gradients were routed to a sink
 
 
@@ -220,6 +221,67 @@ class _AttentionFn(torch.autograd.Function):
 
 def attention_block(x, fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p=0.0, seed=0):
     return _AttentionFn.apply(x, fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed)
+
+
+class _AttentionBlocksFn(torch.autograd.Function):
+    """Several INDEPENDENT attention blocks (the skip attentions, c_network.py:208-211: each a function of one
+    encoder output only) as one autograd node: forward = one set of five launches for all blocks
+    (dcs_attention_fwd_batched), backward likewise once every block's output gradient has arrived.
+    Inputs: n, ksize, then x_0..x_{n-1}, then six parameters per block (fc.0 r/i, fc.2 r/i, conv1 r/i)."""
+
+    @staticmethod
+    def forward(ctx, n, ksize, *args):
+        xs, params = args[:n], [args[n + 6 * i:n + 6 * i + 6] for i in range(n)]
+        w1s, w2s, wsas, biases = [], [], [], []
+        for fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i in params:
+            w1s.append(packed_weight(fc0_r, fc0_i, None, None, False)[0])
+            w2s.append(packed_weight(fc2_r, fc2_i, None, None, False)[0])
+            wsa, zero_bias = packed_weight(c1_r, c1_i, None, None, False)
+            wsas.append(wsa)
+            biases.append(zero_bias)
+        outs = ops.attention_blocks_fwd(xs, w1s, w2s, wsas, biases)
+        ctx.n, ctx.ksize = n, ksize
+        ctx.sinks = [tuple(_sink(t) for t in pr) for pr in params]
+        ctx.shapes = [(tuple(pr[0].shape), tuple(pr[2].shape)) for pr in params]
+        saved = []
+        for x, o, w1, w2, wsa in zip(xs, outs, w1s, w2s, wsas):
+            saved += [x, o['ca'], o['sa'], o['sp'], o['pooled'], o['hidden'], w1, w2, wsa]
+        ctx.save_for_backward(*saved)
+        return tuple(o['y'] for o in outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        n, ksize = ctx.n, ctx.ksize
+        t = ctx.saved_tensors
+        k, pad = (ksize, ksize), (ksize // 2, ksize // 2)
+        saved, gs, wbs, fcs, sps = [], [], [], [], []
+        for i in range(n):
+            x, ca, sa, sp, pooled, hidden, w1, w2, wsa = t[9 * i:9 * i + 9]
+            saved.append(dict(x=x, ca=ca, sa=sa, pooled=pooled, hidden=hidden, w1=w1, w2=w2))
+            sps.append(sp)
+            g = g_outs[i]
+            gs.append(torch.zeros_like(x) if g is None else g.contiguous())
+            wbs.append(ops.pack_conv_weight_bwd(wsa, k, (1, 1), pad))
+            sk, (s0, s2) = ctx.sinks[i], ctx.shapes[i]
+            new = lambda shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+            fcs.append(tuple(sk[j] if sk[j] is not None else new(s0 if j < 2 else s2) for j in range(4)))
+        res = ops.attention_blocks_bwd(saved, gs, wbs, fcs)
+        grads_x, grads_p = [], []
+        for i in range(n):
+            g_x, g_pre = res[i]
+            sk = ctx.sinks[i]
+            g_c1r, g_c1i, _, _ = ops.cconv2d_bwd_weight(sps[i], None, g_pre, (1, 2, ksize, ksize), False, k, (1, 1), pad,
+                                                        outs=(sk[4], sk[5], None, None))
+            full = (*fcs[i], g_c1r, g_c1i)
+            grads_x.append(g_x)
+            grads_p += [None if s_ is not None else g_ for g_, s_ in zip(full, sk)]
+        return (None, None, *grads_x, *grads_p)
+
+
+def attention_blocks(xs, params, ksize):
+    """params[i] = (fc0_r, fc0_i, fc2_r, fc2_i, conv1_r, conv1_i) of block i; returns the tuple of block outputs."""
+    flat = [p for pr in params for p in pr]
+    return _AttentionBlocksFn.apply(len(xs), ksize, *xs, *flat)
 
 
 # ---- complex-tensor conveniences for the drop-in layer surface ---------------------------------

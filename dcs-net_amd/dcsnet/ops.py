@@ -453,6 +453,70 @@ def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop
     return g_x, g0r, g0i, g2r, g2i, g_c1r, g_c1i
 
 
+ATTENTION_BATCH_MAX = 8
+
+
+def _attention_items(blocks):
+    items = (_lib.AttentionItem * len(blocks))()
+    for it, blk in zip(items, blocks):
+        for k, v in blk.items():
+            setattr(it, k, v if isinstance(v, int) else ptr(v))
+    return items
+
+
+def attention_blocks_fwd(xs, w1s, w2s, wsas, biases):
+    """Several independent attention blocks (no dropout, 7x7 spatial kernel) in one set of launches
+    (dcs_attention_fwd_batched).  xs[i] [B,H_i,W_i,C_i,2]; returns per block (y, ca, pooled, hidden, sp, sa)."""
+    lib = _lib.load()
+    B, dev = xs[0].shape[0], xs[0].device
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    blocks, outs = [], []
+    for x, w1, w2, wsa, bias in zip(xs, w1s, w2s, wsas, biases):
+        _chk(x, 'x', 5)
+        _, H, W, C, _ = x.shape
+        Ch = w1.shape[-2]
+        o = dict(y=torch.empty_like(x), ca=new(B, C, 2), pooled=new(B, C, 2), hidden=new(B, Ch, 2), sp=new(B, H, W, 2, 2),
+                 sa=new(B, H, W, 1, 2))
+        blocks.append(dict(x=x, w1=w1, w2=w2, wsa=wsa, sa_bias=bias, H=H, W=W, C=C, Ch=Ch, **o))
+        outs.append(o)
+    items = _attention_items(blocks)
+    n = len(blocks)
+    nbytes = lib.dcs_attention_fwd_batched_workspace_bytes(n, items, B)
+    if nbytes < 0:
+        raise _lib.DcsHipError('attention_blocks_fwd: unsupported block geometry')
+    ws = _workspace(nbytes, dev)
+    check(lib.dcs_attention_fwd_batched(n, items, ptr(ws), ws.numel(), B, cur_stream()), 'dcs_attention_fwd_batched')
+    return outs
+
+
+def attention_blocks_bwd(saved, g_outs, wsa_bwds, fc_outs):
+    """Backward of attention_blocks_fwd.  saved[i]: dict(x, w1, w2, ca, pooled, hidden, sa) of block i; fc_outs[i]: the four
+    FC weight-gradient destinations.  Returns per block (g_x, g_pre); the 7x7 conv's weight gradient is the caller's
+    (cconv2d_bwd_weight(sp, g_pre))."""
+    lib = _lib.load()
+    B, dev = g_outs[0].shape[0], g_outs[0].device
+    blocks, res = [], []
+    for sv, g, wb, fo in zip(saved, g_outs, wsa_bwds, fc_outs):
+        _chk(g, 'g_out', 5)
+        x = sv['x']
+        _, H, W, C, _ = x.shape
+        g_pre = torch.empty((B, H, W, 1, 2), dtype=torch.float32, device=dev)
+        g_sp = torch.empty((B, H, W, 2, 2), dtype=torch.float32, device=dev)
+        g_x = torch.empty_like(x)
+        blocks.append(dict(x=x, w1=sv['w1'], w2=sv['w2'], ca=sv['ca'], pooled=sv['pooled'], hidden=sv['hidden'], sa=sv['sa'],
+                           g_out=g, wsa_bwd=wb, g_pre=g_pre, g_sp=g_sp, g_x=g_x, g_fc0_r=fo[0], g_fc0_i=fo[1], g_fc2_r=fo[2],
+                           g_fc2_i=fo[3], H=H, W=W, C=C, Ch=sv['hidden'].shape[1]))
+        res.append((g_x, g_pre))
+    items = _attention_items(blocks)
+    n = len(blocks)
+    nbytes = lib.dcs_attention_bwd_batched_workspace_bytes(n, items, B)
+    if nbytes < 0:
+        raise _lib.DcsHipError('attention_blocks_bwd: unsupported block geometry')
+    ws = _workspace(nbytes, dev)
+    check(lib.dcs_attention_bwd_batched(n, items, ptr(ws), ws.numel(), B, cur_stream()), 'dcs_attention_bwd_batched')
+    return res
+
+
 def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False):
     """Recurrent half of one LSTM layer for every (set, sequence, direction); see dcs_lstm_layer_fwd.
     gx: float pre-activations addressed by `strides` = (stride_set, stride_n, stride_t) in floats;

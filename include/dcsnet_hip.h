@@ -221,6 +221,27 @@ int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, fl
                             int B, long HW, int C, float drop_p, unsigned long long seed,
                             const unsigned long long* seed_dev, dcs_stream_t stream);
 
+/* Several attention blocks in one set of launches.  The seven skip attentions of the network (c_network.py:208-211)
+ * depend only on the encoder outputs — and their backward pass only on the decoder's — so the forward runs all of
+ * them in five launches right after the encoder and the backward in five right before the encoder's backward,
+ * instead of 5 (6) dependent launches of 5-10 us per block.  One item per block; no dropout on this path; 7x7
+ * spatial kernel; n <= 8.  Forward reads x, w1, w2, wsa (+ its zero bias) and writes ca, pooled, hidden, sp, sa, y
+ * (shapes as in the per-block entry points).  Backward additionally reads g_out, wsa_bwd and writes g_pre, g_sp, g_x and
+ * the four FC weight gradients; the 7x7 conv's own weight gradient stays with dcs_cconv2d_bwd_weight(sp, g_pre). */
+typedef struct {
+    const float* x; const float* w1; const float* w2; const float* wsa; const float* sa_bias;
+    float* ca; float* pooled; float* hidden; float* sp; float* sa; float* y;
+    const float* g_out; const float* wsa_bwd; float* g_pre; float* g_sp; float* g_x;
+    float* g_fc0_r; float* g_fc0_i; float* g_fc2_r; float* g_fc2_i;
+    int H, W, C, Ch;
+} dcs_attention_item;
+long dcs_attention_fwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B);
+int dcs_attention_fwd_batched(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
+                              dcs_stream_t stream);
+long dcs_attention_bwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B);
+int dcs_attention_bwd_batched(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
+                              dcs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Backward of the fused attention block  out = dropout(sa (.) ca (.) x)  built from the four
  * forward entry points above (channel attention -> spatial pool -> 7x7 conv + sigmoid -> apply).

@@ -195,6 +195,39 @@ def test_attention_block_backward(dev, C, hw, relu_in):
         close(ps[n].grad, q.grad, rel=2e-4, what=n)
 
 
+def test_attention_blocks_batched(dev):
+    """The batched entry (all skip attentions in one set of launches) against the CPU oracle, block by block:
+    different channel counts and plane sizes share the launches, including a ReLU input with arg-max ties."""
+    from dcsnet import functional as F
+    geo = [(128, (2, 8), True), (64, (6, 10), False), (8, (20, 12), True), (16, (9, 5), True), (32, (4, 4), False)]
+    xs, params, want = [], [], []
+    for C, hw, relu_in in geo:
+        torch.manual_seed(C + 7)
+        ca_m, sa_m = cno.ComplexChannelAttention(C, 16 if C >= 16 else 4), cno.ComplexSpatialAttention(7)
+        x0 = rand_c((3, C, *hw), C + 3)
+        if relu_in:
+            x0 = cpt.complex_relu(x0)
+        x = x0.clone().requires_grad_(True)
+        z = ca_m(x) * x
+        out = sa_m(z) * z
+        functional_loss(out, C).backward()
+        pc, ps = dev_params(ca_m, dev), dev_params(sa_m, dev)
+        xs.append(nhwc_leaf(x0, dev))
+        params.append((pc['fc.0.conv_r.weight'], pc['fc.0.conv_i.weight'], pc['fc.2.conv_r.weight'], pc['fc.2.conv_i.weight'],
+                       ps['conv1.conv_r.weight'], ps['conv1.conv_i.weight']))
+        want.append((out, x, ca_m, sa_m, pc, ps))
+    ys = F.attention_blocks(xs, params, 7)
+    total = sum(functional_loss(F.from_nhwc(y), g[0]) for y, g in zip(ys, geo))
+    total.backward()
+    for i, (out, x, ca_m, sa_m, pc, ps) in enumerate(want):
+        close(F.from_nhwc(ys[i]), out, rel=2e-5, what=f'forward {i}')
+        close(cgrad(xs[i]), x.grad, rel=2e-4, what=f'g_x {i}')
+        for n, q in ca_m.named_parameters():
+            close(pc[n].grad, q.grad, rel=2e-4, what=f'{i} {n}')
+        for n, q in sa_m.named_parameters():
+            close(ps[n].grad, q.grad, rel=2e-4, what=f'{i} {n}')
+
+
 # --------------------------------------------------------------------------------- LSTM, mask
 
 @pytest.mark.parametrize('B,S', [(2, 8), (3, 40), (1, 1)])
