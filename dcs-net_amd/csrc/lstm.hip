@@ -25,8 +25,9 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 template <bool SAVE>
 __global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
                                                            float* __restrict__ out, float* __restrict__ gates_save,
-                                                           float* __restrict__ c_save, int S, int seqs_per_set,
-                                                           long stride_set, long stride_n, long stride_t) {
+                                                           float* __restrict__ c_save, float* __restrict__ hprev_save,
+                                                           int S, int seqs_per_set, long stride_set, long stride_n,
+                                                           long stride_t) {
     __shared__ __attribute__((aligned(16))) float h_s[H];
     __shared__ float g_s[G4];
     const int j = threadIdx.x;
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restric
             const float ig = g_s[j], fg = g_s[H + j], gg = g_s[2 * H + j], og = g_s[3 * H + j];
             c = fmaf(fg, c, ig * gg);
             const float h = og * tanhf(c);
+            if (SAVE && hprev_save) hprev_save[(((long)n * S + t) * 2 + dir) * H + j] = h_s[j];   // state BEFORE this step
             h_s[j] = h;
             out[((long)n * S + t) * (2 * H) + dir * H + j] = h;
             if (SAVE) c_save[(((long)n * S + t) * 2 + dir) * H + j] = c;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(G4) void lstm_rec_bwd_kernel(const float* __restrict__ g_out,
                                                            const float* __restrict__ gates, const float* __restrict__ cs,
                                                            const float* __restrict__ whh, float* __restrict__ g_pre,
-                                                           int S, int seqs_per_set) {
+                                                           float* __restrict__ g_bias_part, int S, int seqs_per_set) {
     __shared__ float gp_s[G4];
     __shared__ float gh_s[H];
     const int j = threadIdx.x;
@@ -106,24 +108,41 @@ __global__ __launch_bounds__(G4) void lstm_rec_bwd_kernel(const float* __restric
     const int t0 = dir ? S - 1 : 0, dt = dir ? -1 : 1;
     float gc_rec = 0.f;
     if (j < H) gh_s[j] = 0.f;
+    // operands of the step about to run; the next step's are fetched while this one computes (none of them depends on
+    // the recurrence, and left in the loop body their ~1 us of dependent global-load latency is paid S times)
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cp = 0.f, go = 0.f;
+    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;                  // bias gradient of this (sequence, direction)
+    auto fetch = [&](int s_, float& i_, float& f_, float& g_, float& o_, float& cp_, float& go_) {
+        const int t_ = t0 + s_ * dt;
+        const long gb_ = (((long)n * S + t_) * 2 + dir) * G4;
+        i_ = gates[gb_ + j]; f_ = gates[gb_ + H + j]; g_ = gates[gb_ + 2 * H + j]; o_ = gates[gb_ + 3 * H + j];
+        cp_ = s_ > 0 ? cs[(((long)n * S + (t_ - dt)) * 2 + dir) * H + j] : 0.f;
+        go_ = g_out[((long)n * S + t_) * (2 * H) + dir * H + j];
+    };
+    if (j < H) {
+        fetch(S - 1, ig, fg, gg, og, cp, go);
+        c = cs[(((long)n * S + (t0 + (S - 1) * dt)) * 2 + dir) * H + j];
+    }
     __syncthreads();
     for (int s = S - 1; s >= 0; --s) {
         const int t = t0 + s * dt;
+        float n_ig = 0.f, n_fg = 0.f, n_gg = 0.f, n_og = 0.f, n_cp = 0.f, n_go = 0.f;
         if (j < H) {
+            if (s > 0) fetch(s - 1, n_ig, n_fg, n_gg, n_og, n_cp, n_go);
             const long gb = (((long)n * S + t) * 2 + dir) * G4;
-            const float ig = gates[gb + j], fg = gates[gb + H + j], gg = gates[gb + 2 * H + j], og = gates[gb + 3 * H + j];
-            const float c = cs[(((long)n * S + t) * 2 + dir) * H + j];
-            const float cp = s > 0 ? cs[(((long)n * S + (t - dt)) * 2 + dir) * H + j] : 0.f;
             const float tc = tanhf(c);
-            const float gh = g_out[((long)n * S + t) * (2 * H) + dir * H + j] + gh_s[j];
+            const float gh = go + gh_s[j];
             const float gc = gh * og * (1.f - tc * tc) + gc_rec;
             const float pi = gc * gg * ig * (1.f - ig);
             const float pf = gc * cp * fg * (1.f - fg);
             const float pg = gc * ig * (1.f - gg * gg);
             const float po = gh * tc * og * (1.f - og);
             gc_rec = gc * fg;
+            sb0 += pi; sb1 += pf; sb2 += pg; sb3 += po;
             gp_s[j] = pi; gp_s[H + j] = pf; gp_s[2 * H + j] = pg; gp_s[3 * H + j] = po;
             g_pre[gb + j] = pi; g_pre[gb + H + j] = pf; g_pre[gb + 2 * H + j] = pg; g_pre[gb + 3 * H + j] = po;
+            c = cp;                                                    // c_{t-1} of this step is c_t of the next one
+            ig = n_ig; fg = n_fg; gg = n_gg; og = n_og; cp = n_cp; go = n_go;
         }
         __syncthreads();
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -143,22 +162,27 @@ __global__ __launch_bounds__(G4) void lstm_rec_bwd_kernel(const float* __restric
         if (part == 0) gh_s[k] = a;
         __syncthreads();
     }
+    if (g_bias_part && j < H) {
+        float* bp = g_bias_part + (long)blockIdx.x * G4;               // [n][dir][4H]
+        bp[j] = sb0; bp[H + j] = sb1; bp[2 * H + j] = sb2; bp[3 * H + j] = sb3;
+    }
 }
 
 }  // namespace
 
 extern "C" int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_save, const float* w_hh,
-                                  float* g_pre, int n_sets, int seqs_per_set, int S, int Hdim, dcs_stream_t stream) {
+                                  float* g_pre, float* g_bias_part, int n_sets, int seqs_per_set, int S, int Hdim,
+                                  dcs_stream_t stream) {
     if (!g_out || !gates || !c_save || !w_hh || !g_pre || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || Hdim != H)
         return DCS_ERR_BADARG;
     hipLaunchKernelGGL(lstm_rec_bwd_kernel, dim3(n_sets * seqs_per_set * 2), dim3(G4), 0, dcs_stream(stream), g_out,
-                       gates, c_save, w_hh, g_pre, S, seqs_per_set);
+                       gates, c_save, w_hh, g_pre, g_bias_part, S, seqs_per_set);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
 
 extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
-                                  int n_sets, int seqs_per_set, int S, int Hdim, long stride_set, long stride_n,
+                                  float* hprev_save, int n_sets, int seqs_per_set, int S, int Hdim, long stride_set, long stride_n,
                                   long stride_t, dcs_stream_t stream) {
     if (!gx || !w_hh || !out || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || Hdim != H) return DCS_ERR_BADARG;
     if ((gates_save == nullptr) != (c_save == nullptr)) return DCS_ERR_BADARG;
@@ -166,10 +190,10 @@ extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out
     dim3 grid(NS * 2);
     if (gates_save)
         hipLaunchKernelGGL(lstm_rec_fwd_kernel<true>, grid, dim3(G4), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
-                           c_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
     else
         hipLaunchKernelGGL(lstm_rec_fwd_kernel<false>, grid, dim3(G4), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
-                           c_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

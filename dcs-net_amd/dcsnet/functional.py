@@ -381,35 +381,63 @@ class _LstmLayerFn(torch.autograd.Function):
         gx = torch.baddbmm(bias.unsqueeze(1), inp, w_ih.transpose(1, 2))          # (set, n*t, dir*4H)
         G4 = gx.shape[-1] // 2
         need = inp.requires_grad or anchor.requires_grad
-        out, gates, c = ops.lstm_layer(gx, w_hh, 2, B2, S, (B2 * S * 2 * G4, S * 2 * G4, 2 * G4), need)
+        out, gates, c, hprev = ops.lstm_layer(gx, w_hh, 2, B2, S, (B2 * S * 2 * G4, S * 2 * G4, 2 * G4), need, True)
         ctx.st, ctx.dims = st, (B2, S)
         if need:
-            ctx.save_for_backward(inp, out, gates, c)
+            ctx.save_for_backward(inp, hprev, gates, c)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         global sink_hits
-        inp, out, gates, c = ctx.saved_tensors
+        inp, hprev, gates, c = ctx.saved_tensors
         st, (B2, S) = ctx.st, ctx.dims
         w_ih, w_hh = st['weight_ih'][0], st['weight_hh'][0]
         H = w_hh.shape[-1]
-        g_pre = ops.lstm_layer_bwd(g_out.contiguous(), gates, c, w_hh, 2, B2, S)
-        g_pre5 = g_pre.view(2, B2, S, 2, 4 * H)
-        o = out.view(2, B2, S, 2, H)
-        h_prev = torch.zeros_like(o)
-        h_prev[:, :, 1:, 0] = o[:, :, :-1, 0]               # forward direction: h_{t-1}
-        h_prev[:, :, :-1, 1] = o[:, :, 1:, 1]               # reverse direction: h_{t+1}
-        st['weight_hh'][1].add_(torch.einsum('sntdj,sntdk->sdjk', g_pre5, h_prev))
-        g_gx = g_pre.view(2, B2 * S, 8 * H)
-        g_b = g_gx.sum(1)
+        NT = B2 * S
+        g_pre, b_part = ops.lstm_layer_bwd(g_out.contiguous(), gates, c, w_hh, 2, B2, S, True)
+        # W_hh gradient per direction d: g_pre[set, (n t), d, :]^T h_prev[set, (n t), d, :] — strided views, no copies
+        # (n t) is cut into CK chunks that ride the batch axis (rocBLAS runs a [4H x H] output with K = 4096 on 16
+        # workgroups otherwise), summed afterwards in a fixed order
+        CK = 16 if NT % 16 == 0 else 1
+        R = NT // CK
+        part = torch.empty((2, 2 * CK, 4 * H, H), dtype=g_pre.dtype, device=g_pre.device)
+        for d in range(2):
+            a = g_pre.as_strided((2 * CK, R, 4 * H), (R * 8 * H, 8 * H, 1), g_pre.storage_offset() + d * 4 * H)
+            h = hprev.as_strided((2 * CK, R, H), (R * 2 * H, 2 * H, 1), hprev.storage_offset() + d * H)
+            torch.bmm(a.transpose(1, 2), h, out=part[d])
+        st['weight_hh'][1].add_(part.view(2, 2, CK, 4 * H, H).sum(2).transpose(0, 1))
+        g_b = b_part.view(2, B2, 8 * H).sum(1)
         st['bias_ih'][1].add_(g_b)
         st['bias_hh'][1].add_(g_b)
+        g_gx = g_pre.view(2, NT, 8 * H)
         g_wih = st['weight_ih'][1]
         torch.baddbmm(g_wih, g_gx.transpose(1, 2), inp, out=g_wih)      # accumulate in place
         sink_hits += 16
         g_inp = torch.bmm(g_gx, w_ih) if ctx.needs_input_grad[0] else None
         return g_inp, None, None, None, None
+
+
+class _LstmCombineFn(torch.autograd.Function):
+    """real = L_r(x_r) - L_i(x_i), imag = L_r(x_i) + L_i(x_r) (c_network.py:43-46) from the stacked outputs
+    o[set, {re rows | im rows}]: three launches forward, three backward (autograd's slice / complex / sub graph
+    costs ~20 fill / copy / add launches in backward)."""
+
+    @staticmethod
+    def forward(ctx, o, B):
+        ctx.B = B
+        rr, ir, ri, ii = o[0, :B], o[0, B:], o[1, :B], o[1, B:]
+        return torch.complex(rr - ii, ir + ri)
+
+    @staticmethod
+    def backward(ctx, g):
+        B = ctx.B
+        g2 = torch.view_as_real(g if g.is_contiguous() else g.contiguous())      # [B, S, 2H, 2]
+        g_o = torch.empty((2, 2, *g2.shape[:-1]), dtype=g2.dtype, device=g2.device)   # [set, re|im rows, B, S, 2H]
+        g_o[0].copy_(g2.permute(3, 0, 1, 2))               # L_r: rows re <- g.real, rows im <- g.imag
+        g_o[1, 0].copy_(g2[..., 1])                        # L_i(x_r) <- g.imag
+        torch.neg(g2[..., 0], out=g_o[1, 1])               # L_i(x_i) <- -g.real
+        return g_o.view(2, 2 * B, *g2.shape[1:-1]), None
 
 
 def _stacked_lstm(real_lstm):
@@ -453,6 +481,8 @@ def complex_lstm(z, real_lstm, imag_lstm):
         out = _LstmRecFn.apply(gx.view(2, 2 * B, S, 2, -1), w_hh.contiguous())    # [2*2B, S, 2H]
         inp = out.view(2, 2 * B * S, -1)
     o = inp.view(2, 2 * B, S, -1)
+    if torch.is_grad_enabled() and o.requires_grad:
+        return _LstmCombineFn.apply(o, B)
     rr, ir = o[0, :B], o[0, B:]            # real_lstm(re), real_lstm(im)
     ri, ii = o[1, :B], o[1, B:]            # imag_lstm(re), imag_lstm(im)
     return torch.complex(rr - ii, ir + ri)

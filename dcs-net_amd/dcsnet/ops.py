@@ -517,10 +517,10 @@ def attention_blocks_bwd(saved, g_outs, wsa_bwds, fc_outs):
     return res
 
 
-def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False):
+def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False, save_hprev=False):
     """Recurrent half of one LSTM layer for every (set, sequence, direction); see dcs_lstm_layer_fwd.
     gx: float pre-activations addressed by `strides` = (stride_set, stride_n, stride_t) in floats;
-    w_hh: float [n_sets, 2, 4H, H].  Returns (out [n_sets*seqs_per_set, S, 2H], gates, c)."""
+    w_hh: float [n_sets, 2, 4H, H].  Returns (out [n_sets*seqs_per_set, S, 2H], gates, c[, hprev])."""
     _chk(gx, 'gx')
     _chk(w_hh, 'w_hh', 4)
     H = w_hh.shape[-1]
@@ -528,20 +528,23 @@ def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False):
     out = torch.empty((NS, S, 2 * H), dtype=torch.float32, device=gx.device)
     gates = torch.empty((NS, S, 2, 4 * H), dtype=torch.float32, device=gx.device) if save else None
     c = torch.empty((NS, S, 2, H), dtype=torch.float32, device=gx.device) if save else None
-    check(_lib.load().dcs_lstm_layer_fwd(ptr(gx), ptr(w_hh), ptr(out), ptr(gates), ptr(c), n_sets, seqs_per_set, S, H,
-                                         strides[0], strides[1], strides[2], cur_stream()), 'dcs_lstm_layer_fwd')
-    return out, gates, c
+    hprev = torch.empty((NS, S, 2, H), dtype=torch.float32, device=gx.device) if save and save_hprev else None
+    check(_lib.load().dcs_lstm_layer_fwd(ptr(gx), ptr(w_hh), ptr(out), ptr(gates), ptr(c), ptr(hprev), n_sets, seqs_per_set,
+                                         S, H, strides[0], strides[1], strides[2], cur_stream()), 'dcs_lstm_layer_fwd')
+    return (out, gates, c, hprev) if save_hprev else (out, gates, c)
 
 
-def lstm_layer_bwd(g_out, gates, c, w_hh, n_sets, seqs_per_set, S):
+def lstm_layer_bwd(g_out, gates, c, w_hh, n_sets, seqs_per_set, S, bias_part=False):
+    """-> g_pre [NS,S,2,4H] (and, bias_part=True, its per-(sequence, direction) time sums [NS,2,4H])."""
     _chk(g_out, 'g_out', 3)
     _chk(gates, 'gates', 4)
     _chk(c, 'c', 4)
     _chk(w_hh, 'w_hh', 4)
     g_pre = torch.empty_like(gates)
-    check(_lib.load().dcs_lstm_layer_bwd(ptr(g_out), ptr(gates), ptr(c), ptr(w_hh), ptr(g_pre), n_sets, seqs_per_set, S,
-                                         w_hh.shape[-1], cur_stream()), 'dcs_lstm_layer_bwd')
-    return g_pre
+    part = torch.empty((gates.shape[0], 2, gates.shape[-1]), dtype=torch.float32, device=gates.device) if bias_part else None
+    check(_lib.load().dcs_lstm_layer_bwd(ptr(g_out), ptr(gates), ptr(c), ptr(w_hh), ptr(g_pre), ptr(part), n_sets,
+                                         seqs_per_set, S, w_hh.shape[-1], cur_stream()), 'dcs_lstm_layer_bwd')
+    return (g_pre, part) if bias_part else g_pre
 
 
 def dropout(x, drop_p, seed, out=None):

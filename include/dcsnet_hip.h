@@ -274,16 +274,20 @@ int  dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, co
  *   out    float[n_sets*seqs_per_set][S][2H]   ([.., dir*H + u]: forward half then reverse half)
  *   gates_save / c_save  NULL for inference; else float[NS][S][2][4H] (post-activation gates) and
  *          float[NS][S][2][H] (cell state) saved for dcs_lstm_layer_bwd.
+ *   hprev_save  optional (NULL, or with gates_save): float[NS][S][2][H], the hidden state each step STARTED from
+ *          (h_{t-1} forward, h_{t+1} reverse, zero at the sequence ends) = the right-hand operand of the W_hh gradient.
  * H must be 64 (hparams channels[4]//2, config.py:35). */
 int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
-                       int n_sets, int seqs_per_set, int S, int H, long stride_set, long stride_n, long stride_t,
+                       float* hprev_save, int n_sets, int seqs_per_set, int S, int H, long stride_set, long stride_n, long stride_t,
                        dcs_stream_t stream);
 
 /* Backward through time of dcs_lstm_layer_fwd: from g_out float[NS][S][2H] (cotangent of `out`) and
  * the saved gates / cell states, writes the pre-activation cotangents g_pre float[NS][S][2][4H].
- * The caller's plain GEMMs turn g_pre into the gradients of x, W_ih, both biases and W_hh. */
+ * The caller's plain GEMMs turn g_pre into the gradients of x, W_ih and W_hh.  g_bias_part (optional):
+ * float[NS][2][4H], g_pre summed over the time steps of each (sequence, direction); summing it over a set's
+ * sequences gives that set's bias gradient. */
 int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_save, const float* w_hh,
-                       float* g_pre, int n_sets, int seqs_per_set, int S, int H, dcs_stream_t stream);
+                       float* g_pre, float* g_bias_part, int n_sets, int seqs_per_set, int S, int H, dcs_stream_t stream);
 
 /* Stand-alone inverted dropout on a real view (c_network.py:203-204 dropout_fc after the
  * ComplexLinear; c_network.py:221-222 on the last decoder stage, which has no attention to

@@ -171,8 +171,9 @@ def test_backward_kernels_write_into_the_flat_gradient_bucket(dev):
     assert functional.sink_hits - before > 150          # ~190 conv / CBN / attention parameter tensors
     b = grads(False)
     assert a.keys() == b.keys()
-    for n in a:
-        assert torch.allclose(a[n], b[n], rtol=1e-5, atol=1e-7), n
+    for n in a:           # same math, different fp32 summation order in places (LSTM bias: per-sequence partial sums)
+        scale = float(b[n].abs().max())
+        assert float((a[n] - b[n]).abs().max()) <= 2e-5 * scale + 1e-7, n
 
 
 def test_pack_plan_step_is_bit_identical_to_per_layer_packing(dev):

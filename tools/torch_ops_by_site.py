@@ -1,9 +1,12 @@
-"""Which lines of dcsnet/ launch the torch-side (ATen) kernels of one eager train step: aten op -> call site counts.
+"""Which lines of dcsnet/ run torch-side (ATen) ops during one eager train step: (aten op, call site) -> count.
+A TorchDispatchMode sees every ATen call (forward thread and, through the propagated thread-local state, autograd's
+backward thread) and the Python stack gives the dcsnet/ line that issued it.
 usage (GPU box): python tools/torch_ops_by_site.py"""
-import os, sys, collections, torch
+import os, sys, collections, traceback, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'dcs-net_amd'))
 sys.argv = [sys.argv[0]]
+from torch.utils._python_dispatch import TorchDispatchMode
 from dcsnet.config import config, hparams
 from dcsnet.c_network import C_NETWORK
 from dcsnet.dp import TrainStep
@@ -16,17 +19,28 @@ batch = (noise, noisy, clean, list(range(32)))
 for _ in range(3):
     ts(batch)
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+SKIP = ('aten.view', 'aten.empty', 'aten._unsafe_view', 'aten.detach', 'aten.as_strided', 'aten.select', 'aten.slice',
+        'aten.unsqueeze', 'aten.squeeze', 'aten.permute', 'aten.transpose', 'aten.t.', 'aten.expand', 'aten.alias',
+        'aten.view_as_real', 'aten.view_as_complex', 'aten.reshape', 'aten.unbind', 'aten.split', 'aten.narrow',
+        'aten.lift_fresh', 'aten._reshape_alias', 'aten.is_', 'aten.sym_', 'aten.stride', 'aten.size', 'aten.numel',
+        'aten.real', 'aten.imag', 'aten.empty_like', 'aten.new_empty', 'aten.unfold', 'aten.result_type')
+sites = collections.Counter()
+
+
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(SKIP):
+            st = traceback.extract_stack()
+            site = next((f'{os.path.basename(f.filename)}:{f.lineno} {f.name}' for f in reversed(st)
+                         if ('dcsnet' in f.filename or 'bench.py' in f.filename)), 'autograd engine (accumulate)')
+            sites[(name, site)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Log():
     ts(batch)
     torch.cuda.synchronize()
-sites = collections.Counter()
-for ev in prof.events():
-    if not ev.name.startswith('aten::') or ev.device_time_total <= 0 and not ev.kernels:
-        continue
-    if not ev.kernels:
-        continue
-    site = next((s for s in ev.stack if 'dcsnet' in s or 'bench.py' in s), ev.stack[0] if ev.stack else '?')
-    sites[(ev.name, site.split('dcs-net_amd/')[-1][:90])] += len(ev.kernels)
-for (name, site), n in sites.most_common(70):
-    print(f'{n:4d}  {name:28s} {site}')
+for (name, site), n in sorted(sites.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+    print(f'{n:4d}  {name:34s} {site}')
+print(sum(sites.values()), 'ATen calls')
