@@ -202,21 +202,24 @@ __device__ __forceinline__ void ca_bwd_sample_kernel_body(const double* __restri
     }
 }
 
-// Weight half (one thread per weight element, sums over the batch):
+// Weight half (kWLanes lanes per weight element, each summing a strided share of the batch; shuffle reduction):
 //   g_w2[h][c] = sum_b g_o conj(relu(h)) ;  g_w1[c][h] = sum_b g_h conj(pooled)
-// The batch loop is unrolled so that its loads are issued together: a handful of threads on four dependent
-// loads per item is otherwise a chain of ~B memory round trips.
+// One thread per element is a chain of ~B dependent memory round trips (15-20 us on its own once nothing hides it).
 struct CaWeightArgs {
     const float2* go; const float2* gh; const float2* pooled; const float2* hidden;
     float* g_fc0_r; float* g_fc0_i; float* g_fc2_r; float* g_fc2_i;
     int B, C, Ch;
 };
 
-__device__ __forceinline__ void ca_bwd_weight_element(const CaWeightArgs& w, int i) {
-    const int c = i / w.Ch, h = i % w.Ch;
+constexpr int kWLanes = 32;
+
+// gi: global thread index inside the weight half; all 64 lanes of a wave enter (two elements per wave)
+__device__ __forceinline__ void ca_bwd_weight_element(const CaWeightArgs& w, int gi) {
+    const int i = gi / kWLanes, sub = gi % kWLanes;
+    const bool live = i < w.C * w.Ch;
+    const int c = live ? i / w.Ch : 0, h = live ? i % w.Ch : 0;
     float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < w.B; ++b) {
+    for (int b = sub; live && b < w.B; b += kWLanes) {
         const float2 g = w.go[(long)b * w.C + c];
         float2 hv = w.hidden[(long)b * w.Ch + h];
         hv.x = hv.x > 0.f ? hv.x : 0.f; hv.y = hv.y > 0.f ? hv.y : 0.f;
@@ -224,6 +227,12 @@ __device__ __forceinline__ void ca_bwd_weight_element(const CaWeightArgs& w, int
         const float2 q = w.gh[(long)b * w.Ch + h], p = w.pooled[(long)b * w.C + c];
         br += q.x * p.x + q.y * p.y; bi += q.y * p.x - q.x * p.y;
     }
+#pragma unroll
+    for (int o = kWLanes / 2; o > 0; o >>= 1) {
+        ar += __shfl_xor(ar, o, 64); ai += __shfl_xor(ai, o, 64);
+        br += __shfl_xor(br, o, 64); bi += __shfl_xor(bi, o, 64);
+    }
+    if (!live || sub != 0) return;
     w.g_fc2_r[c * w.Ch + h] = ar;                             // fc.2 weight [C][Ch][1][1]
     w.g_fc2_i[c * w.Ch + h] = ai;
     w.g_fc0_r[h * w.C + c] = br;                              // fc.0 weight [Ch][C][1][1]
@@ -235,8 +244,7 @@ __device__ __forceinline__ void ca_bwd_weight_element(const CaWeightArgs& w, int
 __device__ __forceinline__ void att_bwd_pool_kernel_body(float* __restrict__ gx, const float* __restrict__ gpooled,
                                                                  long HW, int G, float inv_hw, int nx_pool, CaWeightArgs w, int vbx, int vby, int vgx) {
     if ((int)vbx >= nx_pool) {
-        const int i = ((int)vbx - nx_pool) * kThreads + threadIdx.x;
-        if (vby == 0 && i < w.C * w.Ch) ca_bwd_weight_element(w, i);
+        if (vby == 0) ca_bwd_weight_element(w, ((int)vbx - nx_pool) * kThreads + threadIdx.x);
         return;
     }
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
@@ -336,8 +344,9 @@ extern "C" long dcs_attention_bwd_workspace_bytes(int B, long HW, int C, int Ch)
 extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, const float* sa,
                                    const float* g_sp, const float* pooled, const float* hidden, const float* w1,
                                    const float* w2, float* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r,
-                                   float* g_fc2_i, void* workspace, long workspace_bytes, int B, long HW, int C, int Ch,
-                                   float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
+                                   float* g_fc2_i, float* g_pooled, void* workspace, long workspace_bytes, int B, long HW,
+                                   int C, int Ch, float drop_p, unsigned long long seed,
+                                   const unsigned long long* seed_dev, dcs_stream_t stream) {
     int G;
     if (!x || !g_out || !ca || !sa || !g_sp || !pooled || !hidden || !w1 || !w2 || !g_x || !g_fc0_r || !g_fc0_i ||
         !g_fc2_r || !g_fc2_i || !workspace)
@@ -350,7 +359,8 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
     double* part = (double*)workspace;
     float2* go = (float2*)((char*)workspace + part_bytes);
     float2* gh = go + (long)B * C;
-    float2* gpooled = gh + (long)B * Ch;
+    // g_pooled given: the caller's consumer adds g_pooled / HW to g_x (dcs_cbn_bwd_add), saving the read-modify-write pass
+    float2* gpooled = g_pooled ? (float2*)g_pooled : gh + (long)B * Ch;
     hipStream_t s = dcs_stream(stream);
     dim3 grid(nch, B);
     const BwdXP xp{x, g_out, ca, (const float2*)sa, (const float4*)g_sp, g_x, part, HW, C, G, nch};
@@ -367,10 +377,10 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
     cw.go = go; cw.gh = gh; cw.pooled = (const float2*)pooled; cw.hidden = (const float2*)hidden;
     cw.g_fc0_r = g_fc0_r; cw.g_fc0_i = g_fc0_i; cw.g_fc2_r = g_fc2_r; cw.g_fc2_i = g_fc2_i;
     cw.B = B; cw.C = C; cw.Ch = Ch;
-    const int nx_pool = stream_grid(HW, G, B);
-    const int nxw = nx_pool + (C * Ch + kThreads - 1) / kThreads;
+    const int nx_pool = g_pooled ? 0 : stream_grid(HW, G, B);
+    const int nxw = nx_pool + (C * Ch * kWLanes + kThreads - 1) / kThreads;
     const PoolP pp{g_x, (const float*)gpooled, HW, G, 1.f / (float)HW, nx_pool, nxw, cw};
-    hipLaunchKernelGGL(att_bwd_pool_kernel, dim3(nxw, B), dim3(kThreads), 0, s, pp);
+    hipLaunchKernelGGL(att_bwd_pool_kernel, dim3(nxw, g_pooled ? 1 : B), dim3(kThreads), 0, s, pp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -423,7 +433,7 @@ extern "C" int dcs_attention_bwd_batched(int n, const dcs_attention_item* items,
         cw.go = go; cw.gh = gh; cw.pooled = (const float2*)it.pooled; cw.hidden = (const float2*)it.hidden;
         cw.g_fc0_r = it.g_fc0_r; cw.g_fc0_i = it.g_fc0_i; cw.g_fc2_r = it.g_fc2_r; cw.g_fc2_i = it.g_fc2_i;
         cw.B = B; cw.C = it.C; cw.Ch = it.Ch;
-        const int nxw = nxs + (it.C * it.Ch + kThreads - 1) / kThreads;
+        const int nxw = nxs + (it.C * it.Ch * kWLanes + kThreads - 1) / kThreads;
         tp.p[i] = PoolP{it.g_x, (const float*)gpooled, HW, G, 1.f / (float)HW, nxs, nxw, cw};
         nx_sa = nxs > nx_sa ? nxs : nx_sa;
         nx_x = nch > nx_x ? nch : nx_x;

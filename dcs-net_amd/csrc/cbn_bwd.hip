@@ -49,6 +49,12 @@ __device__ __forceinline__ float2 grad_y(const Chan& k, float xr, float xi, floa
     return make_float2(dact<ACT>(yr, gr), dact<ACT>(yi, gi));
 }
 
+// g_out + scale * (per-sample, per-channel constant): the broadcast half of an average pool's backward, folded into
+// the consumer instead of a read-modify-write pass over g_out (dcs_cbn_bwd_add)
+__device__ __forceinline__ void add_sample(float4& g, const float4 a, float scale) {
+    g.x = fmaf(a.x, scale, g.x); g.y = fmaf(a.y, scale, g.y); g.z = fmaf(a.z, scale, g.z); g.w = fmaf(a.w, scale, g.w);
+}
+
 __device__ __forceinline__ void acc6(float* s, float2 gy, float u, float v) {
     s[0] += gy.x; s[1] += gy.y;
     s[2] = fmaf(gy.x, u, s[2]); s[3] = fmaf(gy.x, v, s[3]);
@@ -62,7 +68,8 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
                                                                    const float* __restrict__ coef,
                                                                    const float* __restrict__ stats,
                                                                    double* __restrict__ part, long P, int C, int G,
-                                                                   int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+                                                                   int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                                   const float4* __restrict__ g_add, float add_scale, long HW) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     __shared__ double red[kThreads * 12];
     const int t = threadIdx.x;
@@ -107,7 +114,9 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
     const int g = t % G, r0 = t / G;
     const Chan k0 = load_chan(coef, stats, 2 * g), k1 = load_chan(coef, stats, 2 * g + 1);
     for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
-        const float4 v = x4[r * G + g], gg = g4[r * G + g];
+        const float4 v = x4[r * G + g];
+        float4 gg = g4[r * G + g];
+        if (g_add) add_sample(gg, g_add[(r / HW) * G + g], add_scale);
         const uint64_t e = (uint64_t)(r * G + g) * 4;
         acc6(s, grad_y<ACT, DROP>(k0, v.x, v.y, gg.x, gg.y, seed, e, drop_p, inv_keep), v.x - k0.mr, v.y - k0.mi);
         acc6(s + 6, grad_y<ACT, DROP>(k1, v.z, v.w, gg.z, gg.w, seed, e + 2, drop_p, inv_keep), v.z - k1.mr,
@@ -208,7 +217,8 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
                                                                   const float* __restrict__ coef,
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ bcoef, long P, int C, int G,
-                                                                  int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+                                                                  int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                                  const float4* __restrict__ g_add, float add_scale, long HW) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x;
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
@@ -238,7 +248,9 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
     const Chan k0 = load_chan(coef, stats, 2 * g), k1 = load_chan(coef, stats, 2 * g + 1);
     const BChan b0 = load_bchan(bcoef, 2 * g), b1 = load_bchan(bcoef, 2 * g + 1);
     for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
-        const float4 v = x4[r * G + g], gg = g4[r * G + g];
+        const float4 v = x4[r * G + g];
+        float4 gg = g4[r * G + g];
+        if (g_add) add_sample(gg, g_add[(r / HW) * G + g], add_scale);
         const uint64_t e = (uint64_t)(r * G + g) * 4;
         const float2 a = grad_x(b0, grad_y<ACT, DROP>(k0, v.x, v.y, gg.x, gg.y, seed, e, drop_p, inv_keep), v.x, v.y);
         const float2 b = grad_x(b1, grad_y<ACT, DROP>(k1, v.z, v.w, gg.z, gg.w, seed, e + 2, drop_p, inv_keep), v.z, v.w);
@@ -254,12 +266,15 @@ extern "C" long dcs_cbn_bwd_workspace_bytes(long P, int C) {
     return (long)g.nblocks * C * 6 * (long)sizeof(double) + (long)C * 10 * (long)sizeof(float);
 }
 
-extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const float* weight, const float* stats,
-                           const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
-                           long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
-                           const unsigned long long* seed_dev, dcs_stream_t stream) {
+extern "C" int dcs_cbn_bwd_add(const float* x, const float* g_out, float* g_x, const float* weight, const float* stats,
+                               const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
+                               long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
+                               const unsigned long long* seed_dev, const float* g_add, float add_scale, long HW,
+                               dcs_stream_t stream) {
     cbn::Geom g;
     if (!x || !g_out || !g_x || !stats || !coef || !workspace || !cbn::geom(P, C, &g)) return DCS_ERR_BADARG;
+    if (g_add && (C < 2 || HW <= 0 || P % HW != 0)) return DCS_ERR_BADARG;
+    const float4* ga = reinterpret_cast<const float4*>(g_add);
     if ((g_weight == nullptr) != (g_bias == nullptr)) return DCS_ERR_BADARG;
     if (act != DCS_ACT_NONE && act != DCS_ACT_RELU && act != DCS_ACT_LRELU) return DCS_ERR_BADARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
@@ -273,12 +288,13 @@ extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const
 #define DCS_CBN_BWD(A, D)                                                                                          \
     do {                                                                                                           \
         hipLaunchKernelGGL((cbn_bwd_reduce_kernel<A, D>), dim3(g.nblocks), dim3(kThreads), 0, s, x, g_out, coef,    \
-                           stats, part, P, C, g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);             \
+                           stats, part, P, C, g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev,   \
+                           ga, add_scale, HW);                                                                     \
         hipLaunchKernelGGL(cbn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part,      \
                            g.nblocks, weight, stats, coef, g_weight, g_bias, bcoef, P, C, use_batch_stats);        \
         hipLaunchKernelGGL((cbn_bwd_apply_kernel<A, D>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef,    \
                            stats, (const float*)bcoef, P, C, g.vec_per_row, g.rows_per_iter, drop_p,               \
-                           (uint64_t)seed, (const uint64_t*)seed_dev);                                                                        \
+                           (uint64_t)seed, (const uint64_t*)seed_dev, ga, add_scale, HW);                          \
     } while (0)
     if (act == DCS_ACT_RELU) { if (drop) DCS_CBN_BWD(DCS_ACT_RELU, true); else DCS_CBN_BWD(DCS_ACT_RELU, false); }
     else if (act == DCS_ACT_LRELU) { if (drop) DCS_CBN_BWD(DCS_ACT_LRELU, true); else DCS_CBN_BWD(DCS_ACT_LRELU, false); }
@@ -286,4 +302,12 @@ extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const
 #undef DCS_CBN_BWD
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const float* weight, const float* stats,
+                           const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
+                           long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
+                           const unsigned long long* seed_dev, dcs_stream_t stream) {
+    return dcs_cbn_bwd_add(x, g_out, g_x, weight, stats, coef, g_weight, g_bias, workspace, workspace_bytes, P, C,
+                           use_batch_stats, act, drop_p, seed, seed_dev, nullptr, 0.f, 0, stream);
 }

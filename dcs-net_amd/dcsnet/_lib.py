@@ -46,13 +46,14 @@ SIGNATURES = {
     'dcs_cbn_fwd': (_I, [_P] * 9 + [_L, _L, _I, _F, _F, _I, _I, _F, _U64, _P, _P]),
     'dcs_cbn_bwd_workspace_bytes': (_L, [_L, _I]),
     'dcs_cbn_bwd': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P]),
+    'dcs_cbn_bwd_add': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P, _F, _L, _P]),
     'dcs_ca_workspace_bytes': (_L, [_I, _L, _I]),
     'dcs_channel_attention_fwd': (_I, [_P] * 7 + [_L, _I, _L, _I, _I, _P]),
     'dcs_spatial_pool_fwd': (_I, [_P, _P, _P, _I, _L, _I, _P]),
     'dcs_attention_apply_fwd': (_I, [_P, _P, _P, _P, _I, _L, _I, _F, _U64, _P, _P]),
     'dcs_attention_bwd_sa': (_I, [_P] * 5 + [_I, _L, _I, _F, _U64, _P, _P]),
     'dcs_attention_bwd_workspace_bytes': (_L, [_I, _L, _I, _I]),
-    'dcs_attention_bwd_x': (_I, [_P] * 15 + [_L, _I, _L, _I, _I, _F, _U64, _P, _P]),
+    'dcs_attention_bwd_x': (_I, [_P] * 16 + [_L, _I, _L, _I, _I, _F, _U64, _P, _P]),
     'dcs_attention_fwd_batched_workspace_bytes': (_L, [_I, _P, _I]),
     'dcs_attention_fwd_batched': (_I, [_I, _P, _P, _L, _I, _P]),
     'dcs_attention_bwd_batched_workspace_bytes': (_L, [_I, _P, _I]),

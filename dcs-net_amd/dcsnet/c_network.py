@@ -233,9 +233,12 @@ class C_NETWORK(LightningModule):
                 y = F.cconv2d(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight, convt.conv_tran_r.bias,
                               convt.conv_tran_i.bias, True, convt.kernel_size, (1, 1), convt.corr_padding, up)
             dp, seed = self._drop(p_conv)
-            if i != L - 1:
-                a = self._bn(stage[1], y, F.ACT_LRELU)
-                d = self._attend(self.decoder_attention[2 * i], self.decoder_attention[2 * i + 1], a, dp, seed)
+            if i != L - 1:                                   # CBN + CLReLU + decoder attention (+ dropout): one node
+                ca_m, sa_m = self.decoder_attention[2 * i], self.decoder_attention[2 * i + 1]
+                self._drop(0.0)                              # the CBN's (unused) dropout site keeps the seed sequence
+                d = stage[1]._hip_forward(y, F.ACT_LRELU, 0.0, 0, count=not self._counted, attention=(
+                    ca_m.fc[0].conv_r.weight, ca_m.fc[0].conv_i.weight, ca_m.fc[2].conv_r.weight, ca_m.fc[2].conv_i.weight,
+                    sa_m.conv1.conv_r.weight, sa_m.conv1.conv_i.weight, sa_m.kernel_size, dp, seed))
             else:
                 d = F.dropout(y, dp, seed) if dp > 0 else y
 

@@ -119,9 +119,11 @@ class _ComplexBatchNorm(Module):
                 self.weight[:, 2] = 0
                 self.bias.zero_()
 
-    def _hip_forward(self, x_nhwc, act=F.ACT_NONE, drop_p=0.0, seed=0, count=True):
+    def _hip_forward(self, x_nhwc, act=F.ACT_NONE, drop_p=0.0, seed=0, count=True, attention=None):
         """x: float [B,H,W,C,2].  Shared with the fused C_NETWORK.forward (which advances all the
-        num_batches_tracked counters of the network with one launch and passes count=False)."""
+        num_batches_tracked counters of the network with one launch and passes count=False).
+        attention = (fc0_r, fc0_i, fc2_r, fc2_i, conv1_r, conv1_i, ksize, drop_p, seed): the attention block that
+        follows this CBN in a decoder stage, run as one autograd node with it (F.cbn_attention)."""
         use_batch = self.training or not self.track_running_stats
         momentum = -1.0
         if self.training and self.track_running_stats:
@@ -129,6 +131,11 @@ class _ComplexBatchNorm(Module):
                 self.num_batches_tracked += 1
             momentum = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
         rm = torch.view_as_real(self.running_mean) if self.track_running_stats else None
+        if attention is not None:
+            if drop_p:
+                raise F.DcsHipError('CBN + attention: dropout belongs to the attention block')
+            return F.cbn_attention(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
+                                   act, *attention)
         return F.cbn(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
                      act, drop_p, seed)
 

@@ -223,6 +223,47 @@ def attention_block(x, fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p=0.0
     return _AttentionFn.apply(x, fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed)
 
 
+class _CbnAttentionFn(torch.autograd.Function):
+    """A decoder stage's tail as ONE node: a = CBN(x) + activation, out = dropout(sa (.) ca (.) a)
+    (c_network.py:148-150, :219-222).  Same kernels as _CbnFn followed by _AttentionFn; being one node lets the
+    backward hand the average pool's broadcast term (g_pooled / HW, constant per sample and channel) to the CBN
+    backward kernels as an additive input instead of a read-modify-write pass over the attention's g_x."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
+                fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed):
+        a, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, 0.0, 0)
+        w1, _ = packed_weight(fc0_r, fc0_i, None, None, False)
+        w2, _ = packed_weight(fc2_r, fc2_i, None, None, False)
+        wsa, zero_bias = packed_weight(c1_r, c1_i, None, None, False)
+        ca, pooled, hidden = ops.channel_attention(a, w1, w2)
+        sp = ops.spatial_pool(a, ca)
+        sa = ops.cconv2d(sp, None, wsa, zero_bias, (ksize, ksize), (1, 1), (ksize // 2, ksize // 2), (1, 1), ACT_SIGMOID)
+        out = ops.attention_apply(a, ca, sa, drop_p, seed)
+        ctx.cfg = (bool(use_batch_stats), act, weight is not None, ksize, float(drop_p), int(seed))
+        ctx.sinks = tuple(_sink(t) for t in (weight, bias, fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i))
+        ctx.save_for_backward(x, weight, stats, coef, a, ca, sa, sp, pooled, hidden, w1, w2, wsa)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, weight, stats, coef, a, ca, sa, sp, pooled, hidden, w1, w2, wsa = ctx.saved_tensors
+        use_batch, act, affine, ksize, drop_p, seed = ctx.cfg
+        sk = ctx.sinks
+        g = ops.attention_bwd(a, g_out.contiguous(), ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p, seed, sk[2:],
+                              split_pool=True)
+        g_x, g_w, g_b = ops.cbn_bwd(x, g[0], weight, stats, coef, use_batch, act, 0.0, 0, affine, sk[:2], g_add=g[7])
+        full = (g_w, g_b, *g[1:7])
+        gp = tuple(None if s_ is not None else t for t, s_ in zip(full, sk))
+        return (g_x, gp[0], gp[1], None, None, None, None, None, None, *gp[2:], None, None, None)
+
+
+def cbn_attention(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
+                  fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p=0.0, seed=0):
+    return _CbnAttentionFn.apply(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
+                                 fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed)
+
+
 class _AttentionBlocksFn(torch.autograd.Function):
     """Several INDEPENDENT attention blocks (the skip attentions, c_network.py:208-211: each a function of one
     encoder output only) as one autograd node: forward = one set of five launches for all blocks

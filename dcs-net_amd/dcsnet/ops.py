@@ -356,9 +356,10 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
     return y, stats, coef
 
 
-def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, seed=0, affine=True, outs=None):
+def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, seed=0, affine=True, outs=None,
+            g_add=None):
     """Backward of cbn(): returns (g_x, g_weight [C,3], g_bias [C,2]).  `outs`: optional destinations for
-    (g_weight, g_bias)."""
+    (g_weight, g_bias).  g_add [B,C,2]: the cotangent is g_out + g_add[b, c] / (H*W) (attention_bwd's g_pooled)."""
     _chk(x, 'x', 5)
     _chk(g_out, 'g_out', 5)
     B, H, W, C, _ = x.shape
@@ -372,9 +373,11 @@ def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, see
     if nbytes < 0:
         raise _lib.DcsHipError(f'cbn_bwd: unsupported channel count C={C}')
     ws = _workspace(nbytes, x.device)
-    check(lib.dcs_cbn_bwd(ptr(x), ptr(g_out), ptr(g_x), ptr(weight), ptr(stats), ptr(coef), ptr(g_w), ptr(g_b),
-                          ptr(ws), ws.numel(), P, C, int(bool(use_batch_stats)), act, float(drop_p), int(seed),
-                          ptr(SEED_STATE), cur_stream()), 'dcs_cbn_bwd')
+    if g_add is not None:
+        _chk(g_add, 'g_add', 3)
+    check(lib.dcs_cbn_bwd_add(ptr(x), ptr(g_out), ptr(g_x), ptr(weight), ptr(stats), ptr(coef), ptr(g_w), ptr(g_b),
+                              ptr(ws), ws.numel(), P, C, int(bool(use_batch_stats)), act, float(drop_p), int(seed),
+                              ptr(SEED_STATE), ptr(g_add), 1.0 / (H * W), H * W, cur_stream()), 'dcs_cbn_bwd_add')
     return g_x, g_w, g_b
 
 
@@ -419,9 +422,12 @@ def attention_apply(x, ca=None, sa=None, drop_p=0.0, seed=0, out=None):
     return y
 
 
-def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p=0.0, seed=0, outs=None):
+def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p=0.0, seed=0, outs=None,
+                  split_pool=False):
     """Backward of the fused attention block.  Returns (g_x, g_fc0_r, g_fc0_i, g_fc2_r, g_fc2_i,
-    g_conv1_r, g_conv1_i) with the weight gradients in the reference's parameter layout."""
+    g_conv1_r, g_conv1_i) with the weight gradients in the reference's parameter layout.  split_pool: g_x lacks the
+    average pool's broadcast term and an 8th result g_pooled [B,C,2] is returned for the consumer to add
+    (cbn_bwd(g_add=...))."""
     _chk(x, 'x', 5)
     _chk(g_out, 'g_out', 5)
     B, H, W, C, _ = x.shape
@@ -447,9 +453,13 @@ def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop
     if nbytes < 0:
         raise _lib.DcsHipError(f'attention_bwd: unsupported channel count C={C}')
     ws = _workspace(nbytes, dev)
+    g_pooled = new((B, C, 2)) if split_pool else None
     check(lib.dcs_attention_bwd_x(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_sp), ptr(pooled), ptr(hidden), ptr(w1),
-                                  ptr(w2), ptr(g_x), ptr(g0r), ptr(g0i), ptr(g2r), ptr(g2i), ptr(ws), ws.numel(),
-                                  B, HW, C, Ch, float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_attention_bwd_x')
+                                  ptr(w2), ptr(g_x), ptr(g0r), ptr(g0i), ptr(g2r), ptr(g2i), ptr(g_pooled), ptr(ws),
+                                  ws.numel(), B, HW, C, Ch, float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()),
+          'dcs_attention_bwd_x')
+    if split_pool:
+        return g_x, g0r, g0i, g2r, g2i, g_c1r, g_c1i, g_pooled
     return g_x, g0r, g0i, g2r, g2i, g_c1r, g_c1i
 
 

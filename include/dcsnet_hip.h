@@ -182,6 +182,13 @@ int  dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const float* we
                  const float* stats, const float* coef, float* g_weight, float* g_bias,
                  void* workspace, long workspace_bytes, long P, int C, int use_batch_stats, int act,
                  float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
+/* dcs_cbn_bwd of g_out[b][p][c] + add_scale * g_add[b][c] (g_add complex[B][C], HW pixels per sample, P = B*HW):
+ * the broadcast half of an average pool's backward folded into this consumer (see dcs_attention_bwd_x). */
+int  dcs_cbn_bwd_add(const float* x, const float* g_out, float* g_x, const float* weight, const float* stats,
+                     const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
+                     long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
+                     const unsigned long long* seed_dev, const float* g_add, float add_scale, long HW,
+                     dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * ComplexChannelAttention (c_network.py:53-69): per sample, mean over (F,T) of every
@@ -253,13 +260,16 @@ int dcs_attention_bwd_batched(int n, const dcs_attention_item* items, void* work
  *         1x1 convs; writes the gradients of fc.0 / fc.2 conv_r / conv_i in the reference's layout
  *         ([Ch][C][1][1] and [C][Ch][1][1]).  pooled / hidden / ca as saved by
  *         dcs_channel_attention_fwd; w1 / w2 the packed 1x1 weights.  g_out is the gradient of the
- *         block's output; same drop_p / seed as dcs_attention_apply_fwd. */
+ *         block's output; same drop_p / seed as dcs_attention_apply_fwd.
+ *         g_pooled (optional, complex[B][C]): when given, the gradient of ca's average pool is written there and
+ *         NOT broadcast into g_x — the caller's next kernel adds g_pooled[b][c] / HW to every pixel of g_x
+ *         (dcs_cbn_bwd_add does), which saves a read-modify-write pass over g_x. */
 int  dcs_attention_bwd_sa(const float* x, const float* g_out, const float* ca, const float* sa, float* g_pre,
                           int B, long HW, int C, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
 long dcs_attention_bwd_workspace_bytes(int B, long HW, int C, int Ch);
 int  dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, const float* sa, const float* g_sp,
                          const float* pooled, const float* hidden, const float* w1, const float* w2,
-                         float* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r, float* g_fc2_i,
+                         float* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r, float* g_fc2_i, float* g_pooled,
                          void* workspace, long workspace_bytes, int B, long HW, int C, int Ch,
                          float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
 

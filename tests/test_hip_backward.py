@@ -195,6 +195,40 @@ def test_attention_block_backward(dev, C, hw, relu_in):
         close(ps[n].grad, q.grad, rel=2e-4, what=n)
 
 
+@pytest.mark.parametrize('C,hw,drop', [(8, (20, 12), 0.0), (64, (6, 10), 0.25), (128, (2, 8), 0.0)])
+def test_cbn_attention_one_node_matches_the_two_node_chain(dev, C, hw, drop):
+    """F.cbn_attention (decoder stage tail as one autograd node; the average pool's broadcast gradient is added inside the
+    CBN backward kernels) against F.cbn -> F.attention_block on the same inputs: same kernels otherwise, so forward is
+    bit-identical and the gradients agree to fp32 re-association."""
+    from dcsnet import functional as F
+    torch.manual_seed(C)
+    g = torch.Generator().manual_seed(C)
+    x0 = torch.randn((3, *hw, C, 2), generator=g).to(dev)
+    mk = lambda *shape: ((torch.rand(shape, generator=g) - 0.4) * 0.8).to(dev)
+    Ch = max(C // 16, 1)
+    base = [mk(C, 3) + 1.0, mk(C, 2), mk(Ch, C, 1, 1), mk(Ch, C, 1, 1), mk(C, Ch, 1, 1), mk(C, Ch, 1, 1), mk(1, 2, 7, 7),
+            mk(1, 2, 7, 7)]
+    wgt = torch.rand(x0.shape, generator=g).to(dev)
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        p = [t.clone().requires_grad_(True) for t in base]
+        rm, rc = torch.zeros(C, 2, device=dev), torch.ones(C, 3, device=dev)
+        if fused:
+            y = F.cbn_attention(x, p[0], p[1], rm, rc, 1e-5, 0.1, True, F.ACT_LRELU, *p[2:], 7, drop, 11)
+        else:
+            a = F.cbn(x, p[0], p[1], rm, rc, 1e-5, 0.1, True, F.ACT_LRELU)
+            y = F.attention_block(a, *p[2:], 7, drop, 11)
+        (wgt * y * y).sum().backward()
+        return y.detach(), [x.grad] + [t.grad for t in p], (rm, rc)
+
+    y1, g1, st1 = run(True)
+    y0, g0, st0 = run(False)
+    assert torch.equal(y1, y0) and torch.equal(st1[0], st0[0]) and torch.equal(st1[1], st0[1])
+    for i, (a, b) in enumerate(zip(g1, g0)):
+        close(a, b, rel=2e-5, what=f'grad {i}')
+
+
 def test_attention_blocks_batched(dev):
     """The batched entry (all skip attentions in one set of launches) against the CPU oracle, block by block:
     different channel counts and plane sizes share the launches, including a ReLU input with arg-max ties."""
