@@ -58,7 +58,7 @@ struct MArgs {
 template <int WAVES_N, int WM, int WN, int CH, bool BF>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
-    constexpr int U = BF ? CH / 8 : CH / 4, R = U < 4 ? U : 4, PIX = BF ? CH + 4 : 2 * CH + 4, Q = CH / 2;
+    constexpr int U = BF ? CH / 8 : CH / 4, PIX = BF ? CH + 4 : 2 * CH + 4, Q = CH / 2;
     const conv::Args& a = m.c;
     const conv::Cls& k = m.cls[blockIdx.z];
     // pixels per workgroup = (4 / WAVES_N) * WM * 32 = TH * TW
@@ -110,29 +110,45 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) dst[j] = *reinterpret_cast<const float4*>(bp + j * 256);
     };
-    float4 bring[R][WN];
+    // B fragments of one whole tap (U k-groups) live in registers; the NEXT tap's are fetched during the first half of
+    // this tap's k-groups (two per group) into a second set and moved over at the end of the tap.  The compiler drains
+    // vmcnt to zero at every loop header (it cannot carry partial counts across the back edge): with the loads at the
+    // front of the body that drain finds them >= U/2 groups (>= 512 MFMA cycles) old instead of just issued.
+    constexpr int LPG = U >= 2 ? 2 : 1;
+    float4 bcur[U][WN], bnxt[U][WN];
 #pragma unroll
-    for (int g = 0; g < R; ++g) bload(bring[g], c_begin, 0, g);
+    for (int g = 0; g < U; ++g) bload(bcur[g], c_begin, 0, g);
+
+    // source pixel (index into x1 / x2, or -1 for zero) of every patch pixel: the same for all channel chunks
+    int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);
+    for (int p = t; p < rows * cols; p += 256) {
+        long sp;
+        spx[p] = conv::src_pixel(a, b, vy0 + p / cols, vx0 + p % cols, &sp) ? (int)sp : -1;
+    }
 
     for (int ch = c_begin; ch < n_chunks; ++ch) {
         __syncthreads();                                               // previous chunk fully consumed
-        // gather in rounds of GU independent loads per thread (all in flight together), then the LDS stores
+        // gather in rounds of GU independent loads per thread (all in flight together), then the LDS stores.  The source
+        // pixel of every patch pixel comes from the table built once above: per slot a shift, an LDS read and one
+        // 64-bit multiply-add (the index arithmetic it replaces — four runtime divisions per slot and chunk — kept the
+        // VALU busy for ~30 % of a workgroup's life while its MFMA pipe idled).
         constexpr int GU = 4;
         for (int base = t; base < nslots; base += 256 * GU) {
             float4 v[GU];
+            int spv[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int idx = base + u * 256;
+                spv[u] = idx < nslots ? spx[idx / Q] : -1;
+            }
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int idx = base + u * 256;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < nslots) {
-                    const int q = idx % Q, px = idx / Q;
-                    const int ix = px % cols, iy = px / cols;
-                    long sp;
-                    if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
-                        const int c = ch * CH + 2 * q;
-                        const float2* src = (c < a.C1) ? a.x1 + sp * a.C1 + c : a.x2 + sp * a.C2 + (c - a.C1);
-                        v[u] = *reinterpret_cast<const float4*>(src);
-                    }
+                if (spv[u] >= 0) {
+                    const int c = ch * CH + 2 * (idx % Q);
+                    const float2* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
+                    v[u] = *reinterpret_cast<const float4*>(src);
                 }
             }
 #pragma unroll
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        const float4 av = af[g & 1][i], bv = bring[g % R][j];
+                        const float4 av = af[g & 1][i], bv = bcur[g][j];
                         if (BF) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
                                                                                 __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
@@ -179,14 +195,18 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
                         }
                     }
-                // ... which is then refilled with the fragment R iterations ahead (no register copy in between).  The
-                // scheduling barriers pin the load HERE: left alone, the machine scheduler sinks it to just before its
-                // use four iterations later (shorter live range) and the ring degenerates into load-wait-use.
+                // next tap's fragments (scheduling barriers pin the loads here, ahead of the remaining MFMA groups)
                 __builtin_amdgcn_sched_barrier(0);
-                if (g + R < U) bload(bring[g % R], ch, tap, g + R);
-                else bload(bring[g % R], ch, tap + 1, g + R - U);
+                if (g * LPG < U) {
+#pragma unroll
+                    for (int q = 0; q < LPG; ++q) bload(bnxt[g * LPG + q], ch, tap + 1, g * LPG + q);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int g = 0; g < U; ++g)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bcur[g][j] = bnxt[g][j];
             if (U & 1) {                                               // odd U (bf16, CH = 8): the prefetch landed in set 1
 #pragma unroll
                 for (int i = 0; i < WM; ++i) af[0][i] = af[1][i];
@@ -291,24 +311,31 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
 #pragma unroll
     for (int g = 0; g < U8; ++g) bring[g] = bload(0, 0, g);
 
+    int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);       // source pixel of every patch pixel (see above)
+    for (int p = t; p < rows * cols; p += 256) {
+        long sp;
+        spx[p] = conv::src_pixel(a, b, vy0 + p / cols, vx0 + p % cols, &sp) ? (int)sp : -1;
+    }
+
     for (int ch = 0; ch < n_chunks; ++ch) {
         __syncthreads();
         constexpr int GU = 4;
         for (int base = t; base < nslots; base += 256 * GU) {
             float4 v[GU];
+            int spv[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int idx = base + u * 256;
+                spv[u] = idx < nslots ? spx[idx / Q] : -1;
+            }
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int idx = base + u * 256;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < nslots) {
-                    const int q = idx % Q, px = idx / Q;
-                    const int ix = px % cols, iy = px / cols;
-                    long sp;
-                    if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
-                        const int c = ch * CH + 2 * q;
-                        const float2* src = (c < a.C1) ? a.x1 + sp * a.C1 + c : a.x2 + sp * a.C2 + (c - a.C1);
-                        v[u] = *reinterpret_cast<const float4*>(src);
-                    }
+                if (spv[u] >= 0) {
+                    const int c = ch * CH + 2 * (idx % Q);
+                    const float2* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
+                    v[u] = *reinterpret_cast<const float4*>(src);
                 }
             }
 #pragma unroll
@@ -387,7 +414,7 @@ struct Plan { int cand, TH, TW, CH, S, cps; long blocks; };
 template <int WAVES_N, int WM, int WN, int CH, bool BF>
 int launch_bf(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    const size_t lds = (size_t)npix * (BF ? CH + 4 : 2 * CH + 4) * sizeof(float);
+    const size_t lds = (size_t)npix * ((BF ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
     auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, BF>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);
@@ -415,7 +442,7 @@ int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
 template <int CH>
 int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    const size_t lds = (size_t)npix * (2 * CH + 4) * sizeof(float);
+    const size_t lds = (size_t)npix * (2 * CH + 4 + 1) * sizeof(float);                      // patch + source-pixel table
     auto fn = cconv_mfma16_kernel<CH>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, 1, m.ncls);
@@ -543,6 +570,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
     Plan p;
     long npix;
     if (!make_plan(a, ncls, cls, &p, &npix)) return DCS_ERR_BADARG;
+    if ((long)a.B * a.Hin * a.Win >= (1L << 31)) return DCS_ERR_BADARG;     // source-pixel table holds 32-bit indices
     const int Cin = a.C1 + a.C2;
     MArgs m;
     m.c = a;
