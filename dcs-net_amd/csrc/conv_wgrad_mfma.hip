@@ -82,17 +82,21 @@ __global__ __launch_bounds__(256, (MT * KH * KW * 4 <= 160 && !(KH == 5 && WS ==
         const int oy0 = (tile_id / a.tiles_w) * w.TH, ox0 = (tile_id % a.tiles_w) * w.TW;
         const int vy0 = oy0 * a.sf - w.pad_f[cls], vx0 = ox0 * a.st - w.pad_t[cls];
         __syncthreads();
-        for (int idx = t; idx < npix * 4; idx += 256) {
-            const int q = idx & 3, px = idx >> 2;
+        // one thread per patch pixel: its 8 complex channels are 64 contiguous bytes (4 x 16-byte loads), so the index
+        // arithmetic (two runtime divisions + the upsample / zero-insertion mapping) runs once per pixel, not per load
+        for (int px = t; px < npix; px += 256) {
             const int ix = px % a.cols, iy = px / a.cols;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             long sp;
             if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
-                const int c = ci0 + 2 * q;
-                const float2* src = (c < a.C1) ? a.x1 + sp * a.C1 + c : a.x2 + sp * a.C2 + (c - a.C1);
-                v = *reinterpret_cast<const float4*>(src);
+                const float2* src = (ci0 < a.C1) ? a.x1 + sp * a.C1 + ci0 : a.x2 + sp * a.C2 + (ci0 - a.C1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const float4*>(src)[q];
             }
-            *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v[q];
         }
         if (GL) {
             // few output channels (<= 16 per workgroup): a k-step is only TAPS*32 cycles of MFMA, far less than the L2 round trip
