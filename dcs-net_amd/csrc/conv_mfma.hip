@@ -33,6 +33,7 @@ struct MArgs {
     const float* bm;
     float* y2;                 // optional second output: columns >= nsplit go here (g_x1 | g_x2 of a cat)
     int nsplit;
+    int twshift;               // log2(TW): tile widths are powers of two
     int TH, TW, N, KG, NT;     // tile shape (TH*TW = pixels per WG), N = 2*Cout, KG = Cin/4, NT = ceil(N/32)
     int ncls, os_f, os_t;      // output-parity classes (blockIdx.z): pixel (oy, ox) of class c is stored at
     conv::Cls cls[4];          //   (oy*os_f + oo_f, ox*os_t + oo_t) and has its own sub-kernel / padding / panel
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int pi = (wm * WM + i) * 32 + li;
-        pixoff[i] = (((pi / m.TW) * a.sf) * cols + (pi % m.TW) * a.st) * PIX + kk * 4;
+        pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + kk * 4;
     }
     const float* bbase = m.bm + k.bm_off + ((long)nt0 * 64 + lane) * 4;
     const long b_tap_stride = (long)(BF ? m.KG / 2 : m.KG) * m.NT * 256, b_kg_stride = (long)m.NT * 256;
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     // epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (m.ksplit > 1) {                                                // raw partial tile of this K slice
         float* pf = m.part + (long)kslice * m.slab_floats;
+        float* pfb = pf + (long)b * a.Hout * a.Wout * m.N;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = (nt0 + j) * 32 + li;
@@ -228,9 +230,9 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
                     const int pi = (wm * WM + i) * 32 + row;
-                    const int oy = oy0 + pi / m.TW, ox = ox0 + pi % m.TW;
-                    if (oy < k.Hc && ox < k.Wc)
-                        pf[(((long)b * a.Hout + oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * m.N + n] = acc[i][j][r];
+                    const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
+                    if (oy < k.Hc && ox < k.Wc)      // 32-bit offsets inside one image (launcher checks the extent)
+                        pfb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * m.N + n] = acc[i][j][r];
                 }
             }
         }
@@ -247,15 +249,16 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         float* yf = second ? m.y2 : reinterpret_cast<float*>(a.y);
         const int width = m.y2 == nullptr ? m.N : (second ? m.N - m.nsplit : m.nsplit);
         const int col = second ? n - m.nsplit : n;
+        float* yb = yf + (long)b * a.Hout * a.Wout * width;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
                 const int pi = (wm * WM + i) * 32 + row;
-                const int oy = oy0 + pi / m.TW, ox = ox0 + pi % m.TW;
+                const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
                 if (oy < k.Hc && ox < k.Wc)
-                    yf[(((long)b * a.Hout + oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] =
+                    yb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] =
                         dcs_act(acc[i][j][r] + bv, a.act);
             }
         }
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int pi = wave * 32 + i * 16 + li;
-        pixoff[i] = (((pi / m.TW) * a.sf) * cols + (pi % m.TW) * a.st) * PIX + g4 * 4;
+        pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + g4 * 4;
     }
     const float* bbase = m.bm + k.bm_off + (long)lane * 4;
     const long b_tap_stride = (long)(Cin / 8) * 256, b_kg_stride = 256;
@@ -375,15 +378,15 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
     float* yf = second ? m.y2 : reinterpret_cast<float*>(a.y);
     const int width = m.y2 == nullptr ? 16 : (second ? 16 - m.nsplit : m.nsplit);
     const int col = second ? n - m.nsplit : n;
+    float* yb = yf + (long)b * a.Hout * a.Wout * width;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int pi = wave * 32 + i * 16 + g4 * 4 + r;
-            const int oy = oy0 + pi / m.TW, ox = ox0 + pi % m.TW;
+            const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
             if (oy < k.Hc && ox < k.Wc)
-                yf[(((long)b * a.Hout + oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] =
-                    dcs_act(acc[i][r] + bv, a.act);
+                yb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] = dcs_act(acc[i][r] + bv, a.act);
         }
 }
 
@@ -571,6 +574,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
     long npix;
     if (!make_plan(a, ncls, cls, &p, &npix)) return DCS_ERR_BADARG;
     if ((long)a.B * a.Hin * a.Win >= (1L << 31)) return DCS_ERR_BADARG;     // source-pixel table holds 32-bit indices
+    if ((long)a.Hout * a.Wout * 2 * a.Cout >= (1L << 31)) return DCS_ERR_BADARG;  // 32-bit store offsets inside an image
     const int Cin = a.C1 + a.C2;
     MArgs m;
     m.c = a;
@@ -585,6 +589,8 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
     }
     m.N = 2 * a.Cout; m.KG = Cin / 4; m.NT = (m.N + 31) / 32;
     m.TH = p.TH; m.TW = p.TW;
+    m.twshift = __builtin_ctz((unsigned)p.TW);
+    if ((1 << m.twshift) != p.TW) return DCS_ERR_BADARG;
     m.c.tiles_w = (Wc + m.TW - 1) / m.TW;
     m.c.tiles_h = (Hc + m.TH - 1) / m.TH;
     m.slab_floats = (long)a.B * a.Hout * a.Wout * m.N;
