@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-end evidence, all in one gpurun call (run from the repo root on the GPU box):
+#   tools/collect_profiles.sh <tag>    ->  gpurun_out/<tag>/{bench_*.json, *_kernel_stats.csv, pmc_*_{fetch,write}.csv}
+# Every rocprofv3 command has the program itself after `--`; counters are collected in their own passes.
+set -e -o pipefail
+tag=$1; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag
+mkdir -p $out && cd /tmp && export TMPDIR=/tmp
+echo "[collect] bench train (default flags)"; timeout -k 10 400 python3 $R/bench.py > $out/bench_train_default.json 2> $out/bench_train.log
+echo "[collect] bench infer"; timeout -k 10 400 python3 $R/bench.py --mode infer > $out/bench_infer.json 2> $out/bench_infer.log
+for mode in train infer; do
+  echo "[collect] kernel stats $mode"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$mode -- python3 $R/bench.py --mode $mode --no-cpu-baseline > $out/stats_$mode.log 2>&1
+  cp $(find $out/stats_$mode -name "*kernel_stats.csv" | head -1) $out/${mode}_kernel_stats.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    echo "[collect] pmc $c $mode"
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${mode}_$c -- python3 $R/bench.py --mode $mode --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_${mode}_$c.log 2>&1
+    cp $(find $out/pmc_${mode}_$c -name "*counter_collection.csv" | head -1) $out/pmc_${mode}_$c.csv
+  done
+  rm -rf $out/stats_$mode $out/pmc_${mode}_FETCH_SIZE $out/pmc_${mode}_WRITE_SIZE
+done
+echo "[collect] done"; ls -la $out
