@@ -62,27 +62,41 @@ __device__ __forceinline__ void ca_fc_kernel_body(const double* __restrict__ par
                                                           float2* __restrict__ hidden_out, long HW, int C, int Ch, int bx, int by, int gx) {
     __shared__ float2 pooled[128];
     __shared__ float2 hid[64];
+    __shared__ double red[kThreads * 2];
     const int b = bx, t = threadIdx.x;
-    for (int c = t; c < C; c += kThreads) {
+    {   // chunk slabs -> channel sums: kThreads / C threads share a channel's (up to 64) chunks, fixed combine order
+        const int nsl = kThreads / C, c = t % C, sl = t / C;             // C <= 128 is a power of two (att_geom)
         double sr = 0, si = 0;
-        for (int k = 0; k < nchunks; ++k) {
-            const double* p = part + (((long)b * nchunks + k) * C + c) * 2;
-            sr += p[0]; si += p[1];
+        if (sl < nsl)
+            for (int k = sl; k < nchunks; k += nsl) {
+                const double* p = part + (((long)b * nchunks + k) * C + c) * 2;
+                sr += p[0]; si += p[1];
+            }
+        red[t * 2] = sr; red[t * 2 + 1] = si;
+        __syncthreads();
+        if (t < C) {
+            for (int q = 1; q < nsl; ++q) { sr += red[(q * C + t) * 2]; si += red[(q * C + t) * 2 + 1]; }
+            const float2 m = make_float2((float)(sr / (double)HW), (float)(si / (double)HW));
+            pooled[t] = m;
+            pooled_out[(long)b * C + t] = m;
         }
-        const float2 m = make_float2((float)(sr / (double)HW), (float)(si / (double)HW));
-        pooled[c] = m;
-        pooled_out[(long)b * C + c] = m;
     }
     __syncthreads();
-    for (int h = t; h < Ch; h += kThreads) {
+    // hidden[h] = sum_c w1[c][h] pooled[c]: 32 lanes per hidden unit, each a strided share of the channels (a single
+    // thread per unit walks C dependent-latency loads: ~10 us at C = 128)
+    for (int h = t >> 5; h < Ch; h += kThreads / 32) {
         float ar = 0.f, ai = 0.f;
-        for (int c = 0; c < C; ++c) {
+        for (int c = t & 31; c < C; c += 32) {
             const float2 w = w1[c * Ch + h], p = pooled[c];
             ar = fmaf(w.x, p.x, ar); ar = fmaf(-w.y, p.y, ar);
             ai = fmaf(w.x, p.y, ai); ai = fmaf(w.y, p.x, ai);
         }
-        hidden_out[(long)b * Ch + h] = make_float2(ar, ai);
-        hid[h] = make_float2(ar > 0.f ? ar : 0.f, ai > 0.f ? ai : 0.f);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { ar += __shfl_xor(ar, o, 64); ai += __shfl_xor(ai, o, 64); }
+        if ((t & 31) == 0) {
+            hidden_out[(long)b * Ch + h] = make_float2(ar, ai);
+            hid[h] = make_float2(ar > 0.f ? ar : 0.f, ai > 0.f ? ai : 0.f);
+        }
     }
     __syncthreads();
     for (int c = t; c < C; c += kThreads) {

@@ -259,20 +259,23 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
     CbnGeom g;
     if (!x || !y || !stats_out || !coef_out || !cbn_geom(P, C, &g)) return DCS_ERR_BADARG;
     if ((weight == nullptr) != (bias == nullptr)) return DCS_ERR_BADARG;
-    if (!use_batch_stats && (!running_mean || !running_covar)) return DCS_ERR_BADARG;
+    if (use_batch_stats < 0 || use_batch_stats > 2) return DCS_ERR_BADARG;
+    if (use_batch_stats == 0 && (!running_mean || !running_covar)) return DCS_ERR_BADARG;
     if (act != DCS_ACT_NONE && act != DCS_ACT_RELU && act != DCS_ACT_LRELU) return DCS_ERR_BADARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
     hipStream_t s = dcs_stream(stream);
-    if (use_batch_stats) {
+    if (use_batch_stats == 1) {
         if (!workspace || workspace_bytes < (long)g.nblocks * C * 5 * (long)sizeof(double)) return DCS_ERR_WORKSPACE;
         hipLaunchKernelGGL(cbn_stats_kernel, dim3(g.nblocks), dim3(kThreads), 0, s, x, (double*)workspace, P, C,
                            g.vec_per_row, g.rows_per_iter);
         DCS_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(cbn_finalize_kernel, dim3(C), dim3(64), 0, s, x, (const double*)workspace,
-                       g.nblocks, weight, bias, running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum,
-                       use_batch_stats);
-    DCS_CHECK_LAUNCH();
+    if (use_batch_stats != 2) {            // 2: coef_out already holds the coefficients of an earlier eval-mode call
+        hipLaunchKernelGGL(cbn_finalize_kernel, dim3(C), dim3(64), 0, s, x, (const double*)workspace,
+                           g.nblocks, weight, bias, running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum,
+                           use_batch_stats);
+        DCS_CHECK_LAUNCH();
+    }
     // apply: ~4 float4 per thread per workgroup pass, capped at 2048 workgroups
     long iters = (C == 1) ? (P / 2 + kThreads - 1) / kThreads : (P + g.rows_per_iter - 1) / g.rows_per_iter;
     long nb = (iters + 3) / 4;

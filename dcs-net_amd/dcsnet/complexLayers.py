@@ -9,6 +9,8 @@ inner ``nn.Conv2d`` / ``nn.ConvTranspose2d`` / ``nn.Linear`` modules.  The arith
 libdcsnet_hip.so; tensors cross the module boundary as complex64 ``[B,C,H,W]`` in
 channels_last memory (any input layout is accepted and converted once).
 """
+import weakref
+
 import torch
 from torch.nn import Module, Parameter, Conv2d, ConvTranspose2d, Linear
 
@@ -77,6 +79,9 @@ class ComplexLinear(Module):
         return F.complex_linear(input, self.fc_r.weight, self.fc_i.weight, self.fc_r.bias, self.fc_i.bias)
 
 
+_EVAL_COEF = weakref.WeakKeyDictionary()      # CBN module -> (tensor refs, versions, (stats, coef)) of eval-mode calls
+
+
 class _ComplexBatchNorm(Module):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
         super().__init__()
@@ -130,14 +135,35 @@ class _ComplexBatchNorm(Module):
             if count or self.momentum is None:
                 self.num_batches_tracked += 1
             momentum = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+            F.note_state_update()              # the kernel rewrites the running statistics in place
         rm = torch.view_as_real(self.running_mean) if self.track_running_stats else None
         if attention is not None:
             if drop_p:
                 raise F.DcsHipError('CBN + attention: dropout belongs to the attention block')
             return F.cbn_attention(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
                                    act, *attention)
+        if not use_batch and not torch.is_grad_enabled():
+            return self._eval_forward(x_nhwc, rm, act, drop_p, seed)
         return F.cbn(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
                      act, drop_p, seed)
+
+    def _eval_forward(self, x, rm, act, drop_p, seed):
+        """Inference: the whitening + affine coefficients are constants of (weight, bias, running statistics): computed
+        by the first call, kept per module in a weak dictionary (guarded by the identity and version of the four tensors) and re-used —
+        one launch per CBN instead of two."""
+        tensors = (self.weight, self.bias, self.running_mean, self.running_covar)
+        vers = (F.state_generation(),) + tuple(None if t is None else (t._version, t.data_ptr()) for t in tensors)
+        ent = _EVAL_COEF.get(self)
+        cached = None
+        if ent is not None and ent[1] == vers and all((r is None and t is None) or (r is not None and r() is t)
+                                                      for r, t in zip(ent[0], tensors)):
+            cached = ent[2]
+        y, stats, coef = F.ops.cbn(x, self.weight, self.bias, rm, self.running_covar, self.eps, -1.0, False, act,
+                                   drop_p, seed, coef_cached=cached)
+        if cached is None and not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            refs = tuple(None if t is None else weakref.ref(t) for t in tensors)
+            _EVAL_COEF[self] = (refs, vers, (stats, coef))
+        return y
 
 
 class ComplexBatchNorm2d(_ComplexBatchNorm):

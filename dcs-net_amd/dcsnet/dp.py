@@ -267,6 +267,8 @@ class TrainStep:
             if s is not b:
                 s.copy_(b)
         self._graph.replay()
+        from . import functional
+        functional.bump_param_generation()     # the replay rewrote parameters and running statistics behind torch's back
         if self._graph_world > 1:
             self.opt.step(self.bucket.allreduce())
             self.seed_state += 1

@@ -20,11 +20,22 @@ _param_generation = 0
 
 def bump_param_generation():
     """Called by optimizers that update parameters outside torch's version counters (the fused
-    HIP Adam): every packed weight becomes stale."""
+    HIP Adam, a replayed train-step graph): every packed weight and every inference-time constant derived from
+    parameters or running statistics becomes stale."""
     global _param_generation
     _param_generation += 1
     _pack_cache.clear()
     ops.pack_plan_invalidate()
+
+
+def note_state_update():
+    """A kernel changed module state behind torch's version counters (train-mode CBN: running statistics)."""
+    global _param_generation
+    _param_generation += 1
+
+
+def state_generation():
+    return _param_generation
 
 
 def begin_pack_plan():
@@ -494,6 +505,33 @@ def _stacked_lstm(real_lstm):
     return st
 
 
+_LSTM_EVAL_OPERANDS = weakref.WeakKeyDictionary()      # real nn.LSTM -> {layer: (key, parameter refs, stacks)}
+
+
+def _lstm_layer_operands(sets, layer):
+    """Stacked (w_ih [2, 8H, in], bias [2, 8H], w_hh [2, 2, 4H, H]) of one layer of both nn.LSTM containers.  Without
+    autograd (inference) the stacks are cached per parameter identity + version: re-making them costs ~12 cat / add
+    launches per layer and pass."""
+    names = [f'_l{layer}', f'_l{layer}_reverse']
+    params = [getattr(m, k + n) for m in sets for n in names for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    cacheable = not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
+    if cacheable:
+        key = (_param_generation, tuple((p.data_ptr(), p._version) for p in params))
+        hit = _LSTM_EVAL_OPERANDS.get(sets[0], {}).get(layer)
+        if hit is not None and hit[0] == key and all(r() is p for r, p in zip(hit[1], params)):
+            return hit[2]
+    w_ih = torch.stack([torch.cat([getattr(m, 'weight_ih' + n) for n in names]) for m in sets])      # [2, 8H, in]
+    bias = torch.stack([torch.cat([getattr(m, 'bias_ih' + n) + getattr(m, 'bias_hh' + n) for n in names])
+                        for m in sets])                                                                # [2, 8H]
+    w_hh = torch.stack([torch.stack([getattr(m, 'weight_hh' + n) for n in names]) for m in sets]).contiguous()   # [2,2,4H,H]
+    if cacheable:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return w_ih, bias, w_hh             # tensors made during capture live in the graph's pool: do not keep them
+        _LSTM_EVAL_OPERANDS.setdefault(sets[0], {})[layer] = (
+            key, tuple(weakref.ref(p) for p in params), (w_ih.detach(), bias.detach(), w_hh.detach()))
+    return w_ih, bias, w_hh
+
+
 def complex_lstm(z, real_lstm, imag_lstm):
     """ComplexLSTM.forward (c_network.py:33-47) for two bidirectional batch_first nn.LSTM
     parameter containers.  Per layer: one batched input-projection GEMM for all time steps
@@ -513,13 +551,9 @@ def complex_lstm(z, real_lstm, imag_lstm):
             out = _LstmLayerFn.apply(inp, real_lstm.weight_ih_l0, stacked[layer], 2 * B, S)
             inp = out.view(2, 2 * B * S, -1)
             continue
-        names = [f'_l{layer}', f'_l{layer}_reverse']
-        w_ih = torch.stack([torch.cat([getattr(m, 'weight_ih' + n) for n in names]) for m in sets])      # [2, 8H, in]
-        bias = torch.stack([torch.cat([getattr(m, 'bias_ih' + n) + getattr(m, 'bias_hh' + n) for n in names])
-                            for m in sets])                                                                # [2, 8H]
-        w_hh = torch.stack([torch.stack([getattr(m, 'weight_hh' + n) for n in names]) for m in sets])     # [2,2,4H,H]
+        w_ih, bias, w_hh = _lstm_layer_operands(sets, layer)
         gx = torch.baddbmm(bias.unsqueeze(1), inp, w_ih.transpose(1, 2))          # (set, n*t, dir*4H)
-        out = _LstmRecFn.apply(gx.view(2, 2 * B, S, 2, -1), w_hh.contiguous())    # [2*2B, S, 2H]
+        out = _LstmRecFn.apply(gx.view(2, 2 * B, S, 2, -1), w_hh)                 # [2*2B, S, 2H]
         inp = out.view(2, 2 * B * S, -1)
     o = inp.view(2, 2 * B, S, -1)
     if torch.is_grad_enabled() and o.requires_grad:

@@ -332,26 +332,35 @@ def wgrad_defer_flush():
         CONV_TIMER.end(ev)
 
 
+
 def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, use_batch_stats=True,
-        act=ACT_NONE, drop_p=0.0, seed=0, out=None):
+        act=ACT_NONE, drop_p=0.0, seed=0, out=None, coef_cached=None):
     """ComplexBatchNorm2d (+act +dropout).  running_mean: float [C,2] view of the complex buffer.
-    Returns (y, stats [C,8], coef [C,6])."""
+    Returns (y, stats [C,8], coef [C,6]).  coef_cached = (stats, coef) of an earlier eval-mode call with the same
+    parameters and running statistics: only the apply kernel runs."""
     _chk(x, 'x', 5)
     for n, t in (('weight', weight), ('bias', bias), ('running_mean', running_mean), ('running_covar', running_covar)):
         _chk(t, n)
     B, H, W, C, _ = x.shape
     P = B * H * W
     y = torch.empty_like(x) if out is None else out
-    stats = torch.empty((C, 8), dtype=torch.float32, device=x.device)
-    coef = torch.empty((C, 6), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     nbytes = lib.dcs_cbn_workspace_bytes(P, C)
     if nbytes < 0:
         raise _lib.DcsHipError(f'cbn: unsupported channel count C={C}')
     ws = _workspace(nbytes, x.device)
+    mode = int(bool(use_batch_stats))
+    if coef_cached is not None:            # eval mode, coefficients of an earlier call with the same parameters (caller's cache)
+        if mode != 0:
+            raise _lib.DcsHipError('cbn: cached coefficients are an eval-mode feature')
+        stats, coef = coef_cached
+        mode = 2
+    else:
+        stats = torch.empty((C, 8), dtype=torch.float32, device=x.device)
+        coef = torch.empty((C, 6), dtype=torch.float32, device=x.device)
     check(lib.dcs_cbn_fwd(ptr(x), ptr(y), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_covar),
                           ptr(stats), ptr(coef), ptr(ws), ws.numel(), P, C, eps,
-                          -1.0 if momentum is None else momentum, int(bool(use_batch_stats)), act,
+                          -1.0 if momentum is None else momentum, mode, act,
                           float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_cbn_fwd')
     return y, stats, coef
 

@@ -164,6 +164,8 @@ int  dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const float* gy,
  *   stats_out   float[C][8]: mean_r, mean_i, Rrr, Rii, Rri, Crr, Cii, Cri (saved for backward)
  *   coef_out    float[C][6]: y_r = a0 x_r + a1 x_i + c0 ; y_i = a2 x_r + a3 x_i + c1, then act
  *   workspace   >= dcs_cbn_workspace_bytes(P, C) bytes, 16-byte aligned
+ * use_batch_stats == 2: apply only — coef_out already holds the coefficients an earlier eval-mode call
+ * (use_batch_stats == 0) wrote for the same parameters and running statistics (inference: they are constants).
  */
 long dcs_cbn_workspace_bytes(long P, int C);
 int  dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bias,

@@ -176,6 +176,39 @@ def test_backward_kernels_write_into_the_flat_gradient_bucket(dev):
         assert float((a[n] - b[n]).abs().max()) <= 2e-5 * scale + 1e-7, n
 
 
+def test_inference_constants_follow_training_updates(dev):
+    """Eval-mode constants kept between forward passes (CBN coefficients, stacked LSTM operands, packed weights) must not
+    survive a train step that rewrites parameters and running statistics behind torch's version counters (fused Adam,
+    in-kernel running-statistic updates, a replayed train-step graph): eval -> train -> eval equals a fresh eval."""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    import bench
+    for use_graph in (False, True):
+        net = fill_state(C_NETWORK(config, hparams, 0), 7).to(dev)
+        noise, noisy, clean = bench.synthetic_stft_batch(2, 32, dev, seed=5)
+        x = seeded_input(2, 256, 32, 9).to(dev)
+
+        def ev():
+            net.eval()
+            with torch.no_grad():
+                return net(x).clone()
+        e0, e0b = ev(), ev()
+        assert torch.equal(e0, e0b)                      # cached constants: same result
+        net.train()
+        ts = TrainStep(net, use_graph=use_graph, graph_warmup=1)
+        for _ in range(3):
+            ts((noise, noisy, clean, [0, 1]))
+        e1 = ev()
+        assert not torch.allclose(e1, e0, atol=1e-6)     # parameters and running statistics moved
+        ref = C_NETWORK(config, hparams, 0).to(dev)      # same state, nothing cached
+        ref.load_state_dict(net.state_dict())
+        ref.eval()
+        with torch.no_grad():
+            want = ref(x)
+        assert torch.allclose(e1, want, atol=1e-6), float((e1 - want).abs().max())
+
+
 def test_pack_plan_step_is_bit_identical_to_per_layer_packing(dev):
     """dcs_pack_plan_*: every weight re-layout of a step replayed in one launch per dependency level gives
     exactly the parameters the ~200 per-layer pack launches give (same kernels bodies, same inputs)."""
