@@ -8,8 +8,9 @@
 //   * the input projection x_t W_ih^T + b_ih + b_hh of ALL time steps is one plain GEMM done by the
 //     caller (rocBLAS through PyTorch) -> `gx`;
 //   * this kernel walks the sequence with one 256-thread workgroup per (sequence, direction):
-//     thread j owns gate column j (PyTorch order i,f,g,o, H = 64 each) with its W_hh row in 64
-//     VGPRs, h_{t-1} lives in LDS (broadcast reads), c in a register; two barriers per step;
+//     each thread owns one gate row (PyTorch order i,f,g,o, H = 64 each) with its W_hh row in 64
+//     VGPRs; the four gates of a hidden unit share a quad (DPP exchange), h_{t-1} lives in a
+//     double-buffered LDS vector (broadcast reads), c in a register; ONE barrier per step;
 //     next step's gx is prefetched under the FMAs.
 // All four passes of a layer (both weight sets, re and im inputs, both directions) run in the
 // same launch: 8*B independent workgroups.
@@ -20,17 +21,38 @@ namespace {
 constexpr int H = 64;
 constexpr int G4 = 4 * H;
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+// tanh through the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each): 1 - 2 / (2^(2x log2 e) + 1), absolute
+// error ~1e-7 (saturates correctly at +-1).  The library tanhf / expf pair costs ~100 VALU instructions per step on the
+// recurrence's critical path — more than the 64-FMA dot product; the sigmoid gates reuse the same evaluation,
+// sigmoid(x) = 0.5 tanh(x / 2) + 0.5, so the four gates of a quad do not diverge.
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.885390081777927f) + 1.f);
+}
 
+// quad_perm DPP: every lane of a quad reads lane K of its quad (broadcast) or its xor-partner
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) { return dcs_dpp_term<CTRL, 0xf>(v); }
+__device__ __forceinline__ float quad_bcast0(float v) { return quad_dpp<0x00>(v); }
+__device__ __forceinline__ float quad_bcast1(float v) { return quad_dpp<0x55>(v); }
+__device__ __forceinline__ float quad_bcast2(float v) { return quad_dpp<0xAA>(v); }
+__device__ __forceinline__ float quad_bcast3(float v) { return quad_dpp<0xFF>(v); }
+__device__ __forceinline__ float quad_sum(float v) {
+    v += quad_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += quad_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    return v;
+}
+
+// Thread t = 4*u + gate: the four gates (i, f, g, o) of hidden unit u sit in one quad, so the cell update needs no LDS
+// round trip — the activations are exchanged with quad_perm DPP and all four lanes update (c, h) redundantly.  h lives
+// in a double-buffered LDS vector (step s reads buffer s&1 while lane gate 0 writes the other): ONE barrier per step.
 template <bool SAVE>
 __global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
                                                            float* __restrict__ out, float* __restrict__ gates_save,
                                                            float* __restrict__ c_save, float* __restrict__ hprev_save,
                                                            int S, int seqs_per_set, long stride_set, long stride_n,
                                                            long stride_t) {
-    __shared__ __attribute__((aligned(16))) float h_s[H];
-    __shared__ float g_s[G4];
-    const int j = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float h_s[2][H];
+    const int t = threadIdx.x, u = t >> 2, gate = t & 3, j = gate * H + u;      // j: PyTorch gate row (i, f, g, o blocks)
     const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int set = n / seqs_per_set, ns = n % seqs_per_set;
 
@@ -45,17 +67,17 @@ __global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restric
     }
     const float* gxp = gx + set * stride_set + ns * stride_n + dir * G4 + j;
     const int t0 = dir ? S - 1 : 0, dt = dir ? -1 : 1;
-    float c = 0.f;
-    if (j < H) h_s[j] = 0.f;
+    float c = 0.f, hprev = 0.f;
+    if (t < H) h_s[0][t] = 0.f;
     float pre = gxp[(long)t0 * stride_t];
     __syncthreads();
-    const bool is_g = (j >> 6) == 2;
+    const bool is_g = gate == 2;
     for (int s = 0; s < S; ++s) {
-        const int t = t0 + s * dt;
+        const int tt = t0 + s * dt, cur = s & 1;
         float nxt = 0.f;
-        if (s + 1 < S) nxt = gxp[(long)(t + dt) * stride_t];
+        if (s + 1 < S) nxt = gxp[(long)(tt + dt) * stride_t];
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        const float4* h4 = reinterpret_cast<const float4*>(h_s);
+        const float4* h4 = reinterpret_cast<const float4*>(h_s[cur]);
 #pragma unroll
         for (int k = 0; k < H / 4; ++k) {
             const float4 hv = h4[k];
@@ -65,88 +87,80 @@ __global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restric
             a3 = fmaf(w[4 * k + 3], hv.w, a3);
         }
         const float a = pre + ((a0 + a1) + (a2 + a3));
-        const float act = is_g ? tanhf(a) : sigmoidf_(a);
-        g_s[j] = act;
-        if (SAVE) gates_save[(((long)n * S + t) * 2 + dir) * G4 + j] = act;
-        __syncthreads();
-        if (j < H) {
-            const float ig = g_s[j], fg = g_s[H + j], gg = g_s[2 * H + j], og = g_s[3 * H + j];
-            c = fmaf(fg, c, ig * gg);
-            const float h = og * tanhf(c);
-            if (SAVE && hprev_save) hprev_save[(((long)n * S + t) * 2 + dir) * H + j] = h_s[j];   // state BEFORE this step
-            h_s[j] = h;
-            out[((long)n * S + t) * (2 * H) + dir * H + j] = h;
-            if (SAVE) c_save[(((long)n * S + t) * 2 + dir) * H + j] = c;
+        const float th = fast_tanh(is_g ? a : 0.5f * a);
+        const float act = is_g ? th : fmaf(0.5f, th, 0.5f);
+        if (SAVE) gates_save[(((long)n * S + tt) * 2 + dir) * G4 + j] = act;
+        const float ig = quad_bcast0(act), fg = quad_bcast1(act), gg = quad_bcast2(act), og = quad_bcast3(act);
+        c = fmaf(fg, c, ig * gg);
+        const float h = og * fast_tanh(c);
+        if (gate == 0) {
+            h_s[cur ^ 1][u] = h;
+            out[((long)n * S + tt) * (2 * H) + dir * H + u] = h;
+            if (SAVE) {
+                c_save[(((long)n * S + tt) * 2 + dir) * H + u] = c;
+                if (hprev_save) hprev_save[(((long)n * S + tt) * 2 + dir) * H + u] = hprev;   // state BEFORE this step
+            }
         }
+        hprev = h;
         __syncthreads();
         pre = nxt;
     }
 }
 
-// Backward through time for one (sequence, direction) per workgroup.  Threads u < H turn the
-// cotangent of h_t (from the layer above + from step t+1) into the four pre-activation
-// cotangents; then all 256 threads (k = t/4, quarter = t%4) form g_h_{t-1} = W_hh^T g_pre with the
-// W_hh column quarter held in 64 VGPRs and a 4-lane shuffle reduction.  g_pre is written out for
-// the caller's weight / input GEMMs.
+// Backward through time for one (sequence, direction) per workgroup, same quad mapping (t = 4*u + gate): every lane of
+// a quad forms the four pre-activation cotangents of its unit from the saved gates (its own gate loaded, the others by
+// DPP broadcast) and keeps its own; g_h_{t-1} = W_hh^T g_pre is a 64-long dot product per lane over its gate's block
+// (W_hh column of unit u, rows gate*H..) plus a quad sum — so the recurrent cotangent of unit u never leaves the quad.
+// g_pre of the step goes through a double-buffered LDS vector: ONE barrier per step.  The next step's operands are
+// fetched while the current one computes (none depends on the recurrence).
 __global__ __launch_bounds__(G4) void lstm_rec_bwd_kernel(const float* __restrict__ g_out,
                                                            const float* __restrict__ gates, const float* __restrict__ cs,
                                                            const float* __restrict__ whh, float* __restrict__ g_pre,
                                                            float* __restrict__ g_bias_part, int S, int seqs_per_set) {
-    __shared__ float gp_s[G4];
-    __shared__ float gh_s[H];
-    const int j = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float gp_s[2][G4];
+    const int t = threadIdx.x, u = t >> 2, gate = t & 3, j = gate * H + u;
     const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int set = n / seqs_per_set;
-    const int k = j >> 2, part = j & 3;
 
-    float w[H];      // W_hh[part*64 + jj][k]
+    float w[H];      // W_hh[gate*64 + jj][u]
     {
-        const float* wb = whh + ((long)(set * 2 + dir) * G4 + part * H) * H + k;
+        const float* wb = whh + ((long)(set * 2 + dir) * G4 + gate * H) * H + u;
 #pragma unroll
         for (int jj = 0; jj < H; ++jj) w[jj] = wb[(long)jj * H];
     }
     const int t0 = dir ? S - 1 : 0, dt = dir ? -1 : 1;
-    float gc_rec = 0.f;
-    if (j < H) gh_s[j] = 0.f;
-    // operands of the step about to run; the next step's are fetched while this one computes (none of them depends on
-    // the recurrence, and left in the loop body their ~1 us of dependent global-load latency is paid S times)
-    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cp = 0.f, go = 0.f;
-    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;                  // bias gradient of this (sequence, direction)
-    auto fetch = [&](int s_, float& i_, float& f_, float& g_, float& o_, float& cp_, float& go_) {
+    float gc_rec = 0.f, gh_rec = 0.f, sb = 0.f;                         // sb: bias gradient of gate row j
+    float act = 0.f, c = 0.f, cp = 0.f, go = 0.f;
+    auto fetch = [&](int s_, float& a_, float& cp_, float& go_) {
         const int t_ = t0 + s_ * dt;
-        const long gb_ = (((long)n * S + t_) * 2 + dir) * G4;
-        i_ = gates[gb_ + j]; f_ = gates[gb_ + H + j]; g_ = gates[gb_ + 2 * H + j]; o_ = gates[gb_ + 3 * H + j];
-        cp_ = s_ > 0 ? cs[(((long)n * S + (t_ - dt)) * 2 + dir) * H + j] : 0.f;
-        go_ = g_out[((long)n * S + t_) * (2 * H) + dir * H + j];
+        a_ = gates[(((long)n * S + t_) * 2 + dir) * G4 + j];
+        cp_ = s_ > 0 ? cs[(((long)n * S + (t_ - dt)) * 2 + dir) * H + u] : 0.f;
+        go_ = g_out[((long)n * S + t_) * (2 * H) + dir * H + u];
     };
-    if (j < H) {
-        fetch(S - 1, ig, fg, gg, og, cp, go);
-        c = cs[(((long)n * S + (t0 + (S - 1) * dt)) * 2 + dir) * H + j];
-    }
-    __syncthreads();
+    fetch(S - 1, act, cp, go);
+    c = cs[(((long)n * S + (t0 + (S - 1) * dt)) * 2 + dir) * H + u];
     for (int s = S - 1; s >= 0; --s) {
-        const int t = t0 + s * dt;
-        float n_ig = 0.f, n_fg = 0.f, n_gg = 0.f, n_og = 0.f, n_cp = 0.f, n_go = 0.f;
-        if (j < H) {
-            if (s > 0) fetch(s - 1, n_ig, n_fg, n_gg, n_og, n_cp, n_go);
-            const long gb = (((long)n * S + t) * 2 + dir) * G4;
-            const float tc = tanhf(c);
-            const float gh = go + gh_s[j];
-            const float gc = gh * og * (1.f - tc * tc) + gc_rec;
-            const float pi = gc * gg * ig * (1.f - ig);
-            const float pf = gc * cp * fg * (1.f - fg);
-            const float pg = gc * ig * (1.f - gg * gg);
-            const float po = gh * tc * og * (1.f - og);
-            gc_rec = gc * fg;
-            sb0 += pi; sb1 += pf; sb2 += pg; sb3 += po;
-            gp_s[j] = pi; gp_s[H + j] = pf; gp_s[2 * H + j] = pg; gp_s[3 * H + j] = po;
-            g_pre[gb + j] = pi; g_pre[gb + H + j] = pf; g_pre[gb + 2 * H + j] = pg; g_pre[gb + 3 * H + j] = po;
-            c = cp;                                                    // c_{t-1} of this step is c_t of the next one
-            ig = n_ig; fg = n_fg; gg = n_gg; og = n_og; cp = n_cp; go = n_go;
-        }
+        const int tt = t0 + s * dt, cur = s & 1;
+        float n_act = 0.f, n_cp = 0.f, n_go = 0.f;
+        if (s > 0) fetch(s - 1, n_act, n_cp, n_go);
+        const float ig = quad_bcast0(act), fg = quad_bcast1(act), gg = quad_bcast2(act), og = quad_bcast3(act);
+        const float tc = fast_tanh(c);
+        const float gh = go + gh_rec;
+        const float gc = gh * og * (1.f - tc * tc) + gc_rec;
+        const float pi = gc * gg * ig * (1.f - ig);
+        const float pf = gc * cp * fg * (1.f - fg);
+        const float pg = gc * ig * (1.f - gg * gg);
+        const float po = gh * tc * og * (1.f - og);
+        gc_rec = gc * fg;
+        const float mine = gate == 0 ? pi : (gate == 1 ? pf : (gate == 2 ? pg : po));
+        sb += mine;
+        gp_s[cur][j] = mine;
+        g_pre[(((long)n * S + tt) * 2 + dir) * G4 + j] = mine;
+        c = cp;                                                        // c_{t-1} of this step is c_t of the next one
+        act = n_act; cp = n_cp; go = n_go;
         __syncthreads();
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        const float4* g4 = reinterpret_cast<const float4*>(gp_s + part * H);
+        const float4* g4 = reinterpret_cast<const float4*>(gp_s[cur] + gate * H);
 #pragma unroll
         for (int q = 0; q < H / 4; ++q) {
             const float4 gv = g4[q];
@@ -155,17 +169,9 @@ __global__ __launch_bounds__(G4) void lstm_rec_bwd_kernel(const float* __restric
             a2 = fmaf(w[4 * q + 2], gv.z, a2);
             a3 = fmaf(w[4 * q + 3], gv.w, a3);
         }
-        float a = (a0 + a1) + (a2 + a3);
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
-        // gh_s of this step was consumed before the barrier above, so it may be overwritten now
-        if (part == 0) gh_s[k] = a;
-        __syncthreads();
+        gh_rec = quad_sum((a0 + a1) + (a2 + a3));
     }
-    if (g_bias_part && j < H) {
-        float* bp = g_bias_part + (long)blockIdx.x * G4;               // [n][dir][4H]
-        bp[j] = sb0; bp[H + j] = sb1; bp[2 * H + j] = sb2; bp[3 * H + j] = sb3;
-    }
+    if (g_bias_part) g_bias_part[(long)blockIdx.x * G4 + j] = sb;       // [n][dir][4H]
 }
 
 }  // namespace
