@@ -471,6 +471,37 @@ extern "C" int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp
     return launch_direct(p.a, dcs_stream(stream));
 }
 
+// ---- real-valued convolution on the same MFMA kernel (DR-Net: r_network.py:60-66, :90-102) -------------------------
+// A real NHWC activation with an even channel count IS an interleaved "complex" one with half as many channels, and the
+// complex kernel's GEMM is a plain real GEMM over K = taps x real input channels, N = real output channels whose B
+// panel happens to have a 2x2 block structure.  A real conv only needs a B panel WITHOUT that structure: the caller
+// packs B[tap][k][n] = w[n][k][tap] into the 32-column fragment order (dcsnet/r_network.py) and this entry runs it.
+static bool rconv_ok(int C1r, int C2r, int Coutr) {
+    if ((C1r & 1) || (C2r & 1) || (Coutr & 1)) return false;
+    return conv::mfma_ok((C1r + C2r) / 2, Coutr / 2) && !((C1r / 2) & 1);
+}
+
+extern "C" long dcs_rconv2d_fwd_workspace_bytes(int B, int Hin, int Win, int C1r, int C2r, int up_f, int up_t, int Coutr,
+                                                int kh, int kw, int sf, int st, int pad_f, int pad_t) {
+    if (!rconv_ok(C1r, C2r, Coutr) || B <= 0 || Hin <= 0 || Win <= 0) return -1;
+    const ConvArgs a = fwd_args(nullptr, nullptr, B, Hin, Win, C1r / 2, C2r / 2, up_f, up_t, Coutr / 2, kh, kw, sf, st, pad_f,
+                                pad_t);
+    return dcs_conv_mfma_workspace_bytes_plain(a);
+}
+
+extern "C" int dcs_rconv2d_fwd(const float* x1, const float* x2, const float* bm, const float* bias, float* y,
+                               void* workspace, long workspace_bytes, int B, int Hin, int Win, int C1r, int C2r, int up_f,
+                               int up_t, int Coutr, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
+                               dcs_stream_t stream) {
+    if (!bm || !y || !rconv_ok(C1r, C2r, Coutr)) return DCS_ERR_BADARG;
+    if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1r / 2, C2r / 2, up_f, up_t, Coutr / 2, kh, kw, sf, st, pad_f, pad_t))
+        return DCS_ERR_BADARG;
+    if (act < DCS_ACT_NONE || act > DCS_ACT_SIGMOID) return DCS_ERR_BADARG;
+    ConvArgs a = fwd_args(x1, x2, B, Hin, Win, C1r / 2, C2r / 2, up_f, up_t, Coutr / 2, kh, kw, sf, st, pad_f, pad_t);
+    a.wp = nullptr; a.bias = (const float2*)bias; a.y = (float2*)y; a.act = act;
+    return dcs_conv_mfma_launch_wide(a, bm, workspace, workspace_bytes, dcs_stream(stream));
+}
+
 // data-gradient launch description shared by the workspace query and the launch itself
 struct DgradPlan {
     ConvArgs a;

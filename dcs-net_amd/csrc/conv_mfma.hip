@@ -413,6 +413,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // (the B-panel re-layout kernel lives in pack_jobs.hip: packjob::MFMA)
 
 struct Plan { int cand, TH, TW, CH, S, cps; long blocks; };
+thread_local bool g_force_wide_panel = false;
 
 template <int WAVES_N, int WM, int WN, int CH, bool BF>
 int launch_bf(MArgs& m, long npix, hipStream_t stream) {
@@ -599,7 +600,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
                     (y2 != nullptr && (nsplit & 3)))) {
         m.ksplit = 1; m.cps = Cin / p.CH; m.part = nullptr;
     }
-    if (m.N == 16 && p.cand == 3) {                           // 128 pixels x 16 columns, v_mfma_f32_16x16x4_f32
+    if (m.N == 16 && p.cand == 3 && !g_force_wide_panel) {    // 128 pixels x 16 columns, v_mfma_f32_16x16x4_f32
         switch (p.CH) {
             case 32: return launch16_ch<32>(m, npix, stream);
             case 16: return launch16_ch<16>(m, npix, stream);
@@ -632,6 +633,15 @@ static conv::Cls plain_class(const conv::Args& a) {
 long dcs_conv_mfma_workspace_bytes_plain(const conv::Args& a) {
     const conv::Cls c = plain_class(a);
     return dcs_conv_mfma_workspace_bytes(a, 1, &c);
+}
+
+// the caller's B panel is in the 32-column fragment order even where N = 16 (real-weight panels: dcs_rconv2d_fwd)
+int dcs_conv_mfma_launch_wide(conv::Args& a, const float* bm, void* ws, long ws_bytes, hipStream_t stream) {
+    const conv::Cls c = plain_class(a);
+    g_force_wide_panel = true;
+    const int rc = dcs_conv_mfma_launch_classes(a, bm, 1, &c, 1, 1, nullptr, 0, ws, ws_bytes, stream);
+    g_force_wide_panel = false;
+    return rc;
 }
 
 int dcs_conv_mfma_launch(conv::Args& a, const float* bm, void* ws, long ws_bytes, hipStream_t stream) {

@@ -107,6 +107,25 @@ int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const flo
                     dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Real-valued convolution (DR-Net / DRS-Net: torch.nn.Conv2d / ConvTranspose2d of r_network.py:60-66, :90-102) on the
+ * same fp32 MFMA implicit-GEMM kernel.  A real channels-last activation float[B][H][W][Cr] with even Cr is bit-for-bit
+ * an interleaved complex one with Cr/2 channels; the caller supplies the GEMM's B panel directly instead of a packed
+ * complex weight:
+ *   bm    float[taps][K/8 .. see below]: B[tap][k][n] = w[n][k][dy][dx] (k = real input channel of cat(x1, x2),
+ *         n = real output channel) in 32-column fragment order: element (tap, kg, nt, lane, e) with lane = 32*kk + j
+ *         holds B[tap][8*kg + 4*kk + e][32*nt + j], kg < (C1r+C2r)/8, nt < ceil(Coutr/32), zero beyond Coutr
+ *   bias  float[Coutr] or NULL
+ * Geometry as dcs_cconv2d_fwd with real channel counts: (C1r + C2r) % 16 == 0, Coutr % 16 == 0, C1r % 4 == 0.
+ * ConvTranspose2d (stride 1): pass the flipped, in/out-swapped kernel and padding k-1-p.  Forward only. */
+long dcs_rconv2d_fwd_workspace_bytes(int B, int Hin, int Win, int C1r, int C2r, int up_f, int up_t, int Coutr,
+                                     int kh, int kw, int sf, int st, int pad_f, int pad_t);
+int dcs_rconv2d_fwd(const float* x1, const float* x2, const float* bm, const float* bias, float* y,
+                    void* workspace, long workspace_bytes,
+                    int B, int Hin, int Win, int C1r, int C2r, int up_f, int up_t,
+                    int Coutr, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
+                    dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Gradients of dcs_cconv2d_fwd (what torch.autograd derives for the reference through the four
  * real convolutions of apply_complex; gradients of complex tensors are dL/dRe + j dL/dIm).
  *

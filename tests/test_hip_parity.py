@@ -435,3 +435,56 @@ def test_bf16_mode_whole_network_and_gradients(dev):
     print(f'bf16 mode: train-mode mask rel-L2 {e_mask:.3e}; eval-mode gradients rel-L2 {e_all:.3e}')
     assert 1e-4 < e_mask <= 2e-2, e_mask
     assert e_all <= 3e-2, e_all
+
+
+# ---- BASELINE configs[0]: DR-Net (r_network.py) on the HIP path -------------------------------------------------
+
+def test_real_conv_on_the_mfma_kernel(dev):
+    """dcs_rconv2d_fwd: a real conv (cat of two sources, nearest upsample, stride) = the complex kernel's GEMM with an
+    unstructured B panel, against torch.nn.functional.conv2d."""
+    from dcsnet import r_network as rn
+    g = torch.Generator().manual_seed(3)
+    cases = [(2, 12, 20, 32, 0, 48, 3, (2, 1), (1, 1)), (3, 6, 8, 16, 16, 16, 3, (1, 1), (2, 2)),
+             (2, 9, 7, 32, 32, 64, 5, (2, 2), (1, 1)), (1, 4, 32, 256, 256, 128, 3, (1, 1), (2, 1))]
+    for B, H, W, c1, c2, co, k, stride, up in cases:
+        x1 = torch.randn((B, H, W, c1), generator=g)
+        x2 = torch.randn((B, H, W, c2), generator=g) if c2 else None
+        w = torch.randn((co, c1 + c2, k, k), generator=g) * 0.1
+        b = torch.randn(co, generator=g)
+        xin = x1 if x2 is None else torch.cat([x1, x2], -1)
+        xin = xin.permute(0, 3, 1, 2)
+        if up != (1, 1):
+            xin = torch.nn.functional.interpolate(xin, scale_factor=up, mode='nearest')
+        want = torch.nn.functional.conv2d(xin, w, b, stride, k // 2).permute(0, 2, 3, 1)
+        got = rn.rconv2d(x1.to(dev), None if x2 is None else x2.to(dev), rn.pack_real_panel(w.to(dev)), b.to(dev), co,
+                         (k, k), stride, (k // 2, k // 2), up)
+        close(got, want, rel=2e-5)
+
+
+@pytest.mark.parametrize('tag,B,T', [('b1t256', 1, 256), ('b2t32', 2, 32)])
+def test_rnetwork_forward_against_reference_vectors(dev, golden_dir, tag, B, T):
+    """R_NETWORK (DR-Net) forward on the HIP path against the outputs of the reference's own r_network.py
+    (tests/golden/rnet_vectors.npz: seeded state -> eval and train-mode output) — configs[0]."""
+    from dcsnet.config import config, hparams
+    from dcsnet.r_network import R_NETWORK
+    from oracle.seeded_state import fill_state_stream
+    v = np.load(os.path.join(golden_dir, 'rnet_vectors.npz'))
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    net = fill_state_stream(R_NETWORK(config, hp, 0), 5).to(dev)
+    assert sum(p.numel() for p in net.parameters()) == 5808753          # SURVEY.md §8c
+    x = torch.from_numpy(v[f'{tag}_x']).to(dev)
+    net.eval()
+    with torch.no_grad():
+        ev = net(x)
+        ev2 = net(x)                                                     # cached panels / coefficients
+    assert torch.equal(ev, ev2)
+    want = torch.from_numpy(v[f'{tag}_eval'])
+    assert ev.shape == want.shape                                         # [256, T] when B == 1 (squeeze quirk)
+    close(ev, want, rel=0, abs_=2e-5)
+    net.train()
+    with torch.no_grad():
+        tr = net(x)
+    close(tr, torch.from_numpy(v[f'{tag}_train']), rel=0, abs_=5e-5)
+    with pytest.raises(Exception):                                       # forward-only: no silent autograd through it
+        net(x)
