@@ -18,8 +18,7 @@
 
 namespace {
 
-constexpr int H = 64;
-constexpr int G4 = 4 * H;
+constexpr int kHBwd = 64;          // the backward kernel (complex net only) is built for hidden size 64
 
 // tanh through the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each): 1 - 2 / (2^(2x log2 e) + 1), absolute
 // error ~1e-7 (saturates correctly at +-1).  The library tanhf / expf pair costs ~100 VALU instructions per step on the
@@ -45,12 +44,13 @@ __device__ __forceinline__ float quad_sum(float v) {
 // Thread t = 4*u + gate: the four gates (i, f, g, o) of hidden unit u sit in one quad, so the cell update needs no LDS
 // round trip — the activations are exchanged with quad_perm DPP and all four lanes update (c, h) redundantly.  h lives
 // in a double-buffered LDS vector (step s reads buffer s&1 while lane gate 0 writes the other): ONE barrier per step.
-template <bool SAVE>
-__global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+template <int H, bool SAVE>
+__global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
                                                            float* __restrict__ out, float* __restrict__ gates_save,
                                                            float* __restrict__ c_save, float* __restrict__ hprev_save,
                                                            int S, int seqs_per_set, long stride_set, long stride_n,
                                                            long stride_t) {
+    constexpr int G4 = 4 * H;
     __shared__ __attribute__((aligned(16))) float h_s[2][H];
     const int t = threadIdx.x, u = t >> 2, gate = t & 3, j = gate * H + u;      // j: PyTorch gate row (i, f, g, o blocks)
     const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
@@ -113,10 +113,11 @@ __global__ __launch_bounds__(G4) void lstm_rec_fwd_kernel(const float* __restric
 // (W_hh column of unit u, rows gate*H..) plus a quad sum — so the recurrent cotangent of unit u never leaves the quad.
 // g_pre of the step goes through a double-buffered LDS vector: ONE barrier per step.  The next step's operands are
 // fetched while the current one computes (none depends on the recurrence).
-__global__ __launch_bounds__(G4) void lstm_rec_bwd_kernel(const float* __restrict__ g_out,
+__global__ __launch_bounds__(4 * kHBwd) void lstm_rec_bwd_kernel(const float* __restrict__ g_out,
                                                            const float* __restrict__ gates, const float* __restrict__ cs,
                                                            const float* __restrict__ whh, float* __restrict__ g_pre,
                                                            float* __restrict__ g_bias_part, int S, int seqs_per_set) {
+    constexpr int H = kHBwd, G4 = 4 * H;
     __shared__ __attribute__((aligned(16))) float gp_s[2][G4];
     const int t = threadIdx.x, u = t >> 2, gate = t & 3, j = gate * H + u;
     const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
@@ -179,9 +180,9 @@ __global__ __launch_bounds__(G4) void lstm_rec_bwd_kernel(const float* __restric
 extern "C" int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_save, const float* w_hh,
                                   float* g_pre, float* g_bias_part, int n_sets, int seqs_per_set, int S, int Hdim,
                                   dcs_stream_t stream) {
-    if (!g_out || !gates || !c_save || !w_hh || !g_pre || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || Hdim != H)
+    if (!g_out || !gates || !c_save || !w_hh || !g_pre || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || Hdim != kHBwd)
         return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(lstm_rec_bwd_kernel, dim3(n_sets * seqs_per_set * 2), dim3(G4), 0, dcs_stream(stream), g_out,
+    hipLaunchKernelGGL(lstm_rec_bwd_kernel, dim3(n_sets * seqs_per_set * 2), dim3(4 * kHBwd), 0, dcs_stream(stream), g_out,
                        gates, c_save, w_hh, g_pre, g_bias_part, S, seqs_per_set);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -190,15 +191,19 @@ extern "C" int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const 
 extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
                                   float* hprev_save, int n_sets, int seqs_per_set, int S, int Hdim, long stride_set, long stride_n,
                                   long stride_t, dcs_stream_t stream) {
-    if (!gx || !w_hh || !out || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || Hdim != H) return DCS_ERR_BADARG;
+    if (!gx || !w_hh || !out || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || (Hdim != 64 && Hdim != 128)) return DCS_ERR_BADARG;
     if ((gates_save == nullptr) != (c_save == nullptr)) return DCS_ERR_BADARG;
+    if (Hdim == 128 && gates_save) return DCS_ERR_BADARG;     // hidden 128 (DR-Net): inference only, no backward kernel
     const int NS = n_sets * seqs_per_set;
     dim3 grid(NS * 2);
-    if (gates_save)
-        hipLaunchKernelGGL(lstm_rec_fwd_kernel<true>, grid, dim3(G4), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
+    if (Hdim == 128)
+        hipLaunchKernelGGL((lstm_rec_fwd_kernel<128, false>), grid, dim3(512), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
+                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+    else if (gates_save)
+        hipLaunchKernelGGL((lstm_rec_fwd_kernel<64, true>), grid, dim3(256), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
                            c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
     else
-        hipLaunchKernelGGL(lstm_rec_fwd_kernel<false>, grid, dim3(G4), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
+        hipLaunchKernelGGL((lstm_rec_fwd_kernel<64, false>), grid, dim3(256), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
                            c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

@@ -53,6 +53,8 @@ SIGNATURES = {
     'dcs_channel_attention_fwd': (_I, [_P] * 7 + [_L, _I, _L, _I, _I, _P]),
     'dcs_spatial_pool_fwd': (_I, [_P, _P, _P, _I, _L, _I, _P]),
     'dcs_attention_apply_fwd': (_I, [_P, _P, _P, _P, _I, _L, _I, _F, _U64, _P, _P]),
+    'dcs_rattention_workspace_bytes': (_L, [_I, _L, _I]),
+    'dcs_rattention_fwd': (_I, [_P] * 8 + [_L] + [_I] * 6 + [_P]),
     'dcs_attention_bwd_sa': (_I, [_P] * 5 + [_I, _L, _I, _F, _U64, _P, _P]),
     'dcs_attention_bwd_workspace_bytes': (_L, [_I, _L, _I, _I]),
     'dcs_attention_bwd_x': (_I, [_P] * 16 + [_L, _I, _L, _I, _I, _F, _U64, _P, _P]),

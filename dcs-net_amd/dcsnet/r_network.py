@@ -14,12 +14,15 @@ reference checkpoint loads.  `forward` does not run those containers; it runs
     of a 16 -> 1 complex conv with weights (w_even - j w_odd);
   * BatchNorm2d + ReLU / LeakyReLU as the CBN apply kernel with per-real-channel coefficients (a diagonal 2x2 block per
     complex pair), batch statistics (train mode) from two reductions of the activation;
-  * the 7x7 spatial-attention conv (2 -> 1 real = 1 -> 1 complex with the same trick) on the direct kernel.
+  * both attentions of a block in one C-ABI call (dcs_rattention_fwd, csrc/r_attention.hip): channel max pool, FC,
+    per-pixel (mean, max) of ca*x, the 7x7 conv (2 -> 1 real = 1 -> 1 complex with the same pairing trick, direct
+    kernel) and the broadcast multiply;
 
-Plumbing that stays in ATen on this path (tiny tensors, or not on the measured path): the LSTM / Linear (MIOpen / rocBLAS
-through torch.nn.LSTM — hidden size 128; the hand-written recurrence is built for the complex net's 64), the per-channel
-max pool + 1x1 FC of the channel attention, the channel mean / max of the spatial attention and the two broadcast
-multiplies.  Forward only: there is no hand-written backward for the real path (training DR-Net is out of scope).
+  * the LSTM recurrence on the persistent kernel of the complex path, instantiated for hidden size 128 (one weight set);
+    its input projections and the Linear are plain rocBLAS GEMMs.
+
+Plumbing that stays in ATen on this path: the one-channel initial BatchNorm (a scalar affine), the batch statistics of
+train-mode BatchNorm, the final sigmoid.  Forward only: there is no hand-written backward for the real path (training DR-Net is out of scope).
 
 Quirks kept (r_network.py): channel attention = sigmoid(fc(max_pool)) only (:23-24); dropout_fc gated by
 hparams['dropout'] (:152) while dropout_conv is not; torch.squeeze drops the batch dimension at B = 1 (:171).
@@ -231,10 +234,47 @@ class R_NETWORK(LightningModule):
                         pad, up)
         return y[..., 0, 0]                                                                 # [B, Hout, Wout]
 
+    def _lstm(self, x):
+        """torch.nn.LSTM (bidirectional, batch_first) forward: per layer one input-projection GEMM for all time steps
+        (rocBLAS) + the hand-written recurrence (dcs_lstm_layer_fwd, hidden size 128, one weight set)."""
+        lstm = self.lstm
+        if not (lstm.bidirectional and lstm.batch_first and lstm.hidden_size in (64, 128)):
+            raise DcsHipError('R_NETWORK: LSTM geometry outside the HIP recurrence (bidirectional, batch_first, hidden 64/128)')
+        B, S, _ = x.shape
+        Hh = lstm.hidden_size
+        inp = x.reshape(B * S, -1)
+        for layer in range(lstm.num_layers):
+            names = [f'_l{layer}', f'_l{layer}_reverse']
+            ps = [getattr(lstm, k + n) for n in names for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+            def make():
+                w_ih = torch.cat([getattr(lstm, 'weight_ih' + n) for n in names])                       # [8H, in]
+                bias = torch.cat([getattr(lstm, 'bias_ih' + n) + getattr(lstm, 'bias_hh' + n) for n in names])
+                w_hh = torch.stack([getattr(lstm, 'weight_hh' + n) for n in names]).unsqueeze(0).contiguous()   # [1,2,4H,H]
+                return w_ih, bias, w_hh
+            w_ih, bias, w_hh = _packed(lstm, f'lstm{layer}', ps, make)
+            gx = torch.addmm(bias, inp, w_ih.t())                                                        # [B*S, 2*4H]
+            out, _, _ = ops.lstm_layer(gx, w_hh, 1, B, S, (0, S * 8 * Hh, 8 * Hh), False)               # [B, S, 2H]
+            inp = out.reshape(B * S, 2 * Hh)
+        return inp.view(B, S, 2 * Hh)
+
     @staticmethod
     def _attend(ca_m, sa_m, x):
-        z = x * ca_m.hip(x)[:, None, None, :]
-        return z * sa_m.hip(z)
+        """sa (.) ca (.) x (r_network.py:155-158 / :166-167) in one C-ABI call: dcs_rattention_fwd."""
+        from . import _lib
+        lib = _lib.load()
+        B, H, W, C = x.shape
+        w1, w2, w = ca_m.fc[0].weight, ca_m.fc[2].weight, sa_m.conv1.weight
+        wp, bias = _packed(sa_m, 'sa', (w,), lambda: ops.pack_conv_weight(w[:, 0:1].contiguous(), (-w[:, 1:2]).contiguous()))
+        nbytes = lib.dcs_rattention_workspace_bytes(B, H * W, C)
+        if nbytes < 0:
+            raise DcsHipError(f'R_NETWORK attention: unsupported channel count {C}')
+        ws = ops._workspace(nbytes, x.device)
+        ca = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        _lib.check(lib.dcs_rattention_fwd(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(ca),
+                                          _lib.ptr(y), _lib.ptr(ws), ws.numel(), B, H, W, C, w1.shape[0], sa_m.kernel_size,
+                                          _lib.cur_stream()), 'dcs_rattention_fwd')
+        return y
 
     # ---- forward (r_network.py:140-173) ---------------------------------------------------------------------------
     def forward(self, x):
@@ -266,7 +306,7 @@ class R_NETWORK(LightningModule):
             feats.append(drop(y) if drop is not None else y)
         lat = feats[L]
         _, F7, T7, C7 = lat.shape
-        z = self.fc(self.lstm(lat.reshape(B, F7 * T7, C7))[0])
+        z = self.fc(self._lstm(lat.reshape(B, F7 * T7, C7)))
         if hp['dropout'] and self.training:
             z = self.dropout_fc(z)
         d = z.reshape(B, F7, T7, C7)

@@ -271,6 +271,19 @@ int dcs_attention_bwd_batched(int n, const dcs_attention_item* items, void* work
                               dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Real-valued attention pair of DR-Net (r_network.py:8-42; applied :155-158, :166-167) on float[B][H][W][C]:
+ *   ca = sigmoid(fc(max_pool(x)))  (the reference's avg branch is overwritten, r_network.py:23-24);
+ *   y = sa (.) ca (.) x,  sa = sigmoid(conv_kxk(cat(mean_c(ca x), max_c(ca x)))).
+ *   w1, w2    fc.0.weight float[Ch][C], fc.2.weight float[C][Ch] (1x1 nn.Conv2d, no bias, torch layout)
+ *   wsa, sa_bias  dcs_pack_conv_weight of the k x k conv taken as a 1 -> 1 COMPLEX conv with weights
+ *             (w[:,0] , -w[:,1]) and no bias: its real part over the (mean, max) pair is the real 2 -> 1 conv
+ *   ca_out    float[B][C];  y float[B][H][W][C];  C % 4 == 0, C/4 a power of two <= 64;  forward only. */
+long dcs_rattention_workspace_bytes(int B, long HW, int C);
+int  dcs_rattention_fwd(const float* x, const float* w1, const float* w2, const float* wsa, const float* sa_bias,
+                        float* ca_out, float* y, void* workspace, long workspace_bytes,
+                        int B, int H, int W, int C, int Ch, int ksize, dcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Backward of the fused attention block  out = dropout(sa (.) ca (.) x)  built from the four
  * forward entry points above (channel attention -> spatial pool -> 7x7 conv + sigmoid -> apply).
  * Step 1  dcs_attention_bwd_sa: g_pre[b][p] = sigmoid'(sa) (.) sum_c g_o conj(ca x)   (complex[B][HW]);
@@ -307,7 +320,8 @@ int  dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, co
  *          float[NS][S][2][H] (cell state) saved for dcs_lstm_layer_bwd.
  *   hprev_save  optional (NULL, or with gates_save): float[NS][S][2][H], the hidden state each step STARTED from
  *          (h_{t-1} forward, h_{t+1} reverse, zero at the sequence ends) = the right-hand operand of the W_hh gradient.
- * H must be 64 (hparams channels[4]//2, config.py:35). */
+ * H = 64 (C_NETWORK: hparams channels[4]//2, config.py:35) or, for inference only (gates_save == NULL), 128
+ * (R_NETWORK's real LSTM, r_network.py:71-75, with n_sets = 1). */
 int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
                        float* hprev_save, int n_sets, int seqs_per_set, int S, int H, long stride_set, long stride_n, long stride_t,
                        dcs_stream_t stream);

@@ -488,3 +488,22 @@ def test_rnetwork_forward_against_reference_vectors(dev, golden_dir, tag, B, T):
     close(tr, torch.from_numpy(v[f'{tag}_train']), rel=0, abs_=5e-5)
     with pytest.raises(Exception):                                       # forward-only: no silent autograd through it
         net(x)
+
+
+@pytest.mark.parametrize('C,hw', [(16, (37, 5)), (64, (9, 11)), (256, (2, 32))])
+def test_real_attention_pair(dev, C, hw):
+    """dcs_rattention_fwd against the oracle's RealChannelAttention / RealSpatialAttention (r_network.py:8-42)."""
+    from oracle.rnet_oracle import RealChannelAttention as OCA, RealSpatialAttention as OSA
+    from dcsnet.r_network import R_NETWORK, RealChannelAttention, RealSpatialAttention
+    torch.manual_seed(C)
+    oca, osa = OCA(C, 16), OSA(7)
+    x = torch.randn(3, C, *hw)
+    with torch.no_grad():
+        z = oca(x) * x
+        want = (osa(z) * z).permute(0, 2, 3, 1)
+    ca, sa = RealChannelAttention(C, 16), RealSpatialAttention(7)
+    ca.load_state_dict(oca.state_dict()); sa.load_state_dict(osa.state_dict())
+    ca, sa = ca.to(dev), sa.to(dev)
+    with torch.no_grad():
+        got = R_NETWORK._attend(ca, sa, x.permute(0, 2, 3, 1).contiguous().to(dev))
+    close(got, want, rel=2e-5)
