@@ -100,6 +100,25 @@ def test_state_dict_round_trip_with_oracle():
         assert torch.equal(v, o.state_dict()[k]), k
 
 
+def test_rnetwork_state_dict_round_trip_with_oracle():
+    """DR-Net: the oracle (pinned against the reference's r_network.py) and the HIP module share every state_dict key,
+    shape and dtype, so a reference checkpoint loads; the HIP forward refuses CPU tensors (no fallback)."""
+    from dcsnet.config import config, hparams
+    from dcsnet.r_network import R_NETWORK
+    from dcsnet import DcsHipError
+    from oracle.rnet_oracle import R_NETWORK_Oracle
+    from oracle.seeded_state import fill_state_stream
+    o = fill_state_stream(R_NETWORK_Oracle(), 5)
+    net = R_NETWORK(config, hparams, 0)
+    assert list(net.state_dict().keys()) == list(o.state_dict().keys())
+    net.load_state_dict(o.state_dict())
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, o.state_dict()[k]), k
+    with pytest.raises(DcsHipError):
+        with torch.no_grad():
+            net.eval()(torch.zeros(1, 256, 32))
+
+
 def test_forward_validates_input():
     from dcsnet.config import config, hparams
     from dcsnet.c_network import C_NETWORK
