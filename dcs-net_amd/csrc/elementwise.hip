@@ -84,6 +84,54 @@ __global__ __launch_bounds__(kThreads) void tapsum_fwd_kernel(const float2* __re
     }
 }
 
+// Tiled form: a workgroup owns a TOY x TOX output tile, stages the source pixels it touches (all taps of a pixel are
+// contiguous: coalesced rows) in LDS once and sums from there.  The streaming form above re-fetches every source row for
+// each of the up_f + kh - 1 output rows that read it (PMC: 3x the tensor's bytes from HBM at dec6).
+constexpr int TOY = 16, TOX = 64, kTapLds = 10 * 34 * 9;               // float2 elements (24.5 KB): up (2,2), k = 3
+// FIX = true: kh = kw = 3, up = (2, 2) as compile-time constants (dec6), so the index arithmetic is shifts
+template <bool FIX>
+__global__ __launch_bounds__(kThreads) void tapsum_fwd_tiled_kernel(const float2* __restrict__ z, float2* __restrict__ y,
+                                                                     int B, int Hs, int Ws, int CT, int kh_, int kw_, int up_f_,
+                                                                     int up_t_, int pad_f, int pad_t, int SR_, int SC_) {
+    const int kh = FIX ? 3 : kh_, kw = FIX ? 3 : kw_, up_f = FIX ? 2 : up_f_, up_t = FIX ? 2 : up_t_;
+    const int SR = FIX ? 10 : SR_, SC = FIX ? 34 : SC_;
+    __shared__ float2 tile[kTapLds];
+    const int Ho = Hs * up_f, Wo = Ws * up_t, taps = kh * kw;
+    const int tiles_x = (Wo + TOX - 1) / TOX, tiles_y = (Ho + TOY - 1) / TOY;
+    const int t = threadIdx.x;
+    for (long tl = blockIdx.x; tl < (long)B * tiles_y * tiles_x; tl += gridDim.x) {
+        const int tx = (int)(tl % tiles_x), ty = (int)((tl / tiles_x) % tiles_y), b = (int)(tl / ((long)tiles_x * tiles_y));
+        const int oy0 = ty * TOY, ox0 = tx * TOX;
+        const int vy0 = oy0 - pad_f, vx0 = ox0 - pad_t;
+        const int sy0 = (vy0 < 0 ? 0 : vy0) / up_f, sx0 = (vx0 < 0 ? 0 : vx0) / up_t;
+        __syncthreads();
+        for (int i = t; i < SR * SC * taps; i += kThreads) {
+            const int tap = i % taps, px = i / taps;
+            const int sx = sx0 + px % SC, sy = sy0 + px / SC;
+            float2 v = make_float2(0.f, 0.f);
+            if (sy < Hs && sx < Ws) v = z[(((long)b * Hs + sy) * Ws + sx) * CT + tap];
+            tile[i] = v;
+        }
+        __syncthreads();
+        for (int p = t; p < TOY * TOX; p += kThreads) {
+            const int oy = oy0 + p / TOX, ox = ox0 + p % TOX;
+            if (oy >= Ho || ox >= Wo) continue;
+            float sr = 0.f, si = 0.f;
+            for (int dy = 0; dy < kh; ++dy) {
+                const int vy = oy - pad_f + dy;
+                if (vy < 0 || vy >= Ho) continue;
+                for (int dx = 0; dx < kw; ++dx) {
+                    const int vx = ox - pad_t + dx;
+                    if (vx < 0 || vx >= Wo) continue;
+                    const float2 v = tile[((vy / up_f - sy0) * SC + (vx / up_t - sx0)) * taps + dy * kw + dx];
+                    sr += v.x; si += v.y;
+                }
+            }
+            y[((long)b * Ho + oy) * Wo + ox] = make_float2(sr, si);
+        }
+    }
+}
+
 // gz[b][my][mx][tap] = sum over the output pixels that read z[b][my][mx][tap] in the forward pass
 __global__ __launch_bounds__(kThreads) void tapsum_bwd_kernel(const float2* __restrict__ gy, float2* __restrict__ gz,
                                                                int B, int Hs, int Ws, int CT, int kh, int kw, int up_f,
@@ -120,6 +168,20 @@ extern "C" int dcs_tapsum_fwd(const float* z, float* y, int B, int Hs, int Ws, i
         pad_f < 0 || pad_t < 0)
         return DCS_ERR_BADARG;
     const long n = (long)B * Hs * up_f * Ws * up_t;
+    // source rows / columns a TOY x TOX output tile can touch
+    const int SR = (TOY + kh - 2) / up_f + 2, SC = (TOX + kw - 2) / up_t + 2;
+    if ((long)SR * SC * kh * kw <= kTapLds) {
+        const long tiles = (long)B * ((Hs * up_f + TOY - 1) / TOY) * ((Ws * up_t + TOX - 1) / TOX);
+        const dim3 grid((unsigned)(tiles < 8192 ? tiles : 8192));
+        if (kh == 3 && kw == 3 && up_f == 2 && up_t == 2 && SR == 10 && SC == 34)
+            hipLaunchKernelGGL(tapsum_fwd_tiled_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
+                               (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, SR, SC);
+        else
+            hipLaunchKernelGGL(tapsum_fwd_tiled_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
+                               (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, SR, SC);
+        DCS_CHECK_LAUNCH();
+        return DCS_OK;
+    }
     hipLaunchKernelGGL(tapsum_fwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
                        (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t);
     DCS_CHECK_LAUNCH();
