@@ -90,6 +90,8 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
 long dcs_conv_mfma_workspace_bytes(const conv::Args& a, int ncls, const conv::Cls* cls);
 long dcs_conv_mfma_workspace_bytes_plain(const conv::Args& a);
 int dcs_conv_mfma_launch(conv::Args& a, const float* bm, void* ws, long ws_bytes, hipStream_t stream);
+int dcs_conv_mfma_launch_split(conv::Args& a, const float* bm, float* y2, int nsplit, void* ws, long ws_bytes,
+                               hipStream_t stream);
 int dcs_conv_mfma_launch_wide(conv::Args& a, const float* bm, void* ws, long ws_bytes, hipStream_t stream);
 int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const conv::Cls* cls, int os_f, int os_t,
                                  float* y2, int nsplit, void* ws, long ws_bytes, hipStream_t stream);

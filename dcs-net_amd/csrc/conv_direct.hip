@@ -510,6 +510,7 @@ struct DgradPlan {
     int ncls, os_f, os_t;
     conv::Cls cls[4];
     long gxv_bytes;            // gradient of the virtual (upsampled / concatenated) input, 0 when written straight to g_x1
+    bool split;                // path 3 writes g_x1 | g_x2 from its epilogue
     int Hv, Wv, Hout, Wout;
 };
 
@@ -535,7 +536,10 @@ static DgradPlan dgrad_plan(const float* gy, int B, int Hin, int Win, int C1, in
         p.path = 0;
         return p;
     }
-    if (up_f * up_t > 1 || C2 > 0) p.gxv_bytes = (long)B * p.Hv * p.Wv * Cin * (long)sizeof(float2);
+    // stride-1 conv over a plain concatenation (no upsample): the MFMA epilogue splits its columns into g_x1 | g_x2, so the
+    // gradient of the virtual input is never materialised (dec6's 1x1 tap conv: a 67 MB round trip + a split kernel)
+    p.split = up_f * up_t == 1 && sf == 1 && st == 1 && C2 > 0 && conv::mfma_ok(Cout, Cin) && !(C1 & 1);
+    if ((up_f * up_t > 1 || C2 > 0) && !p.split) p.gxv_bytes = (long)B * p.Hv * p.Wv * Cin * (long)sizeof(float2);
     if (C2 == 0 && dcs_conv_small_dgrad_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) { p.path = 1; return p; }
     if (conv::stride_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t)) {
         // one compact sub-kernel per residue class of the input pixel instead of zero insertion
@@ -608,6 +612,8 @@ extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float*
             break;
         case 3:
             p.a.wp = (const float2*)wp_bwd;
+            if (p.split)
+                return dcs_conv_mfma_launch_split(p.a, wp_bwd + conv::direct_floats(Cin, Cout, taps), gx2, 2 * C1, ws2, ws2_bytes, s);
             rc = dcs_conv_mfma_launch(p.a, wp_bwd + conv::direct_floats(Cin, Cout, taps), ws2, ws2_bytes, s);
             break;
         default:

@@ -644,6 +644,13 @@ int dcs_conv_mfma_launch_wide(conv::Args& a, const float* bm, void* ws, long ws_
     return rc;
 }
 
+// columns >= nsplit of the output go to y2 (g_x1 | g_x2 of a concatenation)
+int dcs_conv_mfma_launch_split(conv::Args& a, const float* bm, float* y2, int nsplit, void* ws, long ws_bytes,
+                               hipStream_t stream) {
+    const conv::Cls c = plain_class(a);
+    return dcs_conv_mfma_launch_classes(a, bm, 1, &c, 1, 1, y2, nsplit, ws, ws_bytes, stream);
+}
+
 int dcs_conv_mfma_launch(conv::Args& a, const float* bm, void* ws, long ws_bytes, hipStream_t stream) {
     const conv::Cls c = plain_class(a);
     return dcs_conv_mfma_launch_classes(a, bm, 1, &c, 1, 1, nullptr, 0, ws, ws_bytes, stream);
