@@ -83,6 +83,9 @@ int dcs_conv_small_dgrad_launch(const float* gy, const float* wp_bwd, float* gx,
 
 // conv_direct.hip: n small direct correlations (same batch, Cout 1 or 2) in one launch
 int dcs_conv_direct_multi(conv::Args* a, int n, hipStream_t stream);
+// conv_k7.hip: register-blocked 7x7 / stride 1 / pad 3 complex convs with (Cin, Cout) in {(2,1), (1,2), (1,1)}
+bool dcs_conv_k7_ok(const conv::Args* a, int n);
+int dcs_conv_k7_launch(const conv::Args* a, int n, hipStream_t stream);
 
 // conv_mfma.hip
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);

@@ -269,6 +269,7 @@ bool conv_geometry(ConvArgs& a) {
 // gradients) as one launch; `a`: geometry with Hout / Wout set (tiling is filled in here)
 int launch_direct_multi(ConvArgs* a, int n, hipStream_t stream) {
     if (n < 1 || n > kDirectBatch) return DCS_ERR_BADARG;
+    if (dcs_conv_k7_ok(a, n)) return dcs_conv_k7_launch(a, n, stream);          // the attention convs: conv_k7.hip
     DirectTable t;
     size_t lds = 0;
     int tiles = 0;
@@ -290,6 +291,7 @@ int launch_direct_multi(ConvArgs* a, int n, hipStream_t stream) {
 }
 
 int launch_direct(ConvArgs& a, hipStream_t stream) {
+    if (dcs_conv_k7_ok(&a, 1)) return dcs_conv_k7_launch(&a, 1, stream);        // the attention convs: conv_k7.hip
     if (!conv_geometry(a)) return DCS_ERR_BADARG;
     const int Cin = a.C1 + a.C2;
     const size_t lds = (size_t)(Cin < CHUNK ? Cin : CHUNK) * a.plane * sizeof(float2);

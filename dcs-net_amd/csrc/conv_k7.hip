@@ -1,0 +1,125 @@
+// conv_k7.hip — the 7x7, stride-1, pad-3 complex convolutions with one or two channels on either side: the spatial-
+// attention conv (2 -> 1, c_network.py:74-84; 13 per forward pass) and its data gradient (1 -> 2), register-blocked.
+//
+// The generic direct kernel (conv_direct.hip) does one LDS read of x and one scalar-cache read of w per complex MAC:
+// at Cout = 1 that is 2 memory operations per 4 FMAs with nothing to amortise them (measured ~8 TFLOP/s).  Here a thread
+// owns PB = 4 horizontally adjacent output pixels: per (input channel, kernel row) it loads the 10 input values the four
+// windows span once and re-uses each of them for up to 4 outputs x 7 taps; the 49 x CI x CO weights sit in LDS
+// (broadcast reads).  ~6.6 FMAs per LDS access instead of 2.
+//   tile  16 rows x 64 columns of output per 256-thread workgroup; haloed input 22 x 70 x CI in LDS
+// Problems may be batched (table by value, problem = blockIdx.y) like the other attention kernels.
+#include "conv_common.h"
+
+namespace {
+
+constexpr int K = 7, PAD = 3, TR = 16, TC = 64, PB = 4, ROWS = TR + K - 1, COLS = TC + K - 1, COLSP = COLS + 2;   // 72: rows stay 16-byte aligned
+constexpr int kMaxBatch = 8;
+
+struct K7P {
+    const float2* x; const float2* w; const float2* bias; float2* y;
+    int H, W, tiles_w, tiles, act;
+};
+struct K7Table { K7P p[kMaxBatch]; };
+
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void cconv_k7_kernel(K7Table tb) {
+    __shared__ __attribute__((aligned(16))) float2 tile[CI][ROWS * COLSP];
+    __shared__ float2 wl[K * K * CI * CO];
+    const K7P& p = tb.p[blockIdx.y];
+    if ((int)blockIdx.x >= p.tiles) return;
+    const int t = threadIdx.x, b = blockIdx.z;
+    const int oy0 = ((int)blockIdx.x / p.tiles_w) * TR, ox0 = ((int)blockIdx.x % p.tiles_w) * TC;
+    for (int i = t; i < K * K * CI * CO; i += 256) wl[i] = p.w[i];            // [tap][ci][co]
+    const float2* xb = p.x + (long)b * p.H * p.W * CI;
+    for (int i = t; i < ROWS * COLS; i += 256) {
+        const int iy = i / COLS, ix = i % COLS;
+        const int y = oy0 - PAD + iy, x = ox0 - PAD + ix;
+        const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+            tile[ci][iy * COLSP + ix] = in ? xb[((long)y * p.W + x) * CI + ci] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    const int ty = t / (TC / PB), tx = (t % (TC / PB)) * PB;
+    float ar[PB][CO], ai[PB][CO];
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+#pragma unroll
+        for (int co = 0; co < CO; ++co) { ar[q][co] = 0.f; ai[q][co] = 0.f; }
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+#pragma unroll 1
+        for (int dy = 0; dy < K; ++dy) {
+            float2 xv[PB + K - 1];                                     // 10 values = 5 aligned 16-byte reads
+            const float4* row = reinterpret_cast<const float4*>(&tile[ci][(ty + dy) * COLSP + tx]);
+#pragma unroll
+            for (int j = 0; j < (PB + K - 1) / 2; ++j) {
+                const float4 v4 = row[j];
+                xv[2 * j] = make_float2(v4.x, v4.y); xv[2 * j + 1] = make_float2(v4.z, v4.w);
+            }
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float2 w = wl[((dy * K + dx) * CI + ci) * CO + co];
+#pragma unroll
+                    for (int q = 0; q < PB; ++q) {
+                        const float2 v = xv[q + dx];
+                        ar[q][co] = fmaf(w.x, v.x, ar[q][co]);
+                        ar[q][co] = fmaf(-w.y, v.y, ar[q][co]);
+                        ai[q][co] = fmaf(w.x, v.y, ai[q][co]);
+                        ai[q][co] = fmaf(w.y, v.x, ai[q][co]);
+                    }
+                }
+            }
+        }
+    }
+    const int oy = oy0 + ty;
+    if (oy >= p.H) return;
+    float2* yb = p.y + ((long)b * p.H + oy) * p.W * CO;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int ox = ox0 + tx + q;
+        if (ox >= p.W) continue;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            const float2 bv = p.bias ? p.bias[co] : make_float2(0.f, 0.f);
+            yb[(long)ox * CO + co] = make_float2(dcs_act(ar[q][co] + bv.x, p.act), dcs_act(ai[q][co] + bv.y, p.act));
+        }
+    }
+}
+
+bool k7_geom(const conv::Args& a) {
+    return a.kh == K && a.kw == K && a.sf == 1 && a.st == 1 && a.pad_f == PAD && a.pad_t == PAD && a.up_f == 1 &&
+           a.up_t == 1 && a.C2 == 0 && !a.zero_ins && a.x1 && a.wp && a.y &&
+           ((a.C1 == 2 && a.Cout == 1) || (a.C1 == 1 && a.Cout == 2) || (a.C1 == 1 && a.Cout == 1));
+}
+
+}  // namespace
+
+bool dcs_conv_k7_ok(const conv::Args* a, int n) {
+    if (n < 1 || n > kMaxBatch) return false;
+    for (int i = 0; i < n; ++i)
+        if (!k7_geom(a[i]) || a[i].C1 != a[0].C1 || a[i].Cout != a[0].Cout || a[i].B != a[0].B) return false;
+    return a[0].B <= 65535;
+}
+
+int dcs_conv_k7_launch(const conv::Args* a, int n, hipStream_t stream) {
+    if (!dcs_conv_k7_ok(a, n)) return DCS_ERR_BADARG;
+    K7Table tb;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        K7P& p = tb.p[i];
+        p.x = a[i].x1; p.w = a[i].wp; p.bias = a[i].bias; p.y = a[i].y;
+        p.H = a[i].Hin; p.W = a[i].Win; p.act = a[i].act;
+        p.tiles_w = (p.W + TC - 1) / TC;
+        p.tiles = p.tiles_w * ((p.H + TR - 1) / TR);
+        tiles = p.tiles > tiles ? p.tiles : tiles;
+    }
+    dim3 grid(tiles, n, a[0].B);
+    if (a[0].C1 == 2) hipLaunchKernelGGL((cconv_k7_kernel<2, 1>), grid, dim3(256), 0, stream, tb);
+    else if (a[0].Cout == 2) hipLaunchKernelGGL((cconv_k7_kernel<1, 2>), grid, dim3(256), 0, stream, tb);
+    else hipLaunchKernelGGL((cconv_k7_kernel<1, 1>), grid, dim3(256), 0, stream, tb);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
