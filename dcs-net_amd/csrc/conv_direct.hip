@@ -693,7 +693,11 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     const int Cin = C1 + C2;
     if (dcs_conv_wgrad_small_ok(w.c)) {          // 7x7 2->1 / 1->8: pixel-stationary kernel (conv_wgrad_small.hip)
         hipStream_t s = dcs_stream(stream);
-        const int ns = w.n_slabs < 512 ? w.n_slabs : 512;       // two resident workgroups per CU
+        // two resident workgroups per CU.  The 2 -> 1 attention convs run batched (13 problems in one launch inside a
+        // train step): ~8 tiles per workgroup there, so that the fixed cross-lane reduction of the 196 accumulators at the
+        // end of a workgroup (~2.5 us) is paid per 8 tiles (~6 us of FMAs) rather than per 2
+        int ns = w.n_slabs < 512 ? w.n_slabs : 512;
+        if (Cin == 2 && Cout == 1) { ns = w.total_tiles / 8; ns = ns < 1 ? 1 : (ns > 512 ? 512 : ns); }   // = ~2 of its 16 x 64 tiles
         const int rc = dcs_conv_wgrad_small_launch(w.c, gy, w.slab_w, w.slab_b, ns, s);
         if (rc != DCS_OK) return rc;
         return launch_wgrad_reduce(w.slab_w, w.slab_b, ns, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed, s);

@@ -133,6 +133,100 @@ __device__ __forceinline__ void wgrad_small_body(const SArgs& w, int bid, SmallL
     }
 }
 
+// ---- MODE 0 re-blocked: a thread owns PBS = 4 horizontally adjacent pixels of a 16 x 64 tile ------------------------------
+// One pixel per thread reads one LDS value per complex MAC: 98 ds_read_b64 per pixel, and the 13 attention problems of a
+// step are LDS-bandwidth-bound (~65 us of LDS cycles for 16 us of FMAs).  With four pixels per thread the 10 input values
+// a kernel row's four windows span are read once (5 x ds_read_b128) for 28 MACs.  Same accumulators (all 49 taps x 2
+// channels per thread), same slab layout and cross-lane reduction as the one-pixel form.
+constexpr int STH = 16, STW = 64, PBS = 4, SROWS = STH + KS - 1, SCOLS = STW + KS - 1, SCOLSP = SCOLS + 2;
+struct SaLds {
+    __attribute__((aligned(16))) float2 tile[2][SROWS * SCOLSP];
+    float2 red[4][2 * TAPS + 2];
+};
+
+__device__ __forceinline__ void wgrad_sa_body(const SArgs& w, int bid, SaLds& lds) {
+    const conv::Args& a = w.c;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ty = t / (STW / PBS), tx = (t % (STW / PBS)) * PBS;
+    const int H = a.Hout, W = a.Wout;                                   // stride 1, pad 3: input extent = output extent
+    const int tiles_w = (W + STW - 1) / STW, tiles_per_img = tiles_w * ((H + STH - 1) / STH);
+
+    float ar[TAPS][2], ai[TAPS][2];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) { ar[tp][0] = ar[tp][1] = ai[tp][0] = ai[tp][1] = 0.f; }
+    float2 b0 = make_float2(0.f, 0.f);
+
+    for (int tl = bid; tl < w.total_tiles; tl += w.n_slabs) {
+        const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
+        const int oy0 = (tile_id / tiles_w) * STH, ox0 = (tile_id % tiles_w) * STW;
+        const float4* xb = reinterpret_cast<const float4*>(a.x1) + (long)b * H * W;     // 2 complex channels per pixel
+        __syncthreads();
+        for (int i = t; i < SROWS * SCOLS; i += 256) {
+            const int iy = i / SCOLS, ix = i % SCOLS;
+            const int y = oy0 - a.pad_f + iy, x = ox0 - a.pad_t + ix;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < H && x >= 0 && x < W) v = xb[(long)y * W + x];
+            lds.tile[0][iy * SCOLSP + ix] = make_float2(v.x, v.y);
+            lds.tile[1][iy * SCOLSP + ix] = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+        float2 g[PBS];
+        const int oy = oy0 + ty;
+#pragma unroll
+        for (int q = 0; q < PBS; ++q) {
+            const int ox = ox0 + tx + q;
+            g[q] = (oy < H && ox < W) ? w.gy[((long)b * H + oy) * W + ox] : make_float2(0.f, 0.f);
+            b0.x += g[q].x; b0.y += g[q].y;
+        }
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int dy = 0; dy < KS; ++dy) {
+                float2 xv[PBS + KS - 1];
+                const float4* row = reinterpret_cast<const float4*>(&lds.tile[ci][(ty + dy) * SCOLSP + tx]);
+#pragma unroll
+                for (int j = 0; j < (PBS + KS - 1) / 2; ++j) {
+                    const float4 v4 = row[j];
+                    xv[2 * j] = make_float2(v4.x, v4.y); xv[2 * j + 1] = make_float2(v4.z, v4.w);
+                }
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+                    for (int q = 0; q < PBS; ++q) {                     // g * conj(x)
+                        const float2 x0 = xv[q + dx];
+                        ar[dy * KS + dx][ci] = fmaf(g[q].x, x0.x, fmaf(g[q].y, x0.y, ar[dy * KS + dx][ci]));
+                        ai[dy * KS + dx][ci] = fmaf(g[q].y, x0.x, fmaf(-g[q].x, x0.y, ai[dy * KS + dx][ci]));
+                    }
+            }
+    }
+
+    // lanes -> one value per output j = tap*2 + ci (same tail as the one-pixel form)
+    float2 (*red)[2 * TAPS + 2] = lds.red;
+    float2* slab = w.slab_w + (long)bid * (TAPS * 2);
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float sr = dcs_wave_sum_lane63(ar[tp][k]), si = dcs_wave_sum_lane63(ai[tp][k]);
+            if (lane == 63) red[wave][tp * 2 + k] = make_float2(sr, si);
+        }
+    const float2 s0 = make_float2(dcs_wave_sum_lane63(b0.x), dcs_wave_sum_lane63(b0.y));
+    if (lane == 63) red[wave][2 * TAPS] = s0;
+    __syncthreads();
+    if (t <= 2 * TAPS) {
+        float2 v = red[0][t];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { v.x += red[q][t].x; v.y += red[q][t].y; }
+        if (t < 2 * TAPS) slab[t] = v;                     // [tap][ci][co = 0]
+        else w.slab_b[bid] = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void cconv_wgrad_sa_kernel(SArgs w) {
+    __shared__ SaLds lds;
+    wgrad_sa_body(w, blockIdx.x, lds);
+}
+
 template <int MODE, int S>
 __global__ __launch_bounds__(256, 2) void cconv_wgrad_small_kernel(SArgs w) {
     __shared__ SmallLds<MODE, S> lds;
@@ -146,10 +240,10 @@ constexpr int kSmallBatch = 16;
 struct SmallTable { int n; int blk0[kSmallBatch + 1]; SArgs p[kSmallBatch]; };
 
 __global__ __launch_bounds__(256, 2) void cconv_wgrad_small_multi_kernel(SmallTable t) {
-    __shared__ SmallLds<0, 1> lds;
+    __shared__ SaLds lds;
     int k = 0;
     while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
-    wgrad_small_body<0, 1>(t.p[k], blockIdx.x - t.blk0[k], lds);
+    wgrad_sa_body(t.p[k], blockIdx.x - t.blk0[k], lds);
 }
 
 std::vector<SArgs>* g_small_deferred = nullptr;
@@ -172,12 +266,14 @@ int dcs_conv_wgrad_small_launch(const conv::Args& a, const float* gy, float2* sl
     w.gy = (const float2*)gy; w.slab_w = slab_w; w.slab_b = slab_b;
     w.n_slabs = n_slabs;
     w.total_tiles = a.tiles_w * a.tiles_h * a.B;
+    if (a.C1 == 2)                                           // 16 x 64 tiles (wgrad_sa_body); idle workgroups write zero slabs
+        w.total_tiles = ((a.Wout + STW - 1) / STW) * ((a.Hout + STH - 1) / STH) * a.B;
     if (a.C1 == 2 && wreduce::deferring()) {                 // recorded; dcs_conv_wgrad_small_flush launches the batch
         if (!g_small_deferred) g_small_deferred = new std::vector<SArgs>();
         g_small_deferred->push_back(w);
         return DCS_OK;
     }
-    if (a.C1 == 2) hipLaunchKernelGGL((cconv_wgrad_small_kernel<0, 1>), dim3(n_slabs), dim3(256), 0, stream, w);
+    if (a.C1 == 2) hipLaunchKernelGGL(cconv_wgrad_sa_kernel, dim3(n_slabs), dim3(256), 0, stream, w);
     else hipLaunchKernelGGL((cconv_wgrad_small_kernel<1, 2>), dim3(n_slabs), dim3(256), 0, stream, w);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
