@@ -14,6 +14,7 @@ namespace {
 
 constexpr int K = 7, PAD = 3, TR = 16, TC = 64, PB = 4, ROWS = TR + K - 1, COLS = TC + K - 1, COLSP = COLS + 2;   // 72: rows stay 16-byte aligned
 constexpr int kMaxBatch = 8;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct K7P {
     const float2* x; const float2* w; const float2* bias; float2* y;
@@ -41,34 +42,34 @@ __global__ __launch_bounds__(256) void cconv_k7_kernel(K7Table tb) {
     }
     __syncthreads();
     const int ty = t / (TC / PB), tx = (t % (TC / PB)) * PB;
-    float ar[PB][CO], ai[PB][CO];
+    // complex MAC as two packed FMAs (v_pk_fma_f32): acc(re, im) += w.x * (x.re, x.im) + w.y * (-x.im, x.re)
+    v2f acc[PB][CO];
 #pragma unroll
     for (int q = 0; q < PB; ++q)
 #pragma unroll
-        for (int co = 0; co < CO; ++co) { ar[q][co] = 0.f; ai[q][co] = 0.f; }
+        for (int co = 0; co < CO; ++co) acc[q][co] = v2f{0.f, 0.f};
 #pragma unroll
     for (int ci = 0; ci < CI; ++ci) {
 #pragma unroll 1
         for (int dy = 0; dy < K; ++dy) {
-            float2 xv[PB + K - 1];                                     // 10 values = 5 aligned 16-byte reads
+            v2f xv[PB + K - 1], xr[PB + K - 1];                        // 10 values = 5 aligned 16-byte reads; xr = j * x
             const float4* row = reinterpret_cast<const float4*>(&tile[ci][(ty + dy) * COLSP + tx]);
 #pragma unroll
             for (int j = 0; j < (PB + K - 1) / 2; ++j) {
                 const float4 v4 = row[j];
-                xv[2 * j] = make_float2(v4.x, v4.y); xv[2 * j + 1] = make_float2(v4.z, v4.w);
+                xv[2 * j] = v2f{v4.x, v4.y}; xv[2 * j + 1] = v2f{v4.z, v4.w};
+                xr[2 * j] = v2f{-v4.y, v4.x}; xr[2 * j + 1] = v2f{-v4.w, v4.z};
             }
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
 #pragma unroll
                 for (int co = 0; co < CO; ++co) {
                     const float2 w = wl[((dy * K + dx) * CI + ci) * CO + co];
+                    const v2f wx = v2f{w.x, w.x}, wy = v2f{w.y, w.y};
 #pragma unroll
                     for (int q = 0; q < PB; ++q) {
-                        const float2 v = xv[q + dx];
-                        ar[q][co] = fmaf(w.x, v.x, ar[q][co]);
-                        ar[q][co] = fmaf(-w.y, v.y, ar[q][co]);
-                        ai[q][co] = fmaf(w.x, v.y, ai[q][co]);
-                        ai[q][co] = fmaf(w.y, v.x, ai[q][co]);
+                        acc[q][co] = __builtin_elementwise_fma(wx, xv[q + dx], acc[q][co]);
+                        acc[q][co] = __builtin_elementwise_fma(wy, xr[q + dx], acc[q][co]);
                     }
                 }
             }
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void cconv_k7_kernel(K7Table tb) {
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
             const float2 bv = p.bias ? p.bias[co] : make_float2(0.f, 0.f);
-            yb[(long)ox * CO + co] = make_float2(dcs_act(ar[q][co] + bv.x, p.act), dcs_act(ai[q][co] + bv.y, p.act));
+            yb[(long)ox * CO + co] = make_float2(dcs_act(acc[q][co].x + bv.x, p.act), dcs_act(acc[q][co].y + bv.y, p.act));
         }
     }
 }
