@@ -180,11 +180,20 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    # rehearsal aids for a one-GPU box (never set by the driver): DCS_BENCH_DEVICE pins every rank to one card and
+    # DCS_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so `torch.distributed.run
+    # --nproc-per-node 2 bench.py --gpus 2` exercises the multi-rank control flow end to end
+    if 'DCS_BENCH_DEVICE' in os.environ:
+        local = int(os.environ['DCS_BENCH_DEVICE'])
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('DCS_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from dcsnet import _lib, ops
     from dcsnet.config import config, hparams
@@ -264,10 +273,12 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.active = False
-    if graphed and rank == 0:
+    if graphed and (rank == 0 or (train and world > 1)):
         # kernels inside a hipGraph replay cannot be bracketed by events: time the conv family in an
-        # instrumented EAGER pass of the same K steps, right after (and outside) the timed region
-        timer.active = True
+        # instrumented EAGER pass of the same K steps, right after (and outside) the timed region.  Rank 0 holds the
+        # timer; with world > 1 every rank runs the pass, because a train step contains the gradient all-reduce (a
+        # collective issued by rank 0 alone would pair with the other ranks' next collective)
+        timer.active = rank == 0
         for _ in range(args.steps):
             eager_step()
         torch.cuda.synchronize()
