@@ -62,14 +62,17 @@ namespace {
 // y[b][oy][ox] = sum_{dy,dx} z[b][(oy-pad_f+dy)/up_f][(ox-pad_t+dx)/up_t][dy*kw+dx]
 __global__ __launch_bounds__(kThreads) void tapsum_fwd_kernel(const float2* __restrict__ z, float2* __restrict__ y,
                                                                int B, int Hs, int Ws, int CT, int kh, int kw, int up_f,
-                                                               int up_t, int pad_f, int pad_t) {
+                                                               int up_t, int pad_f, int pad_t, const float* __restrict__ b_r,
+                                                               const float* __restrict__ b_i) {
+    const float br_ = b_r ? b_r[0] : 0.f, bi_ = b_i ? b_i[0] : 0.f;
+    const float2 bias = make_float2(br_ - bi_, br_ + bi_);        // (b_r - b_i) + j (b_r + b_i): the complex layer's bias
     const int Ho = Hs * up_f, Wo = Ws * up_t;
     const long n = (long)B * Ho * Wo;
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
         const int ox = (int)(i % Wo);
         long r = i / Wo;
         const int oy = (int)(r % Ho), b = (int)(r / Ho);
-        float sr = 0.f, si = 0.f;
+        float sr = bias.x, si = bias.y;
         for (int dy = 0; dy < kh; ++dy) {
             const int vy = oy - pad_f + dy;
             if (vy < 0 || vy >= Ho) continue;
@@ -92,7 +95,10 @@ constexpr int TOY = 16, TOX = 64, kTapLds = 10 * 34 * 9;               // float2
 template <bool FIX>
 __global__ __launch_bounds__(kThreads) void tapsum_fwd_tiled_kernel(const float2* __restrict__ z, float2* __restrict__ y,
                                                                      int B, int Hs, int Ws, int CT, int kh_, int kw_, int up_f_,
-                                                                     int up_t_, int pad_f, int pad_t, int SR_, int SC_) {
+                                                                     int up_t_, int pad_f, int pad_t, int SR_, int SC_,
+                                                                     const float* __restrict__ b_r, const float* __restrict__ b_i) {
+    const float br_ = b_r ? b_r[0] : 0.f, bi_ = b_i ? b_i[0] : 0.f;
+    const float2 bias = make_float2(br_ - bi_, br_ + bi_);
     const int kh = FIX ? 3 : kh_, kw = FIX ? 3 : kw_, up_f = FIX ? 2 : up_f_, up_t = FIX ? 2 : up_t_;
     const int SR = FIX ? 10 : SR_, SC = FIX ? 34 : SC_;
     __shared__ float2 tile[kTapLds];
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void tapsum_fwd_tiled_kernel(const float2
         for (int p = t; p < TOY * TOX; p += kThreads) {
             const int oy = oy0 + p / TOX, ox = ox0 + p % TOX;
             if (oy >= Ho || ox >= Wo) continue;
-            float sr = 0.f, si = 0.f;
+            float sr = bias.x, si = bias.y;
             for (int dy = 0; dy < kh; ++dy) {
                 const int vy = oy - pad_f + dy;
                 if (vy < 0 || vy >= Ho) continue;
@@ -162,10 +168,38 @@ __global__ __launch_bounds__(kThreads) void tapsum_bwd_kernel(const float2* __re
 }
 }  // namespace
 
-extern "C" int dcs_tapsum_fwd(const float* z, float* y, int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t,
-                              int pad_f, int pad_t, dcs_stream_t stream) {
+// complex sum of n elements: partials (double2 per workgroup), then one workgroup -> the bias gradients of a complex layer
+// whose bias enters as (b_r - b_i) + j (b_r + b_i):  g_b_r = S.re + S.im,  g_b_i = S.im - S.re
+namespace {
+constexpr int kSumBlocks = 256;
+__global__ __launch_bounds__(kThreads) void csum_partial_kernel(const float2* __restrict__ g, long n, double* __restrict__ part) {
+    __shared__ double red[kThreads / 64][2];
+    double sr = 0, si = 0;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+        const float2 v = g[i];
+        sr += v.x; si += v.y;
+    }
+    sr = dcs_wave_sum_d(sr); si = dcs_wave_sum_d(si);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sr; red[threadIdx.x >> 6][1] = si; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) { sr += red[w][0]; si += red[w][1]; }
+        part[2 * blockIdx.x] = sr; part[2 * blockIdx.x + 1] = si;
+    }
+}
+__global__ __launch_bounds__(64) void csum_bias_final_kernel(const double* __restrict__ part, int nparts, float* __restrict__ gb_r,
+                                                             float* __restrict__ gb_i) {
+    double sr = 0, si = 0;
+    for (int i = threadIdx.x; i < nparts; i += 64) { sr += part[2 * i]; si += part[2 * i + 1]; }
+    sr = dcs_wave_sum_d(sr); si = dcs_wave_sum_d(si);
+    if (threadIdx.x == 0) { gb_r[0] = (float)(sr + si); gb_i[0] = (float)(si - sr); }
+}
+}  // namespace
+
+extern "C" int dcs_tapsum_fwd(const float* z, float* y, const float* b_r, const float* b_i, int B, int Hs, int Ws, int CT,
+                              int kh, int kw, int up_f, int up_t, int pad_f, int pad_t, dcs_stream_t stream) {
     if (!z || !y || B <= 0 || Hs <= 0 || Ws <= 0 || kh < 1 || kw < 1 || CT < kh * kw || up_f < 1 || up_t < 1 ||
-        pad_f < 0 || pad_t < 0)
+        pad_f < 0 || pad_t < 0 || ((b_r == nullptr) != (b_i == nullptr)))
         return DCS_ERR_BADARG;
     const long n = (long)B * Hs * up_f * Ws * up_t;
     // source rows / columns a TOY x TOX output tile can touch
@@ -175,24 +209,36 @@ extern "C" int dcs_tapsum_fwd(const float* z, float* y, int B, int Hs, int Ws, i
         const dim3 grid((unsigned)(tiles < 8192 ? tiles : 8192));
         if (kh == 3 && kw == 3 && up_f == 2 && up_t == 2 && SR == 10 && SC == 34)
             hipLaunchKernelGGL(tapsum_fwd_tiled_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
-                               (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, SR, SC);
+                               (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, SR, SC, b_r, b_i);
         else
             hipLaunchKernelGGL(tapsum_fwd_tiled_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
-                               (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, SR, SC);
+                               (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, SR, SC, b_r, b_i);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     }
     hipLaunchKernelGGL(tapsum_fwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
-                       (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t);
+                       (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, b_r, b_i);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
 
-extern "C" int dcs_tapsum_bwd(const float* gy, float* gz, int B, int Hs, int Ws, int CT, int kh, int kw, int up_f,
-                              int up_t, int pad_f, int pad_t, dcs_stream_t stream) {
+extern "C" long dcs_tapsum_bwd_workspace_bytes(void) { return (long)kSumBlocks * 2 * (long)sizeof(double); }
+
+extern "C" int dcs_tapsum_bwd(const float* gy, float* gz, float* gb_r, float* gb_i, void* workspace, long workspace_bytes,
+                              int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t, int pad_f, int pad_t,
+                              dcs_stream_t stream) {
     if (!gy || !gz || B <= 0 || Hs <= 0 || Ws <= 0 || kh < 1 || kw < 1 || CT < kh * kw || up_f < 1 || up_t < 1 ||
-        pad_f < 0 || pad_t < 0)
+        pad_f < 0 || pad_t < 0 || ((gb_r == nullptr) != (gb_i == nullptr)))
         return DCS_ERR_BADARG;
+    if (gb_r) {                                              // bias gradients of the Cout = 1 layer: complex sum of gy
+        if (!workspace || workspace_bytes < dcs_tapsum_bwd_workspace_bytes()) return DCS_ERR_WORKSPACE;
+        const long ny = (long)B * Hs * up_f * Ws * up_t;
+        hipLaunchKernelGGL(csum_partial_kernel, dim3(kSumBlocks), dim3(kThreads), 0, dcs_stream(stream), (const float2*)gy, ny,
+                           (double*)workspace);
+        hipLaunchKernelGGL(csum_bias_final_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), (const double*)workspace,
+                           kSumBlocks, gb_r, gb_i);
+        DCS_CHECK_LAUNCH();
+    }
     const long n = (long)B * Hs * Ws * CT;
     hipLaunchKernelGGL(tapsum_bwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)gy,
                        (float2*)gz, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t);

@@ -564,15 +564,27 @@ def complex_lstm(z, real_lstm, imag_lstm):
 
 
 class _TapSumFn(torch.autograd.Function):
+    """y = tapsum(z) + bias; the two real bias scalars of the Cout = 1 layer enter and leave through the kernels (their
+    gradients: one complex sum of the cotangent, written straight into the gradient sinks when there are any)."""
+
     @staticmethod
-    def forward(ctx, z, ksize, up, pad):
+    def forward(ctx, z, ksize, up, pad, b_r, b_i):
         ctx.cfg = (tuple(z.shape), tuple(ksize), tuple(up), tuple(pad))
-        return ops.tapsum(z, ksize, up, pad)
+        ctx.bias = b_r is not None
+        ctx.sinks = (_sink(b_r), _sink(b_i)) if ctx.bias else (None, None)
+        return ops.tapsum(z, ksize, up, pad, bias=(b_r, b_i) if ctx.bias else None)
 
     @staticmethod
     def backward(ctx, g):
         shape, ksize, up, pad = ctx.cfg
-        return ops.tapsum(shape, ksize, up, pad, backward=True, grad=g.contiguous()), None, None, None
+        g = g.contiguous()
+        if not ctx.bias:
+            return ops.tapsum(shape, ksize, up, pad, backward=True, grad=g), None, None, None, None, None
+        new = lambda: torch.empty(1, dtype=torch.float32, device=g.device)
+        dst = tuple(s_ if s_ is not None else new() for s_ in ctx.sinks)
+        gz = ops.tapsum(shape, ksize, up, pad, backward=True, grad=g, bias_grad=dst)
+        gb = tuple(None if s_ is not None else d for d, s_ in zip(dst, ctx.sinks))
+        return gz, None, None, None, gb[0], gb[1]
 
 
 class _TapRowsConvFn(torch.autograd.Function):
@@ -617,10 +629,7 @@ def cconv_single_output(x1, x2, w_r, w_i, b_r, b_i, ksize, pad, up):
     ct = (kh * kw + 7) // 8 * 8                                # tap channels, padded for the MFMA N tile
     z = _TapRowsConvFn.apply(x1, x2, w_r, w_i, ct)
     # stride-1 transposed conv == correlation with padding k-1-p (already in `pad`)
-    y = _TapSumFn.apply(z, (kh, kw), tuple(up), tuple(pad))
-    if b_r is not None:
-        y = y + torch.stack((b_r - b_i, b_r + b_i), dim=-1).view(1, 1, 1, 1, 2)
-    return y
+    return _TapSumFn.apply(z, (kh, kw), tuple(up), tuple(pad), b_r, b_i)
 
 
 class _DropoutFn(torch.autograd.Function):

@@ -590,22 +590,26 @@ def complex_upsample(x, up):
     return y
 
 
-def tapsum(z, ksize, up, pad, backward=False, grad=None):
+def tapsum(z, ksize, up, pad, backward=False, grad=None, bias=None, bias_grad=None):
     """Spatial half of a Cout = 1 conv (dcs_tapsum_fwd / _bwd).  Forward: z [B,Hs,Ws,CT,2] -> y
-    [B,Hs*uf,Ws*ut,1,2].  backward=True: grad [B,Ho,Wo,1,2] -> gz shaped like z (pass z's shape via `z`)."""
+    [B,Hs*uf,Ws*ut,1,2], plus the layer's bias if bias = (b_r, b_i) (one float each).  backward=True: grad
+    [B,Ho,Wo,1,2] -> gz shaped like z (pass z's shape via `z`); bias_grad = (gb_r, gb_i) destinations (written)."""
     lib = _lib.load()
     if not backward:
         _chk(z, 'z', 5)
         B, Hs, Ws, CT, _ = z.shape
         y = torch.empty((B, Hs * up[0], Ws * up[1], 1, 2), dtype=torch.float32, device=z.device)
-        check(lib.dcs_tapsum_fwd(ptr(z), ptr(y), B, Hs, Ws, CT, ksize[0], ksize[1], up[0], up[1], pad[0], pad[1],
-                                 cur_stream()), 'dcs_tapsum_fwd')
+        b_r, b_i = bias if bias is not None else (None, None)
+        check(lib.dcs_tapsum_fwd(ptr(z), ptr(y), ptr(b_r), ptr(b_i), B, Hs, Ws, CT, ksize[0], ksize[1], up[0], up[1],
+                                 pad[0], pad[1], cur_stream()), 'dcs_tapsum_fwd')
         return y
     _chk(grad, 'grad', 5)
     B, Hs, Ws, CT, _ = z
     gz = torch.empty((B, Hs, Ws, CT, 2), dtype=torch.float32, device=grad.device)
-    check(lib.dcs_tapsum_bwd(ptr(grad), ptr(gz), B, Hs, Ws, CT, ksize[0], ksize[1], up[0], up[1], pad[0], pad[1],
-                             cur_stream()), 'dcs_tapsum_bwd')
+    gb_r, gb_i = bias_grad if bias_grad is not None else (None, None)
+    ws = _workspace(lib.dcs_tapsum_bwd_workspace_bytes(), grad.device) if gb_r is not None else None
+    check(lib.dcs_tapsum_bwd(ptr(grad), ptr(gz), ptr(gb_r), ptr(gb_i), ptr(ws), 0 if ws is None else ws.numel(), B, Hs, Ws, CT,
+                             ksize[0], ksize[1], up[0], up[1], pad[0], pad[1], cur_stream()), 'dcs_tapsum_bwd')
     return gz
 
 

@@ -355,11 +355,17 @@ int dcs_complex_upsample_fwd(const float* x, float* y, int B, int H, int W, int 
  * channels" on the SOURCE-resolution tensors (dcs_cconv2d_fwd: an MFMA GEMM with full lanes) followed by
  *     y[b][oy][ox] = sum_{dy,dx} z[b][(oy - pad_f + dy)/up_f][(ox - pad_t + dx)/up_t][dy*kw + dx]
  * z: complex[B][Hs][Ws][CT] (CT >= kh*kw tap channels, extra ones ignored); y: complex[B][Hs*up_f][Ws*up_t].
- * dcs_tapsum_bwd is its adjoint: gz from gy (unused tap channels get zeros). */
-int dcs_tapsum_fwd(const float* z, float* y, int B, int Hs, int Ws, int CT, int kh, int kw,
-                   int up_f, int up_t, int pad_f, int pad_t, dcs_stream_t stream);
-int dcs_tapsum_bwd(const float* gy, float* gz, int B, int Hs, int Ws, int CT, int kh, int kw,
-                   int up_f, int up_t, int pad_f, int pad_t, dcs_stream_t stream);
+ * b_r, b_i (both or neither): the layer's two real bias scalars (conv_tran_r.bias, conv_tran_i.bias, Cout = 1); the
+ * complex bias (b_r - b_i) + j (b_r + b_i) is added to every output.
+ * dcs_tapsum_bwd is its adjoint: gz from gy (unused tap channels get zeros); gb_r / gb_i (both or neither, one float
+ * each) receive the bias gradients (S.re + S.im, S.im - S.re with S = sum of gy) — written, not accumulated; they
+ * need `workspace` of dcs_tapsum_bwd_workspace_bytes(). */
+int dcs_tapsum_fwd(const float* z, float* y, const float* b_r, const float* b_i, int B, int Hs, int Ws, int CT,
+                   int kh, int kw, int up_f, int up_t, int pad_f, int pad_t, dcs_stream_t stream);
+long dcs_tapsum_bwd_workspace_bytes(void);
+int dcs_tapsum_bwd(const float* gy, float* gz, float* gb_r, float* gb_i, void* workspace, long workspace_bytes,
+                   int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t, int pad_f, int pad_t,
+                   dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * bound_cRM (network_functions.py:77-88), as called at c_network.py:225:
