@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void polar_frames_fwd_kernel(const float2
 // g_z = (z/|z|) (u.g) + |z| (g - u (u.g)) / |v|,  u = unit(v), v = (z_r + eps, z_i);  g is frame-major
 __global__ __launch_bounds__(kThreads) void polar_frames_bwd_kernel(const float2* __restrict__ z, const float2* __restrict__ g,
                                                                      float2* __restrict__ gz, int F, int Fp, int T,
-                                                                     float eps) {
+                                                                     float eps, int herm) {
     __shared__ float2 tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
@@ -76,7 +76,11 @@ __global__ __launch_bounds__(kThreads) void polar_frames_bwd_kernel(const float2
         const int f = f0 + ty + 8 * r, t = t0 + tx;
         if (f < F && t < T) {
             const long i = (b * F + f) * T + t;
-            const float2 v = z[i], go = tile[ty + 8 * r][tx];
+            const float2 v = z[i];
+            float2 go = tile[ty + 8 * r][tx];
+            // herm: g is the plain rfft of the cotangent of an UNNORMALISED inverse real FFT's output; the cotangent of its
+            // one-sided input counts every bin but DC and Nyquist twice (Hermitian symmetry)
+            if (herm && f > 0 && f < Fp - 1) { go.x *= 2.f; go.y *= 2.f; }
             const float m = hypotf(v.x, v.y);
             const float2 d = unit_dir(v.x + eps, v.y);
             const float dot = d.x * go.x + d.y * go.y;
@@ -150,10 +154,10 @@ extern "C" int dcs_polar_frames_fwd(const float* z, float* out, int B, int F, in
 }
 
 extern "C" int dcs_polar_frames_bwd(const float* z, const float* g_out, float* g_z, int B, int F, int Fp, int T, float eps,
-                                    dcs_stream_t stream) {
+                                    int hermitian, dcs_stream_t stream) {
     if (!z || !g_out || !g_z || B <= 0 || B > 65535 || F <= 0 || Fp < F || T <= 0) return DCS_ERR_BADARG;
     hipLaunchKernelGGL(polar_frames_bwd_kernel, dim3((T + 31) / 32, (F + 31) / 32, B), dim3(kThreads), 0, dcs_stream(stream),
-                       (const float2*)z, (const float2*)g_out, (float2*)g_z, F, Fp, T, eps);
+                       (const float2*)z, (const float2*)g_out, (float2*)g_z, F, Fp, T, eps, hermitian);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

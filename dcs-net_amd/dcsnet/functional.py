@@ -722,6 +722,38 @@ def istft_ola(frames, window, inv_env, hop, scale=1.0):
     return _IstftOlaFn.apply(frames, window, inv_env, hop, scale)
 
 
+class _PolarWaveFn(torch.autograd.Function):
+    """z -> waveform of mag_phase_2_wave(|z|, atan2(z_i, z_r + eps)) (network_functions.py:140-150, :213-221) as ONE node:
+    polar round trip + zero bin + frame-major transpose (HIP), unnormalised inverse real FFT (rocFFT; its 1/n folded into
+    the overlap-add scale), window / overlap-add / envelope / trim (HIP).  Backward: adjoint gather (HIP), one forward real
+    FFT, and the polar backward kernel applies the one-sided x2 weighting itself — autograd's irfft node costs a scale
+    kernel forward and two element-wise complex kernels backward per signal."""
+
+    @staticmethod
+    def forward(ctx, z, window, inv_env, n_fft, hop, scale, eps):
+        B, Fb, T, _ = z.shape
+        if Fb + 1 != n_fft // 2 + 1:
+            raise DcsHipError(f'polar_wave: {Fb} bins + 1 zero bin is not the one-sided spectrum of n_fft = {n_fft}')
+        comp = ops.polar_frames(z, Fb + 1, eps)
+        frames = torch.fft.irfft(torch.view_as_complex(comp), n=n_fft, dim=-1, norm='forward')
+        ctx.cfg = (tuple(frames.shape), n_fft, hop, scale / n_fft, eps)
+        ctx.save_for_backward(z, window, inv_env)
+        return ops.istft_ola(frames, window, inv_env, hop, scale / n_fft)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, window, inv_env = ctx.saved_tensors
+        shape, n_fft, hop, scale, eps = ctx.cfg
+        g_frames = ops.istft_ola(shape, window, inv_env, hop, scale, grad=g.contiguous())
+        G = torch.view_as_real(torch.fft.rfft(g_frames, dim=-1))                  # [B, T, n_fft/2 + 1, 2], no scaling
+        return ops.polar_frames(z, z.shape[1] + 1, eps, grad=G, hermitian=True), None, None, None, None, None, None
+
+
+def polar_wave(z, window, inv_env, n_fft, hop, scale, eps):
+    """Complex z [B, F, T] (F = n_fft/2 bins 1..F of the STFT) -> waveform [B, hop (T-1)]."""
+    return _PolarWaveFn.apply(torch.view_as_real(z.contiguous()), window, inv_env, n_fft, hop, scale, eps)
+
+
 class _SiSNRFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, clean, est, eps):

@@ -190,9 +190,13 @@ def _polar_wave(z, eps, config):
     """mag_phase_2_wave(|z|, atan2(z_i, z_r + eps)) of the step functions (network_functions.py:213-221,
     :244-247): polar round trip + zero bin + frame-major transpose in one HIP pass, contiguous irfft, fused
     overlap-add."""
-    comp_t = F.polar_frames_complex(z, 1, eps)
-    return _frames_to_wave(comp_t, config.fft_size, config.hop_length, _window_on(config, comp_t.device),
-                           config.normalise_stft)
+    window = _window_on(config, z.device)
+    n_fft, hop = config.fft_size, config.hop_length
+    if z.shape[1] + 1 != n_fft // 2 + 1:                  # not the configured geometry: the three-node spelling
+        comp_t = F.polar_frames_complex(z, 1, eps)
+        return _frames_to_wave(comp_t, n_fft, hop, window, config.normalise_stft)
+    scale = float(n_fft) ** 0.5 if config.normalise_stft else 1.0
+    return F.polar_wave(z, window, _inv_envelope(window, z.shape[2], hop), n_fft, hop, scale, eps)
 
 
 def calc_metric(clean_audio, predict_audio, config, metric):

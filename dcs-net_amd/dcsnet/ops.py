@@ -643,9 +643,10 @@ def bound_mask_apply_bwd(Y, M_in, g_M, g_N, g_S, eps=10e-7):
     return g
 
 
-def polar_frames(z, Fp, eps=10e-7, grad=None):
+def polar_frames(z, Fp, eps=10e-7, grad=None, hermitian=False):
     """z: float [B,F,T,2].  Forward (grad None): FRAME-MAJOR [B,T,Fp,2] = |z| unit(z_r+eps, z_i), zero bins F..Fp-1.
-    With grad [B,T,Fp,2]: the cotangent of z."""
+    With grad [B,T,Fp,2]: the cotangent of z (hermitian: grad is the plain rfft of an unnormalised irfft's output
+    cotangent; the one-sided x2 weighting is applied in the kernel)."""
     _chk(z, 'z', 4)
     B, F, T, _ = z.shape
     lib = _lib.load()
@@ -655,7 +656,8 @@ def polar_frames(z, Fp, eps=10e-7, grad=None):
         return out
     _chk(grad, 'grad', 4)
     gz = torch.empty_like(z)
-    check(lib.dcs_polar_frames_bwd(ptr(z), ptr(grad), ptr(gz), B, F, Fp, T, eps, cur_stream()), 'dcs_polar_frames_bwd')
+    check(lib.dcs_polar_frames_bwd(ptr(z), ptr(grad), ptr(gz), B, F, Fp, T, eps, int(bool(hermitian)), cur_stream()),
+          'dcs_polar_frames_bwd')
     return gz
 
 

@@ -394,7 +394,9 @@ int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const float* g_M
  * :213-221 and :244-247).
  * dcs_polar_frames_fwd: out = |z| (cos phi + j sin phi), phi = atan2(z_i, z_r + eps), for bins f < F and zeros for
  *   the padded bins F..Fp-1, written FRAME-MAJOR: z complex[B][F][T] -> out complex[B][T][Fp], so the inverse real
- *   FFT runs over contiguous frames.  _bwd: cotangent of z from the (frame-major) cotangent of out.
+ *   FFT runs over contiguous frames.  _bwd: cotangent of z from the (frame-major) cotangent of out; hermitian != 0:
+ *   g_out is the plain forward real FFT of the cotangent of an unnormalised inverse real FFT's output, and the kernel
+ *   applies the one-sided weighting itself (x2 for every bin but 0 and Fp-1).
  * dcs_istft_envelope: inv_env[n] = 1 / sum_f window^2 of torch.istft(center=True), n in [0, hop (T-1)).
  * dcs_istft_ola_fwd: y[b][n] = scale * inv_env[n] * sum_f window[k] frames[b][f][k], k = n + n_fft/2 - f hop:
  *   synthesis window, overlap-add, envelope division and the n_fft/2 trim in one pass.  frames float[B][T][n_fft]
@@ -403,7 +405,7 @@ int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const float* g_M
  * dcs_istft_ola_bwd: g_frames from g_y (the adjoint gather). */
 int dcs_polar_frames_fwd(const float* z, float* out, int B, int F, int Fp, int T, float eps, dcs_stream_t stream);
 int dcs_polar_frames_bwd(const float* z, const float* g_out, float* g_z, int B, int F, int Fp, int T, float eps,
-                         dcs_stream_t stream);
+                         int hermitian, dcs_stream_t stream);
 int dcs_istft_envelope(const float* window, float* inv_env, int T, int n_fft, int hop, dcs_stream_t stream);
 int dcs_istft_ola_fwd(const float* frames, const float* window, const float* inv_env, float* y, int B, int T,
                       int n_fft, int hop, float scale, dcs_stream_t stream);
