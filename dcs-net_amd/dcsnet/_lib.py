@@ -68,6 +68,7 @@ SIGNATURES = {
     'dcs_complex_act_fwd': (_I, [_P, _P, _L, _I, _P]),
     'dcs_complex_upsample_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'dcs_tapsum_fwd': (_I, [_P, _P, _P, _P] + [_I] * 10 + [_P]),
+    'dcs_cconv_up2_single_fwd': (_I, [_P] * 6 + [_I] * 6 + [_P]),
     'dcs_tapsum_bwd_workspace_bytes': (_L, []),
     'dcs_tapsum_bwd': (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P]),
     'dcs_bound_crm_fwd': (_I, [_P, _P, _L, _F, _P]),

@@ -619,6 +619,44 @@ class _TapRowsConvFn(torch.autograd.Function):
         return gx1, gx2, gw_r, gw_i, None
 
 
+class _Up2SingleFn(torch.autograd.Function):
+    """The last decoder stage (16 -> 1 channels, 3x3, 2x2 upsample) with its forward in ONE kernel (conv_up1.hip: no
+    tap-channel intermediate) and the factored backward of _TapSumFn + _TapRowsConvFn (which needs the tap-channel
+    cotangent anyway)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w_r, w_i, b_r, b_i, ct):
+        wt, _ = packed_weight(w_r, w_i, None, None, False, (1, 1), tap_rows=ct)
+        ctx.ct, ctx.w_shape, ctx.bias = ct, tuple(w_r.shape), b_r is not None
+        ctx.sinks = (_sink(w_r), _sink(w_i), _sink(b_r), _sink(b_i))
+        ctx.save_for_backward(x1, x2, wt)
+        return ops.cconv_up2_single(x1, x2, wt, b_r, b_i)
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, wt = ctx.saved_tensors
+        B, Hs, Ws, C1, _ = x1.shape
+        Cin = C1 + (x2.shape[3] if x2 is not None else 0)
+        sk = ctx.sinks
+        gb = (None, None)
+        dst = None
+        if ctx.bias:
+            new = lambda: torch.empty(1, dtype=torch.float32, device=g.device)
+            dst = tuple(s_ if s_ is not None else new() for s_ in sk[2:])
+            gb = tuple(None if s_ is not None else d for d, s_ in zip(dst, sk[2:]))
+        gz = ops.tapsum((B, Hs, Ws, ctx.ct, 2), (3, 3), (2, 2), (1, 1), backward=True, grad=g.contiguous(), bias_grad=dst)
+        gx1 = gx2 = gw_r = gw_i = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            gt_r, gt_i, _, _ = ops.cconv2d_bwd_weight(x1, x2, gz, (ctx.ct, Cin, 1, 1), False, (1, 1), (1, 1), (0, 0))
+            gw = ops.tap_rows_scatter(gt_r, gt_i, ctx.w_shape, sk[:2])
+            if sk[0] is None or sk[1] is None:
+                gw_r, gw_i = gw
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gx1, gx2 = ops.cconv2d_bwd_data(gz, ops.pack_conv_weight_bwd(wt, (1, 1)), (Hs, Ws, Cin), (1, 1), (1, 1), (0, 0),
+                                            (1, 1), C1)
+        return gx1, gx2, gw_r, gw_i, gb[0], gb[1], None
+
+
 def cconv_single_output(x1, x2, w_r, w_i, b_r, b_i, ksize, pad, up):
     """Stride-1 ComplexConvTranspose2d with ONE output channel over upsample(cat(x1, x2)) (the last decoder
     stage).  Cout = 1 would leave the MFMA tile's N dimension 2 wide, so the stage is factored as
@@ -627,6 +665,10 @@ def cconv_single_output(x1, x2, w_r, w_i, b_r, b_i, ksize, pad, up):
     at SOURCE resolution plus an HBM-bound 9-load gather (elementwise.hip).  w_*: [Cin, 1, kh, kw]."""
     kh, kw = ksize
     ct = (kh * kw + 7) // 8 * 8                                # tap channels, padded for the MFMA N tile
+    c2 = 0 if x2 is None else x2.shape[3]
+    if ((kh, kw) == (3, 3) and tuple(up) == (2, 2) and tuple(pad) == (1, 1) and x1.shape[3] + c2 == 16 and
+            not (x1.shape[3] & 1) and not (c2 & 1)):           # the configured dec6: forward in one kernel
+        return _Up2SingleFn.apply(x1, x2, w_r, w_i, b_r, b_i, ct)
     z = _TapRowsConvFn.apply(x1, x2, w_r, w_i, ct)
     # stride-1 transposed conv == correlation with padding k-1-p (already in `pad`)
     return _TapSumFn.apply(z, (kh, kw), tuple(up), tuple(pad), b_r, b_i)

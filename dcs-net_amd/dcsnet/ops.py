@@ -613,6 +613,20 @@ def tapsum(z, ksize, up, pad, backward=False, grad=None, bias=None, bias_grad=No
     return gz
 
 
+def cconv_up2_single(x1, x2, wt, b_r, b_i):
+    """3x3 / stride 1 / one output channel over the 2x2 upsample of cat(x1, x2) in one kernel (dcs_cconv_up2_single_fwd).
+    wt: tap-rows panel [1, 16, ct, 2] of pack_tap_rows."""
+    _chk(x1, 'x1', 5)
+    _chk(x2, 'x2', 5)
+    _chk(wt, 'wt', 4)
+    B, Hs, Ws, C1, _ = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    y = torch.empty((B, 2 * Hs, 2 * Ws, 1, 2), dtype=torch.float32, device=x1.device)
+    check(_lib.load().dcs_cconv_up2_single_fwd(ptr(x1), ptr(x2), ptr(wt), ptr(b_r), ptr(b_i), ptr(y), B, Hs, Ws, C1, C2,
+                                               wt.shape[2], cur_stream()), 'dcs_cconv_up2_single_fwd')
+    return y
+
+
 def bound_crm(M, eps=10e-7, out=None):
     """M: float [..., 2] interleaved complex."""
     _chk(M, 'M')

@@ -367,6 +367,14 @@ int dcs_tapsum_bwd(const float* gy, float* gz, float* gb_r, float* gb_i, void* w
                    int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t, int pad_f, int pad_t,
                    dcs_stream_t stream);
 
+/* The same stage (3x3, stride 1, ONE output channel, 2x2 nearest upsample of cat(x1, x2), C1 + C2 = 16) forward in one
+ * kernel: no tap-channel intermediate in HBM (conv_up1.hip).  wt: the tap-rows panel of dcs_pack_tap_rows
+ * (complex[16][ct], ct >= 9, column tap = dy*3 + dx of the correlation kernel); b_r / b_i as for dcs_tapsum_fwd;
+ * y complex[B][2 Hs][2 Ws].  Its backward is the factored one: dcs_tapsum_bwd, then the data / weight gradient of the
+ * 1x1 tap conv. */
+int dcs_cconv_up2_single_fwd(const float* x1, const float* x2, const float* wt, const float* b_r, const float* b_i,
+                             float* y, int B, int Hs, int Ws, int C1, int C2, int ct, dcs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * bound_cRM (network_functions.py:77-88), as called at c_network.py:225:
  *     m = tanh|M| ; phi1 = atan2(Mi, Mr+eps) ; phi2 = atan2(m sin phi1, m cos phi1 + eps)
