@@ -106,6 +106,34 @@ def test_convtranspose_cat_upsample_backward(dev, c1, c2, cout, up):
         close(p[n].grad, q.grad, what=n)
 
 
+@pytest.mark.parametrize('c1,c2,up,hw', [(8, 8, (2, 2), (13, 37)), (16, 0, (2, 2), (8, 32)), (8, 8, (2, 1), (6, 11)),
+                                         (8, 0, (2, 2), (5, 9))])
+def test_single_output_stage(dev, c1, c2, up, hw):
+    """The last decoder stage (ConvTranspose2d -> 1 channel behind cat + upsample, c_network.py:135-141) through
+    F.cconv_single_output: the one-kernel forward (16 input channels, 2x2 upsample; ragged tile edges) and the factored
+    tap-channel path (other geometries), both with the factored backward, against the oracle layer."""
+    from dcsnet import functional as F
+    torch.manual_seed(c1 + c2 + up[1])
+    m = cpt.ComplexConvTranspose2d(c1 + c2, 1, 3, 1, 1)
+    d = rand_c((2, c1, *hw), 3).requires_grad_(True)
+    s = rand_c((2, c2, *hw), 4).requires_grad_(True) if c2 else None
+    cat = torch.cat((d, s), dim=1) if c2 else d
+    want = m(cpt.complex_upsample(cat, scale_factor=up, mode='nearest'))
+    functional_loss(want, 2).backward()
+    p = dev_params(m, dev)
+    dn = nhwc_leaf(d.detach(), dev)
+    sn = nhwc_leaf(s.detach(), dev) if c2 else None
+    y = F.cconv_single_output(dn, sn, p['conv_tran_r.weight'], p['conv_tran_i.weight'], p['conv_tran_r.bias'],
+                              p['conv_tran_i.bias'], (3, 3), (1, 1), up)
+    close(F.from_nhwc(y), want, rel=2e-5, what='forward')
+    functional_loss(F.from_nhwc(y), 2).backward()
+    close(cgrad(dn), d.grad, what='g_d')
+    if c2:
+        close(cgrad(sn), s.grad, what='g_skip')
+    for n, q in m.named_parameters():
+        close(p[n].grad, q.grad, what=n)
+
+
 def test_complex_linear_backward(dev):
     from dcsnet import functional as F
     torch.manual_seed(8)
