@@ -8,11 +8,47 @@ namespace wreduce {
 namespace {
 
 // plain slabs: 256 threads = 32 elements x 8 slab groups (coalesced 256-B rows per slab, 8 slabs in flight), LDS combine
+__device__ __forceinline__ void store_plain(const Job& q, long j, float sr, float si) {
+    const int co = (int)(j % q.Cout);
+    const int ci = (int)((j / q.Cout) % q.Cin);
+    const int tap = (int)(j / ((long)q.Cout * q.Cin));
+    const int dy = tap / q.kw, dx = tap % q.kw;
+    long dst;
+    if (q.transposed) dst = (((long)ci * q.Cout + co) * q.kh + (q.kh - 1 - dy)) * q.kw + (q.kw - 1 - dx);
+    else              dst = (((long)co * q.Cin + ci) * q.kh + dy) * q.kw + dx;
+    q.gw_r[dst] = sr;
+    q.gw_i[dst] = si;
+}
+
+// weights with an even element count: one thread sums ALL slabs of its two complex elements (16-byte loads, a wave reads
+// 1 KB contiguous per slab, 8 loads in flight), fixed slab order.  The 32-element x 8-slab-group form below (kept for the
+// bias rows and odd counts) moves 256-byte segments and pays an LDS combine per 32 elements.
+__device__ __forceinline__ bool plain_vec(const Job& q) { return (((long)q.kh * q.kw * q.Cin * q.Cout) & 1) == 0; }
+__device__ __forceinline__ long plain_wblocks(const Job& q) {
+    const long n = (long)q.kh * q.kw * q.Cin * q.Cout;
+    return plain_vec(q) ? (n / 2 + 255) / 256 : (n + 31) / 32;
+}
+
 __device__ __forceinline__ void reduce_plain(const Job& q, int bid, float2* red) {
     const long n = (long)q.kh * q.kw * q.Cin * q.Cout;
-    const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    const long nb = (n + 31) / 32;                          // blocks [0, nb): weights; [nb, ..): bias
+    const long nb = plain_wblocks(q);                       // blocks [0, nb): weights; [nb, ..): bias
     const bool is_bias = bid >= nb;
+    if (!is_bias && plain_vec(q)) {
+        const long j4 = (long)bid * 256 + threadIdx.x;
+        if (j4 * 2 >= n) return;
+        const float4* src = reinterpret_cast<const float4*>(q.slab_w) + j4;
+        const long stride4 = n / 2;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int s_ = 0; s_ < q.n_slabs; ++s_) {
+            const float4 v = src[(long)s_ * stride4];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        store_plain(q, 2 * j4, a.x, a.y);
+        store_plain(q, 2 * j4 + 1, a.z, a.w);
+        return;
+    }
+    const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
     const long j = is_bias ? (long)(bid - nb) * 32 + e : (long)bid * 32 + e;
     const long lim = is_bias ? q.Cout : n;
     const float2* src = is_bias ? q.slab_b : q.slab_w;
@@ -29,15 +65,7 @@ __device__ __forceinline__ void reduce_plain(const Job& q, int bid, float2* red)
         q.gb_i[j] = si - sr;
         return;
     }
-    const int co = (int)(j % q.Cout);
-    const int ci = (int)((j / q.Cout) % q.Cin);
-    const int tap = (int)(j / ((long)q.Cout * q.Cin));
-    const int dy = tap / q.kw, dx = tap % q.kw;
-    long dst;
-    if (q.transposed) dst = (((long)ci * q.Cout + co) * q.kh + (q.kh - 1 - dy)) * q.kw + (q.kw - 1 - dx);
-    else              dst = (((long)co * q.Cin + ci) * q.kh + dy) * q.kw + dx;
-    q.gw_r[dst] = sr;
-    q.gw_i[dst] = si;
+    store_plain(q, j, sr, si);
 }
 
 // destination tap index on one axis: which folded tap of residue class r contains original tap d
@@ -103,7 +131,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(Table t) {
 int blocks_of(const Job& q) {
     if (q.up_f > 0) return (int)((9L * q.Cin * q.Cout + (q.gb_r ? q.Cout : 0) + 255) / 256);
     const long n = (long)q.kh * q.kw * q.Cin * q.Cout;
-    return (int)((n + 31) / 32 + (q.gb_r ? (q.Cout + 31) / 32 : 0));
+    const long nbw = (n & 1) == 0 ? (n / 2 + 255) / 256 : (n + 31) / 32;           // = plain_wblocks
+    return (int)(nbw + (q.gb_r ? (q.Cout + 31) / 32 : 0));
 }
 
 std::vector<Job>* g_deferred = nullptr;                // process-wide: autograd runs backward on its own thread

@@ -430,10 +430,19 @@ class _LstmLayerFn(torch.autograd.Function):
     def forward(ctx, inp, anchor, st, B2, S):
         w_ih, w_hh = st['weight_ih'][0], st['weight_hh'][0]
         bias = st['bias_ih'][0] + st['bias_hh'][0]
-        gx = torch.baddbmm(bias.unsqueeze(1), inp, w_ih.transpose(1, 2))          # (set, n*t, dir*4H)
-        G4 = gx.shape[-1] // 2
         need = inp.requires_grad or anchor.requires_grad
-        out, gates, c, hprev = ops.lstm_layer(gx, w_hh, 2, B2, S, (B2 * S * 2 * G4, S * 2 * G4, 2 * G4), need, True)
+        if inp.dim() == 2:
+            # first layer: both parameter sets read the SAME rows -> one GEMM against the stacked [2*8H, in] weight; the
+            # recurrence takes gx by strides (set stride 8H inside a row), so nothing is expanded or copied
+            G8 = w_ih.shape[1]
+            gx = torch.addmm(bias.reshape(-1), inp, w_ih.reshape(2 * G8, -1).t())              # [(n t), (set, dir*4H)]
+            G4 = G8 // 2
+            strides = (G8, S * 2 * G8, 2 * G8)
+        else:
+            gx = torch.baddbmm(bias.unsqueeze(1), inp, w_ih.transpose(1, 2))                    # (set, n*t, dir*4H)
+            G4 = gx.shape[-1] // 2
+            strides = (B2 * S * 2 * G4, S * 2 * G4, 2 * G4)
+        out, gates, c, hprev = ops.lstm_layer(gx, w_hh, 2, B2, S, strides, need, True)
         ctx.st, ctx.dims = st, (B2, S)
         if need:
             ctx.save_for_backward(inp, hprev, gates, c)
@@ -464,8 +473,15 @@ class _LstmLayerFn(torch.autograd.Function):
         st['bias_hh'][1].add_(g_b)
         g_gx = g_pre.view(2, NT, 8 * H)
         g_wih = st['weight_ih'][1]
-        torch.baddbmm(g_wih, g_gx.transpose(1, 2), inp, out=g_wih)      # accumulate in place
         sink_hits += 16
+        if inp.dim() == 2:                                              # shared first-layer input: per-set GEMMs, no expand
+            for s_ in range(2):
+                g_wih[s_].addmm_(g_gx[s_].t(), inp)
+            g_inp = None
+            if ctx.needs_input_grad[0]:
+                g_inp = torch.addmm(torch.mm(g_gx[0], w_ih[0]), g_gx[1], w_ih[1])
+            return g_inp, None, None, None, None
+        torch.baddbmm(g_wih, g_gx.transpose(1, 2), inp, out=g_wih)      # accumulate in place
         g_inp = torch.bmm(g_gx, w_ih) if ctx.needs_input_grad[0] else None
         return g_inp, None, None, None, None
 
@@ -548,7 +564,7 @@ def complex_lstm(z, real_lstm, imag_lstm):
     stacked = _stacked_lstm(real_lstm) if torch.is_grad_enabled() else None
     for layer in range(real_lstm.num_layers):
         if stacked is not None:
-            out = _LstmLayerFn.apply(inp, real_lstm.weight_ih_l0, stacked[layer], 2 * B, S)
+            out = _LstmLayerFn.apply(x[0] if layer == 0 else inp, real_lstm.weight_ih_l0, stacked[layer], 2 * B, S)
             inp = out.view(2, 2 * B * S, -1)
             continue
         w_ih, bias, w_hh = _lstm_layer_operands(sets, layer)
