@@ -171,7 +171,7 @@ class TrainStep:
             from . import ops
             self.seed_state = torch.zeros(1, dtype=torch.int64, device=self.bucket.flat.device)
             ops.SEED_STATE = self.seed_state
-        self._graph = self._static_batch = self._static_loss = None
+        self._graph = self._graph_opt = self._static_batch = self._static_loss = None
         self.use_pack_plan, self._plan = bool(use_pack_plan), None
         self._calls = 0
 
@@ -247,6 +247,20 @@ class TrainStep:
                 self.seed_state += 1
         functional.bump_param_generation()                 # cache entries made during capture live in its pool
         self._graph, self._static_loss, self._graph_world = g, loss.detach(), world
+        self._graph_opt = None
+        if world > 1:
+            # the optimizer half (device-side norm, fused clip + Adam, seed advance) as a second graph replayed after the
+            # all-reduce: ~6 eager launches per step otherwise sit between the collective and the next forward
+            try:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, capture_error_mode='thread_local'):
+                    self.opt.step(world)
+                    self.seed_state += 1
+                self._graph_opt = g2
+            except Exception as e:                          # noqa: BLE001 - the eager optimizer still works
+                import warnings
+                warnings.warn(f'TrainStep: optimizer graph capture failed ({type(e).__name__}: {e}); optimizer runs eagerly')
+                torch.cuda.synchronize()
 
     def __call__(self, batch, batch_idx=0):
         if not self.use_graph:
@@ -268,8 +282,12 @@ class TrainStep:
                 s.copy_(b)
         self._graph.replay()
         from . import functional
-        functional.bump_param_generation()     # the replay rewrote parameters and running statistics behind torch's back
         if self._graph_world > 1:
-            self.opt.step(self.bucket.allreduce())
-            self.seed_state += 1
+            world = self.bucket.allreduce()
+            if self._graph_opt is not None:
+                self._graph_opt.replay()
+            else:
+                self.opt.step(world)
+                self.seed_state += 1
+        functional.bump_param_generation()     # the replays rewrote parameters and running statistics behind torch's back
         return self._static_loss
