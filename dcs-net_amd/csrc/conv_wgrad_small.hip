@@ -7,7 +7,9 @@
 // generic output-stationary kernel (conv_direct.hip) re-reads both operands from LDS for every FMA quad.  Here a
 // thread owns PIXELS and keeps all 49 taps x 2 of the outputs in registers (196 VGPRs): g_Y comes from HBM once
 // per pixel, the haloed input tile is staged in LDS once per 16x16 tile, and each LDS read feeds 4-8 FMAs.
-//   MODE 0: the 256 threads take the 256 pixels of a tile; acc[tap][ci].
+//   MODE 0: the 256 threads take the 256 pixels of a tile; acc[tap][ci].  (The one-pixel-per-thread form of the template
+//           below is no longer instantiated: the 2 -> 1 problems run wgrad_sa_body — four pixels per thread on 16 x 64
+//           tiles — further down; the template's MODE 0 branches document what it replaced.)
 //   MODE 1: wave w owns output channels (2w, 2w+1) and walks all 256 pixels of the tile in 4 passes; acc[tap][co&1].
 // The lanes are summed once per workgroup (DPP row shifts / broadcasts; cross-wave through LDS for MODE 0) into
 // one partial slab per workgroup — same slab layout and reduce kernel as the other weight-gradient paths, no atomics.
