@@ -782,8 +782,8 @@ def istft_ola(frames, window, inv_env, hop, scale=1.0):
 
 class _PolarWaveFn(torch.autograd.Function):
     """z -> waveform of mag_phase_2_wave(|z|, atan2(z_i, z_r + eps)) (network_functions.py:140-150, :213-221) as ONE node:
-    polar round trip + zero bin + frame-major transpose (HIP), unnormalised inverse real FFT (rocFFT; its 1/n folded into
-    the overlap-add scale), window / overlap-add / envelope / trim (HIP).  Backward: adjoint gather (HIP), one forward real
+    polar round trip + zero bin + frame-major transpose (HIP), unnormalised inverse real FFT (fft512.hip at n_fft = 512, else
+    rocFFT; its 1/n folded into the overlap-add scale), window / overlap-add / envelope / trim (HIP).  Backward: adjoint gather (HIP), one forward real
     FFT, and the polar backward kernel applies the one-sided x2 weighting itself — autograd's irfft node costs a scale
     kernel forward and two element-wise complex kernels backward per signal."""
 
@@ -793,7 +793,10 @@ class _PolarWaveFn(torch.autograd.Function):
         if Fb + 1 != n_fft // 2 + 1:
             raise DcsHipError(f'polar_wave: {Fb} bins + 1 zero bin is not the one-sided spectrum of n_fft = {n_fft}')
         comp = ops.polar_frames(z, Fb + 1, eps)
-        frames = torch.fft.irfft(torch.view_as_complex(comp), n=n_fft, dim=-1, norm='forward')
+        if n_fft == 512:                                   # hand-written 512-point pair (fft512.hip)
+            frames = ops.irfft512(comp)
+        else:
+            frames = torch.fft.irfft(torch.view_as_complex(comp), n=n_fft, dim=-1, norm='forward')
         ctx.cfg = (tuple(frames.shape), n_fft, hop, scale / n_fft, eps)
         ctx.save_for_backward(z, window, inv_env)
         return ops.istft_ola(frames, window, inv_env, hop, scale / n_fft)
@@ -803,7 +806,10 @@ class _PolarWaveFn(torch.autograd.Function):
         z, window, inv_env = ctx.saved_tensors
         shape, n_fft, hop, scale, eps = ctx.cfg
         g_frames = ops.istft_ola(shape, window, inv_env, hop, scale, grad=g.contiguous())
-        G = torch.view_as_real(torch.fft.rfft(g_frames, dim=-1))                  # [B, T, n_fft/2 + 1, 2], no scaling
+        if n_fft == 512:
+            G = ops.rfft512(g_frames)                                                 # [B, T, 257, 2], no scaling
+        else:
+            G = torch.view_as_real(torch.fft.rfft(g_frames, dim=-1))
         return ops.polar_frames(z, z.shape[1] + 1, eps, grad=G, hermitian=True), None, None, None, None, None, None
 
 

@@ -675,6 +675,26 @@ def polar_frames(z, Fp, eps=10e-7, grad=None, hermitian=False):
     return gz
 
 
+def irfft512(X):
+    """X float [..., 257, 2] one-sided spectra -> [..., 512] unnormalised inverse real FFT (dcs_irfft512_frames)."""
+    _chk(X, 'X')
+    if X.shape[-2:] != (257, 2):
+        raise _lib.DcsHipError(f'irfft512: expected [..., 257, 2], got {tuple(X.shape)}')
+    y = torch.empty((*X.shape[:-2], 512), dtype=torch.float32, device=X.device)
+    check(_lib.load().dcs_irfft512_frames(ptr(X), ptr(y), X.numel() // 514, cur_stream()), 'dcs_irfft512_frames')
+    return y
+
+
+def rfft512(g):
+    """g float [..., 512] -> [..., 257, 2] forward real FFT, no scaling (dcs_rfft512_frames)."""
+    _chk(g, 'g')
+    if g.shape[-1] != 512:
+        raise _lib.DcsHipError(f'rfft512: expected [..., 512], got {tuple(g.shape)}')
+    G = torch.empty((*g.shape[:-1], 257, 2), dtype=torch.float32, device=g.device)
+    check(_lib.load().dcs_rfft512_frames(ptr(g), ptr(G), g.numel() // 512, cur_stream()), 'dcs_rfft512_frames')
+    return G
+
+
 def istft_envelope(window, T, hop):
     """1 / (squared-window overlap-add envelope) of torch.istft(center=True) for T frames: float [hop*(T-1)]."""
     _chk(window, 'window', 1)

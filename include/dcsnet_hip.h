@@ -411,6 +411,13 @@ int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const float* g_M
  *   (irfft output), y float[B][hop (T-1)]; scale = sqrt(n_fft) for normalized=True.  No NOLA check (it is a host
  *   read-back in torch.istft): the caller guarantees a non-vanishing envelope.
  * dcs_istft_ola_bwd: g_frames from g_y (the adjoint gather). */
+/* The 512-point real FFT pair of that synthesis (n_fft = 512, config.py:57), one wavefront per frame (fft512.hip):
+ * dcs_irfft512_frames: X complex[frames][257] -> y float[frames][512], UNNORMALISED inverse (the caller folds 1/512 into
+ *   its next scale; imaginary parts of bins 0 and 256 ignored, as by every c2r transform);
+ * dcs_rfft512_frames: g float[frames][512] -> G complex[frames][257], forward, no scaling (= the adjoint of the above up to
+ *   the one-sided x2 weighting that dcs_polar_frames_bwd(hermitian = 1) applies). */
+int dcs_irfft512_frames(const float* X, float* y, long frames, dcs_stream_t stream);
+int dcs_rfft512_frames(const float* g, float* G, long frames, dcs_stream_t stream);
 int dcs_polar_frames_fwd(const float* z, float* out, int B, int F, int Fp, int T, float eps, dcs_stream_t stream);
 int dcs_polar_frames_bwd(const float* z, const float* g_out, float* g_z, int B, int F, int Fp, int T, float eps,
                          int hermitian, dcs_stream_t stream);

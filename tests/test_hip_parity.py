@@ -507,3 +507,18 @@ def test_real_attention_pair(dev, C, hw):
     with torch.no_grad():
         got = R_NETWORK._attend(ca, sa, x.permute(0, 2, 3, 1).contiguous().to(dev))
     close(got, want, rel=2e-5)
+
+
+@pytest.mark.parametrize('frames', [(3, 7), (2, 64), (1, 1)])
+def test_fft512_pair(dev, frames):
+    """dcs_irfft512_frames / dcs_rfft512_frames (fft512.hip) against torch.fft on the CPU: unnormalised inverse of
+    one-sided spectra with COMPLEX bins 0 / 256 (their imaginary parts are ignored, as by torch's c2r), forward without
+    scaling.  Tolerance: 2e-6 of the output scale (fp32 radix-4, 512 points)."""
+    from dcsnet import ops
+    g = torch.Generator().manual_seed(sum(frames))
+    X = torch.complex(torch.randn((*frames, 257), generator=g), torch.randn((*frames, 257), generator=g))
+    want = torch.fft.irfft(X, n=512, dim=-1, norm='forward')
+    got = ops.irfft512(torch.view_as_real(X).contiguous().to(dev))
+    close(got, want, rel=2e-6)
+    y = torch.randn((*frames, 512), generator=g)
+    close(ops.rfft512(y.to(dev)), torch.view_as_real(torch.fft.rfft(y, dim=-1)), rel=2e-6)
