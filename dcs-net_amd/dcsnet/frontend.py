@@ -2,7 +2,7 @@
 workers (data.py:84-134: crop to integer_win_size - hop samples, noise = noisy - clean, three torch.stft calls, keep
 bins 1..n_fft/2), for a whole batch of waveforms already on the GPU.
 
-    frames (HIP: window + reflect padding, all three signals)  ->  one batched contiguous rfft (rocFFT via torch.fft)
+    frames (HIP: window + reflect padding, all three signals)  ->  one batched contiguous real FFT (fft512.hip at n_fft = 512, else rocFFT via torch.fft)
     ->  bins (HIP: drop the DC bin, 1/sqrt(n_fft), transpose to the network's [B, 256, T] layout)
 
 Resampling (data.py:84-85, torchaudio) and file decoding stay with the loader; they are out of scope."""
@@ -42,7 +42,10 @@ def stft_batch(clean_wave, noisy_wave, config):
     T = L // hop + 1
     w = _window_on(config, clean_wave.device)
     frames = ops.stft_frames(clean_wave.contiguous(), noisy_wave.contiguous(), w, T, hop)          # [3,B,T,n_fft]
-    spec = torch.view_as_real(torch.fft.rfft(frames, dim=-1))                                      # [3,B,T,n_fft/2+1,2]
+    if n_fft == 512:                                     # hand-written 512-point real FFT (fft512.hip)
+        spec = ops.rfft512(frames)                                                                  # [3,B,T,257,2]
+    else:
+        spec = torch.view_as_real(torch.fft.rfft(frames, dim=-1))                                  # [3,B,T,n_fft/2+1,2]
     scale = float(n_fft) ** -0.5 if config.normalise_stft else 1.0
     out = torch.view_as_complex(ops.stft_bins(spec.contiguous(), scale))                           # [3,B,F,T]
     clean, noise, noisy = out[0], out[1], out[2]
