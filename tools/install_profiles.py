@@ -1,0 +1,36 @@
+"""Copy one tools/collect_profiles.sh result set into profiles/ under its tag and print the numbers the docs quote:
+    python tools/install_profiles.py <tag> [old_tag_to_remove]"""
+import csv, json, os, shutil, subprocess, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(REPO, 'gpurun_out', tag)
+dst = os.path.join(REPO, 'profiles')
+if len(sys.argv) > 2:
+    for f in os.listdir(dst):
+        if f.startswith(sys.argv[2] + '_'):
+            os.remove(os.path.join(dst, f))
+for a, b in (('bench_train_default.json', 'bench_train_default.json'), ('bench_infer.json', 'bench_infer.json'),
+             ('train_kernel_stats.csv', 'train_b32_t256_kernel_stats.csv'), ('infer_kernel_stats.csv', 'infer_b16_t2000_kernel_stats.csv')):
+    shutil.copy(os.path.join(src, a), os.path.join(dst, f'{tag}_{b}'))
+commit = subprocess.run(['git', 'log', '-1', '--format=%s'], cwd=REPO, capture_output=True, text=True).stdout.strip()[:80]
+subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'pmc_family_traffic.py'), src, tag, commit], stdout=subprocess.DEVNULL)
+for m in ('train_default', 'infer'):
+    d = json.load(open(os.path.join(src, f'bench_{m}.json')))
+    r = d['roofline']
+    print(f"{m}: {d['ms_per_step']:.3f} ms, {d['value']:.0f} frames/s, conv {r['achieved']:.1f} TF frac {r['frac']:.3f}, "
+          f"conv ms/step {r['kernel_ms_per_step']:.3f} over {r['launches'] / d['steps']:.0f} calls, traffic {r['traffic'] / 1e9:.2f} GB, "
+          f"cpu {d['cpu_baseline'] and d['cpu_baseline']['value']:.0f}")
+keys = ('cconv_', 'splitk_reduce', 'wgrad_reduce', 'tapsum', 'tap_rows_scatter', 'csum_')
+for mode, per in (('train', 27.0), ('infer', None)):
+    rows = list(csv.DictReader(open(os.path.join(src, f'{mode}_kernel_stats.csv'))))
+    if per is None:
+        per = sum(int(r['Calls']) for r in rows if 'cbn_apply' in r['Name']) / 14.0
+    t = sum(float(r['TotalDurationNs']) for r in rows if any(k in r['Name'] for k in keys)) / per / 1e6
+    n = sum(int(r['Calls']) for r in rows if any(k in r['Name'] for k in keys)) / per
+    tot = sum(float(r['TotalDurationNs']) for r in rows) / per / 1e6
+    nk = sum(int(r['Calls']) for r in rows) / per
+    print(f'{mode}: rocprof conv family {t:.3f} ms over {n:.0f} kernels per step ({per:.0f} steps in file); all kernels {tot:.3f} ms, {nk:.0f} per step')
+print(open(os.path.join(dst, f'{tag}_pmc_hbm_traffic.txt')).read().split('\n== ')[0].split('\n')[-2])
+for line in open(os.path.join(dst, f'{tag}_pmc_hbm_traffic.txt')):
+    if line.startswith('conv family') or line.startswith('adam'):
+        print(line.strip())
