@@ -3,6 +3,7 @@ ctypes signatures cover exactly those symbols, and the host-side mirror of the r
 surface (module names, state_dict keys, config literals, argument checks) is intact.
 No compute call is made here — there is no GPU."""
 import os
+import sys
 import re
 import ctypes
 import pytest
@@ -117,6 +118,24 @@ def test_rnetwork_state_dict_round_trip_with_oracle():
     with pytest.raises(DcsHipError):
         with torch.no_grad():
             net.eval()(torch.zeros(1, 256, 32))
+
+
+def test_product_path_never_touches_the_oracle_and_has_no_cpu_fallback():
+    """The oracle is test infrastructure: no file of the product package (or of the drop-in shims, bench's product half
+    excepted by contract) may import it, and importing the package must not pull it in; every op refuses CPU tensors."""
+    import re, subprocess
+    pkg = os.path.join(REPO, 'dcs-net_amd')
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                assert not pat.search(open(os.path.join(root, f)).read()), os.path.join(root, f)
+    code = ('import sys; sys.path.insert(0, %r); import dcsnet, dcsnet.c_network, dcsnet.r_network, dcsnet.dp, dcsnet.frontend; '
+            'assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules), "oracle imported"' % pkg)
+    subprocess.run([sys.executable, '-c', code], check=True, cwd=REPO)
+    from dcsnet import ops, DcsHipError
+    with pytest.raises(DcsHipError):
+        ops.bound_crm(torch.zeros(4, 2))
 
 
 def test_forward_validates_input():
