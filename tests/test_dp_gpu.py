@@ -61,3 +61,24 @@ def test_two_rank_graph_replayed_train_step(tmp_path):
     assert r['same'], 'ranks diverged after 5 data-parallel steps'
     assert r['finite'] and r['t'] == 5
     assert all(l == l for l in r['losses'])
+
+
+@pytest.mark.parametrize('mode', ['train', 'infer'])
+def test_bench_two_rank_rehearsal(mode):
+    """bench.py launched exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with the
+    rehearsal switches that put both ranks on the one card and replace RCCL by gloo: the multi-rank control flow
+    (warm-up, barriers, graph A -> all-reduce -> graph B, the instrumented pass on every rank, MAX over ranks, one JSON
+    line from rank 0) must run to completion — a collective issued by one rank alone hangs the job."""
+    import json
+    import subprocess
+    env = dict(os.environ, DCS_BENCH_DEVICE='0', DCS_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--mode', mode, '--steps', '2',
+           '--warmup', '1', '--no-cpu-baseline', '--batch', '4', '--frames', '64']
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-500:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['value'] > 0 and out['scaling'] == 'weak'
+    assert out['config']['global_batch'] == 8 and out['roofline']['achieved'] > 0
