@@ -9,6 +9,10 @@ struct Args {
     const float2* x1; const float2* x2; const float2* wp; const float2* bias; float2* y;
     int B, Hin, Win, C1, C2, up_f, up_t, zero_ins, Cout, kh, kw, sf, st, pad_f, pad_t, act;
     int Hv, Wv, Hout, Wout, tiles_w, tiles_h, rows, cols, colsp, plane;
+    // optional per-output-channel real 2x2 affine applied between bias and activation (forward epilogues only):
+    // (re, im) <- (a0 re + a1 im + c0, a2 re + a3 im + c1), float[Cout][6] = {a0, a1, a2, a3, c0, c1} — an eval-mode
+    // ComplexBatchNorm2d folded into the conv that feeds it (dcs_cconv2d_fwd_affine)
+    const float* coef;
 };
 
 // One output-parity class of a decomposed convolution (conv_mfma.hip): its own sub-kernel, padding,

@@ -77,7 +77,13 @@ __device__ __forceinline__ void cconv_direct_body(const ConvArgs& a, int tile_id
 #pragma unroll
         for (int i = 0; i < COB; ++i) {
             const float2 bv = a.bias ? a.bias[co0 + i] : make_float2(0.f, 0.f);
-            out[i] = make_float2(dcs_act(accr[i] + bv.x, a.act), dcs_act(acci[i] + bv.y, a.act));
+            float vr = accr[i] + bv.x, vi = acci[i] + bv.y;
+            if (a.coef) {                                  // folded eval-mode CBN (conv_common.h)
+                const float* q = a.coef + 6 * (co0 + i);
+                const float ur = vr, ui = vi;
+                vr = fmaf(q[0], ur, fmaf(q[1], ui, q[4])); vi = fmaf(q[2], ur, fmaf(q[3], ui, q[5]));
+            }
+            out[i] = make_float2(dcs_act(vr, a.act), dcs_act(vi, a.act));
         }
     }
 }
@@ -459,11 +465,19 @@ extern "C" int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp
                                void* workspace, long workspace_bytes, int B, int Hin, int Win, int C1, int C2, int up_f,
                                int up_t, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
                                dcs_stream_t stream) {
+    return dcs_cconv2d_fwd_affine(x1, x2, wp, bias, nullptr, y, workspace, workspace_bytes, B, Hin, Win, C1, C2, up_f, up_t, Cout,
+                                  kh, kw, sf, st, pad_f, pad_t, act, stream);
+}
+
+extern "C" int dcs_cconv2d_fwd_affine(const float* x1, const float* x2, const float* wp, const float* bias, const float* coef,
+                                      float* y, void* workspace, long workspace_bytes, int B, int Hin, int Win, int C1, int C2,
+                                      int up_f, int up_t, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t,
+                                      int act, dcs_stream_t stream) {
     if (!wp || !bias || !y) return DCS_ERR_BADARG;
     if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t)) return DCS_ERR_BADARG;
     if (act < DCS_ACT_NONE || act > DCS_ACT_SIGMOID) return DCS_ERR_BADARG;
     FwdPlan p = fwd_plan(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
-    p.a.wp = (const float2*)wp; p.a.bias = (const float2*)bias; p.a.y = (float2*)y; p.a.act = act;
+    p.a.wp = (const float2*)wp; p.a.bias = (const float2*)bias; p.a.y = (float2*)y; p.a.act = act; p.a.coef = coef;
     if (p.path == 0)
         return dcs_conv_mfma_launch_classes(p.a, wp + base_floats(Cout, C1 + C2, kh * kw), p.ncls, p.cls, p.os_f, p.os_t,
                                             nullptr, 0, workspace, workspace_bytes, dcs_stream(stream));

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void cconv_k7_kernel(K7Table tb) {
 
 bool k7_geom(const conv::Args& a) {
     return a.kh == K && a.kw == K && a.sf == 1 && a.st == 1 && a.pad_f == PAD && a.pad_t == PAD && a.up_f == 1 &&
-           a.up_t == 1 && a.C2 == 0 && a.x1 && a.wp && a.y &&          // (zero insertion with up = 1 inserts nothing)
+           a.up_t == 1 && a.C2 == 0 && a.x1 && a.wp && a.y && !a.coef &&          // (zero insertion with up = 1 inserts nothing)
            ((a.C1 == 2 && a.Cout == 1) || (a.C1 == 1 && a.Cout == 2) || (a.C1 == 1 && a.Cout == 1));
 }
 

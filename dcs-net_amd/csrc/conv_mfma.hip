@@ -244,6 +244,14 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         const int n = (nt0 + j) * 32 + li;
         if (n >= m.N) continue;                                        // zero-padded columns of a 16-wide N
         const float bv = biasf ? biasf[n] : 0.f;
+        // folded eval-mode CBN: this lane's column is (channel n/2, re | im); its partner column sits in lane ^ 1
+        // out = fma(c_re, re, fma(c_im, im, c_add)): the association order of cbn_apply_kernel, so the folded and the
+        // two-kernel forms agree bit for bit
+        float c_re = 1.f, c_im = 0.f, c_add = 0.f;
+        if (a.coef) {
+            const float* q = a.coef + 6 * (n >> 1);
+            if (n & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
+        }
         // columns >= nsplit belong to the second tensor of a concatenation
         const bool second = m.y2 != nullptr && n >= m.nsplit;
         float* yf = second ? m.y2 : reinterpret_cast<float*>(a.y);
@@ -257,9 +265,13 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
                 const int pi = (wm * WM + i) * 32 + row;
                 const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
+                float v = acc[i][j][r] + bv;
+                if (a.coef) {
+                    const float pv = dcs_dpp_term<0xB1, 0xf>(v);                     // quad_perm [1,0,3,2]: the partner column
+                    v = (n & 1) ? fmaf(c_re, pv, fmaf(c_im, v, c_add)) : fmaf(c_re, v, fmaf(c_im, pv, c_add));
+                }
                 if (oy < k.Hc && ox < k.Wc)
-                    yb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] =
-                        dcs_act(acc[i][j][r] + bv, a.act);
+                    yb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] = dcs_act(v, a.act);
             }
         }
     }
@@ -379,21 +391,32 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
     const int width = m.y2 == nullptr ? 16 : (second ? 16 - m.nsplit : m.nsplit);
     const int col = second ? n - m.nsplit : n;
     float* yb = yf + (long)b * a.Hout * a.Wout * width;
+    float c_re = 1.f, c_im = 0.f, c_add = 0.f;                        // folded eval-mode CBN (see the 32-column kernel)
+    if (a.coef) {
+        const float* q = a.coef + 6 * (n >> 1);
+        if (n & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int pi = wave * 32 + i * 16 + g4 * 4 + r;
             const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
+            float v = acc[i][r] + bv;
+            if (a.coef) {
+                const float pv = dcs_dpp_term<0xB1, 0xf>(v);
+                v = (n & 1) ? fmaf(c_re, pv, fmaf(c_im, v, c_add)) : fmaf(c_re, v, fmaf(c_im, pv, c_add));
+            }
             if (oy < k.Hc && ox < k.Wc)
-                yb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] = dcs_act(acc[i][r] + bv, a.act);
+                yb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] = dcs_act(v, a.act);
         }
 }
 
 // y[p][n] = act(sum_s part[s][p][n] + bias[n]); columns >= nsplit of a cat split go to y2.  One float4 per thread.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long slab_floats,
                                                             const float* __restrict__ bias, float* __restrict__ y,
-                                                            float* __restrict__ y2, int nsplit, int N, int act) {
+                                                            float* __restrict__ y2, int nsplit, int N, int act,
+                                                            const float* __restrict__ coef) {
     const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
     if (i4 * 4 >= slab_floats) return;
     float4 v = *reinterpret_cast<const float4*>(part + i4 * 4);
@@ -404,6 +427,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const long p = (i4 * 4) / N;
     const int n = (int)((i4 * 4) % N);
     if (bias) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
+    if (coef) {                                             // folded eval-mode CBN: two complex channels per thread
+        const float* q = coef + 6 * (n >> 1);
+        const float4 u = v;
+        v.x = fmaf(q[0], u.x, fmaf(q[1], u.y, q[4])); v.y = fmaf(q[2], u.x, fmaf(q[3], u.y, q[5]));
+        v.z = fmaf(q[6], u.z, fmaf(q[7], u.w, q[10])); v.w = fmaf(q[8], u.z, fmaf(q[9], u.w, q[11]));
+    }
     v.x = dcs_act(v.x, act); v.y = dcs_act(v.y, act); v.z = dcs_act(v.z, act); v.w = dcs_act(v.w, act);
     if (y2 == nullptr) *reinterpret_cast<float4*>(y + i4 * 4) = v;
     else if (n < nsplit) *reinterpret_cast<float4*>(y + p * nsplit + n) = v;
@@ -617,7 +646,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
     if (rc != DCS_OK || m.ksplit <= 1) return rc;
     const long n4 = m.slab_floats / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)m.part,
-                       m.ksplit, m.slab_floats, (const float*)a.bias, (float*)a.y, y2, nsplit, m.N, a.act);
+                       m.ksplit, m.slab_floats, (const float*)a.bias, (float*)a.y, y2, nsplit, m.N, a.act, a.coef);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

@@ -34,6 +34,7 @@ SIGNATURES = {
     'dcs_pack_conv_weight': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'dcs_cconv2d_fwd_workspace_bytes': (_L, [_I] * 14),
     'dcs_cconv2d_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 15 + [_P]),
+    'dcs_cconv2d_fwd_affine': (_I, [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 15 + [_P]),
     'dcs_rconv2d_fwd_workspace_bytes': (_L, [_I] * 14),
     'dcs_rconv2d_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 15 + [_P]),
     'dcs_packed_weight_floats': (_L, [_I] * 6),

@@ -203,8 +203,16 @@ class C_NETWORK(LightningModule):
         e = torch.view_as_real(x.contiguous()).view(B, Fbins, T, 1, 2)
         self._count_batches()
         enc = [self._bn(self.initial_batchnorm, e, F.ACT_NONE)]
+        infer = not self.training and not torch.is_grad_enabled()
         for i in range(L):                                   # c_network.py:193-197
             conv, bn = self.encoder[i][0], self.encoder[i][1]
+            coef = bn.eval_coef() if infer else None
+            if coef is not None:                             # inference: CBN folded into the conv epilogue (constants)
+                self._drop(p_conv)
+                enc.append(F.cconv2d_cbn_eval(enc[i], None, conv.conv_r.weight, conv.conv_i.weight, conv.conv_r.bias,
+                                              conv.conv_i.bias, False, conv.kernel_size, conv.stride, conv.padding, (1, 1),
+                                              coef, F.ACT_RELU))
+                continue
             c = F.cconv2d(enc[i], None, conv.conv_r.weight, conv.conv_i.weight, conv.conv_r.bias, conv.conv_i.bias,
                           False, conv.kernel_size, conv.stride, conv.padding)
             enc.append(self._bn(bn, c, F.ACT_RELU, p_conv))
@@ -230,6 +238,15 @@ class C_NETWORK(LightningModule):
                                           convt.conv_tran_r.bias, convt.conv_tran_i.bias, convt.kernel_size,
                                           convt.corr_padding, up)
             else:
+                coef = stage[1].eval_coef() if infer and i != L - 1 else None
+                if coef is not None:                         # inference: conv + CBN + CLReLU in one kernel, then the attention
+                    a = F.cconv2d_cbn_eval(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight,
+                                           convt.conv_tran_r.bias, convt.conv_tran_i.bias, True, convt.kernel_size, (1, 1),
+                                           convt.corr_padding, up, coef, F.ACT_LRELU)
+                    self._drop(p_conv)
+                    self._drop(0.0)
+                    d = self._attend(self.decoder_attention[2 * i], self.decoder_attention[2 * i + 1], a)
+                    continue
                 y = F.cconv2d(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight, convt.conv_tran_r.bias,
                               convt.conv_tran_i.bias, True, convt.kernel_size, (1, 1), convt.corr_padding, up)
             dp, seed = self._drop(p_conv)

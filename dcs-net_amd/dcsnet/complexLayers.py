@@ -137,15 +137,29 @@ class _ComplexBatchNorm(Module):
             momentum = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
             F.note_state_update()              # the kernel rewrites the running statistics in place
         rm = torch.view_as_real(self.running_mean) if self.track_running_stats else None
+        if attention is not None and drop_p:
+            raise F.DcsHipError('CBN + attention: dropout belongs to the attention block')
+        if not use_batch and not torch.is_grad_enabled():
+            y = self._eval_forward(x_nhwc, rm, act, drop_p, seed)
+            return y if attention is None else F.attention_block(y, *attention)
         if attention is not None:
-            if drop_p:
-                raise F.DcsHipError('CBN + attention: dropout belongs to the attention block')
             return F.cbn_attention(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
                                    act, *attention)
-        if not use_batch and not torch.is_grad_enabled():
-            return self._eval_forward(x_nhwc, rm, act, drop_p, seed)
         return F.cbn(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
                      act, drop_p, seed)
+
+    def eval_coef(self):
+        """The cached inference-time coefficients [C, 6] of this CBN (see _eval_forward), or None when there is no valid
+        entry (first eval pass, training mode, autograd on, parameters or running statistics changed since)."""
+        if self.training or torch.is_grad_enabled() or not self.track_running_stats:
+            return None
+        tensors = (self.weight, self.bias, self.running_mean, self.running_covar)
+        vers = (F.state_generation(),) + tuple(None if t is None else (t._version, t.data_ptr()) for t in tensors)
+        ent = _EVAL_COEF.get(self)
+        if ent is not None and ent[1] == vers and all((r is None and t is None) or (r is not None and r() is t)
+                                                      for r, t in zip(ent[0], tensors)):
+            return ent[2][1]
+        return None
 
     def _eval_forward(self, x, rm, act, drop_p, seed):
         """Inference: the whitening + affine coefficients are constants of (weight, bias, running statistics): computed

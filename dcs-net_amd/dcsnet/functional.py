@@ -152,6 +152,13 @@ def cconv2d(x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up=(1, 1
                             tuple(up), act)
 
 
+def cconv2d_cbn_eval(x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up, coef, act):
+    """Inference only: conv + eval-mode CBN (its cached coefficients, complexLayers.eval_coef) + activation as ONE kernel
+    (dcs_cconv2d_fwd_affine) — the CBN's separate pass over the activation disappears."""
+    wp, bias = packed_weight(w_r, w_i, b_r, b_i, transposed, tuple(up))
+    return ops.cconv2d(x1, x2, wp, bias, tuple(ksize), tuple(stride), tuple(pad), tuple(up), act, coef=coef)
+
+
 class _CbnFn(torch.autograd.Function):
     """dcs_cbn_fwd / dcs_cbn_bwd.  Saves only x and 14 floats per channel."""
 

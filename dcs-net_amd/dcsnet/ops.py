@@ -178,8 +178,9 @@ def tap_rows_scatter(gt_r, gt_i, w_shape, outs=None):
     return g_r, g_i
 
 
-def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=ACT_NONE):
-    """Complex correlation over the virtual input upsample(cat(x1, x2)); see dcs_cconv2d_fwd."""
+def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=ACT_NONE, coef=None):
+    """Complex correlation over the virtual input upsample(cat(x1, x2)); see dcs_cconv2d_fwd.  coef [Cout, 6]: an eval-mode
+    CBN's coefficients folded in between bias and activation (dcs_cconv2d_fwd_affine)."""
     _chk(x1, 'x1', 5)
     _chk(x2, 'x2', 5)
     _chk(wp, 'wp', 4)
@@ -205,9 +206,13 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     nbytes = max(nbytes, 0)
     # bench.py's live roofline probe: 8 real flops per complex MAC
     ev = CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw) if CONV_TIMER is not None else None
-    check(lib.dcs_cconv2d_fwd(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(y), ptr(ws), nbytes, B, Hin, Win, C1, C2,
-                              up[0], up[1], Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], act, cur_stream()),
-          'dcs_cconv2d_fwd')
+    if coef is not None:
+        _chk(coef, 'coef', 2)
+        if tuple(coef.shape) != (Cout, 6):
+            raise _lib.DcsHipError(f'cconv2d: coef {tuple(coef.shape)} does not match Cout={Cout}')
+    check(lib.dcs_cconv2d_fwd_affine(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(coef), ptr(y), ptr(ws), nbytes, B, Hin, Win,
+                                     C1, C2, up[0], up[1], Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], act,
+                                     cur_stream()), 'dcs_cconv2d_fwd_affine')
     if ev is not None:
         CONV_TIMER.end(ev)
     return y

@@ -106,6 +106,17 @@ int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const flo
                     int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
                     dcs_stream_t stream);
 
+/* dcs_cconv2d_fwd with an eval-mode ComplexBatchNorm2d folded into the epilogue: between bias and activation every output
+ * channel goes through the real 2x2 affine map  (re, im) <- (a0 re + a1 im + c0, a2 re + a3 im + c1),
+ * coef float[Cout][6] = {a0, a1, a2, a3, c0, c1} — exactly the `coef_out` an eval-mode dcs_cbn_fwd writes (running statistics
+ * are constants at inference, so conv + CBN + activation is one kernel and one pass over the activation).  coef == NULL:
+ * dcs_cconv2d_fwd. */
+int dcs_cconv2d_fwd_affine(const float* x1, const float* x2, const float* wp, const float* bias, const float* coef, float* y,
+                           void* workspace, long workspace_bytes,
+                           int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                           int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
+                           dcs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Real-valued convolution (DR-Net / DRS-Net: torch.nn.Conv2d / ConvTranspose2d of r_network.py:60-66, :90-102) on the
  * same fp32 MFMA implicit-GEMM kernel.  A real channels-last activation float[B][H][W][Cr] with even Cr is bit-for-bit

@@ -276,7 +276,9 @@ def test_network_forward_against_reference_vectors(dev, cnv, tag, seed):
     net.eval()
     with torch.no_grad():
         ev = net(x)
+        ev2 = net(x)          # second pass: cached inference constants, CBNs folded into the conv epilogues
     close(ev, torch.from_numpy(cnv[f'{tag}_eval']), rel=0, abs_=2e-4)
+    assert torch.equal(ev, ev2)
     net.train()
     with torch.no_grad():
         tr = net(x)
