@@ -18,6 +18,7 @@
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kHBwd = 64;          // the backward kernel (complex net only) is built for hidden size 64
 
 // tanh through the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each): 1 - 2 / (2^(2x log2 e) + 1), absolute
@@ -76,17 +77,17 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
         const int tt = t0 + s * dt, cur = s & 1;
         float nxt = 0.f;
         if (s + 1 < S) nxt = gxp[(long)(tt + dt) * stride_t];
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // four accumulation chains as two packed FMAs per float4 of h (v_pk_fma_f32: half the VALU issue slots of the
+        // scalar form; same chains, same rounding)
+        v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
         const float4* h4 = reinterpret_cast<const float4*>(h_s[cur]);
 #pragma unroll
         for (int k = 0; k < H / 4; ++k) {
             const float4 hv = h4[k];
-            a0 = fmaf(w[4 * k], hv.x, a0);
-            a1 = fmaf(w[4 * k + 1], hv.y, a1);
-            a2 = fmaf(w[4 * k + 2], hv.z, a2);
-            a3 = fmaf(w[4 * k + 3], hv.w, a3);
+            a01 = __builtin_elementwise_fma(v2f{w[4 * k], w[4 * k + 1]}, v2f{hv.x, hv.y}, a01);
+            a23 = __builtin_elementwise_fma(v2f{w[4 * k + 2], w[4 * k + 3]}, v2f{hv.z, hv.w}, a23);
         }
-        const float a = pre + ((a0 + a1) + (a2 + a3));
+        const float a = pre + ((a01.x + a01.y) + (a23.x + a23.y));
         const float th = fast_tanh(is_g ? a : 0.5f * a);
         const float act = is_g ? th : fmaf(0.5f, th, 0.5f);
         if (SAVE) gates_save[(((long)n * S + tt) * 2 + dir) * G4 + j] = act;
@@ -160,17 +161,15 @@ __global__ __launch_bounds__(4 * kHBwd) void lstm_rec_bwd_kernel(const float* __
         c = cp;                                                        // c_{t-1} of this step is c_t of the next one
         act = n_act; cp = n_cp; go = n_go;
         __syncthreads();
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
         const float4* g4 = reinterpret_cast<const float4*>(gp_s[cur] + gate * H);
 #pragma unroll
         for (int q = 0; q < H / 4; ++q) {
             const float4 gv = g4[q];
-            a0 = fmaf(w[4 * q], gv.x, a0);
-            a1 = fmaf(w[4 * q + 1], gv.y, a1);
-            a2 = fmaf(w[4 * q + 2], gv.z, a2);
-            a3 = fmaf(w[4 * q + 3], gv.w, a3);
+            a01 = __builtin_elementwise_fma(v2f{w[4 * q], w[4 * q + 1]}, v2f{gv.x, gv.y}, a01);
+            a23 = __builtin_elementwise_fma(v2f{w[4 * q + 2], w[4 * q + 3]}, v2f{gv.z, gv.w}, a23);
         }
-        gh_rec = quad_sum((a0 + a1) + (a2 + a3));
+        gh_rec = quad_sum((a01.x + a01.y) + (a23.x + a23.y));
     }
     if (g_bias_part) g_bias_part[(long)blockIdx.x * G4 + j] = sb;       // [n][dir][4H]
 }
