@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int TH = 16, TW = 16, KS = 7, TAPS = KS * KS;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct SArgs {
     conv::Args c;
@@ -48,9 +49,10 @@ __device__ __forceinline__ void wgrad_small_body(const SArgs& w, int bid, SmallL
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tiles_per_img = a.tiles_w * a.tiles_h;
 
-    float ar[TAPS][2], ai[TAPS][2];
+    // (re, im) accumulators; g conj(x) = x.re (g.re, g.im) + x.im (g.im, -g.re): two packed FMAs (v_pk_fma_f32) per MAC
+    v2f acc[TAPS][2];
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) { ar[tp][0] = ar[tp][1] = ai[tp][0] = ai[tp][1] = 0.f; }
+    for (int tp = 0; tp < TAPS; ++tp) { acc[tp][0] = v2f{0.f, 0.f}; acc[tp][1] = v2f{0.f, 0.f}; }
     float2 b0 = make_float2(0.f, 0.f), b1 = make_float2(0.f, 0.f);
 
     for (int tl = bid; tl < w.total_tiles; tl += w.n_slabs) {
@@ -81,22 +83,21 @@ __device__ __forceinline__ void wgrad_small_body(const SArgs& w, int bid, SmallL
             }
             b0.x += g0.x; b0.y += g0.y; b1.x += g1.x; b1.y += g1.y;
             const float2* base = tile + (py * S) * COLSP + pxx * S;
+            const v2f g0v = v2f{g0.x, g0.y}, g0r = v2f{g0.y, -g0.x}, g1v = v2f{g1.x, g1.y}, g1r = v2f{g1.y, -g1.x};
 #pragma unroll
             for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < KS; ++dx) {
                     const int tp = dy * KS + dx;
                     const float2 x0 = base[dy * COLSP + dx];
-                    // g * conj(x)
-                    ar[tp][0] = fmaf(g0.x, x0.x, fmaf(g0.y, x0.y, ar[tp][0]));
-                    ai[tp][0] = fmaf(g0.y, x0.x, fmaf(-g0.x, x0.y, ai[tp][0]));
+                    const v2f xx = v2f{x0.x, x0.x}, xy = v2f{x0.y, x0.y};
+                    acc[tp][0] = __builtin_elementwise_fma(xx, g0v, __builtin_elementwise_fma(xy, g0r, acc[tp][0]));
                     if (MODE == 0) {
                         const float2 x1 = base[PLANE + dy * COLSP + dx];
-                        ar[tp][1] = fmaf(g0.x, x1.x, fmaf(g0.y, x1.y, ar[tp][1]));
-                        ai[tp][1] = fmaf(g0.y, x1.x, fmaf(-g0.x, x1.y, ai[tp][1]));
+                        acc[tp][1] = __builtin_elementwise_fma(v2f{x1.x, x1.x}, g0v,
+                                                               __builtin_elementwise_fma(v2f{x1.y, x1.y}, g0r, acc[tp][1]));
                     } else {
-                        ar[tp][1] = fmaf(g1.x, x0.x, fmaf(g1.y, x0.y, ar[tp][1]));
-                        ai[tp][1] = fmaf(g1.y, x0.x, fmaf(-g1.x, x0.y, ai[tp][1]));
+                        acc[tp][1] = __builtin_elementwise_fma(xx, g1v, __builtin_elementwise_fma(xy, g1r, acc[tp][1]));
                     }
                 }
         }
@@ -109,7 +110,7 @@ __device__ __forceinline__ void wgrad_small_body(const SArgs& w, int bid, SmallL
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float sr = dcs_wave_sum_lane63(ar[tp][k]), si = dcs_wave_sum_lane63(ai[tp][k]);
+            const float sr = dcs_wave_sum_lane63(acc[tp][k].x), si = dcs_wave_sum_lane63(acc[tp][k].y);
             if (lane == 63) {
                 if (MODE == 0) red[wave][tp * 2 + k] = make_float2(sr, si);
                 else slab[tp * 8 + 2 * wave + k] = make_float2(sr, si);
