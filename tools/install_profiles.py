@@ -24,7 +24,7 @@ keys = ('cconv_', 'splitk_reduce', 'wgrad_reduce', 'tapsum', 'tap_rows_scatter',
 for mode, per in (('train', 27.0), ('infer', None)):
     rows = list(csv.DictReader(open(os.path.join(src, f'{mode}_kernel_stats.csv'))))
     if per is None:
-        per = sum(int(r['Calls']) for r in rows if 'cbn_apply' in r['Name']) / 14.0
+        per = float(sum(int(r['Calls']) for r in rows if 'bound_mask_apply_kernel' in r['Name']))      # one per pass
     t = sum(float(r['TotalDurationNs']) for r in rows if any(k in r['Name'] for k in keys)) / per / 1e6
     n = sum(int(r['Calls']) for r in rows if any(k in r['Name'] for k in keys)) / per
     tot = sum(float(r['TotalDurationNs']) for r in rows) / per / 1e6
