@@ -24,10 +24,14 @@ struct Cls {
 
 // Element (b, vy, vx, c) of the virtual input: nearest upsample of cat(x1, x2) (c_network.py:214-216),
 // or — for data gradients — g_Y with (up_f-1, up_t-1) zeros inserted between samples.  Zero outside.
+// (the factors are 1 or 2 on every path of the network: shifts / masks there, a real division only otherwise — this
+// runs per patch pixel per tile in the weight-gradient kernels)
+__device__ __forceinline__ int div_up(int v, int up) { return up == 1 ? v : (up == 2 ? v >> 1 : v / up); }
+__device__ __forceinline__ int mod_up(int v, int up) { return up == 1 ? 0 : (up == 2 ? (v & 1) : v % up); }
 __device__ __forceinline__ bool src_pixel(const Args& a, int b, int vy, int vx, long* sp) {
     if (vy < 0 || vy >= a.Hv || vx < 0 || vx >= a.Wv) return false;
-    if (a.zero_ins && ((vy % a.up_f) != 0 || (vx % a.up_t) != 0)) return false;
-    *sp = ((long)b * a.Hin + vy / a.up_f) * a.Win + vx / a.up_t;
+    if (a.zero_ins && (mod_up(vy, a.up_f) != 0 || mod_up(vx, a.up_t) != 0)) return false;
+    *sp = ((long)b * a.Hin + div_up(vy, a.up_f)) * a.Win + div_up(vx, a.up_t);
     return true;
 }
 

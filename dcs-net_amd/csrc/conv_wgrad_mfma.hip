@@ -27,6 +27,7 @@ struct WArgs {
     conv::Args c;
     const float* gy; float2* slab_w; float* slab_b;
     int n_slabs, total_tiles, co_blocks, TH, TW, twshift;
+    unsigned cols_magic;       // ceil(2^32 / c.cols): patch pixel index / cols by one multiply-high (patches are < 2^16 pixels)
     // output-parity classes of an upsample-folded conv (blockIdx.z): class pixel (oy, ox) is g_Y pixel
     // (oy*os_f + oo_f, ox*os_t + oo_t) and reads the SOURCE-resolution input with its own padding; one class = the
     // plain convolution (os = 1, oo = 0, pad = c.pad).  c.Hout / c.Wout: class-space extent (tiling);
@@ -381,6 +382,7 @@ int launch_classes(const conv::Args& c, const Fold& f, int Hy, int Wy, const flo
     w.c.tiles_h = (c.Hout + TH - 1) / TH;
     w.c.rows = (TH - 1) * c.sf + c.kh;
     w.c.cols = (TW - 1) * c.st + c.kw;
+    w.cols_magic = (unsigned)(((1ULL << 32) + w.c.cols - 1) / w.c.cols);
     w.total_tiles = w.c.tiles_w * w.c.tiles_h * c.B;
     w.ncls = f.ncls; w.os_f = f.os_f; w.os_t = f.os_t; w.Hy = Hy; w.Wy = Wy;
     for (int i = 0; i < 4; ++i) { w.pad_f[i] = f.pad_f[i]; w.pad_t[i] = f.pad_t[i]; w.oo_f[i] = f.oo_f[i]; w.oo_t[i] = f.oo_t[i]; }
