@@ -16,6 +16,7 @@
 #include "conv_common.h"
 #include "wgrad_reduce.h"
 
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_small_multi_kernel(SmallTa
     wgrad_sa_body(t.p[k], blockIdx.x - t.blk0[k], lds);
 }
 
-std::vector<SArgs>* g_small_deferred = nullptr;
+std::vector<SArgs>* g_small_deferred = nullptr;         // guarded by g_small_mutex: autograd records on its own thread
+std::mutex g_small_mutex;
 
 }  // namespace
 
@@ -272,6 +274,7 @@ int dcs_conv_wgrad_small_launch(const conv::Args& a, const float* gy, float2* sl
     if (a.C1 == 2)                                           // 16 x 64 tiles (wgrad_sa_body); idle workgroups write zero slabs
         w.total_tiles = ((a.Wout + STW - 1) / STW) * ((a.Hout + STH - 1) / STH) * a.B;
     if (a.C1 == 2 && wreduce::deferring()) {                 // recorded; dcs_conv_wgrad_small_flush launches the batch
+        std::lock_guard<std::mutex> lock(g_small_mutex);
         if (!g_small_deferred) g_small_deferred = new std::vector<SArgs>();
         g_small_deferred->push_back(w);
         return DCS_OK;
@@ -284,8 +287,12 @@ int dcs_conv_wgrad_small_launch(const conv::Args& a, const float* gy, float2* sl
 
 // launch every recorded 2 -> 1 problem (called by dcs_wgrad_defer_flush before the batched reduces)
 int dcs_conv_wgrad_small_flush(hipStream_t stream) {
-    std::vector<SArgs>* jobs = g_small_deferred;
-    g_small_deferred = nullptr;
+    std::vector<SArgs>* jobs;
+    {
+        std::lock_guard<std::mutex> lock(g_small_mutex);
+        jobs = g_small_deferred;
+        g_small_deferred = nullptr;
+    }
     if (!jobs) return DCS_OK;
     int rc = DCS_OK;
     for (size_t i0 = 0; i0 < jobs->size() && rc == DCS_OK; i0 += kSmallBatch) {
