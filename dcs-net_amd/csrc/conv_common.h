@@ -95,6 +95,10 @@ int dcs_conv_direct_multi(conv::Args* a, int n, hipStream_t stream);
 bool dcs_conv_k7_ok(const conv::Args* a, int n);
 int dcs_conv_k7_launch(const conv::Args* a, int n, hipStream_t stream);
 
+// conv_enc0.hip: the 1 -> 8 channel, 7x7, stride-2, pad-3 forward conv with the taps as the MFMA K axis
+bool dcs_conv_enc0_ok(const conv::Args& a);
+int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream);
+
 // conv_mfma.hip
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);
 // split-K scratch (bytes) the launch of this geometry would use; ws / ws_bytes below: that scratch (optional)

@@ -298,6 +298,7 @@ int launch_direct_multi(ConvArgs* a, int n, hipStream_t stream) {
 
 int launch_direct(ConvArgs& a, hipStream_t stream) {
     if (dcs_conv_k7_ok(&a, 1)) return dcs_conv_k7_launch(&a, 1, stream);        // the attention convs: conv_k7.hip
+    if (dcs_conv_enc0_ok(a)) return dcs_conv_enc0_launch(a, stream);            // the first encoder conv: conv_enc0.hip
     if (!conv_geometry(a)) return DCS_ERR_BADARG;
     const int Cin = a.C1 + a.C2;
     const size_t lds = (size_t)(Cin < CHUNK ? Cin : CHUNK) * a.plane * sizeof(float2);

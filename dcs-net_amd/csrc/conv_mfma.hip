@@ -56,10 +56,13 @@ struct MArgs {
 // activations to bf16 on their way into LDS (half the patch), the B panel holds bf16 fragments, and one
 // v_mfma_f32_32x32x16_bf16 covers what eight fp32 MFMAs cover (8 complex channels of one tap).  Measured in float
 // units the fragment addresses are the same as in the fp32 form: a 16-byte read per lane either way.
-template <int WAVES_N, int WM, int WN, int CH, bool BF>
+// TPI > 1 (shallow layers, CH = 8: only U = 2 k-groups per tap): the tap loop advances a whole kernel ROW of TPI = kw taps
+// per iteration — 8 MFMAs per iteration cannot carry the loop's scalar address arithmetic, its waitcnt drain and the
+// B-set copy (enc1 forward: 7 x 2 = 14 k-groups = 56 MFMAs per iteration instead of 8).
+template <int WAVES_N, int WM, int WN, int CH, bool BF, int TPI = 1>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
-    constexpr int U = BF ? CH / 8 : CH / 4, PIX = BF ? CH + 4 : 2 * CH + 4, Q = CH / 2;
+    constexpr int U = BF ? CH / 8 : CH / 4, VU = U * TPI, PIX = BF ? CH + 4 : 2 * CH + 4, Q = CH / 2;
     const conv::Args& a = m.c;
     const conv::Cls& k = m.cls[blockIdx.z];
     // pixels per workgroup = (4 / WAVES_N) * WM * 32 = TH * TW
@@ -104,8 +107,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     // fragment of (chunk c, tap tp, k-group g).  Always a load (past the end it re-reads the last chunk's fragment,
     // which nobody consumes): the tap loop body stays free of branches, so s_waitcnt counts stay exact instead of
     // draining to zero at every loop header.
-    auto bload = [&](float4* dst, int c, int tp, int g) {
-        if (tp >= ntaps) { tp = 0; ++c; }
+    // vg: k-group index inside an iteration = (tap offset vg / U, k-group vg % U)
+    auto bload = [&](float4* dst, int c, int tp, int vg) {
+        tp += vg / U;
+        const int g = vg % U;
+        if (tp >= ntaps) { tp -= ntaps; ++c; }
         c = c < n_chunks ? c : n_chunks - 1;
         const float* bp = bbase + tp * b_tap_stride + (long)(c * U + g) * b_kg_stride;
 #pragma unroll
@@ -115,10 +121,10 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     // this tap's k-groups (two per group) into a second set and moved over at the end of the tap.  The compiler drains
     // vmcnt to zero at every loop header (it cannot carry partial counts across the back edge): with the loads at the
     // front of the body that drain finds them >= U/2 groups (>= 512 MFMA cycles) old instead of just issued.
-    constexpr int LPG = U >= 2 ? 2 : 1;
-    float4 bcur[U][WN], bnxt[U][WN];
+    constexpr int LPG = VU >= 2 ? 2 : 1;
+    float4 bcur[VU][WN], bnxt[VU][WN];
 #pragma unroll
-    for (int g = 0; g < U; ++g) bload(bcur[g], c_begin, 0, g);
+    for (int g = 0; g < VU; ++g) bload(bcur[g], c_begin, 0, g);
 
     // source pixel (index into x1 / x2, or -1 for zero) of every patch pixel: the same for all channel chunks
     int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);
@@ -170,16 +176,16 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const float4*>(patch + pixoff[i]);
         int tapoff = 0;                                                // LDS float offset of the current tap
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int tap2 = tap + 1 < ntaps ? tap + 1 : tap;          // clamped: the last prefetch re-reads this tap
+        for (int tap = 0; tap < ntaps; tap += TPI) {
+            const int tap2 = tap + TPI < ntaps ? tap + TPI : tap;      // clamped: the last prefetch re-reads this tap
             const int tapoff2 = ((tap2 / k.kw) * cols + (tap2 % k.kw)) * PIX;
 #pragma unroll
-            for (int g = 0; g < U; ++g) {
-                // A fragments of the next iteration into the other register set
+            for (int g = 0; g < VU; ++g) {
+                // A fragments of the next iteration into the other register set (taps of a row are adjacent patch columns)
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
                     af[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(
-                        patch + pixoff[i] + (g + 1 < U ? tapoff + (g + 1) * 8 : tapoff2));
+                        patch + pixoff[i] + (g + 1 < VU ? tapoff + ((g + 1) / U) * PIX + ((g + 1) % U) * 8 : tapoff2));
                 // MFMAs straight from the ring slot ...
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
@@ -198,17 +204,18 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     }
                 // next tap's fragments (scheduling barriers pin the loads here, ahead of the remaining MFMA groups)
                 __builtin_amdgcn_sched_barrier(0);
-                if (g * LPG < U) {
+                if (g * LPG < VU) {
 #pragma unroll
-                    for (int q = 0; q < LPG; ++q) bload(bnxt[g * LPG + q], ch, tap + 1, g * LPG + q);
+                    for (int q = 0; q < LPG; ++q)
+                        if (g * LPG + q < VU) bload(bnxt[g * LPG + q], ch, tap + TPI, g * LPG + q);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int g = 0; g < U; ++g)
+            for (int g = 0; g < VU; ++g)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) bcur[g][j] = bnxt[g][j];
-            if (U & 1) {                                               // odd U (bf16, CH = 8): the prefetch landed in set 1
+            if (VU & 1) {                                               // odd U (bf16, CH = 8): the prefetch landed in set 1
 #pragma unroll
                 for (int i = 0; i < WM; ++i) af[0][i] = af[1][i];
             }
@@ -444,17 +451,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 struct Plan { int cand, TH, TW, CH, S, cps; long blocks; };
 thread_local bool g_force_wide_panel = false;
 
-template <int WAVES_N, int WM, int WN, int CH, bool BF>
-int launch_bf(MArgs& m, long npix, hipStream_t stream) {
+template <int WAVES_N, int WM, int WN, int CH, bool BF, int TPI>
+int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
     const size_t lds = (size_t)npix * ((BF ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
-    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, BF>;
+    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, BF, TPI>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+template <int WAVES_N, int WM, int WN, int CH, bool BF>
+int launch_bf(MArgs& m, long npix, hipStream_t stream) {
+    // whole kernel rows per tap-loop iteration for the shallow fp32 layers (one class, 7-wide kernel, 128 x 32 tile)
+    if (!BF && CH == 8 && WM == 1 && WN == 1 && m.ncls == 1 && m.cls[0].kw == 7 && (m.cls[0].kh * m.cls[0].kw) % 7 == 0)
+        return launch_tpi<WAVES_N, WM, WN, CH, BF, (!BF && CH == 8 && WM == 1 && WN == 1) ? 7 : 1>(m, npix, stream);
+    return launch_tpi<WAVES_N, WM, WN, CH, BF, 1>(m, npix, stream);
 }
 
 template <int WAVES_N, int WM, int WN, int CH>

@@ -205,7 +205,9 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     ws = _workspace(nbytes, x1.device) if nbytes > 0 else None
     nbytes = max(nbytes, 0)
     # bench.py's live roofline probe: 8 real flops per complex MAC
-    ev = CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw) if CONV_TIMER is not None else None
+    # (strided forward convs are exactly the encoder's ComplexConv2d stack: tagged for bench.py's encoder roofline)
+    ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None)
+          if CONV_TIMER is not None else None)
     if coef is not None:
         _chk(coef, 'coef', 2)
         if tuple(coef.shape) != (Cout, 6):

@@ -69,6 +69,28 @@ def test_complex_conv2d_encoder_geometries(dev, cin, cout, k, stride):
     close(back(y), want)
 
 
+@pytest.mark.parametrize('H,W', [(257, 96), (35, 131), (15, 7)])
+def test_first_encoder_conv_on_the_mfma_units(dev, H, W):
+    """conv_enc0.hip (taps as the MFMA K axis): whole and ragged 8 x 32 tiles, plain and with the folded eval-mode
+    CBN + ReLU epilogue of the inference path (c_network.py:107-112)."""
+    from dcsnet import functional as F
+    torch.manual_seed(H + W)
+    m = cpt.ComplexConv2d(1, 8, 7, (2, 2), 3)
+    x = rand_c((3, 1, H, W), 21)
+    want = m(x)
+    p = lambda t: t.detach().to(dev)
+    args = (nhwc(x, dev), None, p(m.conv_r.weight), p(m.conv_i.weight), p(m.conv_r.bias), p(m.conv_i.bias), False,
+            (7, 7), (2, 2), (3, 3))
+    close(back(F.cconv2d(*args)), want)
+    coef = torch.randn(8, 6) * 0.5
+    a = coef.view(1, 8, 6, 1, 1)
+    re, im = want.real, want.imag
+    aff = torch.complex(torch.relu(a[:, :, 0] * re + a[:, :, 1] * im + a[:, :, 4]),
+                        torch.relu(a[:, :, 2] * re + a[:, :, 3] * im + a[:, :, 5]))
+    y = F.cconv2d_cbn_eval(*args, (1, 1), coef.to(dev), F.ACT_RELU)
+    close(back(y), aff, rel=4e-5)
+
+
 @pytest.mark.parametrize('c1,c2,cout,up', [(128, 128, 128, (2, 1)), (32, 32, 16, (2, 2)), (8, 8, 1, (2, 2)),
                                             (16, 0, 8, (1, 1))])
 def test_complex_convtranspose_with_fused_cat_upsample(dev, c1, c2, cout, up):
