@@ -4,66 +4,112 @@
 // With ONE input channel the implicit GEMM of conv_mfma.hip has nothing to contract over per tap (K = 2), so the layer ran
 // on the VALU kernel of conv_direct.hip (29-47 TFLOP/s).  Here the 49 taps ARE the K axis:
 //     D[p][(co, re|im)] = sum_{tap, part} A[p][(tap, part)] B[(tap, part)][(co, re|im)],   K = 49 x 2 = 98 (padded to 100), N = 16
-//   A[p][(tap, re|im)] = x_{re|im}[2 p + tap - pad]          read straight from the LDS input patch (ds_read_b32; the four
-//                                                            k of a step are two adjacent taps x (re, im): 64 distinct banks)
-//   B                  = the 2x2 real embedding of the 49 x 8 complex weights: 25 fragments of one float per lane, held in
+//   A[p][(tap, re|im)] = x_{re|im}[2 p + tap - pad]          read straight from the LDS input patch: the four k of a step are
+//                                                            four consecutive taps, a lane reads its tap's (re, im) with ONE
+//                                                            ds_read_b64 and feeds two MFMAs (re step, im step)
+//   B                  = the 2x2 real embedding of the 49 x 8 complex weights: 26 fragments of one float per lane, held in
 //                        REGISTERS for the whole workgroup (built from the direct panel at kernel start)
-// v_mfma_f32_16x16x4_f32: 16 pixels x 16 columns x 4 k per instruction, 25 per 16-pixel tile: 98 % of the issued MACs
-// are useful.  A workgroup = 8 x 32 output pixels (16 M-tiles, four per wave) over a 21 x 69 input patch (11.6 KB).
+// v_mfma_f32_16x16x4_f32: 16 pixels x 16 columns x 4 k per instruction, 26 per 16-pixel tile (taps padded to 52): 94 % of
+// the issued MACs are useful.  Two M-tiles run interleaved (independent accumulators, LDS latency).  A tile = 8 x 32 output pixels (16 M-tiles, four per wave) over a 21 x 69 input patch (11.6 KB); workgroups are
+// persistent and load the next tile's patch under the current tile's MFMAs.
 // Epilogue as everywhere: bias, optional folded eval-mode CBN (conv_common.h), activation; 64-byte rows per pixel.
 #include "conv_common.h"
 
 namespace {
 
-constexpr int K7 = 7, TAPS = 49, KSTEPS = 25, TR = 8, TC = 32, PR = (TR - 1) * 2 + K7, PC = (TC - 1) * 2 + K7, PCP = PC + 1;
+constexpr int K7 = 7, TAPS = 49, KGRP = 13, KSTEPS = 2 * KGRP, TR = 8, TC = 32, PR = (TR - 1) * 2 + K7, PC = (TC - 1) * 2 + K7, PCP = PC + 1;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// patch offset (in complex elements) of tap t relative to a pixel's window origin
-__host__ __device__ constexpr int tap_off(int t) { return (t / K7) * PCP + (t % K7); }
 
-__global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a) {
-    __shared__ float2 patch[PR * PCP];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int li = lane & 15, kg = lane >> 4;
-    const int b = blockIdx.y;
-    const int oy0 = ((int)blockIdx.x / a.tiles_w) * TR, ox0 = ((int)blockIdx.x % a.tiles_w) * TC;
+// One haloed input patch element per (thread, k): element i = t + 256 k of patch[r][c] = x[b][2 oy0 - 3 + r][2 ox0 - 3 + c],
+// r = i / PC.  The six rows of a thread are tile-invariant: packed 5 bits each in `rows` once per workgroup, so a tile
+// costs no divisions; a patch that lies wholly inside the image (the common case) loads without bounds checks.
+constexpr int NL = (PR * PC + 255) / 256;
+// tile -> (image b, tile row, tile column) with float reciprocals (exact for tile < 2^22: the launch checks), instead of
+// two emulated integer divisions per use
+struct TileDiv { float inv_per, inv_w; int per, tiles_w; };
+__device__ __forceinline__ void tile_split(const TileDiv& d, int tile, int* b, int* ty, int* tx) {
+    *b = (int)(((float)tile + 0.5f) * d.inv_per);
+    const int tl = tile - *b * d.per;
+    *ty = (int)(((float)tl + 0.5f) * d.inv_w);
+    *tx = tl - *ty * d.tiles_w;
+}
+__device__ __forceinline__ int row_of(int rows, int k) { return (rows >> (5 * k)) & 31; }
 
-    // B fragments: lane (col n = li, k = 4 s + kg) of step s; k -> (tap = k >> 1, part = k & 1)
-    float bf[KSTEPS];
-    {
-        const int co = li >> 1, im = li & 1, part = kg & 1;
+__device__ __forceinline__ void patch_load(const conv::Args& a, const TileDiv& d, int tile, int t, int rows, float2* pv) {
+    int b, ty, tx;
+    tile_split(d, tile, &b, &ty, &tx);
+    const int y0 = ty * (2 * TR) - 3, x0 = tx * (2 * TC) - 3;
+    const float2* xb = a.x1 + (long)b * a.Hin * a.Win;
+    if (y0 >= 0 && y0 + PR <= a.Hin && x0 >= 0 && x0 + PC <= a.Win) {                 // (uniform)
+        const float2* org = xb + (long)y0 * a.Win + x0;
+        const int skip = a.Win - PC;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int tap = 2 * s + (kg >> 1);
-            float v = 0.f;
-            if (tap < TAPS) {
-                const float2 w = a.wp[tap * a.Cout + co];                  // direct panel complex[tap][ci = 0][co]
-                v = part == 0 ? (im ? w.y : w.x) : (im ? w.x : -w.y);     // (re: w_r, -w_i ; im: w_i, w_r)
-            }
-            bf[s] = v;
+        for (int k = 0; k < NL; ++k) {
+            const int i = t + 256 * k;
+            if (k < NL - 1 || i < PR * PC) pv[k] = org[i + row_of(rows, k) * skip];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = t + 256 * k, r = row_of(rows, k), c = i - r * PC;
+            const int y = y0 + r, x = x0 + c;
+            pv[k] = (i < PR * PC && y >= 0 && y < a.Hin && x >= 0 && x < a.Win) ? xb[(long)y * a.Win + x] : make_float2(0.f, 0.f);
         }
     }
-    // input patch (single channel): patch[r][c] = x[b][2 oy0 - 3 + r][2 ox0 - 3 + c]
-    const float2* xb = a.x1 + (long)b * a.Hin * a.Win;
-    // (all of a thread's loads are issued before its first LDS write: a load -> wait -> write loop pays one memory
-    //  round trip per element)
-    constexpr int NL = (PR * PC + 255) / 256;
-    float2 pv_[NL];
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-        const int i = t + 256 * k, r = i / PC, c = i % PC;
-        const int y = 2 * oy0 - a.pad_f + r, x = 2 * ox0 - a.pad_t + c;
-        pv_[k] = (i < PR * PC && y >= 0 && y < a.Hin && x >= 0 && x < a.Win) ? xb[(long)y * a.Win + x] : make_float2(0.f, 0.f);
-    }
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-        const int i = t + 256 * k, r = i / PC, c = i % PC;
-        if (i < PR * PC) patch[r * PCP + c] = pv_[k];
-    }
-    __syncthreads();
+}
 
-    const float* pf = reinterpret_cast<const float*>(patch);
-    const int part = kg & 1, odd = kg >> 1;
+// bias, folded eval-mode CBN, activation and store of one lane's 2 x 4 accumulators (M-tiles h = 0, 1; rows kg*4 + r)
+template <int ACT, bool CHECK>
+__device__ __forceinline__ void store_pair(const conv::Args& a, const f32x4v* acc, float* yp, int ox, float bv, float c_re,
+                                           float c_im, float c_add, int li) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[h][r] + bv;
+            if (a.coef) {
+                const float pv = dcs_dpp_term<0xB1, 0xf>(v);
+                v = (li & 1) ? fmaf(c_re, pv, fmaf(c_im, v, c_add)) : fmaf(c_re, v, fmaf(c_im, pv, c_add));
+            }
+            v = ACT < 0 ? dcs_act(v, a.act) : dcs_act(v, ACT);
+            if (!CHECK || ox + h * 16 + r < a.Wout) yp[(h * 16 + r) * 16] = v;
+        }
+}
+
+// Persistent workgroups: tile = blockIdx.x, += gridDim.x.  The NEXT tile's patch is loaded into registers while this
+// tile's MFMAs run (two LDS buffers, one barrier per tile), the B fragments are built once per workgroup.
+// ACT: the activation at compile time, or -1 for a.act at run time.
+template <int ACT>
+__global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d, int ntile) {
+    __shared__ float2 patch[2][PR * PCP];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    int tile = blockIdx.x;
+    if (tile >= ntile) return;
+    int rows = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) rows |= ((t + 256 * k) / PC) << (5 * k);
+    float2 pv_[NL];
+    patch_load(a, d, tile, t, rows, pv_);
+
+    // K order: step 2j = (tap 4j + kg, re), step 2j + 1 = (tap 4j + kg, im); taps 49..51 are zero padding.
+    // B fragments of column n = li (co = li >> 1, re | im = li & 1), and this lane's tap offsets into a pixel window (floats)
+    float bf[KSTEPS];
+    int toff[KGRP];
+    {
+        const int co = li >> 1, im = li & 1;
+#pragma unroll
+        for (int j = 0; j < KGRP; ++j) {
+            const int tap = 4 * j + kg;
+            float2 w = make_float2(0.f, 0.f);
+            if (tap < TAPS) w = a.wp[tap * a.Cout + co];                   // direct panel complex[tap][ci = 0][co]
+            bf[2 * j] = im ? w.y : w.x;                                    // x_re: (w_r -> re, w_i -> im)
+            bf[2 * j + 1] = im ? w.x : -w.y;                               // x_im: (-w_i -> re, w_r -> im)
+            const int tc = tap < TAPS ? tap : TAPS - 1;                    // padding taps: any in-range address (B is 0 there)
+            toff[j] = ((tc / K7) * PCP + (tc % K7)) * 2;
+        }
+    }
     const float* biasf = reinterpret_cast<const float*>(a.bias);
     const float bv = biasf ? biasf[li] : 0.f;
     float c_re = 1.f, c_im = 0.f, c_add = 0.f;                            // folded eval-mode CBN (conv_mfma.hip)
@@ -71,31 +117,57 @@ __global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a) {
         const float* q = a.coef + 6 * (li >> 1);
         if (li & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
     }
+    int buf = 0;
 #pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
-        const int mt = wave * 4 + i;                                       // 16 M-tiles: row mt / 2, 16 columns each
-        const int py = mt >> 1, px = (mt & 1) * 16 + li;
-        const float* base = pf + ((py * 2) * PCP + px * 2) * 2 + part;     // this lane's pixel window, its re or im plane
-        f32x4v acc = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (; tile < ntile; tile += gridDim.x, buf ^= 1) {
+        // (buffer `buf` was last read two tiles ago, and every wave passed the barrier of the tile in between since)
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            // taps 2s (kg 0,1) and 2s+1 (kg 2,3); tap 49 (step 24, odd) is the zero pad: any in-range address, B is 0 there
-            const int o0 = tap_off(2 * s), o1 = tap_off(2 * s + 1 < TAPS ? 2 * s + 1 : 2 * s);
-            const float av = base[(odd ? o1 : o0) * 2];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[s], acc, 0, 0, 0);
+        for (int k = 0; k < NL; ++k) {
+            const int i = t + 256 * k;
+            if (k < NL - 1 || i < PR * PC) patch[buf][i + row_of(rows, k)] = pv_[k];         // r PCP + c = i + r
         }
-        // C/D: col = li, rows kg*4 + r -> pixel (py, (mt & 1) * 16 + kg*4 + r)
-        const int oy = oy0 + py;
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntile) patch_load(a, d, tile + gridDim.x, t, rows, pv_);
+        int b, ty, tx;
+        tile_split(d, tile, &b, &ty, &tx);
+        const int oy0 = ty * TR, ox0 = tx * TC;
+        const float* pf = reinterpret_cast<const float*>(patch[buf]);
+#pragma unroll 1
+        for (int i = 0; i < 4; i += 2) {
+            const int mt = wave * 4 + i;                                   // 16 M-tiles: row mt / 2, 16 columns each;
+            const int py = mt >> 1;                                        // mt (columns 0-15) and mt + 1 (16-31) share a row
+            const float* base = pf + ((py * 2) * PCP + li * 2) * 2;        // this lane's pixel window in M-tile mt
+            f32x4v acc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+            // A reads run PF tap groups ahead of the MFMAs that consume them (ring of registers, constant indices after
+            // unrolling): left to itself the compiler re-uses one register quad and waits out every LDS round trip
+            constexpr int PF = 3;
+            float2 va[PF][2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ox = ox0 + (mt & 1) * 16 + kg * 4 + r;
-            float v = acc[r] + bv;
-            if (a.coef) {
-                const float pv = dcs_dpp_term<0xB1, 0xf>(v);
-                v = (li & 1) ? fmaf(c_re, pv, fmaf(c_im, v, c_add)) : fmaf(c_re, v, fmaf(c_im, pv, c_add));
+            for (int j = 0; j < PF; ++j) {
+                va[j][0] = *reinterpret_cast<const float2*>(base + toff[j]);
+                va[j][1] = *reinterpret_cast<const float2*>(base + toff[j] + 16 * 2 * 2);
             }
-            if (oy < a.Hout && ox < a.Wout)
-                reinterpret_cast<float*>(a.y)[(((long)b * a.Hout + oy) * a.Wout + ox) * 16 + li] = dcs_act(v, a.act);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < KGRP; ++j) {
+                const float2 v0 = va[j % PF][0], v1 = va[j % PF][1];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.x, bf[2 * j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.x, bf[2 * j], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.y, bf[2 * j + 1], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.y, bf[2 * j + 1], acc[1], 0, 0, 0);
+                if (j + PF < KGRP) {
+                    va[j % PF][0] = *reinterpret_cast<const float2*>(base + toff[j + PF]);
+                    va[j % PF][1] = *reinterpret_cast<const float2*>(base + toff[j + PF] + 16 * 2 * 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);          // (keeps the read where it is written: the scheduler sinks it to its use)
+            }
+            // C/D: col = li, rows kg*4 + r -> pixel (oy0 + py, ox0 + h*16 + kg*4 + r); one row pointer, constant offsets
+            const int oy = oy0 + py;
+            if (oy < a.Hout) {
+                float* yp = reinterpret_cast<float*>(a.y) + (((long)b * a.Hout + oy) * a.Wout + ox0 + kg * 4) * 16 + li;
+                if (ox0 + TC <= a.Wout) store_pair<ACT, false>(a, acc, yp, 0, bv, c_re, c_im, c_add, li);
+                else store_pair<ACT, true>(a, acc, yp, ox0 + kg * 4, bv, c_re, c_im, c_add, li);
+            }
         }
     }
 }
@@ -104,7 +176,8 @@ __global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a) {
 
 bool dcs_conv_enc0_ok(const conv::Args& a) {
     return a.C1 == 1 && a.C2 == 0 && a.Cout == 8 && a.kh == K7 && a.kw == K7 && a.sf == 2 && a.st == 2 && a.pad_f == 3 &&
-           a.pad_t == 3 && a.up_f == 1 && a.up_t == 1 && !a.zero_ins && a.x1 && a.wp && a.y && a.B <= 65535;
+           a.pad_t == 3 && a.up_f == 1 && a.up_t == 1 && !a.zero_ins && a.x1 && a.wp && a.y &&
+           (long)a.B * ((a.Hin / 2 + TR) / TR) * ((a.Win / 2 + TC) / TC) < (1L << 22);
 }
 
 int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream) {
@@ -113,7 +186,21 @@ int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream) {
     a.Wout = (a.Win + 2 * a.pad_t - K7) / 2 + 1;
     a.tiles_w = (a.Wout + TC - 1) / TC;
     a.tiles_h = (a.Hout + TR - 1) / TR;
-    hipLaunchKernelGGL(cconv_enc0_kernel, dim3(a.tiles_w * a.tiles_h, a.B), dim3(256), 0, stream, a);
+    const long ntile = (long)a.tiles_w * a.tiles_h * a.B;
+    if (ntile >= (1L << 22)) return DCS_ERR_BADARG;          // (tile_split's float reciprocals)
+    TileDiv d;
+    d.per = a.tiles_w * a.tiles_h; d.tiles_w = a.tiles_w; d.inv_per = 1.f / (float)d.per; d.inv_w = 1.f / (float)d.tiles_w;
+    static int resident = 0;                                // workgroups the device holds at once (4 / CU: 120 VGPRs)
+    if (!resident) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return DCS_ERR_LAUNCH;
+        resident = cus * 4;
+    }
+    const int grid = ntile < resident ? (int)ntile : resident;
+    if (a.act == DCS_ACT_NONE) hipLaunchKernelGGL(cconv_enc0_kernel<DCS_ACT_NONE>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
+    else if (a.act == DCS_ACT_RELU) hipLaunchKernelGGL(cconv_enc0_kernel<DCS_ACT_RELU>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
+    else hipLaunchKernelGGL(cconv_enc0_kernel<-1>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
