@@ -98,6 +98,9 @@ int dcs_conv_k7_launch(const conv::Args* a, int n, hipStream_t stream);
 // conv_enc0.hip: the 1 -> 8 channel, 7x7, stride-2, pad-3 forward conv with the taps as the MFMA K axis
 bool dcs_conv_enc0_ok(const conv::Args& a);
 int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream);
+bool dcs_conv_enc0_wgrad_ok(const conv::Args& a);
+int dcs_conv_enc0_wgrad_launch(conv::Args a, const float* gy, float2* slab_w, float2* slab_b, int max_slabs, int* n_used,
+                               hipStream_t stream);
 
 // conv_mfma.hip
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);

@@ -706,6 +706,14 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     w.slab_b = w.slab_w + (long)w.n_slabs * wsz;
     w.total_tiles = w.c.tiles_w * w.c.tiles_h * B;
     const int Cin = C1 + C2;
+    w.c.x1 = (const float2*)x1;
+    if (dcs_conv_enc0_wgrad_ok(w.c)) {           // 7x7 1->8 stride 2: taps x pixels on the MFMA units (conv_enc0.hip)
+        hipStream_t s = dcs_stream(stream);
+        int ns = 0;
+        const int rc = dcs_conv_enc0_wgrad_launch(w.c, gy, w.slab_w, w.slab_b, w.n_slabs, &ns, s);
+        if (rc != DCS_OK) return rc;
+        return launch_wgrad_reduce(w.slab_w, w.slab_b, ns, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed, s);
+    }
     if (dcs_conv_wgrad_small_ok(w.c)) {          // 7x7 2->1 / 1->8: pixel-stationary kernel (conv_wgrad_small.hip)
         hipStream_t s = dcs_stream(stream);
         // two resident workgroups per CU.  The 2 -> 1 attention convs run batched (13 problems in one launch inside a

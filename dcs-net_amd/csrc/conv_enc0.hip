@@ -172,11 +172,127 @@ __global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d
     }
 }
 
+
+// ---- weight gradient of the same layer on the MFMA units --------------------------------------------------------------
+// g_W[tap][co] = sum_p g_Y[p][co] conj(X[2p - 3 + tap]) as D[(tap, re|im)][(co, re|im)] = sum_p A[(tap, part)][p] B[p][(co, q)]:
+//   M = 98 rows (+ row 98: A = 1, the bias gradient; rows 99..111 zero) in 7 M-tiles, N = 16, K = pixels, 4 per instruction;
+//   A from the same LDS input patch as the forward pass (ds_read_b32, one per MFMA, read one pixel quad ahead),
+//   B = g_Y straight from HBM (a wave's quad = 256 contiguous bytes), 16 quads per wave per tile loaded up front.
+// Persistent workgroups keep the 7 x 4 accumulators across their tiles and write ONE partial slab each (the slab layout
+// and reduce kernel of the other weight-gradient paths):  G.re = D[(t,re)][(c,re)] + D[(t,im)][(c,im)],
+// G.im = D[(t,re)][(c,im)] - D[(t,im)][(c,re)].
+constexpr int MT = 7, QPW = 16;                              // M-tiles; pixel quads per wave per tile (2 rows x 8)
+constexpr int RED_FLOATS = 3 * MT * 4 * 64, DL_FLOATS = MT * 16 * 16;
+constexpr int WG_SMEM = (RED_FLOATS + DL_FLOATS) * 4 > 2 * PR * PCP * 8 ? (RED_FLOATS + DL_FLOATS) * 4 : 2 * PR * PCP * 8;
+
+__global__ __launch_bounds__(256) void cconv_enc0_wgrad_kernel(conv::Args a, TileDiv d, int ntile, const float* __restrict__ gy,
+                                                               float2* __restrict__ slab_w, float2* __restrict__ slab_b) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_SMEM];
+    float2 (*patch)[PR * PCP] = reinterpret_cast<float2 (*)[PR * PCP]>(smem);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    int rows = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) rows |= ((t + 256 * k) / PC) << (5 * k);
+    // this lane's A row in M-tile m: R = 16 m + li -> (tap = R >> 1, part = R & 1); float offset into a pixel window
+    int toff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int tap = 8 * m + (li >> 1), tc = tap < TAPS ? tap : TAPS - 1;
+        toff[m] = ((tc / K7) * PCP + (tc % K7)) * 2 + (li & 1);
+    }
+    const float a6 = li == 2 ? 1.f : 0.f;                    // M-tile 6: rows 96, 97 = tap 48; 98 = ones (bias); above: zero
+    f32x4v acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    int tile = blockIdx.x, buf = 0;
+    float2 pv_[NL];
+    if (tile < ntile) patch_load(a, d, tile, t, rows, pv_);
+#pragma unroll 1
+    for (; tile < ntile; tile += gridDim.x, buf ^= 1) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = t + 256 * k;
+            if (k < NL - 1 || i < PR * PC) patch[buf][i + row_of(rows, k)] = pv_[k];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntile) patch_load(a, d, tile + gridDim.x, t, rows, pv_);
+        int b, ty, tx;
+        tile_split(d, tile, &b, &ty, &tx);
+        const int oy0 = ty * TR + 2 * wave, ox0 = tx * TC + kg;            // this wave's two rows; this lane's pixel in a quad
+        // g_Y of the wave's 16 quads: quad q = row (q >> 3), columns (q & 7) * 4 + kg
+        float gv[QPW];
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) {
+            const int oy = oy0 + (q >> 3), ox = ox0 + (q & 7) * 4;
+            gv[q] = (oy < a.Hout && ox < a.Wout) ? gy[(((long)b * a.Hout + oy) * a.Wout + ox) * 16 + li] : 0.f;
+        }
+        // lane's window origin for quad 0: pixel (2 wave, kg); quad q adds a compile-time offset
+        const float* base = reinterpret_cast<const float*>(patch[buf]) + ((4 * wave) * PCP + 2 * kg) * 2;
+        const float* am[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) am[m] = base + toff[m];
+        float av[2][MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[0][m] = am[m][0];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) {
+            if (q + 1 < QPW) {
+                const int qo = (((q + 1) >> 3) * 2 * PCP + ((q + 1) & 7) * 8) * 2;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[(q + 1) & 1][m] = am[m][qo];
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float x = av[q & 1][m];
+                if (m == MT - 1) x = li < 2 ? x : a6;
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, gv[q], acc[m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);               // (keeps the read-ahead where it is written)
+        }
+    }
+    // workgroup total: waves 1..3 through LDS into wave 0, D rows to LDS, then the complex combination
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    float* Dl = red + RED_FLOATS;
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave - 1) * MT * 4 + m * 4 + r) * 64 + lane] = acc[m][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[m][r];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += red[(w * MT * 4 + m * 4 + r) * 64 + lane];
+                Dl[(16 * m + kg * 4 + r) * 16 + li] = v;                   // C/D: col = li, row = kg*4 + r
+            }
+    }
+    __syncthreads();
+    float2* slab = slab_w + (long)blockIdx.x * (TAPS * 8);
+    for (int i = t; i < TAPS * 8; i += 256) {
+        const int tap = i >> 3, co = i & 7;
+        const float* d0 = Dl + (2 * tap) * 16 + 2 * co;                    // row (tap, re): cols (co, re), (co, im)
+        const float* d1 = d0 + 16;                                         // row (tap, im)
+        slab[i] = make_float2(d0[0] + d1[1], d0[1] - d1[0]);
+    }
+    if (t < 8) slab_b[(long)blockIdx.x * 8 + t] = make_float2(Dl[98 * 16 + 2 * t], Dl[98 * 16 + 2 * t + 1]);
+}
+
 }  // namespace
 
-bool dcs_conv_enc0_ok(const conv::Args& a) {
+static bool enc0_geom(const conv::Args& a);
+bool dcs_conv_enc0_ok(const conv::Args& a) { return enc0_geom(a) && a.x1 && a.wp && a.y; }
+static bool enc0_geom(const conv::Args& a) {
     return a.C1 == 1 && a.C2 == 0 && a.Cout == 8 && a.kh == K7 && a.kw == K7 && a.sf == 2 && a.st == 2 && a.pad_f == 3 &&
-           a.pad_t == 3 && a.up_f == 1 && a.up_t == 1 && !a.zero_ins && a.x1 && a.wp && a.y &&
+           a.pad_t == 3 && a.up_f == 1 && a.up_t == 1 && !a.zero_ins &&
            (long)a.B * ((a.Hin / 2 + TR) / TR) * ((a.Win / 2 + TC) / TC) < (1L << 22);
 }
 
@@ -202,5 +318,31 @@ int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream) {
     else if (a.act == DCS_ACT_RELU) hipLaunchKernelGGL(cconv_enc0_kernel<DCS_ACT_RELU>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
     else hipLaunchKernelGGL(cconv_enc0_kernel<-1>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
     DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// Weight gradient (forward geometry `a`, x1 set): at most max_slabs partial slabs float2[49][8] (+ float2[8] bias) are
+// written, *n_used says how many; the caller reduces them (launch_wgrad_reduce of conv_direct.hip).
+bool dcs_conv_enc0_wgrad_ok(const conv::Args& a) { return enc0_geom(a) && a.x1; }
+int dcs_conv_enc0_wgrad_launch(conv::Args a, const float* gy, float2* slab_w, float2* slab_b, int max_slabs, int* n_used,
+                               hipStream_t stream) {
+    if (!dcs_conv_enc0_wgrad_ok(a) || !gy || !slab_w || !slab_b || max_slabs < 1) return DCS_ERR_BADARG;
+    a.Hout = (a.Hin + 2 * a.pad_f - K7) / 2 + 1;
+    a.Wout = (a.Win + 2 * a.pad_t - K7) / 2 + 1;
+    a.tiles_w = (a.Wout + TC - 1) / TC;
+    a.tiles_h = (a.Hout + TR - 1) / TR;
+    const long ntile = (long)a.tiles_w * a.tiles_h * a.B;
+    if (ntile >= (1L << 22)) return DCS_ERR_BADARG;
+    TileDiv d;
+    d.per = a.tiles_w * a.tiles_h; d.tiles_w = a.tiles_w; d.inv_per = 1.f / (float)d.per; d.inv_w = 1.f / (float)d.tiles_w;
+    int grid = max_slabs < 1024 ? max_slabs : 1024;
+    if (ntile < grid) grid = (int)ntile;
+    // equal rounds: with R = ceil(ntile / grid) tiles per workgroup, ceil(ntile / R) workgroups do the same work in the same
+    // time and leave fewer slabs to reduce
+    const int rounds = (int)((ntile + grid - 1) / grid);
+    grid = (int)((ntile + rounds - 1) / rounds);
+    hipLaunchKernelGGL(cconv_enc0_wgrad_kernel, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, gy, slab_w, slab_b);
+    DCS_CHECK_LAUNCH();
+    *n_used = grid;
     return DCS_OK;
 }

@@ -14,6 +14,7 @@ utterances per GPU every rank reproduces the reference's batch-32 semantics (con
   TrainStep       zero-grad -> loss.backward() -> all-reduce -> device-side global norm ->
                   dcs_adam_amsgrad_step (averaging + clip + Adam/AMSGrad in one HIP launch)
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -194,6 +195,9 @@ class TrainStep:
             loss.backward()
             return
         from . import ops
+        if os.environ.get('DCS_WGRAD_DEFER', '1') == '0':       # profiling aid: every reduction as its own kernel
+            loss.backward()
+            return
         ops.wgrad_defer_begin()
         try:
             loss.backward()

@@ -65,7 +65,7 @@ def dev_params(mod, dev):
 
 # --------------------------------------------------------------------------------- convolution
 
-@pytest.mark.parametrize('cin,cout,k,stride,hw', [(1, 8, 7, (2, 2), (40, 36)), (8, 16, 7, (2, 2), (20, 24)),
+@pytest.mark.parametrize('cin,cout,k,stride,hw', [(1, 8, 7, (2, 2), (40, 36)), (1, 8, 7, (2, 2), (75, 134)), (8, 16, 7, (2, 2), (20, 24)),
                                                    (16, 32, 5, (2, 1), (12, 9)), (64, 128, 3, (2, 1), (8, 16)),
                                                    (4, 2, 3, (1, 2), (19, 9))])
 def test_conv2d_backward(dev, cin, cout, k, stride, hw):
