@@ -188,3 +188,23 @@ def test_crop_batch_follows_the_dataset_rule():
     assert torch.equal(c[2], torch.arange(64.))
     with pytest.raises(Exception):
         crop_batch([torch.zeros(10)], [torch.zeros(11)], 8)
+
+
+def test_tile_split_float_reciprocal_is_exact_below_2_22():
+    """conv_enc0.hip's persistent kernels split a linear tile index into (image, tile row, tile column) with float
+    reciprocals instead of integer divisions; the launch refuses >= 2**22 tiles.  Same arithmetic in float32 here."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for per in (1, 3, 68, 69, 544, 2176, 100003, (1 << 22) - 1):
+        for tw in (1, 3, 4, 32, 33):
+            if tw > per:
+                continue
+            tiles = np.unique(np.concatenate([rng.integers(0, 1 << 22, 50000), np.arange(0, min(1 << 22, per * 20)),
+                                              (1 << 22) - 1 - np.arange(500)])).astype(np.int64)
+            inv_per, inv_w = np.float32(1.0) / np.float32(per), np.float32(1.0) / np.float32(tw)
+            b = ((tiles.astype(np.float32) + np.float32(0.5)) * inv_per).astype(np.int32)
+            tl = tiles - b.astype(np.int64) * per
+            ty = ((tl.astype(np.float32) + np.float32(0.5)) * inv_w).astype(np.int32)
+            tx = tl - ty * tw
+            assert np.array_equal(b, tiles // per) and np.array_equal(ty, (tiles % per) // tw)
+            assert np.array_equal(tx, (tiles % per) % tw)
