@@ -84,6 +84,23 @@ def test_conv2d_backward(dev, cin, cout, k, stride, hw):
         close(p[n].grad, q.grad, what=n)
 
 
+def test_first_encoder_conv_weight_gradient_train_size(dev):
+    """BASELINE configs[2] size [32,256,256]: the weight / bias gradient of enc0 over all 2048 tiles (persistent MFMA
+    kernel of conv_enc0.hip, one slab per workgroup, slab-parallel reduce) against autograd on the oracle conv."""
+    from dcsnet import functional as F
+    torch.manual_seed(8)
+    m = cpt.ComplexConv2d(1, 8, 7, (2, 2), 3)
+    x = rand_c((32, 1, 256, 256), 6, 0.5)
+    functional_loss(m(x), 2).backward()
+    p = dev_params(m, dev)
+    xn = nhwc_leaf(x, dev)
+    y = F.cconv2d(xn, None, p['conv_r.weight'], p['conv_i.weight'], p['conv_r.bias'], p['conv_i.bias'], False,
+                  (7, 7), (2, 2), (3, 3))
+    functional_loss(F.from_nhwc(y), 2).backward()
+    for n, q in m.named_parameters():
+        close(p[n].grad, q.grad, rel=3e-4, what=n)     # sums of 524 k fp32 terms in two different orders
+
+
 @pytest.mark.parametrize('c1,c2,cout,up', [(128, 128, 64, (2, 1)), (16, 16, 8, (2, 2)), (8, 8, 1, (2, 2)), (16, 0, 8, (1, 1))])
 def test_convtranspose_cat_upsample_backward(dev, c1, c2, cout, up):
     from dcsnet import functional as F

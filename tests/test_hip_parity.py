@@ -91,6 +91,31 @@ def test_first_encoder_conv_on_the_mfma_units(dev, H, W):
     close(back(y), aff, rel=4e-5)
 
 
+def test_first_encoder_conv_full_size_windows(dev):
+    """BASELINE configs[1] size [16,256,2000] (8192 tiles over the persistent workgroups of conv_enc0.hip): windows of the
+    full-size output — corners, edges, interior, first and last utterance — against the oracle conv of the matching
+    input windows (a conv is local: output rows r..r+h need input rows 2r-3..2(r+h-1)+3)."""
+    from dcsnet import functional as F
+    torch.manual_seed(3)
+    m = cpt.ComplexConv2d(1, 8, 7, (2, 2), 3)
+    B, H, W = 16, 256, 2000
+    x = rand_c((B, 1, H, W), 31)
+    p = lambda t: t.detach().to(dev)
+    y = back(F.cconv2d(nhwc(x, dev), None, p(m.conv_r.weight), p(m.conv_i.weight), p(m.conv_r.bias), p(m.conv_i.bias),
+                       False, (7, 7), (2, 2), (3, 3)))                         # [B, 8, 128, 1000]
+    assert y.shape == (B, 8, 128, 1000)
+    ref = cpt.ComplexConv2d(1, 8, 7, (2, 2), 0)                                   # same weights, windows padded by hand
+    ref.load_state_dict(m.state_dict())
+    h, w = 12, 40
+    for b, r0, c0 in [(0, 0, 0), (0, 116, 960), (7, 60, 500), (15, 0, 960), (15, 116, 0), (9, 3, 29), (15, 116, 960)]:
+        rows, cols = 2 * (h - 1) + 7, 2 * (w - 1) + 7
+        win = torch.zeros((1, 1, rows, cols), dtype=x.dtype)
+        ys, xs = 2 * r0 - 3, 2 * c0 - 3
+        y0, y1, x0, x1 = max(ys, 0), min(ys + rows, H), max(xs, 0), min(xs + cols, W)
+        win[0, 0, y0 - ys:y1 - ys, x0 - xs:x1 - xs] = x[b, 0, y0:y1, x0:x1]
+        close(y[b:b + 1, :, r0:r0 + h, c0:c0 + w], ref(win))
+
+
 @pytest.mark.parametrize('c1,c2,cout,up', [(128, 128, 128, (2, 1)), (32, 32, 16, (2, 2)), (8, 8, 1, (2, 2)),
                                             (16, 0, 8, (1, 1))])
 def test_complex_convtranspose_with_fused_cat_upsample(dev, c1, c2, cout, up):
