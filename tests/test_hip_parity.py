@@ -91,29 +91,80 @@ def test_first_encoder_conv_on_the_mfma_units(dev, H, W):
     close(back(y), aff, rel=4e-5)
 
 
-def test_first_encoder_conv_full_size_windows(dev):
-    """BASELINE configs[1] size [16,256,2000] (8192 tiles over the persistent workgroups of conv_enc0.hip): windows of the
-    full-size output — corners, edges, interior, first and last utterance — against the oracle conv of the matching
-    input windows (a conv is local: output rows r..r+h need input rows 2r-3..2(r+h-1)+3)."""
+# the seven encoder layers at BASELINE configs[1] size (input [16, 256, 2000]): (cin, cout, k, stride, Hin, Win)
+ENC_FULL = [(1, 8, 7, (2, 2), 256, 2000), (8, 16, 7, (2, 2), 128, 1000), (16, 32, 5, (2, 2), 64, 500),
+            (32, 64, 5, (2, 1), 32, 250), (64, 128, 3, (2, 1), 16, 250), (128, 128, 3, (2, 1), 8, 250),
+            (128, 128, 3, (2, 1), 4, 250)]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,H,W', ENC_FULL)
+def test_encoder_convs_full_size_windows(dev, cin, cout, k, stride, H, W):
+    """Every encoder conv at its BASELINE configs[1] size (the tile plans, split-K choices, persistent workgroups and
+    kernel variants that only full-size launches select): windows of the full-size output — corners, edges, interior,
+    first and last utterance — against the oracle conv of the matching input windows (a conv is local: output rows
+    r..r+h-1 need input rows s r - pad .. s (r+h-1) - pad + k - 1)."""
     from dcsnet import functional as F
-    torch.manual_seed(3)
-    m = cpt.ComplexConv2d(1, 8, 7, (2, 2), 3)
-    B, H, W = 16, 256, 2000
-    x = rand_c((B, 1, H, W), 31)
+    torch.manual_seed(cin + k)
+    pad = k // 2
+    m = cpt.ComplexConv2d(cin, cout, k, stride, pad)
+    B = 16
+    x = rand_c((B, cin, H, W), 31, 0.5)
     p = lambda t: t.detach().to(dev)
     y = back(F.cconv2d(nhwc(x, dev), None, p(m.conv_r.weight), p(m.conv_i.weight), p(m.conv_r.bias), p(m.conv_i.bias),
-                       False, (7, 7), (2, 2), (3, 3)))                         # [B, 8, 128, 1000]
-    assert y.shape == (B, 8, 128, 1000)
-    ref = cpt.ComplexConv2d(1, 8, 7, (2, 2), 0)                                   # same weights, windows padded by hand
+                       False, (k, k), stride, (pad, pad)))
+    Ho, Wo = (H + 2 * pad - k) // stride[0] + 1, (W + 2 * pad - k) // stride[1] + 1
+    assert y.shape == (B, cout, Ho, Wo)
+    ref = cpt.ComplexConv2d(cin, cout, k, stride, 0)                              # same weights, windows padded by hand
     ref.load_state_dict(m.state_dict())
-    h, w = 12, 40
-    for b, r0, c0 in [(0, 0, 0), (0, 116, 960), (7, 60, 500), (15, 0, 960), (15, 116, 0), (9, 3, 29), (15, 116, 960)]:
-        rows, cols = 2 * (h - 1) + 7, 2 * (w - 1) + 7
-        win = torch.zeros((1, 1, rows, cols), dtype=x.dtype)
-        ys, xs = 2 * r0 - 3, 2 * c0 - 3
+    h, w = min(12, Ho), min(40, Wo)
+    for b, r0, c0 in [(0, 0, 0), (0, Ho - h, Wo - w), (7, (Ho - h) // 2, Wo // 2), (15, 0, Wo - w), (15, Ho - h, 0),
+                      (9, min(3, Ho - h), 29), (15, Ho - h, Wo - w)]:
+        rows, cols = stride[0] * (h - 1) + k, stride[1] * (w - 1) + k
+        win = torch.zeros((1, cin, rows, cols), dtype=x.dtype)
+        ys, xs = stride[0] * r0 - pad, stride[1] * c0 - pad
         y0, y1, x0, x1 = max(ys, 0), min(ys + rows, H), max(xs, 0), min(xs + cols, W)
-        win[0, 0, y0 - ys:y1 - ys, x0 - xs:x1 - xs] = x[b, 0, y0:y1, x0:x1]
+        win[0, :, y0 - ys:y1 - ys, x0 - xs:x1 - xs] = x[b, :, y0:y1, x0:x1]
         close(y[b:b + 1, :, r0:r0 + h, c0:c0 + w], ref(win))
+
+
+# the seven decoder stages at BASELINE configs[1] size: (c1 (previous stage), c2 (skip), cout, upsample, Hs, Ws)
+DEC_FULL = [(128, 128, 128, (2, 1), 2, 250), (128, 128, 128, (2, 1), 4, 250), (128, 128, 64, (2, 1), 8, 250),
+            (64, 64, 32, (2, 1), 16, 250), (32, 32, 16, (2, 2), 32, 250), (16, 16, 8, (2, 2), 64, 500),
+            (8, 8, 1, (2, 2), 128, 1000)]
+
+
+@pytest.mark.parametrize('c1,c2,cout,up,Hs,Ws', DEC_FULL)
+def test_decoder_stages_full_size_windows(dev, c1, c2, cout, up, Hs, Ws):
+    """Every decoder conv (ComplexConvTranspose2d 3x3 / stride 1 behind cat + nearest upsample: c_network.py:135-141,
+    :214-217) at its BASELINE configs[1] size — the upsample-folded class launches and the one-kernel single-output
+    stage as the network calls them — on output windows against the oracle applied to the matching upsampled input
+    windows (output rows r..r+h-1 read upsampled rows r-1..r+h)."""
+    from dcsnet import functional as F
+    torch.manual_seed(c1 + cout)
+    m = cpt.ComplexConvTranspose2d(c1 + c2, cout, 3, 1, 1)
+    B = 16
+    d, sk = rand_c((B, c1, Hs, Ws), 3, 0.5), rand_c((B, c2, Hs, Ws), 4, 0.5)
+    p = lambda t: t.detach().to(dev)
+    wts = (p(m.conv_tran_r.weight), p(m.conv_tran_i.weight), p(m.conv_tran_r.bias), p(m.conv_tran_i.bias))
+    with torch.no_grad():
+        if cout == 1:
+            y = F.cconv_single_output(nhwc(d, dev), nhwc(sk, dev), *wts, (3, 3), (1, 1), up)
+        else:
+            y = F.cconv2d(nhwc(d, dev), nhwc(sk, dev), *wts, True, (3, 3), (1, 1), (1, 1), up)
+    y = back(y)
+    Hu, Wu = Hs * up[0], Ws * up[1]
+    assert y.shape == (B, cout, Hu, Wu)
+    h, w = min(10, Hu), min(36, Wu)
+    for b, r0, c0 in [(0, 0, 0), (0, Hu - h, Wu - w), (7, (Hu - h) // 2, Wu // 2), (15, 0, Wu - w), (15, Hu - h, 0),
+                      (15, Hu - h, Wu - w)]:
+        ru, cu = torch.arange(r0 - 1, r0 + h + 1), torch.arange(c0 - 1, c0 + w + 1)       # upsampled coordinates
+        rv, cv = (ru >= 0) & (ru < Hu), (cu >= 0) & (cu < Wu)
+        rs, cs = ru.clamp(0, Hu - 1) // up[0], cu.clamp(0, Wu - 1) // up[1]
+        cat = torch.cat((d[b], sk[b]), dim=0)                                            # [C, Hs, Ws]
+        win = cat[:, rs][:, :, cs] * (rv[:, None] & cv[None, :])
+        with torch.no_grad():
+            want = m(win[None])[..., 1:-1, 1:-1]
+        close(y[b:b + 1, :, r0:r0 + h, c0:c0 + w], want)
 
 
 @pytest.mark.parametrize('c1,c2,cout,up', [(128, 128, 128, (2, 1)), (32, 32, 16, (2, 2)), (8, 8, 1, (2, 2)),
