@@ -19,4 +19,4 @@ e0.record()
 for _ in range(20):
     y = ops.cconv2d(x, None, wp, bias, (7, 7), (2, 2), (3, 3), (1, 1))
 e1.record(); torch.cuda.synchronize()
-print(f'enc0 fwd B={B} T={T} dbg={os.environ.get("DCS_ENC0_DBG", "0")}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us')
+print(f'enc0 fwd B={B} T={T}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us')
