@@ -34,6 +34,9 @@ class Log(TorchDispatchMode):
             st = traceback.extract_stack()
             site = next((f'{os.path.basename(f.filename)}:{f.lineno} {f.name}' for f in reversed(st)
                          if ('dcsnet' in f.filename or 'bench.py' in f.filename)), 'autograd engine (accumulate)')
+            if site.startswith('autograd engine'):          # which tensors autograd sums: the shape tells the node
+                shp = next((tuple(a.shape) for a in args if isinstance(a, torch.Tensor)), ())
+                site = f'{site} {shp}'
             sites[(name, site)] += 1
         return func(*args, **(kwargs or {}))
 
