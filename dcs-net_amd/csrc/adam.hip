@@ -19,7 +19,9 @@ __global__ __launch_bounds__(kThreads) void adam_amsgrad_kernel(float4* __restri
                                                                  const float* __restrict__ grad_norm, float max_norm,
                                                                  float grad_scale, long n4, long n, float lr, float b1,
                                                                  float b2, float eps, float wd, float bc1, float bc2s,
-                                                                 const int* __restrict__ step_dev) {
+                                                                 const int* __restrict__ step_dev,
+                                                                 const float* __restrict__ skip) {
+    if (skip && skip[0] != 0.f) return;   // NaN-loss guard (c_network.py:257-261): the whole grid takes the same branch
     if (step_dev) {                       // update count kept on the device (hipGraph replay safe)
         const float t = (float)step_dev[0];
         bc1 = 1.f - powf(b1, t);
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void adam_amsgrad_kernel(float4* __restri
 
 extern "C" int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, const float* grad_norm,
                                      float max_norm, float grad_scale, long n, float lr, float beta1, float beta2,
-                                     float eps, float weight_decay, int step, const int* step_dev,
+                                     float eps, float weight_decay, int step, const int* step_dev, const float* skip,
                                      dcs_stream_t stream) {
     if (!p || !g || !m || !v || !vmax || n <= 0 || (step < 1 && !step_dev)) return DCS_ERR_BADARG;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return DCS_ERR_BADARG;
@@ -72,7 +74,32 @@ extern "C" int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* 
     const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
     hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid), dim3(kThreads), 0, dcs_stream(stream), (float4*)p,
                        (const float4*)g, (float4*)m, (float4*)v, (float4*)vmax, grad_norm, max_norm, grad_scale, n4, n,
-                       lr, beta1, beta2, eps, weight_decay, bc1, bc2s, step_dev);
+                       lr, beta1, beta2, eps, weight_decay, bc1, bc2s, step_dev, skip);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+namespace {
+__global__ void step_guard_kernel(const float* __restrict__ loss, float* __restrict__ skip) {
+    skip[0] = (loss[0] != loss[0]) ? 1.f : 0.f;
+}
+__global__ void step_advance_kernel(const float* __restrict__ skip, int* __restrict__ step_dev,
+                                    long long* __restrict__ seed_dev) {
+    if (step_dev && !(skip && skip[0] != 0.f)) step_dev[0] += 1;
+    if (seed_dev) seed_dev[0] += 1;
+}
+}  // namespace
+
+extern "C" int dcs_step_guard(const float* loss, float* skip, dcs_stream_t stream) {
+    if (!loss || !skip) return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(step_guard_kernel, dim3(1), dim3(1), 0, dcs_stream(stream), loss, skip);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_step_advance(const float* skip, int* step_dev, long long* seed_dev, dcs_stream_t stream) {
+    if (!step_dev && !seed_dev) return DCS_ERR_BADARG;
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, dcs_stream(stream), skip, step_dev, seed_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

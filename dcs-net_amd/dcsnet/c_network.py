@@ -164,7 +164,12 @@ class C_NETWORK(LightningModule):
         if not self.training or p <= 0.0:
             return 0.0, 0
         self._drop_calls += 1
-        return p, (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77) & 0x7FFFFFFFFFFFFFFF
+        # the rank is part of the seed: data-parallel ranks share torch's seed (seed_everything) but must draw
+        # independent masks for their shards of the minibatch, as one process dropping a batch of B*world would
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and
+                                                torch.distributed.is_initialized()) else 0
+        return p, (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77 +
+                   rank * 0xC2B2AE3D27D4EB4F) & 0x7FFFFFFFFFFFFFFF
 
     def _bn(self, bn, x, act, p=0.0):
         dp, seed = self._drop(p)

@@ -72,7 +72,11 @@ class FlatBucket:
             total += (p.numel() + 3) // 4 * 4
         self.numel = total
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
-        self.grad = torch.zeros(total, dtype=dtype, device=dev)
+        # 4 extra floats behind the gradients: [0] = the step's NaN-loss flag.  It rides the gradient all-reduce, so
+        # "some rank saw a NaN loss" reaches every rank in the one collective of the step and all ranks skip together.
+        self.grad_all = torch.zeros(total + 4, dtype=dtype, device=dev)
+        self.grad = self.grad_all[:total]
+        self.skip = self.grad_all[total:total + 1]
         with torch.no_grad():
             for p, o in zip(self.params, offs):
                 n = p.numel()
@@ -89,7 +93,7 @@ class FlatBucket:
             st.setdefault(layer, {})[kind] = (self.flat[o:o + n].view(shape), self.grad[o:o + n].view(shape))
 
     def zero_grad(self):
-        self.grad.zero_()
+        self.grad_all.zero_()
         for p, o in zip(self.params, self.offsets):        # re-attach if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
@@ -98,7 +102,7 @@ class FlatBucket:
     def allreduce(self):
         """Sum over ranks, in place; the 1/world factor is folded into the optimizer kernel."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.grad_all, op=dist.ReduceOp.SUM)
             return dist.get_world_size()
         return 1
 
@@ -116,17 +120,22 @@ class FusedAdam:
         self.t = 0
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=bucket.flat.device)
 
-    def step(self, world=1):
+    def step(self, world=1, seed_state=None):
+        """One update, unless the bucket's skip flag is set (a NaN loss on some rank: the reference's trainer skips
+        the update, c_network.py:257-261) — decided on the device, so the same launches serve a replayed graph.
+        `t` counts calls; the update count the bias corrections use is `t_dev` (advances only with a real update).
+        seed_state: the dropout seed offset, advanced in the same launch as `t_dev`."""
         b = self.b
         if not b.flat.is_cuda:
             raise _lib.DcsHipError('FusedAdam: expected CUDA (HIP) parameters; the HIP path has no CPU fallback')
         self.t += 1
-        self.t_dev += 1
+        lib = _lib.load()
+        check(lib.dcs_step_advance(ptr(b.skip), ptr(self.t_dev), ptr(seed_state), cur_stream()), 'dcs_step_advance')
         norm = torch.linalg.vector_norm(b.grad).reshape(1) if self.max_norm > 0 else None
-        check(_lib.load().dcs_adam_amsgrad_step(ptr(b.flat), ptr(b.grad), ptr(self.m), ptr(self.v), ptr(self.vmax),
-                                                ptr(norm), float(self.max_norm), 1.0 / world, b.numel, self.lr,
-                                                self.betas[0], self.betas[1], self.eps, self.wd, self.t,
-                                                ptr(self.t_dev), cur_stream()), 'dcs_adam_amsgrad_step')
+        check(lib.dcs_adam_amsgrad_step(ptr(b.flat), ptr(b.grad), ptr(self.m), ptr(self.v), ptr(self.vmax),
+                                        ptr(norm), float(self.max_norm), 1.0 / world, b.numel, self.lr,
+                                        self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                        ptr(self.t_dev), ptr(b.skip), cur_stream()), 'dcs_adam_amsgrad_step')
         # the kernel rewrote the parameters behind torch's version counters: invalidate packed weights
         from . import functional
         functional.bump_param_generation()
@@ -142,7 +151,11 @@ class TorchAdam:
         self.opt = torch.optim.Adam(bucket.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                     amsgrad=True)
 
-    def step(self, world=1):
+    def step(self, world=1, seed_state=None):
+        if seed_state is not None:
+            seed_state += 1
+        if float(self.b.skip) != 0.0:             # a NaN loss on some rank: every rank skips (c_network.py:257-261)
+            return
         if world > 1:
             self.b.grad.div_(world)
         if self.max_norm > 0:
@@ -156,8 +169,10 @@ class TrainStep:
     use_graph=True captures forward + losses + backward (+ the fused optimizer when single-process) into
     ONE hipGraph after `graph_warmup` eager steps and replays it afterwards: ~1.3 k launches per step
     become one submission.  Per-step state that must advance under replay lives on the device: the
-    dropout seed offset (ops.SEED_STATE) and Adam's update count.  The batch is copied into static
-    buffers before each replay.  Any capture failure falls back to eager execution, loudly."""
+    dropout seed offset (ops.SEED_STATE), Adam's update count and the NaN-loss flag (the reference skips the update on a
+    NaN loss, c_network.py:257-261: here the optimizer kernel is a no-op when the flag element of the gradient bucket is
+    set).  The batch is copied into static buffers before each replay; a batch whose shape differs from the captured one
+    runs eagerly.  Any capture failure falls back to eager execution, loudly."""
 
     def __init__(self, net, optimizer_cls=FusedAdam, use_graph=False, graph_warmup=3, use_pack_plan=True):
         hp = net.hparams
@@ -177,15 +192,20 @@ class TrainStep:
         self._calls = 0
 
     def _step_body(self, batch, batch_idx):
+        """NaN guard of the reference (c_network.py:257-261: training_step returns None, the trainer skips the update).
+        With several ranks the decision must be the same everywhere and every rank must still enter the collective:
+        a rank whose loss is NaN raises the flag element of the gradient bucket and joins the all-reduce with zero
+        gradients; the summed flag makes every rank's optimizer a no-op."""
         self.bucket.zero_grad()
         loss = self.net.training_step(batch, batch_idx)
-        if loss is None:                       # NaN guard of the reference (c_network.py:257-261)
-            return None
-        self._backward(loss)
+        if loss is None:
+            self.bucket.skip.fill_(1.0)
+        else:
+            self._backward(loss)
         world = self.bucket.allreduce()
-        self.opt.step(world)
-        if self.seed_state is not None:
-            self.seed_state += 1
+        self.opt.step(world, self.seed_state)
+        if loss is None or (world > 1 and float(self.bucket.skip) != 0.0):
+            return None
         return loss.detach()
 
     def _backward(self, loss):
@@ -245,10 +265,11 @@ class TrainStep:
                 functional.run_pack_plan(self._plan)
             self.bucket.zero_grad()
             loss = self._loss_no_sync(static, 0)
+            # the NaN test training_step makes on the host, on the device: flag element of the gradient bucket
+            check(_lib.load().dcs_step_guard(ptr(loss), ptr(self.bucket.skip), cur_stream()), 'dcs_step_guard')
             self._backward(loss)
             if world == 1:                                 # collectives stay outside the graph
-                self.opt.step(1)
-                self.seed_state += 1
+                self.opt.step(1, self.seed_state)
         functional.bump_param_generation()                 # cache entries made during capture live in its pool
         self._graph, self._static_loss, self._graph_world = g, loss.detach(), world
         self._graph_opt = None
@@ -258,8 +279,7 @@ class TrainStep:
             try:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, capture_error_mode='thread_local'):
-                    self.opt.step(world)
-                    self.seed_state += 1
+                    self.opt.step(world, self.seed_state)
                 self._graph_opt = g2
             except Exception as e:                          # noqa: BLE001 - the eager optimizer still works
                 import warnings
@@ -281,6 +301,10 @@ class TrainStep:
                 self.use_graph = False
                 torch.cuda.synchronize()
                 return self._eager(batch, batch_idx)
+        # the graph holds the captured shapes: a batch of another shape (the reference's DataLoader has no drop_last,
+        # config.py:66-69, so an epoch ends on a partial batch) runs eagerly — same kernels, same bucket, same optimizer
+        if any(tuple(s.shape) != tuple(b.shape) or s.dtype != b.dtype for s, b in zip(self._static_batch, batch[:3])):
+            return self._eager(batch, batch_idx)
         for s, b in zip(self._static_batch, batch[:3]):
             if s is not b:
                 s.copy_(b)
@@ -291,7 +315,7 @@ class TrainStep:
             if self._graph_opt is not None:
                 self._graph_opt.replay()
             else:
-                self.opt.step(world)
-                self.seed_state += 1
+                self.opt.step(world, self.seed_state)
         functional.bump_param_generation()     # the replays rewrote parameters and running statistics behind torch's back
-        return self._static_loss
+        # a NaN loss is returned as such (the caller may test it); the update was skipped on the device
+        return self._static_loss.clone()

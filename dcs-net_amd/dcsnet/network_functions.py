@@ -5,8 +5,9 @@ names and argument meaning of the reference's ``network_functions.py`` so ``c_ne
 On the hot path (HIP, libdcsnet_hip.so):  bound_cRM (:77-88), cRM (:62-75), the bound + complex
 multiply + subtract of the step functions (:240-243), complex_lrelu / complex_sigmoid
 (:98-112), and the waveform synthesis of mag_phase_2_wave around the inverse FFT (:140-150: polar
-spectrum, window / overlap-add / envelope).  Plumbing that stays on PyTorch-ROCm (SURVEY.md §8f
-"next"): the inverse FFT itself (rocFFT via torch.fft.irfft), SiSNR, loss assembly.
+spectrum, 512-point inverse real FFT (csrc/fft512.hip), window / overlap-add / envelope), SiSNR and the assembly of
+the configured loss pair (csrc/synth.hip).  On PyTorch-ROCm: the non-configured loss types (wSDR, L1, MSE reductions)
+and, for n_fft != 512 only, the inverse FFT (rocFFT via torch.fft.irfft).
 """
 import sys
 
@@ -211,8 +212,9 @@ def calc_metric(clean_audio, predict_audio, config, metric):
 
 
 def calc_loss(self, **kw):
-    """network_functions.py:168-208 for the loss types the reference configures
-    (noise_loss_type 6, speech_loss_type 0: config.py:38-39)."""
+    """network_functions.py:168-208: every noise_loss_type (0-6) with speech_loss_type 0.  The configured pair (type 6 +
+    type 0, config.py:38-39) on [B, L] device signals runs as fused HIP launches; the other types are plain torch
+    reductions around the same HIP network / synthesis outputs."""
     mode = _mode()
     alpha = self.hparams['speech_alpha']
     if (mode in ('dcs', 'drs') and self.hparams['noise_loss_type'] == 6 and isinstance(self.config.SiSNR, SiSNR) and
@@ -226,14 +228,31 @@ def calc_loss(self, **kw):
     if mode in ('dc', 'dr'):
         return speech_loss
     t = self.hparams['noise_loss_type']
+    # network_functions.py:171-193.  nn.L1Loss of two COMPLEX masks is the mean complex modulus |a - b| (not the mean
+    # of |re| and |im| parts); wSDR and the audio-domain L1 / the mask MSE terms are plain torch reductions.
+    l1_mask = lambda: (kw['target_noise_mask'] - kw['predict_noise_mask']).abs().mean()
+    wsdr = lambda: self.config.wSDR(kw['noisy_audio'], kw['noise_audio'], kw['predict_noise_audio'])
+    l1_audio = lambda: self.config.L1(kw['noise_audio'], kw['predict_noise_audio'])
     if t == 6:
         raw = -self.config.SiSNR(kw['noise_audio'], kw['predict_noise_audio'])
-    elif t == 1:
-        raw = self.config.wSDR(kw['noisy_audio'], kw['noise_audio'], kw['predict_noise_audio'])
     elif t == 0:
-        raw = self.config.L1(torch.view_as_real(kw['target_noise_mask']), torch.view_as_real(kw['predict_noise_mask']))
+        raw = l1_mask()
+    elif t == 1:
+        raw = wsdr()
+    elif t == 2:
+        raw = l1_mask() + l1_audio()
+    elif t == 3:
+        raw = wsdr() + l1_audio()
+    elif t == 4:
+        raw = wsdr() + l1_mask()
+    elif t == 5:
+        tm, pm = kw['target_noise_mask'], kw['predict_noise_mask']
+        if tm.is_complex():
+            raw = wsdr() + self.config.mse(tm.real, pm.real) + self.config.mse(tm.imag, pm.imag)
+        else:
+            raw = wsdr() + self.config.mse(tm, pm)
     else:
-        raise NotImplementedError(f'noise_loss_type {t}')
+        raise ValueError(f'noise_loss_type {t}: the reference defines types 0-6 (network_functions.py:171-193)')
     noise_loss = 1 - alpha * raw                       # QUIRK kept: network_functions.py:196
     return noise_loss, speech_loss, noise_loss + speech_loss
 
@@ -242,13 +261,13 @@ def _complex_step(self, noise_data, noisy_data, clean_data, need_noisy_audio=Fal
     eps = self.hparams['atan2_eps']
     cfg = self.config
     audio = {'noise_audio': _polar_wave(noise_data, eps, cfg), 'clean_audio': _polar_wave(clean_data, eps, cfg)}
-    if need_noisy_audio or self.hparams.get('noise_loss_type') not in (0, 6):
+    if need_noisy_audio or self.hparams.get('noise_loss_type') in (1, 3, 4, 5):
         # only the wSDR losses and the evaluation outputs read it; the reference always builds it
         audio['noisy_audio'] = _polar_wave(noisy_data, eps, cfg)
     mask_out = self(noisy_data)
     if _mode() in ('dcs', 'drs'):
-        if need_noisy_audio or self.hparams.get('noise_loss_type') == 0:
-            # only the L1 mask loss reads it (the reference always builds it: network_functions.py:237-239)
+        if need_noisy_audio or self.hparams.get('noise_loss_type') in (0, 2, 4, 5):
+            # only the mask-domain L1 / MSE losses read it (the reference always builds it: network_functions.py:237-239)
             audio['target_noise_mask'] = bound_cRM(cRM(noise_data, noisy_data), self.hparams)
         mask, noise_hat, clean_hat = bound_mask_apply(noisy_data, mask_out, self.hparams)
         audio['predict_noise_mask'] = mask

@@ -13,7 +13,16 @@
  *     `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *   - Every pointer is a DEVICE pointer BORROWED from the caller.  The library never
  *     allocates, frees or retains caller memory; workspaces are passed in.
- *   - Kernels are enqueued on `stream`; no call synchronises.  No global mutable state.
+ *   - Kernels are enqueued on `stream`; no call synchronises.
+ *   - ONE CONTEXT PER PROCESS.  The library is built for the one-process-per-GPU model and keeps three pieces of
+ *     process-global mutable state (each behind its own entry points, each guarded by a mutex, none per stream):
+ *       (1) the conv operand precision                         dcs_set_conv_precision / dcs_get_conv_precision
+ *       (2) the deferred weight-gradient reduce scope           dcs_wgrad_defer_begin / _suspend / _flush
+ *       (3) the pack-plan recorder                              dcs_pack_plan_begin / _end
+ *     Two training drivers in one process (or two host threads that open scopes concurrently) would see each
+ *     other's precision, recorded reduces and recorded packs.  Everything else is stateless: kernels read only
+ *     their arguments, so forward / backward calls on different streams of one process are safe as long as they
+ *     share the precision mode and at most one of them has a defer scope or a plan recording open.
  *   - Return value: 0 = enqueued; <0 = error (DCS_ERR_*), nothing was enqueued.
  *   - Dropout: mask = hash(seed + *seed_dev, element index); `seed_dev` (device uint64, may be NULL) lets
  *     a captured hipGraph be replayed with a fresh mask every step.  Backward calls take the same pair.
@@ -75,7 +84,6 @@ int dcs_pack_conv_weight(const float* w_r, const float* w_i, const float* b_r, c
                          float* wp, float* bias_out,
                          int Cout, int Cin, int kh, int kw, int transposed, int up_f, int up_t,
                          dcs_stream_t stream);
-/*
 
 /* ------------------------------------------------------------------------------------
  * ComplexConv2d / ComplexConvTranspose2d forward (apply_complex of complexPyTorch 0.3).
@@ -474,11 +482,25 @@ int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs
  * UNSCALED bucket, NULL or max_norm <= 0 disables clipping) and torch.optim.Adam with L2 weight
  * decay and amsgrad (c_network.py:229-234).  step = 1-based update count, or — when step_dev != NULL —
  * read from that device int (so a captured hipGraph can be replayed while the count advances).  All
- * buffers 16-byte aligned, float[n]. */
+ * buffers 16-byte aligned, float[n].
+ * skip (device float, may be NULL): when *skip != 0 the launch changes nothing — the device-side form of the
+ * reference's NaN-loss guard (training_step returns None and the trainer skips the update, c_network.py:257-261),
+ * which a captured step cannot take on the host. */
 int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
                           const float* grad_norm, float max_norm, float grad_scale, long n,
                           float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                          const int* step_dev, dcs_stream_t stream);
+                          const int* step_dev, const float* skip, dcs_stream_t stream);
+
+/* The NaN-loss guard of c_network.py:257-261 without a host round trip.
+ * dcs_step_guard:   *skip = isnan(*loss) ? 1 : 0.  `skip` is meant to be one extra element of the flat gradient
+ *                   bucket, so that a data-parallel sum-all-reduce turns it into "some rank saw a NaN" and every
+ *                   rank takes the same decision.
+ * dcs_step_advance: per-step device counters in one launch: *step_dev += (*skip == 0) (Adam's update count advances
+ *                   only when the update runs), *seed_dev += 1 (the dropout stream advances every step, as the
+ *                   reference's RNG does whether or not the update is skipped).  skip / step_dev / seed_dev may each
+ *                   be NULL. */
+int dcs_step_guard(const float* loss, float* skip, dcs_stream_t stream);
+int dcs_step_advance(const float* skip, int* step_dev, long long* seed_dev, dcs_stream_t stream);
 
 /* Tap-sum factorisation of a ONE-output-channel stride-1 ComplexConvTranspose2d (the last decoder stage,
  * c_network.py:135-141): y = tapsum(conv1x1(x: Cin -> ct "tap channels")) (dcs_tapsum_fwd).

@@ -205,6 +205,28 @@ def rnet_vectors(rn, nf):
     return res
 
 
+def loss_vectors(nf):
+    """The reference's calc_loss (network_functions.py:168-208) for every noise_loss_type 0-6 on seeded masks and
+    signals (sys.argv[1] must read 'dcs' while it runs)."""
+    from oracle.seeded_state import seeded_input
+    res = {}
+    B, L = 3, 480
+    g = torch.Generator().manual_seed(5)
+    sig = {k: torch.randn(B, L, generator=g) * s_ for k, s_ in (('noisy_audio', 0.2), ('noise_audio', 0.1),
+                                                                 ('clean_audio', 0.15), ('predict_noise_audio', 0.1),
+                                                                 ('predict_clean_audio', 0.15))}
+    sig['target_noise_mask'] = seeded_input(B, 8, 16, seed=21, scale=0.6)
+    sig['predict_noise_mask'] = seeded_input(B, 8, 16, seed=22, scale=0.6)
+    for k, v in sig.items():
+        res[k] = _c(v)
+    cfg = types.SimpleNamespace(L1=torch.nn.L1Loss(), mse=torch.nn.MSELoss(), SiSNR=nf.SiSNR(), wSDR=nf.wSDR())
+    for t in range(7):
+        me = types.SimpleNamespace(hparams={'noise_loss_type': t, 'speech_loss_type': 0, 'speech_alpha': 0.7}, config=cfg)
+        noise_loss, speech_loss, total = nf.calc_loss(me, **sig)
+        res[f'type{t}'] = np.array([float(noise_loss), float(speech_loss), float(total)], dtype=np.float64)
+    return res
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit('reference not mounted: fixtures can only be generated in the build container')
@@ -216,9 +238,12 @@ def main():
     import network_functions as nf
     import c_network as cn
     import r_network as rn
-    sys.argv = argv
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)                      # bit-stable reductions
+    np.savez_compressed(os.path.join(OUT, 'loss_vectors.npz'), **loss_vectors(nf))
+    sys.argv = argv
+    if '--only-new' in argv:                      # leave the fixtures of earlier rounds untouched
+        return
     np.savez_compressed(os.path.join(OUT, 'nf_vectors.npz'), **nf_vectors(nf))
     np.savez_compressed(os.path.join(OUT, 'cnet_vectors.npz'), **cnet_vectors(cn, nf))
     np.savez_compressed(os.path.join(OUT, 'rnet_vectors.npz'), **rnet_vectors(rn, nf))

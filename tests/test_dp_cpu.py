@@ -39,7 +39,10 @@ class _OracleAdapter(torch.nn.Module):
     def training_step(self, batch, idx):
         from oracle.nf_oracle import dcs_train_losses
         noise, noisy, clean = batch[:3]
-        return dcs_train_losses(self.net, noise, noisy, clean)[2]
+        loss = dcs_train_losses(self.net, noise, noisy, clean)[2]
+        if torch.any(torch.isnan(loss)):                 # the reference's guard (c_network.py:257-261)
+            return None
+        return loss
 
 
 def _batch(rank, B=2, T=16):
@@ -112,6 +115,49 @@ def test_two_rank_gloo_data_parallel_step(tmp_path):
     assert 0 < r['moved'] <= 1.5e-4                          # Adam's first step moves each weight by ~lr
     assert r['bn_diff'] > 0                                  # BatchNorm statistics stay local
     assert r['loss'] == r['loss']
+
+
+def _nan_worker(rank, world, port, out):
+    for p in (REPO, os.path.join(REPO, 'dcs-net_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dcsnet.dp import TrainStep, TorchAdam
+    model = _OracleAdapter(seed=3)
+    ts = TrainStep(model, optimizer_cls=TorchAdam)
+    before = ts.bucket.flat.clone()
+    noise, noisy, clean = _batch(rank)
+    if rank == 1:                                        # ONE rank's shard produces a NaN loss
+        noisy = noisy.clone()
+        noisy[0, 3, 5] = complex(float('nan'), 0.0)
+    r1 = ts((noise, noisy, clean), 0)                    # must not hang: every rank joins the all-reduce
+    after_nan = ts.bucket.flat.clone()
+    r2 = ts(_batch(rank), 1)                             # the next (clean) step pairs its collective correctly
+    after_ok = ts.bucket.flat.clone()
+    others = [torch.empty_like(after_ok) for _ in range(world)]
+    dist.all_gather(others, after_ok)
+    res = {'skipped': r1 is None, 'unchanged': bool(torch.equal(before, after_nan)), 'stepped': r2 is not None,
+           'moved': float((after_ok - after_nan).abs().max()), 'finite': bool(torch.isfinite(after_ok).all()),
+           'spread': float((others[0] - others[1]).abs().max())}
+    torch.save(res, f'{out}.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_nan_loss_on_one_rank_skips_the_step_on_every_rank(tmp_path):
+    """The reference skips an update whose loss is NaN (c_network.py:257-261).  Data-parallel, the decision must be
+    global and every rank must still issue the step's collective: the NaN flag rides the gradient all-reduce."""
+    out = str(tmp_path / 'nan')
+    mp.spawn(_nan_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in range(2):
+        r = torch.load(f'{out}.{rank}')
+        assert r['skipped'], rank                            # BOTH ranks report the skipped step
+        assert r['unchanged'], rank                          # no parameter moved, NaN gradients never reached Adam
+        assert r['stepped'] and 0 < r['moved'] <= 1.5e-4 and r['finite'], (rank, r)
+        assert r['spread'] == 0.0
 
 
 def test_flat_bucket_preserves_values_and_gradient_views():

@@ -232,3 +232,64 @@ def test_pack_plan_step_is_bit_identical_to_per_layer_packing(dev):
     assert len(ts1._plan.fwd) > 40 and len(ts1._plan.bwd) > 20
     assert l0 == l1
     assert torch.equal(ts0.bucket.flat, ts1.bucket.flat)
+
+
+def test_graph_replay_skips_the_update_on_a_nan_loss(dev):
+    """c_network.py:257-261: a NaN loss skips the update.  Under hipGraph replay there is no host test: the loss's NaN
+    flag stays on the device and turns the fused optimizer launch into a no-op (parameters, Adam moments and the
+    update count unchanged), while the dropout stream still advances."""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    net = fill_state(C_NETWORK(config, hparams, 0), 2).to(dev).train()
+    clean, noise = seeded_input(2, 256, 32, 1, 0.1), seeded_input(2, 256, 32, 2, 0.05)
+    good = (noise.to(dev), (clean + noise).to(dev), clean.to(dev), [0, 1])
+    bad_noisy = (clean + noise).clone()
+    bad_noisy[1, 7, 3] = complex(float('nan'), 0.0)
+    bad = (good[0], bad_noisy.to(dev), good[2], [0, 1])
+    ts = TrainStep(net, use_graph=True, graph_warmup=1)
+    for _ in range(3):
+        ts(good)
+    assert ts._graph is not None
+    snap = [t.clone() for t in (ts.bucket.flat, ts.opt.m, ts.opt.v, ts.opt.vmax)]
+    t_before, seed_before = int(ts.opt.t_dev), int(ts.seed_state)
+    loss = ts(bad)
+    assert loss != loss                                                  # the NaN loss is reported, not hidden
+    for a, b in zip(snap, (ts.bucket.flat, ts.opt.m, ts.opt.v, ts.opt.vmax)):
+        assert torch.equal(a, b)
+    assert int(ts.opt.t_dev) == t_before and int(ts.seed_state) == seed_before + 1
+    loss = ts(good)
+    assert float(loss) == float(loss)
+    assert not torch.equal(snap[0], ts.bucket.flat) and torch.isfinite(ts.bucket.flat).all()
+    assert int(ts.opt.t_dev) == t_before + 1
+    # the eager path takes the same decision on the host
+    ts_e = TrainStep(fill_state(C_NETWORK(config, hparams, 0), 2).to(dev).train())
+    before = ts_e.bucket.flat.clone()
+    assert ts_e(bad) is None and torch.equal(before, ts_e.bucket.flat) and int(ts_e.opt.t_dev) == 0
+
+
+def test_partial_batch_after_capture_runs_eagerly(dev):
+    """The reference's DataLoader has no drop_last (config.py:66-69): an epoch ends on a smaller batch.  A captured graph
+    holds the captured shapes, so that batch must not be broadcast into the static buffers — it runs eagerly."""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    clean, noise = seeded_input(3, 256, 32, 1, 0.1), seeded_input(3, 256, 32, 2, 0.05)
+    full = (noise.to(dev), (clean + noise).to(dev), clean.to(dev), [0, 1, 2])
+    part = tuple(t[:1].contiguous() for t in full[:3]) + ([0],)
+    runs = []
+    for use_graph in (False, True):
+        net = fill_state(C_NETWORK(config, hp, 0), 2).to(dev).train()
+        ts = TrainStep(net, use_graph=use_graph, graph_warmup=1)
+        losses = [float(ts(b)) for b in (full, full, full, part, full)]
+        runs.append((losses, ts))
+    (eager, ts_e), (graph, ts_g) = runs
+    assert ts_g._graph is not None
+    for a, b in zip(eager, graph):
+        assert abs(a - b) <= 1e-3 * abs(a) + 1e-3, (eager, graph)
+    assert abs(eager[3] - eager[2]) > 1e-4          # the partial batch has its own loss (not a broadcast of sample 0 x3)
+    assert torch.allclose(ts_g.bucket.flat, ts_e.bucket.flat, atol=5e-4)
+    l1, l2 = ts_g(full), ts_g(full)
+    assert l1.data_ptr() != l2.data_ptr()           # each call returns its own loss tensor

@@ -208,3 +208,29 @@ def test_tile_split_float_reciprocal_is_exact_below_2_22():
             tx = tl - ty * tw
             assert np.array_equal(b, tiles // per) and np.array_equal(ty, (tiles % per) // tw)
             assert np.array_equal(tx, (tiles % per) % tw)
+
+
+def test_calc_loss_every_noise_loss_type_against_the_reference(golden_dir):
+    """network_functions.py:168-208: noise_loss_type 0-6, values recorded from the reference's own calc_loss
+    (oracle/make_golden.py::loss_vectors).  Type 0 is the L1 of COMPLEX masks = mean |a - b|."""
+    import types
+    import numpy as np
+    from dcsnet import network_functions as nf
+    d = np.load(os.path.join(golden_dir, 'loss_vectors.npz'))
+    kw = {k: torch.from_numpy(d[k]) for k in ('noisy_audio', 'noise_audio', 'clean_audio', 'predict_noise_audio',
+                                              'predict_clean_audio', 'target_noise_mask', 'predict_noise_mask')}
+    cfg = types.SimpleNamespace(L1=torch.nn.L1Loss(), mse=torch.nn.MSELoss(), SiSNR=nf.SiSNR(), wSDR=nf.wSDR())
+    argv = sys.argv
+    sys.argv = ['train.py', 'dcs', '0']
+    try:
+        for t in range(7):
+            me = types.SimpleNamespace(hparams={'noise_loss_type': t, 'speech_loss_type': 0, 'speech_alpha': 0.7}, config=cfg)
+            got = [float(v) for v in nf.calc_loss(me, **kw)]
+            want = d[f'type{t}']
+            for g, w in zip(got, want):
+                assert abs(g - w) <= 1e-5 * max(1.0, abs(w)), (t, got, want)
+        with pytest.raises(ValueError):
+            nf.calc_loss(types.SimpleNamespace(hparams={'noise_loss_type': 9, 'speech_loss_type': 0, 'speech_alpha': 0.7},
+                                               config=cfg), **kw)
+    finally:
+        sys.argv = argv
