@@ -85,7 +85,12 @@ def complex_mat_mult(A, B):
 
 
 def bound_mask_apply(noisy_data, mask_out, hparams):
-    """network_functions.py:240-243 in one kernel: returns (bounded mask, Y (.) M, Y - Y (.) M)."""
+    """network_functions.py:240-243 in one kernel: returns (bounded mask, Y (.) M, Y - Y (.) M).  A batch of ONE reaches
+    here with the network's output already squeezed to [F,T] (c_network.py:224); the reference's element-wise product
+    then broadcasts it against noisy_data [1,F,T]: same shapes out here (mask [F,T], N_hat / S_hat [1,F,T])."""
+    if mask_out.dim() + 1 == noisy_data.dim() and noisy_data.shape[0] == 1:
+        M, N, S = F.bound_mask_apply_complex(noisy_data, mask_out.unsqueeze(0), hparams['atan2_eps'])
+        return M.squeeze(0), N, S
     return F.bound_mask_apply_complex(noisy_data, mask_out, hparams['atan2_eps'])
 
 

@@ -32,6 +32,7 @@ CONV_TIMER = None        # set by bench.py: object with begin(flops) -> token / 
 SEED_STATE = None
 
 _workspaces = {}
+_retired = []
 
 
 def set_conv_precision(mode):
@@ -122,6 +123,8 @@ def _workspace(nbytes, device):
     key = (device.index, cur_stream())
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _retired.append(buf)       # a captured hipGraph may hold its address: never hand it back to the allocator
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf

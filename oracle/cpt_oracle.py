@@ -39,16 +39,21 @@ import torch
 from torch.nn import Module, Parameter, Conv2d, ConvTranspose2d, Linear
 from torch.nn.functional import relu, interpolate
 
+# complexPyTorch casts with a literal torch.complex64; a calibration run (tools/full_size_grad_probe.py) sets this to
+# complex128 to get an fp64 ground truth of the same arithmetic.  Every test leaves it at complex64.
+CDTYPE = torch.complex64
+
 SQRT2 = 1.4142135623730951
 
 
-def apply_complex(fr, fi, input, dtype=torch.complex64):
+def apply_complex(fr, fi, input, dtype=None):
+    dtype = CDTYPE if dtype is None else dtype
     return (fr(input.real) - fi(input.imag)).type(dtype) \
         + 1j * (fr(input.imag) + fi(input.real)).type(dtype)
 
 
 def complex_relu(input):
-    return relu(input.real).type(torch.complex64) + 1j * relu(input.imag).type(torch.complex64)
+    return relu(input.real).type(CDTYPE) + 1j * relu(input.imag).type(CDTYPE)
 
 
 def complex_upsample(input, size=None, scale_factor=None, mode='nearest',
@@ -57,7 +62,7 @@ def complex_upsample(input, size=None, scale_factor=None, mode='nearest',
                             align_corners=align_corners, recompute_scale_factor=recompute_scale_factor)
     outp_imag = interpolate(input.imag, size=size, scale_factor=scale_factor, mode=mode,
                             align_corners=align_corners, recompute_scale_factor=recompute_scale_factor)
-    return outp_real.type(torch.complex64) + 1j * outp_imag.type(torch.complex64)
+    return outp_real.type(CDTYPE) + 1j * outp_imag.type(CDTYPE)
 
 
 class ComplexReLU(Module):
@@ -153,8 +158,8 @@ class ComplexBatchNorm2d(_ComplexBatchNorm):
                     exponential_average_factor = self.momentum
 
         if self.training or (not self.training and not self.track_running_stats):
-            mean_r = input.real.mean([0, 2, 3]).type(torch.complex64)
-            mean_i = input.imag.mean([0, 2, 3]).type(torch.complex64)
+            mean_r = input.real.mean([0, 2, 3]).type(CDTYPE)
+            mean_i = input.imag.mean([0, 2, 3]).type(CDTYPE)
             mean = mean_r + 1j * mean_i
         else:
             mean = self.running_mean
@@ -193,12 +198,12 @@ class ComplexBatchNorm2d(_ComplexBatchNorm):
         Rii = (Crr + s) * inverse_st
         Rri = -Cri * inverse_st
 
-        input = (Rrr[None, :, None, None] * input.real + Rri[None, :, None, None] * input.imag).type(torch.complex64) \
-            + 1j * (Rii[None, :, None, None] * input.imag + Rri[None, :, None, None] * input.real).type(torch.complex64)
+        input = (Rrr[None, :, None, None] * input.real + Rri[None, :, None, None] * input.imag).type(CDTYPE) \
+            + 1j * (Rii[None, :, None, None] * input.imag + Rri[None, :, None, None] * input.real).type(CDTYPE)
 
         if self.affine:
             input = (self.weight[None, :, 0, None, None] * input.real + self.weight[None, :, 2, None, None] * input.imag
-                     + self.bias[None, :, 0, None, None]).type(torch.complex64) \
+                     + self.bias[None, :, 0, None, None]).type(CDTYPE) \
                 + 1j * (self.weight[None, :, 2, None, None] * input.real + self.weight[None, :, 1, None, None] * input.imag
-                        + self.bias[None, :, 1, None, None]).type(torch.complex64)
+                        + self.bias[None, :, 1, None, None]).type(CDTYPE)
         return input

@@ -13,6 +13,10 @@ import torch
 
 ATAN2_EPS = 10e-7          # config.py:45  hparams['atan2_eps']
 
+# complexPyTorch casts with a literal torch.complex64; a calibration run (tools/full_size_grad_probe.py) sets this to
+# complex128 to get an fp64 ground truth of the same arithmetic.  Every test leaves it at complex64.
+CDTYPE = torch.complex64
+
 
 def _cplx(re, im):
     return torch.complex(re, im)
@@ -58,14 +62,14 @@ def complex_lrelu(x):
 
 def complex_sigmoid(x):
     """network_functions.py:111-112."""
-    return torch.sigmoid(x.real).type(torch.complex64) + 1j * torch.sigmoid(x.imag).type(torch.complex64)
+    return torch.sigmoid(x.real).type(CDTYPE) + 1j * torch.sigmoid(x.imag).type(CDTYPE)
 
 
 def complex_adaptive_avg_pool2d(x, output_size):
     """network_functions.py:122-125."""
     r = torch.nn.functional.adaptive_avg_pool2d(x.real, output_size)
     i = torch.nn.functional.adaptive_avg_pool2d(x.imag, output_size)
-    return r.type(torch.complex64) + 1j * i.type(torch.complex64)
+    return r.type(CDTYPE) + 1j * i.type(CDTYPE)
 
 
 def complex_adaptive_max_pool2d(x, output_size):

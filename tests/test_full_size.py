@@ -86,63 +86,94 @@ def test_inference_at_bench_size_against_oracle_eager_and_graph(dev):
     assert torch.equal(eager[0], static[0])
 
 
-@pytest.mark.parametrize('use_graph', [False, True])
-def test_train_step_at_bench_size_against_oracle(dev, use_graph):
-    """BASELINE configs[2] as `bench.py` runs it (dropout off for comparability): loss, all 222 gradient norms and
-    a set of full gradient tensors that covers the split-K layers (enc5 / enc6 / dec0), the 16-column kernel (dec5),
-    the tap-sum stage (dec6), the small-channel kernels (enc0, attention convs), CBN, LSTM and Linear."""
-    from dcsnet.dp import TrainStep
-    seed, B, T = 3, 32, 256
-    clean, noise = seeded_input(B, 256, T, 1, 0.1), seeded_input(B, 256, T, 2, 0.05)
-    noisy = clean + noise
-    ref = fill_state(C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), seed).train()
-    loss_ref = dcs_train_losses(ref, noise, noisy, clean)[2]
-    loss_ref.backward()
-    want = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in ref.named_parameters()}
-    loss_ref = float(loss_ref)
-    del ref
+TRAIN_SEED, TRAIN_B, TRAIN_T = 3, 32, 256
 
-    net = _hip_net(dev, seed).train()
+
+def _train_batch():
+    clean, noise = seeded_input(TRAIN_B, 256, TRAIN_T, 1, 0.1), seeded_input(TRAIN_B, 256, TRAIN_T, 2, 0.05)
+    return noise, clean + noise, clean
+
+
+@pytest.fixture(scope='module')
+def oracle_step():
+    """The oracle's step at [32,256,256] twice: in fp32 (what the reference computes) and in fp64 (the ground truth of
+    the same arithmetic — complexPyTorch's literal complex64 casts widened through cpt_oracle.CDTYPE).  At this size
+    the gradients are sums of ~10^5-10^7 cancelling terms: two CORRECT fp32 evaluations differ by ~3e-3 relative L2 in
+    most tensors (measured: tools/full_size_grad_probe.py), so fp32-vs-fp32 agreement cannot be the criterion; the
+    distance of each to fp64 can."""
+    from oracle import cpt_oracle, nf_oracle
+    _threads()
+    noise, noisy, clean = _train_batch()
+    out = {}
+    for name, cd in (('f32', torch.complex64), ('f64', torch.complex128)):
+        cpt_oracle.CDTYPE = nf_oracle.CDTYPE = cd
+        try:
+            ref = fill_state(C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), TRAIN_SEED).train()
+            if name == 'f64':
+                ref = ref.double()
+            loss = dcs_train_losses(ref, noise.to(cd), noisy.to(cd), clean.to(cd))[2]
+            loss.backward()
+            out[name] = (float(loss.detach()), {n: (None if p.grad is None else p.grad.detach().double())
+                                                for n, p in ref.named_parameters()})
+        finally:
+            cpt_oracle.CDTYPE = nf_oracle.CDTYPE = torch.complex64
+        del ref
+    return out
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_train_step_at_bench_size_against_oracle(dev, oracle_step, use_graph):
+    """BASELINE configs[2] as `bench.py` runs it (dropout off for comparability), every one of the 222 gradient tensors:
+    the split-K layers (enc5 / enc6 / dec0), the 16-column kernel (dec5), the tap-sum stage (dec6), the small-channel
+    kernels (enc0, attention convs), CBN, LSTM, Linear, deferred batched reduces, pack plan.  Criterion: distance to the
+    fp64 oracle, absolute and relative to the fp32 oracle's own distance (see the fixture)."""
+    from dcsnet.dp import TrainStep
+    noise, noisy, clean = _train_batch()
+    loss64, g64 = oracle_step['f64']
+    loss32, g32 = oracle_step['f32']
+    net = _hip_net(dev, TRAIN_SEED).train()
     # lr = 0: the captured graph is replayed on UNCHANGED parameters, so the replayed step is the oracle's step too
     net.hparams['lr'] = 0.0
     net.hparams['optim_weight_decay'] = 0.0
     ts = TrainStep(net, use_graph=use_graph, graph_warmup=1)
-    batch = (noise.to(dev), noisy.to(dev), clean.to(dev), list(range(B)))
+    batch = (noise.to(dev), noisy.to(dev), clean.to(dev), list(range(TRAIN_B)))
     for _ in range(3 if use_graph else 1):
         loss = ts(batch)
     torch.cuda.synchronize()
     if use_graph:
         assert ts._graph is not None, 'capture did not happen (fell back to eager)'
     loss = float(loss)
-    assert abs(loss - loss_ref) <= 2e-3 * abs(loss_ref), (loss, loss_ref)
+    assert abs(loss - loss64) <= 2e-5 * abs(loss64), (loss, loss64, loss32)
 
     pd = dict(net.named_parameters())
-    assert sorted(pd) == sorted(want)
-    checked = 0
-    for n, w in want.items():
+    assert sorted(pd) == sorted(g64)
+    ratios, loud, worst = [], [], (0.0, None)
+    for n, w in g64.items():
         g = pd[n].grad
         if w is None:                                 # decoder_attention.12 / .13: built, never run
             assert g is None, n
             continue
-        gn, wn = float(g.norm()), float(w.norm())
-        if _bias_before_bn(n):
-            assert gn <= 2e-3 * max(1.0, wn) + 1e-3, (n, gn, wn)
+        g = g.detach().cpu().double()
+        if _bias_before_bn(n):                        # analytically zero (1e-17 in fp64): both fp32 sides are noise
+            assert float(g.norm()) <= 2e-3 * max(1.0, float(g32[n].norm())) + 1e-3, (n, float(g.norm()))
             continue
-        assert abs(gn - wn) <= 2e-3 * wn + 1e-7, (n, gn, wn)
-        checked += 1
-    assert checked >= 200
-
-    full = ['encoder.0.0.conv_r.weight', 'encoder.1.0.conv_i.weight', 'encoder.5.0.conv_r.weight',
-            'encoder.6.0.conv_i.weight', 'encoder.6.1.weight', 'decoder.0.0.conv_tran_r.weight',
-            'decoder.1.0.conv_tran_i.weight', 'decoder.3.1.bias', 'decoder.5.0.conv_tran_r.weight',
-            'decoder.6.conv_tran_r.weight', 'decoder.6.conv_tran_i.bias', 'lstm.real_lstm.weight_hh_l0',
-            'lstm.imag_lstm.weight_ih_l1_reverse', 'fc.fc_r.weight', 'skip_attention.1.conv1.conv_r.weight',
-            'skip_attention.12.fc.0.conv_i.weight', 'decoder_attention.5.conv1.conv_i.weight',
-            'decoder_attention.0.fc.2.conv_r.weight', 'initial_batchnorm.weight']
-    for n in full:
-        g, w = pd[n].grad.cpu(), want[n]
-        err = float((g - w).abs().max())
-        assert err <= 2e-3 * float(w.abs().max()) + 1e-7, (n, err, float(w.abs().max()))
+        wn = float(w.norm())
+        e_hip = float((g - w).norm()) / wn
+        e_f32 = float((g32[n] - w).norm()) / wn
+        assert abs(float(g.norm()) - wn) <= 5e-3 * wn, (n, float(g.norm()), wn)
+        assert e_hip <= 1.5e-2, (n, e_hip, e_f32)
+        ratios.append(e_hip / max(e_f32, 1e-9))
+        if e_hip > max(4e-3, 3.0 * e_f32):
+            loud.append((n, e_hip, e_f32))
+        if e_hip > worst[0]:
+            worst = (e_hip, n)
+    assert len(ratios) >= 170
+    ratios.sort()
+    # as accurate as the reference's own fp32 arithmetic: median error ratio ~1, and only a handful of (small,
+    # cancellation-dominated attention) tensors noisier than 3x the CPU's fp32
+    assert ratios[len(ratios) // 2] <= 1.5, ratios[len(ratios) // 2]
+    assert len(loud) <= 5, loud
+    print(f'worst rel-L2 vs fp64: {worst}; median hip/f32 error ratio {ratios[len(ratios) // 2]:.2f}; loud {loud}')
 
 
 def test_complex_lstm_at_inference_sequence_length(dev):
