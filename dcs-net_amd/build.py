@@ -17,6 +17,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdcsnet_hip.so')
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+FLAGS += os.environ.get('DCS_EXTRA_HIPCC_FLAGS', '').split()      # diagnostic builds (e.g. -DDCS_PIPE_DIAG)
 
 
 def _sources():

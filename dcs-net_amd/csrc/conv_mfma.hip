@@ -20,6 +20,7 @@
 // as the direct kernel at ~6x its VALU rate.
 #include "conv_common.h"
 #include "pack_jobs.h"
+#include "conv_mfma_args.h"
 #include <cstdlib>
 
 namespace {
@@ -28,22 +29,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 
-struct MArgs {
-    conv::Args c;              // c.Hout / c.Wout: FULL output extent (addressing); c.sf / c.st: stride in class space
-    const float* bm;
-    float* y2;                 // optional second output: columns >= nsplit go here (g_x1 | g_x2 of a cat)
-    int nsplit;
-    int twshift;               // log2(TW): tile widths are powers of two
-    int TH, TW, N, KG, NT;     // tile shape (TH*TW = pixels per WG), N = 2*Cout, KG = Cin/4, NT = ceil(N/32)
-    int ncls, os_f, os_t;      // output-parity classes (blockIdx.z): pixel (oy, ox) of class c is stored at
-    conv::Cls cls[4];          //   (oy*os_f + oo_f, ox*os_t + oo_t) and has its own sub-kernel / padding / panel
-    // split-K (layers whose pixel x column tiles alone leave most CUs idle): blockIdx.y also indexes ksplit slices of
-    // the input-channel chunks; each slice stores its raw partial tile into part[slice][pixel][N] and
-    // splitk_reduce_kernel adds the slices (+ bias, activation, cat split) in a fixed order
-    int ksplit, cps;           // slices, chunks per slice
-    float* part;
-    long slab_floats;          // B * Hout * Wout * N
-};
 
 // wave grid: WAVES_N waves along N, 4/WAVES_N along M; each wave owns WM x WN tiles of 32x32.
 // CH complex input channels are staged per LDS pass (U = CH/4 k-groups per tap): the gather is latency- not
@@ -448,7 +433,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // (the B-panel re-layout kernel lives in pack_jobs.hip: packjob::MFMA)
 
-struct Plan { int cand, TH, TW, CH, S, cps; long blocks; };
+struct Plan { int cand, TH, TW, CH, S, cps; long blocks; bool pipe; };
 thread_local bool g_force_wide_panel = false;
 
 template <int WAVES_N, int WM, int WN, int CH, bool BF, int TPI>
@@ -566,7 +551,22 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // chunk depth: 16 channels whenever the patch stays within ~1/3 of a CU's LDS (2-3 workgroups per CU overlap
     // each other's gathers), 32 only for small patches (occupancy matters more than barrier count there)
     static const long cap16 = [] { const char* e = getenv("DCS_MFMA_LDS_CAP"); return e ? atol(e) : 56L * 1024; }();
-    if (Cin % 32 == 0 && npix * 68 * 4 <= 32 * 1024) p->CH = 32;
+    // the persistent LDS-DMA kernel (conv_pipe.hip) where it applies: the deepest chunk whose two patch buffers fit
+    // (fewer, longer work items: one barrier per item), 32 channels only while the buffers leave room for two workgroups
+    p->pipe = false;
+    if (!g_force_wide_panel) {
+        static const int force_ch = [] { const char* e = getenv("DCS_PIPE_CH"); return e ? atoi(e) : 0; }();
+        static const long cap32 = [] { const char* e = getenv("DCS_PIPE_LDS32"); return e ? atol(e) : 76L * 1024; }();
+        const int order[3] = {32, 16, 8};
+        for (int i = 0; i < 3 && !p->pipe; ++i) {
+            const int ch = order[i];
+            if (force_ch && ch != force_ch) continue;
+            if (ch == 32 && !force_ch && 2 * npix * 32 * 8 > cap32) continue;
+            if (dcs_conv_pipe_eligible(a, ncls, cls, best, p->TH, p->TW, ch)) { p->CH = ch; p->pipe = true; }
+        }
+    }
+    if (p->pipe) {}
+    else if (Cin % 32 == 0 && npix * 68 * 4 <= 32 * 1024) p->CH = 32;
     else if (Cin % 16 == 0 && npix * 36 * 4 <= cap16) p->CH = 16;
     else if (npix * 20 * 4 <= 150 * 1024) p->CH = 8;
     else return false;
@@ -652,7 +652,8 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         }
     }
     int rc;
-    switch (p.cand) {
+    if (p.pipe) rc = dcs_conv_pipe_launch(m, p.cand, p.CH, stream);
+    else switch (p.cand) {
         case 0: rc = launch<2, 2, 2>(m, p, npix, stream); break;      // 128 x 128
         case 1: rc = launch<2, 2, 1>(m, p, npix, stream); break;      // 128 x 64
         case 2: rc = launch<2, 1, 1>(m, p, npix, stream); break;      //  64 x 64

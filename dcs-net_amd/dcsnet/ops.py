@@ -46,6 +46,16 @@ def set_conv_precision(mode):
     pack_plan_drop()
 
 
+def set_conv_schedule(mode):
+    """'pipe' (default: persistent workgroups, LDS-DMA double buffering) or 'classic' (one patch per workgroup) for the
+    fp32 MFMA conv kernels; bit-identical results (dcs_set_conv_schedule)."""
+    check(_lib.load().dcs_set_conv_schedule({'classic': 0, 'pipe': 1}[mode]), 'dcs_set_conv_schedule')
+
+
+def conv_schedule():
+    return 'pipe' if _lib.load().dcs_get_conv_schedule() == 1 else 'classic'
+
+
 def conv_precision():
     return 'bf16' if _lib.load().dcs_get_conv_precision() == 1 else 'f32'
 
