@@ -69,7 +69,8 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
                                                                    const float* __restrict__ stats,
                                                                    double* __restrict__ part, long P, int C, int G,
                                                                    int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
-                                                                   const float4* __restrict__ g_add, float add_scale, long HW) {
+                                                                   const float4* __restrict__ g_add, float add_scale, long HW,
+                                                                   const float4* __restrict__ g2) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     __shared__ double red[kThreads * 12];
     const int t = threadIdx.x;
@@ -84,7 +85,9 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
         const Chan k = load_chan(coef, stats, 0);
         const long nvec = P / 2;
         for (long i = (long)blockIdx.x * kThreads + t; i < nvec; i += (long)gridDim.x * kThreads) {
-            const float4 v = x4[i], g = g4[i];
+            const float4 v = x4[i];
+            float4 g = g4[i];
+            if (g2) { const float4 h = g2[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
             const uint64_t e = (uint64_t)i * 4;
             acc6(s, grad_y<ACT, DROP>(k, v.x, v.y, g.x, g.y, seed, e, drop_p, inv_keep), v.x - k.mr, v.y - k.mi);
             acc6(s, grad_y<ACT, DROP>(k, v.z, v.w, g.z, g.w, seed, e + 2, drop_p, inv_keep), v.z - k.mr, v.w - k.mi);
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
     for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
         const float4 v = x4[r * G + g];
         float4 gg = g4[r * G + g];
+        if (g2) { const float4 h = g2[r * G + g]; gg.x += h.x; gg.y += h.y; gg.z += h.z; gg.w += h.w; }
         if (g_add) add_sample(gg, g_add[(r / HW) * G + g], add_scale);
         const uint64_t e = (uint64_t)(r * G + g) * 4;
         acc6(s, grad_y<ACT, DROP>(k0, v.x, v.y, gg.x, gg.y, seed, e, drop_p, inv_keep), v.x - k0.mr, v.y - k0.mi);
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ bcoef, long P, int C, int G,
                                                                   int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
-                                                                  const float4* __restrict__ g_add, float add_scale, long HW) {
+                                                                  const float4* __restrict__ g_add, float add_scale, long HW,
+                                                                  const float4* __restrict__ g2) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x;
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
@@ -230,7 +235,9 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
         const BChan bk = load_bchan(bcoef, 0);
         const long nvec = P / 2;
         for (long i = (long)blockIdx.x * kThreads + t; i < nvec; i += (long)gridDim.x * kThreads) {
-            const float4 v = x4[i], g = g4[i];
+            const float4 v = x4[i];
+            float4 g = g4[i];
+            if (g2) { const float4 h = g2[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
             const uint64_t e = (uint64_t)i * 4;
             const float2 a = grad_x(bk, grad_y<ACT, DROP>(k, v.x, v.y, g.x, g.y, seed, e, drop_p, inv_keep), v.x, v.y);
             const float2 b = grad_x(bk, grad_y<ACT, DROP>(k, v.z, v.w, g.z, g.w, seed, e + 2, drop_p, inv_keep), v.z, v.w);
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
     for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
         const float4 v = x4[r * G + g];
         float4 gg = g4[r * G + g];
+        if (g2) { const float4 h = g2[r * G + g]; gg.x += h.x; gg.y += h.y; gg.z += h.z; gg.w += h.w; }
         if (g_add) add_sample(gg, g_add[(r / HW) * G + g], add_scale);
         const uint64_t e = (uint64_t)(r * G + g) * 4;
         const float2 a = grad_x(b0, grad_y<ACT, DROP>(k0, v.x, v.y, gg.x, gg.y, seed, e, drop_p, inv_keep), v.x, v.y);
@@ -270,10 +278,12 @@ extern "C" int dcs_cbn_bwd_add(const float* x, const float* g_out, float* g_x, c
                                const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
                                long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
                                const unsigned long long* seed_dev, const float* g_add, float add_scale, long HW,
-                               dcs_stream_t stream) {
+                               const float* g_out2, dcs_stream_t stream) {
     cbn::Geom g;
     if (!x || !g_out || !g_x || !stats || !coef || !workspace || !cbn::geom(P, C, &g)) return DCS_ERR_BADARG;
     if (g_add && (C < 2 || HW <= 0 || P % HW != 0)) return DCS_ERR_BADARG;
+    if (g_out2 && C == 1 && (P & 1)) return DCS_ERR_BADARG;      // the scalar tail of the one-channel layout reads g_out only
+    const float4* gb = reinterpret_cast<const float4*>(g_out2);
     const float4* ga = reinterpret_cast<const float4*>(g_add);
     if ((g_weight == nullptr) != (g_bias == nullptr)) return DCS_ERR_BADARG;
     if (act != DCS_ACT_NONE && act != DCS_ACT_RELU && act != DCS_ACT_LRELU) return DCS_ERR_BADARG;
@@ -289,12 +299,12 @@ extern "C" int dcs_cbn_bwd_add(const float* x, const float* g_out, float* g_x, c
     do {                                                                                                           \
         hipLaunchKernelGGL((cbn_bwd_reduce_kernel<A, D>), dim3(g.nblocks), dim3(kThreads), 0, s, x, g_out, coef,    \
                            stats, part, P, C, g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev,   \
-                           ga, add_scale, HW);                                                                     \
+                           ga, add_scale, HW, gb);                                                                 \
         hipLaunchKernelGGL(cbn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part,      \
                            g.nblocks, weight, stats, coef, g_weight, g_bias, bcoef, P, C, use_batch_stats);        \
         hipLaunchKernelGGL((cbn_bwd_apply_kernel<A, D>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef,    \
                            stats, (const float*)bcoef, P, C, g.vec_per_row, g.rows_per_iter, drop_p,               \
-                           (uint64_t)seed, (const uint64_t*)seed_dev, ga, add_scale, HW);                          \
+                           (uint64_t)seed, (const uint64_t*)seed_dev, ga, add_scale, HW, gb);                      \
     } while (0)
     if (act == DCS_ACT_RELU) { if (drop) DCS_CBN_BWD(DCS_ACT_RELU, true); else DCS_CBN_BWD(DCS_ACT_RELU, false); }
     else if (act == DCS_ACT_LRELU) { if (drop) DCS_CBN_BWD(DCS_ACT_LRELU, true); else DCS_CBN_BWD(DCS_ACT_LRELU, false); }
@@ -309,5 +319,5 @@ extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const
                            long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
                            const unsigned long long* seed_dev, dcs_stream_t stream) {
     return dcs_cbn_bwd_add(x, g_out, g_x, weight, stats, coef, g_weight, g_bias, workspace, workspace_bytes, P, C,
-                           use_batch_stats, act, drop_p, seed, seed_dev, nullptr, 0.f, 0, stream);
+                           use_batch_stats, act, drop_p, seed, seed_dev, nullptr, 0.f, 0, nullptr, stream);
 }

@@ -8,16 +8,17 @@
 // matrix pipe idle 35-60 % of the time: the co-resident workgroups fall into lockstep and, with two waves per SIMD, each
 // wave's MFMA phase runs at half rate while its partner's does.
 //
-// Here a workgroup is 5 waves with fixed roles and lives for the whole launch:
-//   waves 0-3  one per SIMD, MFMA only: LDS fragment reads, B fragments from L2 (register ring, one tap ahead), the
-//              32x32x2 fp32 MFMA chain, the epilogue.  They never issue a patch load and never wait for one.
-//   wave 4     the loader: walks the SAME sequence of work items one item ahead and fills the other half of a
-//              double-buffered LDS patch with LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write), then
-//              waits for its own DMAs (vmcnt(0)) and joins the item's barrier.
-// A work item = (output tile, K slice, channel chunk).  One s_barrier per item is the only synchronisation: when it
-// opens, item i+1's patch has landed and every MFMA wave has finished reading item i's, so the loader may overwrite it.
-// Workgroups are persistent (grid = resident workgroups; units dealt round-robin), so the pipeline also runs across
-// tile boundaries: the next tile's first chunk streams in under the current tile's last chunk and its epilogue.
+// Here a workgroup (4 waves, as there) lives for the whole launch and walks a sequence of work items = (output tile,
+// K slice, channel chunk).  The patch is double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4: no VGPR
+// staging, no ds_write pass): right after the barrier that opens item i every wave issues its quarter of item i+1's DMA
+// pieces into the OTHER buffer and goes on with item i's MFMA tap loop; the pieces are in flight under the whole loop.
+// One `s_waitcnt vmcnt(0)` + one `s_barrier` per item is the only synchronisation (the guide's minimal two-phase loop):
+// behind it item i+1's patch has landed for every wave and everybody is done reading item i's.  Workgroups are persistent
+// (grid = resident workgroups, units dealt round-robin), so the pipeline also runs across tile boundaries: the next tile's
+// first chunk streams in under the current tile's last chunk.
+// (First form tried: a fifth, dedicated loader wave.  Beside an MFMA wave on its SIMD it issued one DMA piece per
+// 140-170 cycles — 40 alone, tools/micro/dma_rate.hip — and its address arithmetic one instruction per MFMA; at
+// s_setprio 3 it reached parity with conv_mfma.hip, no more.)
 //
 // LDS image.  An LDS-DMA instruction writes wave-uniform base + lane * 16 B: 1 KiB contiguous, so the pixel pitch
 // cannot be padded (conv_mfma.hip's conflict-free pitch of 2*CH + 4 floats).  Instead
@@ -42,6 +43,7 @@ struct PArgs {
     MArgs m;
     int n_units;               // tiles x batch x column groups x K slices x classes
     int buf_floats;            // one patch buffer (whole 1-KiB DMA pieces)
+    int npw_max;               // DMA pieces per wave and item, at most
     long long* dbg;            // diagnostic builds only (-DDCS_PIPE_DIAG): per-wave cycle sums
 };
 
@@ -59,7 +61,7 @@ constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 #define DCS_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 template <int WAVES_N, int WM, int WN, int CH, int TPI>
-__global__ __launch_bounds__(320) void cconv_pipe_kernel(PArgs pa) {
+__global__ __launch_bounds__(256) void cconv_pipe_kernel(PArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int U = CH / 4, VU = U * TPI, SP = CH / 2, LOG_SP = ilog2c(SP), PRSH = ilog2c(16 / SP);
     const MArgs& m = pa.m;
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(320) void cconv_pipe_kernel(PArgs pa) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     float* const buf0 = lds;
     float* const buf1 = lds + pa.buf_floats;
-    int* const tab = reinterpret_cast<int*>(lds + 2 * pa.buf_floats);      // loader-private: source pixel of every pixel slot
+    // wave-private: source pixel (or -1) of the 64 slots of each DMA piece this wave issues (pieces wave, wave + 4, ...)
+    int* const mytab = reinterpret_cast<int*>(lds + 2 * pa.buf_floats) + wave * pa.npw_max * 64 + lane;
 
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int nx = tiles_per_img * a.B;
@@ -95,83 +98,56 @@ __global__ __launch_bounds__(320) void cconv_pipe_kernel(PArgs pa) {
         return o->c0 < o->c1;
     };
 
-    if (wave == 4) {
-        // ------------------------------------------------------------------------------------------ loader
-        // the loader shares its SIMD with one MFMA wave and, being the youngest wave of the workgroup, loses every issue
-        // arbitration to it at equal priority (measured: ~1 instruction per 64-cycle MFMA).  Its instruction stream is
-        // short; at priority 3 it is served when ready and the MFMA wave gives up a few issue slots per work item.
-        __builtin_amdgcn_s_setprio(3);
-        int cnt = 0;
-        long long d_tab = 0, d_issue = 0, d_wait = 0, d_bar = 0, d_start = DIAG_NOW();
-        for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-            Unit q;
-            if (!decode(u, &q)) continue;
-            const long long s0 = DIAG_NOW();
-            const conv::Cls& k = m.cls[q.cls];
-            const int cols = (m.TW - 1) * a.st + k.kw, rows = (m.TH - 1) * a.sf + k.kh;
-            const int P = cols, PW0 = (cols + 1) >> 1;
-            const int NQ = rows * P, NP = (NQ * SP + 63) >> 6;
-            const int vy0 = q.oy0 * a.sf - k.pad_f, vx0 = q.ox0 * a.st - k.pad_t;
-            {   // source pixel of every pixel slot, 64 slots per pass; (row, r) advance incrementally: no division
-                int row = lane / P, r = lane - row * P;                     // one division per unit
-                const int drow = 64 / P, dr = 64 - drow * P;
-                for (int ql = lane; ql < NQ; ql += 64) {
-                    const int col = st2 ? (r >= PW0 ? 2 * (r - PW0) + 1 : 2 * r) : r;
-                    long sp;
-                    tab[ql] = conv::src_pixel(a, q.b, vy0 + row, vx0 + col, &sp) ? (int)sp : -1;
-                    r += dr; row += drow;
-                    if (r >= P) { r -= P; ++row; }
-                }
-            }
-            d_tab += DIAG_NOW() - s0;
-            for (int ch = q.c0; ch < q.c1; ++ch) {
-                const long long s1 = DIAG_NOW();
-                float* dst = (cnt & 1) ? buf1 : buf0;
-                const int c = ch * CH;                                       // first complex channel of the chunk
-                const bool second = c >= a.C1;
-                const char* base = second ? reinterpret_cast<const char*>(a.x2 + (c - a.C1))
-                                          : reinterpret_cast<const char*>(a.x1 + c);
-                const long Cb = (long)(second ? a.C2 : a.C1) * 8;            // bytes per source pixel
-                // pieces in groups of 4: the four table reads first (one LDS round trip), then the four DMAs
-                for (int p0 = 0; p0 < NP; p0 += 4) {
-                    int spv[4];
+    // ---- loading half: every wave issues its quarter of an item's DMA pieces ----------------------------------
+    // table of unit q: for each of this wave's pieces, the source pixel of this lane's 16-byte slot
+    auto build_table = [&](const Unit& q) {
+        const conv::Cls& k = m.cls[q.cls];
+        const int P = (m.TW - 1) * a.st + k.kw, rows = (m.TH - 1) * a.sf + k.kh, PW0 = (P + 1) >> 1;
+        const int NQ = rows * P, NP = (NQ * SP + 63) >> 6;
+        const int vy0 = q.oy0 * a.sf - k.pad_f, vx0 = q.ox0 * a.st - k.pad_t;
+        constexpr int DQ = 256 >> LOG_SP;                                // pixel slots between two pieces of one wave
+        const int drow = DQ / P, dr = DQ - drow * P;
+        int ql = (wave * 64 + lane) >> LOG_SP;
+        int row = (int)(((float)ql + 0.5f) * (1.0f / (float)P));         // exact: ql, P < 2^12
+        int r = ql - row * P;
+        int* tp = mytab;
+        for (int p = wave; p < NP; p += 4) {
+            const int col = st2 ? (r >= PW0 ? 2 * (r - PW0) + 1 : 2 * r) : r;
+            long sp;
+            *tp = (ql < NQ && conv::src_pixel(a, q.b, vy0 + row, vx0 + col, &sp)) ? (int)sp : -1;
+            tp += 64;
+            ql += DQ; r += dr; row += drow;
+            if (r >= P) { r -= P; ++row; }
+        }
+    };
+    auto issue_item = [&](const Unit& q, int ch, float* dst) {
+        const conv::Cls& k = m.cls[q.cls];
+        const int P = (m.TW - 1) * a.st + k.kw, rows = (m.TH - 1) * a.sf + k.kh;
+        const int NP = (rows * P * SP + 63) >> 6;
+        const int c = ch * CH;                                           // first complex channel of the chunk
+        const bool second = c >= a.C1;
+        const char* base = second ? reinterpret_cast<const char*>(a.x2 + (c - a.C1)) : reinterpret_cast<const char*>(a.x1 + c);
+        const long Cb = (long)(second ? a.C2 : a.C1) * 8;                // bytes per source pixel
+        const int* tp = mytab;
+        // pieces in pairs: both table reads first (one LDS round trip), then both DMAs
+        for (int p = wave; p < NP; p += 8) {
+            const int sp0 = tp[0];
+            const int sp1 = p + 4 < NP ? tp[64] : -1;
+            tp += 128;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int ql = ((p0 + e) * 64 + lane) >> LOG_SP;
-                        spv[e] = ql < NQ ? tab[ql] : -1;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (p0 + e >= NP) break;
-                        const int L = (p0 + e) * 64 + lane, ql = L >> LOG_SP;
-                        const int s = (L & (SP - 1)) ^ ((ql >> PRSH) & (SP - 1));
-                        const char* g = spv[e] >= 0 ? base + spv[e] * Cb + s * 16 : reinterpret_cast<const char*>(g_zero_page);
-                        __builtin_amdgcn_global_load_lds(DCS_GPTR(g), DCS_LPTR(dst + (p0 + e) * 256), 16, 0, 0);
-                    }
-                }
-#ifdef DCS_PIPE_DIAG
-                const long long s2 = DIAG_NOW();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const long long s3 = DIAG_NOW();
-                asm volatile("s_barrier" ::: "memory");
-                const long long s4 = DIAG_NOW();
-                d_issue += s2 - s1; d_wait += s3 - s2; d_bar += s4 - s3;
-#else
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-                ++cnt;
+            for (int e = 0; e < 2; ++e) {
+                const int pe = p + 4 * e;
+                if (pe >= NP) break;
+                const int spv = e ? sp1 : sp0;
+                const int L = pe * 64 + lane, ql = L >> LOG_SP;
+                const int sl = (L & (SP - 1)) ^ ((ql >> PRSH) & (SP - 1));
+                const char* g = spv >= 0 ? base + spv * Cb + sl * 16 : reinterpret_cast<const char*>(g_zero_page);
+                __builtin_amdgcn_global_load_lds(DCS_GPTR(g), DCS_LPTR(dst + pe * 256), 16, 0, 0);
             }
         }
-#ifdef DCS_PIPE_DIAG
-        if (pa.dbg && lane == 0) {
-            long long* d = pa.dbg + ((long)blockIdx.x * 5 + 4) * 8;
-            d[0] = d_tab; d[1] = d_issue; d[2] = d_wait; d[3] = d_bar; d[4] = DIAG_NOW() - d_start; d[5] = cnt;
-        }
-#endif
-        return;
-    }
+    };
 
-    // ---------------------------------------------------------------------------------------------- MFMA waves
+    // ---- MFMA half ------------------------------------------------------------------------------------------------
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int kk = lane >> 5, li = lane & 31;
     const long b_tap_stride = (long)m.KG * m.NT * 256, b_kg_stride = (long)m.NT * 256;
@@ -189,7 +165,7 @@ __global__ __launch_bounds__(320) void cconv_pipe_kernel(PArgs pa) {
     Unit cu;
     int u = blockIdx.x;
     while (u < n_units && !decode(u, &cu)) u += gridDim.x;
-    if (u >= n_units) return;                    // (the loader finds no unit either: no barrier is ever entered)
+    if (u >= n_units) return;                    // every wave of the workgroup takes the same decision
 
     f32x16 acc[WM][WN];
     constexpr int LPG = VU >= 2 ? 2 : 1;
@@ -197,8 +173,11 @@ __global__ __launch_bounds__(320) void cconv_pipe_kernel(PArgs pa) {
     const float* bp_item = unit_b(cu);
 #pragma unroll
     for (int g = 0; g < VU; ++g) bload(bcur[g], bp_item, g);
+    // prologue: the first item's patch
+    build_table(cu);
+    issue_item(cu, cu.c0, buf0);
     int cnt = 0;
-    long long d_bar = 0, d_comp = 0, d_epi = 0, d_start = DIAG_NOW();
+    long long d_bar = 0, d_comp = 0, d_epi = 0, d_iss = 0, d_start = DIAG_NOW();
 
     for (;;) {
         Unit nu;
@@ -230,12 +209,20 @@ __global__ __launch_bounds__(320) void cconv_pipe_kernel(PArgs pa) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         for (int ch = cu.c0; ch < cu.c1; ++ch) {
-            const float* bp_next_item = ch + 1 < cu.c1 ? bp_item + (long)U * b_kg_stride : bp_next_unit;
+            const bool last_chunk = ch + 1 >= cu.c1;
+            const float* bp_next_item = last_chunk ? bp_next_unit : bp_item + (long)U * b_kg_stride;
             const float* patch = (cnt & 1) ? buf1 : buf0;
+            float* other = (cnt & 1) ? buf0 : buf1;
+            // this wave's DMAs of the item have landed; after the barrier so have everyone's, and every wave is done
+            // reading the other buffer (the previous item's)
             const long long s0 = DIAG_NOW();
-            asm volatile("s_barrier" ::: "memory");                    // this item's patch has landed (loader: vmcnt(0))
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const long long s1 = DIAG_NOW();
             d_bar += s1 - s0;
+            // the NEXT item's patch into the other buffer: in flight under this item's whole tap loop
+            if (!last_chunk) issue_item(cu, ch + 1, other);
+            else if (has_next) { build_table(nu); issue_item(nu, nu.c0, other); }
+            d_iss += DIAG_NOW() - s1;
             int abase[TPI][WM], ah[TPI][WM], nbase[WM], nh[WM];
             int dy = 0, dx = 0;
 #pragma unroll
@@ -369,7 +356,7 @@ __global__ __launch_bounds__(320) void cconv_pipe_kernel(PArgs pa) {
 #ifdef DCS_PIPE_DIAG
     if (pa.dbg && lane == 0) {
         long long* d = pa.dbg + ((long)blockIdx.x * 5 + wave) * 8;
-        d[0] = d_bar; d[1] = d_comp; d[2] = d_epi; d[4] = DIAG_NOW() - d_start; d[5] = cnt;
+        d[0] = d_bar; d[1] = d_comp; d[2] = d_epi; d[3] = d_iss; d[4] = DIAG_NOW() - d_start; d[5] = cnt;
     }
 #endif
 }
@@ -410,14 +397,14 @@ int launch_one(PArgs& pa, size_t lds, hipStream_t stream) {
     for (int i = 0; i < ncache; ++i)
         if (cache[i].lds == lds) per_cu = cache[i].per_cu;
     if (per_cu == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 320, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        static const int cap = [] { const char* e = getenv("DCS_PIPE_WG_PER_CU"); return e ? atoi(e) : 2; }();
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        static const int cap = [] { const char* e = getenv("DCS_PIPE_WG_PER_CU"); return e ? atoi(e) : 3; }();
         if (per_cu > cap) per_cu = cap;
         if (ncache < 8) cache[ncache++] = Occ{lds, per_cu};
     }
     long grid = (long)per_cu * num_cus();
     if (grid > pa.n_units) grid = pa.n_units;
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(320), lds, stream, pa);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, pa);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -443,7 +430,9 @@ long long* g_dbg = nullptr;
 extern "C" int dcs_debug_set_buffer(void* p) { g_dbg = (long long*)p; return 0; }
 #endif
 namespace {
-int g_schedule = [] { const char* e = getenv("DCS_CONV_PIPE"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+// default 0: measured at B=32, T=256 (tools/conv_ab.py, interleaved rounds in one process) the pipelined schedule is at
+// parity with conv_mfma.hip on the mid layers and behind it on the shallow / few-tile ones
+int g_schedule = [] { const char* e = getenv("DCS_CONV_PIPE"); return (e && atoi(e) != 0) ? 1 : 0; }();
 }
 
 bool dcs_conv_pipe_enabled() { return g_schedule == 1; }
@@ -460,11 +449,10 @@ bool dcs_conv_pipe_eligible(const conv::Args& a, int ncls, const conv::Cls* cls,
     if (!dcs_conv_pipe_enabled() || dcs_conv_precision() != 0) return false;
     if (cand < 0 || cand > 3 || a.sf < 1 || a.sf > 2 || a.st < 1 || a.st > 2) return false;
     if (2 * a.Cout < 32 || (CH != 8 && CH != 16 && CH != 32)) return false;
-    if (cand == 0 && CH == 32) return false;          // 128 x 128 tile + 8 k-groups of B fragments per tap: over 256 VGPRs
     const int Cin = a.C1 + a.C2;
     if (Cin % CH != 0 || (a.C2 > 0 && a.C1 % CH != 0)) return false;      // a chunk lies in ONE tensor of a concatenation
     const Geo g = pipe_geo(a, ncls, cls, TH, TW, CH);
-    const long lds = 2L * g.npmax * 1024 + (long)g.nqmax * 4;
+    const long lds = 2L * g.npmax * 1024 + (long)((g.npmax + 3) / 4) * 4 * 256;
     return lds <= 156 * 1024;
 }
 
@@ -474,8 +462,9 @@ int dcs_conv_pipe_launch(MArgs& m, int cand, int CH, hipStream_t stream) {
     PArgs pa;
     pa.m = m;
     pa.buf_floats = g.npmax * 256;
+    pa.npw_max = (g.npmax + 3) / 4;
     pa.dbg = g_dbg;
-    const size_t lds = 2 * (size_t)g.npmax * 1024 + (size_t)g.nqmax * 4;
+    const size_t lds = 2 * (size_t)g.npmax * 1024 + (size_t)pa.npw_max * 4 * 256;
     const int bn = cand == 0 ? 4 : (cand == 1 ? 2 : (cand == 2 ? 2 : 1));        // 32-column tiles per workgroup
     const long units = (long)a.tiles_w * a.tiles_h * a.B * (m.NT / bn) * m.ksplit * m.ncls;
     if (units <= 0 || units >= (1L << 30)) return DCS_ERR_BADARG;

@@ -49,7 +49,7 @@ SIGNATURES = {
     'dcs_cbn_fwd': (_I, [_P] * 9 + [_L, _L, _I, _F, _F, _I, _I, _F, _U64, _P, _P]),
     'dcs_cbn_bwd_workspace_bytes': (_L, [_L, _I]),
     'dcs_cbn_bwd': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P]),
-    'dcs_cbn_bwd_add': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P, _F, _L, _P]),
+    'dcs_cbn_bwd_add': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P, _F, _L, _P, _P]),
     'dcs_ca_workspace_bytes': (_L, [_I, _L, _I]),
     'dcs_channel_attention_fwd': (_I, [_P] * 7 + [_L, _I, _L, _I, _I, _P]),
     'dcs_spatial_pool_fwd': (_I, [_P, _P, _P, _I, _L, _I, _P]),

@@ -171,9 +171,9 @@ class C_NETWORK(LightningModule):
         return p, (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77 +
                    rank * 0xC2B2AE3D27D4EB4F) & 0x7FFFFFFFFFFFFFFF
 
-    def _bn(self, bn, x, act, p=0.0):
+    def _bn(self, bn, x, act, p=0.0, two=False):
         dp, seed = self._drop(p)
-        return bn._hip_forward(x, act, dp, seed, count=not self._counted)
+        return bn._hip_forward(x, act, dp, seed, count=not self._counted, two=two)
 
     def _count_batches(self):
         """num_batches_tracked += 1 for every CBN of the forward path as ONE launch: the 14 scalar buffers are
@@ -207,7 +207,11 @@ class C_NETWORK(LightningModule):
         # [B,F,T] complex IS channels-last with C = 1 (c_network.py:190)
         e = torch.view_as_real(x.contiguous()).view(B, Fbins, T, 1, 2)
         self._count_batches()
+        # every encoder stage output has TWO consumers (the next stage — the LSTM for the last one — and a skip attention):
+        # `enc` serves the first, `enc_skip` the second; with autograd on they are two tensors over one storage, so the
+        # two cotangents reach the CBN backward kernels separately and are summed there (F._CbnTwoFn)
         enc = [self._bn(self.initial_batchnorm, e, F.ACT_NONE)]
+        enc_skip = [None]
         infer = not self.training and not torch.is_grad_enabled()
         for i in range(L):                                   # c_network.py:193-197
             conv, bn = self.encoder[i][0], self.encoder[i][1]
@@ -217,10 +221,13 @@ class C_NETWORK(LightningModule):
                 enc.append(F.cconv2d_cbn_eval(enc[i], None, conv.conv_r.weight, conv.conv_i.weight, conv.conv_r.bias,
                                               conv.conv_i.bias, False, conv.kernel_size, conv.stride, conv.padding, (1, 1),
                                               coef, F.ACT_RELU))
+                enc_skip.append(enc[-1])
                 continue
             c = F.cconv2d(enc[i], None, conv.conv_r.weight, conv.conv_i.weight, conv.conv_r.bias, conv.conv_i.bias,
                           False, conv.kernel_size, conv.stride, conv.padding)
-            enc.append(self._bn(bn, c, F.ACT_RELU, p_conv))
+            a, b = self._bn(bn, c, F.ACT_RELU, p_conv, two=True)
+            enc.append(a)
+            enc_skip.append(b)
 
         # latent (c_network.py:199-205): channels-last [B,F7,T7,C] is already [B, seq, C]
         lat = enc[L]
@@ -232,7 +239,7 @@ class C_NETWORK(LightningModule):
             zr = F.dropout(zr, dp, seed)
         d = zr.view(B, F7, T7, C7, 2)
 
-        skips = self._skip_attentions(enc)
+        skips = self._skip_attentions(enc_skip)
         for i in range(L):                                   # c_network.py:207-222
             skip = skips[i]
             stage = self.decoder[i]

@@ -124,7 +124,7 @@ class _ComplexBatchNorm(Module):
                 self.weight[:, 2] = 0
                 self.bias.zero_()
 
-    def _hip_forward(self, x_nhwc, act=F.ACT_NONE, drop_p=0.0, seed=0, count=True, attention=None):
+    def _hip_forward(self, x_nhwc, act=F.ACT_NONE, drop_p=0.0, seed=0, count=True, attention=None, two=False):
         """x: float [B,H,W,C,2].  Shared with the fused C_NETWORK.forward (which advances all the
         num_batches_tracked counters of the network with one launch and passes count=False).
         attention = (fc0_r, fc0_i, fc2_r, fc2_i, conv1_r, conv1_i, ksize, drop_p, seed): the attention block that
@@ -141,12 +141,18 @@ class _ComplexBatchNorm(Module):
             raise F.DcsHipError('CBN + attention: dropout belongs to the attention block')
         if not use_batch and not torch.is_grad_enabled():
             y = self._eval_forward(x_nhwc, rm, act, drop_p, seed)
+            if two:
+                return y, y
             return y if attention is None else F.attention_block(y, *attention)
         if attention is not None:
             return F.cbn_attention(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
                                    act, *attention)
-        return F.cbn(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
-                     act, drop_p, seed)
+        if two and torch.is_grad_enabled():    # the output has two consumers: one tensor each (F._CbnTwoFn)
+            return F.cbn_two(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
+                             act, drop_p, seed)
+        y = F.cbn(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
+                  act, drop_p, seed)
+        return (y, y) if two else y
 
     def eval_coef(self):
         """The cached inference-time coefficients [C, 6] of this CBN (see _eval_forward), or None when there is no valid

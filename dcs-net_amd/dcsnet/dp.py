@@ -286,6 +286,12 @@ class TrainStep:
                 warnings.warn(f'TrainStep: optimizer graph capture failed ({type(e).__name__}: {e}); optimizer runs eagerly')
                 torch.cuda.synchronize()
 
+    def input_buffers(self):
+        """(noise, noisy, clean) device tensors the captured step reads — None before capture.  A data pipeline that writes
+        the next batch straight into them (e.g. `buf.copy_(pinned_host_tensor, non_blocking=True)`) and passes THEM to
+        __call__ spares the step its three device-to-device staging copies (16.8 MB each at [32,256,256])."""
+        return None if self._static_batch is None else tuple(self._static_batch)
+
     def __call__(self, batch, batch_idx=0):
         if not self.use_graph:
             return self._eager(batch, batch_idx)

@@ -188,6 +188,45 @@ def cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_s
                         drop_p, seed)
 
 
+class _CbnTwoFn(torch.autograd.Function):
+    """_CbnFn whose output is handed out TWICE (two tensors over one storage) for a stage output with two consumers
+    (the next encoder conv and a skip attention, c_network.py:193-197 / :208-211).  Autograd then delivers the two
+    cotangents separately and the CBN backward kernels add them on the fly (dcs_cbn_bwd_add g_out2) instead of an
+    element-wise add launch over the activation per stage."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, drop_p, seed):
+        y, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats,
+                                 act, drop_p, seed)
+        ctx.cfg = (bool(use_batch_stats), act, float(drop_p), int(seed), weight is not None)
+        ctx.sinks = (_sink(weight), _sink(bias))
+        ctx.save_for_backward(x, weight, stats, coef)
+        ctx.set_materialize_grads(False)
+        y2 = torch.empty(0, dtype=y.dtype, device=y.device).set_(y.untyped_storage(), y.storage_offset(), y.shape, y.stride())
+        return y, y2
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        x, weight, stats, coef = ctx.saved_tensors
+        use_batch, act, drop_p, seed, affine = ctx.cfg
+        if g_a is None and g_b is None:
+            return (None,) * 11
+        if g_a is None:
+            g_a, g_b = g_b, None
+        g_x, g_w, g_b_ = ops.cbn_bwd(x, g_a.contiguous(), weight, stats, coef, use_batch, act, drop_p, seed, affine,
+                                     ctx.sinks, g_out2=None if g_b is None else g_b.contiguous())
+        g_w = None if ctx.sinks[0] is not None else g_w
+        g_b_ = None if ctx.sinks[1] is not None else g_b_
+        return g_x, g_w, g_b_, None, None, None, None, None, None, None, None
+
+
+def cbn_two(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act=ACT_NONE,
+            drop_p=0.0, seed=0):
+    """(y, y') — the same values, for two different consumers (see _CbnTwoFn)."""
+    return _CbnTwoFn.apply(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
+                           drop_p, seed)
+
+
 def channel_attention(x, fc0_r, fc0_i, fc2_r, fc2_i):
     """ComplexChannelAttention (c_network.py:53-69).  fc*_r/_i: the 1x1 conv weights."""
     w1, _ = packed_weight(fc0_r, fc0_i, None, None, False)     # [1, C, Ch, 2]

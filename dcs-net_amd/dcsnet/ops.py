@@ -47,7 +47,7 @@ def set_conv_precision(mode):
 
 
 def set_conv_schedule(mode):
-    """'pipe' (default: persistent workgroups, LDS-DMA double buffering) or 'classic' (one patch per workgroup) for the
+    """'classic' (default: one patch per workgroup) or 'pipe' (persistent workgroups, LDS-DMA double buffering) for the
     fp32 MFMA conv kernels; bit-identical results (dcs_set_conv_schedule)."""
     check(_lib.load().dcs_set_conv_schedule({'classic': 0, 'pipe': 1}[mode]), 'dcs_set_conv_schedule')
 
@@ -386,11 +386,15 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
 
 
 def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, seed=0, affine=True, outs=None,
-            g_add=None):
+            g_add=None, g_out2=None):
     """Backward of cbn(): returns (g_x, g_weight [C,3], g_bias [C,2]).  `outs`: optional destinations for
-    (g_weight, g_bias).  g_add [B,C,2]: the cotangent is g_out + g_add[b, c] / (H*W) (attention_bwd's g_pooled)."""
+    (g_weight, g_bias).  g_add [B,C,2]: the cotangent is g_out + g_add[b, c] / (H*W) (attention_bwd's g_pooled).
+    g_out2: a second cotangent of y (another consumer's), added on the fly."""
     _chk(x, 'x', 5)
     _chk(g_out, 'g_out', 5)
+    _chk(g_out2, 'g_out2', 5)
+    if g_out2 is not None and g_out2.shape != g_out.shape:
+        raise _lib.DcsHipError(f'cbn_bwd: g_out {tuple(g_out.shape)} vs g_out2 {tuple(g_out2.shape)}')
     B, H, W, C, _ = x.shape
     P = B * H * W
     g_x = torch.empty_like(x)
@@ -406,7 +410,7 @@ def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, see
         _chk(g_add, 'g_add', 3)
     check(lib.dcs_cbn_bwd_add(ptr(x), ptr(g_out), ptr(g_x), ptr(weight), ptr(stats), ptr(coef), ptr(g_w), ptr(g_b),
                               ptr(ws), ws.numel(), P, C, int(bool(use_batch_stats)), act, float(drop_p), int(seed),
-                              ptr(SEED_STATE), ptr(g_add), 1.0 / (H * W), H * W, cur_stream()), 'dcs_cbn_bwd_add')
+                              ptr(SEED_STATE), ptr(g_add), 1.0 / (H * W), H * W, ptr(g_out2), cur_stream()), 'dcs_cbn_bwd_add')
     return g_x, g_w, g_b
 
 

@@ -223,13 +223,16 @@ int  dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const float* we
                  const float* stats, const float* coef, float* g_weight, float* g_bias,
                  void* workspace, long workspace_bytes, long P, int C, int use_batch_stats, int act,
                  float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
-/* dcs_cbn_bwd of g_out[b][p][c] + add_scale * g_add[b][c] (g_add complex[B][C], HW pixels per sample, P = B*HW):
- * the broadcast half of an average pool's backward folded into this consumer (see dcs_attention_bwd_x). */
+/* dcs_cbn_bwd of g_out[b][p][c] + g_out2[b][p][c] + add_scale * g_add[b][c] (g_add complex[B][C], HW pixels per
+ * sample, P = B*HW; g_out2 shaped like g_out; either may be NULL):
+ *   g_add   the broadcast half of an average pool's backward folded into this consumer (see dcs_attention_bwd_x);
+ *   g_out2  the cotangent of a SECOND consumer of y — an encoder stage's output feeds the next conv and a skip
+ *           attention (c_network.py:193-197, :208-211): autograd would first add the two with an element-wise kernel. */
 int  dcs_cbn_bwd_add(const float* x, const float* g_out, float* g_x, const float* weight, const float* stats,
                      const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
                      long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
                      const unsigned long long* seed_dev, const float* g_add, float add_scale, long HW,
-                     dcs_stream_t stream);
+                     const float* g_out2, dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * ComplexChannelAttention (c_network.py:53-69): per sample, mean over (F,T) of every
@@ -524,11 +527,11 @@ int dcs_tap_rows_wgrad_scatter(const float* gt_r, const float* gt_i, float* gw_r
 int dcs_set_conv_precision(int mode);
 int dcs_get_conv_precision(void);
 
-/* Schedule of the fp32 MFMA convolution kernels (forward, data gradient): 1 (default) = persistent workgroups with a
- * loader wave and an LDS-DMA double-buffered patch (csrc/conv_pipe.hip), 0 = one patch per workgroup with a synchronous
- * gather (csrc/conv_mfma.hip).  Same GEMM, same panels, same accumulation order: the two produce bit-identical results
+/* Schedule of the fp32 MFMA convolution kernels (forward, data gradient): 0 (default) = one patch per workgroup with a
+ * synchronous gather (csrc/conv_mfma.hip), 1 = persistent workgroups with an LDS-DMA double-buffered patch
+ * (csrc/conv_pipe.hip; measured at parity or behind, kept as the documented alternative).  Same GEMM, same panels, same accumulation order: the two produce bit-identical results
  * (tests/test_hip_parity.py::test_pipelined_conv_schedule_is_bit_identical); the switch exists for that test and for
- * A/B timing inside one process.  Process-wide; also read once from the environment (DCS_CONV_PIPE=0). */
+ * A/B timing inside one process.  Process-wide; also read once from the environment (DCS_CONV_PIPE=1). */
 int dcs_set_conv_schedule(int mode);
 int dcs_get_conv_schedule(void);
 
