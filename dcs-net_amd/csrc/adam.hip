@@ -72,7 +72,7 @@ extern "C" int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* 
     const long n4 = n / 4;
     long nb = (n4 + kThreads * 2 - 1) / (kThreads * 2);
     const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-    hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid), dim3(kThreads), 0, dcs_stream(stream), (float4*)p,
+    DCS_LAUNCH(adam_amsgrad_kernel, dim3(grid), dim3(kThreads), 0, dcs_stream(stream), (float4*)p,
                        (const float4*)g, (float4*)m, (float4*)v, (float4*)vmax, grad_norm, max_norm, grad_scale, n4, n,
                        lr, beta1, beta2, eps, weight_decay, bc1, bc2s, step_dev, skip);
     DCS_CHECK_LAUNCH();
@@ -92,14 +92,14 @@ __global__ void step_advance_kernel(const float* __restrict__ skip, int* __restr
 
 extern "C" int dcs_step_guard(const float* loss, float* skip, dcs_stream_t stream) {
     if (!loss || !skip) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(step_guard_kernel, dim3(1), dim3(1), 0, dcs_stream(stream), loss, skip);
+    DCS_LAUNCH(step_guard_kernel, dim3(1), dim3(1), 0, dcs_stream(stream), loss, skip);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
 
 extern "C" int dcs_step_advance(const float* skip, int* step_dev, long long* seed_dev, dcs_stream_t stream) {
     if (!step_dev && !seed_dev) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, dcs_stream(stream), skip, step_dev, seed_dev);
+    DCS_LAUNCH(step_advance_kernel, dim3(1), dim3(1), 0, dcs_stream(stream), skip, step_dev, seed_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

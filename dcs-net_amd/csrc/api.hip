@@ -1,7 +1,7 @@
 // api.hip — version / error-string entry points of include/dcsnet_hip.h.
 #include "dcs_common.h"
 
-extern "C" int dcs_abi_version(void) { return 6; }
+extern "C" int dcs_abi_version(void) { return 8; }
 
 extern "C" const char* dcs_error_string(int code) {
     switch (code) {
@@ -41,3 +41,61 @@ extern "C" int dcs_set_conv_precision(int mode) {
 }
 
 extern "C" int dcs_get_conv_precision(void) { return g_conv_precision; }
+
+// ---- dcs_stream_hold: park `stream` until the host releases it ----------------------------------------------------
+// One wave polls a word of PINNED HOST memory (system-scope relaxed loads, s_sleep between polls) and exits when it
+// becomes non-zero — or after timeout_ms by the 100 MHz real-time counter, so the wave always terminates.  A measuring
+// harness enqueues a whole step of launches and event records behind it and then writes the word: the kernels run back
+// to back as they do under hipGraph replay, instead of at the pace of the host's launch calls (bench.py's roofline
+// pass).  No compute entry point depends on it.
+namespace {
+__global__ void stream_hold_kernel(const int* flag, unsigned long long timeout_ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) break;
+    }
+}
+}  // namespace
+
+extern "C" int dcs_stream_hold(const int* host_flag, int timeout_ms, dcs_stream_t stream) {
+    if (!host_flag || timeout_ms <= 0 || timeout_ms > 10000) return DCS_ERR_BADARG;
+    DCS_LAUNCH(stream_hold_kernel, dim3(1), dim3(1), 0, dcs_stream(stream), host_flag,
+                       (unsigned long long)timeout_ms * 100000ULL);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// ---- kernel timer: exact per-kernel durations without a profiler (see DCS_LAUNCH in dcs_common.h) ---------------------
+#include <vector>
+DcsKernelTimer g_dcs_ktimer = {nullptr, nullptr, false, false};
+namespace {
+struct Slot { hipEvent_t start, stop; bool used; };
+std::vector<Slot> g_slots;
+}  // namespace
+
+extern "C" int dcs_kernel_timer_begin(int slot) {
+    if (slot < 0 || slot > (1 << 20) || g_dcs_ktimer.armed) return DCS_ERR_BADARG;
+    while ((int)g_slots.size() <= slot) {
+        Slot s{nullptr, nullptr, false};
+        if (hipEventCreate(&s.start) != hipSuccess || hipEventCreate(&s.stop) != hipSuccess) return DCS_ERR_LAUNCH;
+        g_slots.push_back(s);
+    }
+    g_slots[slot].used = true;
+    g_dcs_ktimer.start = g_slots[slot].start;
+    g_dcs_ktimer.stop = g_slots[slot].stop;
+    g_dcs_ktimer.first = true;
+    g_dcs_ktimer.armed = true;
+    return DCS_OK;
+}
+
+extern "C" int dcs_kernel_timer_end(void) {
+    const bool launched = g_dcs_ktimer.armed && !g_dcs_ktimer.first;
+    g_dcs_ktimer.armed = false;
+    return launched ? DCS_OK : 1;                       // 1: nothing was launched while the slot was armed
+}
+
+extern "C" int dcs_kernel_timer_read(int slot, float* ms) {
+    if (slot < 0 || slot >= (int)g_slots.size() || !g_slots[slot].used || !ms) return DCS_ERR_BADARG;
+    return hipEventElapsedTime(ms, g_slots[slot].start, g_slots[slot].stop) == hipSuccess ? DCS_OK : DCS_ERR_LAUNCH;
+}

@@ -262,11 +262,11 @@ extern "C" int dcs_channel_attention_fwd(const float* x, const float* w1, const 
     if (workspace_bytes < (long)B * nch * C * 2 * (long)sizeof(double)) return DCS_ERR_WORKSPACE;
     hipStream_t s = dcs_stream(stream);
     const CaPoolP pp{x, (double*)workspace, HW, C, G, nch};
-    hipLaunchKernelGGL(ca_pool_kernel, dim3(nch, B), dim3(kThreads), 0, s, pp);
+    DCS_LAUNCH(ca_pool_kernel, dim3(nch, B), dim3(kThreads), 0, s, pp);
     DCS_CHECK_LAUNCH();
     const CaFcP fp{(const double*)workspace, nch, (const float2*)w1, (const float2*)w2, (float2*)ca_out, (float2*)pooled_out,
                    (float2*)hidden_out, HW, C, Ch};
-    hipLaunchKernelGGL(ca_fc_kernel, dim3(B), dim3(kThreads), 0, s, fp);
+    DCS_LAUNCH(ca_fc_kernel, dim3(B), dim3(kThreads), 0, s, fp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -277,7 +277,7 @@ extern "C" int dcs_spatial_pool_fwd(const float* x, const float* ca, float* pool
     if (!x || !pooled || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
     const int nx = stream_grid(HW, G, B);
     const SpPoolP sp{x, ca, (float4*)pooled, HW, C, G, nx};
-    hipLaunchKernelGGL(spatial_pool_kernel, dim3(nx, B), dim3(kThreads), 0, dcs_stream(stream), sp);
+    DCS_LAUNCH(spatial_pool_kernel, dim3(nx, B), dim3(kThreads), 0, dcs_stream(stream), sp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -291,10 +291,10 @@ extern "C" int dcs_attention_apply_fwd(const float* x, const float* ca, const fl
     dim3 grid(nx, B);
     const ApplyP ap{x, ca, (const float2*)sa, y, HW, C, G, nx};
     if (drop_p > 0.f)
-        hipLaunchKernelGGL(attention_apply_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), ap, drop_p,
+        DCS_LAUNCH(attention_apply_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), ap, drop_p,
                            (uint64_t)seed, (const uint64_t*)seed_dev);
     else
-        hipLaunchKernelGGL(attention_apply_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), ap, drop_p,
+        DCS_LAUNCH(attention_apply_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), ap, drop_p,
                            (uint64_t)seed, (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -349,15 +349,15 @@ extern "C" int dcs_attention_fwd_batched(int n, const dcs_attention_item* items,
         a.Hv = it.H; a.Wv = it.W; a.Hout = it.H; a.Wout = it.W;
     }
     hipStream_t s = dcs_stream(stream);
-    hipLaunchKernelGGL(ca_pool_multi_kernel, dim3(nx_pool, B, n), dim3(kThreads), 0, s, tp);
+    DCS_LAUNCH(ca_pool_multi_kernel, dim3(nx_pool, B, n), dim3(kThreads), 0, s, tp);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ca_fc_multi_kernel, dim3(B, 1, n), dim3(kThreads), 0, s, tf);
+    DCS_LAUNCH(ca_fc_multi_kernel, dim3(B, 1, n), dim3(kThreads), 0, s, tf);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(spatial_pool_multi_kernel, dim3(nx_stream, B, n), dim3(kThreads), 0, s, ts);
+    DCS_LAUNCH(spatial_pool_multi_kernel, dim3(nx_stream, B, n), dim3(kThreads), 0, s, ts);
     DCS_CHECK_LAUNCH();
     const int rc = dcs_conv_direct_multi(ca_, n, s);
     if (rc != DCS_OK) return rc;
-    hipLaunchKernelGGL(attention_apply_multi_kernel, dim3(nx_stream, B, n), dim3(kThreads), 0, s, ta);
+    DCS_LAUNCH(attention_apply_multi_kernel, dim3(nx_stream, B, n), dim3(kThreads), 0, s, ta);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -367,7 +367,7 @@ extern "C" int dcs_dropout_fwd(const float* x, float* y, long n, float drop_p, u
     if (!x || !y || n <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
     long nb = (n + kThreads * 4 - 1) / (kThreads * 4);
     const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid), dim3(kThreads), 0, dcs_stream(stream), x, y, n, drop_p,
+    DCS_LAUNCH(dropout_kernel, dim3(grid), dim3(kThreads), 0, dcs_stream(stream), x, y, n, drop_p,
                        (uint64_t)seed, (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

@@ -326,10 +326,10 @@ extern "C" int dcs_attention_bwd_sa(const float* x, const float* g_out, const fl
     dim3 grid(nx, B);
     const BwdSaP sp{x, g_out, ca, (const float2*)sa, (float2*)g_pre, HW, G, nx};
     if (drop_p > 0.f)
-        hipLaunchKernelGGL(att_bwd_sa_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), sp, drop_p, (uint64_t)seed,
+        DCS_LAUNCH(att_bwd_sa_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), sp, drop_p, (uint64_t)seed,
                            (const uint64_t*)seed_dev);
     else
-        hipLaunchKernelGGL(att_bwd_sa_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), sp, drop_p, (uint64_t)seed,
+        DCS_LAUNCH(att_bwd_sa_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), sp, drop_p, (uint64_t)seed,
                            (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -365,13 +365,13 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
     dim3 grid(nch, B);
     const BwdXP xp{x, g_out, ca, (const float2*)sa, (const float4*)g_sp, g_x, part, HW, C, G, nch};
     if (drop_p > 0.f)
-        hipLaunchKernelGGL(att_bwd_x_kernel<true>, grid, dim3(kThreads), 0, s, xp, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+        DCS_LAUNCH(att_bwd_x_kernel<true>, grid, dim3(kThreads), 0, s, xp, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     else
-        hipLaunchKernelGGL(att_bwd_x_kernel<false>, grid, dim3(kThreads), 0, s, xp, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+        DCS_LAUNCH(att_bwd_x_kernel<false>, grid, dim3(kThreads), 0, s, xp, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
     DCS_CHECK_LAUNCH();
     const CaBwdP cp{(const double*)part, nch, (const float2*)ca, (const float2*)hidden, (const float2*)w1, (const float2*)w2, go, gh,
                     gpooled, C, Ch};
-    hipLaunchKernelGGL(ca_bwd_sample_kernel, dim3(B), dim3(kThreads), 0, s, cp);
+    DCS_LAUNCH(ca_bwd_sample_kernel, dim3(B), dim3(kThreads), 0, s, cp);
     DCS_CHECK_LAUNCH();
     CaWeightArgs cw;
     cw.go = go; cw.gh = gh; cw.pooled = (const float2*)pooled; cw.hidden = (const float2*)hidden;
@@ -380,7 +380,7 @@ extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const flo
     const int nx_pool = g_pooled ? 0 : stream_grid(HW, G, B);
     const int nxw = nx_pool + (C * Ch * kWLanes + kThreads - 1) / kThreads;
     const PoolP pp{g_x, (const float*)gpooled, HW, G, 1.f / (float)HW, nx_pool, nxw, cw};
-    hipLaunchKernelGGL(att_bwd_pool_kernel, dim3(nxw, g_pooled ? 1 : B), dim3(kThreads), 0, s, pp);
+    DCS_LAUNCH(att_bwd_pool_kernel, dim3(nxw, g_pooled ? 1 : B), dim3(kThreads), 0, s, pp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -447,15 +447,15 @@ extern "C" int dcs_attention_bwd_batched(int n, const dcs_attention_item* items,
         a.Hv = it.H; a.Wv = it.W; a.Hout = it.H; a.Wout = it.W;
     }
     hipStream_t s = dcs_stream(stream);
-    hipLaunchKernelGGL(att_bwd_sa_multi_kernel, dim3(nx_sa, B, n), dim3(kThreads), 0, s, tsa);
+    DCS_LAUNCH(att_bwd_sa_multi_kernel, dim3(nx_sa, B, n), dim3(kThreads), 0, s, tsa);
     DCS_CHECK_LAUNCH();
     const int rc = dcs_conv_direct_multi(dg, n, s);
     if (rc != DCS_OK) return rc;
-    hipLaunchKernelGGL(att_bwd_x_multi_kernel, dim3(nx_x, B, n), dim3(kThreads), 0, s, tx);
+    DCS_LAUNCH(att_bwd_x_multi_kernel, dim3(nx_x, B, n), dim3(kThreads), 0, s, tx);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ca_bwd_sample_multi_kernel, dim3(B, 1, n), dim3(kThreads), 0, s, tc);
+    DCS_LAUNCH(ca_bwd_sample_multi_kernel, dim3(B, 1, n), dim3(kThreads), 0, s, tc);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(att_bwd_pool_multi_kernel, dim3(nx_p, B, n), dim3(kThreads), 0, s, tp);
+    DCS_LAUNCH(att_bwd_pool_multi_kernel, dim3(nx_p, B, n), dim3(kThreads), 0, s, tp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

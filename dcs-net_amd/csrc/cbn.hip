@@ -266,12 +266,12 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
     hipStream_t s = dcs_stream(stream);
     if (use_batch_stats == 1) {
         if (!workspace || workspace_bytes < (long)g.nblocks * C * 5 * (long)sizeof(double)) return DCS_ERR_WORKSPACE;
-        hipLaunchKernelGGL(cbn_stats_kernel, dim3(g.nblocks), dim3(kThreads), 0, s, x, (double*)workspace, P, C,
+        DCS_LAUNCH(cbn_stats_kernel, dim3(g.nblocks), dim3(kThreads), 0, s, x, (double*)workspace, P, C,
                            g.vec_per_row, g.rows_per_iter);
         DCS_CHECK_LAUNCH();
     }
     if (use_batch_stats != 2) {            // 2: coef_out already holds the coefficients of an earlier eval-mode call
-        hipLaunchKernelGGL(cbn_finalize_kernel, dim3(C), dim3(64), 0, s, x, (const double*)workspace,
+        DCS_LAUNCH(cbn_finalize_kernel, dim3(C), dim3(64), 0, s, x, (const double*)workspace,
                            g.nblocks, weight, bias, running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum,
                            use_batch_stats);
         DCS_CHECK_LAUNCH();
@@ -281,7 +281,7 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
     long nb = (iters + 3) / 4;
     int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
 #define DCS_CBN_APPLY(A, D)                                                                                   \
-    hipLaunchKernelGGL((cbn_apply_kernel<A, D>), dim3(grid), dim3(kThreads), 0, s, x, y, coef_out, P, C,         \
+    DCS_LAUNCH((cbn_apply_kernel<A, D>), dim3(grid), dim3(kThreads), 0, s, x, y, coef_out, P, C,         \
                        g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev)
     const bool drop = drop_p > 0.f;
     if (act == DCS_ACT_RELU) { if (drop) DCS_CBN_APPLY(DCS_ACT_RELU, true); else DCS_CBN_APPLY(DCS_ACT_RELU, false); }

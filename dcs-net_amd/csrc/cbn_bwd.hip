@@ -297,12 +297,12 @@ extern "C" int dcs_cbn_bwd_add(const float* x, const float* g_out, float* g_x, c
     const int grid2 = cbn::stream_grid(P, C, g);
 #define DCS_CBN_BWD(A, D)                                                                                          \
     do {                                                                                                           \
-        hipLaunchKernelGGL((cbn_bwd_reduce_kernel<A, D>), dim3(g.nblocks), dim3(kThreads), 0, s, x, g_out, coef,    \
+        DCS_LAUNCH((cbn_bwd_reduce_kernel<A, D>), dim3(g.nblocks), dim3(kThreads), 0, s, x, g_out, coef,    \
                            stats, part, P, C, g.vec_per_row, g.rows_per_iter, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev,   \
                            ga, add_scale, HW, gb);                                                                 \
-        hipLaunchKernelGGL(cbn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part,      \
+        DCS_LAUNCH(cbn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part,      \
                            g.nblocks, weight, stats, coef, g_weight, g_bias, bcoef, P, C, use_batch_stats);        \
-        hipLaunchKernelGGL((cbn_bwd_apply_kernel<A, D>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef,    \
+        DCS_LAUNCH((cbn_bwd_apply_kernel<A, D>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef,    \
                            stats, (const float*)bcoef, P, C, g.vec_per_row, g.rows_per_iter, drop_p,               \
                            (uint64_t)seed, (const uint64_t*)seed_dev, ga, add_scale, HW, gb);                      \
     } while (0)

@@ -290,8 +290,8 @@ int launch_direct_multi(ConvArgs* a, int n, hipStream_t stream) {
     }
     if (lds > 64 * 1024 || a[0].B > 65535) return DCS_ERR_BADARG;
     dim3 grid(tiles, n, a[0].B);
-    if (cob == 1) hipLaunchKernelGGL(cconv_direct_multi_kernel<1>, grid, dim3(TH * TW), lds, stream, t);
-    else hipLaunchKernelGGL(cconv_direct_multi_kernel<2>, grid, dim3(TH * TW), lds, stream, t);
+    if (cob == 1) DCS_LAUNCH(cconv_direct_multi_kernel<1>, grid, dim3(TH * TW), lds, stream, t);
+    else DCS_LAUNCH(cconv_direct_multi_kernel<2>, grid, dim3(TH * TW), lds, stream, t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -313,10 +313,10 @@ int launch_direct(ConvArgs& a, hipStream_t stream) {
     dim3 grid(a.tiles_w * a.tiles_h, Cout / cob, a.B);
     if (grid.y > 65535 || grid.z > 65535) return DCS_ERR_BADARG;
     switch (cob) {
-        case 8: hipLaunchKernelGGL(cconv_direct_kernel<8>, grid, dim3(TH * TW), lds, stream, a); break;
-        case 4: hipLaunchKernelGGL(cconv_direct_kernel<4>, grid, dim3(TH * TW), lds, stream, a); break;
-        case 2: hipLaunchKernelGGL(cconv_direct_kernel<2>, grid, dim3(TH * TW), lds, stream, a); break;
-        default: hipLaunchKernelGGL(cconv_direct_kernel<1>, grid, dim3(TH * TW), lds, stream, a); break;
+        case 8: DCS_LAUNCH(cconv_direct_kernel<8>, grid, dim3(TH * TW), lds, stream, a); break;
+        case 4: DCS_LAUNCH(cconv_direct_kernel<4>, grid, dim3(TH * TW), lds, stream, a); break;
+        case 2: DCS_LAUNCH(cconv_direct_kernel<2>, grid, dim3(TH * TW), lds, stream, a); break;
+        default: DCS_LAUNCH(cconv_direct_kernel<1>, grid, dim3(TH * TW), lds, stream, a); break;
     }
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -642,7 +642,7 @@ extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float*
     const long n = (long)B * Hin * Win * Cin;
     long nb = (n + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(upsample_cat_bwd_kernel, dim3((int)nb), dim3(256), 0, s, (const float2*)gxv, (float2*)gx1,
+    DCS_LAUNCH(upsample_cat_bwd_kernel, dim3((int)nb), dim3(256), 0, s, (const float2*)gxv, (float2*)gx1,
                        (float2*)gx2, B, Hin, Win, C1, C2, up_f, up_t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -738,7 +738,7 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(w.n_slabs, n_ci * w.n_co_chunks);
     if (grid.y > 65535) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(fn, grid, dim3(TH * TW), lds, s, w);
+    DCS_LAUNCH(fn, grid, dim3(TH * TW), lds, s, w);
     DCS_CHECK_LAUNCH();
     return launch_wgrad_reduce(w.slab_w, w.slab_b, w.n_slabs, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed, s);
 }
@@ -750,7 +750,7 @@ extern "C" int dcs_upsample_cat_bwd(const float* gxv, float* gx1, float* gx2, in
     const long n = (long)B * Hin * Win * (C1 + C2);
     long nb = (n + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(upsample_cat_bwd_kernel, dim3((int)nb), dim3(256), 0, dcs_stream(stream), (const float2*)gxv,
+    DCS_LAUNCH(upsample_cat_bwd_kernel, dim3((int)nb), dim3(256), 0, dcs_stream(stream), (const float2*)gxv,
                        (float2*)gx1, (float2*)gx2, B, Hin, Win, C1, C2, up_f, up_t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

@@ -314,9 +314,9 @@ int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream) {
         resident = cus * 4;
     }
     const int grid = ntile < resident ? (int)ntile : resident;
-    if (a.act == DCS_ACT_NONE) hipLaunchKernelGGL(cconv_enc0_kernel<DCS_ACT_NONE>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
-    else if (a.act == DCS_ACT_RELU) hipLaunchKernelGGL(cconv_enc0_kernel<DCS_ACT_RELU>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
-    else hipLaunchKernelGGL(cconv_enc0_kernel<-1>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
+    if (a.act == DCS_ACT_NONE) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_NONE>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
+    else if (a.act == DCS_ACT_RELU) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_RELU>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
+    else DCS_LAUNCH(cconv_enc0_kernel<-1>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -341,7 +341,7 @@ int dcs_conv_enc0_wgrad_launch(conv::Args a, const float* gy, float2* slab_w, fl
     // time and leave fewer slabs to reduce
     const int rounds = (int)((ntile + grid - 1) / grid);
     grid = (int)((ntile + rounds - 1) / rounds);
-    hipLaunchKernelGGL(cconv_enc0_wgrad_kernel, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, gy, slab_w, slab_b);
+    DCS_LAUNCH(cconv_enc0_wgrad_kernel, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, gy, slab_w, slab_b);
     DCS_CHECK_LAUNCH();
     *n_used = grid;
     return DCS_OK;

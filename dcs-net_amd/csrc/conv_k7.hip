@@ -118,9 +118,9 @@ int dcs_conv_k7_launch(const conv::Args* a, int n, hipStream_t stream) {
         tiles = p.tiles > tiles ? p.tiles : tiles;
     }
     dim3 grid(tiles, n, a[0].B);
-    if (a[0].C1 == 2) hipLaunchKernelGGL((cconv_k7_kernel<2, 1>), grid, dim3(256), 0, stream, tb);
-    else if (a[0].Cout == 2) hipLaunchKernelGGL((cconv_k7_kernel<1, 2>), grid, dim3(256), 0, stream, tb);
-    else hipLaunchKernelGGL((cconv_k7_kernel<1, 1>), grid, dim3(256), 0, stream, tb);
+    if (a[0].C1 == 2) DCS_LAUNCH((cconv_k7_kernel<2, 1>), grid, dim3(256), 0, stream, tb);
+    else if (a[0].Cout == 2) DCS_LAUNCH((cconv_k7_kernel<1, 2>), grid, dim3(256), 0, stream, tb);
+    else DCS_LAUNCH((cconv_k7_kernel<1, 1>), grid, dim3(256), 0, stream, tb);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

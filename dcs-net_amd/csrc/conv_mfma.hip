@@ -444,7 +444,7 @@ int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
+    DCS_LAUNCH(fn, grid, dim3(256), lds, stream, m);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -479,7 +479,7 @@ int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
     auto fn = cconv_mfma16_kernel<CH>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, 1, m.ncls);
-    hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, m);
+    DCS_LAUNCH(fn, grid, dim3(256), lds, stream, m);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -661,7 +661,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
     }
     if (rc != DCS_OK || m.ksplit <= 1) return rc;
     const long n4 = m.slab_floats / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)m.part,
+    DCS_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)m.part,
                        m.ksplit, m.slab_floats, (const float*)a.bias, (float*)a.y, y2, nsplit, m.N, a.act, a.coef);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

@@ -404,7 +404,7 @@ int launch_one(PArgs& pa, size_t lds, hipStream_t stream) {
     }
     long grid = (long)per_cu * num_cus();
     if (grid > pa.n_units) grid = pa.n_units;
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, stream, pa);
+    DCS_LAUNCH(fn, dim3((unsigned)grid), dim3(256), lds, stream, pa);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

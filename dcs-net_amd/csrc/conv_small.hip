@@ -105,7 +105,7 @@ int dcs_conv_small_dgrad_launch(const float* gy, const float* wp_bwd, float* gx,
     d.tiles_w = (Wc + TW - 1) / TW; d.tiles_h = (Hc + TH - 1) / TH;
     dim3 grid(d.tiles_w * d.tiles_h, 4, B);
     if (grid.z > 65535) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(cconv_small_dgrad_s2_kernel, grid, dim3(TH * TW), 0, stream, d);
+    DCS_LAUNCH(cconv_small_dgrad_s2_kernel, grid, dim3(TH * TW), 0, stream, d);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

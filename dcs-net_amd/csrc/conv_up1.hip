@@ -128,7 +128,7 @@ extern "C" int dcs_cconv_up2_single_fwd(const float* x1, const float* x2, const 
     p.Hs = Hs; p.Ws = Ws; p.C1 = C1; p.C2 = C2; p.ct = ct;
     p.tiles_w = (Ws + SCT - 1) / SCT;
     p.tiles = p.tiles_w * ((Hs + SRT - 1) / SRT);
-    hipLaunchKernelGGL(cconv_up1_kernel, dim3(p.tiles, B), dim3(256), 0, dcs_stream(stream), p);
+    DCS_LAUNCH(cconv_up1_kernel, dim3(p.tiles, B), dim3(256), 0, dcs_stream(stream), p);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

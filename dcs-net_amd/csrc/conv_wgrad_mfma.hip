@@ -301,7 +301,7 @@ int launch(WArgs& w, int Cin, hipStream_t stream) {
     w.co_blocks = (a.Cout + co_per_block - 1) / co_per_block;
     dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks, w.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, w);
+    DCS_LAUNCH(fn, grid, dim3(256), lds, stream, w);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

@@ -279,8 +279,8 @@ int dcs_conv_wgrad_small_launch(const conv::Args& a, const float* gy, float2* sl
         g_small_deferred->push_back(w);
         return DCS_OK;
     }
-    if (a.C1 == 2) hipLaunchKernelGGL(cconv_wgrad_sa_kernel, dim3(n_slabs), dim3(256), 0, stream, w);
-    else hipLaunchKernelGGL((cconv_wgrad_small_kernel<1, 2>), dim3(n_slabs), dim3(256), 0, stream, w);
+    if (a.C1 == 2) DCS_LAUNCH(cconv_wgrad_sa_kernel, dim3(n_slabs), dim3(256), 0, stream, w);
+    else DCS_LAUNCH((cconv_wgrad_small_kernel<1, 2>), dim3(n_slabs), dim3(256), 0, stream, w);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -305,7 +305,7 @@ int dcs_conv_wgrad_small_flush(hipStream_t stream) {
             nb += (*jobs)[i].n_slabs;
         }
         t.blk0[t.n] = nb;
-        hipLaunchKernelGGL(cconv_wgrad_small_multi_kernel, dim3(nb), dim3(256), 0, stream, t);
+        DCS_LAUNCH(cconv_wgrad_small_multi_kernel, dim3(nb), dim3(256), 0, stream, t);
         if (hipGetLastError() != hipSuccess) rc = DCS_ERR_LAUNCH;
     }
     delete jobs;

@@ -1,10 +1,29 @@
 // dcs_common.h — shared helpers for the gfx950 kernels behind include/dcsnet_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/dcsnet_hip.h"
 
 #define DCS_WAVE 64
+
+// ---- kernel timer (dcs_kernel_timer_*, api.hip) ----------------------------------------------------------------------
+// While a slot is armed every launch of the library goes through hipExtLaunchKernelGGL with a start / stop event pair:
+// the command processor stamps the dispatch itself (what rocprofv3's kernel trace reports), not the stream around it —
+// an event pair recorded around a launch also times ~6-10 us of marker and dispatch latency.  The first launch after
+// arming donates the start stamp, every launch overwrites the stop stamp: a slot spans all the kernels of one C-ABI call.
+struct DcsKernelTimer { hipEvent_t start, stop; bool armed, first; };
+extern DcsKernelTimer g_dcs_ktimer;
+#define DCS_LAUNCH(kern, grid, block, lds, stream, ...)                                                               \
+    do {                                                                                                              \
+        if (g_dcs_ktimer.armed) {                                                                                     \
+            hipEvent_t s__ = g_dcs_ktimer.first ? g_dcs_ktimer.start : nullptr;                                      \
+            g_dcs_ktimer.first = false;                                                                               \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, s__, g_dcs_ktimer.stop, 0, __VA_ARGS__);            \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                          \
+        }                                                                                                             \
+    } while (0)
 
 #define DCS_CHECK_LAUNCH()                                   \
     do {                                                     \

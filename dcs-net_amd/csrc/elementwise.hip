@@ -37,7 +37,7 @@ inline int ew_grid(long n) {
 
 extern "C" int dcs_complex_act_fwd(const float* x, float* y, long n_floats, int act, dcs_stream_t stream) {
     if (!x || !y || n_floats <= 0 || act < DCS_ACT_NONE || act > DCS_ACT_SIGMOID) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(act_kernel, dim3(ew_grid(n_floats)), dim3(kThreads), 0, dcs_stream(stream), x, y, n_floats, act);
+    DCS_LAUNCH(act_kernel, dim3(ew_grid(n_floats)), dim3(kThreads), 0, dcs_stream(stream), x, y, n_floats, act);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -46,7 +46,7 @@ extern "C" int dcs_complex_upsample_fwd(const float* x, float* y, int B, int H, 
                                         dcs_stream_t stream) {
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || up_f < 1 || up_t < 1) return DCS_ERR_BADARG;
     const long n = (long)B * H * up_f * W * up_t * C;
-    hipLaunchKernelGGL(upsample_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)x,
+    DCS_LAUNCH(upsample_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)x,
                        (float2*)y, B, H, W, C, up_f, up_t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -208,15 +208,15 @@ extern "C" int dcs_tapsum_fwd(const float* z, float* y, const float* b_r, const 
         const long tiles = (long)B * ((Hs * up_f + TOY - 1) / TOY) * ((Ws * up_t + TOX - 1) / TOX);
         const dim3 grid((unsigned)(tiles < 8192 ? tiles : 8192));
         if (kh == 3 && kw == 3 && up_f == 2 && up_t == 2 && SR == 10 && SC == 34)
-            hipLaunchKernelGGL(tapsum_fwd_tiled_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
+            DCS_LAUNCH(tapsum_fwd_tiled_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
                                (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, SR, SC, b_r, b_i);
         else
-            hipLaunchKernelGGL(tapsum_fwd_tiled_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
+            DCS_LAUNCH(tapsum_fwd_tiled_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
                                (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, SR, SC, b_r, b_i);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     }
-    hipLaunchKernelGGL(tapsum_fwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
+    DCS_LAUNCH(tapsum_fwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)z,
                        (float2*)y, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t, b_r, b_i);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -233,14 +233,14 @@ extern "C" int dcs_tapsum_bwd(const float* gy, float* gz, float* gb_r, float* gb
     if (gb_r) {                                              // bias gradients of the Cout = 1 layer: complex sum of gy
         if (!workspace || workspace_bytes < dcs_tapsum_bwd_workspace_bytes()) return DCS_ERR_WORKSPACE;
         const long ny = (long)B * Hs * up_f * Ws * up_t;
-        hipLaunchKernelGGL(csum_partial_kernel, dim3(kSumBlocks), dim3(kThreads), 0, dcs_stream(stream), (const float2*)gy, ny,
+        DCS_LAUNCH(csum_partial_kernel, dim3(kSumBlocks), dim3(kThreads), 0, dcs_stream(stream), (const float2*)gy, ny,
                            (double*)workspace);
-        hipLaunchKernelGGL(csum_bias_final_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), (const double*)workspace,
+        DCS_LAUNCH(csum_bias_final_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), (const double*)workspace,
                            kSumBlocks, gb_r, gb_i);
         DCS_CHECK_LAUNCH();
     }
     const long n = (long)B * Hs * Ws * CT;
-    hipLaunchKernelGGL(tapsum_bwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)gy,
+    DCS_LAUNCH(tapsum_bwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)gy,
                        (float2*)gz, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void rfft512_kernel(const float2* __restrict__
 // X complex[frames][257] (one-sided spectra) -> y float[frames][512], unnormalised inverse real FFT
 extern "C" int dcs_irfft512_frames(const float* X, float* y, long frames, dcs_stream_t stream) {
     if (!X || !y || frames <= 0 || frames > (1L << 31)) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(irfft512_kernel, dim3((unsigned)((frames + kFramesPerWg - 1) / kFramesPerWg)), dim3(256), 0,
+    DCS_LAUNCH(irfft512_kernel, dim3((unsigned)((frames + kFramesPerWg - 1) / kFramesPerWg)), dim3(256), 0,
                        dcs_stream(stream), (const float2*)X, (float2*)y, frames);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -141,7 +141,7 @@ extern "C" int dcs_irfft512_frames(const float* X, float* y, long frames, dcs_st
 // g float[frames][512] -> G complex[frames][257], forward real FFT (no scaling)
 extern "C" int dcs_rfft512_frames(const float* g, float* G, long frames, dcs_stream_t stream) {
     if (!g || !G || frames <= 0 || frames > (1L << 31)) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(rfft512_kernel, dim3((unsigned)((frames + kFramesPerWg - 1) / kFramesPerWg)), dim3(256), 0,
+    DCS_LAUNCH(rfft512_kernel, dim3((unsigned)((frames + kFramesPerWg - 1) / kFramesPerWg)), dim3(256), 0,
                        dcs_stream(stream), (const float2*)g, (float2*)G, frames);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

@@ -181,7 +181,7 @@ extern "C" int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const 
                                   dcs_stream_t stream) {
     if (!g_out || !gates || !c_save || !w_hh || !g_pre || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || Hdim != kHBwd)
         return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(lstm_rec_bwd_kernel, dim3(n_sets * seqs_per_set * 2), dim3(4 * kHBwd), 0, dcs_stream(stream), g_out,
+    DCS_LAUNCH(lstm_rec_bwd_kernel, dim3(n_sets * seqs_per_set * 2), dim3(4 * kHBwd), 0, dcs_stream(stream), g_out,
                        gates, c_save, w_hh, g_pre, g_bias_part, S, seqs_per_set);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -196,13 +196,13 @@ extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out
     const int NS = n_sets * seqs_per_set;
     dim3 grid(NS * 2);
     if (Hdim == 128)
-        hipLaunchKernelGGL((lstm_rec_fwd_kernel<128, false>), grid, dim3(512), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
+        DCS_LAUNCH((lstm_rec_fwd_kernel<128, false>), grid, dim3(512), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
                            c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
     else if (gates_save)
-        hipLaunchKernelGGL((lstm_rec_fwd_kernel<64, true>), grid, dim3(256), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
+        DCS_LAUNCH((lstm_rec_fwd_kernel<64, true>), grid, dim3(256), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
                            c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
     else
-        hipLaunchKernelGGL((lstm_rec_fwd_kernel<64, false>), grid, dim3(256), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
+        DCS_LAUNCH((lstm_rec_fwd_kernel<64, false>), grid, dim3(256), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
                            c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

@@ -116,7 +116,7 @@ inline int ew_grid(long n) {
 
 extern "C" int dcs_bound_crm_fwd(const float* M_raw, float* M_out, long n, float eps, dcs_stream_t stream) {
     if (!M_raw || !M_out || n <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(bound_crm_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+    DCS_LAUNCH(bound_crm_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
                        (const float2*)M_raw, (float2*)M_out, n, eps);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -125,7 +125,7 @@ extern "C" int dcs_bound_crm_fwd(const float* M_raw, float* M_out, long n, float
 extern "C" int dcs_bound_mask_apply_fwd(const float* Y, const float* M_in, float* M_out, float* N_hat, float* S_hat,
                                         long n, float eps, dcs_stream_t stream) {
     if (!Y || !M_in || !M_out || !N_hat || !S_hat || n <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(bound_mask_apply_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+    DCS_LAUNCH(bound_mask_apply_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
                        (const float2*)Y, (const float2*)M_in, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -135,7 +135,7 @@ extern "C" int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const
                                         const float* g_S, float* g_Min, long n, float eps, dcs_stream_t stream) {
     if (!M_in || !g_Min || n <= 0) return DCS_ERR_BADARG;
     if ((g_N || g_S) && !Y) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(bound_mask_apply_bwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+    DCS_LAUNCH(bound_mask_apply_bwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
                        (const float2*)Y, (const float2*)M_in, (const float2*)g_M, (const float2*)g_N,
                        (const float2*)g_S, (float2*)g_Min, n, eps);
     DCS_CHECK_LAUNCH();
@@ -144,7 +144,7 @@ extern "C" int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const
 
 extern "C" int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, float eps, dcs_stream_t stream) {
     if (!S || !Y || !M || n <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(crm_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)S,
+    DCS_LAUNCH(crm_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)S,
                        (const float2*)Y, (float2*)M, n, eps);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

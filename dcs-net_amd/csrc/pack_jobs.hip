@@ -199,7 +199,7 @@ int emit(const Job& j, hipStream_t s) {
         std::lock_guard<std::mutex> lock(g_rec_mutex);
         if (g_rec) record(j);
     }
-    hipLaunchKernelGGL(pack_one_kernel, dim3((unsigned)dcs_cdiv(j.total, 256)), dim3(256), 0, s, j);
+    DCS_LAUNCH(pack_one_kernel, dim3((unsigned)dcs_cdiv(j.total, 256)), dim3(256), 0, s, j);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -244,7 +244,7 @@ extern "C" int dcs_tap_rows_wgrad_scatter(const float* gt_r, const float* gt_i, 
                                           int kw, int accumulate, dcs_stream_t stream) {
     if (!gt_r || !gt_i || !gw_r || !gw_i || Cin <= 0 || kh < 1 || kw < 1) return DCS_ERR_BADARG;
     const int n = Cin * kh * kw;
-    hipLaunchKernelGGL(tap_rows_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, dcs_stream(stream), gt_r, gt_i, gw_r, gw_i,
+    DCS_LAUNCH(tap_rows_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, dcs_stream(stream), gt_r, gt_i, gw_r, gw_i,
                        Cin, kh * kw, accumulate);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -317,7 +317,7 @@ extern "C" int dcs_pack_plan_run(const void* plan, dcs_stream_t stream) {
     const Plan* p = (const Plan*)plan;
     hipStream_t s = dcs_stream(stream);
     for (const Level& lv : p->levels) {
-        hipLaunchKernelGGL(packjob::pack_multi_kernel, dim3((unsigned)lv.nblocks), dim3(256), 0, s, lv.d_jobs, lv.d_blk0,
+        DCS_LAUNCH(packjob::pack_multi_kernel, dim3((unsigned)lv.nblocks), dim3(256), 0, s, lv.d_jobs, lv.d_blk0,
                            lv.nj);
         DCS_CHECK_LAUNCH();
     }

@@ -162,11 +162,11 @@ extern "C" int dcs_rattention_fwd(const float* x, const float* w1, const float* 
     float2* pooled = (float2*)ws;
     float2* sa = pooled + (long)B * HW;
     hipStream_t s = dcs_stream(stream);
-    hipLaunchKernelGGL(r_ca_maxpool_kernel, dim3(nch, B), dim3(kThreads), 0, s, x, part, HW, C, G);
+    DCS_LAUNCH(r_ca_maxpool_kernel, dim3(nch, B), dim3(kThreads), 0, s, x, part, HW, C, G);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(r_ca_fc_kernel, dim3(B), dim3(kThreads), 0, s, (const float*)part, nch, w1, w2, ca_out, C, Ch);
+    DCS_LAUNCH(r_ca_fc_kernel, dim3(B), dim3(kThreads), 0, s, (const float*)part, nch, w1, w2, ca_out, C, Ch);
     DCS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(r_spatial_pool_kernel, dim3(nxs, B), dim3(kThreads), 0, s, x, (const float*)ca_out, pooled, HW, C, G);
+    DCS_LAUNCH(r_spatial_pool_kernel, dim3(nxs, B), dim3(kThreads), 0, s, x, (const float*)ca_out, pooled, HW, C, G);
     DCS_CHECK_LAUNCH();
     conv::Args a{};
     a.x1 = pooled; a.x2 = nullptr; a.wp = (const float2*)wsa; a.bias = (const float2*)sa_bias; a.y = sa;
@@ -175,7 +175,7 @@ extern "C" int dcs_rattention_fwd(const float* x, const float* w1, const float* 
     a.Hv = H; a.Wv = W; a.Hout = H; a.Wout = W;
     const int rc = dcs_conv_direct_multi(&a, 1, s);
     if (rc != DCS_OK) return rc;
-    hipLaunchKernelGGL(r_apply_kernel, dim3(nxs, B), dim3(kThreads), 0, s, x, (const float*)ca_out, (const float2*)sa, y, HW, G);
+    DCS_LAUNCH(r_apply_kernel, dim3(nxs, B), dim3(kThreads), 0, s, x, (const float*)ca_out, (const float2*)sa, y, HW, G);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

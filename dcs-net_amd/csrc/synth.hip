@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void istft_ola_bwd_kernel(const float* __
 
 extern "C" int dcs_polar_frames_fwd(const float* z, float* out, int B, int F, int Fp, int T, float eps, dcs_stream_t stream) {
     if (!z || !out || B <= 0 || B > 65535 || F <= 0 || Fp < F || T <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(polar_frames_fwd_kernel, dim3((T + 31) / 32, (Fp + 31) / 32, B), dim3(kThreads), 0, dcs_stream(stream),
+    DCS_LAUNCH(polar_frames_fwd_kernel, dim3((T + 31) / 32, (Fp + 31) / 32, B), dim3(kThreads), 0, dcs_stream(stream),
                        (const float2*)z, (float2*)out, F, Fp, T, eps);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -156,7 +156,7 @@ extern "C" int dcs_polar_frames_fwd(const float* z, float* out, int B, int F, in
 extern "C" int dcs_polar_frames_bwd(const float* z, const float* g_out, float* g_z, int B, int F, int Fp, int T, float eps,
                                     int hermitian, dcs_stream_t stream) {
     if (!z || !g_out || !g_z || B <= 0 || B > 65535 || F <= 0 || Fp < F || T <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(polar_frames_bwd_kernel, dim3((T + 31) / 32, (F + 31) / 32, B), dim3(kThreads), 0, dcs_stream(stream),
+    DCS_LAUNCH(polar_frames_bwd_kernel, dim3((T + 31) / 32, (F + 31) / 32, B), dim3(kThreads), 0, dcs_stream(stream),
                        (const float2*)z, (const float2*)g_out, (float2*)g_z, F, Fp, T, eps, hermitian);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -170,7 +170,7 @@ static bool ola_ok(int B, int T, int n_fft, int hop) {
 extern "C" int dcs_istft_envelope(const float* window, float* inv_env, int T, int n_fft, int hop, dcs_stream_t stream) {
     if (!window || !inv_env || !ola_ok(1, T, n_fft, hop)) return DCS_ERR_BADARG;
     const int Lout = hop * (T - 1);
-    hipLaunchKernelGGL(istft_envelope_kernel, dim3((Lout + kThreads - 1) / kThreads), dim3(kThreads), 0, dcs_stream(stream),
+    DCS_LAUNCH(istft_envelope_kernel, dim3((Lout + kThreads - 1) / kThreads), dim3(kThreads), 0, dcs_stream(stream),
                        window, inv_env, T, n_fft, hop, Lout);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -180,7 +180,7 @@ extern "C" int dcs_istft_ola_fwd(const float* frames, const float* window, const
                                  int n_fft, int hop, float scale, dcs_stream_t stream) {
     if (!frames || !window || !inv_env || !y || !ola_ok(B, T, n_fft, hop)) return DCS_ERR_BADARG;
     const int Lout = hop * (T - 1);
-    hipLaunchKernelGGL(istft_ola_fwd_kernel, dim3((Lout + kThreads - 1) / kThreads, B), dim3(kThreads), 0,
+    DCS_LAUNCH(istft_ola_fwd_kernel, dim3((Lout + kThreads - 1) / kThreads, B), dim3(kThreads), 0,
                        dcs_stream(stream), frames, window, inv_env, y, T, n_fft, hop, Lout, scale);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -191,7 +191,7 @@ extern "C" int dcs_istft_ola_bwd(const float* g_y, const float* window, const fl
     if (!g_y || !window || !inv_env || !g_frames || !ola_ok(B, T, n_fft, hop)) return DCS_ERR_BADARG;
     const int Lout = hop * (T - 1);
     const long per = (long)T * n_fft;
-    hipLaunchKernelGGL(istft_ola_bwd_kernel, dim3((unsigned)((per + kThreads - 1) / kThreads), B), dim3(kThreads), 0,
+    DCS_LAUNCH(istft_ola_bwd_kernel, dim3((unsigned)((per + kThreads - 1) / kThreads), B), dim3(kThreads), 0,
                        dcs_stream(stream), g_y, window, inv_env, g_frames, T, n_fft, hop, Lout, scale);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void sisnr_losses_kernel(const float* __restric
 extern "C" int dcs_sisnr_losses_fwd(const float* snr_speech, const float* snr_noise, float* out3, int B, float alpha,
                                     dcs_stream_t stream) {
     if (!snr_speech || !snr_noise || !out3 || B <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(sisnr_losses_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), snr_speech, snr_noise, out3, B, alpha);
+    DCS_LAUNCH(sisnr_losses_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), snr_speech, snr_noise, out3, B, alpha);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -280,7 +280,7 @@ extern "C" int dcs_sisnr_losses_fwd(const float* snr_speech, const float* snr_no
 extern "C" int dcs_sisnr_fwd(const float* clean, const float* est, float* snr, float* coef, int B, int L, float eps,
                              dcs_stream_t stream) {
     if (!clean || !est || !snr || !coef || B <= 0 || L <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(sisnr_fwd_kernel, dim3(B), dim3(kThreads), 0, dcs_stream(stream), clean, est, L, eps, snr, coef);
+    DCS_LAUNCH(sisnr_fwd_kernel, dim3(B), dim3(kThreads), 0, dcs_stream(stream), clean, est, L, eps, snr, coef);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -288,7 +288,7 @@ extern "C" int dcs_sisnr_fwd(const float* clean, const float* est, float* snr, f
 extern "C" int dcs_sisnr_bwd(const float* clean, const float* est, const float* coef, const float* g, float scale,
                              float* g_est, int B, int L, dcs_stream_t stream) {
     if (!clean || !est || !coef || !g || !g_est || B <= 0 || B > 65535 || L <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(sisnr_bwd_kernel, dim3((L + kThreads - 1) / kThreads, B), dim3(kThreads), 0, dcs_stream(stream), clean,
+    DCS_LAUNCH(sisnr_bwd_kernel, dim3((L + kThreads - 1) / kThreads, B), dim3(kThreads), 0, dcs_stream(stream), clean,
                        est, coef, g, scale, g_est, L);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -353,7 +353,7 @@ extern "C" int dcs_stft_frames_fwd(const float* clean, const float* noisy, const
         (long)(T - 1) * hop > L)
         return DCS_ERR_BADARG;
     const long per = (long)B * T * n_fft;
-    hipLaunchKernelGGL(stft_frames_kernel, dim3((unsigned)((per + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+    DCS_LAUNCH(stft_frames_kernel, dim3((unsigned)((per + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                        dcs_stream(stream), clean, noisy, window, frames, B, L, T, n_fft, hop);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -361,7 +361,7 @@ extern "C" int dcs_stft_frames_fwd(const float* clean, const float* noisy, const
 
 extern "C" int dcs_stft_bins_fwd(const float* spec, float* out, int SB, int T, int F, float scale, dcs_stream_t stream) {
     if (!spec || !out || SB <= 0 || SB > 65535 || T <= 0 || F <= 0) return DCS_ERR_BADARG;
-    hipLaunchKernelGGL(stft_bins_kernel, dim3((T + 31) / 32, (F + 31) / 32, SB), dim3(kThreads), 0, dcs_stream(stream),
+    DCS_LAUNCH(stft_bins_kernel, dim3((T + 31) / 32, (F + 31) / 32, SB), dim3(kThreads), 0, dcs_stream(stream),
                        (const float2*)spec, (float2*)out, F, T, scale);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

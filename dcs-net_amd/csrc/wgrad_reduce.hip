@@ -200,7 +200,7 @@ int emit(Job j, hipStream_t s) {
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_deferred && !g_suspended) { g_deferred->push_back(j); return DCS_OK; }
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(j.nblk), dim3(256), 0, s, j);
+    DCS_LAUNCH(wgrad_reduce_kernel, dim3(j.nblk), dim3(256), 0, s, j);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -239,7 +239,7 @@ extern "C" int dcs_wgrad_defer_flush(dcs_stream_t stream) {
             nb += q.nblk;
             t.jobs[t.n++] = q;
         }
-        hipLaunchKernelGGL(wreduce::wgrad_reduce_multi_kernel, dim3(nb), dim3(256), 0, s, t);
+        DCS_LAUNCH(wreduce::wgrad_reduce_multi_kernel, dim3(nb), dim3(256), 0, s, t);
         if (hipGetLastError() != hipSuccess) rc = DCS_ERR_LAUNCH;
     }
     delete jobs;

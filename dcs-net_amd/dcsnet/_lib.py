@@ -90,6 +90,10 @@ SIGNATURES = {
     'dcs_crm_fwd': (_I, [_P, _P, _P, _L, _F, _P]),
     'dcs_adam_amsgrad_step': (_I, [_P] * 6 + [_F, _F, _L, _F, _F, _F, _F, _F, _I, _P, _P, _P]),
     'dcs_step_guard': (_I, [_P, _P, _P]),
+    'dcs_stream_hold': (_I, [_P, _I, _P]),
+    'dcs_kernel_timer_begin': (_I, [_I]),
+    'dcs_kernel_timer_end': (_I, []),
+    'dcs_kernel_timer_read': (_I, [_I, _P]),
     'dcs_step_advance': (_I, [_P, _P, _P, _P]),
     'dcs_pack_tap_rows': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dcs_tap_rows_wgrad_scatter': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -99,10 +99,18 @@ class FlatBucket:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
                 p._dcs_grad_sink = p.grad
 
-    def allreduce(self):
-        """Sum over ranks, in place; the 1/world factor is folded into the optimizer kernel."""
+    def allreduce(self, events=None):
+        """Sum over ranks, in place; the 1/world factor is folded into the optimizer kernel.  events: a list that
+        receives a (start, end) HIP event pair recorded on the current stream around the collective."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            timed = events is not None and self.grad_all.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(self.grad_all, op=dist.ReduceOp.SUM)
+            if timed:
+                e1.record()
+                events.append((e0, e1))
             return dist.get_world_size()
         return 1
 
@@ -190,6 +198,7 @@ class TrainStep:
         self._graph = self._graph_opt = self._static_batch = self._static_loss = None
         self.use_pack_plan, self._plan = bool(use_pack_plan), None
         self._calls = 0
+        self.comm_events = None        # bench.py sets a list: (start, end) HIP events around every gradient all-reduce
 
     def _step_body(self, batch, batch_idx):
         """NaN guard of the reference (c_network.py:257-261: training_step returns None, the trainer skips the update).
@@ -202,7 +211,7 @@ class TrainStep:
             self.bucket.skip.fill_(1.0)
         else:
             self._backward(loss)
-        world = self.bucket.allreduce()
+        world = self.bucket.allreduce(self.comm_events)
         self.opt.step(world, self.seed_state)
         if loss is None or (world > 1 and float(self.bucket.skip) != 0.0):
             return None
@@ -252,6 +261,33 @@ class TrainStep:
         out = train_batch_2_loss(self.net, batch, batch_idx, dtype='complex')
         return out[2] if isinstance(out, tuple) else out
 
+    def _device_step(self, batch, world=1):
+        """The step exactly as the captured graph holds it: no host synchronisation anywhere (the NaN test is the device-side
+        guard).  With world > 1 it stops before the all-reduce (the collective and the optimizer half follow outside)."""
+        from . import functional
+        if self._plan is not None:
+            functional.run_pack_plan(self._plan)
+        self.bucket.zero_grad()
+        loss = self._loss_no_sync(batch, 0)
+        # the NaN test training_step makes on the host, on the device: flag element of the gradient bucket
+        check(_lib.load().dcs_step_guard(ptr(loss), ptr(self.bucket.skip), cur_stream()), 'dcs_step_guard')
+        self._backward(loss)
+        if world == 1:                                 # collectives stay outside the graph
+            self.opt.step(1, self.seed_state)
+        return loss
+
+    def uncaptured_step(self, batch):
+        """One step through the same launches as a graph replay, issued eagerly and without any host synchronisation
+        (measurement harnesses: bench.py brackets individual launches of it with events)."""
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        loss = self._device_step(batch, world)
+        if world > 1:
+            world = self.bucket.allreduce(self.comm_events)
+            self.opt.step(world, self.seed_state)
+        from . import functional
+        functional.bump_param_generation()
+        return loss
+
     def _capture(self, batch):
         from . import functional
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -261,15 +297,7 @@ class TrainStep:
         g = torch.cuda.CUDAGraph()
         # thread_local: a collective backend's watchdog thread may touch the HIP runtime while this thread captures
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
-            if self._plan is not None:
-                functional.run_pack_plan(self._plan)
-            self.bucket.zero_grad()
-            loss = self._loss_no_sync(static, 0)
-            # the NaN test training_step makes on the host, on the device: flag element of the gradient bucket
-            check(_lib.load().dcs_step_guard(ptr(loss), ptr(self.bucket.skip), cur_stream()), 'dcs_step_guard')
-            self._backward(loss)
-            if world == 1:                                 # collectives stay outside the graph
-                self.opt.step(1, self.seed_state)
+            loss = self._device_step(static, world)
         functional.bump_param_generation()                 # cache entries made during capture live in its pool
         self._graph, self._static_loss, self._graph_world = g, loss.detach(), world
         self._graph_opt = None
@@ -317,7 +345,7 @@ class TrainStep:
         self._graph.replay()
         from . import functional
         if self._graph_world > 1:
-            world = self.bucket.allreduce()
+            world = self.bucket.allreduce(self.comm_events)
             if self._graph_opt is not None:
                 self._graph_opt.replay()
             else:

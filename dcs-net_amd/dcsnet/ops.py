@@ -24,7 +24,7 @@ def _chk(t, name, dims=None):
         raise _lib.DcsHipError(f'{name}: expected {dims} dims, got shape {tuple(t.shape)}')
 
 
-CONV_TIMER = None        # set by bench.py: object with begin(flops) -> token / end(token)
+CONV_TIMER = None        # set by bench.py: object with begin(flops, tag=None, executed=1.0) -> token / end(token)
 
 # Device-side dropout seed offset (int64 tensor with one element, or None).  Every dropout-capable
 # kernel adds it to its by-value seed, so a captured hipGraph draws a fresh mask per replay once the
@@ -219,7 +219,8 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     nbytes = max(nbytes, 0)
     # bench.py's live roofline probe: 8 real flops per complex MAC
     # (strided forward convs are exactly the encoder's ComplexConv2d stack: tagged for bench.py's encoder roofline)
-    ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None)
+    ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None,
+                           executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up))
           if CONV_TIMER is not None else None)
     if coef is not None:
         _chk(coef, 'coef', 2)
@@ -231,6 +232,18 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     if ev is not None:
         CONV_TIMER.end(ev)
     return y
+
+
+def _fold_fraction(C1, Cin, Cout, ksize, stride, pad, up):
+    """Share of a conv's ALGORITHMIC multiply-accumulates (what the reference computes: k*k taps per output pixel) that
+    the library actually issues.  A 3x3 / stride-1 / pad-1 conv over a nearest-upsampled input runs in folded form
+    (csrc/conv_pack.hip: per output-parity class a 2-tap kernel along every upsampled axis, taps pre-summed): 6/9 of
+    the taps for a (2,1) upsample, 4/9 for (2,2) — forward, data gradient and weight gradient alike.  Everything else
+    (strided encoder convs, their class-decomposed data gradients, 1x1) issues exactly the algorithmic count."""
+    if (tuple(ksize) == (3, 3) and tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and tuple(up) in ((2, 1), (1, 2), (2, 2))
+            and Cin % 8 == 0 and Cout % 8 == 0 and C1 % 2 == 0):
+        return (2 if up[0] == 2 else 3) * (2 if up[1] == 2 else 3) / 9.0
+    return 1.0
 
 
 def pack_conv_weight_bwd(wp, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1)):
@@ -273,7 +286,8 @@ def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=Non
     if nbytes < 0:
         raise _lib.DcsHipError(f'cconv2d_bwd_data: unsupported geometry {geo}')
     ws = _workspace(nbytes, gy.device) if nbytes else None
-    ev = CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * Cin * ksize[0] * ksize[1]) if CONV_TIMER is not None else None
+    ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * Cin * ksize[0] * ksize[1],
+                           executed=_fold_fraction(C1, Cin, Cout, ksize, stride, pad, up)) if CONV_TIMER is not None else None)
     check(lib.dcs_cconv2d_bwd_data(ptr(gy), ptr(wp_bwd), ptr(gx1), ptr(gx2), ptr(ws), ws.numel() if ws is not None else 0,
                                    *geo, cur_stream()), 'dcs_cconv2d_bwd_data')
     if ev is not None:
@@ -318,7 +332,8 @@ def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1,
         lib.dcs_wgrad_defer_suspend(1)
     ev = None
     if CONV_TIMER is not None:
-        ev = CONV_TIMER.begin(8.0 * B * gy.shape[1] * gy.shape[2] * Cout * (C1 + C2) * ksize[0] * ksize[1])
+        ev = CONV_TIMER.begin(8.0 * B * gy.shape[1] * gy.shape[2] * Cout * (C1 + C2) * ksize[0] * ksize[1],
+                              executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up))
     try:
         check(lib.dcs_cconv2d_bwd_weight(ptr(x1), ptr(x2), ptr(gy), ptr(gw_r), ptr(gw_i), ptr(gb_r), ptr(gb_i), ptr(ws),
                                          ws.numel(), *geo, int(bool(transposed)), cur_stream()), 'dcs_cconv2d_bwd_weight')

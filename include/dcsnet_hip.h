@@ -14,12 +14,13 @@
  *   - Every pointer is a DEVICE pointer BORROWED from the caller.  The library never
  *     allocates, frees or retains caller memory; workspaces are passed in.
  *   - Kernels are enqueued on `stream`; no call synchronises.
- *   - ONE CONTEXT PER PROCESS.  The library is built for the one-process-per-GPU model and keeps four pieces of
+ *   - ONE CONTEXT PER PROCESS.  The library is built for the one-process-per-GPU model and keeps five pieces of
  *     process-global mutable state (each behind its own entry points, each guarded by a mutex, none per stream):
  *       (1) the conv operand precision                         dcs_set_conv_precision / dcs_get_conv_precision
  *       (2) the deferred weight-gradient reduce scope           dcs_wgrad_defer_begin / _suspend / _flush
  *       (3) the pack-plan recorder                              dcs_pack_plan_begin / _end
  *       (4) the conv kernel schedule                            dcs_set_conv_schedule / dcs_get_conv_schedule
+ *       (5) the kernel timer's armed slot                       dcs_kernel_timer_begin / _end
  *     Two training drivers in one process (or two host threads that open scopes concurrently) would see each
  *     other's precision, recorded reduces and recorded packs.  Everything else is stateless: kernels read only
  *     their arguments, so forward / backward calls on different streams of one process are safe as long as they
@@ -504,6 +505,21 @@ int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* v
  *                   reference's RNG does whether or not the update is skipped).  skip / step_dev / seed_dev may each
  *                   be NULL. */
 int dcs_step_guard(const float* loss, float* skip, dcs_stream_t stream);
+/* Measurement aid: park `stream` behind a one-wave kernel that polls *host_flag (a word of PINNED, device-visible host
+ * memory) and ends when it is non-zero, or after timeout_ms (<= 10000) whatever happens.  A harness enqueues a step's
+ * launches and event records behind it and then sets the word, so the kernels execute back to back as under hipGraph
+ * replay rather than at the pace of the host's launch calls (bench.py's roofline pass). */
+int dcs_stream_hold(const int* host_flag, int timeout_ms, dcs_stream_t stream);
+/* Kernel timer: exact durations of the library's kernels without a profiler.  Between dcs_kernel_timer_begin(slot) and
+ * dcs_kernel_timer_end() every kernel the library launches is dispatched with a start / stop event pair stamped by the
+ * command processor around the dispatch itself (hipExtLaunchKernelGGL) — the quantity rocprofv3's kernel trace reports;
+ * events recorded on the stream around a launch also time 6-10 us of marker and dispatch latency.  A slot spans all
+ * kernels launched while it was armed (first start to last end).  dcs_kernel_timer_read: milliseconds, after the stream
+ * has been synchronised.  One slot armed at a time, process-wide (state (5) of the list above); not for use under
+ * stream capture.  _end returns 1 when nothing was launched. */
+int dcs_kernel_timer_begin(int slot);
+int dcs_kernel_timer_end(void);
+int dcs_kernel_timer_read(int slot, float* ms);
 int dcs_step_advance(const float* skip, int* step_dev, long long* seed_dev, dcs_stream_t stream);
 
 /* Tap-sum factorisation of a ONE-output-channel stride-1 ComplexConvTranspose2d (the last decoder stage,
