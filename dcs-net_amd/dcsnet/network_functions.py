@@ -23,7 +23,7 @@ except ImportError:                      # pragma: no cover
 try:
     from pystoi import stoi
 except ImportError:                      # pragma: no cover
-    stoi = None
+    from .metrics import stoi            # the published algorithm restated (parity unpinned: dcsnet/metrics.py)
 
 
 def _mode():

@@ -234,3 +234,33 @@ def test_calc_loss_every_noise_loss_type_against_the_reference(golden_dir):
                                                config=cfg), **kw)
     finally:
         sys.argv = argv
+
+
+def test_stoi_restatement_properties():
+    """dcsnet/metrics.py::stoi (the published algorithm with pystoi 0.3.3's constants; PARITY UNPINNED: pystoi is not in
+    the image and the reference holds no STOI vectors): identity scores 1, the score falls monotonically with the SNR,
+    is invariant to the level of the processed signal, keeps pystoi's too-short-signal convention, and the band matrix
+    has the published layout."""
+    import numpy as np
+    from dcsnet.metrics import stoi, thirdoct, resample_oct
+    fs = 16000
+    t = np.arange(3 * fs) / fs
+    x = sum(np.sin(2 * np.pi * f * t) * (0.5 + 0.5 * np.sin(2 * np.pi * (3 + i) * t))
+            for i, f in enumerate((180, 360, 720, 1500, 2800, 4200)))
+    x = x * (np.sin(2 * np.pi * 1.5 * t) > -0.3)                      # pauses: exercises the silent-frame removal
+    assert abs(stoi(x, x, fs) - 1.0) < 1e-6
+    rng = np.random.default_rng(0)
+    noise = rng.standard_normal(len(x))
+    noise *= np.linalg.norm(x) / np.linalg.norm(noise)
+    scores = [stoi(x, x + noise / 10 ** (snr / 20), fs) for snr in (20, 10, 0, -10)]
+    assert all(a > b for a, b in zip(scores, scores[1:])) and 0.3 < scores[-1] < scores[0] < 1.0, scores
+    assert abs(stoi(x, 3.7 * (x + noise), fs) - stoi(x, x + noise, fs)) < 1e-9
+    assert stoi(x[:2000], x[:2000], fs) == 1e-5                       # fewer than 30 frames
+    obm, cf = thirdoct(10000, 512, 15, 150)
+    assert obm.shape == (15, 257) and abs(cf[0] - 150) < 1e-9 and abs(cf[-1] - 150 * 2 ** (14 / 3)) < 1e-6
+    assert (obm.sum(0) <= 1).all() and obm.sum() > 0                 # bands do not overlap
+    y = resample_oct(np.sin(2 * np.pi * 440 * t), 10000, fs)          # 16 kHz -> 10 kHz keeps a 440 Hz tone
+    k = int(np.argmax(np.abs(np.fft.rfft(y))))
+    assert len(y) == 3 * 10000 and abs(k * 10000 / len(y) - 440) < 1.0
+    with pytest.raises(ValueError):
+        stoi(x, x[:-1], fs)
