@@ -175,6 +175,71 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ x, const double* _
     co[5] = b1 - a2 * mr - a3 * mi;
 }
 
+// torch.nn.BatchNorm2d on a REAL channels-last tensor float[P][Cr] (DR-Net, r_network.py:56,66,106): with even Cr the
+// tensor is an interleaved complex one with Cr/2 channels, the statistics kernel above already yields every real
+// channel's first and second moment (S_ri is ignored), and the affine map is the DIAGONAL 2x2 block
+// (a0, 0, 0, a3 | c0, c1), a = gamma / sqrt(var + eps) — same apply kernel.  Cr = 1 (the initial BatchNorm over the
+// [B,F,T] magnitude): the P values are read as P/2 complex pixels whose two halves are the same channel (merge).
+// stats_out[c] = {mean_r, mean_i, 1/sigma_r, 1/sigma_i, 0, var_r + eps, var_i + eps, 0}.
+__global__ void rbn_finalize_kernel(const float* __restrict__ x, const double* __restrict__ part, int nblocks,
+                                    const float* __restrict__ weight, const float* __restrict__ bias,
+                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                    float* __restrict__ stats_out, float* __restrict__ coef_out, long P, int C, int merge,
+                                    float eps, float momentum, int use_batch_stats) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float mr, mi, vr, vi;
+    if (use_batch_stats) {
+        double S[5] = {0, 0, 0, 0, 0};
+        for (int b = lane; b < nblocks; b += 64) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) S[i] += part[((long)b * C + c) * 5 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) S[i] = dcs_wave_sum_d(S[i]);
+        if (lane != 0) return;
+        const double n = (double)P;                                       // complex pixels
+        const double kr = (double)x[2 * c], ki = (double)x[2 * c + 1];   // pivot = pixel 0
+        double m_r = kr + S[0] / n, m_i = ki + S[1] / n;
+        double v_r = S[2] / n - (S[0] / n) * (S[0] / n), v_i = S[3] / n - (S[1] / n) * (S[1] / n);
+        double cnt = n;
+        if (merge) {                      // one real channel seen as (re, im) halves: pool the two halves' moments
+            const double m = 0.5 * (m_r + m_i);
+            const double v = 0.5 * (v_r + (m_r - m) * (m_r - m) + v_i + (m_i - m) * (m_i - m));
+            m_r = m_i = m; v_r = v_i = v; cnt = 2 * n;
+        }
+        mr = (float)m_r; mi = (float)m_i; vr = (float)v_r; vi = (float)v_i;
+        if (momentum >= 0.f && running_mean != nullptr) {
+            const float f = momentum, unb = cnt > 1 ? (float)(cnt / (cnt - 1.0)) : 1.f;
+            if (merge) {
+                running_mean[0] = f * mr + (1.f - f) * running_mean[0];
+                running_var[0] = f * vr * unb + (1.f - f) * running_var[0];
+            } else {
+                running_mean[2 * c] = f * mr + (1.f - f) * running_mean[2 * c];
+                running_mean[2 * c + 1] = f * mi + (1.f - f) * running_mean[2 * c + 1];
+                running_var[2 * c] = f * vr * unb + (1.f - f) * running_var[2 * c];
+                running_var[2 * c + 1] = f * vi * unb + (1.f - f) * running_var[2 * c + 1];
+            }
+        }
+    } else {
+        if (lane != 0) return;
+        mr = running_mean[merge ? 0 : 2 * c]; mi = running_mean[merge ? 0 : 2 * c + 1];
+        vr = running_var[merge ? 0 : 2 * c]; vi = running_var[merge ? 0 : 2 * c + 1];
+    }
+    const float isr = 1.0f / sqrtf(vr + eps), isi = 1.0f / sqrtf(vi + eps);
+    float w0 = 1.f, w1 = 1.f, b0 = 0.f, b1 = 0.f;
+    if (weight != nullptr) {
+        w0 = weight[merge ? 0 : 2 * c]; w1 = weight[merge ? 0 : 2 * c + 1];
+        b0 = bias[merge ? 0 : 2 * c]; b1 = bias[merge ? 0 : 2 * c + 1];
+    }
+    const float a0 = w0 * isr, a3 = w1 * isi;
+    float* st = stats_out + 8 * c;
+    st[0] = mr; st[1] = mi; st[2] = isr; st[3] = isi; st[4] = 0.f; st[5] = vr + eps; st[6] = vi + eps; st[7] = 0.f;
+    float* co = coef_out + 6 * c;
+    co[0] = a0; co[1] = 0.f; co[2] = 0.f; co[3] = a3;
+    co[4] = b0 - a0 * mr;
+    co[5] = b1 - a3 * mi;
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_t(float v) {
     if (ACT == DCS_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -288,6 +353,43 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
     else if (act == DCS_ACT_LRELU) { if (drop) DCS_CBN_APPLY(DCS_ACT_LRELU, true); else DCS_CBN_APPLY(DCS_ACT_LRELU, false); }
     else { if (drop) DCS_CBN_APPLY(DCS_ACT_NONE, true); else DCS_CBN_APPLY(DCS_ACT_NONE, false); }
 #undef DCS_CBN_APPLY
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// Real BatchNorm2d (+ ReLU / LeakyReLU) of float[P][Cr]; Cr even, or Cr == 1 with P even (see rbn_finalize_kernel).
+extern "C" int dcs_rbn_fwd(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
+                           float* running_var, float* stats_out, float* coef_out, void* workspace, long workspace_bytes,
+                           long P, int Cr, float eps, float momentum, int use_batch_stats, int act, dcs_stream_t stream) {
+    const int merge = Cr == 1;
+    if (!x || !y || !stats_out || !coef_out || Cr < 1 || (!merge && (Cr & 1)) || (merge && (P & 1))) return DCS_ERR_BADARG;
+    const int C = merge ? 1 : Cr / 2;
+    const long Pc = merge ? P / 2 : P;
+    CbnGeom g;
+    if (!cbn_geom(Pc, C, &g)) return DCS_ERR_BADARG;
+    if ((weight == nullptr) != (bias == nullptr) || use_batch_stats < 0 || use_batch_stats > 1) return DCS_ERR_BADARG;
+    if (use_batch_stats == 0 && (!running_mean || !running_var)) return DCS_ERR_BADARG;
+    if (act != DCS_ACT_NONE && act != DCS_ACT_RELU && act != DCS_ACT_LRELU) return DCS_ERR_BADARG;
+    hipStream_t s = dcs_stream(stream);
+    if (use_batch_stats) {
+        if (!workspace || workspace_bytes < (long)g.nblocks * C * 5 * (long)sizeof(double)) return DCS_ERR_WORKSPACE;
+        DCS_LAUNCH(cbn_stats_kernel, dim3(g.nblocks), dim3(kThreads), 0, s, x, (double*)workspace, Pc, C, g.vec_per_row,
+                   g.rows_per_iter);
+        DCS_CHECK_LAUNCH();
+    }
+    DCS_LAUNCH(rbn_finalize_kernel, dim3(C), dim3(64), 0, s, x, (const double*)workspace, g.nblocks, weight, bias,
+               running_mean, running_var, stats_out, coef_out, Pc, C, merge, eps, momentum, use_batch_stats);
+    DCS_CHECK_LAUNCH();
+    long iters = (C == 1) ? (Pc / 2 + kThreads - 1) / kThreads : (Pc + g.rows_per_iter - 1) / g.rows_per_iter;
+    long nb = (iters + 3) / 4;
+    const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+#define DCS_RBN_APPLY(A)                                                                                        \
+    DCS_LAUNCH((cbn_apply_kernel<A, false>), dim3(grid), dim3(kThreads), 0, s, x, y, coef_out, Pc, C, g.vec_per_row, \
+               g.rows_per_iter, 0.f, (uint64_t)0, (const uint64_t*)nullptr)
+    if (act == DCS_ACT_RELU) DCS_RBN_APPLY(DCS_ACT_RELU);
+    else if (act == DCS_ACT_LRELU) DCS_RBN_APPLY(DCS_ACT_LRELU);
+    else DCS_RBN_APPLY(DCS_ACT_NONE);
+#undef DCS_RBN_APPLY
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

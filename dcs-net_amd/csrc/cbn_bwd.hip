@@ -202,6 +202,45 @@ __global__ void cbn_bwd_finalize_kernel(const double* __restrict__ part, int nbl
     bc[8] = (float)f0; bc[9] = (float)f1;
 }
 
+// Backward finalize of the REAL BatchNorm2d (dcs_rbn_fwd): per real channel, a = gamma / sigma,
+//     g_x = a g_y - a s / n - a d N / (n sigma^2),   g_gamma = N / sigma,   g_beta = s,    s = sum g_y, N = sum g_y d
+// i.e. the diagonal case of the coefficients above; merge (Cr == 1): both halves are one channel (sums pooled, 2n values).
+__global__ void rbn_bwd_finalize_kernel(const double* __restrict__ part, int nblocks, const float* __restrict__ stats,
+                                        const float* __restrict__ coef, float* __restrict__ g_weight,
+                                        float* __restrict__ g_bias, float* __restrict__ bcoef, long P, int C, int merge,
+                                        int use_batch_stats) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = lane; b < nblocks; b += 64) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) S[i] += part[((long)b * C + c) * 6 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S[i] = dcs_wave_sum_d(S[i]);
+    if (lane != 0) return;
+    double sr = S[0], si = S[1], Nr = S[2], Ni = S[5], n = (double)P;
+    const float* st = stats + 8 * c;
+    const double mr = st[0], mi = st[1], isr = st[2], isi = st[3];
+    if (merge) { sr = si = sr + si; Nr = Ni = Nr + Ni; n = 2.0 * n; }
+    if (g_weight) {
+        if (merge) { g_weight[0] = (float)(Nr * isr); g_bias[0] = (float)sr; }
+        else {
+            g_weight[2 * c] = (float)(Nr * isr); g_weight[2 * c + 1] = (float)(Ni * isi);
+            g_bias[2 * c] = (float)sr; g_bias[2 * c + 1] = (float)si;
+        }
+    }
+    const double a0 = coef[6 * c], a3 = coef[6 * c + 3];
+    double d0 = 0, d3 = 0, f0 = 0, f1 = 0;
+    if (use_batch_stats) {
+        d0 = -a0 * Nr * isr * isr / n; d3 = -a3 * Ni * isi * isi / n;
+        f0 = -a0 * sr / n - d0 * mr;  f1 = -a3 * si / n - d3 * mi;
+    }
+    float* bc = bcoef + 10 * c;
+    bc[0] = (float)a0; bc[1] = 0.f; bc[2] = 0.f; bc[3] = (float)a3;
+    bc[4] = (float)d0; bc[5] = 0.f; bc[6] = 0.f; bc[7] = (float)d3;
+    bc[8] = (float)f0; bc[9] = (float)f1;
+}
+
 struct BChan { float t0, t1, t2, t3, d0, d1, d2, d3, f0, f1; };
 __device__ __forceinline__ BChan load_bchan(const float* bcoef, int c) {
     const float* b = bcoef + 10 * c;
@@ -320,4 +359,42 @@ extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const
                            const unsigned long long* seed_dev, dcs_stream_t stream) {
     return dcs_cbn_bwd_add(x, g_out, g_x, weight, stats, coef, g_weight, g_bias, workspace, workspace_bytes, P, C,
                            use_batch_stats, act, drop_p, seed, seed_dev, nullptr, 0.f, 0, nullptr, stream);
+}
+
+// Backward of dcs_rbn_fwd: g_x, g_weight[Cr], g_bias[Cr] (both NULL for affine=False); same Cr / P conventions.
+extern "C" int dcs_rbn_bwd(const float* x, const float* g_out, float* g_x, const float* stats, const float* coef,
+                           float* g_weight, float* g_bias, void* workspace, long workspace_bytes, long P, int Cr,
+                           int use_batch_stats, int act, dcs_stream_t stream) {
+    const int merge = Cr == 1;
+    if (!x || !g_out || !g_x || !stats || !coef || !workspace || Cr < 1 || (!merge && (Cr & 1)) || (merge && (P & 3)))
+        return DCS_ERR_BADARG;                       // merge: P/2 complex pixels, float4 pairs -> P % 4 == 0
+    const int C = merge ? 1 : Cr / 2;
+    const long Pc = merge ? P / 2 : P;
+    cbn::Geom g;
+    if (!cbn::geom(Pc, C, &g)) return DCS_ERR_BADARG;
+    if ((g_weight == nullptr) != (g_bias == nullptr)) return DCS_ERR_BADARG;
+    if (act != DCS_ACT_NONE && act != DCS_ACT_RELU && act != DCS_ACT_LRELU) return DCS_ERR_BADARG;
+    const long part_bytes = (long)g.nblocks * C * 6 * (long)sizeof(double);
+    if (workspace_bytes < part_bytes + (long)C * 10 * (long)sizeof(float)) return DCS_ERR_WORKSPACE;
+    double* part = (double*)workspace;
+    float* bcoef = (float*)((char*)workspace + part_bytes);
+    hipStream_t s = dcs_stream(stream);
+    const int grid2 = cbn::stream_grid(Pc, C, g);
+#define DCS_RBN_BWD(A)                                                                                             \
+    do {                                                                                                           \
+        DCS_LAUNCH((cbn_bwd_reduce_kernel<A, false>), dim3(g.nblocks), dim3(kThreads), 0, s, x, g_out, coef, stats, part, \
+                   Pc, C, g.vec_per_row, g.rows_per_iter, 0.f, (uint64_t)0, (const uint64_t*)nullptr,              \
+                   (const float4*)nullptr, 0.f, (long)0, (const float4*)nullptr);                                  \
+        DCS_LAUNCH(rbn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part, g.nblocks, stats, coef,   \
+                   g_weight, g_bias, bcoef, Pc, C, merge, use_batch_stats);                                        \
+        DCS_LAUNCH((cbn_bwd_apply_kernel<A, false>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef, stats, \
+                   (const float*)bcoef, Pc, C, g.vec_per_row, g.rows_per_iter, 0.f, (uint64_t)0,                   \
+                   (const uint64_t*)nullptr, (const float4*)nullptr, 0.f, (long)0, (const float4*)nullptr);        \
+    } while (0)
+    if (act == DCS_ACT_RELU) DCS_RBN_BWD(DCS_ACT_RELU);
+    else if (act == DCS_ACT_LRELU) DCS_RBN_BWD(DCS_ACT_LRELU);
+    else DCS_RBN_BWD(DCS_ACT_NONE);
+#undef DCS_RBN_BWD
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
 }

@@ -519,6 +519,44 @@ extern "C" int dcs_rconv2d_fwd(const float* x1, const float* x2, const float* bm
     return dcs_conv_mfma_launch_wide(a, bm, workspace, workspace_bytes, dcs_stream(stream));
 }
 
+// Gradient of dcs_rconv2d_fwd's VIRTUAL input (the upsampled concatenation), float[B][Hv][Wv][Cinr]: a stride-1
+// correlation of the zero-inserted g_Y with the caller-packed panel of the flipped, in/out-swapped kernel
+// (B[tap][k = real output channel][n = real input channel]), padding k-1-p.  The block sum over an upsample and the
+// channel split of a concatenation are dcs_upsample_cat_bwd's (complex channel counts Cr/2).
+static conv::Args rconv_dgrad_args(const float* gy, float* gxv, int B, int Hv, int Wv, int Cinr, int Coutr, int kh, int kw,
+                                   int sf, int st, int pad_f, int pad_t) {
+    ConvArgs a{};
+    const int Hout = (Hv + 2 * pad_f - kh) / sf + 1, Wout = (Wv + 2 * pad_t - kw) / st + 1;
+    a.x1 = (const float2*)gy; a.x2 = nullptr; a.bias = nullptr; a.wp = nullptr; a.y = (float2*)gxv;
+    a.B = B; a.Hin = Hout; a.Win = Wout; a.C1 = Coutr / 2; a.C2 = 0; a.Cout = Cinr / 2; a.act = DCS_ACT_NONE;
+    a.up_f = sf; a.up_t = st; a.zero_ins = 1;
+    a.kh = kh; a.kw = kw; a.sf = 1; a.st = 1; a.pad_f = kh - 1 - pad_f; a.pad_t = kw - 1 - pad_t;
+    a.Hv = (Hout - 1) * sf + 1; a.Wv = (Wout - 1) * st + 1;
+    a.Hout = Hv; a.Wout = Wv;
+    return a;
+}
+
+extern "C" long dcs_rconv2d_bwd_data_workspace_bytes(int B, int Hv, int Wv, int Cinr, int Coutr, int kh, int kw, int sf,
+                                                     int st, int pad_f, int pad_t) {
+    if (B <= 0 || Hv <= 0 || Wv <= 0 || !rconv_ok(Coutr, 0, Cinr) || kh < 1 || kw < 1 || sf < 1 || st < 1 || pad_f < 0 ||
+        pad_t < 0 || pad_f > kh - 1 || pad_t > kw - 1)
+        return -1;
+    const ConvArgs a = rconv_dgrad_args(nullptr, nullptr, B, Hv, Wv, Cinr, Coutr, kh, kw, sf, st, pad_f, pad_t);
+    if (a.Hin <= 0 || a.Win <= 0) return -1;
+    return dcs_conv_mfma_workspace_bytes_plain(a);
+}
+
+extern "C" int dcs_rconv2d_bwd_data(const float* gy, const float* bm_bwd, float* gxv, void* workspace, long workspace_bytes,
+                                    int B, int Hv, int Wv, int Cinr, int Coutr, int kh, int kw, int sf, int st, int pad_f,
+                                    int pad_t, dcs_stream_t stream) {
+    if (!gy || !bm_bwd || !gxv || B <= 0 || Hv <= 0 || Wv <= 0 || !rconv_ok(Coutr, 0, Cinr)) return DCS_ERR_BADARG;
+    if (kh < 1 || kw < 1 || sf < 1 || st < 1 || pad_f < 0 || pad_t < 0 || pad_f > kh - 1 || pad_t > kw - 1)
+        return DCS_ERR_BADARG;
+    ConvArgs a = rconv_dgrad_args(gy, gxv, B, Hv, Wv, Cinr, Coutr, kh, kw, sf, st, pad_f, pad_t);
+    if (a.Hin <= 0 || a.Win <= 0) return DCS_ERR_BADARG;
+    return dcs_conv_mfma_launch_wide(a, bm_bwd, workspace, workspace_bytes, dcs_stream(stream));
+}
+
 // data-gradient launch description shared by the workspace query and the launch itself
 struct DgradPlan {
     ConvArgs a;

@@ -19,7 +19,6 @@
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int kHBwd = 64;          // the backward kernel (complex net only) is built for hidden size 64
 
 // tanh through the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each): 1 - 2 / (2^(2x log2 e) + 1), absolute
 // error ~1e-7 (saturates correctly at +-1).  The library tanhf / expf pair costs ~100 VALU instructions per step on the
@@ -114,11 +113,12 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
 // (W_hh column of unit u, rows gate*H..) plus a quad sum — so the recurrent cotangent of unit u never leaves the quad.
 // g_pre of the step goes through a double-buffered LDS vector: ONE barrier per step.  The next step's operands are
 // fetched while the current one computes (none depends on the recurrence).
-__global__ __launch_bounds__(4 * kHBwd) void lstm_rec_bwd_kernel(const float* __restrict__ g_out,
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_rec_bwd_kernel(const float* __restrict__ g_out,
                                                            const float* __restrict__ gates, const float* __restrict__ cs,
                                                            const float* __restrict__ whh, float* __restrict__ g_pre,
                                                            float* __restrict__ g_bias_part, int S, int seqs_per_set) {
-    constexpr int H = kHBwd, G4 = 4 * H;
+    constexpr int G4 = 4 * H;
     __shared__ __attribute__((aligned(16))) float gp_s[2][G4];
     const int t = threadIdx.x, u = t >> 2, gate = t & 3, j = gate * H + u;
     const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
@@ -179,10 +179,15 @@ __global__ __launch_bounds__(4 * kHBwd) void lstm_rec_bwd_kernel(const float* __
 extern "C" int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_save, const float* w_hh,
                                   float* g_pre, float* g_bias_part, int n_sets, int seqs_per_set, int S, int Hdim,
                                   dcs_stream_t stream) {
-    if (!g_out || !gates || !c_save || !w_hh || !g_pre || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || Hdim != kHBwd)
+    if (!g_out || !gates || !c_save || !w_hh || !g_pre || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 ||
+        (Hdim != 64 && Hdim != 128))
         return DCS_ERR_BADARG;
-    DCS_LAUNCH(lstm_rec_bwd_kernel, dim3(n_sets * seqs_per_set * 2), dim3(4 * kHBwd), 0, dcs_stream(stream), g_out,
-                       gates, c_save, w_hh, g_pre, g_bias_part, S, seqs_per_set);
+    if (Hdim == 128)                                         // DR-Net's LSTM (r_network.py:75-79)
+        DCS_LAUNCH(lstm_rec_bwd_kernel<128>, dim3(n_sets * seqs_per_set * 2), dim3(512), 0, dcs_stream(stream), g_out,
+                   gates, c_save, w_hh, g_pre, g_bias_part, S, seqs_per_set);
+    else
+        DCS_LAUNCH(lstm_rec_bwd_kernel<64>, dim3(n_sets * seqs_per_set * 2), dim3(256), 0, dcs_stream(stream), g_out,
+                   gates, c_save, w_hh, g_pre, g_bias_part, S, seqs_per_set);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -192,10 +197,12 @@ extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out
                                   long stride_t, dcs_stream_t stream) {
     if (!gx || !w_hh || !out || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || (Hdim != 64 && Hdim != 128)) return DCS_ERR_BADARG;
     if ((gates_save == nullptr) != (c_save == nullptr)) return DCS_ERR_BADARG;
-    if (Hdim == 128 && gates_save) return DCS_ERR_BADARG;     // hidden 128 (DR-Net): inference only, no backward kernel
     const int NS = n_sets * seqs_per_set;
     dim3 grid(NS * 2);
-    if (Hdim == 128)
+    if (Hdim == 128 && gates_save)
+        DCS_LAUNCH((lstm_rec_fwd_kernel<128, true>), grid, dim3(512), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
+                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+    else if (Hdim == 128)
         DCS_LAUNCH((lstm_rec_fwd_kernel<128, false>), grid, dim3(512), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
                            c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
     else if (gates_save)

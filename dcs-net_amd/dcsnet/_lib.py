@@ -37,6 +37,10 @@ SIGNATURES = {
     'dcs_cconv2d_fwd_affine': (_I, [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 15 + [_P]),
     'dcs_rconv2d_fwd_workspace_bytes': (_L, [_I] * 14),
     'dcs_rconv2d_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 15 + [_P]),
+    'dcs_rconv2d_bwd_data_workspace_bytes': (_L, [_I] * 11),
+    'dcs_rconv2d_bwd_data': (_I, [_P, _P, _P, _P, _L] + [_I] * 11 + [_P]),
+    'dcs_rbn_fwd': (_I, [_P] * 9 + [_L, _L, _I, _F, _F, _I, _I, _P]),
+    'dcs_rbn_bwd': (_I, [_P] * 8 + [_L, _L, _I, _I, _I, _P]),
     'dcs_packed_weight_floats': (_L, [_I] * 6),
     'dcs_packed_weight_bwd_floats': (_L, [_I] * 10),
     'dcs_pack_conv_weight_bwd': (_I, [_P, _P] + [_I] * 10 + [_P]),

@@ -305,8 +305,10 @@ class C_NETWORK(LightningModule):
         return {'optimizer': optimiser, 'lr_scheduler': scheduler,
                 'monitor': 'val_loss' if _mode() in ('dcs', 'drs') else 'speech_loss'}
 
+    _step_dtype = 'complex'            # R_NETWORK shares these hooks with 'real' (r_network.py:176-363)
+
     def training_step(self, train_batch, batch_idx):
-        out = train_batch_2_loss(self, train_batch, batch_idx, dtype='complex')
+        out = train_batch_2_loss(self, train_batch, batch_idx, dtype=self._step_dtype)
         if _mode() in ('dcs', 'drs'):
             noise_loss, speech_loss, loss = out
             metrics = {'train_loss': loss.detach(), 'noise_loss': noise_loss.detach(),
@@ -316,12 +318,12 @@ class C_NETWORK(LightningModule):
             metrics = {'speech_loss': loss.detach()}
         self.log_dict(metrics, on_epoch=True)
         if torch.any(torch.isnan(loss)):
-            print('found NaN in C train loss!')
+            print(f"found NaN in {'C' if self._step_dtype == 'complex' else 'R'} train loss!")
             return None
         return loss
 
     def _eval_step(self, fn, batch, idx, prefix):
-        out = fn(self, batch, idx, dtype='complex')
+        out = fn(self, batch, idx, dtype=self._step_dtype)
         if _mode() in ('dcs', 'drs'):
             noise_loss, speech_loss, loss, pesq_av, stoi_av, n_hat, s_hat, noise, noisy, clean = out[:10]
             metrics = {f'{prefix}_loss': loss.detach(), f'{prefix}_noise_loss': noise_loss.detach(),
@@ -339,7 +341,7 @@ class C_NETWORK(LightningModule):
     def validation_step(self, val_batch, val_idx):
         loss, audio, metrics = self._eval_step(val_batch_2_metric_loss, val_batch, val_idx, 'val')
         if torch.any(torch.isnan(loss)):
-            print('found a NaN in C val loss!')
+            print(f"found a NaN in {'C' if self._step_dtype == 'complex' else 'R'} val loss!")
             return None
         return audio, metrics
 

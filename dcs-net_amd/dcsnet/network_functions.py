@@ -284,18 +284,45 @@ def _complex_step(self, noise_data, noisy_data, clean_data, need_noisy_audio=Fal
     return audio
 
 
+def _real_step(self, noise_data, noisy_data, clean_data, need_noisy_audio=False):
+    """dtype == "real" (DRS / DR-Net, network_functions.py:224-232, :261-267): the network sees |noisy| and returns a
+    sigmoid mask; the estimates keep the noisy phase."""
+    eps = self.hparams['atan2_eps']
+    cfg = self.config
+    audio = {'noise_audio': _polar_wave(noise_data, eps, cfg), 'clean_audio': _polar_wave(clean_data, eps, cfg)}
+    if need_noisy_audio or self.hparams.get('noise_loss_type') in (1, 3, 4, 5):
+        audio['noisy_audio'] = _polar_wave(noisy_data, eps, cfg)
+    noisy_mag = torch.abs(noisy_data)
+    noisy_phase = torch.atan2(noisy_data.imag, noisy_data.real + eps)
+    mask = self(noisy_mag)
+    if _mode() in ('dcs', 'drs'):
+        if need_noisy_audio or self.hparams.get('noise_loss_type') in (0, 2, 4, 5):
+            audio['target_noise_mask'] = torch.sigmoid(torch.abs(noise_data) / noisy_mag)
+        noise_mag_hat = noisy_mag * mask
+        audio['predict_noise_mask'] = mask
+        audio['predict_noise_audio'] = mag_phase_2_wave(noise_mag_hat, noisy_phase, cfg)
+        audio['predict_clean_audio'] = mag_phase_2_wave(noisy_mag - noise_mag_hat, noisy_phase, cfg)
+    else:                                               # 'dr': the mask is applied, not subtracted
+        audio['predict_clean_audio'] = mag_phase_2_wave(noisy_mag * mask, noisy_phase, cfg)
+    return audio
+
+
+def _step(self, dtype, *args, **kw):
+    if dtype == 'complex':
+        return _complex_step(self, *args, **kw)
+    if dtype == 'real':
+        return _real_step(self, *args, **kw)
+    raise ValueError(f'dtype {dtype!r}: the reference passes "complex" (C_NETWORK) or "real" (R_NETWORK)')
+
+
 def train_batch_2_loss(self, train_batch, batch_idx, dtype):
     noise_data, noisy_data, clean_data = train_batch[:3]
-    if dtype != 'complex':
-        raise NotImplementedError('the HIP build covers the complex network (DCS/DC-Net)')
-    return calc_loss(self, **_complex_step(self, noise_data, noisy_data, clean_data))
+    return calc_loss(self, **_step(self, dtype, noise_data, noisy_data, clean_data))
 
 
 def val_batch_2_metric_loss(self, val_batch, val_idx, dtype):
     noise_data, noisy_data, clean_data = val_batch[:3]
-    if dtype != 'complex':
-        raise NotImplementedError('the HIP build covers the complex network (DCS/DC-Net)')
-    a = _complex_step(self, noise_data, noisy_data, clean_data, need_noisy_audio=True)
+    a = _step(self, dtype, noise_data, noisy_data, clean_data, need_noisy_audio=True)
     pesq_av = calc_metric(a['clean_audio'], a['predict_clean_audio'], self.config, pesq)
     stoi_av = calc_metric(a['clean_audio'], a['predict_clean_audio'], self.config, stoi)
     losses = calc_loss(self, **a)

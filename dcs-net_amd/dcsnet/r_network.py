@@ -21,8 +21,19 @@ reference checkpoint loads.  `forward` does not run those containers; it runs
   * the LSTM recurrence on the persistent kernel of the complex path, instantiated for hidden size 128 (one weight set);
     its input projections and the Linear are plain rocBLAS GEMMs.
 
-Plumbing that stays in ATen on this path: the one-channel initial BatchNorm (a scalar affine), the batch statistics of
-train-mode BatchNorm, the final sigmoid.  Forward only: there is no hand-written backward for the real path (training DR-Net is out of scope).
+Training (r_network.py:176-363 hooks, network_functions.py:224-232): with autograd on, `forward` runs the same kernels
+behind autograd nodes —
+  * _RConvFn: forward = the real MFMA conv; data gradient = the same kernel over the zero-inserted cotangent with the
+    flipped, in/out-swapped panel (dcs_rconv2d_bwd_data) + dcs_upsample_cat_bwd; weight gradient = the COMPLEX
+    weight-gradient kernels run twice, on x and on conj(x): with D_qr = sum_p g_q x_r they return
+    (D_rr + D_ii) + j (D_ir - D_ri) and (D_rr - D_ii) + j (D_ir + D_ri), i.e. all four real blocks of the gradient;
+  * _RBnFn: BatchNorm2d (all of them, the one-channel initial one included) on the CBN statistics / apply / backward
+    kernels with diagonal coefficients (dcs_rbn_fwd / dcs_rbn_bwd);
+  * enc0 / dec6 / the 7x7 attention convs: the complex conv nodes of the DCS path over weight views of the real
+    parameters (autograd maps the gradients back through the pairing);
+  * the LSTM recurrence forward + BPTT kernels at hidden size 128, its projections and the Linear as rocBLAS GEMMs.
+In ATen under autograd: the attention blocks' pools / FC / broadcast multiplies (reductions and element-wise ops; the
+fused dcs_rattention_fwd serves inference), dropout, the final sigmoid.
 
 Quirks kept (r_network.py): channel attention = sigmoid(fc(max_pool)) only (:23-24); dropout_fc gated by
 hparams['dropout'] (:152) while dropout_conv is not; torch.squeeze drops the batch dimension at B = 1 (:171).
@@ -122,6 +133,131 @@ def rconv2d(x1, x2, panel, bias, cout, ksize, stride, pad, up=(1, 1), act=F.ACT_
     return y
 
 
+def rconv2d_bwd_data(gy, panel_bwd, Hv, Wv, cin, ksize, stride, pad):
+    """Gradient of the virtual (upsampled, concatenated) input [B,Hv,Wv,cin] of a real conv: dcs_rconv2d_bwd_data."""
+    from . import _lib
+    lib = _lib.load()
+    B, Ho, Wo, cout = gy.shape
+    geo = (B, Hv, Wv, cin, cout, ksize[0], ksize[1], stride[0], stride[1], pad[0], pad[1])
+    nbytes = lib.dcs_rconv2d_bwd_data_workspace_bytes(*geo)
+    if nbytes < 0:
+        raise DcsHipError(f'rconv2d_bwd_data: unsupported geometry {geo}')
+    ws = ops._workspace(nbytes, gy.device) if nbytes > 0 else None
+    gxv = torch.empty((B, Hv, Wv, cin), dtype=torch.float32, device=gy.device)
+    _lib.check(lib.dcs_rconv2d_bwd_data(_lib.ptr(gy), _lib.ptr(panel_bwd), _lib.ptr(gxv), _lib.ptr(ws),
+                                        0 if ws is None else ws.numel(), *geo, _lib.cur_stream()), 'dcs_rconv2d_bwd_data')
+    return gxv
+
+
+def upsample_cat_bwd(gxv, H, W, c1, c2, up):
+    """[B,H*uf,W*ut,c1+c2] -> (g_x1 [B,H,W,c1], g_x2 [B,H,W,c2] | None): block sum + channel split (real channel counts)."""
+    from . import _lib
+    B = gxv.shape[0]
+    g1 = torch.empty((B, H, W, c1), dtype=torch.float32, device=gxv.device)
+    g2 = torch.empty((B, H, W, c2), dtype=torch.float32, device=gxv.device) if c2 else None
+    _lib.check(_lib.load().dcs_upsample_cat_bwd(_lib.ptr(gxv), _lib.ptr(g1), _lib.ptr(g2), B, H, W, c1 // 2, c2 // 2,
+                                                up[0], up[1], _lib.cur_stream()), 'dcs_upsample_cat_bwd')
+    return g1, g2
+
+
+class _RConvFn(torch.autograd.Function):
+    """Real Conv2d / stride-1 ConvTranspose2d over upsample(cat(x1, x2)) on the MFMA kernel, with its gradients (see the
+    module docstring).  w: the module's weight ([Cout,Cin,kh,kw], or [Cin,Cout,kh,kw] when transposed)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b, transposed, stride, pad, up):
+        wc = w.detach()
+        w_corr = wc.flip(2, 3).transpose(0, 1).contiguous() if transposed else wc      # correlation kernel [Cout,Cin,kh,kw]
+        kh, kw = w_corr.shape[2:]
+        cpad = (kh - 1 - pad[0], kw - 1 - pad[1]) if transposed else tuple(pad)
+        cstride = (1, 1) if transposed else tuple(stride)
+        y = rconv2d(x1, x2, pack_real_panel(w_corr), None if b is None else b.detach(), w_corr.shape[0], (kh, kw), cstride,
+                    cpad, tuple(up))
+        ctx.cfg = (bool(transposed), cstride, cpad, tuple(up), b is not None)
+        ctx.save_for_backward(x1, x2, w_corr)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, w_corr = ctx.saved_tensors
+        transposed, stride, pad, up, has_bias = ctx.cfg
+        gy = gy.contiguous()
+        B, H, W, c1 = x1.shape
+        c2 = 0 if x2 is None else x2.shape[3]
+        cout, cin, kh, kw = w_corr.shape
+        g1 = g2 = gw = gb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            panel_b = pack_real_panel(w_corr.flip(2, 3).transpose(0, 1).contiguous())
+            gxv = rconv2d_bwd_data(gy, panel_b, H * up[0], W * up[1], cin, (kh, kw), stride, pad)
+            if up != (1, 1) or c2:
+                g1, g2 = upsample_cat_bwd(gxv, H, W, c1, c2, up)
+            else:
+                g1 = gxv
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            cplx = lambda t: None if t is None else t.view(*t.shape[:3], t.shape[3] // 2, 2)
+            conj = torch.tensor([1.0, -1.0], device=gy.device)
+            gyc = cplx(gy)
+            shape_c = (cout // 2, cin // 2, kh, kw)
+            a_r, a_i, ab_r, ab_i = ops.cconv2d_bwd_weight(cplx(x1), cplx(x2), gyc, shape_c, has_bias, (kh, kw), stride, pad, up)
+            c_r, c_i, _, _ = ops.cconv2d_bwd_weight(cplx(x1) * conj, None if x2 is None else cplx(x2) * conj, gyc, shape_c,
+                                                    False, (kh, kw), stride, pad, up)
+            g_corr = torch.empty_like(w_corr)
+            g_corr[0::2, 0::2] = 0.5 * (a_r + c_r)          # D_rr
+            g_corr[1::2, 1::2] = 0.5 * (a_r - c_r)          # D_ii
+            g_corr[1::2, 0::2] = 0.5 * (a_i + c_i)          # D_ir: imaginary output part x real input part
+            g_corr[0::2, 1::2] = 0.5 * (c_i - a_i)          # D_ri
+            gw = g_corr.flip(2, 3).transpose(0, 1).contiguous() if transposed else g_corr
+            if has_bias:                                     # complex bias = (b_r - b_i) + j (b_r + b_i)
+                gb = torch.empty(cout, dtype=torch.float32, device=gy.device)
+                gb[0::2] = 0.5 * (ab_r - ab_i)
+                gb[1::2] = 0.5 * (ab_r + ab_i)
+        return g1, g2, gw, gb, None, None, None, None
+
+
+class _RBnFn(torch.autograd.Function):
+    """BatchNorm2d (+ activation) of a real channels-last tensor on the CBN kernels (dcs_rbn_fwd / dcs_rbn_bwd).
+    x: [B,H,W,Cr] with even Cr, or [B,F,T] for the one-channel initial BatchNorm."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, use_batch, act):
+        from . import _lib
+        lib = _lib.load()
+        Cr = x.shape[3] if x.dim() == 4 else 1
+        P = x.numel() // Cr
+        C, Pc = (1, P // 2) if Cr == 1 else (Cr // 2, P)
+        y = torch.empty_like(x)
+        stats = torch.empty((C, 8), dtype=torch.float32, device=x.device)
+        coef = torch.empty((C, 6), dtype=torch.float32, device=x.device)
+        nbytes = lib.dcs_cbn_workspace_bytes(Pc, C)
+        if nbytes < 0:
+            raise DcsHipError(f'BatchNorm2d: unsupported channel count {Cr}')
+        ws = ops._workspace(nbytes, x.device)
+        d = lambda t: None if t is None else t.detach()
+        _lib.check(lib.dcs_rbn_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(d(weight)), _lib.ptr(d(bias)), _lib.ptr(running_mean),
+                                   _lib.ptr(running_var), _lib.ptr(stats), _lib.ptr(coef), _lib.ptr(ws), ws.numel(), P, Cr,
+                                   eps, -1.0 if momentum is None else momentum, int(bool(use_batch)), act,
+                                   _lib.cur_stream()), 'dcs_rbn_fwd')
+        ctx.cfg = (P, Cr, C, Pc, bool(use_batch), act, weight is not None)
+        ctx.save_for_backward(x, stats, coef)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        x, stats, coef = ctx.saved_tensors
+        P, Cr, C, Pc, use_batch, act, affine = ctx.cfg
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        gw = torch.empty(Cr, dtype=torch.float32, device=x.device) if affine else None
+        gb = torch.empty(Cr, dtype=torch.float32, device=x.device) if affine else None
+        ws = ops._workspace(lib.dcs_cbn_bwd_workspace_bytes(Pc, C), x.device)
+        _lib.check(lib.dcs_rbn_bwd(_lib.ptr(x), _lib.ptr(g), _lib.ptr(gx), _lib.ptr(stats), _lib.ptr(coef), _lib.ptr(gw),
+                                   _lib.ptr(gb), _lib.ptr(ws), ws.numel(), P, Cr, int(use_batch), act, _lib.cur_stream()),
+                   'dcs_rbn_bwd')
+        return gx, gw, gb, None, None, None, None, None, None
+
+
 class R_NETWORK(LightningModule):
     def __init__(self, config, hparams, seed):
         super().__init__()
@@ -163,6 +299,17 @@ class R_NETWORK(LightningModule):
             self.decoder_attention.append(RealSpatialAttention(sk))
         self.weights_init()
 
+    # ---- trainer hooks (r_network.py:176-363): the same bodies as C_NETWORK's with dtype "real" ---------------------
+    _step_dtype = 'real'
+
+    def _hooks():
+        from .c_network import C_NETWORK
+        return {k: getattr(C_NETWORK, k) for k in ('configure_optimizers', 'training_step', '_eval_step', 'validation_step',
+                                                   'test_step', '_epoch_end', 'validation_epoch_end', 'test_epoch_end',
+                                                   'on_after_backward')}
+    locals().update(_hooks())
+    del _hooks
+
     def weights_init(self):                            # r_network.py:126-137
         init = self.hparams['initialisation_distribution']
         for m in self.modules():
@@ -171,32 +318,21 @@ class R_NETWORK(LightningModule):
 
     # ---- pieces ---------------------------------------------------------------------------------------------------
     def _bn_act(self, bn, x, act):
-        """BatchNorm2d (+ activation) of a channels-last real tensor [B,H,W,Cr] with even Cr through the CBN apply kernel:
-        per complex pair (2k, 2k+1) the coefficients are the diagonal block (a0, 0, 0, a3 | c0, c1)."""
-        B, H, W, C = x.shape
-        if self.training or not bn.track_running_stats:
-            flat = x.reshape(-1, C)
-            mean, var = flat.mean(0), flat.var(0, unbiased=False)
-            if self.training and bn.track_running_stats:
-                n = flat.shape[0]
-                with torch.no_grad():
-                    bn.num_batches_tracked += 1
-                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                    bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                    bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
-        else:
-            mean, var = bn.running_mean, bn.running_var
-        scale = bn.weight * torch.rsqrt(var + bn.eps)
-        shift = bn.bias - mean * scale
-        z = torch.zeros_like(scale[0::2])
-        coef = torch.stack([scale[0::2], z, z, scale[1::2], shift[0::2], shift[1::2]], dim=1).contiguous()   # [C/2, 6]
-        stats = torch.zeros((C // 2, 8), dtype=torch.float32, device=x.device)
-        y, _, _ = ops.cbn(x.view(B, H, W, C // 2, 2), None, None, None, None, bn.eps, None, False, act,
-                          coef_cached=(stats, coef))
-        return y.view(B, H, W, C)
+        """BatchNorm2d (+ activation) of a channels-last real tensor ([B,H,W,Cr] with even Cr, or [B,F,T]: one channel) on
+        the CBN kernels (_RBnFn): statistics, running-statistic update, normalisation and activation; differentiable."""
+        use_batch = self.training or not bn.track_running_stats
+        momentum = None
+        if self.training and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+            momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            F.note_state_update()
+        return _RBnFn.apply(x.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum,
+                            use_batch, act)
 
     def _conv(self, conv, x1, x2=None, up=(1, 1), transposed=False):
         w = conv.weight
+        if torch.is_grad_enabled() and (w.requires_grad or x1.requires_grad):
+            return _RConvFn.apply(x1, x2, w, conv.bias, transposed, tuple(conv.stride), tuple(conv.padding), tuple(up))
         if transposed:                                 # stride-1 ConvTranspose2d = correlation with the flipped, swapped kernel
             kh, kw = w.shape[2:]
             pad = (kh - 1 - conv.padding[0], kw - 1 - conv.padding[1])
@@ -211,18 +347,30 @@ class R_NETWORK(LightningModule):
         """1 -> 16 real channels as a 1 -> 8 complex conv on (x, 0): filters (w[2k] + j w[2k+1]); the complex layer adds
         (b_r - b_i) + j (b_r + b_i), so b_r = (b[2k] + b[2k+1]) / 2, b_i = (b[2k+1] - b[2k]) / 2."""
         w, b = conv.weight, conv.bias
+        xc = torch.stack([x, torch.zeros_like(x)], dim=-1).unsqueeze(3)                    # [B,F,T,1,2]
+        if torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
+            be, bo = b[0::2], b[1::2]                          # weight views: autograd maps the gradients back
+            y = F.cconv2d(xc, None, w[0::2].contiguous(), w[1::2].contiguous(), (be + bo) / 2, (bo - be) / 2, False,
+                          tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding))
+            return y.flatten(3)
         def make():
             be, bo = b[0::2], b[1::2]
             return ops.pack_conv_weight(w[0::2].contiguous(), w[1::2].contiguous(), ((be + bo) / 2).contiguous(),
                                         ((bo - be) / 2).contiguous())
         wp, bias = _packed(conv, 'enc0', (w, b), make)
-        xc = torch.stack([x, torch.zeros_like(x)], dim=-1).unsqueeze(3)                    # [B,F,T,1,2]
         y = ops.cconv2d(xc, None, wp, bias, tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding))
         return y.flatten(3)                                                                 # [B,F,T,16]
 
     def _dec_last(self, convt, d, skip, up):
         """(C1 + C2) -> 1 real channels: real part of a complex conv with weights (w[2k] - j w[2k+1]) over cat(d, skip)."""
         w, b = convt.weight, convt.bias                                                     # [Cin_r, 1, kh, kw]
+        if torch.is_grad_enabled() and (w.requires_grad or d.requires_grad):
+            B, H, W, c1 = d.shape
+            kh, kw = convt.kernel_size
+            pad = (kh - 1 - convt.padding[0], kw - 1 - convt.padding[1])
+            y = F.cconv_single_output(d.view(B, H, W, c1 // 2, 2), skip.view(B, H, W, skip.shape[3] // 2, 2),
+                                      w[0::2].contiguous(), (-w[1::2]).contiguous(), b, torch.zeros_like(b), (kh, kw), pad, up)
+            return y[..., 0, 0]
         def make():
             return ops.pack_conv_weight(w[0::2].contiguous(), (-w[1::2]).contiguous(), b.contiguous(),
                                         torch.zeros_like(b), transposed=True, up=up)
@@ -243,6 +391,16 @@ class R_NETWORK(LightningModule):
         B, S, _ = x.shape
         Hh = lstm.hidden_size
         inp = x.reshape(B * S, -1)
+        if torch.is_grad_enabled() and (x.requires_grad or lstm.weight_ih_l0.requires_grad):
+            for layer in range(lstm.num_layers):             # projections: rocBLAS; recurrence + BPTT: lstm.hip
+                names = [f'_l{layer}', f'_l{layer}_reverse']
+                w_ih = torch.cat([getattr(lstm, 'weight_ih' + n) for n in names])
+                bias = torch.cat([getattr(lstm, 'bias_ih' + n) + getattr(lstm, 'bias_hh' + n) for n in names])
+                w_hh = torch.stack([getattr(lstm, 'weight_hh' + n) for n in names]).unsqueeze(0)
+                gx = torch.addmm(bias, inp, w_ih.t())
+                out = F._LstmRecFn.apply(gx.view(1, B, S, 2, 4 * Hh), w_hh.contiguous())
+                inp = out.reshape(B * S, 2 * Hh)
+            return inp.view(B, S, 2 * Hh)
         for layer in range(lstm.num_layers):
             names = [f'_l{layer}', f'_l{layer}_reverse']
             ps = [getattr(lstm, k + n) for n in names for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
@@ -258,8 +416,25 @@ class R_NETWORK(LightningModule):
         return inp.view(B, S, 2 * Hh)
 
     @staticmethod
+    def _attend_autograd(ca_m, sa_m, x):
+        """The same block under autograd: pools, FC and broadcast multiplies as differentiable torch ops, the 7x7 conv as
+        the complex path's conv node over the (mean, max) pair read as ONE complex channel with weights w_mean - j w_max
+        (its real part is the answer; the complex sigmoid epilogue acts on the parts separately)."""
+        mx = x.amax(dim=(1, 2))                                                          # [B, C]
+        w1, w2, w = ca_m.fc[0].weight.flatten(1), ca_m.fc[2].weight.flatten(1), sa_m.conv1.weight
+        ca = torch.sigmoid(torch.relu(mx @ w1.t()) @ w2.t())
+        z = x * ca[:, None, None, :]
+        pooled = torch.stack([z.mean(dim=-1), z.amax(dim=-1)], dim=-1).unsqueeze(3).contiguous()   # [B,H,W,1,2]
+        k = sa_m.kernel_size
+        sa = F.cconv2d(pooled, None, w[:, 0:1].contiguous(), (-w[:, 1:2]).contiguous(), None, None, False, (k, k), (1, 1),
+                       (k // 2, k // 2), (1, 1), F.ACT_SIGMOID)[..., 0]                  # [B,H,W,1]
+        return z * sa
+
+    @staticmethod
     def _attend(ca_m, sa_m, x):
         """sa (.) ca (.) x (r_network.py:155-158 / :166-167) in one C-ABI call: dcs_rattention_fwd."""
+        if torch.is_grad_enabled() and (x.requires_grad or sa_m.conv1.weight.requires_grad):
+            return R_NETWORK._attend_autograd(ca_m, sa_m, x)
         from . import _lib
         lib = _lib.load()
         B, H, W, C = x.shape
@@ -282,21 +457,10 @@ class R_NETWORK(LightningModule):
         L = hp['no_of_layers']
         if x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:
             raise DcsHipError(f'R_NETWORK.forward expects CUDA float32 [B,F,T], got {x.dtype} {tuple(x.shape)} on {x.device}')
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise DcsHipError('R_NETWORK: the HIP path is forward-only (call under torch.no_grad())')
         B, Fb, T = x.shape
-        bn0 = self.initial_batchnorm                     # one channel: a scalar affine (no pair to hand the CBN kernel)
-        if self.training:
-            mean, var = x.mean(), x.var(unbiased=False)
-            if bn0.track_running_stats:
-                n = x.numel()
-                bn0.num_batches_tracked += 1
-                m = bn0.momentum if bn0.momentum is not None else 1.0 / float(bn0.num_batches_tracked)
-                bn0.running_mean.mul_(1 - m).add_(mean * m)
-                bn0.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)) * m)
-        else:
-            mean, var = bn0.running_mean[0], bn0.running_var[0]
-        e = (x - mean) * torch.rsqrt(var + bn0.eps) * bn0.weight[0] + bn0.bias[0]
+        if (B * Fb * T) % 4:
+            raise DcsHipError(f'R_NETWORK.forward: B*F*T must be a multiple of 4, got {tuple(x.shape)}')
+        e = self._bn_act(self.initial_batchnorm, x, F.ACT_NONE)    # one channel: the P values as P/2 (re, im) pairs
         feats = [e]                                                                          # [B,F,T] (C = 1)
         drop = self.dropout_conv if self.training and self.dropout_conv.p > 0 else None
         for i in range(L):

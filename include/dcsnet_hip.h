@@ -137,7 +137,14 @@ int dcs_cconv2d_fwd_affine(const float* x1, const float* x2, const float* wp, co
  *         holds B[tap][8*kg + 4*kk + e][32*nt + j], kg < (C1r+C2r)/8, nt < ceil(Coutr/32), zero beyond Coutr
  *   bias  float[Coutr] or NULL
  * Geometry as dcs_cconv2d_fwd with real channel counts: (C1r + C2r) % 16 == 0, Coutr % 16 == 0, C1r % 4 == 0.
- * ConvTranspose2d (stride 1): pass the flipped, in/out-swapped kernel and padding k-1-p.  Forward only. */
+ * ConvTranspose2d (stride 1): pass the flipped, in/out-swapped kernel and padding k-1-p.
+ * dcs_rconv2d_bwd_data: gradient of the VIRTUAL input (the upsampled concatenation, Hv = Hin*up_f, Wv = Win*up_t) of the
+ *   forward call with real geometry (Cinr = C1r + C2r, Coutr, k, stride, pad): gxv float[B][Hv][Wv][Cinr] = stride-1
+ *   correlation of the zero-inserted g_Y with bm_bwd = the panel (same fragment order) of the flipped, in/out-swapped
+ *   kernel, B[tap][k = real output channel][n = real input channel].  Block sum over the upsample and channel split of
+ *   the concatenation: dcs_upsample_cat_bwd with complex channel counts C1r/2, C2r/2.  (The weight gradient of a real
+ *   conv comes from two dcs_cconv2d_bwd_weight calls, on x and on conj(x): with D_qr = sum g_q x_r the complex
+ *   gradients are (D_rr + D_ii) + j (D_ir - D_ri) and (D_rr - D_ii) + j (D_ir + D_ri) — dcsnet/r_network.py.) */
 long dcs_rconv2d_fwd_workspace_bytes(int B, int Hin, int Win, int C1r, int C2r, int up_f, int up_t, int Coutr,
                                      int kh, int kw, int sf, int st, int pad_f, int pad_t);
 int dcs_rconv2d_fwd(const float* x1, const float* x2, const float* bm, const float* bias, float* y,
@@ -145,6 +152,27 @@ int dcs_rconv2d_fwd(const float* x1, const float* x2, const float* bm, const flo
                     int B, int Hin, int Win, int C1r, int C2r, int up_f, int up_t,
                     int Coutr, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
                     dcs_stream_t stream);
+long dcs_rconv2d_bwd_data_workspace_bytes(int B, int Hv, int Wv, int Cinr, int Coutr, int kh, int kw, int sf, int st,
+                                          int pad_f, int pad_t);
+int dcs_rconv2d_bwd_data(const float* gy, const float* bm_bwd, float* gxv, void* workspace, long workspace_bytes,
+                         int B, int Hv, int Wv, int Cinr, int Coutr, int kh, int kw, int sf, int st, int pad_f, int pad_t,
+                         dcs_stream_t stream);
+
+/* torch.nn.BatchNorm2d (+ ReLU / LeakyReLU) of a REAL channels-last tensor float[P][Cr] (DR-Net: r_network.py:56,66,106)
+ * on the CBN kernels: with even Cr the tensor is an interleaved complex one with Cr/2 channels, dcs_cbn_fwd's statistics
+ * pass yields every real channel's moments, and the affine map is the diagonal 2x2 block a = gamma / sqrt(var + eps).
+ * Cr == 1 (the initial BatchNorm over the magnitude [B,F,T]; P % 4 == 0): the P values are read as P/2 complex pixels
+ * whose halves are the same channel.  weight / bias / running_mean / running_var: float[Cr] (the module's own
+ * buffers; running_var updated with the unbiased n/(n-1) estimate, as torch does).  stats_out float[ceil(Cr/2)][8],
+ * coef_out float[ceil(Cr/2)][6]: saved for dcs_rbn_bwd.  workspace: dcs_cbn_workspace_bytes(P or P/2, Cr/2 or 1).
+ * dcs_rbn_bwd: g_x (may alias g_out), g_weight / g_bias float[Cr] (NULL, NULL for affine=False);
+ * workspace: dcs_cbn_bwd_workspace_bytes of the same (pixels, complex channels). */
+int dcs_rbn_fwd(const float* x, float* y, const float* weight, const float* bias, float* running_mean, float* running_var,
+                float* stats_out, float* coef_out, void* workspace, long workspace_bytes, long P, int Cr, float eps,
+                float momentum, int use_batch_stats, int act, dcs_stream_t stream);
+int dcs_rbn_bwd(const float* x, const float* g_out, float* g_x, const float* stats, const float* coef, float* g_weight,
+                float* g_bias, void* workspace, long workspace_bytes, long P, int Cr, int use_batch_stats, int act,
+                dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Gradients of dcs_cconv2d_fwd (what torch.autograd derives for the reference through the four

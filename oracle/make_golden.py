@@ -205,6 +205,49 @@ def rnet_vectors(rn, nf):
     return res
 
 
+def rnet_grad_vectors(rn, nf):
+    """Gradients of the reference's own R_NETWORK (r_network.py: stock torch.nn layers, no stand-in anywhere): train-mode
+    forward on a seeded magnitude input, a fixed scalar functional of the mask, every parameter's gradient norm and a
+    set of full gradient tensors."""
+    from oracle.seeded_state import seeded_input, fill_state_stream
+    cfg = _ref_config(nf)
+    cfg.RactivationE, cfg.RactivationD = torch.nn.ReLU, torch.nn.LeakyReLU
+    res = {}
+    B, T = 2, 32
+    net = rn.R_NETWORK(cfg, _ref_hparams(dropout=False), 0)
+    fill_state_stream(net, 5)
+    net.train()
+    x = seeded_input(B, 256, T, seed=9).abs()
+    out = net(x)
+    g = torch.Generator().manual_seed(78)
+    w = torch.rand(out.shape, generator=g)
+    loss = (w * (out ** 2 + 0.3 * out)).sum()
+    net.zero_grad()
+    loss.backward()
+    res['x'], res['out'], res['loss_w'], res['loss'] = _c(x), _c(out), _c(w), _c(loss)
+    names, norms = [], []
+    for n, p in net.named_parameters():
+        names.append(n)
+        norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+    res['grad_names'] = np.array(names)
+    res['grad_norms'] = np.array(norms, dtype=np.float64)
+    keep = ('encoder.0.0.weight', 'encoder.0.0.bias', 'encoder.1.0.weight', 'encoder.3.0.weight', 'encoder.2.1.weight',
+            'encoder.5.1.bias', 'initial_batchnorm.weight', 'initial_batchnorm.bias', 'decoder.0.0.weight',
+            'decoder.4.0.weight', 'decoder.5.0.bias', 'decoder.6.weight', 'decoder.6.bias', 'decoder.2.1.weight',
+            'lstm.weight_hh_l0', 'lstm.weight_ih_l1_reverse', 'lstm.bias_ih_l0', 'fc.weight', 'fc.bias',
+            'skip_attention.0.fc.0.weight', 'skip_attention.5.conv1.weight', 'decoder_attention.2.fc.2.weight',
+            'decoder_attention.9.conv1.weight')
+    pd = dict(net.named_parameters())
+    for k in keep:                                   # large tensors: every 37th element (the test samples likewise)
+        gk = pd[k].grad
+        res[f'grad_{k}'] = _c(gk if gk.numel() <= 20000 else gk.flatten()[::37])
+    sd = net.state_dict()
+    for k in ('initial_batchnorm.running_mean', 'initial_batchnorm.running_var', 'encoder.2.1.running_mean',
+              'encoder.2.1.running_var', 'decoder.1.1.running_var'):
+        res[f'after_{k}'] = _c(sd[k])
+    return res
+
+
 def loss_vectors(nf):
     """The reference's calc_loss (network_functions.py:168-208) for every noise_loss_type 0-6 on seeded masks and
     signals (sys.argv[1] must read 'dcs' while it runs)."""
@@ -241,6 +284,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)                      # bit-stable reductions
     np.savez_compressed(os.path.join(OUT, 'loss_vectors.npz'), **loss_vectors(nf))
+    np.savez_compressed(os.path.join(OUT, 'rnet_grad_vectors.npz'), **rnet_grad_vectors(rn, nf))
     sys.argv = argv
     if '--only-new' in argv:                      # leave the fixtures of earlier rounds untouched
         return

@@ -148,6 +148,21 @@ def dcs_train_losses(net, noise, noisy, clean, speech_alpha=0.7, eps=ATAN2_EPS):
     return noise_loss, speech_loss, noise_loss + speech_loss
 
 
+def drs_train_losses(net, noise, noisy, clean, speech_alpha=0.7, eps=ATAN2_EPS):
+    """network_functions.py:210-232, :249-258 in 'drs' mode (dtype "real": R_NETWORK sees |noisy|, returns a sigmoid mask;
+    the estimates keep the noisy phase) with calc_loss :168-208, noise_loss_type 6 / speech_loss_type 0."""
+    noise_audio = mag_phase_2_wave(*_polar(noise, eps))
+    clean_audio = mag_phase_2_wave(*_polar(clean, eps))
+    noisy_mag, noisy_phase = _polar(noisy, eps)
+    mask = net(noisy_mag)
+    n_mag = noisy_mag * mask
+    n_hat_audio = mag_phase_2_wave(n_mag, noisy_phase)
+    s_hat_audio = mag_phase_2_wave(noisy_mag - n_mag, noisy_phase)
+    noise_loss = 1 - speech_alpha * (-si_snr(noise_audio, n_hat_audio))
+    speech_loss = speech_alpha * (-si_snr(clean_audio, s_hat_audio))
+    return noise_loss, speech_loss, noise_loss + speech_loss
+
+
 def stft_frontend(clean_wave, noisy_wave, n_fft=512, hop=32, window=None, normalized=True):
     """data.py:104-134 for a batch of cropped [B, L] waveforms: noise = noisy - clean in the time domain, then
     torch.stft (center=True, reflect padding) of clean, noise and noisy, keeping bins 1..n_fft/2.

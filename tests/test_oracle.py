@@ -209,3 +209,31 @@ def test_rnetwork_oracle_against_reference(golden_dir, tag, B, T):
         tr = net(x)
     assert torch.allclose(tr, _t(v[f'{tag}_train']), rtol=1e-5, atol=1e-6)
     assert float(ev.min()) >= 0.0 and float(ev.max()) <= 1.0              # sigmoid magnitude mask
+
+
+def test_rnetwork_oracle_gradients_against_reference(golden_dir):
+    """Autograd through the oracle R_NETWORK against the gradients of the reference's own r_network.py (train mode,
+    fixed scalar functional of the mask): all 116 gradient norms and 23 tensors (large ones sampled every 37th element)."""
+    from oracle.rnet_oracle import R_NETWORK_Oracle
+    from oracle.seeded_state import fill_state_stream
+    v = np.load(os.path.join(golden_dir, 'rnet_grad_vectors.npz'))
+    net = fill_state_stream(R_NETWORK_Oracle(dropout_conv=0.0, dropout_fc=0.0), 5).train()
+    out = net(_t(v['x']))
+    assert torch.allclose(out, _t(v['out']), rtol=1e-5, atol=1e-6)
+    loss = (_t(v['loss_w']) * (out ** 2 + 0.3 * out)).sum()
+    loss.backward()
+    assert abs(float(loss) - float(v['loss'])) <= 1e-5 * abs(float(v['loss']))
+    pd = dict(net.named_parameters())
+    names = [str(n) for n in v['grad_names']]
+    assert sorted(names) == sorted(pd)
+    for n, want in zip(names, v['grad_norms']):
+        g = pd[n].grad
+        if want < 0:
+            assert g is None, n
+        else:
+            assert abs(float(g.norm()) - want) <= 2e-3 * want + 2e-5, (n, float(g.norm()), want)
+    for k in v.files:
+        if k.startswith('grad_') and k not in ('grad_names', 'grad_norms'):
+            g, want = pd[k[5:]].grad, _t(v[k])
+            got = g if g.numel() <= 20000 else g.flatten()[::37]
+            assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max()) + 1e-6, k
