@@ -70,12 +70,14 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
     float c = 0.f, hprev = 0.f;
     if (t < H) h_s[0][t] = 0.f;
     float pre = gxp[(long)t0 * stride_t];
+    float pre2 = S > 1 ? gxp[(long)(t0 + dt) * stride_t] : 0.f;        // two steps of input projections in flight
     __syncthreads();
     const bool is_g = gate == 2;
     for (int s = 0; s < S; ++s) {
         const int tt = t0 + s * dt, cur = s & 1;
-        float nxt = 0.f;
-        if (s + 1 < S) nxt = gxp[(long)(tt + dt) * stride_t];
+        const float nxt = pre2;
+        pre2 = 0.f;
+        if (s + 2 < S) pre2 = gxp[(long)(tt + 2 * dt) * stride_t];
         // four accumulation chains as two packed FMAs per float4 of h (v_pk_fma_f32: half the VALU issue slots of the
         // scalar form; same chains, same rounding)
         v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
@@ -141,10 +143,14 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_bwd_kernel(const float* __rest
     };
     fetch(S - 1, act, cp, go);
     c = cs[(((long)n * S + (t0 + (S - 1) * dt)) * 2 + dir) * H + u];
+    // operands of the next TWO steps in flight: one step of compute (~0.5 us) is shorter than an L2 / HBM round trip
+    float q_act = 0.f, q_cp = 0.f, q_go = 0.f;                         // step s - 1
+    if (S > 1) fetch(S - 2, q_act, q_cp, q_go);
     for (int s = S - 1; s >= 0; --s) {
         const int tt = t0 + s * dt, cur = s & 1;
-        float n_act = 0.f, n_cp = 0.f, n_go = 0.f;
-        if (s > 0) fetch(s - 1, n_act, n_cp, n_go);
+        float n_act = q_act, n_cp = q_cp, n_go = q_go;
+        q_act = 0.f; q_cp = 0.f; q_go = 0.f;
+        if (s > 1) fetch(s - 2, q_act, q_cp, q_go);
         const float ig = quad_bcast0(act), fg = quad_bcast1(act), gg = quad_bcast2(act), og = quad_bcast3(act);
         const float tc = fast_tanh(c);
         const float gh = go + gh_rec;

@@ -18,4 +18,15 @@ for mode in train infer; do
   done
   rm -rf $out/stats_$mode $out/pmc_${mode}_FETCH_SIZE $out/pmc_${mode}_WRITE_SIZE
 done
+for mode in train infer; do
+  echo "[collect] pmc MFMA utilisation $mode"
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $out/pmc_${mode}_mfma -- python3 $R/bench.py --mode $mode --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_${mode}_mfma.log 2>&1
+  cp $(find $out/pmc_${mode}_mfma -name "*counter_collection.csv" | head -1) $out/pmc_${mode}_mfma.csv
+  rm -rf $out/pmc_${mode}_mfma
+done
+echo "[collect] sustained fp32 MFMA peak + per-layer conv tables"
+hipcc -O3 --offload-arch=gfx950 $R/tools/micro/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && timeout -k 5 120 /tmp/mfma_peak > $out/mfma_peak.txt
+hipcc -O3 --offload-arch=gfx950 $R/tools/micro/dma_rate.hip -o /tmp/dma_rate 2>/dev/null && timeout -k 5 60 /tmp/dma_rate > $out/dma_rate.txt
+timeout -k 10 300 python3 $R/tools/conv_ab.py 32 256 5 > $out/conv_ab_train.txt 2>/dev/null
+timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 32 256 > $out/conv_layers_train.txt 2>/dev/null
 echo "[collect] done"; ls -la $out
