@@ -29,6 +29,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 // quad_perm DPP: every lane of a quad reads lane K of its quad (broadcast) or its xor-partner
+// The per-step barrier of the recurrences: LDS traffic drained, then s_barrier.  __syncthreads() would also wait for
+// every outstanding GLOBAL access (vmcnt(0)): the prefetched operands of the coming steps and the step's own stores —
+// an L2 / HBM round trip on the critical path of every time step.  Only the h / g_pre vector in LDS crosses the barrier.
+__device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int CTRL>
 __device__ __forceinline__ float quad_dpp(float v) { return dcs_dpp_term<CTRL, 0xf>(v); }
 __device__ __forceinline__ float quad_bcast0(float v) { return quad_dpp<0x00>(v); }
@@ -56,13 +61,19 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
     const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int set = n / seqs_per_set, ns = n % seqs_per_set;
 
-    float w[H];
-    {
-        const float4* wr = reinterpret_cast<const float4*>(whh + ((long)(set * 2 + dir) * G4 + j) * H);
+    // The quad of hidden unit u splits the dot products over h: lane `gate` holds, for ALL four gate rows of the unit, the
+    // H/4 weights that multiply h[gate*H/4 .. (gate+1)*H/4) — the same 64 FMAs per lane as one whole row, but as four
+    // independent chains over H/16 LDS reads instead of one chain over H/4 reads (the step was bound by that chain's
+    // read -> FMA latency, ~1100 cycles), and the four partial sums of a row meet in a quad DPP sum.
+    constexpr int Q = H / 4;
+    float w[4][Q];
 #pragma unroll
-        for (int k = 0; k < H / 4; ++k) {
+    for (int g = 0; g < 4; ++g) {
+        const float4* wr = reinterpret_cast<const float4*>(whh + ((long)(set * 2 + dir) * G4 + g * H + u) * H + gate * Q);
+#pragma unroll
+        for (int k = 0; k < Q / 4; ++k) {
             const float4 v = wr[k];
-            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            w[g][4 * k] = v.x; w[g][4 * k + 1] = v.y; w[g][4 * k + 2] = v.z; w[g][4 * k + 3] = v.w;
         }
     }
     const float* gxp = gx + set * stride_set + ns * stride_n + dir * G4 + j;
@@ -78,17 +89,21 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
         const float nxt = pre2;
         pre2 = 0.f;
         if (s + 2 < S) pre2 = gxp[(long)(tt + 2 * dt) * stride_t];
-        // four accumulation chains as two packed FMAs per float4 of h (v_pk_fma_f32: half the VALU issue slots of the
-        // scalar form; same chains, same rounding)
-        v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
-        const float4* h4 = reinterpret_cast<const float4*>(h_s[cur]);
+        // packed FMAs (v_pk_fma_f32: half the VALU issue slots of the scalar form), one accumulator pair per gate row
+        v2f acc[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+        const float4* h4 = reinterpret_cast<const float4*>(h_s[cur] + gate * Q);
 #pragma unroll
-        for (int k = 0; k < H / 4; ++k) {
+        for (int k = 0; k < Q / 4; ++k) {
             const float4 hv = h4[k];
-            a01 = __builtin_elementwise_fma(v2f{w[4 * k], w[4 * k + 1]}, v2f{hv.x, hv.y}, a01);
-            a23 = __builtin_elementwise_fma(v2f{w[4 * k + 2], w[4 * k + 3]}, v2f{hv.z, hv.w}, a23);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[g] = __builtin_elementwise_fma(v2f{w[g][4 * k], w[g][4 * k + 1]}, v2f{hv.x, hv.y}, acc[g]);
+                acc[g] = __builtin_elementwise_fma(v2f{w[g][4 * k + 2], w[g][4 * k + 3]}, v2f{hv.z, hv.w}, acc[g]);
+            }
         }
-        const float a = pre + ((a01.x + a01.y) + (a23.x + a23.y));
+        const float s0 = quad_sum(acc[0].x + acc[0].y), s1 = quad_sum(acc[1].x + acc[1].y);
+        const float s2 = quad_sum(acc[2].x + acc[2].y), s3 = quad_sum(acc[3].x + acc[3].y);
+        const float a = pre + (gate == 0 ? s0 : (gate == 1 ? s1 : (gate == 2 ? s2 : s3)));
         const float th = fast_tanh(is_g ? a : 0.5f * a);
         const float act = is_g ? th : fmaf(0.5f, th, 0.5f);
         if (SAVE) gates_save[(((long)n * S + tt) * 2 + dir) * G4 + j] = act;
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
             }
         }
         hprev = h;
-        __syncthreads();
+        step_barrier();
         pre = nxt;
     }
 }
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_bwd_kernel(const float* __rest
         g_pre[(((long)n * S + tt) * 2 + dir) * G4 + j] = mine;
         c = cp;                                                        // c_{t-1} of this step is c_t of the next one
         act = n_act; cp = n_cp; go = n_go;
-        __syncthreads();
+        step_barrier();
         v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
         const float4* g4 = reinterpret_cast<const float4*>(gp_s[cur] + gate * H);
 #pragma unroll
