@@ -34,54 +34,112 @@ struct WArgs {
     // Hy / Wy: full g_Y extent (addressing).
     int ncls, os_f, os_t, Hy, Wy;
     int pad_f[4], pad_t[4], oo_f[4], oo_t[4];
+    long long* dbg;            // diagnostic builds only (-DDCS_WGRAD_DIAG): per-wave phase times (s_memtime ticks)
 };
 
-// MT row tiles (8 output channels each) per wave; WS waves split the tile's PIXELS (k-steps) and
-// 4/WS waves split the output channels, so layers with few output channels still fill all four
-// SIMDs: the pixel partials are combined through LDS once, after the last tile.
-// Two workgroups per CU (<= 256 VGPR + AGPR per lane) whenever the accumulator set allows it: one gathers while
-// the other runs its MFMAs.
-template <int KH, int KW, int MT, int WS>
-__global__ __launch_bounds__(256, (MT * KH * KW * 4 <= 160 && !(KH == 5 && WS == 4) ? 2 : 1)) void cconv_wgrad_mfma_kernel(WArgs w) {
+#ifndef DCS_WG_RING_BIG
+#define DCS_WG_RING_BIG 2
+#endif
+#ifndef DCS_WG_RING_SMALL
+#define DCS_WG_RING_SMALL 4
+#endif
+#ifdef DCS_WGRAD_DIAG
+#define WDIAG_NOW() ((long long)__builtin_amdgcn_s_memtime())
+long long* g_wdbg = nullptr;
+#else
+#define WDIAG_NOW() 0LL
+#endif
+
+// MT row tiles (8 output channels each) per wave.  Plain form (TS = false): WS waves split the tile's PIXELS
+// (k-steps) and 4/WS waves split the output channels, so layers with few output channels still fill all four
+// SIMDs: the pixel partials are combined through LDS once, after the last tile.  Tap-split form (TS = true: the
+// 7x7 layer with 16 output channels): the four waves split the TAPS (13 each) and every wave covers all MT*8 output
+// channels of the block and all pixels — 104 accumulator registers per lane instead of 196, so two workgroups fit a CU
+// and overlap each other's gathers.
+// Two workgroups per CU (<= 256 VGPR + AGPR per lane) whenever the accumulator set allows it.
+//
+// The k-step loop of a tile is FULLY unrolled: the g_Y fragments of the next D k-steps are in flight in a register ring
+// whose slots are compile-time indices, every load is unconditional (clamped address, value masked when consumed), so
+// the compiler's s_waitcnt vmcnt(N) counts are exact.  As a rolled loop with predicated loads it drained vmcnt(0)
+// at every back edge — each trip waited out the L2 round trip of the loads it had just issued.
+template <int KH, int KW, int MT, int WS, bool TS>
+__global__ __launch_bounds__(256, (MT * (TS ? (KH * KW + 3) / 4 : KH * KW) * 4 <= 160 && !(KH == 5 && WS == 4) ? 2 : 1))
+void cconv_wgrad_mfma_kernel(WArgs w) {
     constexpr int TAPS = KH * KW;
-    const int cls = blockIdx.z;
-    constexpr int WCO = 4 / WS;
-    constexpr bool GL = MT == 1 && WS >= 2;             // g_Y tile through LDS (<= 16 output channels per workgroup)
-    constexpr int GQ = WCO * 4;                         // float4 per pixel of the g_Y block (WCO*8 channels x 2 floats)
-    constexpr int GP = WCO * 16 + (WCO == 1 ? 0 : 16);  // float pitch per pixel: pixel stride == 16 banks (mod 32)
+    constexpr int TPW = TS ? (TAPS + 3) / 4 : TAPS;     // taps per wave
+    constexpr int PS = TS ? 1 : WS;                     // waves sharing a tile's pixels
+    constexpr int WCO = TS ? 1 : 4 / WS;                // waves sharing the block's output channels
+    constexpr bool GL = TS || (MT == 1 && WS >= 2);     // g_Y tile through LDS (<= 16 output channels per workgroup)
+    constexpr int GLW = TS ? MT : WCO;                  // 8-channel groups per pixel of that block
+    constexpr int GQ = GLW * 4;                         // float4 per pixel of the g_Y block
+    constexpr int GP = GLW * 16 + (GLW == 1 ? 0 : 16);  // float pitch per pixel: pixel stride == 16 banks (mod 32)
+    constexpr int KSW = BMP / 4 / PS;                   // k-steps per wave of a full tile
+    constexpr int KCYC = MT * TPW * 32;                 // MFMA cycles of one k-step
+    constexpr int D0 = (3200 + KCYC - 1) / KCYC;        // ring depth: >= ~1.3 us of MFMAs between a load and its use
+    constexpr int D = GL ? 2 : (D0 < 2 ? 2 : (D0 > 8 ? 8 : D0));
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     const conv::Args& a = w.c;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cls = blockIdx.z;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int ci0 = (blockIdx.y / w.co_blocks) * CHUNK;
-    const int part = wave % WS;                                       // which share of the pixels
-    const int co0 = (blockIdx.y % w.co_blocks) * (WCO * MT * 8) + (wave / WS) * (MT * 8);   // first output channel
-    const int N1 = 2 * a.Cout;                                        // floats per gY pixel
+    const int part = TS ? 0 : wave % WS;                                // which share of the pixels
+    const int cb0 = (blockIdx.y % w.co_blocks) * (GLW * 8);             // first output channel of the block (GL)
+    const int co0 = TS ? cb0 : (blockIdx.y % w.co_blocks) * (WCO * MT * 8) + (wave / WS) * (MT * 8);   // first output channel
+    const int cooff = TS ? 0 : (wave / WS) * 16;                        // this wave's float offset inside a g_Y block pixel
+    const int tap0 = TS ? wave * TPW : 0;
+    const int N1 = 2 * a.Cout;                                          // floats per gY pixel
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int npix = a.rows * a.cols;
+    const int npx = w.TH * w.TW;                                        // 128; 64 on maps too small to fill 128
+    const int pad_f = w.pad_f[cls], pad_t = w.pad_t[cls], oo_f = w.oo_f[cls], oo_t = w.oo_t[cls];
+    const int rowoff = a.cols * PIX;
 
-    f32x4 acc[MT][TAPS];
+    f32x4 acc[MT][TPW];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int tp = 0; tp < TAPS; ++tp) acc[i][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tp = 0; tp < TPW; ++tp) acc[i][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) bsum[i] = 0.f;
 
     // column (row of D) this lane feeds for each of its row tiles; masked beyond Cout
     bool colok[MT];
-    int gcol[MT];
+    int gcol[MT], gcl[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         gcol[i] = 2 * (co0 + i * 8) + li;
         colok[i] = (co0 + i * 8 + (li >> 1)) < a.Cout;
+        gcl[i] = colok[i] ? gcol[i] : 0;
+    }
+    // LDS float offset of each of this wave's taps (tap-split: taps past the last one repeat it and are dropped at the end)
+    int toff[TPW];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+        const int tap = tap0 + tp < TAPS ? tap0 + tp : TAPS - 1;
+        toff[tp] = TS ? (tap / KW) * rowoff + (tap % KW) * PIX : (tp / KW) * rowoff + (tp % KW) * PIX;
     }
 
-    for (int tl = blockIdx.x; tl < w.total_tiles; tl += w.n_slabs) {
+    long long d_gather = 0, d_mfma = 0, d_tiles = 0;
+    const long long d_start = WDIAG_NOW();
+    int tiles_done = 0;
+    const int my_tiles = (w.total_tiles - (int)blockIdx.x + w.n_slabs - 1) / w.n_slabs;      // >= 1: n_slabs <= total_tiles
+    for (int tl = blockIdx.x; tl < w.total_tiles; tl += w.n_slabs, ++tiles_done) {
+        const long long s0 = WDIAG_NOW();
+        // Co-resident workgroups do equal work; the SIMD's oldest-first arbitration lets the first one run ahead and the
+        // last one finish alone on a pipe one wave cannot fill (dec2, four per CU: lifetimes 76 / 95 / 111 / 124 us).  A
+        // workgroup that is ahead yields: its priority falls with the share of its tiles it has finished (100 - 118 us).
+        {
+            const int q = tiles_done * 4 / my_tiles;
+            if (q == 0) __builtin_amdgcn_s_setprio(3);
+            else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
         const int oy0 = (tile_id / a.tiles_w) * w.TH, ox0 = (tile_id % a.tiles_w) * w.TW;
-        const int vy0 = oy0 * a.sf - w.pad_f[cls], vx0 = ox0 * a.st - w.pad_t[cls];
+        const int vy0 = oy0 * a.sf - pad_f, vx0 = ox0 * a.st - pad_t;
         __syncthreads();
         // one thread per patch pixel: its 8 complex channels are 64 contiguous bytes (4 x 16-byte loads), so the index
         // arithmetic (two runtime divisions + the upsample / zero-insertion mapping) runs once per pixel, not per load
@@ -99,68 +157,102 @@ __global__ __launch_bounds__(256, (MT * KH * KW * 4 <= 160 && !(KH == 5 && WS ==
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v[q];
         }
+        float* gt = patch + npix * PIX;
         if (GL) {
             // few output channels (<= 16 per workgroup): a k-step is only TAPS*32 cycles of MFMA, far less than the L2 round trip
-            // of its g_Y fragment — stage the tile's g_Y block [128 pixels][co_per_block*2] in LDS with coalesced
+            // of its g_Y fragment — stage the tile's g_Y block [pixels][co_per_block*2] in LDS with coalesced
             // 16-byte loads instead (zeros outside the map / beyond Cout), and feed the A fragments from there
-            float* gt = patch + npix * PIX;
-            const int cb0 = (blockIdx.y % w.co_blocks) * (WCO * 8);           // first output channel of the block
-            for (int idx = t; idx < BMP * GQ; idx += 256) {
+            for (int idx = t; idx < npx * GQ; idx += 256) {
                 const int q = idx % GQ, p = idx / GQ;
                 const int oy = oy0 + (p >> w.twshift), ox = ox0 + (p & (w.TW - 1));
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (oy < a.Hout && ox < a.Wout && 2 * cb0 + 4 * q < N1)
-                    v = *reinterpret_cast<const float4*>(w.gy + (((long)b * w.Hy + oy * w.os_f + w.oo_f[cls]) * w.Wy +
-                                                                 ox * w.os_t + w.oo_t[cls]) * N1 + 2 * cb0 + 4 * q);
+                    v = *reinterpret_cast<const float4*>(w.gy + (((long)b * w.Hy + oy * w.os_f + oo_f) * w.Wy +
+                                                                 ox * w.os_t + oo_t) * N1 + 2 * cb0 + 4 * q);
                 *reinterpret_cast<float4*>(gt + p * GP + q * 4) = v;
             }
         }
         __syncthreads();
-        // gY fragments come from L2 with ~1-2 us latency and a k-step is only MT*TAPS*32 cycles of MFMA: keep the
-        // next RING k-steps' loads in flight (static register ring; the k-step loop is unrolled over it)
-        constexpr int RING = MT >= 4 ? 2 : 4;                          // BMP/4/WS is 32, 16 or 8
-        float afr[RING][MT];
+        const long long s1 = WDIAG_NOW();
+        d_gather += s1 - s0;
+        // A k-step's four pixels are ks*4 + lk, lk = lane / 16 < 4 <= TW: row and first column of a k-step are
+        // wave-uniform (scalar registers), the lane adds lk.  tws / twm are re-read opaquely per tile so that the 32
+        // unrolled k-steps' scalars are computed where they are used instead of being hoisted out of the tile loop (as
+        // loop invariants they held ~100 registers).
+        int tws = w.twshift, twm = w.TW - 1;
+        asm volatile("" : "+s"(tws), "+s"(twm));
+        const float* gyb = w.gy + (long)b * w.Hy * w.Wy * N1;
+        const int xlane = lk * a.st * PIX + li;                        // lane part of a patch address (floats)
+        const int glane = lk * w.os_t * N1;                            // lane part of a g_Y pixel offset (floats)
+        float afr[D][MT];
         auto load_g = [&](int ks, float* dst) {
+            const int spy = (ks * 4) >> tws, spx = (ks * 4) & twm;     // scalar
             if (GL) {
-                dst[0] = patch[npix * PIX + (ks * 4 + lk) * GP + (wave / WS) * 16 + li];
+                const float* g = gt + (ks * 4 + lk) * GP + cooff + li;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) dst[i] = g[i * 16];
                 return;
             }
-            const int p = ks * 4 + lk;
-            const int oy = oy0 + (p >> w.twshift), ox = ox0 + (p & (w.TW - 1));
-            const bool inb = oy < a.Hout && ox < a.Wout;
-            const float* gp = w.gy + (((long)b * w.Hy + (inb ? oy * w.os_f + w.oo_f[cls] : 0)) * w.Wy +
-                                      (inb ? ox * w.os_t + w.oo_t[cls] : 0)) * N1;
+            const int oy = oy0 + spy, ox = ox0 + spx;                  // scalar; this lane's column is ox + lk
+            const bool inb = oy < a.Hout && ox + lk < a.Wout;
+            const int soff = ((oy * w.os_f + oo_f) * w.Wy + ox * w.os_t + oo_t) * N1;       // < 2^31 floats inside one image
+            const float* gp = gyb + (inb ? soff + glane : 0);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) dst[i] = (inb && colok[i]) ? gp[gcol[i]] : 0.f;
+            for (int i = 0; i < MT; ++i) dst[i] = gp[gcl[i]];          // always a load; masked when consumed
         };
+        auto xp_of = [&](int ks) -> const float* {
+            const int spy = (ks * 4) >> tws, spx = (ks * 4) & twm;     // scalar
+            return patch + ((spy * a.sf) * a.cols + spx * a.st) * PIX + xlane;
+        };
+        const int ks_last = npx / 4 - 1;
 #pragma unroll
-        for (int r = 0; r < RING; ++r) load_g(part + r * WS, afr[r]);
-        for (int ks0 = part; ks0 < BMP / 4; ks0 += WS * RING) {
+        for (int r = 0; r < D; ++r) load_g(part + r * PS, afr[r]);
+        // the first PFT taps' values are read one k-step ahead (an LDS round trip is 3-4 MFMAs long), the rest at the top
+        // of their own k-step; a scheduling barrier per k-step keeps the unrolled code from hoisting later k-steps' reads
+        constexpr int PFT = TPW < 4 ? TPW : 4;
+        float bq[PFT];
+        {
+            const float* xp = xp_of(part);
 #pragma unroll
-            for (int r = 0; r < RING; ++r) {
-                const int ks = ks0 + r * WS;
-                const int p = ks * 4 + lk;                             // this lane's pixel of the k-step
-                const int py = p >> w.twshift, pxx = p & (w.TW - 1);
-                float af[MT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    af[i] = afr[r][i];
-                    bsum[i] += af[i];
-                }
-                if (ks + WS * RING < BMP / 4) load_g(ks + WS * RING, afr[r]);
-                const float* xp = patch + ((py * a.sf) * a.cols + pxx * a.st) * PIX + li;
-#pragma unroll
-                for (int tp = 0; tp < TAPS; ++tp) {
-                    const float bf = xp[((tp / KW) * a.cols + (tp % KW)) * PIX];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        acc[i][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][tp], 0, 0, 0);
-                }
-            }
+            for (int q = 0; q < PFT; ++q) bq[q] = xp[toff[q]];
         }
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) {
+            const int ks = part + j * PS;
+            if (ks * 4 >= npx) break;
+            const int spy = (ks * 4) >> tws, spx = (ks * 4) & twm;
+            const bool inb = GL || (oy0 + spy < a.Hout && ox0 + spx + lk < a.Wout);
+            float af[MT], bc[PFT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                af[i] = (GL || (inb && colok[i])) ? afr[j % D][i] : 0.f;
+                bsum[i] += af[i];
+            }
+#pragma unroll
+            for (int q = 0; q < PFT; ++q) bc[q] = bq[q];
+            // (look-ahead k-steps are clamped to the tile's last one: a 64-pixel tile ends before the unrolled loop does)
+            if (j + D < KSW) load_g(min(part + (j + D) * PS, ks_last), afr[j % D]);
+            const float* xp = xp_of(ks);
+            if (j + 1 < KSW) {
+                const float* xn = xp_of(min(ks + PS, ks_last));
+#pragma unroll
+                for (int q = 0; q < PFT; ++q) bq[q] = xn[toff[q]];
+            }
+#pragma unroll
+            for (int tp = 0; tp < TPW; ++tp) {
+                const float bf = tp < PFT ? bc[tp] : xp[toff[tp]];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    acc[i][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][tp], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        d_mfma += WDIAG_NOW() - s1;
+        ++d_tiles;
     }
+    const long long d_epi = WDIAG_NOW();
 
-    if (WS > 1) {                      // combine the pixel shares: waves with part > 0 hand over through LDS
+    if (!TS && WS > 1) {               // combine the pixel shares: waves with part > 0 hand over through LDS
         __syncthreads();
         float* red = patch;            // reused: [(WS-1) * WCO][MT*TAPS*4 + MT][64]
         constexpr int PER = MT * TAPS * 4 + MT;
@@ -196,23 +288,25 @@ __global__ __launch_bounds__(256, (MT * KH * KW * 4 <= 160 && !(KH == 5 && WS ==
     const long wsz = (long)TAPS * Cin * a.Cout;
     float2* slab = w.slab_w + ((long)blockIdx.x * w.ncls + cls) * wsz;
     const int ci = ci0 + (li >> 1);
+    // Lane pair (2m, 2m+1) holds columns (ci, re) and (ci, im) of rows r = 0..3 = (co_a, re), (co_a, im), (co_b, re),
+    // (co_b, im).  The even lane finishes co_a = (e0 + o1, e1 - o0), the odd lane co_b = (e2 + o3, e3 - o2): each sends its
+    // partner the two values that one needs (one DPP quad swap each) and every lane stores one float2 — the eight lanes
+    // of a ci write 64 contiguous bytes.
+    const bool odd = li & 1;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        const int co = co0 + i * 8 + lk * 2 + (odd ? 1 : 0);
 #pragma unroll
-        for (int tp = 0; tp < TAPS; ++tp) {
+        for (int tp = 0; tp < TPW; ++tp) {
+            const int tap = tap0 + tp;
             const f32x4 v = acc[i][tp];
-            // partner lane holds the (ci, im) column of the same rows
-            const float o0 = __shfl_xor(v[0], 1, 64), o1 = __shfl_xor(v[1], 1, 64);
-            const float o2 = __shfl_xor(v[2], 1, 64), o3 = __shfl_xor(v[3], 1, 64);
-            if ((li & 1) == 0) {
-                const int co_a = co0 + i * 8 + lk * 2, co_b = co_a + 1;
-                // rows r=0,1 -> (co_a, re), (co_a, im); r=2,3 -> (co_b, re), (co_b, im)
-                if (co_a < a.Cout) slab[((long)tp * Cin + ci) * a.Cout + co_a] = make_float2(v[0] + o1, v[1] - o0);
-                if (co_b < a.Cout) slab[((long)tp * Cin + ci) * a.Cout + co_b] = make_float2(v[2] + o3, v[3] - o2);
-            }
+            const float t0 = dcs_dpp_term<0xB1, 0xf>(odd ? v[0] : v[2]);     // quad_perm [1,0,3,2]: the partner's value
+            const float t1 = dcs_dpp_term<0xB1, 0xf>(odd ? v[1] : v[3]);
+            const float2 g = odd ? make_float2(t0 + v[3], t1 - v[2]) : make_float2(v[0] + t1, v[1] - t0);
+            if (co < a.Cout && tap < TAPS) slab[((long)tap * Cin + ci) * a.Cout + co] = g;
         }
     }
-    if (ci0 == 0) {                                                    // bias: column sums of gY
+    if (ci0 == 0 && (!TS || wave == 0)) {                              // bias: column sums of gY
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float s = bsum[i];
@@ -221,9 +315,27 @@ __global__ __launch_bounds__(256, (MT * KH * KW * 4 <= 160 && !(KH == 5 && WS ==
             if (lk == 0 && colok[i]) w.slab_b[((long)blockIdx.x * w.ncls + cls) * N1 + gcol[i]] = s;
         }
     }
+#ifdef DCS_WGRAD_DIAG
+    if (w.dbg && lane == 0) {
+        const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (wg < 8192) {
+            long long* d = w.dbg + (wg * 4 + wave) * 8;
+            const long long e = WDIAG_NOW();
+            d[0] = d_gather; d[1] = d_mfma; d[2] = e - d_epi; d[3] = e - d_start; d[4] = d_tiles; d[5] = d_start;
+            d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+            d[7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_REG_XCC_ID [3:0]
+        }
+    }
+#endif
 }
 
-template <int KH_, int KW_, int MT_, int WS_> struct Variant { static constexpr int KH = KH_, KW = KW_, MT = MT_, WS = WS_; };
+template <int KH_, int KW_, int MT_, int WS_, bool TS_ = false> struct Variant {
+    static constexpr int KH = KH_, KW = KW_, MT = MT_, WS = WS_;
+    static constexpr bool TS = TS_;
+    static constexpr int CPB = TS_ ? MT_ * 8 : (4 / WS_) * MT_ * 8;                 // output channels per workgroup
+    static constexpr bool GL = TS_ || (MT_ == 1 && WS_ >= 2);
+    static constexpr int GLW = TS_ ? MT_ : 4 / WS_;
+};
 
 // (MT, WS) so that the 4 waves cover min(Cout, most-per-kernel-size) output channels without idle lanes
 template <class F>
@@ -254,33 +366,35 @@ int dispatch(int kh, int kw, int co, F&& f) {
             if (co >= 16) return f(Variant<3, 3, 1, 2>{});
             return f(Variant<3, 3, 1, 4>{});
         case 55:
-            if (co >= 64) return f(Variant<5, 5, 2, 1>{});
+            // (MT = 2 for >= 64 output channels holds 200 accumulator registers: one workgroup per CU, every stall exposed;
+            //  two 32-channel blocks gather the patch twice and run at three workgroups per CU)
             if (co >= 32) return f(Variant<5, 5, 1, 1>{});
             if (co >= 16) return f(Variant<5, 5, 1, 2>{});
             return f(Variant<5, 5, 1, 4>{});
         case 77:
             if (co >= 32) return f(Variant<7, 7, 1, 1>{});
-            if (co >= 16) return f(Variant<7, 7, 1, 2>{});
+            if (co >= 16) return f(Variant<7, 7, 2, 1, true>{});
             return f(Variant<7, 7, 1, 4>{});
         default: return DCS_ERR_BADARG;
     }
 }
 
 template <class V>
-size_t lds_bytes(int rows, int cols) {
+size_t lds_bytes(int rows, int cols, int npx) {
     size_t lds = (size_t)rows * cols * PIX * sizeof(float);
-    if (V::MT == 1 && V::WS >= 2) lds += (size_t)BMP * ((4 / V::WS) * 16 + (V::WS == 4 ? 0 : 16)) * sizeof(float);   // g_Y tile
-    const size_t red = (size_t)(V::WS - 1) * (4 / V::WS) * (V::MT * V::KH * V::KW * 4 + V::MT) * 64 * sizeof(float);
+    if (V::GL) lds += (size_t)npx * (V::GLW * 16 + (V::GLW == 1 ? 0 : 16)) * sizeof(float);   // g_Y tile
+    const size_t red = V::TS ? 0 : (size_t)(V::WS - 1) * (4 / V::WS) * (V::MT * V::KH * V::KW * 4 + V::MT) * 64 * sizeof(float);
     return red > lds ? red : lds;
 }
 
 // workgroups of this variant one CU holds at once (registers / LDS), queried once per variant
 template <class V>
 int resident_per_cu(size_t lds) {
-    static int cached = 0;
+    static int by_kb[161] = {0};                        // per LDS size (KB): the same variant serves several tile geometries
+    int& cached = by_kb[lds / 1024 > 160 ? 160 : lds / 1024];
     if (cached == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cconv_wgrad_mfma_kernel<V::KH, V::KW, V::MT, V::WS>, 256, lds) !=
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cconv_wgrad_mfma_kernel<V::KH, V::KW, V::MT, V::WS, V::TS>, 256, lds) !=
                 hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 1;
@@ -293,14 +407,25 @@ int resident_per_cu(size_t lds) {
 template <class V>
 int launch(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
-    const size_t lds = lds_bytes<V>(a.rows, a.cols);
+    size_t lds = lds_bytes<V>(a.rows, a.cols, w.TH * w.TW);
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
-    auto fn = cconv_wgrad_mfma_kernel<V::KH, V::KW, V::MT, V::WS>;
-    if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
-    const int co_per_block = (4 / V::WS) * V::MT * 8;
+    auto fn = cconv_wgrad_mfma_kernel<V::KH, V::KW, V::MT, V::WS, V::TS>;
+    const int co_per_block = V::CPB;
     w.co_blocks = (a.Cout + co_per_block - 1) / co_per_block;
     dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks, w.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
+    // All workgroups are resident at once and do equal work, so the kernel ends with the CU that was handed the most of
+    // them — and the dispatcher fills a CU as far as its registers and LDS allow (dec2: 1024 workgroups planned as four per
+    // CU landed as 3 / 4 / 5, lifetimes 76 / 100 / 124 us).  Ask for just enough LDS that one more than planned cannot fit.
+    {
+        const long wgs = (long)grid.x * grid.y * grid.z;
+        const long per = (wgs + 255) / 256;
+        if (per <= resident_per_cu<V>(lds)) {
+            const size_t want = (size_t)160 * 1024 / (per + 1) + 2048;
+            if (want > lds && want <= 150 * 1024) lds = want;
+        }
+    }
+    if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     DCS_LAUNCH(fn, grid, dim3(256), lds, stream, w);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
@@ -353,21 +478,37 @@ int slabs_for(const conv::Args& c, int ncls, int TH, int TW) {
     int per_cu = 1, cpb = 8;
     dispatch(c.kh, c.kw, c.Cout, [&](auto v) {
         using V = decltype(v);
-        per_cu = resident_per_cu<V>(lds_bytes<V>(rows, cols));
-        cpb = (4 / V::WS) * V::MT * 8;
+        per_cu = resident_per_cu<V>(lds_bytes<V>(rows, cols, TH * TW));
+        cpb = V::CPB;
         return 0;
     });
     const long grid_y = (long)((c.C1 + c.C2) / CHUNK) * ((c.Cout + cpb - 1) / cpb) * ncls;
-    long want = (256L * per_cu + grid_y - 1) / grid_y;
-    if (want < 1) want = 1;
-    if (want < cap) cap = want;
-    return (int)(tiles < cap ? tiles : cap);
+    if (tiles <= 1) return 1;
+    // A CU's MFMA pipe serialises the tiles of all workgroups it holds, and the kernel ends with its fullest CU: pick
+    // the slab count n whose busiest CU has the least work = workgroups per CU x (tiles per workgroup + the workgroup's
+    // fixed epilogue, ~0.2 tile) / how well that many co-resident workgroups hide each other's gathers and LDS round
+    // trips (measured: dec2 / dec3 / dec4 at four per CU beat two per CU with twice the tiles by 10-25 %; 704 workgroups
+    // = 2.75 per CU with three tiles each lose to 512 with four tiles each); more than fit at once run in rounds.
+    long best = 1;
+    double best_cost = 1e30;
+    const long nmax = tiles < cap ? tiles : cap;
+    for (long n = 1; n <= nmax; ++n) {
+        const long wgs = n * grid_y, per = (wgs + 255) / 256, tpw = (tiles + n - 1) / n;
+        static const double eff[5] = {1.0, 0.70, 0.88, 0.95, 1.0};
+        double cost = (double)per * ((double)tpw + 0.2) / eff[per < per_cu ? per : per_cu];
+        if (per > per_cu) cost *= 1.15;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = n; }
+    }
+    return (int)best;
 }
 
-void tile_shape(int Hc, int* TH, int* TW) {
-    if (Hc >= 8) { *TH = 8; *TW = 16; }
+void tile_shape(int Hc, int Wc, int kh, int sf, int* TH, int* TW) {
+    // a 7x7 stride-2 patch of an 8 x 16 tile is 21 x 37 pixels = 62 KB: one workgroup per CU by LDS; 4 x 16 tiles (38 KB)
+    if (kh >= 7 && sf >= 2 && Hc >= 4) { *TH = 4; *TW = 16; }
+    else if (Hc >= 8) { *TH = 8; *TW = 16; }
     else if (Hc >= 4) { *TH = 4; *TW = 32; }
-    else { *TH = 2; *TW = 64; }
+    else if (Wc > 32) { *TH = 2; *TW = 64; }
+    else { *TH = 2; *TW = 32; }          // a map too small to fill 128 pixels (enc6 at T = 256: 2 x 32): 64-pixel tiles
 }
 
 // c: class-space geometry; f: classes; Hy x Wy: full g_Y extent
@@ -375,6 +516,11 @@ int launch_classes(const conv::Args& c, const Fold& f, int Hy, int Wy, const flo
                    int n_slabs, int TH, int TW, hipStream_t stream) {
     WArgs w;
     w.c = c;
+#ifdef DCS_WGRAD_DIAG
+    w.dbg = g_wdbg;
+#else
+    w.dbg = nullptr;
+#endif
     w.gy = gy; w.slab_w = slab_w; w.slab_b = slab_b; w.n_slabs = n_slabs;
     w.TH = TH; w.TW = TW;
     w.twshift = TW == 16 ? 4 : (TW == 32 ? 5 : 6);
@@ -392,13 +538,17 @@ int launch_classes(const conv::Args& c, const Fold& f, int Hy, int Wy, const flo
 
 }  // namespace
 
+#ifdef DCS_WGRAD_DIAG
+extern "C" int dcs_debug_set_wgrad_buffer(void* p) { g_wdbg = (long long*)p; return 0; }
+#endif
+
 bool dcs_conv_wgrad_mfma_ok(int Cin, int Cout, int kh, int kw, int C1) {
     return (Cin % 8) == 0 && (Cout % 8) == 0 && kh == kw && (kh == 1 || kh == 3 || kh == 5 || kh == 7) && !(C1 & 1);
 }
 
 // number of partial slabs and the tile shape for a forward geometry (a.Hout / a.Wout set)
 int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW) {
-    tile_shape(a.Hout, TH, TW);
+    tile_shape(a.Hout, a.Wout, a.kh, a.sf, TH, TW);
     return slabs_for(a, 1, *TH, *TW);
 }
 
@@ -406,7 +556,7 @@ int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW) {
 int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, float* slab_b, int n_slabs,
                                hipStream_t stream) {
     int TH, TW;
-    tile_shape(a.Hout, &TH, &TW);
+    tile_shape(a.Hout, a.Wout, a.kh, a.sf, &TH, &TW);
     Fold f{};
     f.ncls = 1; f.kh = a.kh; f.kw = a.kw; f.os_f = 1; f.os_t = 1;
     f.pad_f[0] = a.pad_f; f.pad_t[0] = a.pad_t;
@@ -423,10 +573,10 @@ bool dcs_conv_wgrad_fold_ok(const conv::Args& a) {
     // worse than the plain form does
     const Fold f = fold_of(a);
     int th, tw;
-    tile_shape(a.Hin, &th, &tw);
-    const long folded = (long)((a.Win + tw - 1) / tw) * ((a.Hin + th - 1) / th) * f.ncls * f.kh * f.kw;
-    tile_shape(a.Hout, &th, &tw);
-    const long plain = (long)((a.Wout + tw - 1) / tw) * ((a.Hout + th - 1) / th) * a.kh * a.kw;
+    tile_shape(a.Hin, a.Win, 3, 1, &th, &tw);
+    const long folded = (long)((a.Win + tw - 1) / tw) * ((a.Hin + th - 1) / th) * th * tw * f.ncls * f.kh * f.kw;
+    tile_shape(a.Hout, a.Wout, a.kh, a.sf, &th, &tw);
+    const long plain = (long)((a.Wout + tw - 1) / tw) * ((a.Hout + th - 1) / th) * th * tw * a.kh * a.kw;
     return folded < plain;
 }
 
@@ -434,7 +584,7 @@ long dcs_conv_wgrad_fold_workspace_bytes(const conv::Args& a) {
     const Fold f = fold_of(a);
     const conv::Args c = class_args(a, f);
     int TH, TW;
-    tile_shape(c.Hout, &TH, &TW);
+    tile_shape(c.Hout, c.Wout, c.kh, c.sf, &TH, &TW);
     const long ns = slabs_for(c, f.ncls, TH, TW);
     return ns * f.ncls * ((long)f.kh * f.kw * (a.C1 + a.C2) * a.Cout + a.Cout) * (long)sizeof(float2);
 }
@@ -445,7 +595,7 @@ int dcs_conv_wgrad_fold_run(const conv::Args& a, const float* gy, void* workspac
     const Fold f = fold_of(a);
     const conv::Args c = class_args(a, f);
     int TH, TW;
-    tile_shape(c.Hout, &TH, &TW);
+    tile_shape(c.Hout, c.Wout, c.kh, c.sf, &TH, &TW);
     const int ns = slabs_for(c, f.ncls, TH, TW);
     const int Cin = a.C1 + a.C2;
     const long wsz_c = (long)f.kh * f.kw * Cin * a.Cout;

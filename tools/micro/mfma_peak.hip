@@ -2,6 +2,8 @@
 // against in DESIGN.md (the datasheet's 157.3 TFLOP/s assumes 2.4 GHz; MI355X_MICROARCH.md, "DVFS give-back").
 //   mode 0  bare v_mfma_f32_32x32x2_f32 chains, operands in registers (random data), one wave per SIMD, 4 accumulators
 //   mode 1  the same with one ds_read_b128 per 4 MFMAs (the conv kernels' operand traffic)
+//   mode 2  ONE accumulator per wave: every MFMA depends on the one before it (the <2,1,1,CH> conv kernel's chain)
+//   mode 3  mode 2 with one ds_read_b128 per 4 MFMAs
 // prints TFLOP/s and the in-kernel clock (delta s_memtime / delta s_memrealtime x 100 MHz).
 // build + run: hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
 #include <hip/hip_runtime.h>
@@ -23,6 +25,20 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* s
         if (MODE == 1) {
             const float4 v = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + it * 64) & 4092));
             a0 = v.x; a1 = v.y; b0 = v.z; b1 = v.w;
+        }
+        if (MODE == 3) {
+            const float4 v = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + it * 64) & 4092));
+            a0 = v.x; a1 = v.y; b0 = v.z; b1 = v.w;
+        }
+        if (MODE >= 2) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[0], 0, 0, 0);
+            }
+            continue;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -46,15 +62,17 @@ int main() {
     for (auto& v : h) v = (float)rand() / RAND_MAX * 2.f - 1.f;
     hipMalloc(&src, h.size() * 4); hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&sink, 4096); hipMalloc(&clk, grid * 16);
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         double best = 0, last = 0; float ms = 0;
-        const int launches = 60;                   // ~2.5 s of back-to-back launches
+        const int launches = 20;                   // ~1 s of back-to-back launches
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
             for (int l = 0; l < launches; ++l) {
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, src, sink, clk, iters);
-                else hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, src, sink, clk, iters);
+                else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, src, sink, clk, iters);
+                else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, src, sink, clk, iters);
+                else hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, src, sink, clk, iters);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
@@ -67,7 +85,7 @@ int main() {
         for (int i = 0; i < grid; ++i) ghz.push_back((double)c[2 * i] / (double)c[2 * i + 1] * 0.1);
         std::sort(ghz.begin(), ghz.end());
         printf("mode %d (%s): %.1f TFLOP/s sustained (last of 3 x %.1f s), best %.1f; in-kernel clock median %.3f GHz\n", mode,
-               mode ? "ds_read_b128 per 4 MFMAs" : "operands in registers", last, ms * 1e-3, best, ghz[grid / 2]);
+               mode == 0 ? "operands in registers" : mode == 1 ? "ds_read_b128 per 4 MFMAs" : mode == 2 ? "single dependent chain" : "single chain + ds_read_b128 per 4 MFMAs", last, ms * 1e-3, best, ghz[grid / 2]);
     }
     return 0;
 }
