@@ -28,6 +28,13 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef DCS_FWD_DIAG
+#define FDIAG_NOW() ((long long)__builtin_amdgcn_s_memtime())
+long long* g_fdbg = nullptr;
+#else
+#define FDIAG_NOW() 0LL
+#endif
+
 
 
 // wave grid: WAVES_N waves along N, 4/WAVES_N along M; each wave owns WM x WN tiles of 32x32.
@@ -55,6 +62,23 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int kk = lane >> 5, li = lane & 31;
 
+    const long long d_start = FDIAG_NOW();
+    long long d_gather = 0, d_mfma = 0;
+#ifdef DCS_FWD_STAGGER
+    if ((((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) >> 8) & 1) __builtin_amdgcn_s_sleep(DCS_FWD_STAGGER);
+#endif
+#ifdef DCS_FWD_STAGGER2
+    {   // spread the CUs over the gather / MFMA period so that the chip's gathers do not all hit memory at once
+        const unsigned ph = (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) >> 3) & 7;
+        for (unsigned q = 0; q < ph; ++q) __builtin_amdgcn_s_sleep(DCS_FWD_STAGGER2);
+    }
+#endif
+#ifdef DCS_FWD_PRIO
+    {
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if ((lin >> DCS_FWD_PRIO) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int b = blockIdx.x / tiles_per_img, tile_id = blockIdx.x % tiles_per_img;
     const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
@@ -118,7 +142,9 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         spx[p] = conv::src_pixel(a, b, vy0 + p / cols, vx0 + p % cols, &sp) ? (int)sp : -1;
     }
 
+    const long long d_loop = FDIAG_NOW();
     for (int ch = c_begin; ch < n_chunks; ++ch) {
+        const long long g0 = FDIAG_NOW();
         __syncthreads();                                               // previous chunk fully consumed
         // gather in rounds of GU independent loads per thread (all in flight together), then the LDS stores.  The source
         // pixel of every patch pixel comes from the table built once above: per slot a shift, an LDS read and one
@@ -157,6 +183,8 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
             }
         }
         __syncthreads();
+        const long long g1 = FDIAG_NOW();
+        d_gather += g1 - g0;
         float4 af[2][WM];
 #pragma unroll
         for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const float4*>(patch + pixoff[i]);
@@ -206,67 +234,85 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
             }
             tapoff = tapoff2;
         }
+        d_mfma += FDIAG_NOW() - g1;
     }
-
-    // epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (m.ksplit > 1) {                                                // raw partial tile of this K slice
-        float* pf = m.part + (long)kslice * m.slab_floats;
-        float* pfb = pf + (long)b * a.Hout * a.Wout * m.N;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = (nt0 + j) * 32 + li;
-            if (n >= m.N) continue;
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    const int pi = (wm * WM + i) * 32 + row;
-                    const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
-                    if (oy < k.Hc && ox < k.Wc)      // 32-bit offsets inside one image (launcher checks the extent)
-                        pfb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * m.N + n] = acc[i][j][r];
-                }
+    const long long d_epi = FDIAG_NOW();
+#ifdef DCS_FWD_DIAG
+    auto diag_out = [&]() {
+        if (m.dbg && lane == 0 && wave == 0) {
+            const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            if (wg < 16384) {
+                long long* d = m.dbg + wg * 8;
+                const long long e = FDIAG_NOW();
+                d[0] = d_gather; d[1] = d_mfma; d[2] = e - d_epi; d[3] = e - d_start; d[4] = d_loop - d_start; d[5] = d_start;
+                d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                d[7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
             }
         }
-        return;
-    }
+    };
+#endif
+
+    // epilogue.  C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) — a lane holds 16 rows of ONE
+    // column, so storing from the accumulators is 16 dword stores per tile that each touch two 128-byte rows (the texture
+    // addresser of a CU took ~4-5 us to work off its eight waves' stores, with nothing left to overlap it).  Each wave
+    // transposes its tile through its own 4.5 KB of the (now idle) patch instead: 16 ds_write_b32, 4 ds_read_b128, and
+    // a lane owns 4 consecutive columns (two complex channels) of 4 rows: 4 float4 stores per tile, 8 whole rows each.
+    __syncthreads();                                                   // every wave is done reading the patch
+    constexpr int TP = 36;                                             // row pitch (floats): 16-byte aligned rows
+    float* tsm = patch + wave * 32 * TP;
+    const int c4 = lane & 7, r8 = lane >> 3;
     const float* biasf = reinterpret_cast<const float*>(a.bias);
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-        const int n = (nt0 + j) * 32 + li;
-        if (n >= m.N) continue;                                        // zero-padded columns of a 16-wide N
-        const float bv = biasf ? biasf[n] : 0.f;
-        // folded eval-mode CBN: this lane's column is (channel n/2, re | im); its partner column sits in lane ^ 1
-        // out = fma(c_re, re, fma(c_im, im, c_add)): the association order of cbn_apply_kernel, so the folded and the
-        // two-kernel forms agree bit for bit
-        float c_re = 1.f, c_im = 0.f, c_add = 0.f;
-        if (a.coef) {
-            const float* q = a.coef + 6 * (n >> 1);
-            if (n & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
+        const int n0 = (nt0 + j) * 32 + 4 * c4;                        // this lane's first column after the transpose
+        // columns >= nsplit belong to the second tensor of a concatenation (nsplit = 2 * C1 is a multiple of 4)
+        const bool second = m.ksplit <= 1 && m.y2 != nullptr && n0 >= m.nsplit;      // (a K slice stores raw [pixel][N] tiles)
+        const int width = m.ksplit > 1 || m.y2 == nullptr ? m.N : (second ? m.N - m.nsplit : m.nsplit);
+        const int col = second ? n0 - m.nsplit : n0;
+        float* yb;
+        if (m.ksplit > 1) yb = m.part + (long)kslice * m.slab_floats + (long)b * a.Hout * a.Wout * m.N;   // raw partial tile
+        else yb = (second ? m.y2 : reinterpret_cast<float*>(a.y)) + (long)b * a.Hout * a.Wout * width;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float q[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) q[e] = 0.f;
+        if (m.ksplit <= 1 && n0 < m.N) {
+            if (biasf) bv = *reinterpret_cast<const float4*>(biasf + n0);
+            // folded eval-mode CBN: out = fma(c_re, re, fma(c_im, im, c_add)) per component, the association order of
+            // cbn_apply_kernel, so the folded and the two-kernel forms agree bit for bit
+            if (a.coef) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) q[e] = a.coef[6 * (n0 >> 1) + e];
+            }
         }
-        // columns >= nsplit belong to the second tensor of a concatenation
-        const bool second = m.y2 != nullptr && n >= m.nsplit;
-        float* yf = second ? m.y2 : reinterpret_cast<float*>(a.y);
-        const int width = m.y2 == nullptr ? m.N : (second ? m.N - m.nsplit : m.nsplit);
-        const int col = second ? n - m.nsplit : n;
-        float* yb = yf + (long)b * a.Hout * a.Wout * width;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            for (int r = 0; r < 16; ++r) tsm[((r & 3) + 8 * (r >> 2) + 4 * kk) * TP + li] = acc[i][j][r];
+            // (a wave's LDS operations complete in order: no barrier between its own writes and reads)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int row = r8 + 8 * qq;
+                float4 v = *reinterpret_cast<const float4*>(tsm + row * TP + 4 * c4);
                 const int pi = (wm * WM + i) * 32 + row;
                 const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
-                float v = acc[i][j][r] + bv;
-                if (a.coef) {
-                    const float pv = dcs_dpp_term<0xB1, 0xf>(v);                     // quad_perm [1,0,3,2]: the partner column
-                    v = (n & 1) ? fmaf(c_re, pv, fmaf(c_im, v, c_add)) : fmaf(c_re, v, fmaf(c_im, pv, c_add));
+                if (m.ksplit <= 1) {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (a.coef) {
+                        const float4 u = v;
+                        v.x = fmaf(q[0], u.x, fmaf(q[1], u.y, q[4])); v.y = fmaf(q[2], u.x, fmaf(q[3], u.y, q[5]));
+                        v.z = fmaf(q[6], u.z, fmaf(q[7], u.w, q[10])); v.w = fmaf(q[8], u.z, fmaf(q[9], u.w, q[11]));
+                    }
+                    v.x = dcs_act(v.x, a.act); v.y = dcs_act(v.y, a.act); v.z = dcs_act(v.z, a.act); v.w = dcs_act(v.w, a.act);
                 }
-                if (oy < k.Hc && ox < k.Wc)
-                    yb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] = dcs_act(v, a.act);
+                if (n0 < m.N && oy < k.Hc && ox < k.Wc)      // 32-bit offsets inside one image (launcher checks the extent)
+                    *reinterpret_cast<float4*>(yb + ((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col) = v;
             }
         }
     }
+#ifdef DCS_FWD_DIAG
+    diag_out();
+#endif
 }
 
 // ---- N = 16 (Cout = 8) variant ---------------------------------------------------------------------------
@@ -439,7 +485,8 @@ thread_local bool g_force_wide_panel = false;
 template <int WAVES_N, int WM, int WN, int CH, bool BF, int TPI>
 int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    const size_t lds = (size_t)npix * ((BF ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
+    size_t lds = (size_t)npix * ((BF ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
+    if (lds < 4 * 32 * 36 * sizeof(float)) lds = 4 * 32 * 36 * sizeof(float);        // the epilogue's four transpose tiles
     auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, BF, TPI>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);
@@ -639,6 +686,11 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
     m.c.tiles_w = (Wc + m.TW - 1) / m.TW;
     m.c.tiles_h = (Hc + m.TH - 1) / m.TH;
     m.slab_floats = (long)a.B * a.Hout * a.Wout * m.N;
+#ifdef DCS_FWD_DIAG
+    m.dbg = g_fdbg;
+#else
+    m.dbg = nullptr;
+#endif
     m.ksplit = p.S; m.cps = p.cps; m.part = (float*)ws;
     if (p.S > 1 && (!ws || ws_bytes < (long)p.S * m.slab_floats * (long)sizeof(float) || (m.N & 3) ||
                     (y2 != nullptr && (nsplit & 3)))) {
@@ -700,3 +752,7 @@ int dcs_conv_mfma_launch(conv::Args& a, const float* bm, void* ws, long ws_bytes
     const conv::Cls c = plain_class(a);
     return dcs_conv_mfma_launch_classes(a, bm, 1, &c, 1, 1, nullptr, 0, ws, ws_bytes, stream);
 }
+
+#ifdef DCS_FWD_DIAG
+extern "C" int dcs_debug_set_fwd_buffer(void* p) { g_fdbg = (long long*)p; return 0; }
+#endif

@@ -18,6 +18,7 @@ struct MArgs {
     int ksplit, cps;           // slices, chunks per slice
     float* part;
     long slab_floats;          // B * Hout * Wout * N
+    long long* dbg;            // diagnostic builds only (-DDCS_FWD_DIAG): per-workgroup phase times (core clocks)
 };
 
 // conv_pipe.hip.  eligible: whether a geometry planned with (cand, CH) can run on the pipelined kernel at all
