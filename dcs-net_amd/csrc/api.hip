@@ -1,7 +1,7 @@
 // api.hip — version / error-string entry points of include/dcsnet_hip.h.
 #include "dcs_common.h"
 
-extern "C" int dcs_abi_version(void) { return 9; }
+extern "C" int dcs_abi_version(void) { return 10; }
 
 extern "C" const char* dcs_error_string(int code) {
     switch (code) {

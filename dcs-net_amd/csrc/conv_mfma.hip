@@ -64,21 +64,6 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 
     const long long d_start = FDIAG_NOW();
     long long d_gather = 0, d_mfma = 0;
-#ifdef DCS_FWD_STAGGER
-    if ((((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) >> 8) & 1) __builtin_amdgcn_s_sleep(DCS_FWD_STAGGER);
-#endif
-#ifdef DCS_FWD_STAGGER2
-    {   // spread the CUs over the gather / MFMA period so that the chip's gathers do not all hit memory at once
-        const unsigned ph = (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) >> 3) & 7;
-        for (unsigned q = 0; q < ph; ++q) __builtin_amdgcn_s_sleep(DCS_FWD_STAGGER2);
-    }
-#endif
-#ifdef DCS_FWD_PRIO
-    {
-        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        if ((lin >> DCS_FWD_PRIO) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-    }
-#endif
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int b = blockIdx.x / tiles_per_img, tile_id = blockIdx.x % tiles_per_img;
     const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
@@ -487,6 +472,9 @@ int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
     size_t lds = (size_t)npix * ((BF ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
     if (lds < 4 * 32 * 36 * sizeof(float)) lds = 4 * 32 * 36 * sizeof(float);        // the epilogue's four transpose tiles
+#ifdef DCS_FWD_ONE_PER_CU
+    if (lds < 84 * 1024) lds = 84 * 1024;                                            // experiment: one workgroup per CU
+#endif
     auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, BF, TPI>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);

@@ -251,13 +251,29 @@ __global__ __launch_bounds__(kThreads) void sisnr_bwd_kernel(const float* __rest
     const float s = g[0] * scale;
     g_est[b * L + i] = s * (coef[2 * b] * clean[b * L + i] + coef[2 * b + 1] * est[b * L + i]);
 }
+
+// the configured loss pair on STACKED signals: rows [0, B) = noise, rows [B, 2B) = speech.
+//   noise_loss = 1 + alpha mean(snr_n), speech_loss = -alpha mean(snr_s), total = their sum; g_* = upstream gradients of
+//   the three outputs (device scalars, any may be null): g_est[b] = (g_noise + g_total) * alpha / B * d snr_b  (b < B),
+//                                                                  -(g_speech + g_total) * alpha / B * d snr_b (b >= B)
+__global__ __launch_bounds__(kThreads) void sisnr_pair_bwd_kernel(const float* __restrict__ tgt, const float* __restrict__ est,
+                                                                   const float* __restrict__ coef, const float* __restrict__ g_noise,
+                                                                   const float* __restrict__ g_speech, const float* __restrict__ g_total,
+                                                                   float alpha_over_B, float* __restrict__ g_est, int B, int L) {
+    const long b = blockIdx.y;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= L) return;
+    const float gt = g_total ? g_total[0] : 0.f;
+    const float s = b < B ? ((g_noise ? g_noise[0] : 0.f) + gt) * alpha_over_B : -((g_speech ? g_speech[0] : 0.f) + gt) * alpha_over_B;
+    g_est[b * L + i] = s * (coef[2 * b] * tgt[b * L + i] + coef[2 * b + 1] * est[b * L + i]);
+}
 }  // namespace
 
 namespace {
 // the reference's loss assembly for noise_loss_type 6 / speech_loss_type 0 (network_functions.py:168-208) on the two
 // per-utterance SiSNR vectors: out = {noise_loss = 1 - alpha * (-mean snr_n), speech_loss = alpha * (-mean snr_s), sum}
 __global__ __launch_bounds__(64) void sisnr_losses_kernel(const float* __restrict__ snr_s, const float* __restrict__ snr_n,
-                                                           float* __restrict__ out, int B, float alpha) {
+                                                           float* __restrict__ out, int B, float alpha, float* __restrict__ skip) {
     float a = 0.f, b = 0.f;
     for (int i = threadIdx.x; i < B; i += 64) { a += snr_s[i]; b += snr_n[i]; }
     a = dcs_wave_sum(a) / (float)B;
@@ -265,6 +281,7 @@ __global__ __launch_bounds__(64) void sisnr_losses_kernel(const float* __restric
     if (threadIdx.x == 0) {
         const float noise_loss = 1.f - alpha * (-b), speech_loss = alpha * (-a);
         out[0] = noise_loss; out[1] = speech_loss; out[2] = noise_loss + speech_loss;
+        if (skip) skip[0] = out[2] != out[2] ? 1.f : 0.f;        // the step guard of dcs_step_guard, without its launch
     }
 }
 }  // namespace
@@ -272,7 +289,27 @@ __global__ __launch_bounds__(64) void sisnr_losses_kernel(const float* __restric
 extern "C" int dcs_sisnr_losses_fwd(const float* snr_speech, const float* snr_noise, float* out3, int B, float alpha,
                                     dcs_stream_t stream) {
     if (!snr_speech || !snr_noise || !out3 || B <= 0) return DCS_ERR_BADARG;
-    DCS_LAUNCH(sisnr_losses_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), snr_speech, snr_noise, out3, B, alpha);
+    DCS_LAUNCH(sisnr_losses_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), snr_speech, snr_noise, out3, B, alpha,
+               (float*)nullptr);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_sisnr_losses_guard_fwd(const float* snr_speech, const float* snr_noise, float* out3, int B, float alpha,
+                                          float* skip, dcs_stream_t stream) {
+    if (!snr_speech || !snr_noise || !out3 || B <= 0) return DCS_ERR_BADARG;
+    DCS_LAUNCH(sisnr_losses_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), snr_speech, snr_noise, out3, B, alpha, skip);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_sisnr_pair_bwd(const float* target, const float* est, const float* coef, const float* g_noise,
+                                  const float* g_speech, const float* g_total, float alpha, float* g_est, int B, int L,
+                                  dcs_stream_t stream) {
+    if (!target || !est || !coef || !g_est || B <= 0 || 2 * B > 65535 || L <= 0) return DCS_ERR_BADARG;
+    if (!g_noise && !g_speech && !g_total) return DCS_ERR_BADARG;
+    DCS_LAUNCH(sisnr_pair_bwd_kernel, dim3((L + kThreads - 1) / kThreads, 2 * B), dim3(kThreads), 0, dcs_stream(stream), target,
+               est, coef, g_noise, g_speech, g_total, alpha / (float)B, g_est, B, L);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

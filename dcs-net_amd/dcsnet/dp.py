@@ -268,9 +268,15 @@ class TrainStep:
         if self._plan is not None:
             functional.run_pack_plan(self._plan)
         self.bucket.zero_grad()
-        loss = self._loss_no_sync(batch, 0)
-        # the NaN test training_step makes on the host, on the device: flag element of the gradient bucket
-        check(_lib.load().dcs_step_guard(ptr(loss), ptr(self.bucket.skip), cur_stream()), 'dcs_step_guard')
+        # the NaN test training_step makes on the host, on the device: flag element of the gradient bucket.  The fused loss
+        # assembly writes it in its own launch when handed the flag; any other loss goes through dcs_step_guard.
+        self.net._dcs_skip_flag, self.net._dcs_skip_written = self.bucket.skip, False
+        try:
+            loss = self._loss_no_sync(batch, 0)
+        finally:
+            self.net._dcs_skip_flag = None
+        if not self.net._dcs_skip_written:
+            check(_lib.load().dcs_step_guard(ptr(loss), ptr(self.bucket.skip), cur_stream()), 'dcs_step_guard')
         self._backward(loss)
         if world == 1:                                 # collectives stay outside the graph
             self.opt.step(1, self.seed_state)
@@ -292,7 +298,15 @@ class TrainStep:
         from . import functional
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         functional.bump_param_generation()                 # packed weights must be re-made INSIDE the graph
-        self._static_batch = [t.clone() for t in batch[:3]]
+        # (noise, clean, noisy) in ONE allocation: the step synthesises the two target waveforms as a single batch of 2B
+        # signals straight from the adjacent noise | clean buffers (network_functions._stacked: no concatenation)
+        noise, noisy, clean = batch[:3]
+        if noise.shape == noisy.shape == clean.shape and noise.dtype == noisy.dtype == clean.dtype:
+            buf = torch.empty((3,) + tuple(noise.shape), dtype=noise.dtype, device=noise.device)
+            buf[0].copy_(noise); buf[1].copy_(clean); buf[2].copy_(noisy)
+            self._static_batch = [buf[0], buf[2], buf[1]]
+        else:
+            self._static_batch = [t.clone() for t in batch[:3]]
         static = (*self._static_batch, *batch[3:])
         g = torch.cuda.CUDAGraph()
         # thread_local: a collective backend's watchdog thread may touch the HIP runtime while this thread captures

@@ -786,6 +786,29 @@ class _BoundMaskApplyFn(torch.autograd.Function):
         return None, ops.bound_mask_apply_bwd(Y, M_in, c(gM), c(gN), c(gS), ctx.eps), None
 
 
+class _BoundMaskApplyPairFn(torch.autograd.Function):
+    """bound + multiply + subtract with the two estimates stacked in one [2, B, F, T, 2] output (ops.bound_mask_apply_pair)."""
+
+    @staticmethod
+    def forward(ctx, Y, M_in, eps):
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(Y, M_in)
+        return ops.bound_mask_apply_pair(Y, M_in, eps)
+
+    @staticmethod
+    def backward(ctx, gM, gNS):
+        Y, M_in = ctx.saved_tensors
+        if gM is None and gNS is None:
+            return None, None, None
+        gM = None if gM is None else gM.contiguous()
+        gN = gS = None
+        if gNS is not None:
+            gNS = gNS.contiguous()
+            gN, gS = gNS[0], gNS[1]
+        return None, ops.bound_mask_apply_bwd(Y, M_in, gM, gN, gS, ctx.eps), None
+
+
 class _PolarFramesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, Fp, eps):
@@ -916,6 +939,42 @@ class _SiSNRLossesFn(torch.autograd.Function):
 def sisnr_losses(clean, est_clean, noise, est_noise, alpha, eps=1e-8):
     return _SiSNRLossesFn.apply(clean.detach().contiguous(), est_clean.contiguous(), noise.detach().contiguous(),
                                 est_noise.contiguous(), float(alpha), eps)
+
+
+class _SiSNRLossesPairFn(torch.autograd.Function):
+    """The same three losses from STACKED signals (rows [0,B) noise, [B,2B) speech): one dcs_sisnr_fwd over 2B utterances,
+    the combine launch (which also writes the train step's NaN flag when given one), one dcs_sisnr_pair_bwd."""
+
+    @staticmethod
+    def forward(ctx, target, est, alpha, eps, skip):
+        B = est.shape[0] // 2
+        snr, coef = ops.sisnr(target, est, eps)
+        out = ops.sisnr_losses_guard(snr[B:], snr[:B], alpha, skip)
+        ctx.save_for_backward(target, est, coef)
+        ctx.alpha = float(alpha)
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_noise, g_speech, g_total):
+        target, est, coef = ctx.saved_tensors
+        if g_noise is None and g_speech is None and g_total is None:
+            return None, None, None, None, None
+        c = lambda t: None if t is None else t.contiguous()
+        return None, ops.sisnr_pair_bwd(target, est, coef, c(g_noise), c(g_speech), c(g_total), ctx.alpha), None, None, None
+
+
+def sisnr_losses_pair(target, est, alpha, eps=1e-8, skip=None):
+    """(noise_loss, speech_loss, total) from target / est float [2B, L], rows [0,B) = noise, [B,2B) = speech."""
+    return _SiSNRLossesPairFn.apply(target.detach().contiguous(), est.contiguous(), float(alpha), eps, skip)
+
+
+def bound_mask_apply_pair_complex(Y, M_in, eps=10e-7):
+    """(bound_cRM(M_in), [Y (.) M ; Y - Y (.) M]) — the estimates stacked on a new leading axis; differentiable w.r.t. M_in."""
+    y = torch.view_as_real(Y.contiguous())
+    m = torch.view_as_real(M_in.contiguous())
+    M, NS = _BoundMaskApplyPairFn.apply(y, m, eps)
+    return torch.view_as_complex(M), torch.view_as_complex(NS)
 
 
 def bound_crm_complex(M, eps=10e-7):

@@ -226,7 +226,14 @@ def calc_loss(self, **kw):
             all(kw[k].is_cuda and kw[k].dim() == 2 and kw[k].dtype == torch.float32
                 for k in ('clean_audio', 'predict_clean_audio', 'noise_audio', 'predict_noise_audio')) and
             not (kw['clean_audio'].requires_grad or kw['noise_audio'].requires_grad)):
-        # the configured pair of SiSNR losses and their assembly in five HIP launches (forward + backward)
+        # the configured pair of SiSNR losses and their assembly in five HIP launches (forward + backward) — three when
+        # the step handed over the stacked signals (and the train step's NaN flag rides the assembly launch)
+        if '_pair' in kw:
+            tw, ew = kw['_pair']
+            skip = getattr(self, '_dcs_skip_flag', None)
+            if skip is not None:
+                self._dcs_skip_written = True
+            return F.sisnr_losses_pair(tw, ew, alpha, skip=skip)
         return F.sisnr_losses(kw['clean_audio'], kw['predict_clean_audio'], kw['noise_audio'], kw['predict_noise_audio'],
                               alpha)
     speech_loss = alpha * (-self.config.SiSNR(kw['clean_audio'], kw['predict_clean_audio']))
@@ -262,9 +269,42 @@ def calc_loss(self, **kw):
     return noise_loss, speech_loss, noise_loss + speech_loss
 
 
+def _stacked(a, b):
+    """[2B, ...] tensor of two equally shaped batches: a zero-copy view when b sits right behind a in one allocation (the
+    captured train step's input buffers do), else one concatenation."""
+    if (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device and
+            a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and
+            b.storage_offset() == a.storage_offset() + a.numel() and not (a.requires_grad or b.requires_grad)):
+        return torch.as_strided(a, (2 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+    return torch.cat((a, b), 0)
+
+
+def _complex_step_pair(self, noise_data, noisy_data, clean_data):
+    """The 'dcs' train step with the two targets and the two estimates each synthesised as ONE batch of 2B signals (rows
+    [0,B) noise, [B,2B) speech): 3 + 3 synthesis launches instead of 6 + 6, one SiSNR launch instead of two, and the
+    same halved counts backward.  Same arithmetic per signal as _complex_step."""
+    eps = self.hparams['atan2_eps']
+    cfg = self.config
+    B = noisy_data.shape[0]
+    tw = _polar_wave(_stacked(noise_data, clean_data), eps, cfg)
+    mask_out = self(noisy_data)
+    if mask_out.dim() + 1 == noisy_data.dim() and B == 1:          # the B = 1 squeeze quirk (c_network.py:224)
+        mask, NS = F.bound_mask_apply_pair_complex(noisy_data, mask_out.unsqueeze(0), eps)
+        mask = mask.squeeze(0)
+    else:
+        mask, NS = F.bound_mask_apply_pair_complex(noisy_data, mask_out, eps)
+    ew = _polar_wave(NS.reshape((2 * B,) + tuple(NS.shape[2:])), eps, cfg)
+    return {'noise_audio': tw[:B], 'clean_audio': tw[B:], 'predict_noise_mask': mask,
+            'predict_noise_audio': ew[:B], 'predict_clean_audio': ew[B:], '_pair': (tw, ew)}
+
+
 def _complex_step(self, noise_data, noisy_data, clean_data, need_noisy_audio=False):
     eps = self.hparams['atan2_eps']
     cfg = self.config
+    if (_mode() in ('dcs', 'drs') and not need_noisy_audio and self.hparams.get('noise_loss_type') == 6 and
+            noisy_data.is_cuda and noise_data.shape == noisy_data.shape == clean_data.shape and
+            noisy_data.shape[1] + 1 == cfg.fft_size // 2 + 1):
+        return _complex_step_pair(self, noise_data, noisy_data, clean_data)
     audio = {'noise_audio': _polar_wave(noise_data, eps, cfg), 'clean_audio': _polar_wave(clean_data, eps, cfg)}
     if need_noisy_audio or self.hparams.get('noise_loss_type') in (1, 3, 4, 5):
         # only the wSDR losses and the evaluation outputs read it; the reference always builds it

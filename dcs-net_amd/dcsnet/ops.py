@@ -685,6 +685,20 @@ def bound_mask_apply(Y, M_in, eps=10e-7):
     return M, N, S
 
 
+def bound_mask_apply_pair(Y, M_in, eps=10e-7):
+    """The same launch with the two estimates STACKED: returns (M, NS) with NS[0] = Y (.) M, NS[1] = Y - Y (.) M in one
+    [2, *Y.shape] buffer, so that the waveform synthesis and the SiSNR pair downstream run once over 2B signals."""
+    _chk(Y, 'Y')
+    _chk(M_in, 'M_in')
+    if Y.shape != M_in.shape:
+        raise _lib.DcsHipError(f'bound_mask_apply: Y {tuple(Y.shape)} vs M {tuple(M_in.shape)}')
+    M = torch.empty_like(Y)
+    NS = torch.empty((2,) + tuple(Y.shape), dtype=Y.dtype, device=Y.device)
+    check(_lib.load().dcs_bound_mask_apply_fwd(ptr(Y), ptr(M_in), ptr(M), ptr(NS[0]), ptr(NS[1]), Y.numel() // 2, eps,
+                                               cur_stream()), 'dcs_bound_mask_apply_fwd')
+    return M, NS
+
+
 def bound_mask_apply_bwd(Y, M_in, g_M, g_N, g_S, eps=10e-7):
     """Cotangent of M_in; any of g_M / g_N / g_S (and Y when only g_M is given) may be None."""
     _chk(M_in, 'M_in')
@@ -811,6 +825,28 @@ def sisnr_losses(snr_speech, snr_noise, alpha):
     check(_lib.load().dcs_sisnr_losses_fwd(ptr(snr_speech), ptr(snr_noise), ptr(out), snr_speech.numel(), float(alpha),
                                            cur_stream()), 'dcs_sisnr_losses_fwd')
     return out
+
+
+def sisnr_losses_guard(snr_speech, snr_noise, alpha, skip):
+    """sisnr_losses with the train step's NaN flag written by the same launch (skip: 1-element float tensor or None)."""
+    _chk(snr_speech, 'snr_speech', 1)
+    _chk(snr_noise, 'snr_noise', 1)
+    _chk(skip, 'skip')
+    out = torch.empty(3, dtype=torch.float32, device=snr_speech.device)
+    check(_lib.load().dcs_sisnr_losses_guard_fwd(ptr(snr_speech), ptr(snr_noise), ptr(out), snr_speech.numel(), float(alpha),
+                                                 ptr(skip), cur_stream()), 'dcs_sisnr_losses_guard_fwd')
+    return out
+
+
+def sisnr_pair_bwd(target, est, coef, g_noise, g_speech, g_total, alpha):
+    """Cotangent of est [2B, L] (rows [0,B) noise, [B,2B) speech) for the configured loss pair; g_*: device scalars or None."""
+    B2, L = est.shape
+    for n, t in (('g_noise', g_noise), ('g_speech', g_speech), ('g_total', g_total)):
+        _chk(t, n)
+    g_est = torch.empty_like(est)
+    check(_lib.load().dcs_sisnr_pair_bwd(ptr(target), ptr(est), ptr(coef), ptr(g_noise), ptr(g_speech), ptr(g_total),
+                                         float(alpha), ptr(g_est), B2 // 2, L, cur_stream()), 'dcs_sisnr_pair_bwd')
+    return g_est
 
 
 def sisnr_bwd(clean, est, coef, g, scale):

@@ -493,6 +493,17 @@ int dcs_sisnr_bwd(const float* clean, const float* est, const float* coef, const
  * out3 = { 1 - alpha * (-mean snr_noise), alpha * (-mean snr_speech), their sum } (the "1 -" quirk of :196 kept). */
 int dcs_sisnr_losses_fwd(const float* snr_speech, const float* snr_noise, float* out3, int B, float alpha,
                          dcs_stream_t stream);
+/* The same with the train step's NaN guard folded in (c_network.py:257-261; dcs_step_guard without its launch):
+ * skip[0] = isnan(total) ? 1 : 0 when skip is not null. */
+int dcs_sisnr_losses_guard_fwd(const float* snr_speech, const float* snr_noise, float* out3, int B, float alpha,
+                               float* skip, dcs_stream_t stream);
+/* Backward of that loss pair on STACKED signals (one launch for both estimates): target / est float[2B][L] with rows
+ * [0, B) = noise and [B, 2B) = speech, coef float[2B][2] from ONE dcs_sisnr_fwd over the 2B rows; g_noise / g_speech /
+ * g_total = upstream gradients of out3 (device scalars, any may be null, not all):
+ *   g_est[b] = +(g_noise + g_total) alpha / B d snr_b / d est_b (b < B), -(g_speech + g_total) alpha / B ... (b >= B). */
+int dcs_sisnr_pair_bwd(const float* target, const float* est, const float* coef, const float* g_noise,
+                       const float* g_speech, const float* g_total, float alpha, float* g_est, int B, int L,
+                       dcs_stream_t stream);
 
 /* On-device STFT front end (data.py:104-134: noise = noisy - clean, then torch.stft(n_fft, hop, hann, center=True,
  * normalized)[1 : n_fft/2 + 1] of clean, noise, noisy on the DataLoader's CPU workers).
