@@ -235,3 +235,70 @@ extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
+
+
+// ---- glue of the complex LSTM that autograd ran as ~10 ATen launches per layer and step -------------------------------
+namespace {
+// ComplexLSTM's recombination (c_network.py:43-46) from the stacked recurrence outputs o[set][{re rows | im rows}][S][W]:
+// out[b] = (L_r(x_r) - L_i(x_i)) + j (L_r(x_i) + L_i(x_r)), interleaved complex.  n = B*S*W complex elements.
+__global__ __launch_bounds__(256) void lstm_combine_fwd_kernel(const float* __restrict__ o, float2* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float rr = o[i], ir = o[n + i], ri = o[2 * n + i], ii = o[3 * n + i];
+    out[i] = make_float2(rr - ii, ir + ri);
+}
+// its cotangent: g_o[0] = (g.re | g.im), g_o[1] = (g.im | -g.re)
+__global__ __launch_bounds__(256) void lstm_combine_bwd_kernel(const float2* __restrict__ g, float* __restrict__ g_o, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 v = g[i];
+    g_o[i] = v.x; g_o[n + i] = v.y; g_o[2 * n + i] = v.y; g_o[3 * n + i] = -v.x;
+}
+// parameter gradients of one layer from the partial products the backward left:
+//   g_whh[set][dir][j][k] += sum_c part[dir][set*CK + c][j][k]      (the K-chunked bmm outputs, fixed order)
+//   g_bih[set][q] += s, g_bhh[set][q] += s,  s = sum_n b_part[set][n][q]   (per-sequence bias sums of the BPTT kernel)
+__global__ __launch_bounds__(256) void lstm_param_grads_kernel(const float* __restrict__ part, const float* __restrict__ b_part,
+                                                                float* __restrict__ g_whh, float* __restrict__ g_bih,
+                                                                float* __restrict__ g_bhh, int CK, int seqs, int H) {
+    const int WH = 4 * H * H, nW = 4 * WH, nB = 2 * 8 * H;              // [2 sets][2 dirs][4H][H]; [2 sets][8H]
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nW) {
+        const int e = i % WH, d = (i / WH) % 2, s_ = i / (2 * WH);
+        const float* p = part + ((long)d * 2 * CK + (long)s_ * CK) * WH + e;
+        float a = 0.f;
+        for (int c = 0; c < CK; ++c) a += p[(long)c * WH];
+        g_whh[i] += a;
+    } else if (i < nW + nB) {
+        const int q = (i - nW) % (8 * H), s_ = (i - nW) / (8 * H);
+        const float* p = b_part + (long)s_ * seqs * 8 * H + q;
+        float a = 0.f;
+        for (int n = 0; n < seqs; ++n) a += p[(long)n * 8 * H];
+        g_bih[i - nW] += a;
+        g_bhh[i - nW] += a;
+    }
+}
+}  // namespace
+
+extern "C" int dcs_lstm_combine_fwd(const float* o, float* out, long n, dcs_stream_t stream) {
+    if (!o || !out || n <= 0) return DCS_ERR_BADARG;
+    DCS_LAUNCH(lstm_combine_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dcs_stream(stream), o, (float2*)out, n);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_lstm_combine_bwd(const float* g, float* g_o, long n, dcs_stream_t stream) {
+    if (!g || !g_o || n <= 0) return DCS_ERR_BADARG;
+    DCS_LAUNCH(lstm_combine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dcs_stream(stream), (const float2*)g, g_o, n);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_lstm_param_grads(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,
+                                    int seqs_per_set, int H, dcs_stream_t stream) {
+    if (!part || !b_part || !g_whh || !g_bih || !g_bhh || CK < 1 || seqs_per_set < 1 || H < 1) return DCS_ERR_BADARG;
+    const int total = 16 * H * H + 16 * H;
+    DCS_LAUNCH(lstm_param_grads_kernel, dim3((total + 255) / 256), dim3(256), 0, dcs_stream(stream), part, b_part, g_whh, g_bih,
+               g_bhh, CK, seqs_per_set, H);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}

@@ -513,10 +513,9 @@ class _LstmLayerFn(torch.autograd.Function):
             a = g_pre.as_strided((2 * CK, R, 4 * H), (R * 8 * H, 8 * H, 1), g_pre.storage_offset() + d * 4 * H)
             h = hprev.as_strided((2 * CK, R, H), (R * 2 * H, 2 * H, 1), hprev.storage_offset() + d * H)
             torch.bmm(a.transpose(1, 2), h, out=part[d])
-        st['weight_hh'][1].add_(part.view(2, 2, CK, 4 * H, H).sum(2).transpose(0, 1))
-        g_b = b_part.view(2, B2, 8 * H).sum(1)
-        st['bias_ih'][1].add_(g_b)
-        st['bias_hh'][1].add_(g_b)
+        # chunk sums of the W_hh products and the per-sequence bias sums, accumulated into the three gradient views by one
+        # launch (autograd's spelling: two reductions and three adds)
+        ops.lstm_param_grads(part, b_part.contiguous(), st['weight_hh'][1], st['bias_ih'][1], st['bias_hh'][1], CK, B2, H)
         g_gx = g_pre.view(2, NT, 8 * H)
         g_wih = st['weight_ih'][1]
         sink_hits += 16
@@ -535,23 +534,16 @@ class _LstmLayerFn(torch.autograd.Function):
 class _LstmCombineFn(torch.autograd.Function):
     """real = L_r(x_r) - L_i(x_i), imag = L_r(x_i) + L_i(x_r) (c_network.py:43-46) from the stacked outputs
     o[set, {re rows | im rows}]: three launches forward, three backward (autograd's slice / complex / sub graph
-    costs ~20 fill / copy / add launches in backward)."""
+    costs ~20 fill / copy / add launches in backward); one HIP launch each way."""
 
     @staticmethod
     def forward(ctx, o, B):
-        ctx.B = B
-        rr, ir, ri, ii = o[0, :B], o[0, B:], o[1, :B], o[1, B:]
-        return torch.complex(rr - ii, ir + ri)
+        return ops.lstm_combine(o.contiguous(), B)
 
     @staticmethod
     def backward(ctx, g):
-        B = ctx.B
         g2 = torch.view_as_real(g if g.is_contiguous() else g.contiguous())      # [B, S, 2H, 2]
-        g_o = torch.empty((2, 2, *g2.shape[:-1]), dtype=g2.dtype, device=g2.device)   # [set, re|im rows, B, S, 2H]
-        g_o[0].copy_(g2.permute(3, 0, 1, 2))               # L_r: rows re <- g.real, rows im <- g.imag
-        g_o[1, 0].copy_(g2[..., 1])                        # L_i(x_r) <- g.imag
-        torch.neg(g2[..., 0], out=g_o[1, 1])               # L_i(x_i) <- -g.real
-        return g_o.view(2, 2 * B, *g2.shape[1:-1]), None
+        return ops.lstm_combine_bwd(g2), None
 
 
 def _stacked_lstm(real_lstm):
@@ -620,9 +612,8 @@ def complex_lstm(z, real_lstm, imag_lstm):
     o = inp.view(2, 2 * B, S, -1)
     if torch.is_grad_enabled() and o.requires_grad:
         return _LstmCombineFn.apply(o, B)
-    rr, ir = o[0, :B], o[0, B:]            # real_lstm(re), real_lstm(im)
-    ri, ii = o[1, :B], o[1, B:]            # imag_lstm(re), imag_lstm(im)
-    return torch.complex(rr - ii, ir + ri)
+    # rows: o[0] = real_lstm(re | im), o[1] = imag_lstm(re | im)
+    return ops.lstm_combine(o.contiguous(), B)
 
 
 class _TapSumFn(torch.autograd.Function):

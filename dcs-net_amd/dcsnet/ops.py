@@ -827,6 +827,32 @@ def sisnr_losses(snr_speech, snr_noise, alpha):
     return out
 
 
+def lstm_combine(o, B):
+    """o float [2 sets, 2B rows, S, W] -> complex64 [B, S, W] = (L_r(x_r) - L_i(x_i)) + j (L_r(x_i) + L_i(x_r))."""
+    _chk(o, 'o', 4)
+    _, B2, S, W = o.shape
+    out = torch.empty((B, S, W, 2), dtype=torch.float32, device=o.device)
+    check(_lib.load().dcs_lstm_combine_fwd(ptr(o), ptr(out), B * S * W, cur_stream()), 'dcs_lstm_combine_fwd')
+    return torch.view_as_complex(out)
+
+
+def lstm_combine_bwd(g):
+    """g float [B, S, W, 2] (cotangent of the complex output) -> g_o float [2, 2B, S, W]."""
+    _chk(g, 'g', 4)
+    B, S, W, _ = g.shape
+    g_o = torch.empty((2, 2 * B, S, W), dtype=torch.float32, device=g.device)
+    check(_lib.load().dcs_lstm_combine_bwd(ptr(g), ptr(g_o), B * S * W, cur_stream()), 'dcs_lstm_combine_bwd')
+    return g_o
+
+
+def lstm_param_grads(part, b_part, g_whh, g_bih, g_bhh, CK, seqs, H):
+    """Accumulate one layer's recurrent-weight and bias gradients from the backward's partial products (in place)."""
+    for n, t in (('part', part), ('b_part', b_part), ('g_whh', g_whh), ('g_bih', g_bih), ('g_bhh', g_bhh)):
+        _chk(t, n)
+    check(_lib.load().dcs_lstm_param_grads(ptr(part), ptr(b_part), ptr(g_whh), ptr(g_bih), ptr(g_bhh), CK, seqs, H,
+                                           cur_stream()), 'dcs_lstm_param_grads')
+
+
 def sisnr_losses_guard(snr_speech, snr_noise, alpha, skip):
     """sisnr_losses with the train step's NaN flag written by the same launch (skip: 1-element float tensor or None)."""
     _chk(snr_speech, 'snr_speech', 1)

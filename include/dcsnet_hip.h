@@ -386,6 +386,18 @@ int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* ga
 int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_save, const float* w_hh,
                        float* g_pre, float* g_bias_part, int n_sets, int seqs_per_set, int S, int H, dcs_stream_t stream);
 
+/* Glue of the complex LSTM (c_network.py:33-47) that autograd otherwise runs as ~10 element-wise / reduction launches per
+ * layer and step.
+ * dcs_lstm_combine_fwd: out complex[n] = (o[0][i] - o[3][i]) + j (o[1][i] + o[2][i]) from the stacked recurrence outputs
+ *   o float[4][n] = { L_r(x_r), L_r(x_i), L_i(x_r), L_i(x_i) }, n = B*S*2H;  _bwd: g_o = { g.re, g.im, g.im, -g.re }.
+ * dcs_lstm_param_grads: g_whh float[2 sets][2 dirs][4H][H] += sum over the CK K-chunks of part float[2 dirs][2*CK][4H][H]
+ *   (chunk c of set s at index s*CK + c); g_bih, g_bhh float[2][8H] += sum_n b_part float[2][seqs_per_set][8H]
+ *   (dcs_lstm_layer_bwd's g_bias_part).  Fixed summation order. */
+int dcs_lstm_combine_fwd(const float* o, float* out, long n, dcs_stream_t stream);
+int dcs_lstm_combine_bwd(const float* g, float* g_o, long n, dcs_stream_t stream);
+int dcs_lstm_param_grads(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,
+                         int seqs_per_set, int H, dcs_stream_t stream);
+
 /* Stand-alone inverted dropout on a real view (c_network.py:203-204 dropout_fc after the
  * ComplexLinear; c_network.py:221-222 on the last decoder stage, which has no attention to
  * fuse it into).  n floats; same mask rule as above; y may alias x; drop_p == 0 copies. */
