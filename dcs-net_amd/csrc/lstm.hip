@@ -259,22 +259,36 @@ __global__ __launch_bounds__(256) void lstm_combine_bwd_kernel(const float2* __r
 //   g_bih[set][q] += s, g_bhh[set][q] += s,  s = sum_n b_part[set][n][q]   (per-sequence bias sums of the BPTT kernel)
 __global__ __launch_bounds__(256) void lstm_param_grads_kernel(const float* __restrict__ part, const float* __restrict__ b_part,
                                                                 float* __restrict__ g_whh, float* __restrict__ g_bih,
-                                                                float* __restrict__ g_bhh, int CK, int seqs, int H) {
-    const int WH = 4 * H * H, nW = 4 * WH, nB = 2 * 8 * H;              // [2 sets][2 dirs][4H][H]; [2 sets][8H]
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nW) {
+                                                                float* __restrict__ g_bhh, int CK, int seqs, int H, int w_blocks) {
+    const int WH = 4 * H * H, nW = 4 * WH;                             // [2 sets][2 dirs][4H][H]
+    if ((int)blockIdx.x < w_blocks) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= nW) return;
         const int e = i % WH, d = (i / WH) % 2, s_ = i / (2 * WH);
         const float* p = part + ((long)d * 2 * CK + (long)s_ * CK) * WH + e;
         float a = 0.f;
         for (int c = 0; c < CK; ++c) a += p[(long)c * WH];
         g_whh[i] += a;
-    } else if (i < nW + nB) {
-        const int q = (i - nW) % (8 * H), s_ = (i - nW) / (8 * H);
-        const float* p = b_part + (long)s_ * seqs * 8 * H + q;
-        float a = 0.f;
-        for (int n = 0; n < seqs; ++n) a += p[(long)n * 8 * H];
-        g_bih[i - nW] += a;
-        g_bhh[i - nW] += a;
+        return;
+    }
+    // bias blocks: 16 columns x 16 sequence chunks per block (a thread per column alone walked all the sequences in
+    // one serial chain of loads: 17 us), combined through LDS in a fixed order
+    __shared__ float red[16][17];
+    const int q = (blockIdx.x - w_blocks) * 16 + (threadIdx.x & 15), ch = threadIdx.x >> 4;     // column of [2 sets][8H]
+    const int s_ = q / (8 * H), qq = q % (8 * H);
+    const int per = (seqs + 15) / 16;
+    float a = 0.f;
+    if (q < 16 * H) {
+        const float* p = b_part + (long)s_ * seqs * 8 * H + qq;
+        for (int n = ch * per; n < seqs && n < (ch + 1) * per; ++n) a += p[(long)n * 8 * H];
+    }
+    red[ch][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (threadIdx.x < 16 && q < 16 * H) {
+        float t = 0.f;
+        for (int c = 0; c < 16; ++c) t += red[c][threadIdx.x];
+        g_bih[q] += t;
+        g_bhh[q] += t;
     }
 }
 }  // namespace
@@ -296,9 +310,9 @@ extern "C" int dcs_lstm_combine_bwd(const float* g, float* g_o, long n, dcs_stre
 extern "C" int dcs_lstm_param_grads(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,
                                     int seqs_per_set, int H, dcs_stream_t stream) {
     if (!part || !b_part || !g_whh || !g_bih || !g_bhh || CK < 1 || seqs_per_set < 1 || H < 1) return DCS_ERR_BADARG;
-    const int total = 16 * H * H + 16 * H;
-    DCS_LAUNCH(lstm_param_grads_kernel, dim3((total + 255) / 256), dim3(256), 0, dcs_stream(stream), part, b_part, g_whh, g_bih,
-               g_bhh, CK, seqs_per_set, H);
+    const int w_blocks = (16 * H * H + 255) / 256, b_blocks = H;         // 16 H bias columns, 16 per block
+    DCS_LAUNCH(lstm_param_grads_kernel, dim3(w_blocks + b_blocks), dim3(256), 0, dcs_stream(stream), part, b_part, g_whh, g_bih,
+               g_bhh, CK, seqs_per_set, H, w_blocks);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
