@@ -122,9 +122,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 
     // source pixel (index into x1 / x2, or -1 for zero) of every patch pixel: the same for all channel chunks
     int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);
+    const unsigned cols_magic = 0xFFFFFFFFu / (unsigned)cols + 1u;    // ceil(2^32 / cols): exact quotients for p < 2^16
     for (int p = t; p < rows * cols; p += 256) {
+        const int py = (int)__umulhi((unsigned)p, cols_magic), px = p - py * cols;        // p / cols, p % cols
         long sp;
-        spx[p] = conv::src_pixel(a, b, vy0 + p / cols, vx0 + p % cols, &sp) ? (int)sp : -1;
+        spx[p] = conv::src_pixel(a, b, vy0 + py, vx0 + px, &sp) ? (int)sp : -1;
     }
 
     const long long d_loop = FDIAG_NOW();
@@ -350,9 +352,11 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
     for (int g = 0; g < U8; ++g) bring[g] = bload(0, 0, g);
 
     int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);       // source pixel of every patch pixel (see above)
+    const unsigned cols_magic = 0xFFFFFFFFu / (unsigned)cols + 1u;    // ceil(2^32 / cols): exact quotients for p < 2^16
     for (int p = t; p < rows * cols; p += 256) {
+        const int py = (int)__umulhi((unsigned)p, cols_magic), px = p - py * cols;        // p / cols, p % cols
         long sp;
-        spx[p] = conv::src_pixel(a, b, vy0 + p / cols, vx0 + p % cols, &sp) ? (int)sp : -1;
+        spx[p] = conv::src_pixel(a, b, vy0 + py, vx0 + px, &sp) ? (int)sp : -1;
     }
 
     for (int ch = 0; ch < n_chunks; ++ch) {
