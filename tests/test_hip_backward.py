@@ -478,3 +478,65 @@ def test_fused_sisnr_loss_assembly(dev):
     got[2].backward()
     close(ecd.grad, ec.grad, rel=2e-4, what='g_est_clean')
     close(end_.grad, en.grad, rel=2e-4, what='g_est_noise')
+
+
+def test_fused_sisnr_pair_losses_and_guard(dev):
+    """The stacked form (rows [0,B) noise, [B,2B) speech): one dcs_sisnr_fwd over 2B rows, dcs_sisnr_losses_guard_fwd (which
+    also writes the train step's NaN flag) and ONE dcs_sisnr_pair_bwd, against the reference's loss assembly and autograd;
+    gradients reaching only one of the three outputs; a NaN total raises the flag."""
+    from dcsnet import functional as F
+    g = torch.Generator().manual_seed(19)
+    B, L, alpha = 6, 3000, 0.7
+    clean, noise = torch.randn(B, L, generator=g) * 0.3, torch.randn(B, L, generator=g) * 0.1
+    ec = (clean + 0.1 * torch.randn(B, L, generator=g)).requires_grad_(True)
+    en = (noise + 0.05 * torch.randn(B, L, generator=g)).requires_grad_(True)
+    speech = alpha * (-nf.si_snr(clean, ec))
+    nl = 1 - alpha * (-nf.si_snr(noise, en))
+    tgt = torch.cat((noise, clean)).to(dev)
+    for pick in (2, 0, 1):                                   # total, noise_loss only, speech_loss only
+        for t in (ec, en):
+            t.grad = None
+        (nl, speech, nl + speech)[pick].backward(retain_graph=True)
+        est = torch.cat((en.detach(), ec.detach())).to(dev).requires_grad_(True)
+        skip = torch.full((1,), 7.0, device=dev)
+        got = F.sisnr_losses_pair(tgt, est, alpha, skip=skip)
+        for a, b in zip(got, (nl, speech, nl + speech)):
+            assert abs(float(a) - float(b)) <= 2e-5 * abs(float(b)) + 2e-5
+        assert float(skip) == 0.0
+        got[pick].backward()
+        want = torch.cat((en.grad if en.grad is not None else torch.zeros_like(en),
+                          ec.grad if ec.grad is not None else torch.zeros_like(ec)))
+        close(est.grad, want, rel=2e-4, what=f'g_est (output {pick})')
+    bad = est.detach().clone()
+    bad[0, 0] = float('nan')
+    skip = torch.zeros(1, device=dev)
+    F.sisnr_losses_pair(tgt, bad, alpha, skip=skip)
+    assert float(skip) == 1.0
+
+
+def test_lstm_glue_kernels(dev):
+    """dcs_lstm_combine_fwd / _bwd (ComplexLSTM's recombination, c_network.py:43-46) and dcs_lstm_param_grads (chunk sums of
+    the recurrent-weight products, per-sequence bias sums) against their torch spellings."""
+    from dcsnet import ops
+    g = torch.Generator().manual_seed(23)
+    B, S, W = 3, 5, 128
+    o = torch.randn(2, 2 * B, S, W, generator=g)
+    want = torch.complex(o[0, :B] - o[1, B:], o[0, B:] + o[1, :B])
+    got = ops.lstm_combine(o.to(dev), B)
+    close(torch.view_as_real(got), torch.view_as_real(want), rel=1e-6, what='lstm_combine')
+    gc = torch.randn(B, S, W, 2, generator=g)
+    g_o = ops.lstm_combine_bwd(gc.to(dev))
+    want_o = torch.stack((torch.cat((gc[..., 0], gc[..., 1])), torch.cat((gc[..., 1], -gc[..., 0]))))
+    close(g_o, want_o, rel=1e-6, what='lstm_combine_bwd')
+    H, CK, seqs = 64, 16, 10
+    part = torch.randn(2, 2 * CK, 4 * H, H, generator=g)
+    b_part = torch.randn(2, seqs, 8 * H, generator=g)
+    g_whh, g_bih, g_bhh = (torch.randn(2, 2, 4 * H, H, generator=g), torch.randn(2, 8 * H, generator=g),
+                           torch.randn(2, 8 * H, generator=g))
+    w_whh = g_whh + part.view(2, 2, CK, 4 * H, H).sum(2).transpose(0, 1)
+    w_b = b_part.sum(1)
+    d = [t.clone().to(dev) for t in (g_whh, g_bih, g_bhh)]
+    ops.lstm_param_grads(part.to(dev), b_part.to(dev), d[0], d[1], d[2], CK, seqs, H)
+    close(d[0], w_whh, rel=1e-5, what='g_whh')
+    close(d[1], g_bih + w_b, rel=1e-5, what='g_bih')
+    close(d[2], g_bhh + w_b, rel=1e-5, what='g_bhh')
