@@ -293,6 +293,61 @@ __global__ __launch_bounds__(256) void lstm_param_grads_kernel(const float* __re
 }
 }  // namespace
 
+namespace {
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+// Recurrent-weight gradient partial products on the MFMA pipe:
+//   part[d][s*CK + c][j][k] = sum over the R = NT/CK rows r of chunk c of  g_pre[s][r][d][j] * h_prev[s][r][d][k]
+// (g_pre float[2][NT][2][4H], h_prev float[2][NT][2][H]).  rocBLAS ran these four [4H x H] = [NT]^T [NT] products as strided
+// batched GEMMs at ~5 TFLOP/s (26 us each).  One wave per workgroup: a 32-row (gate) tile x all H = 64 columns, K = the
+// chunk's rows two at a time with v_mfma_f32_32x32x2_f32 — both operands are read straight from global memory in fragment
+// order (a lane's A element is g_pre[row + lane/32][j0 + lane%32]: 128-byte runs), eight row pairs in flight.
+__global__ __launch_bounds__(64) void lstm_whh_grad_kernel(const float* __restrict__ g_pre, const float* __restrict__ h_prev,
+                                                            float* __restrict__ part, int NT, int CK, int H) {
+    const int lane = threadIdx.x, kk = lane >> 5, li = lane & 31;
+    const int j0 = blockIdx.x * 32, bi = blockIdx.y, d = blockIdx.z;   // gate tile, (set, chunk), direction
+    const int s_ = bi / CK, c = bi % CK, R = NT / CK;
+    const float* ga = g_pre + (((long)s_ * NT + (long)c * R + kk) * 2 + d) * 4 * H + j0 + li;
+    const float* hb = h_prev + (((long)s_ * NT + (long)c * R + kk) * 2 + d) * H + li;
+    const long ga_step = 2L * 2 * 4 * H, hb_step = 2L * 2 * H;        // two rows further
+    f32x16w acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    constexpr int UN = 8;
+    for (int i0 = 0; i0 < R / 2; i0 += UN) {
+        float av[UN], b0[UN], b1[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool ok = i0 + u < R / 2;
+            av[u] = ok ? ga[(i0 + u) * ga_step] : 0.f;
+            b0[u] = ok ? hb[(i0 + u) * hb_step] : 0.f;
+            b1[u] = ok ? hb[(i0 + u) * hb_step + 32] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b1[u], acc1, 0, 0, 0);
+        }
+    }
+    // C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* o = part + (((long)d * 2 * CK + bi) * 4 * H + j0) * H + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        o[(long)row * H] = acc0[r];
+        o[(long)row * H + 32] = acc1[r];
+    }
+}
+}  // namespace
+
+extern "C" int dcs_lstm_whh_grad(const float* g_pre, const float* h_prev, float* part, int NT, int CK, int H,
+                                 dcs_stream_t stream) {
+    if (!g_pre || !h_prev || !part || NT < 2 || CK < 1 || NT % CK != 0 || ((NT / CK) & 1) || H != 64) return DCS_ERR_BADARG;
+    if (2 * CK > 65535) return DCS_ERR_BADARG;
+    DCS_LAUNCH(lstm_whh_grad_kernel, dim3(4 * H / 32, 2 * CK, 2), dim3(64), 0, dcs_stream(stream), g_pre, h_prev, part, NT, CK, H);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
 extern "C" int dcs_lstm_combine_fwd(const float* o, float* out, long n, dcs_stream_t stream) {
     if (!o || !out || n <= 0) return DCS_ERR_BADARG;
     DCS_LAUNCH(lstm_combine_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dcs_stream(stream), o, (float2*)out, n);

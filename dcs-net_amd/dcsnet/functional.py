@@ -506,13 +506,16 @@ class _LstmLayerFn(torch.autograd.Function):
         # W_hh gradient per direction d: g_pre[set, (n t), d, :]^T h_prev[set, (n t), d, :] — strided views, no copies
         # (n t) is cut into CK chunks that ride the batch axis (rocBLAS runs a [4H x H] output with K = 4096 on 16
         # workgroups otherwise), summed afterwards in a fixed order
-        CK = 16 if NT % 16 == 0 else 1
-        R = NT // CK
-        part = torch.empty((2, 2 * CK, 4 * H, H), dtype=g_pre.dtype, device=g_pre.device)
-        for d in range(2):
-            a = g_pre.as_strided((2 * CK, R, 4 * H), (R * 8 * H, 8 * H, 1), g_pre.storage_offset() + d * 4 * H)
-            h = hprev.as_strided((2 * CK, R, H), (R * 2 * H, 2 * H, 1), hprev.storage_offset() + d * H)
-            torch.bmm(a.transpose(1, 2), h, out=part[d])
+        CK = 16 if NT % 32 == 0 else 1
+        if H == 64 and NT % (2 * CK) == 0:
+            part = ops.lstm_whh_grad(g_pre, hprev, NT, CK, H)           # one MFMA launch (rocBLAS: four ~26 us batched GEMMs)
+        else:
+            R = NT // CK
+            part = torch.empty((2, 2 * CK, 4 * H, H), dtype=g_pre.dtype, device=g_pre.device)
+            for d in range(2):
+                a = g_pre.as_strided((2 * CK, R, 4 * H), (R * 8 * H, 8 * H, 1), g_pre.storage_offset() + d * 4 * H)
+                h = hprev.as_strided((2 * CK, R, H), (R * 2 * H, 2 * H, 1), hprev.storage_offset() + d * H)
+                torch.bmm(a.transpose(1, 2), h, out=part[d])
         # chunk sums of the W_hh products and the per-sequence bias sums, accumulated into the three gradient views by one
         # launch (autograd's spelling: two reductions and three adds)
         ops.lstm_param_grads(part, b_part.contiguous(), st['weight_hh'][1], st['bias_ih'][1], st['bias_hh'][1], CK, B2, H)

@@ -845,6 +845,15 @@ def lstm_combine_bwd(g):
     return g_o
 
 
+def lstm_whh_grad(g_pre, h_prev, NT, CK, H):
+    """part float [2 dirs, 2*CK, 4H, H]: the chunked g_pre^T h_prev products of one layer (both sets, both directions)."""
+    _chk(g_pre, 'g_pre')
+    _chk(h_prev, 'h_prev')
+    part = torch.empty((2, 2 * CK, 4 * H, H), dtype=torch.float32, device=g_pre.device)
+    check(_lib.load().dcs_lstm_whh_grad(ptr(g_pre), ptr(h_prev), ptr(part), NT, CK, H, cur_stream()), 'dcs_lstm_whh_grad')
+    return part
+
+
 def lstm_param_grads(part, b_part, g_whh, g_bih, g_bhh, CK, seqs, H):
     """Accumulate one layer's recurrent-weight and bias gradients from the backward's partial products (in place)."""
     for n, t in (('part', part), ('b_part', b_part), ('g_whh', g_whh), ('g_bih', g_bih), ('g_bhh', g_bhh)):

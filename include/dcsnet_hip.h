@@ -393,6 +393,11 @@ int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_sa
  * dcs_lstm_param_grads: g_whh float[2 sets][2 dirs][4H][H] += sum over the CK K-chunks of part float[2 dirs][2*CK][4H][H]
  *   (chunk c of set s at index s*CK + c); g_bih, g_bhh float[2][8H] += sum_n b_part float[2][seqs_per_set][8H]
  *   (dcs_lstm_layer_bwd's g_bias_part).  Fixed summation order. */
+/* dcs_lstm_whh_grad: the K-chunked partial products dcs_lstm_param_grads sums, on the MFMA pipe (fp32, exact):
+ *   part[d][s*CK + c][j][k] = sum over the NT/CK rows r of chunk c of g_pre[s][r][d][j] * h_prev[s][r][d][k],
+ *   g_pre float[2 sets][NT][2 dirs][4H] (dcs_lstm_layer_bwd), h_prev float[2][NT][2][H] (dcs_lstm_layer_fwd), H = 64,
+ *   NT/CK even. */
+int dcs_lstm_whh_grad(const float* g_pre, const float* h_prev, float* part, int NT, int CK, int H, dcs_stream_t stream);
 int dcs_lstm_combine_fwd(const float* o, float* out, long n, dcs_stream_t stream);
 int dcs_lstm_combine_bwd(const float* g, float* g_o, long n, dcs_stream_t stream);
 int dcs_lstm_param_grads(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,

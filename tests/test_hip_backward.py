@@ -540,3 +540,15 @@ def test_lstm_glue_kernels(dev):
     close(d[0], w_whh, rel=1e-5, what='g_whh')
     close(d[1], g_bih + w_b, rel=1e-5, what='g_bih')
     close(d[2], g_bhh + w_b, rel=1e-5, what='g_bhh')
+    # dcs_lstm_whh_grad: the chunked g_pre^T h_prev products on the MFMA pipe vs the strided batched GEMM it replaces
+    NT = 2 * 16 * 6
+    g_pre = torch.randn(2, NT, 8 * H, generator=g)
+    hprev = torch.randn(2, NT, 2 * H, generator=g)
+    R = NT // CK
+    want_p = torch.empty(2, 2 * CK, 4 * H, H)
+    for dd in range(2):
+        a = g_pre.view(2, NT, 2, 4 * H)[:, :, dd].reshape(2 * CK, R, 4 * H)
+        h = hprev.view(2, NT, 2, H)[:, :, dd].reshape(2 * CK, R, H)
+        want_p[dd] = torch.bmm(a.transpose(1, 2), h)
+    got_p = ops.lstm_whh_grad(g_pre.to(dev), hprev.to(dev), NT, CK, H)
+    close(got_p, want_p, rel=2e-5, what='lstm_whh_grad')
