@@ -295,29 +295,37 @@ __global__ __launch_bounds__(256) void lstm_param_grads_kernel(const float* __re
 
 namespace {
 typedef float f32x16w __attribute__((ext_vector_type(16)));
-// Recurrent-weight gradient partial products on the MFMA pipe:
-//   part[d][s*CK + c][j][k] = sum over the R = NT/CK rows r of chunk c of  g_pre[s][r][d][j] * h_prev[s][r][d][k]
-// (g_pre float[2][NT][2][4H], h_prev float[2][NT][2][H]).  rocBLAS ran these four [4H x H] = [NT]^T [NT] products as strided
-// batched GEMMs at ~5 TFLOP/s (26 us each).  One wave per workgroup: a 32-row (gate) tile x all H = 64 columns, K = the
-// chunk's rows two at a time with v_mfma_f32_32x32x2_f32 — both operands are read straight from global memory in fragment
-// order (a lane's A element is g_pre[row + lane/32][j0 + lane%32]: 128-byte runs), eight row pairs in flight.
-__global__ __launch_bounds__(64) void lstm_whh_grad_kernel(const float* __restrict__ g_pre, const float* __restrict__ h_prev,
-                                                            float* __restrict__ part, int NT, int CK, int H) {
-    const int lane = threadIdx.x, kk = lane >> 5, li = lane & 31;
-    const int j0 = blockIdx.x * 32, bi = blockIdx.y, d = blockIdx.z;   // gate tile, (set, chunk), direction
-    const int s_ = bi / CK, c = bi % CK, R = NT / CK;
-    const float* ga = g_pre + (((long)s_ * NT + (long)c * R + kk) * 2 + d) * 4 * H + j0 + li;
-    const float* hb = h_prev + (((long)s_ * NT + (long)c * R + kk) * 2 + d) * H + li;
-    const long ga_step = 2L * 2 * 4 * H, hb_step = 2L * 2 * H;        // two rows further
+// Chunked A^T B on the MFMA pipe (fp32, exact) — the LSTM's parameter-gradient products, which rocBLAS ran as strided batched
+// GEMMs with 32x32x128 tiles at ~5-20 TFLOP/s (25 us each):
+//   part[(b * CK + c)][m][n] = sum over the R rows r of chunk c of  A_b[r][m] * B_b[r][n],   b = hi * nlo + lo,
+//   A_b = A + lo * a_lo + hi * a_hi (row pitch lda), B_b likewise (ldb).
+// A workgroup = one 32-row x 64-column output tile of one (batch, chunk); its four waves split the chunk's rows and are
+// summed through LDS in a fixed order.  Both operands are read straight from global memory in fragment order (a lane's A
+// element is A[r + lane/32][m0 + lane%32]: 128-byte runs), eight row pairs in flight per wave.
+struct AtB {
+    const float* A; const float* B; float* part;
+    long a_lo, a_hi, b_lo, b_hi;
+    int nlo, lda, ldb, M, N, R, CK;
+};
+__global__ __launch_bounds__(256) void atb_chunks_kernel(AtB p) {
+    __shared__ float red[3][32][64];                                    // waves 1..3 -> wave 0: 2 tiles x 16 registers x 64 lanes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kk = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+    const int bc = blockIdx.z, bb = bc / p.CK, c = bc % p.CK, lo = bb % p.nlo, hi = bb / p.nlo;
+    const int RW = p.R / 4;                                            // rows per wave (even)
+    const long r0 = (long)c * p.R + (long)wave * RW + kk;
+    const float* ga = p.A + lo * p.a_lo + hi * p.a_hi + r0 * p.lda + m0 + li;
+    const float* hb = p.B + lo * p.b_lo + hi * p.b_hi + r0 * p.ldb + n0 + li;
+    const long ga_step = 2L * p.lda, hb_step = 2L * p.ldb;
     f32x16w acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     constexpr int UN = 8;
-    for (int i0 = 0; i0 < R / 2; i0 += UN) {
+    for (int i0 = 0; i0 < RW / 2; i0 += UN) {
         float av[UN], b0[UN], b1[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const bool ok = i0 + u < R / 2;
+            const bool ok = i0 + u < RW / 2;
             av[u] = ok ? ga[(i0 + u) * ga_step] : 0.f;
             b0[u] = ok ? hb[(i0 + u) * hb_step] : 0.f;
             b1[u] = ok ? hb[(i0 + u) * hb_step + 32] : 0.f;
@@ -328,24 +336,64 @@ __global__ __launch_bounds__(64) void lstm_whh_grad_kernel(const float* __restri
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b1[u], acc1, 0, 0, 0);
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { red[wave - 1][r][lane] = acc0[r]; red[wave - 1][16 + r][lane] = acc1[r]; }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] += red[w][r][lane]; acc1[r] += red[w][16 + r][lane]; }
     // C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    float* o = part + (((long)d * 2 * CK + bi) * 4 * H + j0) * H + li;
+    float* o = p.part + ((long)bc * p.M + m0) * p.N + n0 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-        o[(long)row * H] = acc0[r];
-        o[(long)row * H + 32] = acc1[r];
+        o[(long)row * p.N] = acc0[r];
+        o[(long)row * p.N + 32] = acc1[r];
     }
+}
+// out_b[i] += sum_c part[(b * CK + c)][i]  (i < MN), out_b = out + lo * o_lo + hi * o_hi; fixed order
+__global__ __launch_bounds__(256) void chunk_sum_acc_kernel(const float* __restrict__ part, float* __restrict__ out, long o_lo,
+                                                             long o_hi, int nlo, int CK, long MN) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    const int bb = blockIdx.y, lo = bb % nlo, hi = bb / nlo;
+    const float* q = part + (long)bb * CK * MN + i;
+    float a = 0.f;
+    for (int c = 0; c < CK; ++c) a += q[(long)c * MN];
+    out[lo * o_lo + hi * o_hi + i] += a;
 }
 }  // namespace
 
-extern "C" int dcs_lstm_whh_grad(const float* g_pre, const float* h_prev, float* part, int NT, int CK, int H,
-                                 dcs_stream_t stream) {
-    if (!g_pre || !h_prev || !part || NT < 2 || CK < 1 || NT % CK != 0 || ((NT / CK) & 1) || H != 64) return DCS_ERR_BADARG;
-    if (2 * CK > 65535) return DCS_ERR_BADARG;
-    DCS_LAUNCH(lstm_whh_grad_kernel, dim3(4 * H / 32, 2 * CK, 2), dim3(64), 0, dcs_stream(stream), g_pre, h_prev, part, NT, CK, H);
+extern "C" int dcs_atb_chunks(const float* A, const float* B, float* part, long a_lo, long a_hi, long b_lo, long b_hi, int nlo,
+                              int nhi, int lda, int ldb, int M, int N, int R, int CK, dcs_stream_t stream) {
+    if (!A || !B || !part || nlo < 1 || nhi < 1 || M < 32 || (M & 31) || N < 64 || (N & 63) || R < 8 || (R & 7) || CK < 1)
+        return DCS_ERR_BADARG;
+    if ((long)nlo * nhi * CK > 65535 || N / 64 > 65535) return DCS_ERR_BADARG;
+    AtB p{A, B, part, a_lo, a_hi, b_lo, b_hi, nlo, lda, ldb, M, N, R, CK};
+    DCS_LAUNCH(atb_chunks_kernel, dim3(M / 32, N / 64, nlo * nhi * CK), dim3(256), 0, dcs_stream(stream), p);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+extern "C" int dcs_chunk_sum_acc(const float* part, float* out, long o_lo, long o_hi, int nlo, int nhi, int CK, long MN,
+                                 dcs_stream_t stream) {
+    if (!part || !out || nlo < 1 || nhi < 1 || CK < 1 || MN < 1 || (long)nlo * nhi > 65535) return DCS_ERR_BADARG;
+    DCS_LAUNCH(chunk_sum_acc_kernel, dim3((unsigned)((MN + 255) / 256), nlo * nhi), dim3(256), 0, dcs_stream(stream), part, out,
+               o_lo, o_hi, nlo, CK, MN);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// the recurrent-weight products of one layer: batches (d, s) = (hi, lo), part[d][s*CK + c][4H][H]
+extern "C" int dcs_lstm_whh_grad(const float* g_pre, const float* h_prev, float* part, int NT, int CK, int H,
+                                 dcs_stream_t stream) {
+    if (NT < 8 || CK < 1 || NT % CK != 0 || ((NT / CK) & 7) || H < 64 || (H & 63)) return DCS_ERR_BADARG;
+    return dcs_atb_chunks(g_pre, h_prev, part, (long)NT * 8 * H, 4L * H, (long)NT * 2 * H, (long)H, 2, 2, 8 * H, 2 * H, 4 * H, H,
+                          NT / CK, CK, stream);
 }
 
 extern "C" int dcs_lstm_combine_fwd(const float* o, float* out, long n, dcs_stream_t stream) {

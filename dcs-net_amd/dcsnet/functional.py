@@ -507,7 +507,7 @@ class _LstmLayerFn(torch.autograd.Function):
         # (n t) is cut into CK chunks that ride the batch axis (rocBLAS runs a [4H x H] output with K = 4096 on 16
         # workgroups otherwise), summed afterwards in a fixed order
         CK = 16 if NT % 32 == 0 else 1
-        if H == 64 and NT % (2 * CK) == 0:
+        if H % 64 == 0 and NT % (8 * CK) == 0:
             part = ops.lstm_whh_grad(g_pre, hprev, NT, CK, H)           # one MFMA launch (rocBLAS: four ~26 us batched GEMMs)
         else:
             R = NT // CK
@@ -522,14 +522,23 @@ class _LstmLayerFn(torch.autograd.Function):
         g_gx = g_pre.view(2, NT, 8 * H)
         g_wih = st['weight_ih'][1]
         sink_hits += 16
+        # W_ih gradient g_gx[s]^T inp over the (n t) rows: chunked A^T B on the MFMA pipe (rocBLAS: 25 us per 512 x 2048 x 256)
+        n_in = inp.shape[-1]
+        mfma_ok = g_wih.is_contiguous() and n_in % 64 == 0 and (8 * H) % 32 == 0 and NT % (8 * CK) == 0 and inp.is_contiguous()
         if inp.dim() == 2:                                              # shared first-layer input: per-set GEMMs, no expand
-            for s_ in range(2):
-                g_wih[s_].addmm_(g_gx[s_].t(), inp)
+            if mfma_ok:
+                ops.atb_chunks_acc(g_gx, inp, g_wih, 2, 8 * H, n_in, 8 * H, n_in, NT, CK, b_shared=True)
+            else:
+                for s_ in range(2):
+                    g_wih[s_].addmm_(g_gx[s_].t(), inp)
             g_inp = None
             if ctx.needs_input_grad[0]:
                 g_inp = torch.addmm(torch.mm(g_gx[0], w_ih[0]), g_gx[1], w_ih[1])
             return g_inp, None, None, None, None
-        torch.baddbmm(g_wih, g_gx.transpose(1, 2), inp, out=g_wih)      # accumulate in place
+        if mfma_ok:
+            ops.atb_chunks_acc(g_gx, inp, g_wih, 2, 8 * H, n_in, 8 * H, n_in, NT, CK)
+        else:
+            torch.baddbmm(g_wih, g_gx.transpose(1, 2), inp, out=g_wih)  # accumulate in place
         g_inp = torch.bmm(g_gx, w_ih) if ctx.needs_input_grad[0] else None
         return g_inp, None, None, None, None
 

@@ -854,6 +854,18 @@ def lstm_whh_grad(g_pre, h_prev, NT, CK, H):
     return part
 
 
+def atb_chunks_acc(A, B, out, nsets, lda, ldb, M, N, NT, CK, b_shared=False):
+    """out[s] (float [M, N], contiguous per set) += A[s]^T B[s] over the NT rows (A: [nsets, NT, lda-pitched M columns],
+    B: [nsets or 1, NT, N]) as CK row chunks on the MFMA pipe + one fixed-order chunk sum."""
+    for n, t in (('A', A), ('B', B), ('out', out)):
+        _chk(t, n)
+    lib = _lib.load()
+    part = torch.empty((nsets * CK, M, N), dtype=torch.float32, device=A.device)
+    check(lib.dcs_atb_chunks(ptr(A), ptr(B), ptr(part), NT * lda, 0, 0 if b_shared else NT * ldb, 0, nsets, 1, lda, ldb, M, N,
+                             NT // CK, CK, cur_stream()), 'dcs_atb_chunks')
+    check(lib.dcs_chunk_sum_acc(ptr(part), ptr(out), M * N, 0, nsets, 1, CK, M * N, cur_stream()), 'dcs_chunk_sum_acc')
+
+
 def lstm_param_grads(part, b_part, g_whh, g_bih, g_bhh, CK, seqs, H):
     """Accumulate one layer's recurrent-weight and bias gradients from the backward's partial products (in place)."""
     for n, t in (('part', part), ('b_part', b_part), ('g_whh', g_whh), ('g_bih', g_bih), ('g_bhh', g_bhh)):

@@ -396,8 +396,16 @@ int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_sa
 /* dcs_lstm_whh_grad: the K-chunked partial products dcs_lstm_param_grads sums, on the MFMA pipe (fp32, exact):
  *   part[d][s*CK + c][j][k] = sum over the NT/CK rows r of chunk c of g_pre[s][r][d][j] * h_prev[s][r][d][k],
  *   g_pre float[2 sets][NT][2 dirs][4H] (dcs_lstm_layer_bwd), h_prev float[2][NT][2][H] (dcs_lstm_layer_fwd), H = 64,
- *   NT/CK even. */
+ *   NT/CK a multiple of 8, H a multiple of 64. */
 int dcs_lstm_whh_grad(const float* g_pre, const float* h_prev, float* part, int NT, int CK, int H, dcs_stream_t stream);
+/* The general form: part[(b * CK + c)][m][n] = sum over the R rows r of chunk c of A_b[r][m] * B_b[r][n], batches
+ * b = hi * nlo + lo, A_b = A + lo * a_lo + hi * a_hi (floats; row pitch lda), B_b likewise; M % 32 == 0, N % 64 == 0,
+ * R % 8 == 0.  dcs_chunk_sum_acc: out_b[i] += sum_c part[(b * CK + c)][i], i < MN, out_b = out + lo * o_lo + hi * o_hi
+ * (the input-projection weight gradients of the LSTM: A = g_pre [NT][8H], B = the layer input [NT][in]). */
+int dcs_atb_chunks(const float* A, const float* B, float* part, long a_lo, long a_hi, long b_lo, long b_hi, int nlo, int nhi,
+                   int lda, int ldb, int M, int N, int R, int CK, dcs_stream_t stream);
+int dcs_chunk_sum_acc(const float* part, float* out, long o_lo, long o_hi, int nlo, int nhi, int CK, long MN,
+                      dcs_stream_t stream);
 int dcs_lstm_combine_fwd(const float* o, float* out, long n, dcs_stream_t stream);
 int dcs_lstm_combine_bwd(const float* g, float* g_o, long n, dcs_stream_t stream);
 int dcs_lstm_param_grads(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,

@@ -541,7 +541,7 @@ def test_lstm_glue_kernels(dev):
     close(d[1], g_bih + w_b, rel=1e-5, what='g_bih')
     close(d[2], g_bhh + w_b, rel=1e-5, what='g_bhh')
     # dcs_lstm_whh_grad: the chunked g_pre^T h_prev products on the MFMA pipe vs the strided batched GEMM it replaces
-    NT = 2 * 16 * 6
+    NT = 2 * 16 * 8
     g_pre = torch.randn(2, NT, 8 * H, generator=g)
     hprev = torch.randn(2, NT, 2 * H, generator=g)
     R = NT // CK
@@ -552,3 +552,11 @@ def test_lstm_glue_kernels(dev):
         want_p[dd] = torch.bmm(a.transpose(1, 2), h)
     got_p = ops.lstm_whh_grad(g_pre.to(dev), hprev.to(dev), NT, CK, H)
     close(got_p, want_p, rel=2e-5, what='lstm_whh_grad')
+    # the general chunked A^T B + chunk sum (the W_ih gradients): per-set inputs and one shared input
+    for n_in, shared in ((128, False), (256, True)):
+        inp = torch.randn((NT, n_in) if shared else (2, NT, n_in), generator=g)
+        out0 = torch.randn(2, 8 * H, n_in, generator=g)
+        want_w = out0 + torch.stack([g_pre[s_].t() @ (inp if shared else inp[s_]) for s_ in range(2)])
+        out = out0.clone().to(dev)
+        ops.atb_chunks_acc(g_pre.to(dev), inp.to(dev), out, 2, 8 * H, n_in, 8 * H, n_in, NT, CK, b_shared=shared)
+        close(out, want_w, rel=2e-5, what=f'atb_chunks_acc in={n_in}')
