@@ -54,7 +54,8 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
                                                            float* __restrict__ out, float* __restrict__ gates_save,
                                                            float* __restrict__ c_save, float* __restrict__ hprev_save,
                                                            int S, int seqs_per_set, long stride_set, long stride_n,
-                                                           long stride_t) {
+                                                           long stride_t, const float* __restrict__ bias_a,
+                                                           const float* __restrict__ bias_b) {
     constexpr int G4 = 4 * H;
     __shared__ __attribute__((aligned(16))) float h_s[2][H];
     const int t = threadIdx.x, u = t >> 2, gate = t & 3, j = gate * H + u;      // j: PyTorch gate row (i, f, g, o blocks)
@@ -77,6 +78,10 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
         }
     }
     const float* gxp = gx + set * stride_set + ns * stride_n + dir * G4 + j;
+    // optional gate biases [n_sets][2 dirs][4H] (b_ih, b_hh) added here instead of by a bias-broadcast pass over gx
+    float bias = 0.f;
+    if (bias_a) bias = bias_a[(set * 2 + dir) * G4 + j];
+    if (bias_b) bias += bias_b[(set * 2 + dir) * G4 + j];
     const int t0 = dir ? S - 1 : 0, dt = dir ? -1 : 1;
     float c = 0.f, hprev = 0.f;
     if (t < H) h_s[0][t] = 0.f;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
         }
         const float s0 = quad_sum(acc[0].x + acc[0].y), s1 = quad_sum(acc[1].x + acc[1].y);
         const float s2 = quad_sum(acc[2].x + acc[2].y), s3 = quad_sum(acc[3].x + acc[3].y);
-        const float a = pre + (gate == 0 ? s0 : (gate == 1 ? s1 : (gate == 2 ? s2 : s3)));
+        const float a = (pre + bias) + (gate == 0 ? s0 : (gate == 1 ? s1 : (gate == 2 ? s2 : s3)));
         const float th = fast_tanh(is_g ? a : 0.5f * a);
         const float act = is_g ? th : fmaf(0.5f, th, 0.5f);
         if (SAVE) gates_save[(((long)n * S + tt) * 2 + dir) * G4 + j] = act;
@@ -213,27 +218,35 @@ extern "C" int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const 
     return DCS_OK;
 }
 
-extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
-                                  float* hprev_save, int n_sets, int seqs_per_set, int S, int Hdim, long stride_set, long stride_n,
-                                  long stride_t, dcs_stream_t stream) {
+extern "C" int dcs_lstm_layer_fwd_bias(const float* gx, const float* w_hh, const float* bias_a, const float* bias_b, float* out,
+                                       float* gates_save, float* c_save, float* hprev_save, int n_sets, int seqs_per_set, int S,
+                                       int Hdim, long stride_set, long stride_n, long stride_t, dcs_stream_t stream) {
     if (!gx || !w_hh || !out || n_sets <= 0 || seqs_per_set <= 0 || S <= 0 || (Hdim != 64 && Hdim != 128)) return DCS_ERR_BADARG;
     if ((gates_save == nullptr) != (c_save == nullptr)) return DCS_ERR_BADARG;
+    if (bias_b && !bias_a) return DCS_ERR_BADARG;
     const int NS = n_sets * seqs_per_set;
     dim3 grid(NS * 2);
     if (Hdim == 128 && gates_save)
         DCS_LAUNCH((lstm_rec_fwd_kernel<128, true>), grid, dim3(512), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
-                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t, bias_a, bias_b);
     else if (Hdim == 128)
         DCS_LAUNCH((lstm_rec_fwd_kernel<128, false>), grid, dim3(512), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
-                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t, bias_a, bias_b);
     else if (gates_save)
         DCS_LAUNCH((lstm_rec_fwd_kernel<64, true>), grid, dim3(256), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
-                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t, bias_a, bias_b);
     else
         DCS_LAUNCH((lstm_rec_fwd_kernel<64, false>), grid, dim3(256), 0, dcs_stream(stream), gx, w_hh, out, gates_save,
-                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t);
+                           c_save, hprev_save, S, seqs_per_set, stride_set, stride_n, stride_t, bias_a, bias_b);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+extern "C" int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* gates_save, float* c_save,
+                                  float* hprev_save, int n_sets, int seqs_per_set, int S, int Hdim, long stride_set, long stride_n,
+                                  long stride_t, dcs_stream_t stream) {
+    return dcs_lstm_layer_fwd_bias(gx, w_hh, nullptr, nullptr, out, gates_save, c_save, hprev_save, n_sets, seqs_per_set, S, Hdim,
+                                   stride_set, stride_n, stride_t, stream);
 }
 
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     'dcs_attention_bwd_batched_workspace_bytes': (_L, [_I, _P, _I]),
     'dcs_attention_bwd_batched': (_I, [_I, _P, _P, _L, _I, _P]),
     'dcs_lstm_layer_fwd': (_I, [_P] * 6 + [_I, _I, _I, _I, _L, _L, _L, _P]),
+    'dcs_lstm_layer_fwd_bias': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P]),
     'dcs_lstm_layer_bwd': (_I, [_P] * 6 + [_I] * 4 + [_P]),
     'dcs_dropout_fwd': (_I, [_P, _P, _L, _F, _U64, _P, _P]),
     'dcs_complex_act_fwd': (_I, [_P, _P, _L, _I, _P]),

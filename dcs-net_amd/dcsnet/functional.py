@@ -475,20 +475,22 @@ class _LstmLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inp, anchor, st, B2, S):
         w_ih, w_hh = st['weight_ih'][0], st['weight_hh'][0]
-        bias = st['bias_ih'][0] + st['bias_hh'][0]
         need = inp.requires_grad or anchor.requires_grad
+        # the gate biases (b_ih + b_hh, [2 sets, 8H] = [set][dir][4H]) are added inside the recurrence kernel: no add, no
+        # bias-broadcast pass over gx
         if inp.dim() == 2:
             # first layer: both parameter sets read the SAME rows -> one GEMM against the stacked [2*8H, in] weight; the
             # recurrence takes gx by strides (set stride 8H inside a row), so nothing is expanded or copied
             G8 = w_ih.shape[1]
-            gx = torch.addmm(bias.reshape(-1), inp, w_ih.reshape(2 * G8, -1).t())              # [(n t), (set, dir*4H)]
+            gx = torch.mm(inp, w_ih.reshape(2 * G8, -1).t())                                    # [(n t), (set, dir*4H)]
             G4 = G8 // 2
             strides = (G8, S * 2 * G8, 2 * G8)
         else:
-            gx = torch.baddbmm(bias.unsqueeze(1), inp, w_ih.transpose(1, 2))                    # (set, n*t, dir*4H)
+            gx = torch.bmm(inp, w_ih.transpose(1, 2))                                           # (set, n*t, dir*4H)
             G4 = gx.shape[-1] // 2
             strides = (B2 * S * 2 * G4, S * 2 * G4, 2 * G4)
-        out, gates, c, hprev = ops.lstm_layer(gx, w_hh, 2, B2, S, strides, need, True)
+        out, gates, c, hprev = ops.lstm_layer(gx, w_hh, 2, B2, S, strides, need, True,
+                                              bias=(st['bias_ih'][0], st['bias_hh'][0]))
         ctx.st, ctx.dims = st, (B2, S)
         if need:
             ctx.save_for_backward(inp, hprev, gates, c)
@@ -618,6 +620,14 @@ def complex_lstm(z, real_lstm, imag_lstm):
             inp = out.view(2, 2 * B * S, -1)
             continue
         w_ih, bias, w_hh = _lstm_layer_operands(sets, layer)
+        if not (torch.is_grad_enabled() and (inp.requires_grad or bias.requires_grad or w_ih.requires_grad)):
+            # inference: bare projection, the gate biases are added inside the recurrence kernel (baddbmm's bias broadcast was
+            # a 27 us pass over gx per layer at [16,256,2000])
+            gx = torch.bmm(inp, w_ih.transpose(1, 2))
+            out = ops.lstm_layer(gx, w_hh.contiguous(), 2, 2 * B, S, (2 * B * S * gx.shape[-1], S * gx.shape[-1], gx.shape[-1]),
+                                 False, bias=(bias.contiguous(), None))[0]
+            inp = out.view(2, 2 * B * S, -1)
+            continue
         gx = torch.baddbmm(bias.unsqueeze(1), inp, w_ih.transpose(1, 2))          # (set, n*t, dir*4H)
         out = _LstmRecFn.apply(gx.view(2, 2 * B, S, 2, -1), w_hh)                 # [2*2B, S, 2H]
         inp = out.view(2, 2 * B * S, -1)

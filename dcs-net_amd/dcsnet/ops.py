@@ -575,7 +575,7 @@ def attention_blocks_bwd(saved, g_outs, wsa_bwds, fc_outs):
     return res
 
 
-def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False, save_hprev=False):
+def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False, save_hprev=False, bias=None):
     """Recurrent half of one LSTM layer for every (set, sequence, direction); see dcs_lstm_layer_fwd.
     gx: float pre-activations addressed by `strides` = (stride_set, stride_n, stride_t) in floats;
     w_hh: float [n_sets, 2, 4H, H].  Returns (out [n_sets*seqs_per_set, S, 2H], gates, c[, hprev])."""
@@ -587,8 +587,12 @@ def lstm_layer(gx, w_hh, n_sets, seqs_per_set, S, strides, save=False, save_hpre
     gates = torch.empty((NS, S, 2, 4 * H), dtype=torch.float32, device=gx.device) if save else None
     c = torch.empty((NS, S, 2, H), dtype=torch.float32, device=gx.device) if save else None
     hprev = torch.empty((NS, S, 2, H), dtype=torch.float32, device=gx.device) if save and save_hprev else None
-    check(_lib.load().dcs_lstm_layer_fwd(ptr(gx), ptr(w_hh), ptr(out), ptr(gates), ptr(c), ptr(hprev), n_sets, seqs_per_set,
-                                         S, H, strides[0], strides[1], strides[2], cur_stream()), 'dcs_lstm_layer_fwd')
+    ba, bb = (None, None) if bias is None else bias      # gate biases [n_sets, 2*4H] added inside the recurrence
+    _chk(ba, 'bias_a')
+    _chk(bb, 'bias_b')
+    check(_lib.load().dcs_lstm_layer_fwd_bias(ptr(gx), ptr(w_hh), ptr(ba), ptr(bb), ptr(out), ptr(gates), ptr(c), ptr(hprev),
+                                              n_sets, seqs_per_set, S, H, strides[0], strides[1], strides[2], cur_stream()),
+          'dcs_lstm_layer_fwd_bias')
     return (out, gates, c, hprev) if save_hprev else (out, gates, c)
 
 

@@ -383,6 +383,11 @@ int dcs_lstm_layer_fwd(const float* gx, const float* w_hh, float* out, float* ga
  * The caller's plain GEMMs turn g_pre into the gradients of x, W_ih and W_hh.  g_bias_part (optional):
  * float[NS][2][4H], g_pre summed over the time steps of each (sequence, direction); summing it over a set's
  * sequences gives that set's bias gradient. */
+/* dcs_lstm_layer_fwd with the gate biases added inside the recurrence: bias_a / bias_b float[n_sets][2 dirs][4H] (b_ih and
+ * b_hh, or their sum and NULL, or both NULL) — gx then holds the bare input projection (no bias-broadcast pass). */
+int dcs_lstm_layer_fwd_bias(const float* gx, const float* w_hh, const float* bias_a, const float* bias_b, float* out,
+                            float* gates_save, float* c_save, float* hprev_save, int n_sets, int seqs_per_set, int S,
+                            int Hdim, long stride_set, long stride_n, long stride_t, dcs_stream_t stream);
 int dcs_lstm_layer_bwd(const float* g_out, const float* gates, const float* c_save, const float* w_hh,
                        float* g_pre, float* g_bias_part, int n_sets, int seqs_per_set, int S, int H, dcs_stream_t stream);
 
