@@ -85,15 +85,17 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
     const int t0 = dir ? S - 1 : 0, dt = dir ? -1 : 1;
     float c = 0.f, hprev = 0.f;
     if (t < H) h_s[0][t] = 0.f;
-    float pre = gxp[(long)t0 * stride_t];
+    float pre = gxp[(long)t0 * stride_t] + bias;                      // (consumes the bias loads before the loop: the loop's
+                                                                       //  vmcnt counts then only ever see the gx prefetches)
     float pre2 = S > 1 ? gxp[(long)(t0 + dt) * stride_t] : 0.f;        // two steps of input projections in flight
     __syncthreads();
     const bool is_g = gate == 2;
     for (int s = 0; s < S; ++s) {
         const int tt = t0 + s * dt, cur = s & 1;
         const float nxt = pre2;
-        pre2 = 0.f;
-        if (s + 2 < S) pre2 = gxp[(long)(tt + 2 * dt) * stride_t];
+        // always a load (the last two steps re-read the final time index): a branch around it makes the compiler wait with
+        // vmcnt(0) — i.e. for this very load — instead of counting past it
+        pre2 = gxp[(long)(s + 2 < S ? tt + 2 * dt : t0 + (S - 1) * dt) * stride_t];
         // packed FMAs (v_pk_fma_f32: half the VALU issue slots of the scalar form), one accumulator pair per gate row
         v2f acc[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
         const float4* h4 = reinterpret_cast<const float4*>(h_s[cur] + gate * Q);
@@ -108,24 +110,26 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_fwd_kernel(const float* __rest
         }
         const float s0 = quad_sum(acc[0].x + acc[0].y), s1 = quad_sum(acc[1].x + acc[1].y);
         const float s2 = quad_sum(acc[2].x + acc[2].y), s3 = quad_sum(acc[3].x + acc[3].y);
-        const float a = (pre + bias) + (gate == 0 ? s0 : (gate == 1 ? s1 : (gate == 2 ? s2 : s3)));
+        const float a = pre + (gate == 0 ? s0 : (gate == 1 ? s1 : (gate == 2 ? s2 : s3)));
         const float th = fast_tanh(is_g ? a : 0.5f * a);
         const float act = is_g ? th : fmaf(0.5f, th, 0.5f);
         if (SAVE) gates_save[(((long)n * S + tt) * 2 + dir) * G4 + j] = act;
         const float ig = quad_bcast0(act), fg = quad_bcast1(act), gg = quad_bcast2(act), og = quad_bcast3(act);
         c = fmaf(fg, c, ig * gg);
         const float h = og * fast_tanh(c);
-        if (gate == 0) {
-            h_s[cur ^ 1][u] = h;
-            out[((long)n * S + tt) * (2 * H) + dir * H + u] = h;
-            if (SAVE) {
-                c_save[(((long)n * S + tt) * 2 + dir) * H + u] = c;
-                if (hprev_save) hprev_save[(((long)n * S + tt) * 2 + dir) * H + u] = hprev;   // state BEFORE this step
-            }
+        // All four lanes of a quad hold the same (c, h): they all store them (same value, same address — one write after
+        // coalescing).  Under `if (gate == 0)` the global stores sat in a divergent branch, the compiler could not count
+        // them, and the wait for the next step's input projection became vmcnt(0): every step then also waited for the
+        // previous step's stores (the no-save form ran 270 us at S = 500 against 243 us for the form that stores more).
+        if (gate == 0) h_s[cur ^ 1][u] = h;
+        out[((long)n * S + tt) * (2 * H) + dir * H + u] = h;
+        if (SAVE) {
+            c_save[(((long)n * S + tt) * 2 + dir) * H + u] = c;
+            if (hprev_save) hprev_save[(((long)n * S + tt) * 2 + dir) * H + u] = hprev;   // state BEFORE this step (uniform test)
         }
         hprev = h;
         step_barrier();
-        pre = nxt;
+        pre = nxt + bias;
     }
 }
 
@@ -155,22 +159,24 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_bwd_kernel(const float* __rest
     const int t0 = dir ? S - 1 : 0, dt = dir ? -1 : 1;
     float gc_rec = 0.f, gh_rec = 0.f, sb = 0.f;                         // sb: bias gradient of gate row j
     float act = 0.f, c = 0.f, cp = 0.f, go = 0.f;
+    // every fetch is three UNCONDITIONAL loads (clamped indices, values selected afterwards): a branch around a load makes
+    // the compiler wait with vmcnt(0) for the look-ahead loads it has just issued (lstm_rec_fwd_kernel: 270 -> 168 us)
     auto fetch = [&](int s_, float& a_, float& cp_, float& go_) {
         const int t_ = t0 + s_ * dt;
         a_ = gates[(((long)n * S + t_) * 2 + dir) * G4 + j];
-        cp_ = s_ > 0 ? cs[(((long)n * S + (t_ - dt)) * 2 + dir) * H + u] : 0.f;
+        const float cv = cs[(((long)n * S + (s_ > 0 ? t_ - dt : t_)) * 2 + dir) * H + u];
+        cp_ = s_ > 0 ? cv : 0.f;
         go_ = g_out[((long)n * S + t_) * (2 * H) + dir * H + u];
     };
     fetch(S - 1, act, cp, go);
     c = cs[(((long)n * S + (t0 + (S - 1) * dt)) * 2 + dir) * H + u];
     // operands of the next TWO steps in flight: one step of compute (~0.5 us) is shorter than an L2 / HBM round trip
     float q_act = 0.f, q_cp = 0.f, q_go = 0.f;                         // step s - 1
-    if (S > 1) fetch(S - 2, q_act, q_cp, q_go);
+    fetch(S > 1 ? S - 2 : 0, q_act, q_cp, q_go);
     for (int s = S - 1; s >= 0; --s) {
         const int tt = t0 + s * dt, cur = s & 1;
         float n_act = q_act, n_cp = q_cp, n_go = q_go;
-        q_act = 0.f; q_cp = 0.f; q_go = 0.f;
-        if (s > 1) fetch(s - 2, q_act, q_cp, q_go);
+        fetch(s > 1 ? s - 2 : 0, q_act, q_cp, q_go);                   // (the last two steps re-read step 0: unused)
         const float ig = quad_bcast0(act), fg = quad_bcast1(act), gg = quad_bcast2(act), og = quad_bcast3(act);
         const float tc = fast_tanh(c);
         const float gh = go + gh_rec;

@@ -20,4 +20,9 @@ for (sets, seqs, S, H) in ((2, 64, 64, 64), (2, 32, 500, 64), (1, 32, 64, 128)):
         return e0.elapsed_time(e1) / n * 1e3
     f = t(lambda: ops.lstm_layer(gx, whh, sets, seqs, S, st, True))
     b = t(lambda: ops.lstm_layer_bwd(go, gates, c, whh, sets, seqs, S))
-    print(f'sets {sets} seqs {seqs} S {S} H {H}: fwd {f:.1f} us ({f / S:.2f} us/step), bwd {b:.1f} us ({b / S:.2f} us/step)')
+    ba, bb = torch.randn(sets, 8 * H, device=dev) * 0.1, torch.randn(sets, 8 * H, device=dev) * 0.1
+    fb = t(lambda: ops.lstm_layer(gx, whh, sets, seqs, S, st, True, bias=(ba, bb)))
+    fi = t(lambda: ops.lstm_layer(gx, whh, sets, seqs, S, st, False))
+    fib = t(lambda: ops.lstm_layer(gx, whh, sets, seqs, S, st, False, bias=(ba, None)))
+    print(f'sets {sets} seqs {seqs} S {S} H {H}: fwd {f:.1f} us ({f / S:.2f} us/step; with biases {fb:.1f}; inference form {fi:.1f}, '
+          f'with bias {fib:.1f}), bwd {b:.1f} us ({b / S:.2f} us/step)')
