@@ -102,11 +102,13 @@ __global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d
 #pragma unroll
         for (int j = 0; j < KGRP; ++j) {
             const int tap = 4 * j + kg;
-            float2 w = make_float2(0.f, 0.f);
-            if (tap < TAPS) w = a.wp[tap * a.Cout + co];                   // direct panel complex[tap][ci = 0][co]
+            const int tc = tap < TAPS ? tap : TAPS - 1;                    // padding taps: any in-range address (B is 0 there)
+            // always a load, zeroed afterwards: under `if (tap < TAPS)` each of the 13 loads sat in its own branch and was
+            // waited for with vmcnt(0) before the next one was issued — 13 serial round trips at the head of every workgroup
+            float2 w = a.wp[tc * a.Cout + co];                             // direct panel complex[tap][ci = 0][co]
+            if (tap >= TAPS) w = make_float2(0.f, 0.f);
             bf[2 * j] = im ? w.y : w.x;                                    // x_re: (w_r -> re, w_i -> im)
             bf[2 * j + 1] = im ? w.x : -w.y;                               // x_im: (-w_i -> re, w_r -> im)
-            const int tc = tap < TAPS ? tap : TAPS - 1;                    // padding taps: any in-range address (B is 0 there)
             toff[j] = ((tc / K7) * PCP + (tc % K7)) * 2;
         }
     }
@@ -226,7 +228,11 @@ __global__ __launch_bounds__(256) void cconv_enc0_wgrad_kernel(conv::Args a, Til
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
             const int oy = oy0 + (q >> 3), ox = ox0 + (q & 7) * 4;
-            gv[q] = (oy < a.Hout && ox < a.Wout) ? gy[(((long)b * a.Hout + oy) * a.Wout + ox) * 16 + li] : 0.f;
+            // always a load (clamped pixel), zeroed afterwards: as sixteen predicated loads each one sat in its own branch
+            // and was waited for with vmcnt(0) before the next was issued
+            const bool inb = oy < a.Hout && ox < a.Wout;
+            const float v = gy[(((long)b * a.Hout + (inb ? oy : 0)) * a.Wout + (inb ? ox : 0)) * 16 + li];
+            gv[q] = inb ? v : 0.f;
         }
         // lane's window origin for quad 0: pixel (2 wave, kg); quad q adds a compile-time offset
         const float* base = reinterpret_cast<const float*>(patch[buf]) + ((4 * wave) * PCP + 2 * kg) * 2;

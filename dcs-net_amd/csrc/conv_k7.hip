@@ -32,13 +32,28 @@ __global__ __launch_bounds__(256) void cconv_k7_kernel(K7Table tb) {
     const int oy0 = ((int)blockIdx.x / p.tiles_w) * TR, ox0 = ((int)blockIdx.x % p.tiles_w) * TC;
     for (int i = t; i < K * K * CI * CO; i += 256) wl[i] = p.w[i];            // [tap][ci][co]
     const float2* xb = p.x + (long)b * p.H * p.W * CI;
-    for (int i = t; i < ROWS * COLS; i += 256) {
-        const int iy = i / COLS, ix = i % COLS;
-        const int y = oy0 - PAD + iy, x = ox0 - PAD + ix;
-        const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
+    // The haloed tile in ONE batch of unconditional loads (clamped coordinates, zeroed afterwards).  As a loop of predicated
+    // loads every trip was its own memory round trip: a branch, the load, s_waitcnt vmcnt(0), the LDS store — six in a row.
+    constexpr int NIT = (ROWS * COLS + 255) / 256;
+    float2 tv[NIT][CI];
 #pragma unroll
-        for (int ci = 0; ci < CI; ++ci)
-            tile[ci][iy * COLSP + ix] = in ? xb[((long)y * p.W + x) * CI + ci] : make_float2(0.f, 0.f);
+    for (int k = 0; k < NIT; ++k) {
+        const int i = t + 256 * k < ROWS * COLS ? t + 256 * k : ROWS * COLS - 1;
+        const int y = oy0 - PAD + i / COLS, x = ox0 - PAD + i % COLS;
+        const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y), xc = x < 0 ? 0 : (x >= p.W ? p.W - 1 : x);
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) tv[k][ci] = xb[((long)yc * p.W + xc) * CI + ci];
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = t + 256 * k;
+        if (i < ROWS * COLS) {
+            const int iy = i / COLS, ix = i % COLS;
+            const int y = oy0 - PAD + iy, x = ox0 - PAD + ix;
+            const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) tile[ci][iy * COLSP + ix] = in ? tv[k][ci] : make_float2(0.f, 0.f);
+        }
     }
     __syncthreads();
     const int ty = t / (TC / PB), tx = (t % (TC / PB)) * PB;
