@@ -29,4 +29,12 @@ hipcc -O3 --offload-arch=gfx950 $R/tools/micro/mfma_peak.hip -o /tmp/mfma_peak 2
 hipcc -O3 --offload-arch=gfx950 $R/tools/micro/dma_rate.hip -o /tmp/dma_rate 2>/dev/null && timeout -k 5 60 /tmp/dma_rate > $out/dma_rate.txt
 timeout -k 10 300 python3 $R/tools/conv_ab.py 32 256 5 > $out/conv_ab_train.txt 2>/dev/null
 timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 32 256 > $out/conv_layers_train.txt 2>/dev/null
+timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 16 2000 > $out/conv_layers_infer.txt 2>/dev/null
+timeout -k 10 120 python3 $R/tools/lstm_bench.py > $out/lstm_bench.txt 2>/dev/null
+echo "[collect] kernel sequence of one replayed train step / inference pass"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/kt_train -- python3 $R/bench.py --no-cpu-baseline --steps 4 --warmup 2 > $out/kt_train.log 2>&1
+python3 $R/tools/step_sequence.py $(find $out/kt_train -name "*kernel_trace.csv" | head -1) 6 > $out/step_sequence_train.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/kt_infer -- python3 $R/bench.py --mode infer --no-cpu-baseline --steps 4 --warmup 2 > $out/kt_infer.log 2>&1
+python3 $R/tools/infer_sequence.py $(find $out/kt_infer -name "*kernel_trace.csv" | head -1) > $out/step_sequence_infer.txt
+rm -rf $out/kt_train $out/kt_infer
 echo "[collect] done"; ls -la $out
