@@ -170,7 +170,8 @@ __device__ __forceinline__ void ca_bwd_sample_kernel_body(const double* __restri
     const int b = vbx, t = threadIdx.x;
     for (int c = t; c < C; c += kThreads) {
         double sr = 0, si = 0;
-        for (int k = 0; k < nchunks; ++k) {
+#pragma unroll 8
+        for (int k = 0; k < nchunks; ++k) {                            // (unrolled: the chunk loads go out together)
             const double* p = part + (((long)b * nchunks + k) * C + c) * 2;
             sr += p[0]; si += p[1];
         }

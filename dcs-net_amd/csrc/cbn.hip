@@ -122,10 +122,21 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ x, const double* _
     const int c = blockIdx.x, lane = threadIdx.x;
     float mr, mi, Crr, Cii, Cri;
     if (use_batch_stats) {
+        // all of a lane's slab loads in flight at once (<= 512 slabs = 8 per lane; clamped index, masked value): as a rolled
+        // loop of `b < nblocks` trips every trip was its own L2 round trip — 8 x ~0.7 us of a 5.7 us kernel
         double S[5] = {0, 0, 0, 0, 0};
-        for (int b = lane; b < nblocks; b += 64) {
+        for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
+            double v[8][5];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) S[i] += part[((long)b * C + c) * 5 + i];
+            for (int k = 0; k < 8; ++k) {
+                const int b = b0 + 64 * k < nblocks ? b0 + 64 * k : nblocks - 1;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) v[k][i] = part[((long)b * C + c) * 5 + i];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) S[i] += b0 + 64 * k < nblocks ? v[k][i] : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i) S[i] = dcs_wave_sum_d(S[i]);
@@ -189,10 +200,21 @@ __global__ void rbn_finalize_kernel(const float* __restrict__ x, const double* _
     const int c = blockIdx.x, lane = threadIdx.x;
     float mr, mi, vr, vi;
     if (use_batch_stats) {
+        // all of a lane's slab loads in flight at once (<= 512 slabs = 8 per lane; clamped index, masked value): as a rolled
+        // loop of `b < nblocks` trips every trip was its own L2 round trip — 8 x ~0.7 us of a 5.7 us kernel
         double S[5] = {0, 0, 0, 0, 0};
-        for (int b = lane; b < nblocks; b += 64) {
+        for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
+            double v[8][5];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) S[i] += part[((long)b * C + c) * 5 + i];
+            for (int k = 0; k < 8; ++k) {
+                const int b = b0 + 64 * k < nblocks ? b0 + 64 * k : nblocks - 1;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) v[k][i] = part[((long)b * C + c) * 5 + i];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) S[i] += b0 + 64 * k < nblocks ? v[k][i] : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i) S[i] = dcs_wave_sum_d(S[i]);

@@ -146,10 +146,20 @@ __global__ void cbn_bwd_finalize_kernel(const double* __restrict__ part, int nbl
                                         int use_batch_stats) {
     // one wavefront per channel: lanes stride over the partial slabs, fp64 butterfly, lane 0 finishes
     const int c = blockIdx.x, lane = threadIdx.x;
+    // (all of a lane's slab loads in flight at once: see cbn_finalize_kernel)
     double S[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = lane; b < nblocks; b += 64) {
+    for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
+        double v[8][6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) S[i] += part[((long)b * C + c) * 6 + i];
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + 64 * k < nblocks ? b0 + 64 * k : nblocks - 1;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[k][i] = part[((long)b * C + c) * 6 + i];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) S[i] += b0 + 64 * k < nblocks ? v[k][i] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) S[i] = dcs_wave_sum_d(S[i]);
@@ -210,10 +220,20 @@ __global__ void rbn_bwd_finalize_kernel(const double* __restrict__ part, int nbl
                                         float* __restrict__ g_bias, float* __restrict__ bcoef, long P, int C, int merge,
                                         int use_batch_stats) {
     const int c = blockIdx.x, lane = threadIdx.x;
+    // (all of a lane's slab loads in flight at once: see cbn_finalize_kernel)
     double S[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = lane; b < nblocks; b += 64) {
+    for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
+        double v[8][6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) S[i] += part[((long)b * C + c) * 6 + i];
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + 64 * k < nblocks ? b0 + 64 * k : nblocks - 1;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[k][i] = part[((long)b * C + c) * 6 + i];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) S[i] += b0 + 64 * k < nblocks ? v[k][i] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) S[i] = dcs_wave_sum_d(S[i]);

@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
     if (i4 * 4 >= slab_floats) return;
     float4 v = *reinterpret_cast<const float4*>(part + i4 * 4);
+#pragma unroll 4
     for (int s_ = 1; s_ < S; ++s_) {
         const float4 u = *reinterpret_cast<const float4*>(part + (long)s_ * slab_floats + i4 * 4);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;

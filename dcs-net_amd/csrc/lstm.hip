@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void lstm_param_grads_kernel(const float* __re
         const int e = i % WH, d = (i / WH) % 2, s_ = i / (2 * WH);
         const float* p = part + ((long)d * 2 * CK + (long)s_ * CK) * WH + e;
         float a = 0.f;
-        for (int c = 0; c < CK; ++c) a += p[(long)c * WH];
+#pragma unroll 8
+        for (int c = 0; c < CK; ++c) a += p[(long)c * WH];            // (unrolled: the chunk loads go out together)
         g_whh[i] += a;
         return;
     }
@@ -343,11 +344,13 @@ __global__ __launch_bounds__(256) void atb_chunks_kernel(AtB p) {
     for (int i0 = 0; i0 < RW / 2; i0 += UN) {
         float av[UN], b0[UN], b1[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
+        for (int u = 0; u < UN; ++u) {                                  // always loads (clamped row pair), A zeroed past the end
             const bool ok = i0 + u < RW / 2;
-            av[u] = ok ? ga[(i0 + u) * ga_step] : 0.f;
-            b0[u] = ok ? hb[(i0 + u) * hb_step] : 0.f;
-            b1[u] = ok ? hb[(i0 + u) * hb_step + 32] : 0.f;
+            const int ii = ok ? i0 + u : RW / 2 - 1;
+            const float a_ = ga[ii * ga_step];
+            av[u] = ok ? a_ : 0.f;
+            b0[u] = hb[ii * hb_step];
+            b1[u] = hb[ii * hb_step + 32];
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -382,6 +385,7 @@ __global__ __launch_bounds__(256) void chunk_sum_acc_kernel(const float* __restr
     const int bb = blockIdx.y, lo = bb % nlo, hi = bb / nlo;
     const float* q = part + (long)bb * CK * MN + i;
     float a = 0.f;
+#pragma unroll 8
     for (int c = 0; c < CK; ++c) a += q[(long)c * MN];
     out[lo * o_lo + hi * o_hi + i] += a;
 }
