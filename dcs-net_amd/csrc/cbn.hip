@@ -10,6 +10,7 @@
 //   cbn_apply_kernel     y = act(A x + c) (+ dropout), float4 streaming, coefficients in VGPRs
 // HBM-bound: algorithmic bytes per pixel-channel = 8 (stats read) + 8 + 8 (apply read + write).
 #include "dcs_common.h"
+#include "cbn_geom.h"
 
 namespace {
 
@@ -27,7 +28,7 @@ inline bool cbn_geom(long P, int C, CbnGeom* g) {
     if (C == 1) {
         long nvec = P / 2;
         long it = (nvec + kThreads - 1) / kThreads;
-        long nb = (it + 7) / 8;
+        long nb = (it + DCS_CBN_RED_IT - 1) / DCS_CBN_RED_IT;
         g->vec_per_row = 0;
         g->rows_per_iter = 0;
         g->nblocks = (int)(nb < 1 ? 1 : (nb > kMaxBlocks ? kMaxBlocks : nb));
@@ -39,7 +40,7 @@ inline bool cbn_geom(long P, int C, CbnGeom* g) {
     g->vec_per_row = G;
     g->rows_per_iter = kThreads / G;
     long it = (P + g->rows_per_iter - 1) / g->rows_per_iter;
-    long nb = (it + 7) / 8;
+    long nb = (it + DCS_CBN_RED_IT - 1) / DCS_CBN_RED_IT;
     g->nblocks = (int)(nb < 1 ? 1 : (nb > kMaxBlocks ? kMaxBlocks : nb));
     return true;
 }
@@ -365,7 +366,7 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
     }
     // apply: ~4 float4 per thread per workgroup pass, capped at 2048 workgroups
     long iters = (C == 1) ? (P / 2 + kThreads - 1) / kThreads : (P + g.rows_per_iter - 1) / g.rows_per_iter;
-    long nb = (iters + 3) / 4;
+    long nb = (iters + DCS_CBN_APP_IT - 1) / DCS_CBN_APP_IT;
     int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
 #define DCS_CBN_APPLY(A, D)                                                                                   \
     DCS_LAUNCH((cbn_apply_kernel<A, D>), dim3(grid), dim3(kThreads), 0, s, x, y, coef_out, P, C,         \
@@ -403,7 +404,7 @@ extern "C" int dcs_rbn_fwd(const float* x, float* y, const float* weight, const 
                running_mean, running_var, stats_out, coef_out, Pc, C, merge, eps, momentum, use_batch_stats);
     DCS_CHECK_LAUNCH();
     long iters = (C == 1) ? (Pc / 2 + kThreads - 1) / kThreads : (Pc + g.rows_per_iter - 1) / g.rows_per_iter;
-    long nb = (iters + 3) / 4;
+    long nb = (iters + DCS_CBN_APP_IT - 1) / DCS_CBN_APP_IT;
     const int grid = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
 #define DCS_RBN_APPLY(A)                                                                                        \
     DCS_LAUNCH((cbn_apply_kernel<A, false>), dim3(grid), dim3(kThreads), 0, s, x, y, coef_out, Pc, C, g.vec_per_row, \

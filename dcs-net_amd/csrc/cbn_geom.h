@@ -3,6 +3,12 @@
 // pass, so a thread keeps ONE channel pair for the whole kernel (statistics and coefficients
 // stay in registers) and every global access is a contiguous 16-byte-per-lane stream.
 #pragma once
+#ifndef DCS_CBN_RED_IT
+#define DCS_CBN_RED_IT 8      // row passes per reduction workgroup
+#endif
+#ifndef DCS_CBN_APP_IT
+#define DCS_CBN_APP_IT 4      // row passes per streaming workgroup
+#endif
 
 namespace cbn {
 
@@ -30,14 +36,14 @@ inline bool geom(long P, int C, Geom* g) {
         g->rows_per_iter = kThreads / G;
         it = (P + g->rows_per_iter - 1) / g->rows_per_iter;
     }
-    const long nb = (it + 7) / 8;
+    const long nb = (it + DCS_CBN_RED_IT - 1) / DCS_CBN_RED_IT;
     g->nblocks = (int)(nb < 1 ? 1 : (nb > kMaxBlocks ? kMaxBlocks : nb));
     return true;
 }
 
 inline int stream_grid(long P, int C, const Geom& g) {
     const long iters = (C == 1) ? (P / 2 + kThreads - 1) / kThreads : (P + g.rows_per_iter - 1) / g.rows_per_iter;
-    const long nb = (iters + 3) / 4;
+    const long nb = (iters + DCS_CBN_APP_IT - 1) / DCS_CBN_APP_IT;
     return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
 }
 
