@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void atb_chunks_kernel(AtB p) {
     f32x16w acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    constexpr int UN = 8;
+    constexpr int UN = 16;                                             // row pairs in flight (all of a wave's at the LSTM's shapes)
     for (int i0 = 0; i0 < RW / 2; i0 += UN) {
         float av[UN], b0[UN], b1[UN];
 #pragma unroll
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256) void atb_chunks_kernel(AtB p) {
             b0[u] = hb[ii * hb_step];
             b1[u] = hb[ii * hb_step + 32];
         }
+        __builtin_amdgcn_sched_barrier(0);                             // every load issued before the first MFMA waits
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b0[u], acc0, 0, 0, 0);

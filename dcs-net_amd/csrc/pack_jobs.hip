@@ -157,12 +157,25 @@ __global__ __launch_bounds__(256) void pack_one_kernel(Job j) { run(j, (long)blo
 
 // blk0[k] = first block of job k (ascending; blk0[nj] = grid size)
 __global__ __launch_bounds__(256) void pack_multi_kernel(const Job* __restrict__ jobs, const int* __restrict__ blk0, int nj) {
-    int lo = 0, hi = nj - 1;
-    const int b = blockIdx.x;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (blk0[mid] <= b) lo = mid; else hi = mid - 1;
+    // which job owns this block: thread k tests job k (one coalesced read of the table; a binary search over it in global
+    // memory was six dependent round trips at the head of every block), jobs beyond 256 by the serial search
+    __shared__ int s_lo;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (nj <= 256) {
+        if (t < nj && blk0[t] <= b && b < blk0[t + 1]) s_lo = t;
+        __syncthreads();
+    } else {
+        if (t == 0) {
+            int lo = 0, hi = nj - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (blk0[mid] <= b) lo = mid; else hi = mid - 1;
+            }
+            s_lo = lo;
+        }
+        __syncthreads();
     }
+    const int lo = s_lo;
     run(jobs[lo], (long)(b - blk0[lo]) * 256 + threadIdx.x);
 }
 
