@@ -18,7 +18,23 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxChunks = 64;
+#ifndef DCS_ATT_RED_IT
+#define DCS_ATT_RED_IT 2          // row passes per reduction workgroup: each pass is loads + cross-lane reductions IN SERIES (~1 us),
+                                  // so eight of them made every decoder block's kernels 16-20 us whatever the tensor size
+#endif
+#ifndef DCS_ATT_APP_IT
+#define DCS_ATT_APP_IT 2          // row passes per streaming workgroup
+#endif
+#ifndef DCS_ATT_SMALL_IT
+#define DCS_ATT_SMALL_IT 256      // row passes of a sample below which the short-chain grids are used
+#endif
+#ifndef DCS_ATT_MAX_CHUNKS
+#define DCS_ATT_MAX_CHUNKS 256
+#endif
+#ifndef DCS_ATT_GRID_CAP
+#define DCS_ATT_GRID_CAP 8192
+#endif
+constexpr int kMaxChunks = DCS_ATT_MAX_CHUNKS;
 
 inline bool att_geom(int C, int* G) {
     if (C < 2 || (C & 1)) return false;
@@ -30,7 +46,10 @@ inline bool att_geom(int C, int* G) {
 inline int chunks_for(long HW, int G) {
     const int rpi = kThreads / G;
     long it = (HW + rpi - 1) / rpi;
-    long nb = (it + 7) / 8;
+    // few passes only where there are few rows to begin with (the train shapes' decoder blocks); large maps keep 8 passes and
+    // 64 chunks (more chunks there cost more in slab traffic than the shorter chains return: inference 4.31 -> 4.43 ms)
+    long nb = it <= DCS_ATT_SMALL_IT ? (it + DCS_ATT_RED_IT - 1) / DCS_ATT_RED_IT : (it + 7) / 8;
+    if (it > DCS_ATT_SMALL_IT && nb > 64) nb = 64;
     return (int)(nb < 1 ? 1 : (nb > kMaxChunks ? kMaxChunks : nb));
 }
 
@@ -310,8 +329,8 @@ __global__ __launch_bounds__(kThreads) void att_bwd_pool_multi_kernel(Tbl<PoolP>
 inline int stream_grid(long HW, int G, int B) {
     const int rpi = kThreads / G;
     long it = (HW + rpi - 1) / rpi;
-    long nb = (it + 3) / 4;
-    long cap = 2048 / (B > 0 ? B : 1);
+    long nb = it <= DCS_ATT_SMALL_IT ? (it + DCS_ATT_APP_IT - 1) / DCS_ATT_APP_IT : (it + 3) / 4;
+    long cap = (it <= DCS_ATT_SMALL_IT ? DCS_ATT_GRID_CAP : 2048) / (B > 0 ? B : 1);
     if (cap < 1) cap = 1;
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
 }
