@@ -57,13 +57,15 @@ __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
         const int q = i % (CIN / 2), px_ = i / (CIN / 2);
         const int hc = px_ % HC, hr = px_ / HC;
         const int sy = m0 - 1 + hr, sx = n0 - 1 + hc;
-        sv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < NSLOT && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws) {
-            const long sp = img + (long)sy * p.Ws + sx;
-            const int c = 2 * q;
-            const float2* src = c < p.C1 ? p.x1 + sp * p.C1 + c : p.x2 + sp * p.C2 + (c - p.C1);
-            sv[k] = *reinterpret_cast<const float4*>(src);
-        }
+        // always a load (clamped pixel), zeroed afterwards: predicated, each load sat in its own branch and the eleven of a
+        // thread went out one memory round trip after the other
+        const bool in = i < NSLOT && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
+        const int syc = sy < 0 ? 0 : (sy >= p.Hs ? p.Hs - 1 : sy), sxc = sx < 0 ? 0 : (sx >= p.Ws ? p.Ws - 1 : sx);
+        const long sp = img + (long)syc * p.Ws + sxc;
+        const int c = 2 * q;
+        const float2* src = c < p.C1 ? p.x1 + sp * p.C1 + c : p.x2 + sp * p.C2 + (c - p.C1);
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        sv[k] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
