@@ -559,7 +559,8 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // candidate workgroup tiles (pixels x columns): the largest whose USEFUL workgroups (workgroups x the share of their
     // pixels inside the map) number >= min_blocks — several per CU, so one workgroup's MFMA phase hides another's
     // patch gather ...
-    static const long min_blocks = [] { const char* e = getenv("DCS_MFMA_MIN_BLOCKS"); return e ? atol(e) : 1024L; }();
+    static const long min_blocks = [] { const char* e = getenv("DCS_MFMA_MIN_BLOCKS"); return e ? atol(e) : 768L; }();   // (3 per CU; at 1024 the
+    // inference shapes' enc6 / enc3 took the smaller tile: 118 -> 94 us, 224 -> 217 us; the train shapes do not move)
     static const long split_below = [] { const char* e = getenv("DCS_MFMA_SPLIT_BELOW"); return e ? atol(e) : 512L; }();
     int best = -1; long best_blocks = -1; double best_useful = -1;
     for (int i = 0; i < 4; ++i) {
