@@ -17,6 +17,13 @@
 
 namespace {
 
+#ifdef DCS_ENC0_DIAG
+#define EDIAG_NOW() ((long long)__builtin_amdgcn_s_memtime())
+long long* g_edbg = nullptr;
+#else
+#define EDIAG_NOW() 0LL
+#endif
+
 constexpr int K7 = 7, TAPS = 49, KGRP = 13, KSTEPS = 2 * KGRP, TR = 8, TC = 32, PR = (TR - 1) * 2 + K7, PC = (TC - 1) * 2 + K7, PCP = PC + 1;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -81,7 +88,7 @@ __device__ __forceinline__ void store_pair(const conv::Args& a, const f32x4v* ac
 // tile's MFMAs run (two LDS buffers, one barrier per tile), the B fragments are built once per workgroup.
 // ACT: the activation at compile time, or -1 for a.act at run time.
 template <int ACT>
-__global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d, int ntile) {
+__global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d, int ntile, long long* dbg) {
     __shared__ float2 patch[2][PR * PCP];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -120,8 +127,11 @@ __global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d
         if (li & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
     }
     int buf = 0;
+    long long d_fill = 0, d_comp = 0, d_n = 0;
+    const long long d_start = EDIAG_NOW();
 #pragma unroll 1
     for (; tile < ntile; tile += gridDim.x, buf ^= 1) {
+        const long long e0 = EDIAG_NOW();
         // (buffer `buf` was last read two tiles ago, and every wave passed the barrier of the tile in between since)
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
@@ -129,6 +139,8 @@ __global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d
             if (k < NL - 1 || i < PR * PC) patch[buf][i + row_of(rows, k)] = pv_[k];         // r PCP + c = i + r
         }
         __syncthreads();
+        const long long e1 = EDIAG_NOW();
+        d_fill += e1 - e0; ++d_n;
         if (tile + (int)gridDim.x < ntile) patch_load(a, d, tile + gridDim.x, t, rows, pv_);
         int b, ty, tx;
         tile_split(d, tile, &b, &ty, &tx);
@@ -171,7 +183,15 @@ __global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d
                 else store_pair<ACT, true>(a, acc, yp, ox0 + kg * 4, bv, c_re, c_im, c_add, li);
             }
         }
+        d_comp += EDIAG_NOW() - e1;
     }
+#ifdef DCS_ENC0_DIAG
+    if (dbg && t == 0 && blockIdx.x < 4096) {
+        long long* q = dbg + blockIdx.x * 8;
+        q[0] = d_fill; q[1] = d_comp; q[2] = EDIAG_NOW() - d_start; q[3] = d_n; q[4] = d_start;
+        q[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q[6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    }
+#endif
 }
 
 
@@ -320,9 +340,14 @@ int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream) {
         resident = cus * 4;
     }
     const int grid = ntile < resident ? (int)ntile : resident;
-    if (a.act == DCS_ACT_NONE) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_NONE>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
-    else if (a.act == DCS_ACT_RELU) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_RELU>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
-    else DCS_LAUNCH(cconv_enc0_kernel<-1>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile);
+#ifdef DCS_ENC0_DIAG
+    long long* dbgp = g_edbg;
+#else
+    long long* dbgp = nullptr;
+#endif
+    if (a.act == DCS_ACT_NONE) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_NONE>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
+    else if (a.act == DCS_ACT_RELU) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_RELU>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
+    else DCS_LAUNCH(cconv_enc0_kernel<-1>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -352,3 +377,7 @@ int dcs_conv_enc0_wgrad_launch(conv::Args a, const float* gy, float2* slab_w, fl
     *n_used = grid;
     return DCS_OK;
 }
+
+#ifdef DCS_ENC0_DIAG
+extern "C" int dcs_debug_set_enc0_buffer(void* p) { g_edbg = (long long*)p; return 0; }
+#endif
