@@ -281,7 +281,23 @@ __device__ __forceinline__ void att_bwd_pool_kernel_body(float* __restrict__ gx,
 
 // ---- launch forms: one problem per launch, or several problems (blockIdx.z) sharing one launch (see attention.hip) ----
 constexpr int kMaxBatch = 8;
-template <class P> struct Tbl { P p[kMaxBatch]; };
+// x0: first blockIdx.x of each problem in the compacted grid (attention.hip)
+template <class P> struct Tbl { P p[kMaxBatch]; int x0[kMaxBatch + 1]; };
+template <class P> __device__ __forceinline__ int tbl_find(const Tbl<P>& t, int bx) {
+    int z = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxBatch; ++k) z += bx >= t.x0[k] ? 1 : 0;
+    return z;
+}
+template <class P> void tbl_compact(Tbl<P>& t, int n, int* total) {
+    int a = 0;
+    for (int k = 0; k <= kMaxBatch; ++k) {
+        t.x0[k] = k < n ? a : 0x7fffffff;
+        if (k < n) a += t.p[k].nx;
+    }
+    t.x0[n] = a;
+    *total = a;
+}
 
 struct BwdSaP { const float* x; const float* go; const float* ca; const float2* sa; float2* gpre; long HW; int G, nx; };
 struct BwdXP { const float* x; const float* go; const float* ca; const float2* sa; const float4* gsp; float* gx; double* part;
@@ -295,9 +311,9 @@ __global__ __launch_bounds__(kThreads) void att_bwd_sa_kernel(BwdSaP p, float dr
     att_bwd_sa_kernel_body<DROP>(p.x, p.go, p.ca, p.sa, p.gpre, p.HW, p.G, drop_p, seed, seed_dev, blockIdx.x, blockIdx.y, gridDim.x);
 }
 __global__ __launch_bounds__(kThreads) void att_bwd_sa_multi_kernel(Tbl<BwdSaP> t) {
-    const BwdSaP& p = t.p[blockIdx.z];
-    if ((int)blockIdx.x >= p.nx) return;
-    att_bwd_sa_kernel_body<false>(p.x, p.go, p.ca, p.sa, p.gpre, p.HW, p.G, 0.f, 0, nullptr, blockIdx.x, blockIdx.y, p.nx);
+    const int z = tbl_find(t, blockIdx.x);
+    const BwdSaP& p = t.p[z];
+    att_bwd_sa_kernel_body<false>(p.x, p.go, p.ca, p.sa, p.gpre, p.HW, p.G, 0.f, 0, nullptr, blockIdx.x - t.x0[z], blockIdx.y, p.nx);
 }
 template <bool DROP>
 __global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(BwdXP p, float drop_p, uint64_t seed, const uint64_t* seed_dev) {
@@ -305,10 +321,10 @@ __global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(BwdXP p, float drop
                                 blockIdx.y, gridDim.x);
 }
 __global__ __launch_bounds__(kThreads) void att_bwd_x_multi_kernel(Tbl<BwdXP> t) {
-    const BwdXP& p = t.p[blockIdx.z];
-    if ((int)blockIdx.x >= p.nx) return;
-    att_bwd_x_kernel_body<false>(p.x, p.go, p.ca, p.sa, p.gsp, p.gx, p.part, p.HW, p.C, p.G, 0.f, 0, nullptr, blockIdx.x, blockIdx.y,
-                                 p.nx);
+    const int z = tbl_find(t, blockIdx.x);
+    const BwdXP& p = t.p[z];
+    att_bwd_x_kernel_body<false>(p.x, p.go, p.ca, p.sa, p.gsp, p.gx, p.part, p.HW, p.C, p.G, 0.f, 0, nullptr, blockIdx.x - t.x0[z],
+                                 blockIdx.y, p.nx);
 }
 __global__ __launch_bounds__(kThreads) void ca_bwd_sample_kernel(CaBwdP p) {
     ca_bwd_sample_kernel_body(p.part, p.nchunks, p.ca, p.hidden, p.w1, p.w2, p.go, p.gh, p.gpooled, p.C, p.Ch, blockIdx.x, 0, 0);
@@ -321,9 +337,9 @@ __global__ __launch_bounds__(kThreads) void att_bwd_pool_kernel(PoolP p) {
     att_bwd_pool_kernel_body(p.gx, p.gpooled, p.HW, p.G, p.inv_hw, p.nx_pool, p.w, blockIdx.x, blockIdx.y, gridDim.x);
 }
 __global__ __launch_bounds__(kThreads) void att_bwd_pool_multi_kernel(Tbl<PoolP> t) {
-    const PoolP& p = t.p[blockIdx.z];
-    if ((int)blockIdx.x >= p.nx) return;
-    att_bwd_pool_kernel_body(p.gx, p.gpooled, p.HW, p.G, p.inv_hw, p.nx_pool, p.w, blockIdx.x, blockIdx.y, p.nx);
+    const int z = tbl_find(t, blockIdx.x);
+    const PoolP& p = t.p[z];
+    att_bwd_pool_kernel_body(p.gx, p.gpooled, p.HW, p.G, p.inv_hw, p.nx_pool, p.w, blockIdx.x - t.x0[z], blockIdx.y, p.nx);
 }
 
 inline int stream_grid(long HW, int G, int B) {
@@ -467,15 +483,16 @@ extern "C" int dcs_attention_bwd_batched(int n, const dcs_attention_item* items,
         a.Hv = it.H; a.Wv = it.W; a.Hout = it.H; a.Wout = it.W;
     }
     hipStream_t s = dcs_stream(stream);
-    DCS_LAUNCH(att_bwd_sa_multi_kernel, dim3(nx_sa, B, n), dim3(kThreads), 0, s, tsa);
+    tbl_compact(tsa, n, &nx_sa); tbl_compact(tx, n, &nx_x); tbl_compact(tp, n, &nx_p);
+    DCS_LAUNCH(att_bwd_sa_multi_kernel, dim3(nx_sa, B, 1), dim3(kThreads), 0, s, tsa);
     DCS_CHECK_LAUNCH();
     const int rc = dcs_conv_direct_multi(dg, n, s);
     if (rc != DCS_OK) return rc;
-    DCS_LAUNCH(att_bwd_x_multi_kernel, dim3(nx_x, B, n), dim3(kThreads), 0, s, tx);
+    DCS_LAUNCH(att_bwd_x_multi_kernel, dim3(nx_x, B, 1), dim3(kThreads), 0, s, tx);
     DCS_CHECK_LAUNCH();
     DCS_LAUNCH(ca_bwd_sample_multi_kernel, dim3(B, 1, n), dim3(kThreads), 0, s, tc);
     DCS_CHECK_LAUNCH();
-    DCS_LAUNCH(att_bwd_pool_multi_kernel, dim3(nx_p, B, n), dim3(kThreads), 0, s, tp);
+    DCS_LAUNCH(att_bwd_pool_multi_kernel, dim3(nx_p, B, 1), dim3(kThreads), 0, s, tp);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

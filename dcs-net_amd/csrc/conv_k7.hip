@@ -7,7 +7,8 @@
 // windows span once and re-uses each of them for up to 4 outputs x 7 taps; the 49 x CI x CO weights sit in LDS
 // (broadcast reads).  ~6.6 FMAs per LDS access instead of 2.
 //   tile  16 rows x 64 columns of output per 256-thread workgroup; haloed input 22 x 70 x CI in LDS
-// Problems may be batched (table by value, problem = blockIdx.y) like the other attention kernels.
+// Problems may be batched (table by value) like the other attention kernels; the grid is compacted: problem k owns
+// blockIdx.x in [x0[k], x0[k+1]), so no workgroup is dispatched only to find it has no tile.
 #include "conv_common.h"
 
 namespace {
@@ -20,16 +21,19 @@ struct K7P {
     const float2* x; const float2* w; const float2* bias; float2* y;
     int H, W, tiles_w, tiles, act;
 };
-struct K7Table { K7P p[kMaxBatch]; };
+struct K7Table { K7P p[kMaxBatch]; int x0[kMaxBatch + 1]; };
 
 template <int CI, int CO>
 __global__ __launch_bounds__(256) void cconv_k7_kernel(K7Table tb) {
     __shared__ __attribute__((aligned(16))) float2 tile[CI][ROWS * COLSP];
     __shared__ float2 wl[K * K * CI * CO];
-    const K7P& p = tb.p[blockIdx.y];
-    if ((int)blockIdx.x >= p.tiles) return;
-    const int t = threadIdx.x, b = blockIdx.z;
-    const int oy0 = ((int)blockIdx.x / p.tiles_w) * TR, ox0 = ((int)blockIdx.x % p.tiles_w) * TC;
+    int z = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxBatch; ++k) z += (int)blockIdx.x >= tb.x0[k] ? 1 : 0;
+    const K7P& p = tb.p[z];
+    const int tl = (int)blockIdx.x - tb.x0[z];
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int oy0 = (tl / p.tiles_w) * TR, ox0 = (tl % p.tiles_w) * TC;
     for (int i = t; i < K * K * CI * CO; i += 256) wl[i] = p.w[i];            // [tap][ci][co]
     const float2* xb = p.x + (long)b * p.H * p.W * CI;
     // The haloed tile in ONE batch of unconditional loads (clamped coordinates, zeroed afterwards).  As a loop of predicated
@@ -130,9 +134,11 @@ int dcs_conv_k7_launch(const conv::Args* a, int n, hipStream_t stream) {
         p.H = a[i].Hin; p.W = a[i].Win; p.act = a[i].act;
         p.tiles_w = (p.W + TC - 1) / TC;
         p.tiles = p.tiles_w * ((p.H + TR - 1) / TR);
-        tiles = p.tiles > tiles ? p.tiles : tiles;
+        tb.x0[i] = tiles;
+        tiles += p.tiles;
     }
-    dim3 grid(tiles, n, a[0].B);
+    for (int i = n; i <= kMaxBatch; ++i) tb.x0[i] = i == n ? tiles : 0x7fffffff;
+    dim3 grid(tiles, a[0].B, 1);
     if (a[0].C1 == 2) DCS_LAUNCH((cconv_k7_kernel<2, 1>), grid, dim3(256), 0, stream, tb);
     else if (a[0].Cout == 2) DCS_LAUNCH((cconv_k7_kernel<1, 2>), grid, dim3(256), 0, stream, tb);
     else DCS_LAUNCH((cconv_k7_kernel<1, 1>), grid, dim3(256), 0, stream, tb);
