@@ -68,15 +68,16 @@ class ConvTimer:
         self._seq = 0
         self._step += 1
 
-    def begin(self, flops, tag=None, executed=1.0):
+    def begin(self, flops, tag=None, executed=1.0, emulated=False):
         """flops: ALGORITHMIC flops of the launch (what the reference computes); executed: the share of them the kernel
         actually issues (< 1 for the upsample-folded decoder launches).  tag: sub-family of the launch ('enc_fwd' =
-        forward ComplexConv2d of the encoder stack, the layers BASELINE.json's target names), summed separately as well."""
+        forward ComplexConv2d of the encoder stack, the layers BASELINE.json's target names), summed separately as well.
+        emulated: the launch multiplies on the bf16 MFMA (six bf16 MFMA flops per fp32 flop) instead of the fp32 MFMA."""
         if not self.active:
             return None
         j = self._seq
         self._seq += 1
-        self.flops_by_seq[j] = (flops, executed, tag)
+        self.flops_by_seq[j] = (flops, executed, tag, bool(emulated))
         if (j + self._step) % self.stride:
             return None
         from dcsnet import _lib
@@ -105,17 +106,20 @@ class ConvTimer:
         return self._ms
 
     def _median_ms(self, pred):
-        """Per step: sum over the selected launches of the median of their timed samples; (ms, launches, flops, executed)."""
-        ms = fl = ex = 0.0
+        """Per step: sum over the selected launches of the median of their timed samples; (ms, launches, flops, executed,
+        pipe_ms).  pipe_ms: the time the MFMA pipes need at their dense peak for the instructions the launches issue —
+        executed fp32 flops at the fp32 MFMA peak, or six bf16 flops per fp32 flop at the bf16 peak for emulated launches."""
+        ms = fl = ex = pipe = 0.0
         n = 0
         for j, d in sorted(self._read().items()):
-            f, e, tag = self.flops_by_seq[j]
+            f, e, tag, emu = self.flops_by_seq[j]
             if pred(tag):
                 ms += sorted(d)[len(d) // 2]
                 fl += f
                 ex += f * e
+                pipe += (6.0 * f * e / (PEAK_BF16_MFMA_TFLOPS * 1e12) if emu else f * e / (PEAK_F32_MFMA_TFLOPS * 1e12)) * 1e3
                 n += 1
-        return ms, n, fl, ex
+        return ms, n, fl, ex, pipe
 
     def summary(self):
         return self._median_ms(lambda tag: True)
@@ -229,7 +233,16 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help='operand precision of the MFMA conv forward / data gradient (bf16 = BASELINE configs[4] mixed '
                          'precision; NOT the headline: the reference computes in fp32)')
+    ap.add_argument('--no-native-line', action='store_true',
+                    help='skip the second measurement with the native fp32 MFMA (default run, one GPU: a child process '
+                         'repeats the timed region with --f32-mfma native and its numbers are attached as "native_f32_mfma")')
+    ap.add_argument('--f32-mfma', default='bf16x6', choices=['native', 'bf16x6'],
+                    help='how the fp32 MFMA conv forward / data gradient multiplies (--dtype f32 only): native = '
+                         'v_mfma_f32_32x32x2_f32; bf16x6 = fp32 emulated on the bf16 MFMA (exact three-way bf16 splits of both '
+                         'operands, six cross products, fp32 accumulate: error vs fp64 no larger than the native instruction\'s, '
+                         'profiles/*conv_precision.txt)')
     args = ap.parse_args()
+    conv_mode = args.dtype if args.dtype != 'f32' else ('f32' if args.f32_mfma == 'native' else 'bf16x6')
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -256,7 +269,7 @@ def main():
     from dcsnet.c_network import C_NETWORK
     from dcsnet import functional as F
     _lib.load()
-    ops.set_conv_precision(args.dtype)
+    ops.set_conv_precision(conv_mode)
 
     def log(msg):
         if rank == 0:
@@ -383,8 +396,10 @@ def main():
     log(f'timed region done: {dt / args.steps * 1e3:.2f} ms/step')
     if rank == 0:
         frames = B * T * world * args.steps
-        conv_ms, n_launch, conv_flops, conv_exec = timer.summary()          # per step
-        # dense MFMA peak of the operand type (bf16 mode: forward / data gradient on bf16 MFMA, weight gradients still fp32)
+        conv_ms, n_launch, conv_flops, conv_exec, conv_pipe_ms = timer.summary()          # per step
+        # dense MFMA peak of the dtype (bf16 mode: forward / data gradient on bf16 MFMA, weight gradients still fp32).  With
+        # --f32-mfma bf16x6 the dtype is still f32 (fp32 in, fp32 out, fp32 accumulation, products exact to 2^-24) and
+        # `frac` stays relative to the fp32 MFMA peak; what the instructions actually issued need is `executed_frac`
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         line = {
@@ -403,6 +418,11 @@ def main():
                        'world_seen': (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1),
                        'collective_backend': (dist.get_backend() if dist.is_available() and dist.is_initialized() else None),
                        'allreduce_ms_per_step': comm_ms, 'allreduce_bytes': (4 * (ts.bucket.numel + 4) if train else 0),
+                       'f32_mfma': (None if args.dtype != 'f32' else
+                                    'native: v_mfma_f32_32x32x2_f32' if conv_mode == 'f32' else
+                                    'bf16x6: conv forward / data gradient emulate fp32 on v_mfma_f32_32x32x16_bf16 (exact 3-way '
+                                    'bf16 split of both operands, 6 cross products, fp32 accumulate; error vs fp64 below the native '
+                                    'MFMA\'s: profiles/*conv_precision.txt); weight gradients and the 8-channel layers on the native fp32 MFMA'),
                        'per_gpu_batch': B, 'frames_per_utterance': T, 'global_batch': B * world,
                        'frames_per_step': B * T * world, 'hip_graph': bool(graphed), 'parallelism': (f'dp{world} (utterance sharding, one flat-bucket gradient all-reduce)' if train
                                        else f'dp{world} (utterance sharding, no collective)')},
@@ -427,10 +447,13 @@ def main():
                          # reference's taps (same result), so their algorithmic rate can exceed the MFMA peak; this one cannot
                          'executed_gflop_per_step': conv_exec / 1e9,
                          'executed_achieved': (conv_exec / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0),
-                         'executed_frac': (conv_exec / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0)},
+                         # share of the launches' time that the MFMA pipes need at their dense peak for the instructions
+                         # actually issued: executed fp32 flops at 157.3 TFLOP/s on the native path, six bf16 MFMA flops per
+                         # fp32 flop at 2500 TFLOP/s on the emulated one
+                         'executed_frac': (conv_pipe_ms / conv_ms if conv_ms > 0 else 0.0)},
         }
         # BASELINE.json's target names the ComplexConv2d ENCODER stack: its forward launches on their own (same pass)
-        e_ms, e_n, e_fl, _ = timer.tag_summary('enc_fwd')
+        e_ms, e_n, e_fl, _, _ = timer.tag_summary('enc_fwd')
         if e_ms > 0:
             e_tf = e_fl / (e_ms * 1e-3) / 1e12
             line['roofline']['encoder_stack_forward'] = {'achieved': e_tf, 'frac': e_tf / peak, 'unit': 'TFLOP/s',
@@ -443,6 +466,25 @@ def main():
             line['cpu_baseline'] = cpu_baseline_train(B, T) if train else cpu_baseline(T)
         else:
             line['cpu_baseline'] = None
+        line['native_f32_mfma'] = None
+        if world == 1 and args.dtype == 'f32' and conv_mode == 'bf16x6' and not args.no_native_line:
+            # the same timed region on the native fp32 MFMA, in a child process (its own graph, plans and packed panels)
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), '--mode', args.mode, '--steps', str(args.steps), '--warmup',
+                   str(args.warmup), '--f32-mfma', 'native', '--no-cpu-baseline', '--no-native-line']
+            cmd += (['--batch', str(args.batch)] if args.batch else []) + (['--frames', str(args.frames)] if args.frames else [])
+            cmd += ['--no-graph'] if args.no_graph else []
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                nat = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+                enc = nat['roofline'].get('encoder_stack_forward') or {}
+                line['native_f32_mfma'] = {'value': nat['value'], 'ms_per_step': nat['ms_per_step'],
+                                           'roofline_frac': nat['roofline']['frac'],
+                                           'executed_frac': nat['roofline']['executed_frac'],
+                                           'encoder_stack_forward_frac': enc.get('frac'),
+                                           'kernel_ms_per_step': nat['roofline']['kernel_ms_per_step']}
+            except Exception as e:                              # the headline line must not depend on the second run
+                line['native_f32_mfma'] = {'error': repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -44,9 +44,18 @@ __device__ __forceinline__ float2 gather(const Args& a, int b, int vy, int vx, i
 // MFMA eligibility of a (Cin, Cout) pair: K groups of 4 complex input channels staged 8 at a time,
 // N = 2*Cout real columns in tiles of 32 (a 16-wide remainder is zero-padded).
 inline bool mfma_ok(int Cin, int Cout) { return (Cin % 8) == 0 && (Cout % 8) == 0; }
+// precision mode of the MFMA forward / data-gradient GEMM with K = 2*Cin: the bf16x6 emulation (mode 2) needs 16-channel
+// chunks to amortise its per-iteration cost — 8-channel layers (enc1: the fp32 kernel runs a whole kernel row per
+// iteration there) stay on the fp32 MFMA.  Decides the panel layout (pack) and the kernel (launch) alike.
+inline int mfma_precision(int Cin) {
+    const int p = dcs_conv_precision();
+    return (p == 2 && (Cin % 16) != 0) ? 0 : p;
+}
 inline long direct_floats(int Cout, int Cin, int taps) { return (long)taps * Cin * Cout * 2; }
 inline long mfma_floats(int Cout, int Cin, int taps) {      // N = 2*Cout padded to whole 32-column tiles
-    return mfma_ok(Cin, Cout) ? (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 256 : 0;
+    // (precision mode 2 keeps three bf16 planes, each half an fp32 panel: 1.5 x)
+    const long n = mfma_ok(Cin, Cout) ? (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 256 : 0;
+    return dcs_conv_precision() == 2 ? n + n / 2 : n;
 }
 
 // conv_pack.hip: derived panels (upsample fold, its data gradient, strided data gradient)

@@ -21,6 +21,7 @@
 #include "conv_common.h"
 #include "pack_jobs.h"
 #include "conv_mfma_args.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -48,13 +49,21 @@ long long* g_fdbg = nullptr;
 // activations to bf16 on their way into LDS (half the patch), the B panel holds bf16 fragments, and one
 // v_mfma_f32_32x32x16_bf16 covers what eight fp32 MFMAs cover (8 complex channels of one tap).  Measured in float
 // units the fragment addresses are the same as in the fp32 form: a 16-byte read per lane either way.
+// PR = 2: fp32 emulated on the bf16 MFMA ("bf16x6").  Every fp32 operand is split EXACTLY into three bf16 terms
+// x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1: 8 + 8 + 8 significand bits); of the nine cross
+// products of a*b the six with i + j <= 2 are accumulated in fp32 (each bf16 x bf16 product is exact in fp32), smallest
+// terms first.  The dropped terms are below 3 * 2^-24 |a||b|, the size of one fp32 rounding of the product; six
+// v_mfma_f32_32x32x16_bf16 cover what eight v_mfma_f32_32x32x2_f32 cover at 192 instead of 512 MFMA cycles.  The patch holds
+// three bf16 planes per pixel (CH words each), the B panel three planes of bf16 fragments (packjob::MFMA, flag 3).
 // TPI > 1 (shallow layers, CH = 8: only U = 2 k-groups per tap): the tap loop advances a whole kernel ROW of TPI = kw taps
 // per iteration — 8 MFMAs per iteration cannot carry the loop's scalar address arithmetic, its waitcnt drain and the
 // B-set copy (enc1 forward: 7 x 2 = 14 k-groups = 56 MFMAs per iteration instead of 8).
-template <int WAVES_N, int WM, int WN, int CH, bool BF, int TPI = 1>
+template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI = 1>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
+    constexpr bool BF = PR != 0;
+    constexpr int NP = PR == 2 ? 3 : 1;                                // bf16 planes per operand
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
-    constexpr int U = BF ? CH / 8 : CH / 4, VU = U * TPI, PIX = BF ? CH + 4 : 2 * CH + 4, Q = CH / 2;
+    constexpr int U = BF ? CH / 8 : CH / 4, VU = U * TPI, PIX = BF ? NP * CH + 4 : 2 * CH + 4, Q = CH / 2;
     const conv::Args& a = m.c;
     const conv::Cls& k = m.cls[blockIdx.z];
     // pixels per workgroup = (4 / WAVES_N) * WM * 32 = TH * TW
@@ -85,6 +94,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     }
     const float* bbase = m.bm + k.bm_off + ((long)nt0 * 64 + lane) * 4;
     const long b_tap_stride = (long)(BF ? m.KG / 2 : m.KG) * m.NT * 256, b_kg_stride = (long)m.NT * 256;
+    const long b_plane_stride = (long)(k.kh * k.kw) * b_tap_stride;    // (PR = 2: planes of this class's panel)
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -102,21 +112,23 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     // which nobody consumes): the tap loop body stays free of branches, so s_waitcnt counts stay exact instead of
     // draining to zero at every loop header.
     // vg: k-group index inside an iteration = (tap offset vg / U, k-group vg % U)
-    auto bload = [&](float4* dst, int c, int tp, int vg) {
+    auto bload = [&](float4 (*dst)[WN], int c, int tp, int vg) {
         tp += vg / U;
         const int g = vg % U;
         if (tp >= ntaps) { tp -= ntaps; ++c; }
         c = c < n_chunks ? c : n_chunks - 1;
         const float* bp = bbase + tp * b_tap_stride + (long)(c * U + g) * b_kg_stride;
 #pragma unroll
-        for (int j = 0; j < WN; ++j) dst[j] = *reinterpret_cast<const float4*>(bp + j * 256);
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) dst[pl][j] = *reinterpret_cast<const float4*>(bp + pl * b_plane_stride + j * 256);
     };
     // B fragments of one whole tap (U k-groups) live in registers; the NEXT tap's are fetched during the first half of
     // this tap's k-groups (two per group) into a second set and moved over at the end of the tap.  The compiler drains
     // vmcnt to zero at every loop header (it cannot carry partial counts across the back edge): with the loads at the
     // front of the body that drain finds them >= U/2 groups (>= 512 MFMA cycles) old instead of just issued.
     constexpr int LPG = VU >= 2 ? 2 : 1;
-    float4 bcur[VU][WN], bnxt[VU][WN];
+    float4 bcur[VU][NP][WN], bnxt[VU][NP][WN];
 #pragma unroll
     for (int g = 0; g < VU; ++g) bload(bcur[g], c_begin, 0, g);
 
@@ -160,7 +172,17 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
             for (int u = 0; u < GU; ++u) {
                 const int idx = base + u * 256;
                 if (idx >= nslots) continue;
-                if (BF) {                                              // 2 complex -> 4 bf16 (round to nearest even)
+                if (PR == 2) {                                         // 2 complex -> 3 planes of 4 bf16 (exact split)
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    float4 r = v[u];
+                    float* dst = patch + (idx / Q) * PIX + (idx % Q) * 2;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const bf16x4 h = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
+                        *reinterpret_cast<bf16x4*>(dst + pl * CH) = h;
+                        r.x -= (float)h[0]; r.y -= (float)h[1]; r.z -= (float)h[2]; r.w -= (float)h[3];
+                    }
+                } else if (BF) {                                       // 2 complex -> 4 bf16 (round to nearest even)
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     const bf16x4 h = {(__bf16)v[u].x, (__bf16)v[u].y, (__bf16)v[u].z, (__bf16)v[u].w};
                     *reinterpret_cast<bf16x4*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = h;
@@ -172,9 +194,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         __syncthreads();
         const long long g1 = FDIAG_NOW();
         d_gather += g1 - g0;
-        float4 af[2][WM];
+        float4 af[2][NP][WM];
 #pragma unroll
-        for (int i = 0; i < WM; ++i) af[0][i] = *reinterpret_cast<const float4*>(patch + pixoff[i]);
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + pl * CH);
         int tapoff = 0;                                                // LDS float offset of the current tap
         for (int tap = 0; tap < ntaps; tap += TPI) {
             const int tap2 = tap + TPI < ntaps ? tap + TPI : tap;      // clamped: the last prefetch re-reads this tap
@@ -183,16 +207,25 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
             for (int g = 0; g < VU; ++g) {
                 // A fragments of the next iteration into the other register set (taps of a row are adjacent patch columns)
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
-                    af[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(
-                        patch + pixoff[i] + (g + 1 < VU ? tapoff + ((g + 1) / U) * PIX + ((g + 1) % U) * 8 : tapoff2));
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+                        af[(g + 1) & 1][pl][i] = *reinterpret_cast<const float4*>(
+                            patch + pixoff[i] + pl * CH + (g + 1 < VU ? tapoff + ((g + 1) / U) * PIX + ((g + 1) % U) * 8 : tapoff2));
                 // MFMAs straight from the ring slot ...
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        const float4 av = af[g & 1][i], bv = bcur[g][j];
-                        if (BF) {
+                        const float4 av = af[g & 1][0][i], bv = bcur[g][0][j];
+                        if (PR == 2) {                                  // a0 b2, a1 b1, a2 b0, a0 b1, a1 b0, a0 b0
+                            constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                            for (int e = 0; e < 6; ++e)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    __builtin_bit_cast(bf16x8, af[g & 1][pa[e] < NP ? pa[e] : 0][i]),
+                                    __builtin_bit_cast(bf16x8, bcur[g][pb[e] < NP ? pb[e] : 0][j]), acc[i][j], 0, 0, 0);
+                        } else if (BF) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
                                                                                 __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
                         } else {
@@ -214,10 +247,14 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
             for (int g = 0; g < VU; ++g)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bcur[g][j] = bnxt[g][j];
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bcur[g][pl][j] = bnxt[g][pl][j];
             if (VU & 1) {                                               // odd U (bf16, CH = 8): the prefetch landed in set 1
 #pragma unroll
-                for (int i = 0; i < WM; ++i) af[0][i] = af[1][i];
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) af[0][pl][i] = af[1][pl][i];
             }
             tapoff = tapoff2;
         }
@@ -287,8 +324,18 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     if (a.coef) {
                         const float4 u = v;
-                        v.x = fmaf(q[0], u.x, fmaf(q[1], u.y, q[4])); v.y = fmaf(q[2], u.x, fmaf(q[3], u.y, q[5]));
-                        v.z = fmaf(q[6], u.z, fmaf(q[7], u.w, q[10])); v.w = fmaf(q[8], u.z, fmaf(q[9], u.w, q[11]));
+                        // Scalar FMAs, kept apart by empty asm statements: paired by the compiler into v_pk_fma_f32 with op_sel
+                        // (low half = q1 * u.y + q4 taking the HIGH half of the {u.x, u.y} pair) the low half sporadically
+                        // came out as q4 alone — 16 lanes (48..63) of one row at a time, ~300 of 4 M outputs, different ones
+                        // every run — in the instances built on the bf16 MFMA (PR = 2, 64x64 tile, CH = 16) with other
+                        // workgroups' MFMAs in flight on the CU; never seen beside the fp32 MFMA, gone with scalar FMAs.
+                        v.x = fmaf(q[0], u.x, fmaf(q[1], u.y, q[4]));
+                        asm volatile("" : "+v"(v.x));
+                        v.y = fmaf(q[2], u.x, fmaf(q[3], u.y, q[5]));
+                        asm volatile("" : "+v"(v.y));
+                        v.z = fmaf(q[6], u.z, fmaf(q[7], u.w, q[10]));
+                        asm volatile("" : "+v"(v.z));
+                        v.w = fmaf(q[8], u.z, fmaf(q[9], u.w, q[11]));
                     }
                     v.x = dcs_act(v.x, a.act); v.y = dcs_act(v.y, a.act); v.z = dcs_act(v.z, a.act); v.w = dcs_act(v.w, a.act);
                 }
@@ -472,15 +519,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 struct Plan { int cand, TH, TW, CH, S, cps; long blocks; bool pipe; };
 thread_local bool g_force_wide_panel = false;
 
-template <int WAVES_N, int WM, int WN, int CH, bool BF, int TPI>
+template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI>
 int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    size_t lds = (size_t)npix * ((BF ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
+    size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH + 4 : PR == 1 ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
     if (lds < 4 * 32 * 36 * sizeof(float)) lds = 4 * 32 * 36 * sizeof(float);        // the epilogue's four transpose tiles
 #ifdef DCS_FWD_ONE_PER_CU
     if (lds < 84 * 1024) lds = 84 * 1024;                                            // experiment: one workgroup per CU
 #endif
-    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, BF, TPI>;
+    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, PR, TPI>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
@@ -489,18 +536,22 @@ int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     return DCS_OK;
 }
 
-template <int WAVES_N, int WM, int WN, int CH, bool BF>
+template <int WAVES_N, int WM, int WN, int CH, int PR>
 int launch_bf(MArgs& m, long npix, hipStream_t stream) {
+    constexpr bool BF = PR != 0;
     // whole kernel rows per tap-loop iteration for the shallow fp32 layers (one class, 7-wide kernel, 128 x 32 tile)
     if (!BF && CH == 8 && WM == 1 && WN == 1 && m.ncls == 1 && m.cls[0].kw == 7 && (m.cls[0].kh * m.cls[0].kw) % 7 == 0)
-        return launch_tpi<WAVES_N, WM, WN, CH, BF, (!BF && CH == 8 && WM == 1 && WN == 1) ? 7 : 1>(m, npix, stream);
-    return launch_tpi<WAVES_N, WM, WN, CH, BF, 1>(m, npix, stream);
+        return launch_tpi<WAVES_N, WM, WN, CH, PR, (!BF && CH == 8 && WM == 1 && WN == 1) ? 7 : 1>(m, npix, stream);
+    return launch_tpi<WAVES_N, WM, WN, CH, PR, 1>(m, npix, stream);
 }
 
 template <int WAVES_N, int WM, int WN, int CH>
 int launch_ch(MArgs& m, long npix, hipStream_t stream) {
-    return dcs_conv_precision() == 1 ? launch_bf<WAVES_N, WM, WN, CH, true>(m, npix, stream)
-                                     : launch_bf<WAVES_N, WM, WN, CH, false>(m, npix, stream);
+    // (a caller-packed wide panel — the real-valued convs of DR-Net — is always in the fp32 fragment order)
+    const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(m.c.C1 + m.c.C2);
+    if (pr == 2) return launch_bf<WAVES_N, WM, WN, CH, 2>(m, npix, stream);
+    if (pr == 1) return launch_bf<WAVES_N, WM, WN, CH, 1>(m, npix, stream);
+    return launch_bf<WAVES_N, WM, WN, CH, 0>(m, npix, stream);
 }
 
 template <int WAVES_N, int WM, int WN>
@@ -606,10 +657,13 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
             if (dcs_conv_pipe_eligible(a, ncls, cls, best, p->TH, p->TW, ch)) { p->CH = ch; p->pipe = true; }
         }
     }
+    // patch words per pixel at chunk depth ch: fp32 2 ch + 4; bf16 ch + 4; three bf16 planes 3 ch + 4
+    const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin);
+    auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
     if (p->pipe) {}
-    else if (Cin % 32 == 0 && npix * 68 * 4 <= 32 * 1024) p->CH = 32;
-    else if (Cin % 16 == 0 && npix * 36 * 4 <= cap16) p->CH = 16;
-    else if (npix * 20 * 4 <= 150 * 1024) p->CH = 8;
+    else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 32 * 1024) p->CH = 32;
+    else if (Cin % 16 == 0 && npix * pixw(16) * 4 <= cap16) p->CH = 16;
+    else if (npix * pixw(8) * 4 <= 150 * 1024) p->CH = 8;
     else return false;
     const int n_chunks = Cin / p->CH;
     if (2 * a.Cout == 16) want_s = 1;                        // the 16-column kernel does not slice K
@@ -632,7 +686,10 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     if (2 * Cout == 16) {                                                // 16-column layout of cconv_mfma16_kernel (half the region)
         j.flag = 16;
         j.total = (long)taps * (Cin / 8) * 64;
-    } else if (dcs_conv_precision() == 1) {                              // bf16 fragments: [tap][kg8][nt][64 lanes][8 bf16]
+    } else if (conv::mfma_precision(Cin) == 2) {                         // three planes of bf16 fragments (exact split)
+        j.flag = 3;
+        j.total = 3L * taps * (Cin / 8) * ((2 * Cout + 31) / 32) * 64;
+    } else if (conv::mfma_precision(Cin) == 1) {                         // bf16 fragments: [tap][kg8][nt][64 lanes][8 bf16]
         j.flag = 2;
         j.total = (long)taps * (Cin / 8) * ((2 * Cout + 31) / 32) * 64;
     } else {
@@ -690,6 +747,11 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
                     (y2 != nullptr && (nsplit & 3)))) {
         m.ksplit = 1; m.cps = Cin / p.CH; m.part = nullptr;
     }
+    static const bool trace = getenv("DCS_MFMA_TRACE") != nullptr;        // diagnostic: the plan of every launch
+    if (trace)
+        fprintf(stderr, "[mfma] B %d in %dx%d C %d+%d -> %dx%d Cout %d k %dx%d ncls %d | cand %d tile %dx%d CH %d S %d/%d cps %d prec %d coef %d\n",
+                a.B, a.Hin, a.Win, a.C1, a.C2, a.Hout, a.Wout, a.Cout, a.kh, a.kw, ncls, p.cand, p.TH, p.TW, p.CH, m.ksplit, p.S,
+                m.cps, g_force_wide_panel ? 0 : conv::mfma_precision(Cin), a.coef != nullptr);
     if (m.N == 16 && p.cand == 3 && !g_force_wide_panel) {    // 128 pixels x 16 columns, v_mfma_f32_16x16x4_f32
         switch (p.CH) {
             case 32: return launch16_ch<32>(m, npix, stream);

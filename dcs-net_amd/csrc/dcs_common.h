@@ -101,5 +101,6 @@ static inline int dcs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // permitted while a stream is being captured into a hipGraph, and the eager warm-up steps have already made it.
 hipError_t dcs_ensure_dynamic_lds(const void* fn, size_t bytes);
 
-// 0: fp32 operands (default), 1: bf16 operands in the MFMA conv GEMMs (dcs_set_conv_precision)
+// 0: native fp32 MFMA, 1: bf16 operands, 2 (default): fp32 emulated by six bf16 MFMAs on exact three-way operand splits, in the
+// MFMA conv forward / data-gradient GEMMs (dcs_set_conv_precision)
 int dcs_conv_precision();

@@ -1,4 +1,5 @@
-// pack_jobs.hip — the weight re-layout kernels (one element per thread) behind a job table, and the pack plan.
+// pack_jobs.hip — the weight re-layout kernels (one element per thread, 32-bit index arithmetic: a 64-bit division
+// chain per element was most of these kernels) behind a job table, and the pack plan.
 //
 // The reference has no counterpart: cuDNN consumes the nn.Parameter layout directly (c_network.py:107-147).
 // Here the hot kernels read pre-packed panels (conv_direct.hip / conv_mfma.hip / conv_pack.hip), so a training
@@ -13,58 +14,58 @@
 namespace packjob {
 namespace {
 
-__device__ __forceinline__ void run_direct(const Job& j, long i) {
+__device__ __forceinline__ void run_direct(const Job& j, int i) {
     const float* w_r = (const float*)j.src0; const float* w_i = (const float*)j.src1;
     const float* b_r = (const float*)j.src2; const float* b_i = (const float*)j.src3;
     float2* wp = (float2*)j.dst0; float2* bias_out = (float2*)j.dst1;
     const int Cout = j.Cout, Cin = j.Cin, kh = j.kh, kw = j.kw;
-    const long n = (long)kh * kw * Cin * Cout;
+    const int n = kh * kw * Cin * Cout;
     if (i < Cout) {
         const float br = b_r ? b_r[i] : 0.f, bi = b_i ? b_i[i] : 0.f;
         bias_out[i] = make_float2(br - bi, br + bi);
     }
     if (i >= n) return;
-    const int co = (int)(i % Cout);
-    const int ci = (int)((i / Cout) % Cin);
-    const int tap = (int)(i / ((long)Cout * Cin));
+    const int co = i % Cout;
+    const int ci = (i / Cout) % Cin;
+    const int tap = i / (Cout * Cin);
     const int dy = tap / kw, dx = tap % kw;
-    long src;
+    int src;
     if (j.flag)       // ConvTranspose2d weight [Cin][Cout][kh][kw], flipped
-        src = (((long)ci * Cout + co) * kh + (kh - 1 - dy)) * kw + (kw - 1 - dx);
+        src = ((ci * Cout + co) * kh + (kh - 1 - dy)) * kw + (kw - 1 - dx);
     else              // Conv2d weight [Cout][Cin][kh][kw]
-        src = (((long)co * Cin + ci) * kh + dy) * kw + dx;
+        src = ((co * Cin + ci) * kh + dy) * kw + dx;
     wp[i] = make_float2(w_r[src], w_i[src]);
 }
 
 // wp_bwd[tap'][co][ci] = conj(wp[ntaps-1-tap'][ci][co])
-__device__ __forceinline__ void run_bwd(const Job& j, long i) {
+__device__ __forceinline__ void run_bwd(const Job& j, int i) {
     const float2* wp = (const float2*)j.src0; float2* wpb = (float2*)j.dst0;
     const int Cout = j.Cout, Cin = j.Cin, ntaps = j.kh;
-    const int ci = (int)(i % Cin);
-    const int co = (int)((i / Cin) % Cout);
-    const int tp = (int)(i / ((long)Cout * Cin));
-    const float2 v = wp[((long)(ntaps - 1 - tp) * Cin + ci) * Cout + co];
+    const int ci = i % Cin;
+    const int co = (i / Cin) % Cout;
+    const int tp = i / (Cout * Cin);
+    const float2 v = wp[((ntaps - 1 - tp) * Cin + ci) * Cout + co];
     wpb[i] = make_float2(v.x, -v.y);
 }
 
 // dst[(jy*nx + jx)][e'] = (conj?) sum_{dy in Y[jy]} sum_{dx in X[jx]} src[(dy*skw + dx)][e]
 // elements: src [A][B] complex per tap; swap -> dst [B][A] (in/out channel swap)
-__device__ __forceinline__ void run_fold(const Job& j, long i) {
+__device__ __forceinline__ void run_fold(const Job& j, int i) {
     const float2* src = (const float2*)j.src0; float2* dst = (float2*)j.dst0;
     const int A = j.Cout, Bc = j.Cin, skw = j.kw;
-    const long per = (long)A * Bc;
-    const long e = i % per;
-    const int tap = (int)(i / per);
+    const int per = A * Bc;
+    const int e = i % per;
+    const int tap = i / per;
     const int jy = tap / j.xn, jx = tap % j.xn;
-    long se = e;
+    int se = e;
     if (j.flag) {                          // dst element (b, a) <- src element (a, b)
-        const int b = (int)(e / A), a = (int)(e % A);
-        se = (long)a * Bc + b;
+        const int b = e / A, a = e % A;
+        se = a * Bc + b;
     }
     float sr = 0.f, si = 0.f;
     for (int dy = j.ylo[jy]; dy <= j.yhi[jy]; ++dy)
         for (int dx = j.xlo[jx]; dx <= j.xhi[jx]; ++dx) {
-            const float2 v = src[(long)(dy * skw + dx) * per + se];
+            const float2 v = src[(dy * skw + dx) * per + se];
             sr += v.x; si += v.y;
         }
     dst[i] = make_float2(sr, j.flag ? -si : si);
@@ -73,76 +74,83 @@ __device__ __forceinline__ void run_fold(const Job& j, long i) {
 // bm[tap][kg][nt][kk][j][e]: e = 0..3 -> (ci = 4kg+2kk, re), (.., im), (ci+1, re), (ci+1, im); column n = nt*32+j
 // N = 16 (flag == 16): bm[tap][kg8][lane][q]: lane = g*16 + col, real k index r = 4g + q of the 8-channel block kg8
 // (ci = 8 kg8 + r/2, re|im = r&1), column col = (co = col>>1, re|im = col&1)
-__device__ __forceinline__ void run_mfma16(const Job& jb, long i) {
+__device__ __forceinline__ void run_mfma16(const Job& jb, int i) {
     const float2* wp = (const float2*)jb.src0; float4* bm = (float4*)jb.dst0;
     const int Cout = jb.Cout, Cin = jb.Cin;
-    const int col = (int)(i & 15), g = (int)((i >> 4) & 3);
-    const long r = i >> 6;
-    const int kg8 = (int)(r % (Cin / 8)), tap = (int)(r / (Cin / 8));
+    const int col = i & 15, g = (i >> 4) & 3;
+    const int r = i >> 6;
+    const int kg8 = r % (Cin / 8), tap = r / (Cin / 8);
     const int co = col >> 1, im = col & 1;
     const int ci = 8 * kg8 + 2 * g;
-    const float2 w0 = wp[((long)tap * Cin + ci) * Cout + co], w1 = wp[((long)tap * Cin + ci + 1) * Cout + co];
+    const float2 w0 = wp[(tap * Cin + ci) * Cout + co], w1 = wp[(tap * Cin + ci + 1) * Cout + co];
     // k = (ci, re): [w_r | w_i];  k = (ci, im): [-w_i | w_r]  for columns (co, re) | (co, im)
     bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
 }
 
 // bf16 (flag == 2): bm[tap][kg8][nt][lane][8 bf16]: lane = 32h + j, element e = real k index 8h + e of the 8-channel block
 // (ci = 8 kg8 + 4h + e/2, re|im = e&1), column n = nt*32 + j — the A/B lane map of v_mfma_f32_32x32x16_bf16
-__device__ __forceinline__ void run_mfma_bf16(const Job& jb, long i) {
+__device__ __forceinline__ void run_mfma_bf16(const Job& jb, int i) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     const float2* wp = (const float2*)jb.src0; bf16x8* bm = (bf16x8*)jb.dst0;
     const int Cout = jb.Cout, Cin = jb.Cin;
     const int KG8 = Cin / 8, NT = (2 * Cout + 31) / 32;
-    const int j = (int)(i & 31), h = (int)((i >> 5) & 1);
-    long r = i >> 6;
-    const int nt = (int)(r % NT); r /= NT;
-    const int kg8 = (int)(r % KG8);
-    const int tap = (int)(r / KG8);
+    // flag == 3: three such panels in a row, plane pl holding the pl-th term of the exact split w = w0 + w1 + w2
+    // (w0 = bf16(w), w1 = bf16(w - w0), w2 = w - w0 - w1; ntaps = jb.kh)
+    const int per_plane = jb.kh * KG8 * NT * 64;
+    const int pl = jb.flag == 3 ? i / per_plane : 0;
+    const int ip = i - pl * per_plane;
+    const int j = ip & 31, h = (ip >> 5) & 1;
+    int r = ip >> 6;
+    const int nt = r % NT; r /= NT;
+    const int kg8 = r % KG8;
+    const int tap = r / KG8;
     const int n = nt * 32 + j, co = n >> 1, im = n & 1;
     bf16x8 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float2 w = make_float2(0.f, 0.f);
-        if (co < Cout) w = wp[((long)tap * Cin + 8 * kg8 + 4 * h + q) * Cout + co];
+        if (co < Cout) w = wp[(tap * Cin + 8 * kg8 + 4 * h + q) * Cout + co];
         // column (co, re): [ w_r, -w_i ] ; column (co, im): [ w_i, w_r ]   for k = (ci, re), (ci, im)
-        o[2 * q] = (__bf16)(im ? w.y : w.x);
-        o[2 * q + 1] = (__bf16)(im ? w.x : -w.y);
+        float e0 = im ? w.y : w.x, e1 = im ? w.x : -w.y;
+        for (int s_ = 0; s_ < pl; ++s_) { e0 -= (float)(__bf16)e0; e1 -= (float)(__bf16)e1; }
+        o[2 * q] = (__bf16)e0;
+        o[2 * q + 1] = (__bf16)e1;
     }
     bm[i] = o;
 }
 
-__device__ __forceinline__ void run_mfma(const Job& jb, long i) {
+__device__ __forceinline__ void run_mfma(const Job& jb, int i) {
     if (jb.flag == 16) { run_mfma16(jb, i); return; }
-    if (jb.flag == 2) { run_mfma_bf16(jb, i); return; }
+    if (jb.flag == 2 || jb.flag == 3) { run_mfma_bf16(jb, i); return; }
     const float2* wp = (const float2*)jb.src0; float4* bm = (float4*)jb.dst0;
     const int Cout = jb.Cout, Cin = jb.Cin;
     const int KG = Cin / 4, NT = (2 * Cout + 31) / 32;
-    const int j = (int)(i & 31), kk = (int)((i >> 5) & 1);
-    long r = i >> 6;
-    const int nt = (int)(r % NT); r /= NT;
-    const int kg = (int)(r % KG);
-    const int tap = (int)(r / KG);
+    const int j = i & 31, kk = (i >> 5) & 1;
+    int r = i >> 6;
+    const int nt = r % NT; r /= NT;
+    const int kg = r % KG;
+    const int tap = r / KG;
     const int n = nt * 32 + j, co = n >> 1, im = n & 1;
     if (co >= Cout) { bm[i] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
     const int ci = 4 * kg + 2 * kk;
-    const float2 w0 = wp[((long)tap * Cin + ci) * Cout + co], w1 = wp[((long)tap * Cin + ci + 1) * Cout + co];
+    const float2 w0 = wp[(tap * Cin + ci) * Cout + co], w1 = wp[(tap * Cin + ci + 1) * Cout + co];
     // column (co, re): [ w_r, -w_i ] ; column (co, im): [ w_i, w_r ]
     bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
 }
 
 // wp[0][ci][tap] = w[ci][0][kh-1-dy][kw-1-dx] (tap = dy*kw + dx), 0 for tap >= kh*kw; bias = 0.  Cout = ct columns.
-__device__ __forceinline__ void run_taprows(const Job& j, long i) {
+__device__ __forceinline__ void run_taprows(const Job& j, int i) {
     const float* w_r = (const float*)j.src0; const float* w_i = (const float*)j.src1;
     float2* wp = (float2*)j.dst0; float2* bias_out = (float2*)j.dst1;
     const int ct = j.Cout, taps = j.kh * j.kw;
     if (i < ct) bias_out[i] = make_float2(0.f, 0.f);
-    const int tap = (int)(i % ct), ci = (int)(i / ct);
+    const int tap = i % ct, ci = i / ct;
     float2 v = make_float2(0.f, 0.f);
-    if (tap < taps) { const long src = (long)ci * taps + (taps - 1 - tap); v = make_float2(w_r[src], w_i[src]); }
+    if (tap < taps) { const int src = ci * taps + (taps - 1 - tap); v = make_float2(w_r[src], w_i[src]); }
     wp[i] = v;
 }
 
-__device__ __forceinline__ void run(const Job& j, long i) {
+__device__ __forceinline__ void run(const Job& j, int i) {
     if (i >= j.total) return;
     switch (j.kind) {
         case DIRECT: run_direct(j, i); break;
@@ -153,7 +161,7 @@ __device__ __forceinline__ void run(const Job& j, long i) {
     }
 }
 
-__global__ __launch_bounds__(256) void pack_one_kernel(Job j) { run(j, (long)blockIdx.x * 256 + threadIdx.x); }
+__global__ __launch_bounds__(256) void pack_one_kernel(Job j) { run(j, (int)(blockIdx.x * 256 + threadIdx.x)); }
 
 // blk0[k] = first block of job k (ascending; blk0[nj] = grid size)
 __global__ __launch_bounds__(256) void pack_multi_kernel(const Job* __restrict__ jobs, const int* __restrict__ blk0, int nj) {
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const Job* __restrict__
         __syncthreads();
     }
     const int lo = s_lo;
-    run(jobs[lo], (long)(b - blk0[lo]) * 256 + threadIdx.x);
+    run(jobs[lo], (b - blk0[lo]) * 256 + (int)threadIdx.x);
 }
 
 struct Level { Job* d_jobs = nullptr; int* d_blk0 = nullptr; int nj = 0, nblocks = 0; };
@@ -207,7 +215,7 @@ void record(const Job& j) {
 }  // namespace
 
 int emit(const Job& j, hipStream_t s) {
-    if (j.total <= 0) return DCS_ERR_BADARG;
+    if (j.total <= 0 || j.total > 0x7fffff00L || j.dst_bytes > 0x7fffffffL * 4) return DCS_ERR_BADARG;   // 32-bit element indices
     {
         std::lock_guard<std::mutex> lock(g_rec_mutex);
         if (g_rec) record(j);

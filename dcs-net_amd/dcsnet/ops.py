@@ -36,10 +36,12 @@ _retired = []
 
 
 def set_conv_precision(mode):
-    """'f32' (default: exact fp32 MFMA) or 'bf16' (bf16 operands, fp32 accumulate, in the MFMA conv forward / data
-    gradient: dcs_set_conv_precision).  Every packed weight made under the other mode becomes invalid: the caches
+    """'bf16x6' (default: fp32 emulated on the bf16 MFMA — exact three-way bf16 splits of both operands, the six leading
+    cross products accumulated in fp32; product error < 2^-24, measured error against fp64 below the native
+    instruction's), 'f32' (native fp32 MFMA) or 'bf16' (bf16-rounded operands, fp32 accumulate: BASELINE configs[4]) in
+    the MFMA conv forward / data gradient (dcs_set_conv_precision).  Every packed weight made under the other mode becomes invalid: the caches
     are cleared here, a recorded pack plan must be re-recorded by its owner."""
-    code = {'f32': 0, 'fp32': 0, 'bf16': 1}[mode]
+    code = {'f32': 0, 'fp32': 0, 'bf16': 1, 'bf16x6': 2}[mode]
     check(_lib.load().dcs_set_conv_precision(code), 'dcs_set_conv_precision')
     from . import functional
     functional._pack_cache.clear()
@@ -57,7 +59,7 @@ def conv_schedule():
 
 
 def conv_precision():
-    return 'bf16' if _lib.load().dcs_get_conv_precision() == 1 else 'f32'
+    return ('f32', 'bf16', 'bf16x6')[_lib.load().dcs_get_conv_precision()]
 
 
 class PackPlan:
@@ -220,7 +222,8 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     # bench.py's live roofline probe: 8 real flops per complex MAC
     # (strided forward convs are exactly the encoder's ComplexConv2d stack: tagged for bench.py's encoder roofline)
     ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None,
-                           executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up))
+                           executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
+                           emulated=_emulated(C1 + C2, Cout) and C1 % 2 == 0)
           if CONV_TIMER is not None else None)
     if coef is not None:
         _chk(coef, 'coef', 2)
@@ -232,6 +235,12 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     if ev is not None:
         CONV_TIMER.end(ev)
     return y
+
+
+def _emulated(k_channels, n_channels):
+    """Whether the MFMA GEMM with K = 2 * k_channels, N = 2 * n_channels runs on the bf16 MFMA in fp32-emulation mode
+    (conv::mfma_precision, conv_mfma.hip: 16-channel chunks, 32-column tiles) — for bench.py's instruction accounting."""
+    return (conv_precision() == 'bf16x6' and k_channels % 16 == 0 and n_channels % 8 == 0 and 2 * n_channels != 16)
 
 
 def _fold_fraction(C1, Cin, Cout, ksize, stride, pad, up):
@@ -287,7 +296,8 @@ def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=Non
         raise _lib.DcsHipError(f'cconv2d_bwd_data: unsupported geometry {geo}')
     ws = _workspace(nbytes, gy.device) if nbytes else None
     ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * Cin * ksize[0] * ksize[1],
-                           executed=_fold_fraction(C1, Cin, Cout, ksize, stride, pad, up)) if CONV_TIMER is not None else None)
+                           executed=_fold_fraction(C1, Cin, Cout, ksize, stride, pad, up), emulated=_emulated(Cout, Cin))
+          if CONV_TIMER is not None else None)
     check(lib.dcs_cconv2d_bwd_data(ptr(gy), ptr(wp_bwd), ptr(gx1), ptr(gx2), ptr(ws), ws.numel() if ws is not None else 0,
                                    *geo, cur_stream()), 'dcs_cconv2d_bwd_data')
     if ev is not None:

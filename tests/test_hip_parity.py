@@ -477,14 +477,15 @@ def test_bf16_operand_mode_of_the_mfma_conv(dev):
         want_f32 = m(x)
     p = {n: q.detach().to(dev) for n, q in m.named_parameters()}
     xn = ops.to_nhwc(x.to(dev))
-    assert ops.conv_precision() == 'f32'
+    default = ops.conv_precision()
+    assert default in ('f32', 'bf16x6')                # the library default, or DCS_CONV_PRECISION=0 for a native-MFMA run
     try:
         ops.set_conv_precision('bf16')
         assert ops.conv_precision() == 'bf16'
         y = F.from_nhwc(F.cconv2d(xn, None, p['conv_r.weight'], p['conv_i.weight'], p['conv_r.bias'], p['conv_i.bias'],
                                   False, (3, 3), (2, 1), (1, 1))).cpu()
     finally:
-        ops.set_conv_precision('f32')
+        ops.set_conv_precision(default)
     scale = float(want_f32.abs().max())
     assert float((y - want_exact).abs().max()) <= 2e-5 * scale
     err = float((y - want_f32).abs().max())
@@ -516,6 +517,7 @@ def test_bf16_mode_whole_network_and_gradients(dev):
     out_r = ref(x)
     w = torch.rand(out_r.shape, generator=torch.Generator().manual_seed(2))
     loss_of(out_r, w).backward()
+    default = ops.conv_precision()
     try:
         ops.set_conv_precision('bf16')
         net = fill_state(C_NETWORK(config, hp, 0), 6).to(dev)
@@ -527,7 +529,7 @@ def test_bf16_mode_whole_network_and_gradients(dev):
         loss_of(out, w.to(dev)).backward()
         grads = {n: p.grad.detach().cpu() for n, p in net.named_parameters() if p.grad is not None}
     finally:
-        ops.set_conv_precision('f32')
+        ops.set_conv_precision(default)
     e_mask = rel_l2(got_train, mask_train)
     pr = dict(ref.named_parameters())
     num = sum(float((g - pr[n].grad).pow(2).sum()) for n, g in grads.items()) ** 0.5
@@ -735,3 +737,78 @@ def test_pipelined_conv_schedule_is_bit_identical(dev, cin, c2, cout, k, stride,
     for a, b in zip(res['classic'], res['pipe']):
         assert (a is None and b is None) or torch.equal(a, b)
     close(res['pipe'][0], res['classic'][0], rel=0, abs_=0)
+
+
+def _conv_fp64(x, w_r, w_i, b_r, b_i, stride, pad, gy):
+    """fp64 complex conv of channels-last x [B,H,W,C,2] with the two-real-layer bias convention of complexPyTorch
+    (re: b_r - b_i, im: b_r + b_i) and its gradient with respect to x for the cotangent gy."""
+    import torch.nn.functional as tF
+    x64 = x.double().cpu().requires_grad_(True)
+    xr, xi = x64[..., 0].permute(0, 3, 1, 2), x64[..., 1].permute(0, 3, 1, 2)
+    wr, wi = w_r.double().cpu(), w_i.double().cpu()
+    c = lambda a, w: tF.conv2d(a, w, None, stride, pad)
+    yr = c(xr, wr) - c(xi, wi) + (b_r - b_i).double().cpu()[None, :, None, None]
+    yi = c(xi, wr) + c(xr, wi) + (b_r + b_i).double().cpu()[None, :, None, None]
+    y = torch.stack((yr, yi), -1).permute(0, 2, 3, 1, 4)
+    (y * gy.double().cpu()).sum().backward()
+    return y.detach(), x64.grad
+
+
+@pytest.mark.parametrize('geom', [(4, 16, 32, 64, 128, 3, (2, 1)), (2, 48, 40, 16, 32, 5, (2, 2)), (2, 8, 32, 128, 128, 3, (1, 1))])
+def test_f32_emulation_on_the_bf16_mfma_is_at_least_as_accurate_as_the_native_mfma(dev, geom):
+    """Precision mode 'bf16x6' (the default): every fp32 operand split exactly into three bf16 terms, six bf16 MFMAs per
+    product group, fp32 accumulation (conv_mfma.hip, PR = 2).  Criterion: distance to an fp64 evaluation, forward and
+    data gradient — no larger than the native v_mfma_f32_32x32x2_f32's own distance (+25 % slack for the sample), and
+    both at fp32 rounding level (1e-6 of the output's max-abs)."""
+    from dcsnet import ops
+    B, H, W, Cin, Cout, k, st = geom
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, Cin, 2, generator=g).to(dev)
+    w_r, w_i = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).to(dev), (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).to(dev)
+    b_r, b_i = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+    pad = (k // 2, k // 2)
+    Ho, Wo = (H + 2 * pad[0] - k) // st[0] + 1, (W + 2 * pad[1] - k) // st[1] + 1
+    gy = torch.randn(B, Ho, Wo, Cout, 2, generator=g).to(dev)
+    y64, gx64 = _conv_fp64(x, w_r, w_i, b_r, b_i, st, pad, gy)
+    default = ops.conv_precision()
+    err = {}
+    try:
+        for mode in ('f32', 'bf16x6'):
+            ops.set_conv_precision(mode)
+            wp, bias = ops.pack_conv_weight(w_r, w_i, b_r, b_i, False, (1, 1))
+            y = ops.cconv2d(x, None, wp, bias, (k, k), st, pad, (1, 1))
+            wpb = ops.pack_conv_weight_bwd(wp, (k, k), st, pad, (1, 1))
+            gx = ops.cconv2d_bwd_data(gy, wpb, (H, W, Cin), (k, k), st, pad, (1, 1), Cin)[0]
+            err[mode] = (float((y.double().cpu() - y64).norm() / y64.norm()), float((gx.double().cpu() - gx64).norm() / gx64.norm()),
+                         float((y.double().cpu() - y64).abs().max() / y64.abs().max()))
+    finally:
+        ops.set_conv_precision(default)
+    assert err['bf16x6'][0] <= 1.25 * err['f32'][0] and err['bf16x6'][1] <= 1.25 * err['f32'][1], err
+    assert err['bf16x6'][2] <= 1e-6 and err['f32'][2] <= 1e-6, err
+
+
+def test_folded_cbn_epilogue_under_co_resident_bf16_mfma_workgroups(dev):
+    """The enc5 forward at the inference bench shape [16,8,250,128] -> 128 with folded eval-mode CBN coefficients, in
+    both fp32 modes: the epilogue's affine map used to come out without its q1 * im term in ~300 of 4 M outputs when
+    the compiler paired its FMAs into v_pk_fma_f32 and other workgroups' bf16 MFMAs were in flight (conv_mfma.hip
+    epilogue comment) — the two modes must agree to rounding everywhere."""
+    from dcsnet import ops, functional as F
+    g = torch.Generator().manual_seed(9)
+    B, H, W, C, k, st = 16, 8, 250, 128, 3, (2, 1)
+    x = torch.randn(B, H, W, C, 2, generator=g).to(dev)
+    w_r, w_i = (torch.randn(C, C, k, k, generator=g) * 0.05).to(dev), (torch.randn(C, C, k, k, generator=g) * 0.05).to(dev)
+    b_r, b_i = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    coef = torch.randn(C, 6, generator=g).to(dev)
+    default = ops.conv_precision()
+    out = {}
+    try:
+        for mode in ('f32', 'bf16x6'):
+            ops.set_conv_precision(mode)
+            wp, bias = ops.pack_conv_weight(w_r, w_i, b_r, b_i, False, (1, 1))
+            out[mode] = [ops.cconv2d(x, None, wp, bias, (k, k), st, (1, 1), (1, 1), F.ACT_RELU, coef=coef) for _ in range(3)]
+    finally:
+        ops.set_conv_precision(default)
+    scale = float(out['f32'][0].abs().max())
+    for a in out['bf16x6']:
+        assert torch.equal(a, out['bf16x6'][0])                       # run-to-run identical
+        assert float((a - out['f32'][0]).abs().max()) <= 2e-5 * scale

@@ -1,5 +1,5 @@
 """Per-layer timing of the complex conv kernels (forward, data gradient, weight gradient) at the network's
-shapes.  usage: python tools/conv_layers_bench.py [B] [T]"""
+shapes.  usage: python tools/conv_layers_bench.py [B] [T] [f32|bf16]"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'dcs-net_amd'))
@@ -8,6 +8,8 @@ from dcsnet import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device('cuda:0')
+if len(sys.argv) > 3:  # f32 | bf16 | bf16x6
+    ops.set_conv_precision(sys.argv[3])
 # name, Hin, Win, C1, C2, Cout, k, stride, up, transposed
 t8 = T // 8
 L = [('enc0', 256, T, 1, 0, 8, 7, (2, 2), (1, 1)), ('enc1', 128, T // 2, 8, 0, 16, 7, (2, 2), (1, 1)),
