@@ -604,11 +604,19 @@ int dcs_pack_tap_rows(const float* w_r, const float* w_i, float* wp, float* bias
 int dcs_tap_rows_wgrad_scatter(const float* gt_r, const float* gt_i, float* gw_r, float* gw_i, int Cin, int kh, int kw,
                                int accumulate, dcs_stream_t stream);
 
-/* Operand precision of the MFMA convolution GEMMs (forward and data gradient; BASELINE configs[4] "bf16 mixed
- * precision"): 0 = fp32 operands (default, exact fp32), 1 = bf16 operands (activations rounded to nearest-even on
- * their way into LDS, weights rounded at pack time), fp32 accumulate, fp32 storage everywhere.  Weight gradients,
- * the 16-column and the small-channel kernels stay fp32.  Process-wide; weights packed under one mode are only valid
- * under that mode (the caller re-packs after switching). */
+/* Arithmetic of the MFMA convolution GEMMs (forward and data gradient).  fp32 storage and fp32 accumulation in every mode.
+ *   2 (default)  fp32 EMULATED on the bf16 MFMA: each fp32 operand is split exactly into three bf16 terms
+ *                (x = x0 + x1 + x2, 8 + 8 + 8 significand bits; activations on their way into LDS, weights at pack time)
+ *                and the six cross products x_i w_j with i + j <= 2 are accumulated (each exact in fp32); the dropped
+ *                terms are below 2^-24 |x w|.  Measured against an fp64 reference the result is closer than the native
+ *                fp32 MFMA's (tests/test_hip_parity.py::test_f32_emulation_..., tools/conv_precision_check.py), at
+ *                6 x 32 instead of 8 x 64 MFMA cycles per 16 k-values.  Layers with 8-channel chunks stay on mode 0.
+ *   0            native v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain).
+ *   1            bf16 operands (BASELINE configs[4] "bf16 mixed precision"): activations rounded to nearest-even on
+ *                their way into LDS, weights rounded at pack time — a genuine bf16 computation (2^-8 operand error).
+ * Weight gradients, the 16-column and the small-channel kernels are native fp32 in every mode.  Process-wide (the
+ * environment variable DCS_CONV_PRECISION presets it); the packed panel layout and size depend on the mode, so weights
+ * packed under one mode are only valid under that mode (the caller re-packs after switching). */
 int dcs_set_conv_precision(int mode);
 int dcs_get_conv_precision(void);
 

@@ -9,18 +9,18 @@ echo "[collect] bench train (default flags)"; timeout -k 10 400 python3 $R/bench
 echo "[collect] bench infer"; timeout -k 10 400 python3 $R/bench.py --mode infer > $out/bench_infer.json 2> $out/bench_infer.log
 for mode in train infer; do
   echo "[collect] kernel stats $mode"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$mode -- python3 $R/bench.py --mode $mode --no-cpu-baseline > $out/stats_$mode.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$mode -- python3 $R/bench.py --mode $mode --no-cpu-baseline --no-native-line > $out/stats_$mode.log 2>&1
   cp $(find $out/stats_$mode -name "*kernel_stats.csv" | head -1) $out/${mode}_kernel_stats.csv
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "[collect] pmc $c $mode"
-    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${mode}_$c -- python3 $R/bench.py --mode $mode --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_${mode}_$c.log 2>&1
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${mode}_$c -- python3 $R/bench.py --mode $mode --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-native-line > $out/pmc_${mode}_$c.log 2>&1
     cp $(find $out/pmc_${mode}_$c -name "*counter_collection.csv" | head -1) $out/pmc_${mode}_$c.csv
   done
   rm -rf $out/stats_$mode $out/pmc_${mode}_FETCH_SIZE $out/pmc_${mode}_WRITE_SIZE
 done
 for mode in train infer; do
   echo "[collect] pmc MFMA utilisation $mode"
-  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $out/pmc_${mode}_mfma -- python3 $R/bench.py --mode $mode --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_${mode}_mfma.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $out/pmc_${mode}_mfma -- python3 $R/bench.py --mode $mode --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-native-line > $out/pmc_${mode}_mfma.log 2>&1
   cp $(find $out/pmc_${mode}_mfma -name "*counter_collection.csv" | head -1) $out/pmc_${mode}_mfma.csv
   rm -rf $out/pmc_${mode}_mfma
 done
@@ -30,11 +30,21 @@ hipcc -O3 --offload-arch=gfx950 $R/tools/micro/dma_rate.hip -o /tmp/dma_rate 2>/
 timeout -k 10 300 python3 $R/tools/conv_ab.py 32 256 5 > $out/conv_ab_train.txt 2>/dev/null
 timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 32 256 > $out/conv_layers_train.txt 2>/dev/null
 timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 16 2000 > $out/conv_layers_infer.txt 2>/dev/null
+timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 32 256 f32 > $out/conv_layers_train_native.txt 2>/dev/null
+timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 16 2000 f32 > $out/conv_layers_infer_native.txt 2>/dev/null
+echo "[collect] error of the three conv arithmetic modes against fp64"
+timeout -k 10 300 python3 $R/tools/conv_precision_check.py > $out/conv_precision.txt 2>/dev/null
+echo "[collect] kernel stats with the native fp32 MFMA (comparison)"
+for mode in train infer; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_native_$mode -- python3 $R/bench.py --mode $mode --f32-mfma native --no-cpu-baseline --no-native-line > $out/stats_native_$mode.log 2>&1
+  cp $(find $out/stats_native_$mode -name "*kernel_stats.csv" | head -1) $out/${mode}_native_kernel_stats.csv
+  rm -rf $out/stats_native_$mode
+done
 timeout -k 10 120 python3 $R/tools/lstm_bench.py > $out/lstm_bench.txt 2>/dev/null
 echo "[collect] kernel sequence of one replayed train step / inference pass"
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/kt_train -- python3 $R/bench.py --no-cpu-baseline --steps 4 --warmup 2 > $out/kt_train.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/kt_train -- python3 $R/bench.py --no-cpu-baseline --no-native-line --steps 4 --warmup 2 > $out/kt_train.log 2>&1
 python3 $R/tools/step_sequence.py $(find $out/kt_train -name "*kernel_trace.csv" | head -1) 6 > $out/step_sequence_train.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/kt_infer -- python3 $R/bench.py --mode infer --no-cpu-baseline --steps 4 --warmup 2 > $out/kt_infer.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/kt_infer -- python3 $R/bench.py --mode infer --no-cpu-baseline --no-native-line --steps 4 --warmup 2 > $out/kt_infer.log 2>&1
 python3 $R/tools/infer_sequence.py $(find $out/kt_infer -name "*kernel_trace.csv" | head -1) > $out/step_sequence_infer.txt
 rm -rf $out/kt_train $out/kt_infer
 echo "[collect] done"; ls -la $out
