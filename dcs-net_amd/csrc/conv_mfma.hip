@@ -657,11 +657,12 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
             if (dcs_conv_pipe_eligible(a, ncls, cls, best, p->TH, p->TW, ch)) { p->CH = ch; p->pipe = true; }
         }
     }
+    static const long cap32c = [] { const char* e = getenv("DCS_MFMA_LDS_CAP32"); return e ? atol(e) : 32L * 1024; }();
     // patch words per pixel at chunk depth ch: fp32 2 ch + 4; bf16 ch + 4; three bf16 planes 3 ch + 4
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
     if (p->pipe) {}
-    else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 32 * 1024) p->CH = 32;
+    else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= cap32c) p->CH = 32;
     else if (Cin % 16 == 0 && npix * pixw(16) * 4 <= cap16) p->CH = 16;
     else if (npix * pixw(8) * 4 <= 150 * 1024) p->CH = 8;
     else return false;
