@@ -357,10 +357,16 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 // Same LDS patch, gather, classes and B ring as the 32-wide kernel; no split-K (these layers have plenty of pixels).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int CH>
+// PR = 2 (fp32 emulated on the bf16 MFMA, as in the 32-column kernel): v_mfma_f32_16x16x32_bf16, a k-group = 16 complex
+// channels; the lane's 16-byte LDS read is its 8 consecutive bf16 reals of one of the three planes, the B panel is
+// [tap][kg16][plane][64 lanes][8 bf16] (packjob::MFMA, flag 17).  Six MFMAs of 16 cycles per tile and k-group instead
+// of sixteen of 32.
+template <int CH, int PR = 0>
 __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
-    constexpr int U8 = CH / 8, PIX = 2 * CH + 4, Q = CH / 2;
+    constexpr int NP = PR == 2 ? 3 : 1;
+    constexpr int U8 = PR == 2 ? CH / 16 : CH / 8, PIX = PR == 2 ? 3 * CH + 4 : 2 * CH + 4, Q = CH / 2;
+    static_assert(PR == 0 || (PR == 2 && CH % 16 == 0), "emulated form: 16-channel k-groups");
     const conv::Args& a = m.c;
     const conv::Cls& k = m.cls[blockIdx.z];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -382,21 +388,23 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
         pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + g4 * 4;
     }
     const float* bbase = m.bm + k.bm_off + (long)lane * 4;
-    const long b_tap_stride = (long)(Cin / 8) * 256, b_kg_stride = 256;
+    const long b_tap_stride = PR == 2 ? (long)(Cin / 16) * 3 * 256 : (long)(Cin / 8) * 256, b_kg_stride = PR == 2 ? 3 * 256 : 256;
 
     f32x4v acc[2];
     acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
     const int n_chunks = Cin / CH;
     const int nslots = rows * cols * Q;
 
-    auto bload = [&](int c, int tp, int g) -> float4 {
+    auto bload = [&](float4* dst, int c, int tp, int g) {
         if (tp >= ntaps) { tp = 0; ++c; }
         c = c < n_chunks ? c : n_chunks - 1;
-        return *reinterpret_cast<const float4*>(bbase + tp * b_tap_stride + (long)(c * U8 + g) * b_kg_stride);
-    };
-    float4 bring[U8];
+        const float* bp = bbase + tp * b_tap_stride + (long)(c * U8 + g) * b_kg_stride;
 #pragma unroll
-    for (int g = 0; g < U8; ++g) bring[g] = bload(0, 0, g);
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const float4*>(bp + pl * 256);
+    };
+    float4 bring[U8][NP];
+#pragma unroll
+    for (int g = 0; g < U8; ++g) bload(bring[g], 0, 0, g);
 
     int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);       // source pixel of every patch pixel (see above)
     const unsigned cols_magic = 0xFFFFFFFFu / (unsigned)cols + 1u;    // ceil(2^32 / cols): exact quotients for p < 2^16
@@ -430,7 +438,20 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int idx = base + u * 256;
-                if (idx < nslots) *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
+                if (idx >= nslots) continue;
+                if (PR == 2) {                                         // 2 complex -> 3 planes of 4 bf16 (exact split)
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    float4 r = v[u];
+                    float* dst = patch + (idx / Q) * PIX + (idx % Q) * 2;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const bf16x4 h = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
+                        *reinterpret_cast<bf16x4*>(dst + pl * CH) = h;
+                        r.x -= (float)h[0]; r.y -= (float)h[1]; r.z -= (float)h[2]; r.w -= (float)h[3];
+                    }
+                } else {
+                    *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
+                }
             }
         }
         __syncthreads();
@@ -438,9 +459,29 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
             const int tapoff = ((tap / k.kw) * cols + (tap % k.kw)) * PIX;
 #pragma unroll
             for (int g = 0; g < U8; ++g) {
+                if (PR == 2) {
+                    float4 af[2][NP];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl)
+                            af[i][pl] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff + g * 16 + pl * CH);
+                    constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, af[i][pa[e] < NP ? pa[e] : 0]),
+                                __builtin_bit_cast(bf16x8, bring[g][pb[e] < NP ? pb[e] : 0]), acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bload(bring[g], ch, tap + 1, g);
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
                 const float4 a0 = *reinterpret_cast<const float4*>(patch + pixoff[0] + tapoff + g * 16);
                 const float4 a1 = *reinterpret_cast<const float4*>(patch + pixoff[1] + tapoff + g * 16);
-                const float4 bv = bring[g];
+                const float4 bv = bring[g][0];
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv.x, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv.x, acc[1], 0, 0, 0);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv.y, acc[0], 0, 0, 0);
@@ -450,7 +491,7 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv.w, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                bring[g] = bload(ch, tap + 1, g);                      // same slot, next tap (U8 iterations ahead)
+                bload(bring[g], ch, tap + 1, g);                       // same slot, next tap (U8 iterations ahead)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -563,11 +604,11 @@ int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
     }
 }
 
-template <int CH>
+template <int CH, int PR = 0>
 int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    const size_t lds = (size_t)npix * (2 * CH + 4 + 1) * sizeof(float);                      // patch + source-pixel table
-    auto fn = cconv_mfma16_kernel<CH>;
+    const size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH : 2 * CH) + 4 + 1) * sizeof(float);   // patch + source-pixel table
+    auto fn = cconv_mfma16_kernel<CH, PR>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, 1, m.ncls);
     DCS_LAUNCH(fn, grid, dim3(256), lds, stream, m);
@@ -662,6 +703,10 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
     if (p->pipe) {}
+    else if (2 * a.Cout == 16 && pr == 2 && !(Cin % 32 == 0 && npix * pixw(32) * 4 <= cap32c)) {
+        if (npix * pixw(16) * 4 > 150 * 1024) return false;            // the emulated 16-column kernel has no 8-channel form
+        p->CH = 16;
+    }
     else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= cap32c) p->CH = 32;
     else if (Cin % 16 == 0 && npix * pixw(16) * 4 <= cap16) p->CH = 16;
     else if (npix * pixw(8) * 4 <= 150 * 1024) p->CH = 8;
@@ -684,7 +729,10 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     packjob::Job j{};
     j.kind = packjob::MFMA;
     j.Cout = Cout; j.Cin = Cin; j.kh = taps;
-    if (2 * Cout == 16) {                                                // 16-column layout of cconv_mfma16_kernel (half the region)
+    if (2 * Cout == 16 && conv::mfma_precision(Cin) == 2) {              // 16 columns, three bf16 planes: [tap][kg16][plane][64 lanes][8 bf16]
+        j.flag = 17;
+        j.total = 3L * taps * (Cin / 16) * 64;
+    } else if (2 * Cout == 16) {                                         // 16-column layout of cconv_mfma16_kernel (half the region)
         j.flag = 16;
         j.total = (long)taps * (Cin / 8) * 64;
     } else if (conv::mfma_precision(Cin) == 2) {                         // three planes of bf16 fragments (exact split)
@@ -754,6 +802,11 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
                 a.B, a.Hin, a.Win, a.C1, a.C2, a.Hout, a.Wout, a.Cout, a.kh, a.kw, ncls, p.cand, p.TH, p.TW, p.CH, m.ksplit, p.S,
                 m.cps, g_force_wide_panel ? 0 : conv::mfma_precision(Cin), a.coef != nullptr);
     if (m.N == 16 && p.cand == 3 && !g_force_wide_panel) {    // 128 pixels x 16 columns, v_mfma_f32_16x16x4_f32
+        if (conv::mfma_precision(Cin) == 2) {                  // (make_plan chose a 16- or 32-channel chunk)
+            if (p.CH == 32) return launch16_ch<32, 2>(m, npix, stream);
+            if (p.CH == 16) return launch16_ch<16, 2>(m, npix, stream);
+            return DCS_ERR_BADARG;
+        }
         switch (p.CH) {
             case 32: return launch16_ch<32>(m, npix, stream);
             case 16: return launch16_ch<16>(m, npix, stream);

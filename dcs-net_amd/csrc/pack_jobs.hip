@@ -87,6 +87,30 @@ __device__ __forceinline__ void run_mfma16(const Job& jb, int i) {
     bm[i] = im ? make_float4(w0.y, w0.x, w1.y, w1.x) : make_float4(w0.x, -w0.y, w1.x, -w1.y);
 }
 
+// N = 16, fp32 emulated on the bf16 MFMA (flag == 17): bm[tap][kg16][plane][lane][8 bf16] for v_mfma_f32_16x16x32_bf16:
+// lane = 16 kb + col holds the real k indices 8 kb .. 8 kb + 7 of the 16-channel block (ci = 16 kg16 + 4 kb + e/2,
+// re|im = e&1) for column col = (co = col>>1, re|im = col&1); plane pl = the pl-th term of the exact bf16 split
+__device__ __forceinline__ void run_mfma16_split(const Job& jb, int i) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const float2* wp = (const float2*)jb.src0; bf16x8* bm = (bf16x8*)jb.dst0;
+    const int Cout = jb.Cout, Cin = jb.Cin;
+    const int col = i & 15, kb = (i >> 4) & 3;
+    int r = i >> 6;
+    const int pl = r % 3; r /= 3;
+    const int kg16 = r % (Cin / 16), tap = r / (Cin / 16);
+    const int co = col >> 1, im = col & 1;
+    bf16x8 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float2 w = wp[(tap * Cin + 16 * kg16 + 4 * kb + q) * Cout + co];
+        float e0 = im ? w.y : w.x, e1 = im ? w.x : -w.y;
+        for (int s_ = 0; s_ < pl; ++s_) { e0 -= (float)(__bf16)e0; e1 -= (float)(__bf16)e1; }
+        o[2 * q] = (__bf16)e0;
+        o[2 * q + 1] = (__bf16)e1;
+    }
+    bm[i] = o;
+}
+
 // bf16 (flag == 2): bm[tap][kg8][nt][lane][8 bf16]: lane = 32h + j, element e = real k index 8h + e of the 8-channel block
 // (ci = 8 kg8 + 4h + e/2, re|im = e&1), column n = nt*32 + j — the A/B lane map of v_mfma_f32_32x32x16_bf16
 __device__ __forceinline__ void run_mfma_bf16(const Job& jb, int i) {
@@ -121,6 +145,7 @@ __device__ __forceinline__ void run_mfma_bf16(const Job& jb, int i) {
 
 __device__ __forceinline__ void run_mfma(const Job& jb, int i) {
     if (jb.flag == 16) { run_mfma16(jb, i); return; }
+    if (jb.flag == 17) { run_mfma16_split(jb, i); return; }
     if (jb.flag == 2 || jb.flag == 3) { run_mfma_bf16(jb, i); return; }
     const float2* wp = (const float2*)jb.src0; float4* bm = (float4*)jb.dst0;
     const int Cout = jb.Cout, Cin = jb.Cin;
