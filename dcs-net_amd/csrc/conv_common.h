@@ -47,9 +47,9 @@ inline bool mfma_ok(int Cin, int Cout) { return (Cin % 8) == 0 && (Cout % 8) == 
 // precision mode of the MFMA forward / data-gradient GEMM with K = 2*Cin: the bf16x6 emulation (mode 2) needs 16-channel
 // chunks to amortise its per-iteration cost — 8-channel layers (enc1: the fp32 kernel runs a whole kernel row per
 // iteration there) stay on the fp32 MFMA.  Decides the panel layout (pack) and the kernel (launch) alike.
-inline int mfma_precision(int Cin) {
+inline int mfma_precision(int Cin, int taps = 0) {
     const int p = dcs_conv_precision();
-    return (p == 2 && (Cin % 16) != 0) ? 0 : p;
+    return (p == 2 && (Cin % 16) != 0 && !(Cin == 8 && taps == 49)) ? 0 : p;      // (8 channels: only the 7x7 row form)
 }
 inline long direct_floats(int Cout, int Cin, int taps) { return (long)taps * Cin * Cout * 2; }
 inline long mfma_floats(int Cout, int Cin, int taps) {      // N = 2*Cout padded to whole 32-column tiles

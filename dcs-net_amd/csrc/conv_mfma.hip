@@ -112,11 +112,26 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     // which nobody consumes): the tap loop body stays free of branches, so s_waitcnt counts stay exact instead of
     // draining to zero at every loop header.
     // vg: k-group index inside an iteration = (tap offset vg / U, k-group vg % U)
+    // (INPLACE, below: uniform panel base in SGPRs + one 32-bit lane offset, so that the 147 loads of the unrolled rows
+    // share one address register instead of a 64-bit VGPR pair each — 252 VGPRs before, one wave per SIMD)
+    const char* ubase = reinterpret_cast<const char*>(m.bm + k.bm_off) +
+                        (size_t)__builtin_amdgcn_readfirstlane(nt0) * 1024;
+    const unsigned lane_off = (unsigned)lane * 16u;
     auto bload = [&](float4 (*dst)[WN], int c, int tp, int vg) {
         tp += vg / U;
         const int g = vg % U;
         if (tp >= ntaps) { tp -= ntaps; ++c; }
         c = c < n_chunks ? c : n_chunks - 1;
+        if (PR == 2 && TPI > 1) {
+            unsigned so = (unsigned)((tp * b_tap_stride + (long)(c * U + g) * b_kg_stride) * 4);
+            asm volatile("" : "+s"(so));                               // keep the offset where it is used (no hoisting of 49 rows)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    dst[pl][j] = *reinterpret_cast<const float4*>(ubase + so + (unsigned)((pl * b_plane_stride + j * 256) * 4) + lane_off);
+            return;
+        }
         const float* bp = bbase + tp * b_tap_stride + (long)(c * U + g) * b_kg_stride;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
@@ -128,7 +143,14 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     // vmcnt to zero at every loop header (it cannot carry partial counts across the back edge): with the loads at the
     // front of the body that drain finds them >= U/2 groups (>= 512 MFMA cycles) old instead of just issued.
     constexpr int LPG = VU >= 2 ? 2 : 1;
-    float4 bcur[VU][NP][WN], bnxt[VU][NP][WN];
+    // INPLACE (the emulated 7x7 layer, enc1: PR = 2, a kernel ROW of 7 taps per iteration, one k-group per tap): three
+    // planes x 7 taps of B fragments are 84 VGPRs, so there is ONE set; a slot is refilled right after its MFMAs with the
+    // same tap of the next kernel row (7 k-groups = 1344 MFMA cycles ahead), and the row loop is fully unrolled (49 taps:
+    // the launcher guarantees kh = kw = 7) — straight-line code keeps exact vmcnt counts, a loop header would drain the
+    // refill issued just before it.
+    constexpr bool INPLACE = PR == 2 && TPI > 1;
+    constexpr int NTAPS_C = INPLACE ? TPI * TPI : 0;
+    float4 bcur[VU][NP][WN], bnxt[INPLACE ? 1 : VU][NP][WN];
 #pragma unroll
     for (int g = 0; g < VU; ++g) bload(bcur[g], c_begin, 0, g);
 
@@ -200,7 +222,8 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
             for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + pl * CH);
         int tapoff = 0;                                                // LDS float offset of the current tap
-        for (int tap = 0; tap < ntaps; tap += TPI) {
+#pragma unroll(INPLACE ? TPI : 1)
+        for (int tap = 0; tap < (INPLACE ? NTAPS_C : ntaps); tap += TPI) {
             const int tap2 = tap + TPI < ntaps ? tap + TPI : tap;      // clamped: the last prefetch re-reads this tap
             const int tapoff2 = ((tap2 / k.kw) * cols + (tap2 % k.kw)) * PIX;
 #pragma unroll
@@ -237,19 +260,23 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     }
                 // next tap's fragments (scheduling barriers pin the loads here, ahead of the remaining MFMA groups)
                 __builtin_amdgcn_sched_barrier(0);
-                if (g * LPG < VU) {
+                if (INPLACE) {
+                    bload(bcur[g], ch, tap + TPI, g);
+                } else if (g * LPG < VU) {
 #pragma unroll
                     for (int q = 0; q < LPG; ++q)
-                        if (g * LPG + q < VU) bload(bnxt[g * LPG + q], ch, tap + TPI, g * LPG + q);
+                        if (g * LPG + q < VU) bload(bnxt[INPLACE ? 0 : g * LPG + q], ch, tap + TPI, g * LPG + q);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (!INPLACE) {
 #pragma unroll
-            for (int g = 0; g < VU; ++g)
+                for (int g = 0; g < VU; ++g)
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
+                    for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) bcur[g][pl][j] = bnxt[g][pl][j];
+                        for (int j = 0; j < WN; ++j) bcur[g][pl][j] = bnxt[INPLACE ? 0 : g][pl][j];
+            }
             if (VU & 1) {                                               // odd U (bf16, CH = 8): the prefetch landed in set 1
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
@@ -580,16 +607,18 @@ int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
 template <int WAVES_N, int WM, int WN, int CH, int PR>
 int launch_bf(MArgs& m, long npix, hipStream_t stream) {
     constexpr bool BF = PR != 0;
-    // whole kernel rows per tap-loop iteration for the shallow fp32 layers (one class, 7-wide kernel, 128 x 32 tile)
-    if (!BF && CH == 8 && WM == 1 && WN == 1 && m.ncls == 1 && m.cls[0].kw == 7 && (m.cls[0].kh * m.cls[0].kw) % 7 == 0)
-        return launch_tpi<WAVES_N, WM, WN, CH, PR, (!BF && CH == 8 && WM == 1 && WN == 1) ? 7 : 1>(m, npix, stream);
+    // whole kernel rows per tap-loop iteration for the shallow layers (one class, 7-wide kernel, 128 x 32 tile): native fp32,
+    // and the emulated form of the 7 x 7 layer (fully unrolled over its 7 rows)
+    constexpr bool ROWS = (PR == 0 || PR == 2) && CH == 8 && WM == 1 && WN == 1;
+    if (ROWS && m.ncls == 1 && m.cls[0].kw == 7 && (PR == 2 ? m.cls[0].kh == 7 : (m.cls[0].kh * m.cls[0].kw) % 7 == 0))
+        return launch_tpi<WAVES_N, WM, WN, CH, PR, ROWS ? 7 : 1>(m, npix, stream);
     return launch_tpi<WAVES_N, WM, WN, CH, PR, 1>(m, npix, stream);
 }
 
 template <int WAVES_N, int WM, int WN, int CH>
 int launch_ch(MArgs& m, long npix, hipStream_t stream) {
     // (a caller-packed wide panel — the real-valued convs of DR-Net — is always in the fp32 fragment order)
-    const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(m.c.C1 + m.c.C2);
+    const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(m.c.C1 + m.c.C2, m.ncls == 1 ? m.cls[0].kh * m.cls[0].kw : 0);
     if (pr == 2) return launch_bf<WAVES_N, WM, WN, CH, 2>(m, npix, stream);
     if (pr == 1) return launch_bf<WAVES_N, WM, WN, CH, 1>(m, npix, stream);
     return launch_bf<WAVES_N, WM, WN, CH, 0>(m, npix, stream);
@@ -700,7 +729,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     }
     static const long cap32c = [] { const char* e = getenv("DCS_MFMA_LDS_CAP32"); return e ? atol(e) : 32L * 1024; }();
     // patch words per pixel at chunk depth ch: fp32 2 ch + 4; bf16 ch + 4; three bf16 planes 3 ch + 4
-    const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin);
+    const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
     if (p->pipe) {}
     else if (2 * a.Cout == 16 && pr == 2 && !(Cin % 32 == 0 && npix * pixw(32) * 4 <= cap32c)) {
@@ -735,7 +764,7 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     } else if (2 * Cout == 16) {                                         // 16-column layout of cconv_mfma16_kernel (half the region)
         j.flag = 16;
         j.total = (long)taps * (Cin / 8) * 64;
-    } else if (conv::mfma_precision(Cin) == 2) {                         // three planes of bf16 fragments (exact split)
+    } else if (conv::mfma_precision(Cin, taps) == 2) {                   // three planes of bf16 fragments (exact split)
         j.flag = 3;
         j.total = 3L * taps * (Cin / 8) * ((2 * Cout + 31) / 32) * 64;
     } else if (conv::mfma_precision(Cin) == 1) {                         // bf16 fragments: [tap][kg8][nt][64 lanes][8 bf16]
@@ -800,7 +829,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
     if (trace)
         fprintf(stderr, "[mfma] B %d in %dx%d C %d+%d -> %dx%d Cout %d k %dx%d ncls %d | cand %d tile %dx%d CH %d S %d/%d cps %d prec %d coef %d\n",
                 a.B, a.Hin, a.Win, a.C1, a.C2, a.Hout, a.Wout, a.Cout, a.kh, a.kw, ncls, p.cand, p.TH, p.TW, p.CH, m.ksplit, p.S,
-                m.cps, g_force_wide_panel ? 0 : conv::mfma_precision(Cin), a.coef != nullptr);
+                m.cps, g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0), a.coef != nullptr);
     if (m.N == 16 && p.cand == 3 && !g_force_wide_panel) {    // 128 pixels x 16 columns, v_mfma_f32_16x16x4_f32
         if (conv::mfma_precision(Cin) == 2) {                  // (make_plan chose a 16- or 32-channel chunk)
             if (p.CH == 32) return launch16_ch<32, 2>(m, npix, stream);

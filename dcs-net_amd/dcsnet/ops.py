@@ -223,7 +223,7 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     # (strided forward convs are exactly the encoder's ComplexConv2d stack: tagged for bench.py's encoder roofline)
     ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None,
                            executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
-                           emulated=_emulated(C1 + C2, Cout) and C1 % 2 == 0)
+                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and C1 % 2 == 0)
           if CONV_TIMER is not None else None)
     if coef is not None:
         _chk(coef, 'coef', 2)
@@ -237,10 +237,11 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     return y
 
 
-def _emulated(k_channels, n_channels):
+def _emulated(k_channels, n_channels, taps=0):
     """Whether the MFMA GEMM with K = 2 * k_channels, N = 2 * n_channels runs on the bf16 MFMA in fp32-emulation mode
     (conv::mfma_precision, conv_mfma.hip: 16-channel chunks, 32-column tiles) — for bench.py's instruction accounting."""
-    return (conv_precision() == 'bf16x6' and k_channels % 16 == 0 and n_channels % 8 == 0 and 2 * n_channels != 16)
+    return (conv_precision() == 'bf16x6' and n_channels % 8 == 0 and
+            (k_channels % 16 == 0 or (k_channels == 8 and taps == 49 and n_channels != 8)))
 
 
 def _fold_fraction(C1, Cin, Cout, ksize, stride, pad, up):
