@@ -329,6 +329,194 @@ void cconv_wgrad_mfma_kernel(WArgs w) {
 #endif
 }
 
+// ---- fp32 emulated on the bf16 MFMA (the forward kernel's "bf16x6", conv_mfma.hip) --------------------------------
+// Same decomposition (pixels = the K axis, all taps x MT row tiles of accumulators per wave, slabs), with
+// v_mfma_f32_16x16x32_bf16: a k-step is 32 pixels, a lane holds 8 consecutive pixels of one channel for each operand.
+//   * X: the patch keeps three bf16 planes per pixel ([pixel][plane][16 reals], 112-byte pitch); the B operand — 8
+//     pixels x one input-channel column per lane — is read with ds_read_b64_tr_b16 (a 16-lane group fetches 4 pixel rows
+//     x 16 columns and gets them column-major: two reads per plane and tap), so the image stays pixel-major as gathered;
+//   * g_Y: straight from L2 as before (a lane's 8 pixels are 8 dword loads, the 16 lanes of a group cover 64 contiguous
+//     bytes each) and split into its three planes in registers;
+//   * six MFMAs of 16 cycles per (tap, row tile, 32 pixels) instead of eight of 32 cycles per 4 x 8 pixels.
+// Plain form only (4 waves split the output channels, WS = 1; MT <= 2: the raw g_Y ring is 8 x MT registers per slot).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+constexpr int PIXE = 28;       // LDS floats per patch pixel: 3 planes x 8 floats (16 bf16) + 4 floats of pad
+
+template <int KH, int KW, int MT>
+__global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
+    constexpr int TAPS = KH * KW;
+    extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIXE]
+    const conv::Args& a = w.c;
+    const int cls = blockIdx.z;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int ci0 = (blockIdx.y / w.co_blocks) * CHUNK;
+    const int co0 = (blockIdx.y % w.co_blocks) * (4 * MT * 8) + wave * (MT * 8);
+    const int N1 = 2 * a.Cout;
+    const int tiles_per_img = a.tiles_w * a.tiles_h;
+    const int npix = a.rows * a.cols;
+    const int npx = w.TH * w.TW;
+    const int pad_f = w.pad_f[cls], pad_t = w.pad_t[cls], oo_f = w.oo_f[cls], oo_t = w.oo_t[cls];
+
+    f32x4 acc[MT][TAPS];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) acc[i][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[MT];
+    bool colok[MT];
+    int gcol[MT], gcl[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        bsum[i] = 0.f;
+        gcol[i] = 2 * (co0 + i * 8) + li;
+        colok[i] = (co0 + i * 8 + (li >> 1)) < a.Cout;
+        gcl[i] = colok[i] ? gcol[i] : 0;
+    }
+    int toff[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) toff[tp] = ((tp / KW) * a.cols + (tp % KW)) * PIXE;
+
+    int tiles_done = 0;
+    const int my_tiles = (w.total_tiles - (int)blockIdx.x + w.n_slabs - 1) / w.n_slabs;
+    for (int tl = blockIdx.x; tl < w.total_tiles; tl += w.n_slabs, ++tiles_done) {
+        {
+            const int q = tiles_done * 4 / my_tiles;
+            if (q == 0) __builtin_amdgcn_s_setprio(3);
+            else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
+        const int oy0 = (tile_id / a.tiles_w) * w.TH, ox0 = (tile_id % a.tiles_w) * w.TW;
+        const int vy0 = oy0 * a.sf - pad_f, vx0 = ox0 * a.st - pad_t;
+        __syncthreads();
+        for (int px = t; px < npix; px += 256) {
+            const int iy = (int)__umulhi((unsigned)px, w.cols_magic), ix = px - iy * a.cols;
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            long sp;
+            if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
+                const float2* src = (ci0 < a.C1) ? a.x1 + sp * a.C1 + ci0 : a.x2 + sp * a.C2 + (ci0 - a.C1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const float4*>(src)[q];
+            }
+            float r[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { r[4 * q] = v[q].x; r[4 * q + 1] = v[q].y; r[4 * q + 2] = v[q].z; r[4 * q + 3] = v[q].w; }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                bf16x8w h0, h1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h0[e] = (__bf16)r[e]; r[e] -= (float)h0[e];
+                    h1[e] = (__bf16)r[8 + e]; r[8 + e] -= (float)h1[e];
+                }
+                *reinterpret_cast<bf16x8w*>(patch + px * PIXE + pl * 8) = h0;
+                *reinterpret_cast<bf16x8w*>(patch + px * PIXE + pl * 8 + 4) = h1;
+            }
+        }
+        __syncthreads();
+        int tws = w.twshift, twm = w.TW - 1;
+        asm volatile("" : "+s"(tws), "+s"(twm));
+        const float* gyb = w.gy + (long)b * w.Hy * w.Wy * N1;
+        const int estr = w.os_t * N1;                                  // floats between horizontally adjacent g_Y pixels of the class
+        const int nks = npx >> 5;
+        // this lane's 8 pixels of k-step ks: tile pixel 32 ks + 8 lk + e, e = 0..7 (one tile row: TW >= 16)
+        float raw[2][MT][8];
+        auto load_g = [&](int ks, float (*dst)[8]) {
+            const int p8 = ks * 32 + 8 * lk;
+            const int oy = oy0 + (p8 >> tws), oxb = ox0 + (p8 & twm);
+            const bool rowok = oy < a.Hout;
+            const int soff = ((oy * w.os_f + oo_f) * w.Wy + oxb * w.os_t + oo_t) * N1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int off = (rowok && oxb + e < a.Wout) ? soff + e * estr : 0;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) dst[i][e] = gyb[off + gcl[i]];
+            }
+        };
+        load_g(0, raw[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks >= nks) break;
+            const int p8 = ks * 32 + 8 * lk;
+            const int py = p8 >> tws, px0 = p8 & twm;
+            const bool rowok = oy0 + py < a.Hout;
+            // operand A: the three planes of this lane's 8 g_Y values per row tile
+            bf16x8w ap[MT][3];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float r[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    r[e] = (rowok && ox0 + px0 + e < a.Wout && colok[i]) ? raw[ks & 1][i][e] : 0.f;
+                    bsum[i] += r[e];
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ap[i][pl][e] = (__bf16)r[e]; r[e] -= (float)ap[i][pl][e]; }
+            }
+            if (ks + 1 < 4) load_g(ks + 1 < nks ? ks + 1 : nks - 1, raw[(ks + 1) & 1]);
+            // operand B: lane (row q = li / 4, column quad li % 4) of its 16-lane group addresses pixel 8 lk + q (+ 4)
+            const int q = li >> 2, p4 = li & 3;
+            const int xrow0 = ((py * a.sf) * a.cols + (px0 + q) * a.st) * PIXE + p4 * 2;
+            const int xrow1 = xrow0 + 4 * a.st * PIXE;
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) {
+                bf16x8w bp[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(patch + xrow0 + toff[tp] + pl * 8));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(patch + xrow1 + toff[tp] + pl * 8));
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    bp[pl] = __builtin_bit_cast(bf16x8w, both);
+                }
+                constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};         // smallest terms first
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        acc[i][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i][pa[e]], bp[pb[e]], acc[i][tp], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: as cconv_wgrad_mfma_kernel (same C/D map)
+    const int Cin = a.C1 + a.C2;
+    const long wsz = (long)TAPS * Cin * a.Cout;
+    float2* slab = w.slab_w + ((long)blockIdx.x * w.ncls + cls) * wsz;
+    const int ci = ci0 + (li >> 1);
+    const bool odd = li & 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int co = co0 + i * 8 + lk * 2 + (odd ? 1 : 0);
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+            const f32x4 v = acc[i][tp];
+            const float t0 = dcs_dpp_term<0xB1, 0xf>(odd ? v[0] : v[2]);
+            const float t1 = dcs_dpp_term<0xB1, 0xf>(odd ? v[1] : v[3]);
+            const float2 g = odd ? make_float2(t0 + v[3], t1 - v[2]) : make_float2(v[0] + t1, v[1] - t0);
+            if (co < a.Cout) slab[((long)tp * Cin + ci) * a.Cout + co] = g;
+        }
+    }
+    if (ci0 == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float s = bsum[i];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lk == 0 && colok[i]) w.slab_b[((long)blockIdx.x * w.ncls + cls) * N1 + gcol[i]] = s;
+        }
+    }
+}
+
 template <int KH_, int KW_, int MT_, int WS_, bool TS_ = false> struct Variant {
     static constexpr int KH = KH_, KW = KW_, MT = MT_, WS = WS_;
     static constexpr bool TS = TS_;
@@ -404,9 +592,34 @@ int resident_per_cu(size_t lds) {
     return cached;
 }
 
+// the emulated kernel for a plain (non-GL, WS = 1) variant: MT capped at 2 (more, smaller output-channel blocks)
+template <int KH, int KW, int MT>
+int launch_x6(WArgs& w, int Cin, hipStream_t stream) {
+    const conv::Args& a = w.c;
+    const size_t lds = (size_t)a.rows * a.cols * PIXE * sizeof(float);
+    if (lds > 150 * 1024) return DCS_ERR_BADARG;
+    auto fn = cconv_wgrad_x6_kernel<KH, KW, MT>;
+    w.co_blocks = (a.Cout + 4 * MT * 8 - 1) / (4 * MT * 8);
+    dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks, w.ncls);
+    if (grid.y > 65535) return DCS_ERR_BADARG;
+    if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
+    DCS_LAUNCH(fn, grid, dim3(256), lds, stream, w);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+inline bool wgrad_x6_enabled() {
+    static const int e = [] { const char* v = getenv("DCS_WGRAD_X6"); return v ? atoi(v) : 1; }();   // (0: native kernels in every mode)
+    return e != 0 && dcs_conv_precision() == 2;
+}
+
 template <class V>
 int launch(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
+    if constexpr (!V::GL && V::WS == 1 && !V::TS && V::KH * V::KW > 1 && V::KH < 7) {
+        if (wgrad_x6_enabled() && w.TW >= 16 && (w.TH * w.TW) % 32 == 0)
+            return launch_x6<V::KH, V::KW, (V::MT > 2 ? 2 : V::MT)>(w, Cin, stream);
+    }
     size_t lds = lds_bytes<V>(a.rows, a.cols, w.TH * w.TW);
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
     auto fn = cconv_wgrad_mfma_kernel<V::KH, V::KW, V::MT, V::WS, V::TS>;

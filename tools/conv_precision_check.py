@@ -23,8 +23,12 @@ def ref_conv(x, w_r, w_i, b_r, b_i, st, pad, gy=None):
     y = torch.stack((yr, yi), -1).permute(0, 2, 3, 1, 4)
     if gy is None:
         return y.detach()
-    (y * gy.double().cpu()).sum().backward()
-    return y.detach(), x64.grad
+    wr.requires_grad_(True); wi.requires_grad_(True)
+    yr = c(xr, wr) - c(xi, wi)
+    yi = c(xi, wr) + c(xr, wi)
+    y2 = torch.stack((yr, yi), -1).permute(0, 2, 3, 1, 4)
+    (y2 * gy.double().cpu()).sum().backward()
+    return y.detach(), x64.grad, wr.grad, wi.grad
 
 
 cases = [('3x3 s(2,1) 64->128', 4, 16, 32, 64, 128, 3, (2, 1)), ('5x5 s(2,2) 16->32', 4, 64, 64, 16, 32, 5, (2, 2)),
@@ -36,7 +40,7 @@ for name, B, H, W, Cin, Cout, k, st in cases:
     pad = (k // 2, k // 2)
     Ho, Wo = (H + 2 * pad[0] - k) // st[0] + 1, (W + 2 * pad[1] - k) // st[1] + 1
     gy = torch.randn(B, Ho, Wo, Cout, 2, device=dev)
-    ref, gx_ref = ref_conv(x, w_r, w_i, b_r, b_i, st, pad, gy)
+    ref, gx_ref, gwr_ref, gwi_ref = ref_conv(x, w_r, w_i, b_r, b_i, st, pad, gy)
     print(name)
     for mode in ('f32', 'bf16', 'bf16x6'):
         ops.set_conv_precision(mode)
@@ -46,9 +50,12 @@ for name, B, H, W, Cin, Cout, k, st in cases:
         gx = ops.cconv2d_bwd_data(gy, wpb, (H, W, Cin), (k, k), st, pad, (1, 1), Cin)
         gx = gx[0] if isinstance(gx, tuple) else gx
         e, ge = y.double().cpu() - ref, gx.double().cpu() - gx_ref
+        gw = ops.cconv2d_bwd_weight(x, None, gy, tuple(w_r.shape), True, (k, k), st, pad, (1, 1), False)
+        we = torch.cat(((gw[0].double().cpu() - gwr_ref).flatten(), (gw[1].double().cpu() - gwi_ref).flatten()))
+        wn = torch.cat((gwr_ref.flatten(), gwi_ref.flatten()))
         print(f'  {mode:7s} forward: max|err|/max|y| {e.abs().max().item() / ref.abs().max().item():.3e}  rel-L2 '
               f'{(e.norm() / ref.norm()).item():.3e}   data gradient: max {ge.abs().max().item() / gx_ref.abs().max().item():.3e}'
-              f'  rel-L2 {(ge.norm() / gx_ref.norm()).item():.3e}')
+              f'  rel-L2 {(ge.norm() / gx_ref.norm()).item():.3e}   weight gradient: rel-L2 {(we.norm() / wn.norm()).item():.3e}')
 ops.set_conv_precision('f32')
 
 # every MFMA layer of the network at the bench's shapes: bf16x6 against the fp32 MFMA (forward and data gradient)
