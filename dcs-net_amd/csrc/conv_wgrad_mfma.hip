@@ -338,22 +338,25 @@ void cconv_wgrad_mfma_kernel(WArgs w) {
 //   * g_Y: straight from L2 as before (a lane's 8 pixels are 8 dword loads, the 16 lanes of a group cover 64 contiguous
 //     bytes each) and split into its three planes in registers;
 //   * six MFMAs of 16 cycles per (tap, row tile, 32 pixels) instead of eight of 32 cycles per 4 x 8 pixels.
-// Plain form only (4 waves split the output channels, WS = 1; MT <= 2: the raw g_Y ring is 8 x MT registers per slot).
+// WS waves split a tile's four k-steps and 4 / WS waves the output channels (few output channels: the pixel partials are
+// combined through LDS after the last tile, as in the native kernel); MT <= 2: the raw g_Y ring is 8 x MT registers per slot.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 constexpr int PIXE = 28;       // LDS floats per patch pixel: 3 planes x 8 floats (16 bf16) + 4 floats of pad
 
-template <int KH, int KW, int MT>
+template <int KH, int KW, int MT, int WS = 1>
 __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
     constexpr int TAPS = KH * KW;
+    constexpr int WCO = 4 / WS;                         // waves sharing the block's output channels
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIXE]
     const conv::Args& a = w.c;
     const int cls = blockIdx.z;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int ci0 = (blockIdx.y / w.co_blocks) * CHUNK;
-    const int co0 = (blockIdx.y % w.co_blocks) * (4 * MT * 8) + wave * (MT * 8);
+    const int part = wave % WS;                                        // which k-steps of a tile
+    const int co0 = (blockIdx.y % w.co_blocks) * (WCO * MT * 8) + (wave / WS) * (MT * 8);
     const int N1 = 2 * a.Cout;
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int npix = a.rows * a.cols;
@@ -439,9 +442,10 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                 for (int i = 0; i < MT; ++i) dst[i][e] = gyb[off + gcl[i]];
             }
         };
-        load_g(0, raw[0]);
+        load_g(part < nks ? part : nks - 1, raw[0]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int j = 0; j < 4 / WS; ++j) {
+            const int ks = part + j * WS;
             if (ks >= nks) break;
             const int p8 = ks * 32 + 8 * lk;
             const int py = p8 >> tws, px0 = p8 & twm;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                 float r[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    r[e] = (rowok && ox0 + px0 + e < a.Wout && colok[i]) ? raw[ks & 1][i][e] : 0.f;
+                    r[e] = (rowok && ox0 + px0 + e < a.Wout && colok[i]) ? raw[j & 1][i][e] : 0.f;
                     bsum[i] += r[e];
                 }
 #pragma unroll
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { ap[i][pl][e] = (__bf16)r[e]; r[e] -= (float)ap[i][pl][e]; }
             }
-            if (ks + 1 < 4) load_g(ks + 1 < nks ? ks + 1 : nks - 1, raw[(ks + 1) & 1]);
+            if (j + 1 < 4 / WS) load_g(ks + WS < nks ? ks + WS : nks - 1, raw[(j + 1) & 1]);
             // operand B: lane (row q = li / 4, column quad li % 4) of its 16-lane group addresses pixel 8 lk + q (+ 4)
             const int q = li >> 2, p4 = li & 3;
             const int xrow0 = ((py * a.sf) * a.cols + (px0 + q) * a.st) * PIXE + p4 * 2;
@@ -484,6 +488,37 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
 #pragma unroll
                     for (int e = 0; e < 6; ++e)
                         acc[i][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i][pa[e]], bp[pb[e]], acc[i][tp], 0, 0, 0);
+            }
+        }
+    }
+
+    if (WS > 1) {                      // combine the pixel shares: waves with part > 0 hand over through LDS
+        __syncthreads();
+        float* red = patch;            // reused: [(WS-1) * WCO][MT*TAPS*4 + MT][64]
+        constexpr int PER = MT * TAPS * 4 + MT;
+        if (part > 0) {
+            float* dst = red + ((long)((part - 1) * WCO + wave / WS) * PER) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((i * TAPS + tp) * 4 + r) * 64] = acc[i][tp][r];
+                dst[(MT * TAPS * 4 + i) * 64] = bsum[i];
+            }
+        }
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int q = 1; q < WS; ++q) {
+            const float* src = red + ((long)((q - 1) * WCO + wave / WS) * PER) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][tp][r] += src[((i * TAPS + tp) * 4 + r) * 64];
+                bsum[i] += src[(MT * TAPS * 4 + i) * 64];
             }
         }
     }
@@ -593,13 +628,16 @@ int resident_per_cu(size_t lds) {
 }
 
 // the emulated kernel for a plain (non-GL, WS = 1) variant: MT capped at 2 (more, smaller output-channel blocks)
-template <int KH, int KW, int MT>
+template <int KH, int KW, int MT, int WS>
 int launch_x6(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
-    const size_t lds = (size_t)a.rows * a.cols * PIXE * sizeof(float);
+    size_t lds = (size_t)a.rows * a.cols * PIXE * sizeof(float);
+    const size_t red = (size_t)(WS - 1) * (4 / WS) * (MT * KH * KW * 4 + MT) * 64 * sizeof(float);
+    if (red > lds) lds = red;
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
-    auto fn = cconv_wgrad_x6_kernel<KH, KW, MT>;
-    w.co_blocks = (a.Cout + 4 * MT * 8 - 1) / (4 * MT * 8);
+    auto fn = cconv_wgrad_x6_kernel<KH, KW, MT, WS>;
+    constexpr int CPBX = (4 / WS) * MT * 8;
+    w.co_blocks = (a.Cout + CPBX - 1) / CPBX;
     dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks, w.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
@@ -616,9 +654,9 @@ inline bool wgrad_x6_enabled() {
 template <class V>
 int launch(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
-    if constexpr (!V::GL && V::WS == 1 && !V::TS && V::KH * V::KW > 1 && V::KH < 7) {
+    if constexpr ((V::WS == 1 || V::MT == 1) && !V::TS && V::KH * V::KW > 1 && V::KH < 7) {
         if (wgrad_x6_enabled() && w.TW >= 16 && (w.TH * w.TW) % 32 == 0)
-            return launch_x6<V::KH, V::KW, (V::MT > 2 ? 2 : V::MT)>(w, Cin, stream);
+            return launch_x6<V::KH, V::KW, (V::MT > 2 ? 2 : V::MT), V::WS>(w, Cin, stream);
     }
     size_t lds = lds_bytes<V>(a.rows, a.cols, w.TH * w.TW);
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
