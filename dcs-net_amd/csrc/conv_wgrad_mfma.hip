@@ -345,18 +345,22 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 constexpr int PIXE = 28;       // LDS floats per patch pixel: 3 planes x 8 floats (16 bf16) + 4 floats of pad
 
-template <int KH, int KW, int MT, int WS = 1>
+// TS (the 7x7 layer with 16 output channels, as in the native kernel): the four waves split the TAPS (13 each) and every
+// wave covers all MT*8 output channels and all pixels.
+template <int KH, int KW, int MT, int WS = 1, bool TS = false>
 __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
-    constexpr int TAPS = KH * KW;
-    constexpr int WCO = 4 / WS;                         // waves sharing the block's output channels
+    constexpr int TAPS = TS ? (KH * KW + 3) / 4 : KH * KW;          // taps per wave
+    constexpr int ALLTAPS = KH * KW;
+    constexpr int WCO = TS ? 1 : 4 / WS;                // waves sharing the block's output channels
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIXE]
     const conv::Args& a = w.c;
     const int cls = blockIdx.z;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int ci0 = (blockIdx.y / w.co_blocks) * CHUNK;
-    const int part = wave % WS;                                        // which k-steps of a tile
-    const int co0 = (blockIdx.y % w.co_blocks) * (WCO * MT * 8) + (wave / WS) * (MT * 8);
+    const int part = TS ? 0 : wave % WS;                               // which k-steps of a tile
+    const int tap0 = TS ? wave * TAPS : 0;
+    const int co0 = (blockIdx.y % w.co_blocks) * (WCO * MT * 8) + (TS ? 0 : (wave / WS) * (MT * 8));
     const int N1 = 2 * a.Cout;
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int npix = a.rows * a.cols;
@@ -380,7 +384,10 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
     }
     int toff[TAPS];
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) toff[tp] = ((tp / KW) * a.cols + (tp % KW)) * PIXE;
+    for (int tp = 0; tp < TAPS; ++tp) {
+        const int tap = tap0 + tp < ALLTAPS ? tap0 + tp : ALLTAPS - 1;    // (tap-split: taps past the last repeat it and are dropped)
+        toff[tp] = ((tap / KW) * a.cols + (tap % KW)) * PIXE;
+    }
 
     int tiles_done = 0;
     const int my_tiles = (w.total_tiles - (int)blockIdx.x + w.n_slabs - 1) / w.n_slabs;
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         }
     }
 
-    if (WS > 1) {                      // combine the pixel shares: waves with part > 0 hand over through LDS
+    if (!TS && WS > 1) {               // combine the pixel shares: waves with part > 0 hand over through LDS
         __syncthreads();
         float* red = patch;            // reused: [(WS-1) * WCO][MT*TAPS*4 + MT][64]
         constexpr int PER = MT * TAPS * 4 + MT;
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
 
     // epilogue: as cconv_wgrad_mfma_kernel (same C/D map)
     const int Cin = a.C1 + a.C2;
-    const long wsz = (long)TAPS * Cin * a.Cout;
+    const long wsz = (long)ALLTAPS * Cin * a.Cout;
     float2* slab = w.slab_w + ((long)blockIdx.x * w.ncls + cls) * wsz;
     const int ci = ci0 + (li >> 1);
     const bool odd = li & 1;
@@ -534,14 +541,15 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         const int co = co0 + i * 8 + lk * 2 + (odd ? 1 : 0);
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) {
+            const int tap = tap0 + tp;
             const f32x4 v = acc[i][tp];
             const float t0 = dcs_dpp_term<0xB1, 0xf>(odd ? v[0] : v[2]);
             const float t1 = dcs_dpp_term<0xB1, 0xf>(odd ? v[1] : v[3]);
             const float2 g = odd ? make_float2(t0 + v[3], t1 - v[2]) : make_float2(v[0] + t1, v[1] - t0);
-            if (co < a.Cout) slab[((long)tp * Cin + ci) * a.Cout + co] = g;
+            if (co < a.Cout && tap < ALLTAPS) slab[((long)tap * Cin + ci) * a.Cout + co] = g;
         }
     }
-    if (ci0 == 0) {
+    if (ci0 == 0 && (!TS || wave == 0)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             float s = bsum[i];
@@ -628,15 +636,15 @@ int resident_per_cu(size_t lds) {
 }
 
 // the emulated kernel for a plain (non-GL, WS = 1) variant: MT capped at 2 (more, smaller output-channel blocks)
-template <int KH, int KW, int MT, int WS>
+template <int KH, int KW, int MT, int WS, bool TS = false>
 int launch_x6(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
     size_t lds = (size_t)a.rows * a.cols * PIXE * sizeof(float);
-    const size_t red = (size_t)(WS - 1) * (4 / WS) * (MT * KH * KW * 4 + MT) * 64 * sizeof(float);
+    const size_t red = TS ? 0 : (size_t)(WS - 1) * (4 / WS) * (MT * KH * KW * 4 + MT) * 64 * sizeof(float);
     if (red > lds) lds = red;
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
-    auto fn = cconv_wgrad_x6_kernel<KH, KW, MT, WS>;
-    constexpr int CPBX = (4 / WS) * MT * 8;
+    auto fn = cconv_wgrad_x6_kernel<KH, KW, MT, WS, TS>;
+    constexpr int CPBX = TS ? MT * 8 : (4 / WS) * MT * 8;
     w.co_blocks = (a.Cout + CPBX - 1) / CPBX;
     dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks, w.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
@@ -654,7 +662,11 @@ inline bool wgrad_x6_enabled() {
 template <class V>
 int launch(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
-    if constexpr ((V::WS == 1 || V::MT == 1) && !V::TS && V::KH * V::KW > 1 && V::KH < 7) {
+    if constexpr (V::TS) {
+        if (wgrad_x6_enabled() && w.TW >= 16 && (w.TH * w.TW) % 32 == 0)
+            return launch_x6<V::KH, V::KW, V::MT, 1, true>(w, Cin, stream);
+    }
+    if constexpr ((V::WS == 1 || V::MT == 1) && !V::TS && V::KH * V::KW > 1 && V::KH < 7 && !(V::KH == 5 && V::WS == 4)) {
         if (wgrad_x6_enabled() && w.TW >= 16 && (w.TH * w.TW) % 32 == 0)
             return launch_x6<V::KH, V::KW, (V::MT > 2 ? 2 : V::MT), V::WS>(w, Cin, stream);
     }
