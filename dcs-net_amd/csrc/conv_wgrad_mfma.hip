@@ -568,6 +568,34 @@ template <int KH_, int KW_, int MT_, int WS_, bool TS_ = false> struct Variant {
     static constexpr int GLW = TS_ ? MT_ : 4 / WS_;
 };
 
+// which emulated instance (cconv_wgrad_x6_kernel) stands in for a native variant, if any
+template <class V> struct X6 {
+    static constexpr bool ok = V::TS || ((V::WS == 1 || V::MT == 1) && V::KH * V::KW > 1 && V::KH < 7 && !(V::KH == 5 && V::WS == 4));
+    static constexpr int MT = V::TS ? V::MT : (V::MT > 2 ? 2 : V::MT);
+    static constexpr int WS = V::TS ? 1 : V::WS;
+    static constexpr int CPB = V::TS ? V::MT * 8 : (4 / WS) * MT * 8;
+};
+
+inline bool wgrad_x6_enabled() {
+    static const int e = [] { const char* v = getenv("DCS_WGRAD_X6"); return v ? atoi(v) : 1; }();   // (0: native kernels in every mode)
+    return e != 0 && dcs_conv_precision() == 2;
+}
+
+template <int KH, int KW, int MT, int WS, bool TS>
+int resident_x6(size_t lds) {
+    static int by_kb[161] = {0};
+    int& cached = by_kb[lds / 1024 > 160 ? 160 : lds / 1024];
+    if (cached == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cconv_wgrad_x6_kernel<KH, KW, MT, WS, TS>, 256, lds) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 1;
+        }
+        cached = n > 4 ? 4 : n;
+    }
+    return cached;
+}
+
 // (MT, WS) so that the 4 waves cover min(Cout, most-per-kernel-size) output channels without idle lanes
 template <class F>
 int dispatch(int kh, int kw, int co, F&& f) {
@@ -654,21 +682,12 @@ int launch_x6(WArgs& w, int Cin, hipStream_t stream) {
     return DCS_OK;
 }
 
-inline bool wgrad_x6_enabled() {
-    static const int e = [] { const char* v = getenv("DCS_WGRAD_X6"); return v ? atoi(v) : 1; }();   // (0: native kernels in every mode)
-    return e != 0 && dcs_conv_precision() == 2;
-}
-
 template <class V>
 int launch(WArgs& w, int Cin, hipStream_t stream) {
     const conv::Args& a = w.c;
-    if constexpr (V::TS) {
+    if constexpr (X6<V>::ok) {
         if (wgrad_x6_enabled() && w.TW >= 16 && (w.TH * w.TW) % 32 == 0)
-            return launch_x6<V::KH, V::KW, V::MT, 1, true>(w, Cin, stream);
-    }
-    if constexpr ((V::WS == 1 || V::MT == 1) && !V::TS && V::KH * V::KW > 1 && V::KH < 7 && !(V::KH == 5 && V::WS == 4)) {
-        if (wgrad_x6_enabled() && w.TW >= 16 && (w.TH * w.TW) % 32 == 0)
-            return launch_x6<V::KH, V::KW, (V::MT > 2 ? 2 : V::MT), V::WS>(w, Cin, stream);
+            return launch_x6<V::KH, V::KW, X6<V>::MT, X6<V>::WS, V::TS>(w, Cin, stream);
     }
     size_t lds = lds_bytes<V>(a.rows, a.cols, w.TH * w.TW);
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
@@ -743,6 +762,12 @@ int slabs_for(const conv::Args& c, int ncls, int TH, int TW) {
         using V = decltype(v);
         per_cu = resident_per_cu<V>(lds_bytes<V>(rows, cols, TH * TW));
         cpb = V::CPB;
+        if constexpr (X6<V>::ok) {
+            if (wgrad_x6_enabled() && TW >= 16 && (TH * TW) % 32 == 0) {     // the emulated instance: its own block size / residency
+                cpb = X6<V>::CPB;
+                per_cu = resident_x6<V::KH, V::KW, X6<V>::MT, X6<V>::WS, V::TS>((size_t)rows * cols * PIXE * sizeof(float));
+            }
+        }
         return 0;
     });
     const long grid_y = (long)((c.C1 + c.C2) / CHUNK) * ((c.Cout + cpb - 1) / cpb) * ncls;

@@ -244,6 +244,18 @@ def _emulated(k_channels, n_channels, taps=0):
             (k_channels % 16 == 0 or (k_channels == 8 and taps == 49 and n_channels != 8)))
 
 
+def _wgrad_emulated(C1, Cin, Cout, ksize):
+    """Whether the weight gradient of this geometry runs on the emulated kernel (conv_wgrad_mfma.hip, launch<V>: the MFMA
+    variants with more than one tap — 3x3 incl. its folded forms, 5x5, the 7x7 / 16-channel layer — under precision mode
+    'bf16x6' unless DCS_WGRAD_X6=0) — for bench.py's instruction accounting."""
+    import os
+    if conv_precision() != 'bf16x6' or os.environ.get('DCS_WGRAD_X6', '1') == '0':
+        return False
+    if Cin % 8 or Cout % 8 or C1 % 2 or ksize[0] != ksize[1]:
+        return False
+    return ksize[0] in (3, 5) or (ksize[0] == 7 and 16 <= Cout < 32)
+
+
 def _fold_fraction(C1, Cin, Cout, ksize, stride, pad, up):
     """Share of a conv's ALGORITHMIC multiply-accumulates (what the reference computes: k*k taps per output pixel) that
     the library actually issues.  A 3x3 / stride-1 / pad-1 conv over a nearest-upsampled input runs in folded form
@@ -344,7 +356,8 @@ def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1,
     ev = None
     if CONV_TIMER is not None:
         ev = CONV_TIMER.begin(8.0 * B * gy.shape[1] * gy.shape[2] * Cout * (C1 + C2) * ksize[0] * ksize[1],
-                              executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up))
+                              executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
+                              emulated=_wgrad_emulated(C1, C1 + C2, Cout, ksize))
     try:
         check(lib.dcs_cconv2d_bwd_weight(ptr(x1), ptr(x2), ptr(gy), ptr(gw_r), ptr(gw_i), ptr(gb_r), ptr(gb_i), ptr(ws),
                                          ws.numel(), *geo, int(bool(transposed)), cur_stream()), 'dcs_cconv2d_bwd_weight')

@@ -750,16 +750,18 @@ def _conv_fp64(x, w_r, w_i, b_r, b_i, stride, pad, gy):
     yr = c(xr, wr) - c(xi, wi) + (b_r - b_i).double().cpu()[None, :, None, None]
     yi = c(xi, wr) + c(xr, wi) + (b_r + b_i).double().cpu()[None, :, None, None]
     y = torch.stack((yr, yi), -1).permute(0, 2, 3, 1, 4)
-    (y * gy.double().cpu()).sum().backward()
-    return y.detach(), x64.grad
+    wr.requires_grad_(True); wi.requires_grad_(True)
+    y2 = torch.stack((c(xr, wr) - c(xi, wi), c(xi, wr) + c(xr, wi)), -1).permute(0, 2, 3, 1, 4)
+    (y2 * gy.double().cpu()).sum().backward()
+    return y.detach(), x64.grad, torch.cat((wr.grad.flatten(), wi.grad.flatten()))
 
 
 @pytest.mark.parametrize('geom', [(4, 16, 32, 64, 128, 3, (2, 1)), (2, 48, 40, 16, 32, 5, (2, 2)), (2, 8, 32, 128, 128, 3, (1, 1))])
 def test_f32_emulation_on_the_bf16_mfma_is_at_least_as_accurate_as_the_native_mfma(dev, geom):
     """Precision mode 'bf16x6' (the default): every fp32 operand split exactly into three bf16 terms, six bf16 MFMAs per
-    product group, fp32 accumulation (conv_mfma.hip, PR = 2).  Criterion: distance to an fp64 evaluation, forward and
-    data gradient — no larger than the native v_mfma_f32_32x32x2_f32's own distance (+25 % slack for the sample), and
-    both at fp32 rounding level (1e-6 of the output's max-abs)."""
+    product group, fp32 accumulation (conv_mfma.hip, PR = 2; conv_wgrad_mfma.hip, cconv_wgrad_x6_kernel).  Criterion: distance
+    to an fp64 evaluation, forward, data gradient and weight gradient — no larger than the native fp32 MFMA kernels' own
+    distance (+25 % slack for the sample), and both at fp32 rounding level (1e-6)."""
     from dcsnet import ops
     B, H, W, Cin, Cout, k, st = geom
     g = torch.Generator().manual_seed(5)
@@ -769,7 +771,7 @@ def test_f32_emulation_on_the_bf16_mfma_is_at_least_as_accurate_as_the_native_mf
     pad = (k // 2, k // 2)
     Ho, Wo = (H + 2 * pad[0] - k) // st[0] + 1, (W + 2 * pad[1] - k) // st[1] + 1
     gy = torch.randn(B, Ho, Wo, Cout, 2, generator=g).to(dev)
-    y64, gx64 = _conv_fp64(x, w_r, w_i, b_r, b_i, st, pad, gy)
+    y64, gx64, gw64 = _conv_fp64(x, w_r, w_i, b_r, b_i, st, pad, gy)
     default = ops.conv_precision()
     err = {}
     try:
@@ -779,11 +781,14 @@ def test_f32_emulation_on_the_bf16_mfma_is_at_least_as_accurate_as_the_native_mf
             y = ops.cconv2d(x, None, wp, bias, (k, k), st, pad, (1, 1))
             wpb = ops.pack_conv_weight_bwd(wp, (k, k), st, pad, (1, 1))
             gx = ops.cconv2d_bwd_data(gy, wpb, (H, W, Cin), (k, k), st, pad, (1, 1), Cin)[0]
+            gw = ops.cconv2d_bwd_weight(x, None, gy, (Cout, Cin, k, k), True, (k, k), st, pad, (1, 1), False)
+            gw = torch.cat((gw[0].double().cpu().flatten(), gw[1].double().cpu().flatten()))
             err[mode] = (float((y.double().cpu() - y64).norm() / y64.norm()), float((gx.double().cpu() - gx64).norm() / gx64.norm()),
-                         float((y.double().cpu() - y64).abs().max() / y64.abs().max()))
+                         float((y.double().cpu() - y64).abs().max() / y64.abs().max()), float((gw - gw64).norm() / gw64.norm()))
     finally:
         ops.set_conv_precision(default)
     assert err['bf16x6'][0] <= 1.25 * err['f32'][0] and err['bf16x6'][1] <= 1.25 * err['f32'][1], err
+    assert err['bf16x6'][3] <= 1.25 * err['f32'][3] and err['f32'][3] <= 1e-6, err            # weight gradient (cconv_wgrad_x6_kernel)
     assert err['bf16x6'][2] <= 1e-6 and err['f32'][2] <= 1e-6, err
 
 
