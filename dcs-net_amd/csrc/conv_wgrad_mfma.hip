@@ -568,9 +568,12 @@ template <int KH_, int KW_, int MT_, int WS_, bool TS_ = false> struct Variant {
     static constexpr int GLW = TS_ ? MT_ : 4 / WS_;
 };
 
+#ifndef DCS_X6_MIN_TAPS
+#define DCS_X6_MIN_TAPS 0
+#endif
 // which emulated instance (cconv_wgrad_x6_kernel) stands in for a native variant, if any
 template <class V> struct X6 {
-    static constexpr bool ok = V::TS || ((V::WS == 1 || V::MT == 1) && V::KH * V::KW > 1 && V::KH < 7 && !(V::KH == 5 && V::WS == 4));
+    static constexpr bool ok = V::TS || ((V::WS == 1 || V::MT == 1) && V::KH * V::KW > DCS_X6_MIN_TAPS && V::KH < 7 && !(V::KH == 5 && V::WS == 4));
     static constexpr int MT = V::TS ? V::MT : (V::MT > 2 ? 2 : V::MT);
     static constexpr int WS = V::TS ? 1 : V::WS;
     static constexpr int CPB = V::TS ? V::MT * 8 : (4 / WS) * MT * 8;
