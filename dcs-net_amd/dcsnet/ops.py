@@ -246,14 +246,14 @@ def _emulated(k_channels, n_channels, taps=0):
 
 def _wgrad_emulated(C1, Cin, Cout, ksize):
     """Whether the weight gradient of this geometry runs on the emulated kernel (conv_wgrad_mfma.hip, launch<V>: the MFMA
-    variants with more than one tap — 3x3 incl. its folded forms, 5x5, the 7x7 / 16-channel layer — under precision mode
+    variants 1x1, 3x3 incl. its folded forms, 5x5 and the 7x7 / 16-channel layer — under precision mode
     'bf16x6' unless DCS_WGRAD_X6=0) — for bench.py's instruction accounting."""
     import os
     if conv_precision() != 'bf16x6' or os.environ.get('DCS_WGRAD_X6', '1') == '0':
         return False
     if Cin % 8 or Cout % 8 or C1 % 2 or ksize[0] != ksize[1]:
         return False
-    return ksize[0] in (3, 5) or (ksize[0] == 7 and 16 <= Cout < 32)
+    return ksize[0] in (1, 3, 5) or (ksize[0] == 7 and 16 <= Cout < 32)
 
 
 def _fold_fraction(C1, Cin, Cout, ksize, stride, pad, up):
