@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         };
         load_g(part < nks ? part : nks - 1, raw[0]);
 #pragma unroll
-        for (int j = 0; j < 4 / WS; ++j) {
+        for (int j = 0; j < 8 / WS; ++j) {                             // (tiles of up to 256 pixels: tile_shape_for)
             const int ks = part + j * WS;
             if (ks >= nks) break;
             const int p8 = ks * 32 + 8 * lk;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { ap[i][pl][e] = (__bf16)r[e]; r[e] -= (float)ap[i][pl][e]; }
             }
-            if (j + 1 < 4 / WS) load_g(ks + WS < nks ? ks + WS : nks - 1, raw[(j + 1) & 1]);
+            if (j + 1 < 8 / WS) load_g(ks + WS < nks ? ks + WS : nks - 1, raw[(j + 1) & 1]);
             // operand B: lane (row q = li / 4, column quad li % 4) of its 16-lane group addresses pixel 8 lk + q (+ 4)
             const int q = li >> 2, p4 = li & 3;
             const int xrow0 = ((py * a.sf) * a.cols + (px0 + q) * a.st) * PIXE + p4 * 2;
@@ -802,6 +802,20 @@ void tile_shape(int Hc, int Wc, int kh, int sf, int* TH, int* TW) {
     else { *TH = 2; *TW = 32; }          // a map too small to fill 128 pixels (enc6 at T = 256: 2 x 32): 64-pixel tiles
 }
 
+// The emulated kernel's tile is four k-steps of 32 pixels between two barrier pairs; where the map has the rows and the
+// three-plane patch stays small it takes 256-pixel tiles (twice the rows): half as many gathers, barriers and first-fragment
+// round trips per pixel.  g: the geometry the launch dispatches on (kh, kw, strides, Cout); Hc x Wc: the (class) extent.
+void tile_shape_for(const conv::Args& g, int Hc, int Wc, int* TH, int* TW) {
+    tile_shape(Hc, Wc, g.kh, g.sf, TH, TW);
+    static const int big = [] { const char* e = getenv("DCS_WGRAD_X6_BIG"); return e ? atoi(e) : 1; }();
+    if (!big || !wgrad_x6_enabled() || *TW < 16 || ((*TH) * (*TW)) % 32 != 0 || (*TH) * (*TW) != 128) return;
+    bool ok = false;
+    dispatch(g.kh, g.kw, g.Cout, [&](auto v) { ok = X6<decltype(v)>::ok; return 0; });
+    if (!ok || Hc < 2 * (*TH)) return;
+    const long patch = (long)((2 * (*TH) - 1) * g.sf + g.kh) * ((*TW - 1) * g.st + g.kw) * PIXE * (long)sizeof(float);
+    if (patch <= 48 * 1024) *TH *= 2;
+}
+
 // c: class-space geometry; f: classes; Hy x Wy: full g_Y extent
 int launch_classes(const conv::Args& c, const Fold& f, int Hy, int Wy, const float* gy, float2* slab_w, float* slab_b,
                    int n_slabs, int TH, int TW, hipStream_t stream) {
@@ -839,7 +853,7 @@ bool dcs_conv_wgrad_mfma_ok(int Cin, int Cout, int kh, int kw, int C1) {
 
 // number of partial slabs and the tile shape for a forward geometry (a.Hout / a.Wout set)
 int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW) {
-    tile_shape(a.Hout, a.Wout, a.kh, a.sf, TH, TW);
+    tile_shape_for(a, a.Hout, a.Wout, TH, TW);
     return slabs_for(a, 1, *TH, *TW);
 }
 
@@ -847,7 +861,7 @@ int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW) {
 int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, float* slab_b, int n_slabs,
                                hipStream_t stream) {
     int TH, TW;
-    tile_shape(a.Hout, a.Wout, a.kh, a.sf, &TH, &TW);
+    tile_shape_for(a, a.Hout, a.Wout, &TH, &TW);
     Fold f{};
     f.ncls = 1; f.kh = a.kh; f.kw = a.kw; f.os_f = 1; f.os_t = 1;
     f.pad_f[0] = a.pad_f; f.pad_t[0] = a.pad_t;
@@ -875,7 +889,7 @@ long dcs_conv_wgrad_fold_workspace_bytes(const conv::Args& a) {
     const Fold f = fold_of(a);
     const conv::Args c = class_args(a, f);
     int TH, TW;
-    tile_shape(c.Hout, c.Wout, c.kh, c.sf, &TH, &TW);
+    tile_shape_for(c, c.Hout, c.Wout, &TH, &TW);
     const long ns = slabs_for(c, f.ncls, TH, TW);
     return ns * f.ncls * ((long)f.kh * f.kw * (a.C1 + a.C2) * a.Cout + a.Cout) * (long)sizeof(float2);
 }
@@ -886,7 +900,7 @@ int dcs_conv_wgrad_fold_run(const conv::Args& a, const float* gy, void* workspac
     const Fold f = fold_of(a);
     const conv::Args c = class_args(a, f);
     int TH, TW;
-    tile_shape(c.Hout, c.Wout, c.kh, c.sf, &TH, &TW);
+    tile_shape_for(c, c.Hout, c.Wout, &TH, &TW);
     const int ns = slabs_for(c, f.ncls, TH, TW);
     const int Cin = a.C1 + a.C2;
     const long wsz_c = (long)f.kh * f.kw * Cin * a.Cout;

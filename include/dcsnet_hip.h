@@ -614,7 +614,9 @@ int dcs_tap_rows_wgrad_scatter(const float* gt_r, const float* gt_i, float* gw_r
  *   0            native v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain).
  *   1            bf16 operands (BASELINE configs[4] "bf16 mixed precision"): activations rounded to nearest-even on
  *                their way into LDS, weights rounded at pack time — a genuine bf16 computation (2^-8 operand error).
- * Weight gradients, the 16-column and the small-channel kernels are native fp32 in every mode.  Process-wide (the
+ * In mode 2 the weight gradients (conv_wgrad_mfma.hip) and the 16-column kernel are emulated the same way; the small-
+ * channel kernels (enc0, the 7x7 attention convs, dec6) are native fp32 in every mode; modes 0 and 1 keep every weight
+ * gradient native.  Process-wide (the
  * environment variable DCS_CONV_PRECISION presets it); the packed panel layout and size depend on the mode, so weights
  * packed under one mode are only valid under that mode (the caller re-packs after switching). */
 int dcs_set_conv_precision(int mode);
