@@ -7,7 +7,7 @@ import collections, csv, json, os, sys
 
 src, tag, commit = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else '')
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAM = ['cconv_mfma', 'cconv_wgrad_mfma', 'cconv_wgrad_sa', 'cconv_wgrad_small', 'cconv_small_dgrad', 'cconv_direct', 'cconv_k7',
+FAM = ['cconv_mfma', 'cconv_wgrad_mfma', 'cconv_wgrad_x6', 'cconv_wgrad_sa', 'cconv_wgrad_small', 'cconv_small_dgrad', 'cconv_direct', 'cconv_k7',
        'wgrad_reduce', 'splitk_reduce', 'tapsum', 'tap_rows', 'pack_', 'cbn_', 'att_', 'ca_', 'spatial_pool', 'attention_apply',
        'lstm', 'adam', 'polar_frames', 'istft_ola', 'sisnr', 'bound_']
 CONV = ('cconv_', 'wgrad_reduce', 'splitk_reduce', 'tapsum', 'tap_rows')

@@ -36,7 +36,7 @@ for u, m, b, c, d, k in rows:
     print(f'{u:6.3f} {int(c):8d} {d:10.1f}  {k}')
 fam = lambda pred: (sum(m for _, m, _, _, _, k in rows if pred(k)), sum(b for _, _, b, _, _, k in rows if pred(k)))
 for name, pred in (('cconv_mfma_kernel + cconv_mfma16_kernel (forward / data gradient)', lambda k: k.startswith('cconv_mfma')),
-                   ('cconv_wgrad_mfma_kernel (weight gradient)', lambda k: k.startswith('cconv_wgrad_mfma')),
+                   ('cconv_wgrad_mfma_kernel / cconv_wgrad_x6_kernel (weight gradient)', lambda k: k.startswith('cconv_wgrad_mfma') or k.startswith('cconv_wgrad_x6')),
                    ('cconv_enc0_kernel + cconv_enc0_wgrad_kernel', lambda k: k.startswith('cconv_enc0')),
                    ('all MFMA kernels', lambda k: True)):
     m, b = fam(pred)
