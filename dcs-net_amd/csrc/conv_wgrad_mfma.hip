@@ -343,6 +343,9 @@ void cconv_wgrad_mfma_kernel(WArgs w) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+#ifndef DCS_X6_TAP_GROUP
+#define DCS_X6_TAP_GROUP 2
+#endif
 constexpr int PIXE = 28;       // LDS floats per patch pixel: 3 planes x 8 floats (16 bf16) + 4 floats of pad
 
 // TS (the 7x7 layer with 16 output channels, as in the native kernel): the four waves split the TAPS (13 each) and every
@@ -389,9 +392,12 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         toff[tp] = ((tap / KW) * a.cols + (tap % KW)) * PIXE;
     }
 
+    long long d_gather = 0, d_mfma = 0, d_tiles = 0;
+    const long long d_start = WDIAG_NOW();
     int tiles_done = 0;
     const int my_tiles = (w.total_tiles - (int)blockIdx.x + w.n_slabs - 1) / w.n_slabs;
     for (int tl = blockIdx.x; tl < w.total_tiles; tl += w.n_slabs, ++tiles_done) {
+        const long long s0 = WDIAG_NOW();
         {
             const int q = tiles_done * 4 / my_tiles;
             if (q == 0) __builtin_amdgcn_s_setprio(3);
@@ -430,6 +436,8 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
             }
         }
         __syncthreads();
+        const long long s1 = WDIAG_NOW();
+        d_gather += s1 - s0;
         int tws = w.twshift, twm = w.TW - 1;
         asm volatile("" : "+s"(tws), "+s"(twm));
         const float* gyb = w.gy + (long)b * w.Hy * w.Wy * N1;
@@ -477,27 +485,43 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
             const int q = li >> 2, p4 = li & 3;
             const int xrow0 = ((py * a.sf) * a.cols + (px0 + q) * a.st) * PIXE + p4 * 2;
             const int xrow1 = xrow0 + 4 * a.st * PIXE;
+            // TG taps at a time, terms outermost: consecutive MFMAs go to TG x MT different accumulators (six back-to-back
+            // MFMAs into ONE accumulator — a 4-pass instruction — wait out each other's latency)
+            constexpr int TG = DCS_X6_TAP_GROUP;
 #pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) {
-                bf16x8w bp[3];
+            for (int tp0 = 0; tp0 < TAPS; tp0 += TG) {
+                bf16x8w bp[TG][3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(patch + xrow0 + toff[tp] + pl * 8));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(patch + xrow1 + toff[tp] + pl * 8));
-                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    bp[pl] = __builtin_bit_cast(bf16x8w, both);
+                for (int u = 0; u < TG; ++u) {
+                    const int tp = tp0 + u < TAPS ? tp0 + u : TAPS - 1;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(patch + xrow0 + toff[tp] + pl * 8));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(patch + xrow1 + toff[tp] + pl * 8));
+                        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        bp[u][pl] = __builtin_bit_cast(bf16x8w, both);
+                    }
                 }
                 constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};         // smallest terms first
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int e = 0; e < 6; ++e)
 #pragma unroll
-                    for (int e = 0; e < 6; ++e)
-                        acc[i][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i][pa[e]], bp[pb[e]], acc[i][tp], 0, 0, 0);
+                    for (int u = 0; u < TG; ++u)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            if (tp0 + u < TAPS) {
+                                constexpr int dummy = 0; (void)dummy;
+                                f32x4& c = acc[i][tp0 + u < TAPS ? tp0 + u : 0];
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i][pa[e]], bp[u][pb[e]], c, 0, 0, 0);
+                            }
             }
         }
+        d_mfma += WDIAG_NOW() - s1;
+        ++d_tiles;
     }
+    const long long d_epi = WDIAG_NOW();
 
     if (!TS && WS > 1) {               // combine the pixel shares: waves with part > 0 hand over through LDS
         __syncthreads();
@@ -558,6 +582,18 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
             if (lk == 0 && colok[i]) w.slab_b[((long)blockIdx.x * w.ncls + cls) * N1 + gcol[i]] = s;
         }
     }
+#ifdef DCS_WGRAD_DIAG
+    if (w.dbg && lane == 0) {                                           // (tools/wgrad_diag.py: same record as the native kernel)
+        const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (wg < 8192) {
+            long long* d = w.dbg + (wg * 4 + wave) * 8;
+            const long long e = WDIAG_NOW();
+            d[0] = d_gather; d[1] = d_mfma; d[2] = e - d_epi; d[3] = e - d_start; d[4] = d_tiles; d[5] = d_start;
+            d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            d[7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        }
+    }
+#endif
 }
 
 template <int KH_, int KW_, int MT_, int WS_, bool TS_ = false> struct Variant {
