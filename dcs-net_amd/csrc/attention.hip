@@ -87,7 +87,8 @@ __device__ __forceinline__ void ca_fc_kernel_body(const double* __restrict__ par
         const int nsl = kThreads / C, c = t % C, sl = t / C;             // C <= 128 is a power of two (att_geom)
         double sr = 0, si = 0;
         if (sl < nsl)
-            for (int k = sl; k < nchunks; k += nsl) {
+#pragma unroll 8
+            for (int k = sl; k < nchunks; k += nsl) {                    // (unrolled: the slab loads go out together)
                 const double* p = part + (((long)b * nchunks + k) * C + c) * 2;
                 sr += p[0]; si += p[1];
             }
@@ -105,6 +106,7 @@ __device__ __forceinline__ void ca_fc_kernel_body(const double* __restrict__ par
     // thread per unit walks C dependent-latency loads: ~10 us at C = 128)
     for (int h = t >> 5; h < Ch; h += kThreads / 32) {
         float ar = 0.f, ai = 0.f;
+#pragma unroll 4
         for (int c = t & 31; c < C; c += 32) {
             const float2 w = w1[c * Ch + h], p = pooled[c];
             ar = fmaf(w.x, p.x, ar); ar = fmaf(-w.y, p.y, ar);
@@ -120,6 +122,7 @@ __device__ __forceinline__ void ca_fc_kernel_body(const double* __restrict__ par
     __syncthreads();
     for (int c = t; c < C; c += kThreads) {
         float ar = 0.f, ai = 0.f;
+#pragma unroll 8
         for (int h = 0; h < Ch; ++h) {
             const float2 w = w2[h * C + c], p = hid[h];
             ar = fmaf(w.x, p.x, ar); ar = fmaf(-w.y, p.y, ar);
