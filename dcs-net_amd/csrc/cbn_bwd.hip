@@ -116,15 +116,34 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
 
     const int g = t % G, r0 = t / G;
     const Chan k0 = load_chan(coef, stats, 2 * g), k1 = load_chan(coef, stats, 2 * g + 1);
-    for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
-        const float4 v = x4[r * G + g];
-        float4 gg = g4[r * G + g];
-        if (g2) { const float4 h = g2[r * G + g]; gg.x += h.x; gg.y += h.y; gg.z += h.z; gg.w += h.w; }
-        if (g_add) add_sample(gg, g_add[(r / HW) * G + g], add_scale);
-        const uint64_t e = (uint64_t)(r * G + g) * 4;
-        acc6(s, grad_y<ACT, DROP>(k0, v.x, v.y, gg.x, gg.y, seed, e, drop_p, inv_keep), v.x - k0.mr, v.y - k0.mi);
-        acc6(s + 6, grad_y<ACT, DROP>(k1, v.z, v.w, gg.z, gg.w, seed, e + 2, drop_p, inv_keep), v.z - k1.mr,
-             v.w - k1.mi);
+    // Four row passes per trip, every load unconditional (clamped row; the optional second cotangent and per-sample term
+    // read through a valid stand-in pointer and are dropped by a select): as a rolled loop with `if (g2)` / `if (g_add)`
+    // around their loads every pass was its own memory round trip — up to eight in a row, 8-11 us for a 5-us kernel.
+    constexpr int UN = 4;
+    const long stride = (long)gridDim.x * rows_per_iter;
+    const float4* g2p = g2 ? g2 : g4;
+    const float4* gap = g_add ? g_add : g4;
+    for (long rb = (long)blockIdx.x * rows_per_iter + r0; rb < P; rb += stride * UN) {
+        float4 v[UN], gg[UN], h[UN], ga[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long r = rb + u * stride, rc = r < P ? r : P - 1;
+            v[u] = x4[rc * G + g];
+            gg[u] = g4[rc * G + g];
+            h[u] = g2p[rc * G + g];
+            ga[u] = gap[g_add ? (rc / HW) * G + g : rc * G + g];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long r = rb + u * stride;
+            if (r >= P) continue;
+            if (g2) { gg[u].x += h[u].x; gg[u].y += h[u].y; gg[u].z += h[u].z; gg[u].w += h[u].w; }
+            if (g_add) add_sample(gg[u], ga[u], add_scale);
+            const uint64_t e = (uint64_t)(r * G + g) * 4;
+            acc6(s, grad_y<ACT, DROP>(k0, v[u].x, v[u].y, gg[u].x, gg[u].y, seed, e, drop_p, inv_keep), v[u].x - k0.mr, v[u].y - k0.mi);
+            acc6(s + 6, grad_y<ACT, DROP>(k1, v[u].z, v[u].w, gg[u].z, gg[u].w, seed, e + 2, drop_p, inv_keep), v[u].z - k1.mr,
+                 v[u].w - k1.mi);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) red[t * 12 + i] = (double)s[i];
