@@ -760,20 +760,20 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     j.Cout = Cout; j.Cin = Cin; j.kh = taps;
     if (2 * Cout == 16 && conv::mfma_precision(Cin) == 2) {              // 16 columns, three bf16 planes: [tap][kg16][plane][64 lanes][8 bf16]
         j.flag = 17;
-        j.total = 3L * taps * (Cin / 16) * 64;
+        j.total = (long)taps * (Cin / 16) * 64;                          // (a thread writes its element of all three planes)
     } else if (2 * Cout == 16) {                                         // 16-column layout of cconv_mfma16_kernel (half the region)
         j.flag = 16;
         j.total = (long)taps * (Cin / 8) * 64;
     } else if (conv::mfma_precision(Cin, taps) == 2) {                   // three planes of bf16 fragments (exact split)
         j.flag = 3;
-        j.total = 3L * taps * (Cin / 8) * ((2 * Cout + 31) / 32) * 64;
+        j.total = (long)taps * (Cin / 8) * ((2 * Cout + 31) / 32) * 64;   // (a thread writes its element of all three planes)
     } else if (conv::mfma_precision(Cin) == 1) {                         // bf16 fragments: [tap][kg8][nt][64 lanes][8 bf16]
         j.flag = 2;
         j.total = (long)taps * (Cin / 8) * ((2 * Cout + 31) / 32) * 64;
     } else {
         j.total = (long)taps * (Cin / 4) * ((2 * Cout + 31) / 32) * 64;  // float4 elements
     }
-    j.dst_bytes = j.total * (long)sizeof(float4);
+    j.dst_bytes = j.total * (long)sizeof(float4) * (j.flag == 3 || j.flag == 17 ? 3 : 1);
     j.src0 = wp_direct; j.dst0 = bm;
     return packjob::emit(j, stream);
 }

@@ -91,24 +91,27 @@ __device__ __forceinline__ void run_mfma16(const Job& jb, int i) {
 // lane = 16 kb + col holds the real k indices 8 kb .. 8 kb + 7 of the 16-channel block (ci = 16 kg16 + 4 kb + e/2,
 // re|im = e&1) for column col = (co = col>>1, re|im = col&1); plane pl = the pl-th term of the exact bf16 split
 __device__ __forceinline__ void run_mfma16_split(const Job& jb, int i) {
+    // (one thread per (tap, kg16, lane): it reads its four weights once and writes all three planes)
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     const float2* wp = (const float2*)jb.src0; bf16x8* bm = (bf16x8*)jb.dst0;
     const int Cout = jb.Cout, Cin = jb.Cin;
     const int col = i & 15, kb = (i >> 4) & 3;
-    int r = i >> 6;
-    const int pl = r % 3; r /= 3;
+    const int r = i >> 6;
     const int kg16 = r % (Cin / 16), tap = r / (Cin / 16);
     const int co = col >> 1, im = col & 1;
-    bf16x8 o;
+    float e[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float2 w = wp[(tap * Cin + 16 * kg16 + 4 * kb + q) * Cout + co];
-        float e0 = im ? w.y : w.x, e1 = im ? w.x : -w.y;
-        for (int s_ = 0; s_ < pl; ++s_) { e0 -= (float)(__bf16)e0; e1 -= (float)(__bf16)e1; }
-        o[2 * q] = (__bf16)e0;
-        o[2 * q + 1] = (__bf16)e1;
+        e[2 * q] = im ? w.y : w.x; e[2 * q + 1] = im ? w.x : -w.y;
     }
-    bm[i] = o;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o[k] = (__bf16)e[k]; e[k] -= (float)o[k]; }
+        bm[(r * 3 + pl) * 64 + (i & 63)] = o;
+    }
 }
 
 // bf16 (flag == 2): bm[tap][kg8][nt][lane][8 bf16]: lane = 32h + j, element e = real k index 8h + e of the 8-channel block
@@ -119,28 +122,30 @@ __device__ __forceinline__ void run_mfma_bf16(const Job& jb, int i) {
     const int Cout = jb.Cout, Cin = jb.Cin;
     const int KG8 = Cin / 8, NT = (2 * Cout + 31) / 32;
     // flag == 3: three such panels in a row, plane pl holding the pl-th term of the exact split w = w0 + w1 + w2
-    // (w0 = bf16(w), w1 = bf16(w - w0), w2 = w - w0 - w1; ntaps = jb.kh)
+    // (w0 = bf16(w), w1 = bf16(w - w0), w2 = w - w0 - w1; ntaps = jb.kh); one thread reads its four weights once and
+    // writes its element of all three planes
     const int per_plane = jb.kh * KG8 * NT * 64;
-    const int pl = jb.flag == 3 ? i / per_plane : 0;
-    const int ip = i - pl * per_plane;
-    const int j = ip & 31, h = (ip >> 5) & 1;
-    int r = ip >> 6;
+    const int j = i & 31, h = (i >> 5) & 1;
+    int r = i >> 6;
     const int nt = r % NT; r /= NT;
     const int kg8 = r % KG8;
     const int tap = r / KG8;
     const int n = nt * 32 + j, co = n >> 1, im = n & 1;
-    bf16x8 o;
+    float e[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float2 w = make_float2(0.f, 0.f);
         if (co < Cout) w = wp[(tap * Cin + 8 * kg8 + 4 * h + q) * Cout + co];
         // column (co, re): [ w_r, -w_i ] ; column (co, im): [ w_i, w_r ]   for k = (ci, re), (ci, im)
-        float e0 = im ? w.y : w.x, e1 = im ? w.x : -w.y;
-        for (int s_ = 0; s_ < pl; ++s_) { e0 -= (float)(__bf16)e0; e1 -= (float)(__bf16)e1; }
-        o[2 * q] = (__bf16)e0;
-        o[2 * q + 1] = (__bf16)e1;
+        e[2 * q] = im ? w.y : w.x; e[2 * q + 1] = im ? w.x : -w.y;
     }
-    bm[i] = o;
+    const int np = jb.flag == 3 ? 3 : 1;
+    for (int pl = 0; pl < np; ++pl) {
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o[k] = (__bf16)e[k]; e[k] -= (float)o[k]; }
+        bm[pl * per_plane + i] = o;
+    }
 }
 
 __device__ __forceinline__ void run_mfma(const Job& jb, int i) {
