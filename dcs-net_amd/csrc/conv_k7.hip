@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void cconv_k7_kernel(K7Table tb) {
     const int tl = (int)blockIdx.x - tb.x0[z];
     const int t = threadIdx.x, b = blockIdx.y;
     const int oy0 = (tl / p.tiles_w) * TR, ox0 = (tl % p.tiles_w) * TC;
-    for (int i = t; i < K * K * CI * CO; i += 256) wl[i] = p.w[i];            // [tap][ci][co]
+    static_assert(K * K * CI * CO <= 256, "one weight per thread");
+    const float2 wv = p.w[t < K * K * CI * CO ? t : 0];                       // [tap][ci][co]; unconditional: goes out with the tile loads
     const float2* xb = p.x + (long)b * p.H * p.W * CI;
     // The haloed tile in ONE batch of unconditional loads (clamped coordinates, zeroed afterwards).  As a loop of predicated
     // loads every trip was its own memory round trip: a branch, the load, s_waitcnt vmcnt(0), the LDS store — six in a row.
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void cconv_k7_kernel(K7Table tb) {
             for (int ci = 0; ci < CI; ++ci) tile[ci][iy * COLSP + ix] = in ? tv[k][ci] : make_float2(0.f, 0.f);
         }
     }
+    if (t < K * K * CI * CO) wl[t] = wv;
     __syncthreads();
     const int ty = t / (TC / PB), tx = (t % (TC / PB)) * PB;
     // complex MAC as two packed FMAs (v_pk_fma_f32): acc(re, im) += w.x * (x.re, x.im) + w.y * (-x.im, x.re)
