@@ -422,7 +422,7 @@ def main():
                                     'native: v_mfma_f32_32x32x2_f32' if conv_mode == 'f32' else
                                     'bf16x6: conv forward / data gradient emulate fp32 on v_mfma_f32_32x32x16_bf16 (exact 3-way '
                                     'bf16 split of both operands, 6 cross products, fp32 accumulate; error vs fp64 below the native '
-                                    'MFMA\'s: profiles/*conv_precision.txt); weight gradients and the 8-channel layers on the native fp32 MFMA'),
+                                    'MFMA\'s: profiles/*conv_precision.txt); the weight gradients run on the same emulation (cconv_wgrad_x6_kernel), enc0 and the small-channel kernels on the native fp32 pipe / VALU'),
                        'per_gpu_batch': B, 'frames_per_utterance': T, 'global_batch': B * world,
                        'frames_per_step': B * T * world, 'hip_graph': bool(graphed), 'parallelism': (f'dp{world} (utterance sharding, one flat-bucket gradient all-reduce)' if train
                                        else f'dp{world} (utterance sharding, no collective)')},
