@@ -24,6 +24,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef DCS_X6_GU32
+#define DCS_X6_GU32 8       // gather loads in flight per thread at 32-channel chunks of the emulated kernel
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         // pixel of every patch pixel comes from the table built once above: per slot a shift, an LDS read and one
         // 64-bit multiply-add (the index arithmetic it replaces — four runtime divisions per slot and chunk — kept the
         // VALU busy for ~30 % of a workgroup's life while its MFMA pipe idled).
-        constexpr int GU = 4;
+        constexpr int GU = (PR == 2 && CH == 32) ? DCS_X6_GU32 : 4;
         for (int base = t; base < nslots; base += 256 * GU) {
             float4 v[GU];
             int spv[GU];
@@ -727,7 +731,13 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
             if (dcs_conv_pipe_eligible(a, ncls, cls, best, p->TH, p->TW, ch)) { p->CH = ch; p->pipe = true; }
         }
     }
-    static const long cap32c = [] { const char* e = getenv("DCS_MFMA_LDS_CAP32"); return e ? atol(e) : 32L * 1024; }();
+    const int pr_for_cap = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
+    // 32-channel chunks (half the gather rounds, twice the patch): for the emulated kernel also up to 56 KB where the launch
+    // puts at most ~3 workgroups on a CU anyway, so the larger patch costs no residency (train shapes: step -1.5 %; with
+    // every layer allowed, the inference shapes lose 0.8 %)
+    static const long cap32e = [] { const char* e = getenv("DCS_MFMA_LDS_CAP32"); return e ? atol(e) : 32L * 1024; }();
+    const long wg_est = best_blocks * (want_s > 1 ? want_s : 1);
+    const long cap32c = (pr_for_cap == 2 && wg_est <= 768 && cap32e < 56L * 1024) ? 56L * 1024 : cap32e;
     // patch words per pixel at chunk depth ch: fp32 2 ch + 4; bf16 ch + 4; three bf16 planes 3 ch + 4
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
