@@ -24,6 +24,9 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef DCS_X6_GU16
+#define DCS_X6_GU16 4
+#endif
 #ifndef DCS_X6_GU32
 #define DCS_X6_GU32 8       // gather loads in flight per thread at 32-channel chunks of the emulated kernel
 #endif
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         // pixel of every patch pixel comes from the table built once above: per slot a shift, an LDS read and one
         // 64-bit multiply-add (the index arithmetic it replaces — four runtime divisions per slot and chunk — kept the
         // VALU busy for ~30 % of a workgroup's life while its MFMA pipe idled).
-        constexpr int GU = (PR == 2 && CH == 32) ? DCS_X6_GU32 : 4;
+        constexpr int GU = (PR == 2 && CH == 32) ? DCS_X6_GU32 : (PR == 2 ? DCS_X6_GU16 : 4);
         for (int base = t; base < nslots; base += 256 * GU) {
             float4 v[GU];
             int spv[GU];
