@@ -343,6 +343,15 @@ void cconv_wgrad_mfma_kernel(WArgs w) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+#ifndef DCS_X6_FASTMASK
+#define DCS_X6_FASTMASK 1
+#endif
+#ifndef DCS_X6_CFMAP
+#define DCS_X6_CFMAP 1
+#endif
+#ifndef DCS_X6_BPIPE
+#define DCS_X6_BPIPE 0       // reads of the next tap group ahead of the current MFMAs: +50 VGPRs, step +0.4 % (measured)
+#endif
 #ifndef DCS_X6_TAP_GROUP
 #define DCS_X6_TAP_GROUP 2
 #endif
@@ -369,6 +378,13 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
     const int npix = a.rows * a.cols;
     const int npx = w.TH * w.TW;
     const int pad_f = w.pad_f[cls], pad_t = w.pad_t[cls], oo_f = w.oo_f[cls], oo_t = w.oo_t[cls];
+    // Patch pitch (floats per pixel) and the pixel <-> k-index map are chosen so that the transposed reads are free of bank
+    // conflicts: a 32-lane half reads 8 pixel rows x 32 bytes = all 64 banks once if the rows are 8 CONSECUTIVE class pixels
+    // at a pitch of 96 bytes (stride 1: 96 n mod 256 runs through the multiples of 32) or 112 bytes (stride 2: 224 n).
+    // So lane group lk = 2h + o holds, as k-indices 8 lk .. 8 lk + 7, the pixels 16h + 4o + {0..3} and 16h + 8 + 4o + {0..3}
+    // of the k-step — for BOTH operands (with 8 consecutive pixels per group every read was 2-way conflicted at any pitch).
+    constexpr bool CF = DCS_X6_CFMAP;
+    const int PIXR = CF ? (a.st == 2 ? PIXE : 24) : PIXE;
 
     f32x4 acc[MT][TAPS];
 #pragma unroll
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp) {
         const int tap = tap0 + tp < ALLTAPS ? tap0 + tp : ALLTAPS - 1;    // (tap-split: taps past the last repeat it and are dropped)
-        toff[tp] = ((tap / KW) * a.cols + (tap % KW)) * PIXE;
+        toff[tp] = ((tap / KW) * a.cols + (tap % KW)) * PIXR;
     }
 
     long long d_gather = 0, d_mfma = 0, d_tiles = 0;
@@ -408,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
         const int oy0 = (tile_id / a.tiles_w) * w.TH, ox0 = (tile_id % a.tiles_w) * w.TW;
         const int vy0 = oy0 * a.sf - pad_f, vx0 = ox0 * a.st - pad_t;
+        const bool interior = oy0 + w.TH <= a.Hout && ox0 + w.TW <= a.Wout && co0 + MT * 8 <= a.Cout;   // (wave-uniform)
         __syncthreads();
         for (int px = t; px < npix; px += 256) {
             const int iy = (int)__umulhi((unsigned)px, w.cols_magic), ix = px - iy * a.cols;
@@ -431,8 +448,8 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                     h0[e] = (__bf16)r[e]; r[e] -= (float)h0[e];
                     h1[e] = (__bf16)r[8 + e]; r[8 + e] -= (float)h1[e];
                 }
-                *reinterpret_cast<bf16x8w*>(patch + px * PIXE + pl * 8) = h0;
-                *reinterpret_cast<bf16x8w*>(patch + px * PIXE + pl * 8 + 4) = h1;
+                *reinterpret_cast<bf16x8w*>(patch + px * PIXR + pl * 8) = h0;
+                *reinterpret_cast<bf16x8w*>(patch + px * PIXR + pl * 8 + 4) = h1;
             }
         }
         __syncthreads();
@@ -446,13 +463,14 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         // this lane's 8 pixels of k-step ks: tile pixel 32 ks + 8 lk + e, e = 0..7 (one tile row: TW >= 16)
         float raw[2][MT][8];
         auto load_g = [&](int ks, float (*dst)[8]) {
-            const int p8 = ks * 32 + 8 * lk;
+            const int p8 = CF ? ks * 32 + 16 * (lk >> 1) + 4 * (lk & 1) : ks * 32 + 8 * lk;     // e < 4: pixels p8 + e; e >= 4: p8 + 8 + (e - 4)
             const int oy = oy0 + (p8 >> tws), oxb = ox0 + (p8 & twm);
             const bool rowok = oy < a.Hout;
             const int soff = ((oy * w.os_f + oo_f) * w.Wy + oxb * w.os_t + oo_t) * N1;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int off = (rowok && oxb + e < a.Wout) ? soff + e * estr : 0;
+                const int ee = CF ? (e < 4 ? e : e + 4) : e;
+                const int off = (rowok && oxb + ee < a.Wout) ? soff + ee * estr : 0;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) dst[i][e] = gyb[off + gcl[i]];
             }
@@ -462,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         for (int j = 0; j < 8 / WS; ++j) {                             // (tiles of up to 256 pixels: tile_shape_for)
             const int ks = part + j * WS;
             if (ks >= nks) break;
-            const int p8 = ks * 32 + 8 * lk;
+            const int p8 = CF ? ks * 32 + 16 * (lk >> 1) + 4 * (lk & 1) : ks * 32 + 8 * lk;
             const int py = p8 >> tws, px0 = p8 & twm;
             const bool rowok = oy0 + py < a.Hout;
             // operand A: the three planes of this lane's 8 g_Y values per row tile
@@ -470,10 +488,19 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 float r[8];
+                // (interior tiles — wave-uniform test — skip the per-value masks; only the workgroups of the first input
+                // chunk need the bias sums: ~30 % of the k-step's VALU work beside its 72 MFMAs)
+                if (DCS_X6_FASTMASK && interior) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    r[e] = (rowok && ox0 + px0 + e < a.Wout && colok[i]) ? raw[j & 1][i][e] : 0.f;
-                    bsum[i] += r[e];
+                    for (int e = 0; e < 8; ++e) r[e] = raw[j & 1][i][e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        r[e] = (rowok && ox0 + px0 + (CF ? (e < 4 ? e : e + 4) : e) < a.Wout && colok[i]) ? raw[j & 1][i][e] : 0.f;
+                }
+                if (!DCS_X6_FASTMASK || ci0 == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[i] += r[e];
                 }
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
@@ -483,17 +510,18 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
             if (j + 1 < 8 / WS) load_g(ks + WS < nks ? ks + WS : nks - 1, raw[(j + 1) & 1]);
             // operand B: lane (row q = li / 4, column quad li % 4) of its 16-lane group addresses pixel 8 lk + q (+ 4)
             const int q = li >> 2, p4 = li & 3;
-            const int xrow0 = ((py * a.sf) * a.cols + (px0 + q) * a.st) * PIXE + p4 * 2;
-            const int xrow1 = xrow0 + 4 * a.st * PIXE;
-            // TG taps at a time, terms outermost: consecutive MFMAs go to TG x MT different accumulators (six back-to-back
-            // MFMAs into ONE accumulator — a 4-pass instruction — wait out each other's latency)
+            const int xrow0 = ((py * a.sf) * a.cols + (px0 + q) * a.st) * PIXR + p4 * 2;
+            const int xrow1 = xrow0 + (CF ? 8 : 4) * a.st * PIXR;
+            // TG taps at a time, terms outermost: consecutive MFMAs go to TG x MT different accumulators.  The transposed reads
+            // of tap group n + 1 are issued BEFORE the MFMAs of group n (two operand sets): issued right in front of their own
+            // MFMAs, every group waited out an LDS round trip (s_waitcnt lgkmcnt(0) after 12 reads, three times per k-step).
             constexpr int TG = DCS_X6_TAP_GROUP;
-#pragma unroll
-            for (int tp0 = 0; tp0 < TAPS; tp0 += TG) {
-                bf16x8w bp[TG][3];
+            constexpr int NG = (TAPS + TG - 1) / TG;
+            bf16x8w bp[2][TG][3];
+            auto read_group = [&](int gidx, bf16x8w (*dst)[3]) {
 #pragma unroll
                 for (int u = 0; u < TG; ++u) {
-                    const int tp = tp0 + u < TAPS ? tp0 + u : TAPS - 1;
+                    const int tp = gidx * TG + u < TAPS ? gidx * TG + u : TAPS - 1;
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -501,9 +529,16 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (s16x4 __attribute__((address_space(3)))*)(patch + xrow1 + toff[tp] + pl * 8));
                         const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        bp[u][pl] = __builtin_bit_cast(bf16x8w, both);
+                        dst[u][pl] = __builtin_bit_cast(bf16x8w, both);
                     }
                 }
+            };
+            if (DCS_X6_BPIPE) read_group(0, bp[0]);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (!DCS_X6_BPIPE) read_group(gi, bp[gi & 1]);
+                else if (gi + 1 < NG) read_group(gi + 1, bp[(gi + 1) & 1]);
+                if (DCS_X6_BPIPE) __builtin_amdgcn_sched_barrier(0);
                 constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};         // smallest terms first
 #pragma unroll
                 for (int e = 0; e < 6; ++e)
@@ -511,11 +546,11 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                     for (int u = 0; u < TG; ++u)
 #pragma unroll
                         for (int i = 0; i < MT; ++i)
-                            if (tp0 + u < TAPS) {
-                                constexpr int dummy = 0; (void)dummy;
-                                f32x4& c = acc[i][tp0 + u < TAPS ? tp0 + u : 0];
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i][pa[e]], bp[u][pb[e]], c, 0, 0, 0);
+                            if (gi * TG + u < TAPS) {
+                                f32x4& c = acc[i][gi * TG + u < TAPS ? gi * TG + u : 0];
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i][pa[e]], bp[gi & 1][u][pb[e]], c, 0, 0, 0);
                             }
+                if (DCS_X6_BPIPE) __builtin_amdgcn_sched_barrier(0);
             }
         }
         d_mfma += WDIAG_NOW() - s1;
