@@ -366,7 +366,20 @@ def _bias_before_bn(n):
                                     or ('.0.conv_tran_' in n and n.startswith('decoder')))
 
 
-def test_network_gradients_against_reference_vectors(dev, golden_dir):
+@pytest.mark.parametrize('conv_mode', ['bf16x6', 'f32'])
+def test_network_gradients_against_reference_vectors(dev, golden_dir, conv_mode):
+    """Both fp32 arithmetic modes of the conv kernels (ops.set_conv_precision): 'bf16x6' = the default emulation on the bf16
+    MFMA (forward, data gradient, weight gradient), 'f32' = the native fp32 MFMA kernels."""
+    from dcsnet import ops
+    default = ops.conv_precision()
+    ops.set_conv_precision(conv_mode)
+    try:
+        _network_gradients_against_reference_vectors(dev, golden_dir)
+    finally:
+        ops.set_conv_precision(default)
+
+
+def _network_gradients_against_reference_vectors(dev, golden_dir):
     cnv = np.load(os.path.join(golden_dir, 'cnet_vectors.npz'))
     tag = 'b2t32'
     net = _hip_net(dev, 0).train()

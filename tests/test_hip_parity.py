@@ -367,8 +367,19 @@ def _hip_net(dev, seed, dropout=False):
     return net.to(dev)
 
 
+@pytest.mark.parametrize('conv_mode', ['bf16x6', 'f32'])
 @pytest.mark.parametrize('tag,seed', [('b2t32', 0), ('b1t16', 1), ('b3t8', 2)])
-def test_network_forward_against_reference_vectors(dev, cnv, tag, seed):
+def test_network_forward_against_reference_vectors(dev, cnv, tag, seed, conv_mode):
+    from dcsnet import ops
+    default = ops.conv_precision()
+    ops.set_conv_precision(conv_mode)          # both fp32 arithmetic modes: the bf16-MFMA emulation (default) and the native MFMA
+    try:
+        _network_forward_against_reference_vectors(dev, cnv, tag, seed)
+    finally:
+        ops.set_conv_precision(default)
+
+
+def _network_forward_against_reference_vectors(dev, cnv, tag, seed):
     net = _hip_net(dev, seed)
     x = torch.from_numpy(cnv[f'{tag}_x']).to(dev)
     net.eval()
