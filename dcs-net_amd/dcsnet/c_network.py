@@ -232,6 +232,20 @@ class C_NETWORK(LightningModule):
         # latent (c_network.py:199-205): channels-last [B,F7,T7,C] is already [B, seq, C]
         lat = enc[L]
         _, F7, T7, C7, _ = lat.shape
+        # The skip attentions depend on the encoder outputs only, and the latent LSTM is a sequential kernel with one workgroup
+        # per CU (350 us at S = 500): at inference they run on a side stream beside it — the fork / join become graph
+        # dependencies under capture (inference pass 3.46 -> 3.37 ms).  Not in training: with the backward's mirror-image
+        # fork the two cross-stream edges cost more than the overlap returns there (step 4.06 -> 4.12 ms, measured).
+        side = None
+        if self.overlap_skip_attention and infer and x.is_cuda:
+            cur = torch.cuda.current_stream(x.device)
+            side = self.__dict__.get('_side_stream')
+            if side is None:
+                side = torch.cuda.Stream(device=x.device)
+                self.__dict__['_side_stream'] = side
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                skips = self._skip_attentions(enc_skip)
         z = self.fc(self.lstm(torch.view_as_complex(lat).view(B, F7 * T7, C7)))
         zr = torch.view_as_real(z.contiguous())
         dp, seed = self._drop(p_fc)
@@ -239,7 +253,12 @@ class C_NETWORK(LightningModule):
             zr = F.dropout(zr, dp, seed)
         d = zr.view(B, F7, T7, C7, 2)
 
-        skips = self._skip_attentions(enc_skip)
+        if side is not None:
+            cur.wait_stream(side)
+            for t_ in skips:
+                t_.record_stream(cur)
+        else:
+            skips = self._skip_attentions(enc_skip)
         for i in range(L):                                   # c_network.py:207-222
             skip = skips[i]
             stage = self.decoder[i]
@@ -287,6 +306,8 @@ class C_NETWORK(LightningModule):
         return F.attention_blocks([enc[L - i] for i in range(L)], params, 7)
 
     batch_skip_attention = True
+    import os as _os
+    overlap_skip_attention = _os.environ.get('DCS_OVERLAP_SKIP', '1') == '1'      # inference only (see forward); 0 disables
 
     @staticmethod
     def _attend(ca_m, sa_m, x, drop_p=0.0, seed=0):
