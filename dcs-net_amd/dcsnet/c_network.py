@@ -240,7 +240,7 @@ class C_NETWORK(LightningModule):
         if self.overlap_skip_attention and infer and x.is_cuda:
             cur = torch.cuda.current_stream(x.device)
             side = self.__dict__.get('_side_stream')
-            if side is None:
+            if side is None or side.device != x.device:
                 side = torch.cuda.Stream(device=x.device)
                 self.__dict__['_side_stream'] = side
             side.wait_stream(cur)
