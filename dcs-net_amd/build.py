@@ -33,39 +33,62 @@ def _stamp(paths):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, flags=None, lib=None, objdir=None, per_source_flags=None):
+    """Incremental: an object is rebuilt when its source, any header or the flags changed (one stamp per object), the
+    library when any object was.  flags / lib / objdir / per_source_flags ({source: [extra flags]}) serve diagnostic
+    variants (tools/) — the product build uses the defaults."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    os.makedirs(OBJ, exist_ok=True)
-    os.makedirs(LIBDIR, exist_ok=True)
+    flags = FLAGS if flags is None else flags
+    lib = LIB if lib is None else lib
+    objdir = OBJ if objdir is None else objdir
+    per_source_flags = per_source_flags or {}
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     srcs = _sources()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
-    headers.append(os.path.join(HERE, '..', 'include', 'dcsnet_hip.h'))
-    stamp_file = os.path.join(OBJ, 'stamp.txt')
-    stamp = _stamp([os.path.join(CSRC, s) for s in srcs] + sorted(headers))
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
-        return LIB
+    headers = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] +
+                     [os.path.join(HERE, '..', 'include', 'dcsnet_hip.h')])
+    hdr_stamp = _stamp(headers)
+
+    def stamp_of(src):
+        h = hashlib.sha256()
+        with open(os.path.join(CSRC, src), 'rb') as f:
+            h.update(f.read())
+        h.update(hdr_stamp.encode())
+        h.update(' '.join(flags + per_source_flags.get(src, [])).encode())
+        return h.hexdigest()
 
     def compile_one(src):
-        obj = os.path.join(OBJ, src[:-4] + '.o')
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        obj = os.path.join(objdir, src[:-4] + '.o')
+        st_file, st = obj + '.stamp', stamp_of(src)
+        if not force and os.path.exists(obj) and os.path.exists(st_file) and open(st_file).read() == st:
+            return obj, False
+        cmd = [hipcc] + flags + per_source_flags.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{r.stdout}\n{r.stderr}')
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
-        return obj
+        with open(st_file, 'w') as f:
+            f.write(st)
+        return obj, True
 
     with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs
+        res = list(ex.map(compile_one, srcs))
+    objs = [o for o, _ in res]
+    stamp_file = os.path.join(objdir, 'stamp.txt')
+    stamp = hashlib.sha256(''.join(stamp_of(s_) for s_ in srcs).encode()).hexdigest()
+    if (not force and not any(c for _, c in res) and os.path.exists(lib) and os.path.exists(stamp_file) and
+            open(stamp_file).read() == stamp):
+        return lib
+    cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', lib] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
     with open(stamp_file, 'w') as f:
         f.write(stamp)
     if verbose:
-        print(f'built {LIB}')
-    return LIB
+        print(f'built {lib}')
+    return lib
 
 
 if __name__ == '__main__':

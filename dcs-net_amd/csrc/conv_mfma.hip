@@ -363,6 +363,69 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                         // came out as q4 alone — 16 lanes (48..63) of one row at a time, ~300 of 4 M outputs, different ones
                         // every run — in the instances built on the bf16 MFMA (PR = 2, 64x64 tile, CH = 16) with other
                         // workgroups' MFMAs in flight on the CU; never seen beside the fp32 MFMA, gone with scalar FMAs.
+#if defined(DCS_EXP_EPI) && DCS_EXP_EPI >= 3
+                        // 3 = the failing instruction pair replicated by hand: v_pk_add_f32 (bias) directly followed by the
+                        // v_pk_fma_f32 whose LOW lane reads the HIGH half of the sum (op_sel:[0,1,0]); 4 = the same with two wait
+                        // states between them; 5 = the same pk_add followed by four scalar v_fma_f32 (control).  One asm block
+                        // per pair, so the spacing is exactly what is written (the hazard recognizer does not look inside).
+                        typedef float f2v __attribute__((ext_vector_type(2)));
+                        v = *reinterpret_cast<const float4*>(tsm + row * TP + 4 * c4);      // un-biased again
+#define DCS_EPI_PAIR(VX, VY, BX, BY, QA0, QA1, QB0, QB1, QC0, QC1)                                                        \
+                        {                                                                                               \
+                            f2v uv = {VX, VY}, bb = {BX, BY}, qa = {QA0, QA1}, qb = {QB0, QB1}, qc = {QC0, QC1}, rr;     \
+                            if (DCS_EXP_EPI == 3)                                                                       \
+                                asm volatile("v_pk_add_f32 %1, %2, %1\n\tv_pk_fma_f32 %0, %3, %1, %5 op_sel:[0,1,0]\n\ts_nop 0\n\t" \
+                                             "v_pk_fma_f32 %0, %4, %1, %0 op_sel_hi:[1,0,1]\n\ts_nop 0"                  \
+                                             : "=&v"(rr), "+v"(uv) : "v"(bb), "v"(qa), "v"(qb), "v"(qc));               \
+                            else if (DCS_EXP_EPI == 4)                                                                  \
+                                asm volatile("v_pk_add_f32 %1, %2, %1\n\ts_nop 1\n\tv_pk_fma_f32 %0, %3, %1, %5 op_sel:[0,1,0]\n\ts_nop 0\n\t" \
+                                             "v_pk_fma_f32 %0, %4, %1, %0 op_sel_hi:[1,0,1]\n\ts_nop 0"                  \
+                                             : "=&v"(rr), "+v"(uv) : "v"(bb), "v"(qa), "v"(qb), "v"(qc));               \
+                            else if (DCS_EXP_EPI == 6) {      /* no cross-half selection: operands broadcast by v_mov first */ \
+                                f2v ui, ur;                                                                             \
+                                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(uv) : "v"(bb));                           \
+                                ui[0] = uv[1]; ui[1] = uv[1]; ur[0] = uv[0]; ur[1] = uv[0];                             \
+                                asm volatile("v_pk_fma_f32 %0, %1, %2, %3\n\ts_nop 0\n\tv_pk_fma_f32 %0, %4, %5, %0\n\ts_nop 0" \
+                                             : "=&v"(rr) : "v"(qa), "v"(ui), "v"(qc), "v"(qb), "v"(ur));                 \
+                            } else if (DCS_EXP_EPI == 7) {    /* first pair scalar, second = op_sel_hi:[1,0,1] (HIGH lane reads the LOW half) */ \
+                                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(uv) : "v"(bb));                           \
+                                rr[0] = fmaf(qa[0], uv[1], qc[0]);                                                       \
+                                asm volatile("" : "+v"(rr[0]));                                                          \
+                                rr[1] = fmaf(qa[1], uv[1], qc[1]);                                                       \
+                                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\ts_nop 0" : "+v"(rr) : "v"(qb), "v"(uv)); \
+                            } else if (DCS_EXP_EPI == 8) {    /* only the cross-half form, fed by registers written long before */ \
+                                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(uv) : "v"(bb));                           \
+                                asm volatile("s_nop 7\n\ts_nop 7\n\tv_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]\n\ts_nop 7" \
+                                             : "=&v"(rr) : "v"(qa), "v"(uv), "v"(qc));                                   \
+                                rr[0] = fmaf(qb[0], uv[0], rr[0]);                                                       \
+                                asm volatile("" : "+v"(rr[0]));                                                          \
+                                rr[1] = fmaf(qb[1], uv[0], rr[1]);                                                       \
+                                asm volatile("" : "+v"(rr[1]));                                                          \
+                            } else {                                                                                    \
+                                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(uv) : "v"(bb));                           \
+                                rr[0] = fmaf(qb[0], uv[0], fmaf(qa[0], uv[1], qc[0]));                                   \
+                                asm volatile("" : "+v"(rr[0]));                                                          \
+                                rr[1] = fmaf(qb[1], uv[0], fmaf(qa[1], uv[1], qc[1]));                                   \
+                                asm volatile("" : "+v"(rr[1]));                                                          \
+                            }                                                                                           \
+                            VX = rr[0]; VY = rr[1];                                                                     \
+                        }
+                        DCS_EPI_PAIR(v.x, v.y, bv.x, bv.y, q[1], q[3], q[0], q[2], q[4], q[5])
+                        DCS_EPI_PAIR(v.z, v.w, bv.z, bv.w, q[7], q[9], q[6], q[8], q[10], q[11])
+#undef DCS_EPI_PAIR
+#elif defined(DCS_EXP_EPI) && DCS_EXP_EPI >= 1
+                        // tools/pk_hazard_probe.py builds: 1 = the failing form (the compiler pairs the FMAs into v_pk_fma_f32
+                        // with op_sel directly behind the v_pk_add_f32 of the bias), 2 = the same pairing with wait states
+                        // between the bias add and the FMAs
+                        float4 w = u;
+#if DCS_EXP_EPI == 2
+                        asm volatile("s_nop 3" : "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w));
+#endif
+                        v.x = fmaf(q[0], w.x, fmaf(q[1], w.y, q[4]));
+                        v.y = fmaf(q[2], w.x, fmaf(q[3], w.y, q[5]));
+                        v.z = fmaf(q[6], w.z, fmaf(q[7], w.w, q[10]));
+                        v.w = fmaf(q[8], w.z, fmaf(q[9], w.w, q[11]));
+#else
                         v.x = fmaf(q[0], u.x, fmaf(q[1], u.y, q[4]));
                         asm volatile("" : "+v"(v.x));
                         v.y = fmaf(q[2], u.x, fmaf(q[3], u.y, q[5]));
@@ -370,6 +433,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                         v.z = fmaf(q[6], u.z, fmaf(q[7], u.w, q[10]));
                         asm volatile("" : "+v"(v.z));
                         v.w = fmaf(q[8], u.z, fmaf(q[9], u.w, q[11]));
+#endif
                     }
                     v.x = dcs_act(v.x, a.act); v.y = dcs_act(v.y, a.act); v.z = dcs_act(v.z, a.act); v.w = dcs_act(v.w, a.act);
                 }

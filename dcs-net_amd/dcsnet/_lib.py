@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libdcsnet_hip.so')
+# DCS_LIB_PATH: a diagnostic build of the same library (tools/pk_hazard_probe.py); never a different implementation
+LIB_PATH = os.environ.get('DCS_LIB_PATH') or os.path.join(os.path.dirname(_HERE), 'lib', 'libdcsnet_hip.so')
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 

@@ -246,18 +246,23 @@ class C_NETWORK(LightningModule):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 skips = self._skip_attentions(enc_skip)
-        z = self.fc(self.lstm(torch.view_as_complex(lat).view(B, F7 * T7, C7)))
+        z = self.lstm(torch.view_as_complex(lat).view(B, F7 * T7, C7))
+        if side is not None:
+            # join BEFORE self.fc: the side stream's VALU kernels overlap the LSTM recurrence only (a VALU kernel too), never
+            # an MFMA conv kernel — see the packed-fp32 / bf16-MFMA co-residency note in DESIGN.md §3
+            cur.wait_stream(side)
+            for t_ in skips:
+                t_.record_stream(cur)
+            for t_ in enc_skip[1:]:
+                t_.record_stream(side)
+        z = self.fc(z)
         zr = torch.view_as_real(z.contiguous())
         dp, seed = self._drop(p_fc)
         if dp > 0:
             zr = F.dropout(zr, dp, seed)
         d = zr.view(B, F7, T7, C7, 2)
 
-        if side is not None:
-            cur.wait_stream(side)
-            for t_ in skips:
-                t_.record_stream(cur)
-        else:
+        if side is None:
             skips = self._skip_attentions(enc_skip)
         for i in range(L):                                   # c_network.py:207-222
             skip = skips[i]

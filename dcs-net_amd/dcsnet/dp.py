@@ -258,7 +258,7 @@ class TrainStep:
     def _loss_no_sync(self, batch, batch_idx):
         """training_step without its NaN test (a host synchronisation, illegal under capture)."""
         from .network_functions import train_batch_2_loss
-        out = train_batch_2_loss(self.net, batch, batch_idx, dtype='complex')
+        out = train_batch_2_loss(self.net, batch, batch_idx, dtype=getattr(self.net, '_step_dtype', 'complex'))
         return out[2] if isinstance(out, tuple) else out
 
     def _device_step(self, batch, world=1):

@@ -172,3 +172,24 @@ def test_flat_bucket_preserves_values_and_gradient_views():
     (p0 * 2).sum().backward()
     assert float(b.grad[:p0.numel()].sum()) == 2.0 * p0.numel()          # autograd wrote into the bucket
     assert all(o % 4 == 0 for o in b.offsets)                # float4-aligned slices for the fused kernel
+
+
+def test_bench_gpus_flag_launches_its_own_ranks_and_refuses_a_mismatch():
+    """`python bench.py --gpus N` with no launcher around it must start N rank processes itself (before any GPU call) and
+    relay a line that saw N ranks; under a launcher whose WORLD_SIZE differs from --gpus it must fail, not print a line
+    labelled with the wrong n_gpus (missing #4).  DCS_BENCH_LAUNCH_ONLY=1 runs the launch plumbing over gloo
+    without the GPU workload."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(REPO, 'bench.py')
+    env = dict(os.environ, DCS_BENCH_LAUNCH_ONLY='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, bench, '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['world_seen'] == 2
+    r = subprocess.run([sys.executable, bench, '--gpus', '4'], env=dict(env, WORLD_SIZE='2', RANK='0'), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
