@@ -24,6 +24,20 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
+def _mfma_source_flags():
+    """Sources whose kernels issue MFMAs are compiled WITHOUT the SLP vectoriser: it pairs adjacent scalar fp32 operations
+    into v_pk_*_f32, and a packed FMA whose low lane takes the HIGH dword of a source pair (op_sel) loses that lane's
+    product beside co-resident bf16-MFMA waves on gfx950 (profiles/r03_pk_fma_op_sel_hazard.txt); packed fp32 VALU beside
+    MFMAs is slower than the scalar form anyway (MI355X_MICROARCH.md, cycle constants).  tests/test_host_cpu.py checks the
+    built library's ISA for it."""
+    out = {}
+    for f in _sources():
+        with open(os.path.join(CSRC, f)) as fh:
+            if '__builtin_amdgcn_mfma' in fh.read():
+                out[f] = ['-fno-slp-vectorize']
+    return out
+
+
 def _stamp(paths):
     h = hashlib.sha256()
     for p in paths:
@@ -41,7 +55,7 @@ def build(force=False, verbose=True, flags=None, lib=None, objdir=None, per_sour
     flags = FLAGS if flags is None else flags
     lib = LIB if lib is None else lib
     objdir = OBJ if objdir is None else objdir
-    per_source_flags = per_source_flags or {}
+    per_source_flags = dict(_mfma_source_flags(), **(per_source_flags or {}))
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     srcs = _sources()

@@ -114,36 +114,48 @@ __global__ __launch_bounds__(kThreads) void cbn_stats_kernel(const float* __rest
     }
 }
 
-__global__ void cbn_finalize_kernel(const float* __restrict__ x, const double* __restrict__ part, int nblocks,
+// PT: element type of the partial slabs — double (cbn_stats_kernel) or float (the conv epilogues' per-workgroup sums,
+// conv_common.h Args::stat).  pivot: float[C][2], the value the partial sums are relative to (pixel 0 of x, or the conv's
+// bias).  One workgroup of 256 threads per channel: a thread's slab loads are all in flight at once (8 per round), then a
+// wave butterfly and an LDS combine in a fixed order.
+template <typename PT>
+__global__ __launch_bounds__(256) void cbn_finalize_kernel(const float* __restrict__ pivot, const PT* __restrict__ part, int nblocks, int stride,
                                     const float* __restrict__ weight, const float* __restrict__ bias,
                                     float* __restrict__ running_mean, float* __restrict__ running_covar,
                                     float* __restrict__ stats_out, float* __restrict__ coef_out,
                                     long P, int C, float eps, float momentum, int use_batch_stats) {
-    // one wavefront per channel: lanes stride over the partial slabs, fp64 butterfly, lane 0 finishes
-    const int c = blockIdx.x, lane = threadIdx.x;
+    __shared__ double wsum[4][5];
+    const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     float mr, mi, Crr, Cii, Cri;
     if (use_batch_stats) {
-        // all of a lane's slab loads in flight at once (<= 512 slabs = 8 per lane; clamped index, masked value): as a rolled
-        // loop of `b < nblocks` trips every trip was its own L2 round trip — 8 x ~0.7 us of a 5.7 us kernel
         double S[5] = {0, 0, 0, 0, 0};
-        for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
-            double v[8][5];
+        // double slabs: [block][C][5] (cbn_stats_kernel); float slabs: [C][5][stride] (conv epilogues: coalesced here)
+        constexpr bool ROWS = sizeof(PT) == sizeof(float);
+        for (int b0 = t; b0 < nblocks; b0 += 256 * 8) {
+            PT v[8][5];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int b = b0 + 64 * k < nblocks ? b0 + 64 * k : nblocks - 1;
+                const int b = b0 + 256 * k < nblocks ? b0 + 256 * k : nblocks - 1;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) v[k][i] = part[((long)b * C + c) * 5 + i];
+                for (int i = 0; i < 5; ++i) v[k][i] = ROWS ? part[(long)(c * 5 + i) * stride + b] : part[((long)b * C + c) * 5 + i];
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
 #pragma unroll
-                for (int i = 0; i < 5; ++i) S[i] += b0 + 64 * k < nblocks ? v[k][i] : 0.0;
+                for (int i = 0; i < 5; ++i) S[i] += b0 + 256 * k < nblocks ? (double)v[k][i] : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i) S[i] = dcs_wave_sum_d(S[i]);
-        if (lane != 0) return;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) wsum[wave][i] = S[i];
+        }
+        __syncthreads();
+        if (t != 0) return;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) S[i] = wsum[0][i] + wsum[1][i] + wsum[2][i] + wsum[3][i];
         const double n = (double)P;
-        const double kr = (double)x[2 * c], ki = (double)x[2 * c + 1];   // pivot = pixel 0
+        const double kr = (double)pivot[2 * c], ki = (double)pivot[2 * c + 1];
         const double dr = S[0] / n, di = S[1] / n;
         mr = (float)(kr + dr);
         mi = (float)(ki + di);
@@ -160,7 +172,7 @@ __global__ void cbn_finalize_kernel(const float* __restrict__ x, const double* _
             running_covar[3 * c + 2] = f * Cri * unb + (1.f - f) * running_covar[3 * c + 2];
         }
     } else {
-        if (lane != 0) return;
+        if (t != 0) return;
         mr = running_mean[2 * c];
         mi = running_mean[2 * c + 1];
         Crr = running_covar[3 * c + 0] + eps;
@@ -340,14 +352,16 @@ extern "C" long dcs_cbn_workspace_bytes(long P, int C) {
     return (long)g.nblocks * C * 5 * (long)sizeof(double);
 }
 
-extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
-                           float* running_covar, float* stats_out, float* coef_out, void* workspace,
-                           long workspace_bytes, long P, int C, float eps, float momentum, int use_batch_stats,
-                           int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
+static int cbn_fwd_impl(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
+                        float* running_covar, float* stats_out, float* coef_out, void* workspace,
+                        long workspace_bytes, long P, int C, float eps, float momentum, int use_batch_stats,
+                        int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream,
+                        const float* slab_part, int slab_rows, int slab_stride, const float* slab_pivot) {
     CbnGeom g;
     if (!x || !y || !stats_out || !coef_out || !cbn_geom(P, C, &g)) return DCS_ERR_BADARG;
     if ((weight == nullptr) != (bias == nullptr)) return DCS_ERR_BADARG;
-    if (use_batch_stats < 0 || use_batch_stats > 2) return DCS_ERR_BADARG;
+    if (use_batch_stats < 0 || use_batch_stats > 3) return DCS_ERR_BADARG;
+    if (use_batch_stats == 3 && (!slab_part || !slab_pivot || slab_rows < 1 || slab_stride < slab_rows)) return DCS_ERR_BADARG;
     if (use_batch_stats == 0 && (!running_mean || !running_covar)) return DCS_ERR_BADARG;
     if (act != DCS_ACT_NONE && act != DCS_ACT_RELU && act != DCS_ACT_LRELU) return DCS_ERR_BADARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
@@ -358,9 +372,13 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
                            g.vec_per_row, g.rows_per_iter);
         DCS_CHECK_LAUNCH();
     }
-    if (use_batch_stats != 2) {            // 2: coef_out already holds the coefficients of an earlier eval-mode call
-        DCS_LAUNCH(cbn_finalize_kernel, dim3(C), dim3(64), 0, s, x, (const double*)workspace,
-                           g.nblocks, weight, bias, running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum,
+    if (use_batch_stats == 3) {            // 3: the producing conv's epilogue left the partial sums (dcs_cbn_fwd_slabs)
+        DCS_LAUNCH(cbn_finalize_kernel<float>, dim3(C), dim3(256), 0, s, slab_pivot, slab_part, slab_rows, slab_stride, weight, bias,
+                   running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum, 1);
+        DCS_CHECK_LAUNCH();
+    } else if (use_batch_stats != 2) {     // 2: coef_out already holds the coefficients of an earlier eval-mode call
+        DCS_LAUNCH(cbn_finalize_kernel<double>, dim3(C), dim3(256), 0, s, x, (const double*)workspace,
+                           g.nblocks, 0, weight, bias, running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum,
                            use_batch_stats);
         DCS_CHECK_LAUNCH();
     }
@@ -378,6 +396,26 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
 #undef DCS_CBN_APPLY
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
+                           float* running_covar, float* stats_out, float* coef_out, void* workspace,
+                           long workspace_bytes, long P, int C, float eps, float momentum, int use_batch_stats,
+                           int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
+    if (use_batch_stats == 3) return DCS_ERR_BADARG;
+    return cbn_fwd_impl(x, y, weight, bias, running_mean, running_covar, stats_out, coef_out, workspace, workspace_bytes, P, C,
+                        eps, momentum, use_batch_stats, act, drop_p, seed, seed_dev, stream, nullptr, 0, 0, nullptr);
+}
+
+// Training-mode dcs_cbn_fwd whose batch statistics come from the conv that produced x (dcs_cconv2d_fwd_stats): `part` =
+// float[C][5][stride] partial sums of (x - pivot), columns 0..rows-1 valid, `pivot` = float[C][2] (the conv's packed bias).
+// No statistics pass over x.
+extern "C" int dcs_cbn_fwd_slabs(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
+                                 float* running_covar, float* stats_out, float* coef_out, const float* part, int rows,
+                                 int stride, const float* pivot, long P, int C, float eps, float momentum, int act, float drop_p,
+                                 unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
+    return cbn_fwd_impl(x, y, weight, bias, running_mean, running_covar, stats_out, coef_out, nullptr, 0, P, C, eps, momentum,
+                        3, act, drop_p, seed, seed_dev, stream, part, rows, stride, pivot);
 }
 
 // Real BatchNorm2d (+ ReLU / LeakyReLU) of float[P][Cr]; Cr even, or Cr == 1 with P even (see rbn_finalize_kernel).

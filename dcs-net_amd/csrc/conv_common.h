@@ -13,6 +13,12 @@ struct Args {
     // (re, im) <- (a0 re + a1 im + c0, a2 re + a3 im + c1), float[Cout][6] = {a0, a1, a2, a3, c0, c1} — an eval-mode
     // ComplexBatchNorm2d folded into the conv that feeds it (dcs_cconv2d_fwd_affine)
     const float* coef;
+    // optional CBN statistics of the raw output (training: the ComplexBatchNorm2d that follows reads them instead of a
+    // pass over y): float[Cout][5][stat_stride], column `row` = one workgroup's partial {S_r, S_i, S_rr, S_ii, S_ri} of
+    // (y - bias) over its valid output pixels (rows contiguous: the finalize kernel's reads coalesce), fixed order, no
+    // atomics.  Forward launches with act = NONE and no coef only.
+    float* stat;
+    int stat_stride;
 };
 
 // One output-parity class of a decomposed convolution (conv_mfma.hip): its own sub-kernel, padding,
@@ -107,11 +113,14 @@ int dcs_conv_k7_launch(const conv::Args* a, int n, hipStream_t stream);
 // conv_enc0.hip: the 1 -> 8 channel, 7x7, stride-2, pad-3 forward conv with the taps as the MFMA K axis
 bool dcs_conv_enc0_ok(const conv::Args& a);
 int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream);
+int dcs_conv_enc0_stat_rows(const conv::Args& a);          // rows of a.stat the launch writes
 bool dcs_conv_enc0_wgrad_ok(const conv::Args& a);
 int dcs_conv_enc0_wgrad_launch(conv::Args a, const float* gy, float2* slab_w, float2* slab_b, int max_slabs, int* n_used,
                                hipStream_t stream);
 
 // conv_mfma.hip
+// rows of a.stat the launch of (a, classes) writes (given the split-K scratch it would be handed), 0: no statistics path
+int dcs_conv_mfma_stat_rows(const conv::Args& a, int ncls, const conv::Cls* cls, bool have_ws);
 int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int taps, hipStream_t stream);
 // split-K scratch (bytes) the launch of this geometry would use; ws / ws_bytes below: that scratch (optional)
 long dcs_conv_mfma_workspace_bytes(const conv::Args& a, int ncls, const conv::Cls* cls);

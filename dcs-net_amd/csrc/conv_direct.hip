@@ -488,6 +488,58 @@ extern "C" int dcs_cconv2d_fwd_affine(const float* x1, const float* x2, const fl
     return launch_direct(p.a, dcs_stream(stream));
 }
 
+// Rows of CBN partial sums (float[rows][Cout][5]) dcs_cconv2d_fwd_stats writes for this geometry when handed the split-K
+// scratch dcs_cconv2d_fwd_workspace_bytes asks for; 0: the geometry has no statistics epilogue (run dcs_cbn_fwd instead).
+static int fwd_stat_rows(const FwdPlan& p, bool have_ws) {
+    if (p.path == 0) return dcs_conv_mfma_stat_rows(p.a, p.ncls, p.cls, have_ws);
+    if (p.path == 1) {
+        conv::Cls c;
+        c.kh = p.a.kh; c.kw = p.a.kw; c.pad_f = p.a.pad_f; c.pad_t = p.a.pad_t; c.oo_f = 0; c.oo_t = 0;
+        c.Hc = p.a.Hout; c.Wc = p.a.Wout; c.bm_off = 0;
+        return dcs_conv_mfma_stat_rows(p.a, 1, &c, have_ws);
+    }
+    if (!dcs_conv_k7_ok(&p.a, 1) && p.a.C2 == 0) return dcs_conv_enc0_stat_rows(p.a);
+    return 0;
+}
+
+extern "C" int dcs_cconv2d_fwd_stats_rows(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh,
+                                          int kw, int sf, int st, int pad_f, int pad_t) {
+    if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || up_f < 1 || up_t < 1 || kh < 1 || kw < 1 ||
+        sf < 1 || st < 1 || pad_f < 0 || pad_t < 0)
+        return -1;
+    const FwdPlan p = fwd_plan(nullptr, nullptr, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    if (p.a.Hout <= 0 || p.a.Wout <= 0) return -1;
+    return fwd_stat_rows(p, true);
+}
+
+// dcs_cconv2d_fwd (no activation) that ALSO leaves the training-mode CBN statistics of its raw output: stat =
+// float[Cout][5][stat_rows], column r = one workgroup's partial {S_r, S_i, S_rr, S_ii, S_ri} of (y - bias), fixed order;
+// *rows_used (host int) = the rows actually written (<= stat_rows = dcs_cconv2d_fwd_stats_rows).  Feeds dcs_cbn_fwd_slabs
+// with pivot = bias: the CBN's statistics pass over y (c_network.py:107-114: conv, CBN back to back) disappears.
+extern "C" int dcs_cconv2d_fwd_stats(const float* x1, const float* x2, const float* wp, const float* bias, float* y,
+                                     float* stat, int stat_rows, int* rows_used, void* workspace, long workspace_bytes, int B,
+                                     int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh, int kw, int sf,
+                                     int st, int pad_f, int pad_t, dcs_stream_t stream) {
+    if (!wp || !bias || !y || !stat || !rows_used || stat_rows < 1) return DCS_ERR_BADARG;
+    if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t)) return DCS_ERR_BADARG;
+    FwdPlan p = fwd_plan(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
+    const long need = p.path == 0 ? dcs_conv_mfma_workspace_bytes(p.a, p.ncls, p.cls)
+                    : p.path == 1 ? dcs_conv_mfma_workspace_bytes_plain(p.a) : 0;
+    const bool have_ws = need > 0 && workspace != nullptr && workspace_bytes >= need;
+    const int rows = fwd_stat_rows(p, have_ws);
+    if (rows < 1 || rows > stat_rows) return DCS_ERR_BADARG;
+    *rows_used = rows;
+    p.a.wp = (const float2*)wp; p.a.bias = (const float2*)bias; p.a.y = (float2*)y; p.a.act = DCS_ACT_NONE; p.a.coef = nullptr;
+    p.a.stat = stat; p.a.stat_stride = stat_rows;
+    if (p.path == 0)
+        return dcs_conv_mfma_launch_classes(p.a, wp + base_floats(Cout, C1 + C2, kh * kw), p.ncls, p.cls, p.os_f, p.os_t,
+                                            nullptr, 0, workspace, workspace_bytes, dcs_stream(stream));
+    if (p.path == 1)
+        return dcs_conv_mfma_launch(p.a, wp + conv::direct_floats(Cout, C1 + C2, kh * kw), workspace, workspace_bytes,
+                                    dcs_stream(stream));
+    return dcs_conv_enc0_launch(p.a, dcs_stream(stream));
+}
+
 // ---- real-valued convolution on the same MFMA kernel (DR-Net: r_network.py:60-66, :90-102) -------------------------
 // A real NHWC activation with an even channel count IS an interleaved "complex" one with half as many channels, and the
 // complex kernel's GEMM is a plain real GEMM over K = taps x real input channels, N = real output channels whose B
@@ -559,7 +611,7 @@ extern "C" int dcs_rconv2d_bwd_data(const float* gy, const float* bm_bwd, float*
 
 // data-gradient launch description shared by the workspace query and the launch itself
 struct DgradPlan {
-    ConvArgs a;
+    ConvArgs a{};
     int path;                  // 0: gradient of the upsample-folded conv, 1: enc0 class kernel, 2: stride classes (MFMA),
                                // 3: zero-insertion MFMA, 4: zero-insertion direct
     int ncls, os_f, os_t;

@@ -67,13 +67,17 @@ __device__ __forceinline__ void patch_load(const conv::Args& a, const TileDiv& d
 }
 
 // bias, folded eval-mode CBN, activation and store of one lane's 2 x 4 accumulators (M-tiles h = 0, 1; rows kg*4 + r)
-template <int ACT, bool CHECK>
+template <int ACT, bool CHECK, bool STAT>
 __device__ __forceinline__ void store_pair(const conv::Args& a, const f32x4v* acc, float* yp, int ox, float bv, float c_re,
-                                           float c_im, float c_add, int li) {
+                                           float c_im, float c_add, int li, float* st) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (STAT) {                                     // CBN statistics of the raw, UN-biased output
+                const float raw = (!CHECK || ox + h * 16 + r < a.Wout) ? acc[h][r] : 0.f;
+                st[0] += raw; st[1] = fmaf(raw, raw, st[1]); st[2] = fmaf(raw, dcs_dpp_term<0xB1, 0xf>(raw), st[2]);
+            }
             float v = acc[h][r] + bv;
             if (a.coef) {
                 const float pv = dcs_dpp_term<0xB1, 0xf>(v);
@@ -87,8 +91,9 @@ __device__ __forceinline__ void store_pair(const conv::Args& a, const f32x4v* ac
 // Persistent workgroups: tile = blockIdx.x, += gridDim.x.  The NEXT tile's patch is loaded into registers while this
 // tile's MFMAs run (two LDS buffers, one barrier per tile), the B fragments are built once per workgroup.
 // ACT: the activation at compile time, or -1 for a.act at run time.
-template <int ACT>
-__global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d, int ntile, long long* dbg) {
+// STAT: also leave the training-mode CBN statistics of the raw output (conv_common.h Args::stat), one row per workgroup.
+template <int ACT, bool STAT = false>
+__global__ __launch_bounds__(256, 4) void cconv_enc0_kernel(conv::Args a, TileDiv d, int ntile, long long* dbg) {
     __shared__ float2 patch[2][PR * PCP];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, kg = lane >> 4;
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d
         if (li & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
     }
     int buf = 0;
+    float st[3] = {0.f, 0.f, 0.f};                          // this lane's column: sum, sum of squares, sum of re * im
     long long d_fill = 0, d_comp = 0, d_n = 0;
     const long long d_start = EDIAG_NOW();
 #pragma unroll 1
@@ -179,11 +185,28 @@ __global__ __launch_bounds__(256) void cconv_enc0_kernel(conv::Args a, TileDiv d
             const int oy = oy0 + py;
             if (oy < a.Hout) {
                 float* yp = reinterpret_cast<float*>(a.y) + (((long)b * a.Hout + oy) * a.Wout + ox0 + kg * 4) * 16 + li;
-                if (ox0 + TC <= a.Wout) store_pair<ACT, false>(a, acc, yp, 0, bv, c_re, c_im, c_add, li);
-                else store_pair<ACT, true>(a, acc, yp, ox0 + kg * 4, bv, c_re, c_im, c_add, li);
+                if (ox0 + TC <= a.Wout) store_pair<ACT, false, STAT>(a, acc, yp, 0, bv, c_re, c_im, c_add, li, st);
+                else store_pair<ACT, true, STAT>(a, acc, yp, ox0 + kg * 4, bv, c_re, c_im, c_add, li, st);
             }
         }
         d_comp += EDIAG_NOW() - e1;
+    }
+    if (STAT) {
+        // one row of partial sums per (persistent) workgroup: over the 4 row groups of a column by shuffles, over the waves in LDS
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { st[e] += __shfl_xor(st[e], 16, 64); st[e] += __shfl_xor(st[e], 32, 64); }
+        __syncthreads();                                    // every wave is done with the patches
+        float* red = reinterpret_cast<float*>(patch[0]);
+        if (lane < 16) { red[(wave * 16 + li) * 3] = st[0]; red[(wave * 16 + li) * 3 + 1] = st[1]; red[(wave * 16 + li) * 3 + 2] = st[2]; }
+        __syncthreads();
+        if (t < 40) {                                       // channel c: {S_r, S_i, S_rr, S_ii, S_ri}
+            const int c = t / 5, e = t % 5;
+            const int colx = 2 * c + (e == 1 || e == 3), which = e < 2 ? 0 : (e < 4 ? 1 : 2);
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sum += red[(w * 16 + colx) * 3 + which];
+            a.stat[(long)t * a.stat_stride + blockIdx.x] = sum;
+        }
     }
 #ifdef DCS_ENC0_DIAG
     if (dbg && t == 0 && blockIdx.x < 4096) {
@@ -345,7 +368,11 @@ int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream) {
 #else
     long long* dbgp = nullptr;
 #endif
-    if (a.act == DCS_ACT_NONE) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_NONE>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
+    if (a.stat) {
+        if (a.act != DCS_ACT_NONE || a.coef) return DCS_ERR_BADARG;
+        DCS_LAUNCH((cconv_enc0_kernel<DCS_ACT_NONE, true>), dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
+    }
+    else if (a.act == DCS_ACT_NONE) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_NONE>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
     else if (a.act == DCS_ACT_RELU) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_RELU>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
     else DCS_LAUNCH(cconv_enc0_kernel<-1>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
     DCS_CHECK_LAUNCH();
@@ -354,6 +381,18 @@ int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream) {
 
 // Weight gradient (forward geometry `a`, x1 set): at most max_slabs partial slabs float2[49][8] (+ float2[8] bias) are
 // written, *n_used says how many; the caller reduces them (launch_wgrad_reduce of conv_direct.hip).
+int dcs_conv_enc0_stat_rows(const conv::Args& a0) {
+    conv::Args a = a0;
+    if (!enc0_geom(a)) return 0;
+    a.Hout = (a.Hin + 2 * a.pad_f - K7) / 2 + 1;
+    a.Wout = (a.Win + 2 * a.pad_t - K7) / 2 + 1;
+    const long ntile = (long)((a.Wout + TC - 1) / TC) * ((a.Hout + TR - 1) / TR) * a.B;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return 0;
+    return (int)(ntile < cus * 4 ? ntile : cus * 4);
+}
+
 bool dcs_conv_enc0_wgrad_ok(const conv::Args& a) { return enc0_geom(a) && a.x1; }
 int dcs_conv_enc0_wgrad_launch(conv::Args a, const float* gy, float2* slab_w, float2* slab_b, int max_slabs, int* n_used,
                                hipStream_t stream) {

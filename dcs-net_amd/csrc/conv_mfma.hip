@@ -65,7 +65,7 @@ long long* g_fdbg = nullptr;
 // TPI > 1 (shallow layers, CH = 8: only U = 2 k-groups per tap): the tap loop advances a whole kernel ROW of TPI = kw taps
 // per iteration — 8 MFMAs per iteration cannot carry the loop's scalar address arithmetic, its waitcnt drain and the
 // B-set copy (enc1 forward: 7 x 2 = 14 k-groups = 56 MFMAs per iteration instead of 8).
-template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI = 1>
+template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI = 1, bool STAT = false>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     constexpr bool BF = PR != 0;
     constexpr int NP = PR == 2 ? 3 : 1;                                // bf16 planes per operand
@@ -83,11 +83,22 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int b = blockIdx.x / tiles_per_img, tile_id = blockIdx.x % tiles_per_img;
     const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
-    if (oy0 >= k.Hc || ox0 >= k.Wc) return;                           // tile outside this (smaller) class
-    const int vy0 = oy0 * a.sf - k.pad_f, vx0 = ox0 * a.st - k.pad_t;
     const int ny = m.NT / (WAVES_N * WN);
     const int kslice = blockIdx.y / ny;
     const int nt0 = ((blockIdx.y % ny) * WAVES_N + wn) * WN;           // first 32-column tile of this wave
+    // STAT: CBN statistics of the raw output (a.stat, training; unsliced launches only): a row of partial sums per workgroup
+    if (oy0 >= k.Hc || ox0 >= k.Wc) {                                  // tile outside this (smaller) class
+        if (STAT) {
+            float* const stat_row = a.stat + ((long)blockIdx.z * gridDim.x + blockIdx.x);
+            const int stat_nt0 = (blockIdx.y % ny) * WAVES_N * WN;
+            for (int o = t; o < WAVES_N * WN * 80; o += 256) {
+                const int e = o % 80, c = ((stat_nt0 + o / 80) * 32 + 4 * (e & 7)) / 2 + e / 40;
+                if (c < a.Cout) stat_row[(long)(c * 5 + ((e % 40) >> 3)) * a.stat_stride] = 0.f;
+            }
+        }
+        return;
+    }
+    const int vy0 = oy0 * a.sf - k.pad_f, vx0 = ox0 * a.st - k.pad_t;
     const int Cin = a.C1 + a.C2;
     const int ntaps = k.kh * k.kw;
     const int cols = (m.TW - 1) * a.st + k.kw, rows = (m.TH - 1) * a.sf + k.kh;
@@ -320,6 +331,13 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     float* tsm = patch + wave * 32 * TP;
     const int c4 = lane & 7, r8 = lane >> 3;
     const float* biasf = reinterpret_cast<const float*>(a.bias);
+    float sst[STAT ? WN : 1][10];                                      // {S_r, S_i, S_rr, S_ii, S_ri} of this lane's two channels
+    if (STAT) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 10; ++e) sst[j][e] = 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int n0 = (nt0 + j) * 32 + 4 * c4;                        // this lane's first column after the transpose
@@ -354,6 +372,13 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 float4 v = *reinterpret_cast<const float4*>(tsm + row * TP + 4 * c4);
                 const int pi = (wm * WM + i) * 32 + row;
                 const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
+                if (STAT && n0 < m.N && oy < k.Hc && ox < k.Wc) {      // moments of the UN-biased value (pivot = bias)
+                    float* q_ = sst[STAT ? j : 0];
+                    q_[0] += v.x; q_[1] += v.y;
+                    q_[2] = fmaf(v.x, v.x, q_[2]); q_[3] = fmaf(v.y, v.y, q_[3]); q_[4] = fmaf(v.x, v.y, q_[4]);
+                    q_[5] += v.z; q_[6] += v.w;
+                    q_[7] = fmaf(v.z, v.z, q_[7]); q_[8] = fmaf(v.w, v.w, q_[8]); q_[9] = fmaf(v.z, v.w, q_[9]);
+                }
                 if (m.ksplit <= 1) {
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     if (a.coef) {
@@ -442,6 +467,38 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
             }
         }
     }
+    if (STAT) {
+        // lanes c4 + 8 r8 hold the same two channels: sum over r8 through the wave's own transpose tile (in-order LDS), then
+        // over the waves that share a column tile (different pixel rows wm) through `comb`, one row of partial sums per workgroup
+        float* comb = patch + 4 * 32 * TP;                             // [wave][j][80]
+        float* const stat_row = a.stat + ((long)blockIdx.z * gridDim.x + blockIdx.x);
+        const int stat_nt0 = (blockIdx.y % ny) * WAVES_N * WN;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+#pragma unroll
+            for (int e = 0; e < 10; ++e) tsm[e * 64 + lane] = sst[STAT ? j : 0][e];
+            float r0 = 0.f, r1 = 0.f;
+            const int k5 = lane >> 3;
+            if (lane < 40) {
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                    r0 += tsm[k5 * 64 + c4 + 8 * q8];
+                    r1 += tsm[(5 + k5) * 64 + c4 + 8 * q8];
+                }
+                comb[(wave * WN + j) * 80 + lane] = r0;
+                comb[(wave * WN + j) * 80 + 40 + lane] = r1;
+            }
+        }
+        __syncthreads();
+        for (int o = t; o < WAVES_N * WN * 80; o += 256) {
+            const int ct = o / 80, e = o % 80, wn_ = ct / WN, j_ = ct % WN;
+            float sum = 0.f;
+#pragma unroll
+            for (int wm_ = 0; wm_ < 4 / WAVES_N; ++wm_) sum += comb[((wm_ * WAVES_N + wn_) * WN + j_) * 80 + e];
+            const int c = ((stat_nt0 + ct) * 32 + 4 * (e & 7)) / 2 + e / 40;
+            if (c < a.Cout) stat_row[(long)(c * 5 + ((e % 40) >> 3)) * a.stat_stride] = sum;
+        }
+    }
 #ifdef DCS_FWD_DIAG
     diag_out();
 #endif
@@ -473,7 +530,11 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int b = blockIdx.x / tiles_per_img, tile_id = blockIdx.x % tiles_per_img;
     const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
-    if (oy0 >= k.Hc || ox0 >= k.Wc) return;
+    float* const stat_row = a.stat ? a.stat + ((long)blockIdx.z * gridDim.x + blockIdx.x) : nullptr;   // (Cout = 8: 40 sums)
+    if (oy0 >= k.Hc || ox0 >= k.Wc) {
+        if (stat_row && t < 40) stat_row[(long)t * a.stat_stride] = 0.f;
+        return;
+    }
     const int vy0 = oy0 * a.sf - k.pad_f, vx0 = ox0 * a.st - k.pad_t;
     const int Cin = a.C1 + a.C2;
     const int ntaps = k.kh * k.kw;
@@ -609,12 +670,17 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
         const float* q = a.coef + 6 * (n >> 1);
         if (n & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
     }
+    float s1 = 0.f, s2 = 0.f, sri = 0.f;                               // CBN statistics of the raw output (a.stat)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int pi = wave * 32 + i * 16 + g4 * 4 + r;
             const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
+            if (stat_row) {                                            // (uniform) moments of the UN-biased value
+                const float raw = (oy < k.Hc && ox < k.Wc) ? acc[i][r] : 0.f;
+                s1 += raw; s2 = fmaf(raw, raw, s2); sri = fmaf(raw, dcs_dpp_term<0xB1, 0xf>(raw), sri);
+            }
             float v = acc[i][r] + bv;
             if (a.coef) {
                 const float pv = dcs_dpp_term<0xB1, 0xf>(v);
@@ -623,6 +689,22 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
             if (oy < k.Hc && ox < k.Wc)
                 yb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] = dcs_act(v, a.act);
         }
+    if (stat_row) {
+        // column li of 4 row groups (lanes li + 16 g4) x 4 waves: shuffles over g4, then LDS over the waves
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); sri += __shfl_xor(sri, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); sri += __shfl_xor(sri, 32, 64);
+        __syncthreads();                                               // every wave is done with the patch
+        if (lane < 16) { patch[(wave * 16 + li) * 3] = s1; patch[(wave * 16 + li) * 3 + 1] = s2; patch[(wave * 16 + li) * 3 + 2] = sri; }
+        __syncthreads();
+        if (t < 40) {                                                  // channel c: {S_r, S_i, S_rr, S_ii, S_ri}
+            const int c = t / 5, e = t % 5;
+            const int colx = 2 * c + (e == 1 || e == 3), which = e < 2 ? 0 : (e < 4 ? 1 : 2);
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sum += patch[(w * 16 + colx) * 3 + which];
+            stat_row[(long)t * a.stat_stride] = sum;
+        }
+    }
 }
 
 // y[p][n] = act(sum_s part[s][p][n] + bias[n]); columns >= nsplit of a cat split go to y2.  One float4 per thread.
@@ -653,20 +735,60 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     else *reinterpret_cast<float4*>(y2 + p * (N - nsplit) + (n - nsplit)) = v;
 }
 
+// The same slice sum for a layer followed by a training-mode ComplexBatchNorm2d (plain output, no activation): a thread
+// keeps ONE column group (two complex channels) and walks pixel rows, so the CBN statistics of the raw output come out of
+// the same pass — partial {S_r, S_i, S_rr, S_ii, S_ri} of (y - bias) per workgroup, column blockIdx.x of float[C][5][stride]
+// (conv_common.h Args::stat), fixed order, no atomics.  G = N / 4 column groups, rpi = 256 / G pixel rows per pass.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ part, int S, long slab_floats,
+                                                                  const float* __restrict__ bias, float* __restrict__ y,
+                                                                  float* __restrict__ stat, int stat_stride, long P, int N,
+                                                                  int G, int rpi) {
+    __shared__ float red[256 * 10];
+    const int t = threadIdx.x, g = t % G, r0 = t / G;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * g);
+    float s[10];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) s[e] = 0.f;
+    for (long r = (long)blockIdx.x * rpi + r0; r < P; r += (long)gridDim.x * rpi) {
+        const long o = r * N + 4 * g;
+        float4 v = *reinterpret_cast<const float4*>(part + o);
+#pragma unroll 4
+        for (int s_ = 1; s_ < S; ++s_) {
+            const float4 u = *reinterpret_cast<const float4*>(part + (long)s_ * slab_floats + o);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        s[0] += v.x; s[1] += v.y; s[2] = fmaf(v.x, v.x, s[2]); s[3] = fmaf(v.y, v.y, s[3]); s[4] = fmaf(v.x, v.y, s[4]);
+        s[5] += v.z; s[6] += v.w; s[7] = fmaf(v.z, v.z, s[7]); s[8] = fmaf(v.w, v.w, s[8]); s[9] = fmaf(v.z, v.w, s[9]);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        *reinterpret_cast<float4*>(y + o) = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 10; ++e) red[e * 256 + t] = s[e];
+    __syncthreads();
+    for (int o = t; o < G * 10; o += 256) {
+        const int gg = o % G, e = o / G;
+        float a = 0.f;
+        for (int r = 0; r < rpi; ++r) a += red[e * 256 + r * G + gg];
+        stat[(long)((2 * gg + (e >= 5)) * 5 + (e % 5)) * stat_stride + blockIdx.x] = a;
+    }
+}
+
 // (the B-panel re-layout kernel lives in pack_jobs.hip: packjob::MFMA)
 
 struct Plan { int cand, TH, TW, CH, S, cps; long blocks; bool pipe; };
 thread_local bool g_force_wide_panel = false;
 
-template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI>
+template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI, bool STAT = false>
 int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
     size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH + 4 : PR == 1 ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
     if (lds < 4 * 32 * 36 * sizeof(float)) lds = 4 * 32 * 36 * sizeof(float);        // the epilogue's four transpose tiles
+    if (STAT && lds < (4 * 32 * 36 + 4 * WN * 80) * sizeof(float)) lds = (4 * 32 * 36 + 4 * WN * 80) * sizeof(float);   // + the statistics' combine area
 #ifdef DCS_FWD_ONE_PER_CU
     if (lds < 84 * 1024) lds = 84 * 1024;                                            // experiment: one workgroup per CU
 #endif
-    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, PR, TPI>;
+    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, PR, TPI, STAT>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
@@ -681,9 +803,11 @@ int launch_bf(MArgs& m, long npix, hipStream_t stream) {
     // whole kernel rows per tap-loop iteration for the shallow layers (one class, 7-wide kernel, 128 x 32 tile): native fp32,
     // and the emulated form of the 7 x 7 layer (fully unrolled over its 7 rows)
     constexpr bool ROWS = (PR == 0 || PR == 2) && CH == 8 && WM == 1 && WN == 1;
+    const bool stat = m.c.stat != nullptr && m.ksplit <= 1;           // (a sliced launch leaves the statistics to its reduce kernel)
     if (ROWS && m.ncls == 1 && m.cls[0].kw == 7 && (PR == 2 ? m.cls[0].kh == 7 : (m.cls[0].kh * m.cls[0].kw) % 7 == 0))
-        return launch_tpi<WAVES_N, WM, WN, CH, PR, ROWS ? 7 : 1>(m, npix, stream);
-    return launch_tpi<WAVES_N, WM, WN, CH, PR, 1>(m, npix, stream);
+        return stat ? launch_tpi<WAVES_N, WM, WN, CH, PR, ROWS ? 7 : 1, true>(m, npix, stream)
+                    : launch_tpi<WAVES_N, WM, WN, CH, PR, ROWS ? 7 : 1>(m, npix, stream);
+    return stat ? launch_tpi<WAVES_N, WM, WN, CH, PR, 1, true>(m, npix, stream) : launch_tpi<WAVES_N, WM, WN, CH, PR, 1>(m, npix, stream);
 }
 
 template <int WAVES_N, int WM, int WN, int CH>
@@ -855,6 +979,27 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     return packjob::emit(j, stream);
 }
 
+// split-K statistics: workgroups of splitk_reduce_stats_kernel for P pixels of N columns (0: N does not tile 256 threads)
+static int splitk_stat_blocks(long P, int N) {
+    const int G = N / 4;
+    if ((N & 3) || G < 1 || G > 256 || 256 % G) return 0;
+    const long passes = (P + 256 / G - 1) / (256 / G);
+    long nb = (passes + 3) / 4;
+    return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb));
+}
+
+int dcs_conv_mfma_stat_rows(const conv::Args& a, int ncls, const conv::Cls* cls, bool have_ws) {
+    Plan p;
+    long npix;
+    if (!make_plan(a, ncls, cls, &p, &npix)) return 0;
+    const int N = 2 * a.Cout;
+    if (p.S > 1 && have_ws && !(N & 3)) return splitk_stat_blocks((long)a.B * a.Hout * a.Wout, N);
+    int Hc = 0, Wc = 0;
+    for (int c = 0; c < ncls; ++c) { Hc = cls[c].Hc > Hc ? cls[c].Hc : Hc; Wc = cls[c].Wc > Wc ? cls[c].Wc : Wc; }
+    if (p.pipe) return 0;
+    return ((Wc + p.TW - 1) / p.TW) * ((Hc + p.TH - 1) / p.TH) * a.B * ncls;
+}
+
 // bytes of split-K scratch the launch of (a, classes) would use (0: the layer is not sliced)
 long dcs_conv_mfma_workspace_bytes(const conv::Args& a, int ncls, const conv::Cls* cls) {
     Plan p;
@@ -897,6 +1042,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
 #else
     m.dbg = nullptr;
 #endif
+    if (a.stat && (p.pipe || a.coef || a.act != DCS_ACT_NONE || y2 != nullptr)) return DCS_ERR_BADARG;   // raw plain outputs only
     m.ksplit = p.S; m.cps = p.cps; m.part = (float*)ws;
     if (p.S > 1 && (!ws || ws_bytes < (long)p.S * m.slab_floats * (long)sizeof(float) || (m.N & 3) ||
                     (y2 != nullptr && (nsplit & 3)))) {
@@ -928,6 +1074,15 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         default: rc = launch<1, 1, 1>(m, p, npix, stream); break;     // 128 x 32
     }
     if (rc != DCS_OK || m.ksplit <= 1) return rc;
+    if (a.stat) {                                                      // slice sum + CBN statistics of the raw output
+        const long P = (long)a.B * a.Hout * a.Wout;
+        const int nb = splitk_stat_blocks(P, m.N);
+        if (nb < 1 || y2 != nullptr || a.coef || a.act != DCS_ACT_NONE) return DCS_ERR_BADARG;
+        DCS_LAUNCH(splitk_reduce_stats_kernel, dim3(nb), dim3(256), 0, stream, (const float*)m.part, m.ksplit, m.slab_floats,
+                   (const float*)a.bias, (float*)a.y, a.stat, a.stat_stride, P, m.N, m.N / 4, 256 / (m.N / 4));
+        DCS_CHECK_LAUNCH();
+        return DCS_OK;
+    }
     const long n4 = m.slab_floats / 4;
     DCS_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)m.part,
                        m.ksplit, m.slab_floats, (const float*)a.bias, (float*)a.y, y2, nsplit, m.N, a.act, a.coef);

@@ -36,6 +36,8 @@ SIGNATURES = {
     'dcs_cconv2d_fwd_workspace_bytes': (_L, [_I] * 14),
     'dcs_cconv2d_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 15 + [_P]),
     'dcs_cconv2d_fwd_affine': (_I, [_P, _P, _P, _P, _P, _P, _P, _L] + [_I] * 15 + [_P]),
+    'dcs_cconv2d_fwd_stats_rows': (_I, [_I] * 14),
+    'dcs_cconv2d_fwd_stats': (_I, [_P] * 6 + [_I, _P, _P, _L] + [_I] * 14 + [_P]),
     'dcs_rconv2d_fwd_workspace_bytes': (_L, [_I] * 14),
     'dcs_rconv2d_fwd': (_I, [_P, _P, _P, _P, _P, _P, _L] + [_I] * 15 + [_P]),
     'dcs_rconv2d_bwd_data_workspace_bytes': (_L, [_I] * 11),
@@ -52,6 +54,7 @@ SIGNATURES = {
     'dcs_cconv2d_bwd_weight': (_I, [_P] * 8 + [_L] + [_I] * 15 + [_P]),
     'dcs_cbn_workspace_bytes': (_L, [_L, _I]),
     'dcs_cbn_fwd': (_I, [_P] * 9 + [_L, _L, _I, _F, _F, _I, _I, _F, _U64, _P, _P]),
+    'dcs_cbn_fwd_slabs': (_I, [_P] * 9 + [_I, _I, _P, _L, _I, _F, _F, _I, _F, _U64, _P, _P]),
     'dcs_cbn_bwd_workspace_bytes': (_L, [_L, _I]),
     'dcs_cbn_bwd': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P]),
     'dcs_cbn_bwd_add': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P, _F, _L, _P, _P]),

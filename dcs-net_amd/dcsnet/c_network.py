@@ -171,9 +171,9 @@ class C_NETWORK(LightningModule):
         return p, (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77 +
                    rank * 0xC2B2AE3D27D4EB4F) & 0x7FFFFFFFFFFFFFFF
 
-    def _bn(self, bn, x, act, p=0.0, two=False):
+    def _bn(self, bn, x, act, p=0.0, two=False, stat=None):
         dp, seed = self._drop(p)
-        return bn._hip_forward(x, act, dp, seed, count=not self._counted, two=two)
+        return bn._hip_forward(x, act, dp, seed, count=not self._counted, two=two, stat=stat)
 
     def _count_batches(self):
         """num_batches_tracked += 1 for every CBN of the forward path as ONE launch: the 14 scalar buffers are
@@ -223,9 +223,14 @@ class C_NETWORK(LightningModule):
                                               coef, F.ACT_RELU))
                 enc_skip.append(enc[-1])
                 continue
-            c = F.cconv2d(enc[i], None, conv.conv_r.weight, conv.conv_i.weight, conv.conv_r.bias, conv.conv_i.bias,
-                          False, conv.kernel_size, conv.stride, conv.padding)
-            a, b = self._bn(bn, c, F.ACT_RELU, p_conv, two=True)
+            stat = None
+            if self.training:                                # batch statistics straight from the conv's epilogue
+                c, stat = F.cconv2d_with_stats(enc[i], None, conv.conv_r.weight, conv.conv_i.weight, conv.conv_r.bias,
+                                               conv.conv_i.bias, False, conv.kernel_size, conv.stride, conv.padding)
+            else:
+                c = F.cconv2d(enc[i], None, conv.conv_r.weight, conv.conv_i.weight, conv.conv_r.bias, conv.conv_i.bias,
+                              False, conv.kernel_size, conv.stride, conv.padding)
+            a, b = self._bn(bn, c, F.ACT_RELU, p_conv, two=True, stat=stat)
             enc.append(a)
             enc_skip.append(b)
 
@@ -266,6 +271,7 @@ class C_NETWORK(LightningModule):
             skips = self._skip_attentions(enc_skip)
         for i in range(L):                                   # c_network.py:207-222
             skip = skips[i]
+            stat = None
             stage = self.decoder[i]
             convt = stage if i == L - 1 else stage[0]
             up = tuple(cfg.upsample_scale_factor[i])
@@ -283,15 +289,21 @@ class C_NETWORK(LightningModule):
                     self._drop(0.0)
                     d = self._attend(self.decoder_attention[2 * i], self.decoder_attention[2 * i + 1], a)
                     continue
-                y = F.cconv2d(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight, convt.conv_tran_r.bias,
-                              convt.conv_tran_i.bias, True, convt.kernel_size, (1, 1), convt.corr_padding, up)
+                stat = None
+                if self.training and i != L - 1:             # batch statistics straight from the conv's epilogue
+                    y, stat = F.cconv2d_with_stats(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight,
+                                                   convt.conv_tran_r.bias, convt.conv_tran_i.bias, True, convt.kernel_size,
+                                                   (1, 1), convt.corr_padding, up)
+                else:
+                    y = F.cconv2d(d, skip, convt.conv_tran_r.weight, convt.conv_tran_i.weight, convt.conv_tran_r.bias,
+                                  convt.conv_tran_i.bias, True, convt.kernel_size, (1, 1), convt.corr_padding, up)
             dp, seed = self._drop(p_conv)
             if i != L - 1:                                   # CBN + CLReLU + decoder attention (+ dropout): one node
                 ca_m, sa_m = self.decoder_attention[2 * i], self.decoder_attention[2 * i + 1]
                 self._drop(0.0)                              # the CBN's (unused) dropout site keeps the seed sequence
                 d = stage[1]._hip_forward(y, F.ACT_LRELU, 0.0, 0, count=not self._counted, attention=(
                     ca_m.fc[0].conv_r.weight, ca_m.fc[0].conv_i.weight, ca_m.fc[2].conv_r.weight, ca_m.fc[2].conv_i.weight,
-                    sa_m.conv1.conv_r.weight, sa_m.conv1.conv_i.weight, sa_m.kernel_size, dp, seed))
+                    sa_m.conv1.conv_r.weight, sa_m.conv1.conv_i.weight, sa_m.kernel_size, dp, seed), stat=stat)
             else:
                 d = F.dropout(y, dp, seed) if dp > 0 else y
 

@@ -124,7 +124,7 @@ class _ComplexBatchNorm(Module):
                 self.weight[:, 2] = 0
                 self.bias.zero_()
 
-    def _hip_forward(self, x_nhwc, act=F.ACT_NONE, drop_p=0.0, seed=0, count=True, attention=None, two=False):
+    def _hip_forward(self, x_nhwc, act=F.ACT_NONE, drop_p=0.0, seed=0, count=True, attention=None, two=False, stat=None):
         """x: float [B,H,W,C,2].  Shared with the fused C_NETWORK.forward (which advances all the
         num_batches_tracked counters of the network with one launch and passes count=False).
         attention = (fc0_r, fc0_i, fc2_r, fc2_i, conv1_r, conv1_i, ksize, drop_p, seed): the attention block that
@@ -144,14 +144,16 @@ class _ComplexBatchNorm(Module):
             if two:
                 return y, y
             return y if attention is None else F.attention_block(y, *attention)
+        if not use_batch:
+            stat = None                        # (stat: the batch statistics the producing conv's epilogue left, F.cconv2d_with_stats)
         if attention is not None:
             return F.cbn_attention(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
-                                   act, *attention)
+                                   act, *attention, stat)
         if two and torch.is_grad_enabled():    # the output has two consumers: one tensor each (F._CbnTwoFn)
             return F.cbn_two(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
-                             act, drop_p, seed)
+                             act, drop_p, seed, stat)
         y = F.cbn(x_nhwc, self.weight, self.bias, rm, self.running_covar, self.eps, momentum, use_batch,
-                  act, drop_p, seed)
+                  act, drop_p, seed, stat)
         return (y, y) if two else y
 
     def eval_coef(self):

@@ -115,9 +115,12 @@ class _CConv2dFn(torch.autograd.Function):
     """dcs_cconv2d_fwd with its hand-written data / weight gradients."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up, act):
+    def forward(ctx, x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up, act, holder=None):
         wp, bias = packed_weight(w_r, w_i, b_r, b_i, transposed, up)
-        y = ops.cconv2d(x1, x2, wp, bias, ksize, stride, pad, up, act)
+        if holder is not None:                 # a training-mode CBN follows: its statistics come out of this conv's epilogue
+            y, holder['stat'] = ops.cconv2d_stats(x1, x2, wp, bias, ksize, stride, pad, up)
+        else:
+            y = ops.cconv2d(x1, x2, wp, bias, ksize, stride, pad, up, act)
         ctx.geom = (transposed, tuple(ksize), tuple(stride), tuple(pad), tuple(up), act, tuple(w_r.shape),
                     b_r is not None)
         ctx.sinks = (_sink(w_r), _sink(w_i), _sink(b_r), _sink(b_i))
@@ -144,12 +147,23 @@ class _CConv2dFn(torch.autograd.Function):
             g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks)
             # gradients written straight into their sink are not handed back to autograd
             gw_r, gw_i, gb_r, gb_i = (None if sk is not None else t for t, sk in zip(g, ctx.sinks))
-        return gx1, gx2, gw_r, gw_i, gb_r, gb_i, None, None, None, None, None, None
+        return gx1, gx2, gw_r, gw_i, gb_r, gb_i, None, None, None, None, None, None, None
 
 
 def cconv2d(x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up=(1, 1), act=ACT_NONE):
     return _CConv2dFn.apply(x1, x2, w_r, w_i, b_r, b_i, transposed, tuple(ksize), tuple(stride), tuple(pad),
                             tuple(up), act)
+
+
+def cconv2d_with_stats(x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up=(1, 1)):
+    """(y, stat): the conv with no activation, and the batch statistics of y its epilogue left for the training-mode
+    ComplexBatchNorm2d that follows (c_network.py:107-114: conv and CBN back to back) — stat goes to cbn(..., stat=stat);
+    None when the geometry has no statistics epilogue.  Not differentiable through the statistics (the CBN's backward is
+    the closed form over x and its saved moments, whichever way the moments were summed)."""
+    holder = {}
+    y = _CConv2dFn.apply(x1, x2, w_r, w_i, b_r, b_i, transposed, tuple(ksize), tuple(stride), tuple(pad), tuple(up),
+                         ACT_NONE, holder)
+    return y, holder.get('stat')
 
 
 def cconv2d_cbn_eval(x1, x2, w_r, w_i, b_r, b_i, transposed, ksize, stride, pad, up, coef, act):
@@ -163,9 +177,9 @@ class _CbnFn(torch.autograd.Function):
     """dcs_cbn_fwd / dcs_cbn_bwd.  Saves only x and 14 floats per channel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, drop_p, seed):
+    def forward(ctx, x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, drop_p, seed, stat=None):
         y, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats,
-                                 act, drop_p, seed)
+                                 act, drop_p, seed, stat=stat)
         ctx.cfg = (bool(use_batch_stats), act, float(drop_p), int(seed), weight is not None)
         ctx.sinks = (_sink(weight), _sink(bias))
         ctx.save_for_backward(x, weight, stats, coef)
@@ -179,13 +193,13 @@ class _CbnFn(torch.autograd.Function):
                                     ctx.sinks)
         g_w = None if ctx.sinks[0] is not None else g_w
         g_b = None if ctx.sinks[1] is not None else g_b
-        return g_x, g_w, g_b, None, None, None, None, None, None, None, None
+        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None
 
 
 def cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act=ACT_NONE,
-        drop_p=0.0, seed=0):
+        drop_p=0.0, seed=0, stat=None):
     return _CbnFn.apply(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
-                        drop_p, seed)
+                        drop_p, seed, stat)
 
 
 class _CbnTwoFn(torch.autograd.Function):
@@ -195,9 +209,9 @@ class _CbnTwoFn(torch.autograd.Function):
     element-wise add launch over the activation per stage."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, drop_p, seed):
+    def forward(ctx, x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, drop_p, seed, stat=None):
         y, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats,
-                                 act, drop_p, seed)
+                                 act, drop_p, seed, stat=stat)
         ctx.cfg = (bool(use_batch_stats), act, float(drop_p), int(seed), weight is not None)
         ctx.sinks = (_sink(weight), _sink(bias))
         ctx.save_for_backward(x, weight, stats, coef)
@@ -210,21 +224,21 @@ class _CbnTwoFn(torch.autograd.Function):
         x, weight, stats, coef = ctx.saved_tensors
         use_batch, act, drop_p, seed, affine = ctx.cfg
         if g_a is None and g_b is None:
-            return (None,) * 11
+            return (None,) * 12
         if g_a is None:
             g_a, g_b = g_b, None
         g_x, g_w, g_b_ = ops.cbn_bwd(x, g_a.contiguous(), weight, stats, coef, use_batch, act, drop_p, seed, affine,
                                      ctx.sinks, g_out2=None if g_b is None else g_b.contiguous())
         g_w = None if ctx.sinks[0] is not None else g_w
         g_b_ = None if ctx.sinks[1] is not None else g_b_
-        return g_x, g_w, g_b_, None, None, None, None, None, None, None, None
+        return g_x, g_w, g_b_, None, None, None, None, None, None, None, None, None
 
 
 def cbn_two(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act=ACT_NONE,
-            drop_p=0.0, seed=0):
+            drop_p=0.0, seed=0, stat=None):
     """(y, y') — the same values, for two different consumers (see _CbnTwoFn)."""
     return _CbnTwoFn.apply(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
-                           drop_p, seed)
+                           drop_p, seed, stat)
 
 
 def channel_attention(x, fc0_r, fc0_i, fc2_r, fc2_i):
@@ -288,8 +302,9 @@ class _CbnAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
-                fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed):
-        a, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, 0.0, 0)
+                fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed, stat=None):
+        a, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, 0.0, 0,
+                                 stat=stat)
         w1, _ = packed_weight(fc0_r, fc0_i, None, None, False)
         w2, _ = packed_weight(fc2_r, fc2_i, None, None, False)
         wsa, zero_bias = packed_weight(c1_r, c1_i, None, None, False)
@@ -312,13 +327,13 @@ class _CbnAttentionFn(torch.autograd.Function):
         g_x, g_w, g_b = ops.cbn_bwd(x, g[0], weight, stats, coef, use_batch, act, 0.0, 0, affine, sk[:2], g_add=g[7])
         full = (g_w, g_b, *g[1:7])
         gp = tuple(None if s_ is not None else t for t, s_ in zip(full, sk))
-        return (g_x, gp[0], gp[1], None, None, None, None, None, None, *gp[2:], None, None, None)
+        return (g_x, gp[0], gp[1], None, None, None, None, None, None, *gp[2:], None, None, None, None)
 
 
 def cbn_attention(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
-                  fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p=0.0, seed=0):
+                  fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p=0.0, seed=0, stat=None):
     return _CbnAttentionFn.apply(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
-                                 fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed)
+                                 fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed, stat)
 
 
 class _AttentionBlocksFn(torch.autograd.Function):

@@ -237,6 +237,50 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     return y
 
 
+def cconv2d_stats(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1)):
+    """cconv2d (no activation) that also leaves the training-mode CBN statistics of its raw output in its epilogue
+    (dcs_cconv2d_fwd_stats).  Returns (y, stat): stat = (part float[Cout, 5, rows capacity], rows, pivot = bias) for cbn(stat=...),
+    or None when this geometry has no statistics epilogue (the plain conv ran: the CBN makes its own statistics pass)."""
+    import ctypes
+    _chk(x1, 'x1', 5)
+    _chk(x2, 'x2', 5)
+    _chk(wp, 'wp', 4)
+    _chk(bias, 'bias', 2)
+    B, Hin, Win, C1, _ = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    kh, kw = ksize
+    Cout = wp.shape[2]
+    lib = _lib.load()
+    geo = (B, Hin, Win, C1, C2, up[0], up[1], Cout, kh, kw, stride[0], stride[1], pad[0], pad[1])
+    rows = lib.dcs_cconv2d_fwd_stats_rows(*geo) if STATS_EPILOGUE else 0
+    if rows < 1:
+        return cconv2d(x1, x2, wp, bias, ksize, stride, pad, up, ACT_NONE), None
+    if x2 is not None and x2.shape[:3] != x1.shape[:3]:
+        raise _lib.DcsHipError(f'cconv2d: x1 {tuple(x1.shape)} and x2 {tuple(x2.shape)} differ in B/H/W')
+    if wp.shape[0] != kh * kw or wp.shape[1] != C1 + C2:
+        raise _lib.DcsHipError(f'cconv2d: packed weight {tuple(wp.shape)} does not match k={ksize}, Cin={C1 + C2}')
+    Hout = (Hin * up[0] + 2 * pad[0] - kh) // stride[0] + 1
+    Wout = (Win * up[1] + 2 * pad[1] - kw) // stride[1] + 1
+    y = torch.empty((B, Hout, Wout, Cout, 2), dtype=torch.float32, device=x1.device)
+    part = torch.empty((Cout, 5, rows), dtype=torch.float32, device=x1.device)
+    nbytes = max(lib.dcs_cconv2d_fwd_workspace_bytes(*geo), 0)
+    ws = _workspace(nbytes, x1.device) if nbytes > 0 else None
+    ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None,
+                           executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
+                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and C1 % 2 == 0)
+          if CONV_TIMER is not None else None)
+    used = ctypes.c_int(0)
+    check(lib.dcs_cconv2d_fwd_stats(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(y), ptr(part), rows, ctypes.byref(used), ptr(ws),
+                                    nbytes, *geo, cur_stream()), 'dcs_cconv2d_fwd_stats')
+    if ev is not None:
+        CONV_TIMER.end(ev)
+    return y, (part, used.value, bias)
+
+
+import os as _os
+STATS_EPILOGUE = _os.environ.get('DCS_STATS_EPILOGUE', '1') != '0'       # 0 (A/B runs): every training-mode CBN makes its own statistics pass
+
+
 def _emulated(k_channels, n_channels, taps=0):
     """Whether the MFMA GEMM with K = 2 * k_channels, N = 2 * n_channels runs on the bf16 MFMA in fp32-emulation mode
     (conv::mfma_precision, conv_mfma.hip: 16-channel chunks, 32-column tiles) — for bench.py's instruction accounting."""
@@ -393,10 +437,11 @@ def wgrad_defer_flush():
 
 
 def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, use_batch_stats=True,
-        act=ACT_NONE, drop_p=0.0, seed=0, out=None, coef_cached=None):
+        act=ACT_NONE, drop_p=0.0, seed=0, out=None, coef_cached=None, stat=None):
     """ComplexBatchNorm2d (+act +dropout).  running_mean: float [C,2] view of the complex buffer.
     Returns (y, stats [C,8], coef [C,6]).  coef_cached = (stats, coef) of an earlier eval-mode call with the same
-    parameters and running statistics: only the apply kernel runs."""
+    parameters and running statistics: only the apply kernel runs.  stat = (part, rows, pivot) from cconv2d_stats (batch
+    statistics only): the partial sums the producing conv left — no statistics pass over x (dcs_cbn_fwd_slabs)."""
     _chk(x, 'x', 5)
     for n, t in (('weight', weight), ('bias', bias), ('running_mean', running_mean), ('running_covar', running_covar)):
         _chk(t, n)
@@ -404,6 +449,19 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
     P = B * H * W
     y = torch.empty_like(x) if out is None else out
     lib = _lib.load()
+    if stat is not None and use_batch_stats:
+        part, rows, pivot = stat
+        _chk(part, 'stat part', 3)
+        _chk(pivot, 'stat pivot', 2)
+        if part.shape[2] < rows or tuple(part.shape[:2]) != (C, 5) or tuple(pivot.shape) != (C, 2):
+            raise _lib.DcsHipError(f'cbn: statistics slabs {tuple(part.shape)} / pivot {tuple(pivot.shape)} do not match C={C}')
+        stats = torch.empty((C, 8), dtype=torch.float32, device=x.device)
+        coef = torch.empty((C, 6), dtype=torch.float32, device=x.device)
+        check(lib.dcs_cbn_fwd_slabs(ptr(x), ptr(y), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_covar), ptr(stats),
+                                    ptr(coef), ptr(part), int(rows), int(part.shape[2]), ptr(pivot), P, C, eps,
+                                    -1.0 if momentum is None else momentum, act, float(drop_p), int(seed), ptr(SEED_STATE),
+                                    cur_stream()), 'dcs_cbn_fwd_slabs')
+        return y, stats, coef
     nbytes = lib.dcs_cbn_workspace_bytes(P, C)
     if nbytes < 0:
         raise _lib.DcsHipError(f'cbn: unsupported channel count C={C}')

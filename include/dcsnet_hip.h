@@ -116,6 +116,22 @@ int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const flo
                     int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
                     dcs_stream_t stream);
 
+/* Training-mode conv -> ComplexBatchNorm2d pairs (reference: c_network.py:107-114, :135-150 — ComplexConv2d /
+ * ComplexConvTranspose2d followed at once by ComplexBatchNorm2d): dcs_cconv2d_fwd (act = NONE) that also leaves the batch
+ * statistics of its raw output, taken from the fp32 accumulators in the epilogue, so the CBN needs no pass over y:
+ *   stat        float[Cout][5][stat_rows]: column r = one workgroup's partial sums {S_r, S_i, S_rr, S_ii, S_ri} of (y - bias)
+ *               over its valid output pixels — fixed summation order, no atomics (bitwise reproducible)
+ *   stat_rows   capacity of `stat` in rows, >= dcs_cconv2d_fwd_stats_rows(geometry) (0 there: this geometry has no
+ *               statistics epilogue — use dcs_cconv2d_fwd + dcs_cbn_fwd)
+ *   rows_used   HOST int, out: rows written (depends on whether the split-K scratch was handed over)
+ * Consumer: dcs_cbn_fwd_slabs(part = stat, rows = *rows_used, stride = stat_rows, pivot = bias). */
+int dcs_cconv2d_fwd_stats_rows(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                               int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t);
+int dcs_cconv2d_fwd_stats(const float* x1, const float* x2, const float* wp, const float* bias, float* y,
+                          float* stat, int stat_rows, int* rows_used, void* workspace, long workspace_bytes,
+                          int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                          int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, dcs_stream_t stream);
+
 /* dcs_cconv2d_fwd with an eval-mode ComplexBatchNorm2d folded into the epilogue: between bias and activation every output
  * channel goes through the real 2x2 affine map  (re, im) <- (a0 re + a1 im + c0, a2 re + a3 im + c1),
  * coef float[Cout][6] = {a0, a1, a2, a3, c0, c1} — exactly the `coef_out` an eval-mode dcs_cbn_fwd writes (running statistics
@@ -241,6 +257,15 @@ int  dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bia
                  float* stats_out, float* coef_out, void* workspace, long workspace_bytes,
                  long P, int C, float eps, float momentum, int use_batch_stats, int act,
                  float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
+
+/* Training-mode dcs_cbn_fwd whose batch statistics were left by the conv that produced x (dcs_cconv2d_fwd_stats):
+ * part float[C][5][stride] partial sums of (x - pivot), columns 0..rows-1 valid, pivot float[C][2] (that conv's packed bias).
+ * Finalize + apply only. */
+int  dcs_cbn_fwd_slabs(const float* x, float* y, const float* weight, const float* bias,
+                       float* running_mean, float* running_covar, float* stats_out, float* coef_out,
+                       const float* part, int rows, int stride, const float* pivot,
+                       long P, int C, float eps, float momentum, int act,
+                       float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
 
 /* Backward of dcs_cbn_fwd (closed form of what autograd derives through complexPyTorch's CBN,
  * the activation and the dropout).  g_out: gradient w.r.t. y; g_x: gradient w.r.t. x (may alias

@@ -252,6 +252,67 @@ def test_cbn_train_and_eval(dev, C, shape, act):
     close(back(y2), want_ev, rel=3e-5)
 
 
+# (B, Hin, Win, C1, C2, Cout, k, stride, pad, up, transposed): every conv -> CBN pair of the network at reduced size (the
+# 7x7 one-channel layer, the emulated row kernel, split-K layers, upsample-folded decoder classes incl. a class smaller than
+# the tile grid, the 16-column kernel) + ragged maps
+_STAT_GEOMS = [
+    (2, 32, 40, 1, 0, 8, 7, (2, 2), 3, (1, 1), False),          # enc0: conv_enc0.hip, persistent workgroups
+    (3, 18, 22, 1, 0, 8, 7, (2, 2), 3, (1, 1), False),          # ... ragged
+    (2, 32, 32, 8, 0, 16, 7, (2, 2), 3, (1, 1), False),         # enc1
+    (2, 16, 24, 16, 0, 32, 5, (2, 2), 2, (1, 1), False),        # enc2
+    (2, 16, 16, 32, 0, 64, 5, (2, 1), 2, (1, 1), False),        # enc3
+    (2, 8, 32, 64, 0, 128, 3, (2, 1), 1, (1, 1), False),        # enc4
+    (2, 8, 32, 128, 0, 128, 3, (2, 1), 1, (1, 1), False),       # enc5 (split-K at this size)
+    (32, 4, 32, 128, 0, 128, 3, (2, 1), 1, (1, 1), False),      # enc6 at the train batch (split-K + reduce with statistics)
+    (2, 2, 32, 128, 128, 128, 3, (1, 1), 1, (2, 1), True),      # dec0: classes, split-K
+    (2, 8, 32, 128, 128, 64, 3, (1, 1), 1, (2, 1), True),       # dec2
+    (2, 16, 16, 32, 32, 16, 3, (1, 1), 1, (2, 2), True),        # dec4: four classes, 32-column tiles
+    (2, 24, 20, 16, 16, 8, 3, (1, 1), 1, (2, 2), True),         # dec5: the 16-column kernel, ragged
+    (1, 5, 7, 16, 16, 8, 3, (1, 1), 1, (2, 2), True),           # ... tiny: tiles outside the map
+]
+
+
+@pytest.mark.parametrize('geom', _STAT_GEOMS, ids=[f'g{i}' for i in range(len(_STAT_GEOMS))])
+@pytest.mark.parametrize('mode', ['bf16x6', 'f32'])
+def test_cbn_statistics_from_the_conv_epilogue(dev, geom, mode):
+    """dcs_cconv2d_fwd_stats + dcs_cbn_fwd_slabs against dcs_cconv2d_fwd + dcs_cbn_fwd (itself pinned to the oracle by
+    test_cbn_train_and_eval): the conv output bit-identical, the moments / coefficients / running statistics / output equal
+    to summation order, and every geometry of the network really takes the statistics epilogue."""
+    from dcsnet import ops, functional as F
+    B, H, W, C1, C2, Cout, k, st, pad, up, tr = geom
+    g = torch.Generator().manual_seed(11)
+    x1 = (torch.randn(B, H, W, C1, 2, generator=g) + 0.3).to(dev)
+    x2 = (torch.randn(B, H, W, C2, 2, generator=g) - 0.2).to(dev) if C2 else None
+    Cin = C1 + C2
+    shape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    w_r, w_i = (torch.randn(shape, generator=g) * 0.1).to(dev), (torch.randn(shape, generator=g) * 0.1).to(dev)
+    b_r, b_i = (torch.randn(Cout, generator=g) * 2).to(dev), (torch.randn(Cout, generator=g) * 2).to(dev)
+    bnw = (torch.randn(Cout, 3, generator=g) * 0.3 + torch.tensor([1.2, 1.1, 0.1])).to(dev)
+    bnb = torch.randn(Cout, 2, generator=g).to(dev)
+    default = ops.conv_precision()
+    ops.set_conv_precision(mode)
+    try:
+        wp, bias = ops.pack_conv_weight(w_r, w_i, b_r, b_i, tr, up)
+        ks, pd = (k, k), ((k - 1 - pad, k - 1 - pad) if tr else (pad, pad))
+        y0 = ops.cconv2d(x1, x2, wp, bias, ks, st, pd, up, ops.ACT_NONE)
+        rm0, rc0 = torch.zeros(Cout, 2, device=dev), torch.ones(Cout, 3, device=dev)
+        a0, stats0, coef0 = ops.cbn(y0, bnw, bnb, rm0, rc0, 1e-5, 0.1, True, ops.ACT_LRELU)
+        y1, stat = ops.cconv2d_stats(x1, x2, wp, bias, ks, st, pd, up)
+        assert stat is not None, 'this geometry must take the statistics epilogue'
+        assert torch.equal(y0, y1)
+        rm1, rc1 = torch.zeros(Cout, 2, device=dev), torch.ones(Cout, 3, device=dev)
+        a1, stats1, coef1 = ops.cbn(y1, bnw, bnb, rm1, rc1, 1e-5, 0.1, True, ops.ACT_LRELU, stat=stat)
+        y2, stat2 = ops.cconv2d_stats(x1, x2, wp, bias, ks, st, pd, up)
+        assert torch.equal(stat2[0][:, :, :stat2[1]], stat[0][:, :, :stat[1]])     # fixed summation order: bitwise repeatable
+    finally:
+        ops.set_conv_precision(default)
+    close(stats1, stats0, rel=2e-5, abs_=1e-6)
+    close(coef1, coef0, rel=2e-5, abs_=1e-6)
+    close(rm1, rm0, rel=2e-5, abs_=1e-7)
+    close(rc1, rc0, rel=2e-5, abs_=1e-7)
+    close(a1, a0, rel=2e-5, abs_=1e-6)
+
+
 def test_cbn_large_offset_is_stable(dev):
     """mean >> std: the pivoted one-pass statistics must not cancel catastrophically."""
     from dcsnet import ops

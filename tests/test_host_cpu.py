@@ -264,3 +264,52 @@ def test_stoi_restatement_properties():
     assert len(y) == 3 * 10000 and abs(k * 10000 / len(y) - 440) < 1.0
     with pytest.raises(ValueError):
         stoi(x, x[:-1], fs)
+
+
+def test_no_cross_half_packed_f32_in_mfma_kernels(tmp_path):
+    """Static guard for the gfx950 behaviour pinned in profiles/r03_pk_fma_op_sel_hazard.txt: a v_pk_fma_f32 whose LOW lane
+    takes the HIGH dword of a source pair (an op_sel bit set) can lose that lane's product while co-resident waves issue
+    bf16 MFMAs.  No kernel of the built library that issues MFMAs may contain a packed-f32 op with an op_sel bit set (their
+    sources are built without the SLP vectoriser, build.py); the VALU kernels that do contain them never run beside an
+    MFMA kernel (one stream; the inference side stream joins before the fc conv)."""
+    import re
+    import struct
+    import subprocess
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump not available')
+    from dcsnet import _lib
+    data = open(_lib.LIB_PATH, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    n_obj = n_mfma = 0
+    bad = []
+    for m in re.finditer(magic, data):
+        p = m.start()
+        q = p + len(magic)
+        cnt = struct.unpack_from('<Q', data, q)[0]
+        q += 8
+        for _ in range(cnt):
+            off, size, tl = struct.unpack_from('<QQQ', data, q)
+            q += 24
+            triple = data[q:q + tl].decode()
+            q += tl
+            if 'gfx950' not in triple or size == 0:
+                continue
+            blob = data[p + off:p + off + size]
+            if b'v_mfma' not in blob and b'mfma' not in blob:          # (mnemonics are not in the binary; cheap pre-filter on names)
+                pass
+            f = tmp_path / f'co{n_obj}.o'
+            f.write_bytes(blob)
+            n_obj += 1
+            asm = subprocess.run([objdump, '-d', '--mcpu=gfx950', str(f)], capture_output=True, text=True, check=True).stdout
+            parts = re.split(r'\n[0-9a-f]+ <([^>]+)>:\n', asm)
+            for name, body in zip(parts[1::2], parts[2::2]):
+                if 'v_mfma' not in body:
+                    continue
+                n_mfma += 1
+                hits = [ln for ln in body.split('\n')
+                        if re.search(r'v_pk_(fma|mul|add)_f32', ln) and re.search(r'op_sel:\[[^\]]*1', ln)]
+                if hits:
+                    bad.append((name, len(hits), hits[0].strip()))
+    assert n_obj > 0 and n_mfma > 20, (n_obj, n_mfma)
+    assert not bad, bad[:5]
