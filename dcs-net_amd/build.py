@@ -24,6 +24,12 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
+# Sources that touch ACTIVATIONS are compiled a second time with -DDCS_ACT_BF16 (csrc/dcs_common.h: act_t = bf16 storage,
+# entry points suffixed _h): BASELINE configs[4]'s bf16 activations in HBM.
+ACT_SOURCES = ('cbn.hip', 'cbn_bwd.hip', 'attention.hip', 'attention_bwd.hip', 'conv_direct.hip', 'conv_mfma.hip',
+               'conv_enc0.hip', 'conv_small.hip', 'conv_wgrad_mfma.hip')
+
+
 def _mfma_source_flags():
     """Sources whose kernels issue MFMAs are compiled WITHOUT the SLP vectoriser: it pairs adjacent scalar fp32 operations
     into v_pk_*_f32, and a packed FMA whose low lane takes the HIGH dword of a source pair (op_sel) loses that lane's
@@ -71,12 +77,14 @@ def build(force=False, verbose=True, flags=None, lib=None, objdir=None, per_sour
         h.update(' '.join(flags + per_source_flags.get(src, [])).encode())
         return h.hexdigest()
 
-    def compile_one(src):
-        obj = os.path.join(objdir, src[:-4] + '.o')
-        st_file, st = obj + '.stamp', stamp_of(src)
+    def compile_one(job):
+        src, variant = job
+        extra = ['-DDCS_ACT_BF16'] if variant else []
+        obj = os.path.join(objdir, src[:-4] + variant + '.o')
+        st_file, st = obj + '.stamp', stamp_of(src) + variant
         if not force and os.path.exists(obj) and os.path.exists(st_file) and open(st_file).read() == st:
             return obj, False
-        cmd = [hipcc] + flags + per_source_flags.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + flags + per_source_flags.get(src, []) + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{r.stdout}\n{r.stderr}')
@@ -86,8 +94,10 @@ def build(force=False, verbose=True, flags=None, lib=None, objdir=None, per_sour
             f.write(st)
         return obj, True
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        res = list(ex.map(compile_one, srcs))
+    jobs = [(s_, '') for s_ in srcs] + [(s_, '_h') for s_ in srcs if s_ in ACT_SOURCES]
+    jobs.sort(key=lambda j: -os.path.getsize(os.path.join(CSRC, j[0])))        # the long compiles first
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        res = list(ex.map(compile_one, jobs))
     objs = [o for o, _ in res]
     stamp_file = os.path.join(objdir, 'stamp.txt')
     stamp = hashlib.sha256(''.join(stamp_of(s_) for s_ in srcs).encode()).hexdigest()

@@ -53,12 +53,12 @@ inline int ca_chunks(long HW, int G) {
 }
 
 // part[b][chunk][C][2] (double): sum over this chunk's pixels of x[b][p][c]
-__device__ __forceinline__ void ca_pool_kernel_body(const float* __restrict__ x, double* __restrict__ part,
+__device__ __forceinline__ void ca_pool_kernel_body(const act_t* __restrict__ x, double* __restrict__ part,
                                                             long HW, int C, int G, int bx, int by, int gx) {
     __shared__ double red[kThreads * 4];
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = by;
-    const float4* x4 = reinterpret_cast<const float4*>(x) + (long)b * HW * G;
+    const ActIn4<act_t> x4 = act_in4(x) + (long)b * HW * G;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (long r = (long)bx * rpi + r0; r < HW; r += (long)gx * rpi) {
         const float4 v = x4[r * G + g];
@@ -144,12 +144,12 @@ __device__ __forceinline__ float group_max(float v, int G) {
 }
 
 // pooled[b][p] = { mean_c z , max_c Re z + j max_c Im z },  z = ca[b][c] * x[b][p][c]
-__device__ __forceinline__ void spatial_pool_kernel_body(const float* __restrict__ x,
+__device__ __forceinline__ void spatial_pool_kernel_body(const act_t* __restrict__ x,
                                                                  const float* __restrict__ ca,
                                                                  float4* __restrict__ pooled, long HW, int C, int G, int bx, int by, int gx) {
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = by;
-    const float4* x4 = reinterpret_cast<const float4*>(x) + (long)b * HW * G;
+    const ActIn4<act_t> x4 = act_in4(x) + (long)b * HW * G;
     float4 a = make_float4(1.f, 0.f, 1.f, 0.f);
     if (ca) a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
     const float invC = 1.f / (float)C;
@@ -169,16 +169,16 @@ __device__ __forceinline__ void spatial_pool_kernel_body(const float* __restrict
 }
 
 template <bool DROP>
-__device__ __forceinline__ void attention_apply_kernel_body(const float* __restrict__ x,
+__device__ __forceinline__ void attention_apply_kernel_body(const act_t* __restrict__ x,
                                                                     const float* __restrict__ ca,
-                                                                    const float2* __restrict__ sa, float* __restrict__ y,
+                                                                    const float2* __restrict__ sa, act_t* __restrict__ y,
                                                                     long HW, int C, int G, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev, int bx, int by, int gx) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = by;
     const long base = (long)b * HW * G;
-    const float4* x4 = reinterpret_cast<const float4*>(x) + base;
-    float4* y4 = reinterpret_cast<float4*>(y) + base;
+    const ActIn4<act_t> x4 = act_in4(x) + base;
+    const ActOut4<act_t> y4 = act_out4(y) + base;
     float4 a = make_float4(1.f, 0.f, 1.f, 0.f);
     if (ca) a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
@@ -219,11 +219,11 @@ template <class P> __device__ __forceinline__ int tbl_find(const Tbl<P>& t, int 
     return z;
 }
 
-struct CaPoolP { const float* x; double* part; long HW; int C, G, nx; };
+struct CaPoolP { const act_t* x; double* part; long HW; int C, G, nx; };
 struct CaFcP { const double* part; int nchunks; const float2* w1; const float2* w2; float2* ca; float2* pooled; float2* hidden;
                long HW; int C, Ch; };
-struct SpPoolP { const float* x; const float* ca; float4* pooled; long HW; int C, G, nx; };
-struct ApplyP { const float* x; const float* ca; const float2* sa; float* y; long HW; int C, G, nx; };
+struct SpPoolP { const act_t* x; const float* ca; float4* pooled; long HW; int C, G, nx; };
+struct ApplyP { const act_t* x; const float* ca; const float2* sa; act_t* y; long HW; int C, G, nx; };
 
 __global__ __launch_bounds__(kThreads) void ca_pool_kernel(CaPoolP p) {
     ca_pool_kernel_body(p.x, p.part, p.HW, p.C, p.G, blockIdx.x, blockIdx.y, gridDim.x);
@@ -258,6 +258,7 @@ __global__ __launch_bounds__(kThreads) void attention_apply_multi_kernel(Tbl<App
     attention_apply_kernel_body<false>(p.x, p.ca, p.sa, p.y, p.HW, p.C, p.G, 0.f, 0, nullptr, blockIdx.x - t.x0[z], blockIdx.y, p.nx);
 }
 
+#ifndef DCS_ACT_BF16
 __global__ __launch_bounds__(kThreads) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
                                                             float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(kThreads) void dropout_kernel(const float* __restri
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads)
         y[i] = x[i] * (drop_p > 0.f ? dcs_keep_scale(seed, (uint64_t)i, drop_p, inv_keep) : 1.f);
 }
+#endif
 
 inline int stream_grid(long HW, int G, int B) {
     const int rpi = kThreads / G;
@@ -277,13 +279,15 @@ inline int stream_grid(long HW, int G, int B) {
 
 }  // namespace
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_ca_workspace_bytes(int B, long HW, int C) {
     int G;
     if (B <= 0 || HW <= 0 || !att_geom(C, &G)) return -1;
     return (long)B * ca_chunks(HW, G) * C * 2 * (long)sizeof(double);
 }
+#endif
 
-extern "C" int dcs_channel_attention_fwd(const float* x, const float* w1, const float* w2, float* ca_out,
+extern "C" int DCS_SYM(dcs_channel_attention_fwd)(const act_t* x, const float* w1, const float* w2, float* ca_out,
                                          float* pooled_out, float* hidden_out, void* workspace, long workspace_bytes,
                                          int B, long HW, int C, int Ch, dcs_stream_t stream) {
     int G;
@@ -302,7 +306,7 @@ extern "C" int dcs_channel_attention_fwd(const float* x, const float* w1, const 
     return DCS_OK;
 }
 
-extern "C" int dcs_spatial_pool_fwd(const float* x, const float* ca, float* pooled, int B, long HW, int C,
+extern "C" int DCS_SYM(dcs_spatial_pool_fwd)(const act_t* x, const float* ca, float* pooled, int B, long HW, int C,
                                     dcs_stream_t stream) {
     int G;
     if (!x || !pooled || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
@@ -313,7 +317,7 @@ extern "C" int dcs_spatial_pool_fwd(const float* x, const float* ca, float* pool
     return DCS_OK;
 }
 
-extern "C" int dcs_attention_apply_fwd(const float* x, const float* ca, const float* sa, float* y, int B, long HW,
+extern "C" int DCS_SYM(dcs_attention_apply_fwd)(const act_t* x, const float* ca, const float* sa, act_t* y, int B, long HW,
                                        int C, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
     int G;
     if (!x || !y || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
@@ -335,7 +339,7 @@ extern "C" int dcs_attention_apply_fwd(const float* x, const float* ca, const fl
 // items[i]: one block (the reference's skip_attention[2i], [2i+1] on encoder output i: c_network.py:208-211), no dropout.
 // Five launches for all n blocks: channel pooling, channel FCs, spatial pooling, the 7x7 2->1 conv + sigmoid
 // (conv_direct.hip), apply.  workspace: sum of the blocks' dcs_ca_workspace_bytes, each rounded up to 256 bytes.
-extern "C" long dcs_attention_fwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B) {
+static long fwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B) {
     if (n < 1 || n > kMaxBatch || !items || B <= 0) return -1;
     long total = 0;
     for (int i = 0; i < n; ++i) {
@@ -347,10 +351,17 @@ extern "C" long dcs_attention_fwd_batched_workspace_bytes(int n, const dcs_atten
     return total;
 }
 
-extern "C" int dcs_attention_fwd_batched(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
+#ifndef DCS_ACT_BF16
+extern "C" long dcs_attention_fwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B) {
+    return fwd_batched_workspace_bytes(n, items, B);
+}
+#endif
+
+// (the _h form: x and y of every item are bf16 tensors, all the small maps fp32)
+extern "C" int DCS_SYM(dcs_attention_fwd_batched)(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
                                          dcs_stream_t stream) {
     if (n < 1 || n > kMaxBatch || !items || !workspace || B <= 0 || B > 65535) return DCS_ERR_BADARG;
-    if (workspace_bytes < dcs_attention_fwd_batched_workspace_bytes(n, items, B)) return DCS_ERR_WORKSPACE;
+    if (workspace_bytes < fwd_batched_workspace_bytes(n, items, B)) return DCS_ERR_WORKSPACE;
     Tbl<CaPoolP> tp; Tbl<CaFcP> tf; Tbl<SpPoolP> ts; Tbl<ApplyP> ta;
     conv::Args ca_[kMaxBatch];
     int nx_pool = 1, nx_stream = 1;
@@ -363,18 +374,18 @@ extern "C" int dcs_attention_fwd_batched(int n, const dcs_attention_item* items,
             return DCS_ERR_BADARG;
         const long HW = (long)it.H * it.W;
         const int nch = ca_chunks(HW, G), nxs = stream_grid(HW, G, B);
-        tp.p[i] = CaPoolP{it.x, (double*)ws, HW, it.C, G, nch};
+        tp.p[i] = CaPoolP{(const act_t*)it.x, (double*)ws, HW, it.C, G, nch};
         tf.p[i] = CaFcP{(const double*)ws, nch, (const float2*)it.w1, (const float2*)it.w2, (float2*)it.ca, (float2*)it.pooled,
                         (float2*)it.hidden, HW, it.C, it.Ch};
-        ts.p[i] = SpPoolP{it.x, it.ca, (float4*)it.sp, HW, it.C, G, nxs};
-        ta.p[i] = ApplyP{it.x, it.ca, (const float2*)it.sa, it.y, HW, it.C, G, nxs};
+        ts.p[i] = SpPoolP{(const act_t*)it.x, it.ca, (float4*)it.sp, HW, it.C, G, nxs};
+        ta.p[i] = ApplyP{(const act_t*)it.x, it.ca, (const float2*)it.sa, (act_t*)it.y, HW, it.C, G, nxs};
         ws += ((long)B * nch * it.C * 2 * (long)sizeof(double) + 255) / 256 * 256;
         nx_pool = nch > nx_pool ? nch : nx_pool;
         nx_stream = nxs > nx_stream ? nxs : nx_stream;
         conv::Args& a = ca_[i];                           // sa = sigmoid(conv7x7(sp)): 2 -> 1 channels, pad 3
         a = conv::Args{};
-        a.x1 = (const float2*)it.sp; a.x2 = nullptr; a.wp = (const float2*)it.wsa; a.bias = (const float2*)it.sa_bias;
-        a.y = (float2*)it.sa;
+        a.x1 = (const act2_t*)it.sp;    /* (fp32 maps in either build: conv_k7.hip reads them as float2) */ a.x2 = nullptr; a.wp = (const float2*)it.wsa; a.bias = (const float2*)it.sa_bias;
+        a.y = (act2_t*)it.sa;
         a.B = B; a.Hin = it.H; a.Win = it.W; a.C1 = 2; a.C2 = 0; a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Cout = 1;
         a.kh = 7; a.kw = 7; a.sf = 1; a.st = 1; a.pad_f = 3; a.pad_t = 3; a.act = DCS_ACT_SIGMOID;
         a.Hv = it.H; a.Wv = it.W; a.Hout = it.H; a.Wout = it.W;
@@ -402,6 +413,7 @@ extern "C" int dcs_attention_fwd_batched(int n, const dcs_attention_item* items,
     return DCS_OK;
 }
 
+#ifndef DCS_ACT_BF16
 extern "C" int dcs_dropout_fwd(const float* x, float* y, long n, float drop_p, unsigned long long seed,
                                const unsigned long long* seed_dev, dcs_stream_t stream) {
     if (!x || !y || n <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
@@ -412,3 +424,4 @@ extern "C" int dcs_dropout_fwd(const float* x, float* y, long n, float drop_p, u
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
+#endif

@@ -79,7 +79,7 @@ __device__ __forceinline__ float4 masked(float4 g, uint64_t seed, uint64_t e, fl
 
 // g_pre[b][p] = sigmoid'(sa[p]) (.) sum_c g_o[p][c] conj(ca[c] x[p][c])
 template <bool DROP>
-__device__ __forceinline__ void att_bwd_sa_kernel_body(const float* __restrict__ x, const float* __restrict__ go,
+__device__ __forceinline__ void att_bwd_sa_kernel_body(const act_t* __restrict__ x, const act_t* __restrict__ go,
                                                                const float* __restrict__ ca,
                                                                const float2* __restrict__ sa, float2* __restrict__ gpre,
                                                                long HW, int G, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev, int vbx, int vby, int vgx) {
@@ -87,8 +87,7 @@ __device__ __forceinline__ void att_bwd_sa_kernel_body(const float* __restrict__
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = vby;
     const long base = (long)b * HW * G;
-    const float4* x4 = reinterpret_cast<const float4*>(x) + base;
-    const float4* g4 = reinterpret_cast<const float4*>(go) + base;
+    const ActIn4<act_t> x4 = act_in4(x) + base, g4 = act_in4(go) + base;
     const float4 a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
     const long iters = (HW + (long)vgx * rpi - 1) / ((long)vgx * rpi);
@@ -115,9 +114,9 @@ __device__ __forceinline__ void att_bwd_sa_kernel_body(const float* __restrict__
 
 // g_x = conj(ca) g_z ; part[b][chunk][C][2] = sum_p g_z conj(x)
 template <bool DROP>
-__device__ __forceinline__ void att_bwd_x_kernel_body(const float* __restrict__ x, const float* __restrict__ go,
+__device__ __forceinline__ void att_bwd_x_kernel_body(const act_t* __restrict__ x, const act_t* __restrict__ go,
                                                               const float* __restrict__ ca, const float2* __restrict__ sa,
-                                                              const float4* __restrict__ gsp, float* __restrict__ gx,
+                                                              const float4* __restrict__ gsp, act_t* __restrict__ gx,
                                                               double* __restrict__ part, long HW, int C, int G,
                                                               float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev, int vbx, int vby, int vgx) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
@@ -125,9 +124,8 @@ __device__ __forceinline__ void att_bwd_x_kernel_body(const float* __restrict__ 
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = vby;
     const long base = (long)b * HW * G;
-    const float4* x4 = reinterpret_cast<const float4*>(x) + base;
-    const float4* g4 = reinterpret_cast<const float4*>(go) + base;
-    float4* o4 = reinterpret_cast<float4*>(gx) + base;
+    const ActIn4<act_t> x4 = act_in4(x) + base, g4 = act_in4(go) + base;
+    const ActOut4<act_t> o4 = act_out4(gx) + base;
     const float4 a = reinterpret_cast<const float4*>(ca)[(long)b * G + g];
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
     const float invC = 1.f / (float)C;
@@ -261,7 +259,7 @@ __device__ __forceinline__ void ca_bwd_weight_element(const CaWeightArgs& w, int
 
 // g_x += g_pooled / HW (broadcast over the sample's pixels).  Workgroups with blockIdx.x >= nx_pool of batch row 0 are
 // the FC weight-gradient half (nothing downstream waits for it, so it rides along instead of taking its own launch).
-__device__ __forceinline__ void att_bwd_pool_kernel_body(float* __restrict__ gx, const float* __restrict__ gpooled,
+__device__ __forceinline__ void att_bwd_pool_kernel_body(act_t* __restrict__ gx, const float* __restrict__ gpooled,
                                                                  long HW, int G, float inv_hw, int nx_pool, CaWeightArgs w, int vbx, int vby, int vgx) {
     if ((int)vbx >= nx_pool) {
         if (vby == 0) ca_bwd_weight_element(w, ((int)vbx - nx_pool) * kThreads + threadIdx.x);
@@ -269,11 +267,12 @@ __device__ __forceinline__ void att_bwd_pool_kernel_body(float* __restrict__ gx,
     }
     const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
     const int b = vby;
-    float4* o4 = reinterpret_cast<float4*>(gx) + (long)b * HW * G;
+    const ActOut4<act_t> o4 = act_out4(gx) + (long)b * HW * G;
+    const ActIn4<act_t> i4 = act_in4((const act_t*)gx) + (long)b * HW * G;
     float4 p = reinterpret_cast<const float4*>(gpooled)[(long)b * G + g];
     p.x *= inv_hw; p.y *= inv_hw; p.z *= inv_hw; p.w *= inv_hw;
     for (long r = (long)vbx * rpi + r0; r < HW; r += (long)nx_pool * rpi) {
-        float4 v = o4[r * G + g];
+        float4 v = i4[r * G + g];
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
         o4[r * G + g] = v;
     }
@@ -299,12 +298,12 @@ template <class P> void tbl_compact(Tbl<P>& t, int n, int* total) {
     *total = a;
 }
 
-struct BwdSaP { const float* x; const float* go; const float* ca; const float2* sa; float2* gpre; long HW; int G, nx; };
-struct BwdXP { const float* x; const float* go; const float* ca; const float2* sa; const float4* gsp; float* gx; double* part;
+struct BwdSaP { const act_t* x; const act_t* go; const float* ca; const float2* sa; float2* gpre; long HW; int G, nx; };
+struct BwdXP { const act_t* x; const act_t* go; const float* ca; const float2* sa; const float4* gsp; act_t* gx; double* part;
                long HW; int C, G, nx; };
 struct CaBwdP { const double* part; int nchunks; const float2* ca; const float2* hidden; const float2* w1; const float2* w2;
                 float2* go; float2* gh; float2* gpooled; int C, Ch; };
-struct PoolP { float* gx; const float* gpooled; long HW; int G; float inv_hw; int nx_pool, nx; CaWeightArgs w; };
+struct PoolP { act_t* gx; const float* gpooled; long HW; int G; float inv_hw; int nx_pool, nx; CaWeightArgs w; };
 
 template <bool DROP>
 __global__ __launch_bounds__(kThreads) void att_bwd_sa_kernel(BwdSaP p, float drop_p, uint64_t seed, const uint64_t* seed_dev) {
@@ -353,7 +352,7 @@ inline int stream_grid(long HW, int G, int B) {
 
 }  // namespace
 
-extern "C" int dcs_attention_bwd_sa(const float* x, const float* g_out, const float* ca, const float* sa, float* g_pre,
+extern "C" int DCS_SYM(dcs_attention_bwd_sa)(const act_t* x, const act_t* g_out, const float* ca, const float* sa, float* g_pre,
                                     int B, long HW, int C, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
     int G;
     if (!x || !g_out || !ca || !sa || !g_pre || B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G)) return DCS_ERR_BADARG;
@@ -371,15 +370,17 @@ extern "C" int dcs_attention_bwd_sa(const float* x, const float* g_out, const fl
     return DCS_OK;
 }
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_attention_bwd_workspace_bytes(int B, long HW, int C, int Ch) {
     int G;
     if (B <= 0 || HW <= 0 || Ch <= 0 || !att_geom(C, &G)) return -1;
     return (long)B * chunks_for(HW, G) * C * 2 * (long)sizeof(double) + (2L * B * C + (long)B * Ch) * 8 + 64;
 }
+#endif
 
-extern "C" int dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, const float* sa,
+extern "C" int DCS_SYM(dcs_attention_bwd_x)(const act_t* x, const act_t* g_out, const float* ca, const float* sa,
                                    const float* g_sp, const float* pooled, const float* hidden, const float* w1,
-                                   const float* w2, float* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r,
+                                   const float* w2, act_t* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r,
                                    float* g_fc2_i, float* g_pooled, void* workspace, long workspace_bytes, int B, long HW,
                                    int C, int Ch, float drop_p, unsigned long long seed,
                                    const unsigned long long* seed_dev, dcs_stream_t stream) {
@@ -428,7 +429,7 @@ static long bwd_item_bytes(const dcs_attention_item& it, int B, int G) {
     return (b + 255) / 256 * 256;
 }
 
-extern "C" long dcs_attention_bwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B) {
+static long bwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B) {
     if (n < 1 || n > kMaxBatch || !items || B <= 0) return -1;
     long total = 0;
     for (int i = 0; i < n; ++i) {
@@ -439,10 +440,17 @@ extern "C" long dcs_attention_bwd_batched_workspace_bytes(int n, const dcs_atten
     return total;
 }
 
-extern "C" int dcs_attention_bwd_batched(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
+#ifndef DCS_ACT_BF16
+extern "C" long dcs_attention_bwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B) {
+    return bwd_batched_workspace_bytes(n, items, B);
+}
+#endif
+
+// (the _h form: x, g_out and g_x of every item are bf16 tensors, all the small maps fp32)
+extern "C" int DCS_SYM(dcs_attention_bwd_batched)(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
                                          dcs_stream_t stream) {
     if (n < 1 || n > kMaxBatch || !items || !workspace || B <= 0 || B > 65535) return DCS_ERR_BADARG;
-    if (workspace_bytes < dcs_attention_bwd_batched_workspace_bytes(n, items, B)) return DCS_ERR_WORKSPACE;
+    if (workspace_bytes < bwd_batched_workspace_bytes(n, items, B)) return DCS_ERR_WORKSPACE;
     Tbl<BwdSaP> tsa; Tbl<BwdXP> tx; Tbl<CaBwdP> tc; Tbl<PoolP> tp;
     conv::Args dg[kMaxBatch];
     int nx_sa = 1, nx_x = 1, nx_p = 1;
@@ -461,8 +469,8 @@ extern "C" int dcs_attention_bwd_batched(int n, const dcs_attention_item* items,
         float2* gh = go + (long)B * it.C;
         float2* gpooled = gh + (long)B * it.Ch;
         ws += bwd_item_bytes(it, B, G);
-        tsa.p[i] = BwdSaP{it.x, it.g_out, it.ca, (const float2*)it.sa, (float2*)it.g_pre, HW, G, nxs};
-        tx.p[i] = BwdXP{it.x, it.g_out, it.ca, (const float2*)it.sa, (const float4*)it.g_sp, it.g_x, part, HW, it.C, G, nch};
+        tsa.p[i] = BwdSaP{(const act_t*)it.x, (const act_t*)it.g_out, it.ca, (const float2*)it.sa, (float2*)it.g_pre, HW, G, nxs};
+        tx.p[i] = BwdXP{(const act_t*)it.x, (const act_t*)it.g_out, it.ca, (const float2*)it.sa, (const float4*)it.g_sp, (act_t*)it.g_x, part, HW, it.C, G, nch};
         tc.p[i] = CaBwdP{(const double*)part, nch, (const float2*)it.ca, (const float2*)it.hidden, (const float2*)it.w1,
                          (const float2*)it.w2, go, gh, gpooled, it.C, it.Ch};
         CaWeightArgs cw;
@@ -470,14 +478,14 @@ extern "C" int dcs_attention_bwd_batched(int n, const dcs_attention_item* items,
         cw.g_fc0_r = it.g_fc0_r; cw.g_fc0_i = it.g_fc0_i; cw.g_fc2_r = it.g_fc2_r; cw.g_fc2_i = it.g_fc2_i;
         cw.B = B; cw.C = it.C; cw.Ch = it.Ch;
         const int nxw = nxs + (it.C * it.Ch * kWLanes + kThreads - 1) / kThreads;
-        tp.p[i] = PoolP{it.g_x, (const float*)gpooled, HW, G, 1.f / (float)HW, nxs, nxw, cw};
+        tp.p[i] = PoolP{(act_t*)it.g_x, (const float*)gpooled, HW, G, 1.f / (float)HW, nxs, nxw, cw};
         nx_sa = nxs > nx_sa ? nxs : nx_sa;
         nx_x = nch > nx_x ? nch : nx_x;
         nx_p = nxw > nx_p ? nxw : nx_p;
         conv::Args& a = dg[i];                            // g_sp = data gradient of the 7x7 2->1 conv: 1 -> 2 over g_pre
         a = conv::Args{};
-        a.x1 = (const float2*)it.g_pre; a.x2 = nullptr; a.wp = (const float2*)it.wsa_bwd; a.bias = nullptr;
-        a.y = (float2*)it.g_sp;
+        a.x1 = (const act2_t*)it.g_pre;    /* (fp32 maps in either build) */ a.x2 = nullptr; a.wp = (const float2*)it.wsa_bwd; a.bias = nullptr;
+        a.y = (act2_t*)it.g_sp;
         a.B = B; a.Hin = it.H; a.Win = it.W; a.C1 = 1; a.C2 = 0; a.up_f = 1; a.up_t = 1; a.zero_ins = 0; a.Cout = 2;
         a.kh = 7; a.kw = 7; a.sf = 1; a.st = 1; a.pad_f = 3; a.pad_t = 3; a.act = DCS_ACT_NONE;
         a.Hv = it.H; a.Wv = it.W; a.Hout = it.H; a.Wout = it.W;

@@ -46,7 +46,7 @@ inline bool cbn_geom(long P, int C, CbnGeom* g) {
 }
 
 // partial slab layout: double part[nblocks][C][5] = {S_r, S_i, S_rr, S_ii, S_ri} of (x - pivot)
-__global__ __launch_bounds__(kThreads) void cbn_stats_kernel(const float* __restrict__ x, double* __restrict__ part,
+__global__ __launch_bounds__(kThreads) void cbn_stats_kernel(const act_t* __restrict__ x, double* __restrict__ part,
                                                               long P, int C, int G, int rows_per_iter) {
     __shared__ double red[kThreads * 10];
     const int t = threadIdx.x;
@@ -55,9 +55,9 @@ __global__ __launch_bounds__(kThreads) void cbn_stats_kernel(const float* __rest
     for (int i = 0; i < 10; ++i) s[i] = 0.f;
 
     if (C == 1) {
-        const float kr = x[0], ki = x[1];
+        const float kr = dcs_ld1(x), ki = dcs_ld1(x + 1);
         const long nvec = P / 2;
-        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const ActIn4<act_t> x4 = act_in4(x);
         for (long i = (long)blockIdx.x * kThreads + t; i < nvec; i += (long)gridDim.x * kThreads) {
             float4 v = x4[i];
             float ar = v.x - kr, ai = v.y - ki, br = v.z - kr, bi = v.w - ki;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void cbn_stats_kernel(const float* __rest
             s[4] = fmaf(ar, ai, fmaf(br, bi, s[4]));
         }
         if ((P & 1) && blockIdx.x == 0 && t == 0) {
-            float ar = x[2 * (P - 1)] - kr, ai = x[2 * (P - 1) + 1] - ki;
+            float ar = dcs_ld1(x + 2 * (P - 1)) - kr, ai = dcs_ld1(x + 2 * (P - 1) + 1) - ki;
             s[0] += ar; s[1] += ai; s[2] += ar * ar; s[3] += ai * ai; s[4] += ar * ai;
         }
         // all threads hold channel 0
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(kThreads) void cbn_stats_kernel(const float* __rest
 
     const int g = t % G;      // float4 group = complex channels 2g, 2g+1
     const int r0 = t / G;
-    const float4 piv = reinterpret_cast<const float4*>(x)[g];   // row 0 of this channel pair
-    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const ActIn4<act_t> x4 = act_in4(x);
+    const float4 piv = x4[g];   // row 0 of this channel pair
     for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
         float4 v = x4[r * G + g];
         float ar = v.x - piv.x, ai = v.y - piv.y, br = v.z - piv.z, bi = v.w - piv.w;
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(kThreads) void cbn_stats_kernel(const float* __rest
 // conv_common.h Args::stat).  pivot: float[C][2], the value the partial sums are relative to (pixel 0 of x, or the conv's
 // bias).  One workgroup of 256 threads per channel: a thread's slab loads are all in flight at once (8 per round), then a
 // wave butterfly and an LDS combine in a fixed order.
-template <typename PT>
-__global__ __launch_bounds__(256) void cbn_finalize_kernel(const float* __restrict__ pivot, const PT* __restrict__ part, int nblocks, int stride,
+template <typename PT, typename PV>
+__global__ __launch_bounds__(256) void cbn_finalize_kernel(const PV* __restrict__ pivot, const PT* __restrict__ part, int nblocks, int stride,
                                     const float* __restrict__ weight, const float* __restrict__ bias,
                                     float* __restrict__ running_mean, float* __restrict__ running_covar,
                                     float* __restrict__ stats_out, float* __restrict__ coef_out,
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void cbn_finalize_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < 5; ++i) S[i] = wsum[0][i] + wsum[1][i] + wsum[2][i] + wsum[3][i];
         const double n = (double)P;
-        const double kr = (double)pivot[2 * c], ki = (double)pivot[2 * c + 1];
+        const double kr = use_batch_stats ? (double)dcs_ld1(pivot + 2 * c) : 0.0, ki = use_batch_stats ? (double)dcs_ld1(pivot + 2 * c + 1) : 0.0;
         const double dr = S[0] / n, di = S[1] / n;
         mr = (float)(kr + dr);
         mi = (float)(ki + di);
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void cbn_finalize_kernel(const float* __restri
     co[5] = b1 - a2 * mr - a3 * mi;
 }
 
+#ifndef DCS_ACT_BF16
 // torch.nn.BatchNorm2d on a REAL channels-last tensor float[P][Cr] (DR-Net, r_network.py:56,66,106): with even Cr the
 // tensor is an interleaved complex one with Cr/2 channels, the statistics kernel above already yields every real
 // channel's first and second moment (S_ri is ignored), and the affine map is the DIAGONAL 2x2 block
@@ -275,8 +276,10 @@ __global__ void rbn_finalize_kernel(const float* __restrict__ x, const double* _
     co[5] = b1 - a3 * mi;
 }
 
+#endif
+
 template <int ACT>
-__device__ __forceinline__ float act_t(float v) {
+__device__ __forceinline__ float act_fn(float v) {
     if (ACT == DCS_ACT_RELU) return v > 0.f ? v : 0.f;
     if (ACT == DCS_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
     return v;
@@ -284,23 +287,23 @@ __device__ __forceinline__ float act_t(float v) {
 
 // y = act(A x + c); thread keeps the coefficients of its fixed channel pair in registers.
 template <int ACT, bool DROP>
-__global__ __launch_bounds__(kThreads) void cbn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(kThreads) void cbn_apply_kernel(const act_t* __restrict__ x, act_t* __restrict__ y,
                                                               const float* __restrict__ coef, long P, int C, int G,
                                                               int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
     const int t = threadIdx.x;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    float4* y4 = reinterpret_cast<float4*>(y);
+    const ActIn4<act_t> x4 = act_in4(x);
+    const ActOut4<act_t> y4 = act_out4(y);
     if (C == 1) {
         const float a0 = coef[0], a1 = coef[1], a2 = coef[2], a3 = coef[3], c0 = coef[4], c1 = coef[5];
         const long nvec = P / 2;
         for (long i = (long)blockIdx.x * kThreads + t; i < nvec; i += (long)gridDim.x * kThreads) {
             float4 v = x4[i], o;
-            o.x = act_t<ACT>(fmaf(a0, v.x, fmaf(a1, v.y, c0)));
-            o.y = act_t<ACT>(fmaf(a2, v.x, fmaf(a3, v.y, c1)));
-            o.z = act_t<ACT>(fmaf(a0, v.z, fmaf(a1, v.w, c0)));
-            o.w = act_t<ACT>(fmaf(a2, v.z, fmaf(a3, v.w, c1)));
+            o.x = act_fn<ACT>(fmaf(a0, v.x, fmaf(a1, v.y, c0)));
+            o.y = act_fn<ACT>(fmaf(a2, v.x, fmaf(a3, v.y, c1)));
+            o.z = act_fn<ACT>(fmaf(a0, v.z, fmaf(a1, v.w, c0)));
+            o.w = act_fn<ACT>(fmaf(a2, v.z, fmaf(a3, v.w, c1)));
             if (DROP) {
                 const uint64_t e = (uint64_t)i * 4;
                 o.x *= dcs_keep_scale(seed, e, drop_p, inv_keep);
@@ -311,15 +314,15 @@ __global__ __launch_bounds__(kThreads) void cbn_apply_kernel(const float* __rest
             y4[i] = o;
         }
         if ((P & 1) && blockIdx.x == 0 && t == 0) {
-            const float xr = x[2 * (P - 1)], xi = x[2 * (P - 1) + 1];
-            float yr = act_t<ACT>(fmaf(a0, xr, fmaf(a1, xi, c0)));
-            float yi = act_t<ACT>(fmaf(a2, xr, fmaf(a3, xi, c1)));
+            const float xr = dcs_ld1(x + 2 * (P - 1)), xi = dcs_ld1(x + 2 * (P - 1) + 1);
+            float yr = act_fn<ACT>(fmaf(a0, xr, fmaf(a1, xi, c0)));
+            float yi = act_fn<ACT>(fmaf(a2, xr, fmaf(a3, xi, c1)));
             if (DROP) {
                 yr *= dcs_keep_scale(seed, (uint64_t)2 * (P - 1), drop_p, inv_keep);
                 yi *= dcs_keep_scale(seed, (uint64_t)2 * (P - 1) + 1, drop_p, inv_keep);
             }
-            y[2 * (P - 1)] = yr;
-            y[2 * (P - 1) + 1] = yi;
+            dcs_st1(y + 2 * (P - 1), yr);
+            dcs_st1(y + 2 * (P - 1) + 1, yi);
         }
         return;
     }
@@ -329,10 +332,10 @@ __global__ __launch_bounds__(kThreads) void cbn_apply_kernel(const float* __rest
     const float e0 = ca[6], e1 = ca[7], e2 = ca[8], e3 = ca[9], f0 = ca[10], f1 = ca[11];
     for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
         float4 v = x4[r * G + g], o;
-        o.x = act_t<ACT>(fmaf(a0, v.x, fmaf(a1, v.y, c0)));
-        o.y = act_t<ACT>(fmaf(a2, v.x, fmaf(a3, v.y, c1)));
-        o.z = act_t<ACT>(fmaf(e0, v.z, fmaf(e1, v.w, f0)));
-        o.w = act_t<ACT>(fmaf(e2, v.z, fmaf(e3, v.w, f1)));
+        o.x = act_fn<ACT>(fmaf(a0, v.x, fmaf(a1, v.y, c0)));
+        o.y = act_fn<ACT>(fmaf(a2, v.x, fmaf(a3, v.y, c1)));
+        o.z = act_fn<ACT>(fmaf(e0, v.z, fmaf(e1, v.w, f0)));
+        o.w = act_fn<ACT>(fmaf(e2, v.z, fmaf(e3, v.w, f1)));
         if (DROP) {
             const uint64_t e = (uint64_t)(r * G + g) * 4;
             o.x *= dcs_keep_scale(seed, e, drop_p, inv_keep);
@@ -346,13 +349,15 @@ __global__ __launch_bounds__(kThreads) void cbn_apply_kernel(const float* __rest
 
 }  // namespace
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_cbn_workspace_bytes(long P, int C) {
     CbnGeom g;
     if (!cbn_geom(P, C, &g)) return -1;
     return (long)g.nblocks * C * 5 * (long)sizeof(double);
 }
+#endif
 
-static int cbn_fwd_impl(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
+static int cbn_fwd_impl(const act_t* x, act_t* y, const float* weight, const float* bias, float* running_mean,
                         float* running_covar, float* stats_out, float* coef_out, void* workspace,
                         long workspace_bytes, long P, int C, float eps, float momentum, int use_batch_stats,
                         int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream,
@@ -373,11 +378,11 @@ static int cbn_fwd_impl(const float* x, float* y, const float* weight, const flo
         DCS_CHECK_LAUNCH();
     }
     if (use_batch_stats == 3) {            // 3: the producing conv's epilogue left the partial sums (dcs_cbn_fwd_slabs)
-        DCS_LAUNCH(cbn_finalize_kernel<float>, dim3(C), dim3(256), 0, s, slab_pivot, slab_part, slab_rows, slab_stride, weight, bias,
+        DCS_LAUNCH((cbn_finalize_kernel<float, float>), dim3(C), dim3(256), 0, s, slab_pivot, slab_part, slab_rows, slab_stride, weight, bias,
                    running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum, 1);
         DCS_CHECK_LAUNCH();
     } else if (use_batch_stats != 2) {     // 2: coef_out already holds the coefficients of an earlier eval-mode call
-        DCS_LAUNCH(cbn_finalize_kernel<double>, dim3(C), dim3(256), 0, s, x, (const double*)workspace,
+        DCS_LAUNCH((cbn_finalize_kernel<double, act_t>), dim3(C), dim3(256), 0, s, x, (const double*)workspace,
                            g.nblocks, 0, weight, bias, running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum,
                            use_batch_stats);
         DCS_CHECK_LAUNCH();
@@ -398,7 +403,7 @@ static int cbn_fwd_impl(const float* x, float* y, const float* weight, const flo
     return DCS_OK;
 }
 
-extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
+extern "C" int DCS_SYM(dcs_cbn_fwd)(const act_t* x, act_t* y, const float* weight, const float* bias, float* running_mean,
                            float* running_covar, float* stats_out, float* coef_out, void* workspace,
                            long workspace_bytes, long P, int C, float eps, float momentum, int use_batch_stats,
                            int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
@@ -410,7 +415,7 @@ extern "C" int dcs_cbn_fwd(const float* x, float* y, const float* weight, const 
 // Training-mode dcs_cbn_fwd whose batch statistics come from the conv that produced x (dcs_cconv2d_fwd_stats): `part` =
 // float[C][5][stride] partial sums of (x - pivot), columns 0..rows-1 valid, `pivot` = float[C][2] (the conv's packed bias).
 // No statistics pass over x.
-extern "C" int dcs_cbn_fwd_slabs(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
+extern "C" int DCS_SYM(dcs_cbn_fwd_slabs)(const act_t* x, act_t* y, const float* weight, const float* bias, float* running_mean,
                                  float* running_covar, float* stats_out, float* coef_out, const float* part, int rows,
                                  int stride, const float* pivot, long P, int C, float eps, float momentum, int act, float drop_p,
                                  unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
@@ -418,6 +423,7 @@ extern "C" int dcs_cbn_fwd_slabs(const float* x, float* y, const float* weight, 
                         3, act, drop_p, seed, seed_dev, stream, part, rows, stride, pivot);
 }
 
+#ifndef DCS_ACT_BF16
 // Real BatchNorm2d (+ ReLU / LeakyReLU) of float[P][Cr]; Cr even, or Cr == 1 with P even (see rbn_finalize_kernel).
 extern "C" int dcs_rbn_fwd(const float* x, float* y, const float* weight, const float* bias, float* running_mean,
                            float* running_var, float* stats_out, float* coef_out, void* workspace, long workspace_bytes,
@@ -454,3 +460,4 @@ extern "C" int dcs_rbn_fwd(const float* x, float* y, const float* weight, const 
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
+#endif

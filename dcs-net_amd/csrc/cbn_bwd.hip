@@ -63,20 +63,19 @@ __device__ __forceinline__ void acc6(float* s, float2 gy, float u, float v) {
 
 // part[nblocks][C][6] (double): {sum gyr, sum gyi, N00, N01, N10, N11}
 template <int ACT, bool DROP>
-__global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* __restrict__ x,
-                                                                   const float* __restrict__ go,
+__global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const act_t* __restrict__ x,
+                                                                   const act_t* __restrict__ go,
                                                                    const float* __restrict__ coef,
                                                                    const float* __restrict__ stats,
                                                                    double* __restrict__ part, long P, int C, int G,
                                                                    int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                                    const float4* __restrict__ g_add, float add_scale, long HW,
-                                                                   const float4* __restrict__ g2) {
+                                                                   const act_t* __restrict__ g2_) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     __shared__ double red[kThreads * 12];
     const int t = threadIdx.x;
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    const float4* g4 = reinterpret_cast<const float4*>(go);
+    const ActIn4<act_t> x4 = act_in4(x), g4 = act_in4(go), g2 = act_in4(g2_);
     float s[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = 0.f;
@@ -87,15 +86,16 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
         for (long i = (long)blockIdx.x * kThreads + t; i < nvec; i += (long)gridDim.x * kThreads) {
             const float4 v = x4[i];
             float4 g = g4[i];
-            if (g2) { const float4 h = g2[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
+            if (g2_) { const float4 h = g2[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
             const uint64_t e = (uint64_t)i * 4;
             acc6(s, grad_y<ACT, DROP>(k, v.x, v.y, g.x, g.y, seed, e, drop_p, inv_keep), v.x - k.mr, v.y - k.mi);
             acc6(s, grad_y<ACT, DROP>(k, v.z, v.w, g.z, g.w, seed, e + 2, drop_p, inv_keep), v.z - k.mr, v.w - k.mi);
         }
         if ((P & 1) && blockIdx.x == 0 && t == 0) {
             const long q = 2 * (P - 1);
-            acc6(s, grad_y<ACT, DROP>(k, x[q], x[q + 1], go[q], go[q + 1], seed, (uint64_t)q, drop_p, inv_keep),
-                 x[q] - k.mr, x[q + 1] - k.mi);
+            const float xr = dcs_ld1(x + q), xi = dcs_ld1(x + q + 1);
+            acc6(s, grad_y<ACT, DROP>(k, xr, xi, dcs_ld1(go + q), dcs_ld1(go + q + 1), seed, (uint64_t)q, drop_p, inv_keep),
+                 xr - k.mr, xi - k.mi);
         }
         double d[6];
 #pragma unroll
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
     // around their loads every pass was its own memory round trip — up to eight in a row, 8-11 us for a 5-us kernel.
     constexpr int UN = 4;
     const long stride = (long)gridDim.x * rows_per_iter;
-    const float4* g2p = g2 ? g2 : g4;
-    const float4* gap = g_add ? g_add : g4;
+    const ActIn4<act_t> g2p = g2_ ? g2 : g4;
+    const float4* gap = g_add ? g_add : reinterpret_cast<const float4*>(stats);      // (stand-in: element 0 of any fp32 array)
     for (long rb = (long)blockIdx.x * rows_per_iter + r0; rb < P; rb += stride * UN) {
         float4 v[UN], gg[UN], h[UN], ga[UN];
 #pragma unroll
@@ -131,13 +131,13 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const float* _
             v[u] = x4[rc * G + g];
             gg[u] = g4[rc * G + g];
             h[u] = g2p[rc * G + g];
-            ga[u] = gap[g_add ? (rc / HW) * G + g : rc * G + g];
+            ga[u] = gap[g_add ? (rc / HW) * G + g : 0];
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const long r = rb + u * stride;
             if (r >= P) continue;
-            if (g2) { gg[u].x += h[u].x; gg[u].y += h[u].y; gg[u].z += h[u].z; gg[u].w += h[u].w; }
+            if (g2_) { gg[u].x += h[u].x; gg[u].y += h[u].y; gg[u].z += h[u].z; gg[u].w += h[u].w; }
             if (g_add) add_sample(gg[u], ga[u], add_scale);
             const uint64_t e = (uint64_t)(r * G + g) * 4;
             acc6(s, grad_y<ACT, DROP>(k0, v[u].x, v[u].y, gg[u].x, gg[u].y, seed, e, drop_p, inv_keep), v[u].x - k0.mr, v[u].y - k0.mi);
@@ -294,20 +294,19 @@ __device__ __forceinline__ float2 grad_x(const BChan& k, float2 gy, float xr, fl
 }
 
 template <int ACT, bool DROP>
-__global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __restrict__ x,
-                                                                  const float* __restrict__ go, float* __restrict__ gx,
+__global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const act_t* __restrict__ x,
+                                                                  const act_t* __restrict__ go, act_t* __restrict__ gx,
                                                                   const float* __restrict__ coef,
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ bcoef, long P, int C, int G,
                                                                   int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                                   const float4* __restrict__ g_add, float add_scale, long HW,
-                                                                  const float4* __restrict__ g2) {
+                                                                  const act_t* __restrict__ g2_) {
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x;
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    const float4* g4 = reinterpret_cast<const float4*>(go);
-    float4* o4 = reinterpret_cast<float4*>(gx);
+    const ActIn4<act_t> x4 = act_in4(x), g4 = act_in4(go), g2 = act_in4(g2_);
+    const ActOut4<act_t> o4 = act_out4(gx);
     if (C == 1) {
         const Chan k = load_chan(coef, stats, 0);
         const BChan bk = load_bchan(bcoef, 0);
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
         for (long i = (long)blockIdx.x * kThreads + t; i < nvec; i += (long)gridDim.x * kThreads) {
             const float4 v = x4[i];
             float4 g = g4[i];
-            if (g2) { const float4 h = g2[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
+            if (g2_) { const float4 h = g2[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
             const uint64_t e = (uint64_t)i * 4;
             const float2 a = grad_x(bk, grad_y<ACT, DROP>(k, v.x, v.y, g.x, g.y, seed, e, drop_p, inv_keep), v.x, v.y);
             const float2 b = grad_x(bk, grad_y<ACT, DROP>(k, v.z, v.w, g.z, g.w, seed, e + 2, drop_p, inv_keep), v.z, v.w);
@@ -323,9 +322,10 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
         }
         if ((P & 1) && blockIdx.x == 0 && t == 0) {
             const long q = 2 * (P - 1);
-            const float2 a = grad_x(bk, grad_y<ACT, DROP>(k, x[q], x[q + 1], go[q], go[q + 1], seed, (uint64_t)q, drop_p,
-                                                          inv_keep), x[q], x[q + 1]);
-            gx[q] = a.x; gx[q + 1] = a.y;
+            const float xr = dcs_ld1(x + q), xi = dcs_ld1(x + q + 1);
+            const float2 a = grad_x(bk, grad_y<ACT, DROP>(k, xr, xi, dcs_ld1(go + q), dcs_ld1(go + q + 1), seed, (uint64_t)q, drop_p,
+                                                          inv_keep), xr, xi);
+            dcs_st1(gx + q, a.x); dcs_st1(gx + q + 1, a.y);
         }
         return;
     }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
     for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
         const float4 v = x4[r * G + g];
         float4 gg = g4[r * G + g];
-        if (g2) { const float4 h = g2[r * G + g]; gg.x += h.x; gg.y += h.y; gg.z += h.z; gg.w += h.w; }
+        if (g2_) { const float4 h = g2[r * G + g]; gg.x += h.x; gg.y += h.y; gg.z += h.z; gg.w += h.w; }
         if (g_add) add_sample(gg, g_add[(r / HW) * G + g], add_scale);
         const uint64_t e = (uint64_t)(r * G + g) * 4;
         const float2 a = grad_x(b0, grad_y<ACT, DROP>(k0, v.x, v.y, gg.x, gg.y, seed, e, drop_p, inv_keep), v.x, v.y);
@@ -346,22 +346,24 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const float* __
 
 }  // namespace
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_cbn_bwd_workspace_bytes(long P, int C) {
     cbn::Geom g;
     if (!cbn::geom(P, C, &g)) return -1;
     return (long)g.nblocks * C * 6 * (long)sizeof(double) + (long)C * 10 * (long)sizeof(float);
 }
+#endif
 
-extern "C" int dcs_cbn_bwd_add(const float* x, const float* g_out, float* g_x, const float* weight, const float* stats,
+extern "C" int DCS_SYM(dcs_cbn_bwd_add)(const act_t* x, const act_t* g_out, act_t* g_x, const float* weight, const float* stats,
                                const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
                                long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
                                const unsigned long long* seed_dev, const float* g_add, float add_scale, long HW,
-                               const float* g_out2, dcs_stream_t stream) {
+                               const act_t* g_out2, dcs_stream_t stream) {
     cbn::Geom g;
     if (!x || !g_out || !g_x || !stats || !coef || !workspace || !cbn::geom(P, C, &g)) return DCS_ERR_BADARG;
     if (g_add && (C < 2 || HW <= 0 || P % HW != 0)) return DCS_ERR_BADARG;
     if (g_out2 && C == 1 && (P & 1)) return DCS_ERR_BADARG;      // the scalar tail of the one-channel layout reads g_out only
-    const float4* gb = reinterpret_cast<const float4*>(g_out2);
+    const act_t* gb = g_out2;
     const float4* ga = reinterpret_cast<const float4*>(g_add);
     if ((g_weight == nullptr) != (g_bias == nullptr)) return DCS_ERR_BADARG;
     if (act != DCS_ACT_NONE && act != DCS_ACT_RELU && act != DCS_ACT_LRELU) return DCS_ERR_BADARG;
@@ -392,14 +394,15 @@ extern "C" int dcs_cbn_bwd_add(const float* x, const float* g_out, float* g_x, c
     return DCS_OK;
 }
 
-extern "C" int dcs_cbn_bwd(const float* x, const float* g_out, float* g_x, const float* weight, const float* stats,
+extern "C" int DCS_SYM(dcs_cbn_bwd)(const act_t* x, const act_t* g_out, act_t* g_x, const float* weight, const float* stats,
                            const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
                            long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
                            const unsigned long long* seed_dev, dcs_stream_t stream) {
-    return dcs_cbn_bwd_add(x, g_out, g_x, weight, stats, coef, g_weight, g_bias, workspace, workspace_bytes, P, C,
+    return DCS_SYM(dcs_cbn_bwd_add)(x, g_out, g_x, weight, stats, coef, g_weight, g_bias, workspace, workspace_bytes, P, C,
                            use_batch_stats, act, drop_p, seed, seed_dev, nullptr, 0.f, 0, nullptr, stream);
 }
 
+#ifndef DCS_ACT_BF16
 // Backward of dcs_rbn_fwd: g_x, g_weight[Cr], g_bias[Cr] (both NULL for affine=False); same Cr / P conventions.
 extern "C" int dcs_rbn_bwd(const float* x, const float* g_out, float* g_x, const float* stats, const float* coef,
                            float* g_weight, float* g_bias, void* workspace, long workspace_bytes, long P, int Cr,
@@ -423,12 +426,12 @@ extern "C" int dcs_rbn_bwd(const float* x, const float* g_out, float* g_x, const
     do {                                                                                                           \
         DCS_LAUNCH((cbn_bwd_reduce_kernel<A, false>), dim3(g.nblocks), dim3(kThreads), 0, s, x, g_out, coef, stats, part, \
                    Pc, C, g.vec_per_row, g.rows_per_iter, 0.f, (uint64_t)0, (const uint64_t*)nullptr,              \
-                   (const float4*)nullptr, 0.f, (long)0, (const float4*)nullptr);                                  \
+                   (const float4*)nullptr, 0.f, (long)0, (const act_t*)nullptr);                                   \
         DCS_LAUNCH(rbn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part, g.nblocks, stats, coef,   \
                    g_weight, g_bias, bcoef, Pc, C, merge, use_batch_stats);                                        \
         DCS_LAUNCH((cbn_bwd_apply_kernel<A, false>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef, stats, \
                    (const float*)bcoef, Pc, C, g.vec_per_row, g.rows_per_iter, 0.f, (uint64_t)0,                   \
-                   (const uint64_t*)nullptr, (const float4*)nullptr, 0.f, (long)0, (const float4*)nullptr);        \
+                   (const uint64_t*)nullptr, (const float4*)nullptr, 0.f, (long)0, (const act_t*)nullptr);         \
     } while (0)
     if (act == DCS_ACT_RELU) DCS_RBN_BWD(DCS_ACT_RELU);
     else if (act == DCS_ACT_LRELU) DCS_RBN_BWD(DCS_ACT_LRELU);
@@ -437,3 +440,4 @@ extern "C" int dcs_rbn_bwd(const float* x, const float* g_out, float* g_x, const
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
+#endif

@@ -3,10 +3,38 @@
 #pragma once
 #include "dcs_common.h"
 
+// The conv family is compiled twice (dcs_common.h: act_t): every cross-file function that touches activations gets its own
+// symbol in the bf16 build.  NOT renamed — taken from the once-compiled fp32 objects, whose operands are fp32 in either
+// mode: the 7x7 attention convs (conv_k7.hip, conv_wgrad_small.hip, dcs_conv_direct_multi), the weight packers
+// (conv_pack.hip, pack_jobs.hip), the slab reduces (wgrad_reduce.hip), the pipelined schedule (conv_pipe.hip, fp32 only).
+#ifdef DCS_ACT_BF16
+#define dcs_conv_mfma_stat_rows dcs_conv_mfma_stat_rows_h
+#define dcs_conv_mfma_pack dcs_conv_mfma_pack_h
+#define dcs_conv_mfma_workspace_bytes dcs_conv_mfma_workspace_bytes_h
+#define dcs_conv_mfma_workspace_bytes_plain dcs_conv_mfma_workspace_bytes_plain_h
+#define dcs_conv_mfma_launch dcs_conv_mfma_launch_h
+#define dcs_conv_mfma_launch_split dcs_conv_mfma_launch_split_h
+#define dcs_conv_mfma_launch_wide dcs_conv_mfma_launch_wide_h
+#define dcs_conv_mfma_launch_classes dcs_conv_mfma_launch_classes_h
+#define dcs_conv_enc0_ok dcs_conv_enc0_ok_h
+#define dcs_conv_enc0_launch dcs_conv_enc0_launch_h
+#define dcs_conv_enc0_stat_rows dcs_conv_enc0_stat_rows_h
+#define dcs_conv_enc0_wgrad_ok dcs_conv_enc0_wgrad_ok_h
+#define dcs_conv_enc0_wgrad_launch dcs_conv_enc0_wgrad_launch_h
+#define dcs_conv_wgrad_mfma_ok dcs_conv_wgrad_mfma_ok_h
+#define dcs_conv_wgrad_mfma_slabs dcs_conv_wgrad_mfma_slabs_h
+#define dcs_conv_wgrad_mfma_launch dcs_conv_wgrad_mfma_launch_h
+#define dcs_conv_wgrad_fold_ok dcs_conv_wgrad_fold_ok_h
+#define dcs_conv_wgrad_fold_workspace_bytes dcs_conv_wgrad_fold_workspace_bytes_h
+#define dcs_conv_wgrad_fold_run dcs_conv_wgrad_fold_run_h
+#define dcs_conv_small_dgrad_ok dcs_conv_small_dgrad_ok_h
+#define dcs_conv_small_dgrad_launch dcs_conv_small_dgrad_launch_h
+#endif
+
 namespace conv {
 
 struct Args {
-    const float2* x1; const float2* x2; const float2* wp; const float2* bias; float2* y;
+    const act2_t* x1; const act2_t* x2; const float2* wp; const float2* bias; act2_t* y;      // (activations: act_t pairs)
     int B, Hin, Win, C1, C2, up_f, up_t, zero_ins, Cout, kh, kw, sf, st, pad_f, pad_t, act;
     int Hv, Wv, Hout, Wout, tiles_w, tiles_h, rows, cols, colsp, plane;
     // optional per-output-channel real 2x2 affine applied between bias and activation (forward epilogues only):
@@ -41,10 +69,16 @@ __device__ __forceinline__ bool src_pixel(const Args& a, int b, int vy, int vx, 
     return true;
 }
 
+// one complex activation value
+__device__ __forceinline__ float2 ldc(const float2* p) { return *p; }
+__device__ __forceinline__ float2 ldc(const unsigned* p) { return dcs_ld2(reinterpret_cast<const unsigned short*>(p)); }
+__device__ __forceinline__ void stc(float2* p, float2 v) { *p = v; }
+__device__ __forceinline__ void stc(unsigned* p, float2 v) { *p = dcs_pack_bf16x2(v.x, v.y); }
+
 __device__ __forceinline__ float2 gather(const Args& a, int b, int vy, int vx, int c) {
     long sp;
     if (!src_pixel(a, b, vy, vx, &sp)) return make_float2(0.f, 0.f);
-    return (c < a.C1) ? a.x1[sp * a.C1 + c] : a.x2[sp * a.C2 + (c - a.C1)];
+    return (c < a.C1) ? ldc(a.x1 + sp * a.C1 + c) : ldc(a.x2 + sp * a.C2 + (c - a.C1));
 }
 
 // MFMA eligibility of a (Cin, Cout) pair: K groups of 4 complex input channels staged 8 at a time,
@@ -84,14 +118,14 @@ void stride_classes(int Cout, int Cin, int kh, int kw, int sf, int st, int pad_f
 // conv_wgrad_mfma.hip
 bool dcs_conv_wgrad_mfma_ok(int Cin, int Cout, int kh, int kw, int C1);
 int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW);
-int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, float* slab_b, int n_slabs,
+int dcs_conv_wgrad_mfma_launch(conv::Args& a, const act_t* gy, float2* slab_w, float* slab_b, int n_slabs,
                                hipStream_t stream);
 
 // conv_wgrad_mfma.hip: weight gradient of a 3x3 conv over an upsampled input in its folded (per-class, source-
 // resolution) form; kernel + reduce into the parameter layout
 bool dcs_conv_wgrad_fold_ok(const conv::Args& a);
 long dcs_conv_wgrad_fold_workspace_bytes(const conv::Args& a);
-int dcs_conv_wgrad_fold_run(const conv::Args& a, const float* gy, void* workspace, long workspace_bytes, float* gw_r,
+int dcs_conv_wgrad_fold_run(const conv::Args& a, const act_t* gy, void* workspace, long workspace_bytes, float* gw_r,
                             float* gw_i, float* gb_r, float* gb_i, int transposed, hipStream_t stream);
 
 // conv_wgrad_small.hip (a: forward geometry with conv_direct.hip's 16x16 tiling filled in)
@@ -101,7 +135,7 @@ int dcs_conv_wgrad_small_launch(const conv::Args& a, const float* gy, float2* sl
 
 // conv_small.hip: class-decomposed data gradient of the 1->8 stride-2 7x7 conv
 bool dcs_conv_small_dgrad_ok(int Cin, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int up_f, int up_t);
-int dcs_conv_small_dgrad_launch(const float* gy, const float* wp_bwd, float* gx, int B, int Hx, int Wx, int Hg, int Wg,
+int dcs_conv_small_dgrad_launch(const act_t* gy, const float* wp_bwd, act_t* gx, int B, int Hx, int Wx, int Hg, int Wg,
                                 int pad_f, int pad_t, hipStream_t stream);
 
 // conv_direct.hip: n small direct correlations (same batch, Cout 1 or 2) in one launch
@@ -115,7 +149,7 @@ bool dcs_conv_enc0_ok(const conv::Args& a);
 int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream);
 int dcs_conv_enc0_stat_rows(const conv::Args& a);          // rows of a.stat the launch writes
 bool dcs_conv_enc0_wgrad_ok(const conv::Args& a);
-int dcs_conv_enc0_wgrad_launch(conv::Args a, const float* gy, float2* slab_w, float2* slab_b, int max_slabs, int* n_used,
+int dcs_conv_enc0_wgrad_launch(conv::Args a, const act_t* gy, float2* slab_w, float2* slab_b, int max_slabs, int* n_used,
                                hipStream_t stream);
 
 // conv_mfma.hip
@@ -126,8 +160,8 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
 long dcs_conv_mfma_workspace_bytes(const conv::Args& a, int ncls, const conv::Cls* cls);
 long dcs_conv_mfma_workspace_bytes_plain(const conv::Args& a);
 int dcs_conv_mfma_launch(conv::Args& a, const float* bm, void* ws, long ws_bytes, hipStream_t stream);
-int dcs_conv_mfma_launch_split(conv::Args& a, const float* bm, float* y2, int nsplit, void* ws, long ws_bytes,
+int dcs_conv_mfma_launch_split(conv::Args& a, const float* bm, act_t* y2, int nsplit, void* ws, long ws_bytes,
                                hipStream_t stream);
 int dcs_conv_mfma_launch_wide(conv::Args& a, const float* bm, void* ws, long ws_bytes, hipStream_t stream);
 int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const conv::Cls* cls, int os_f, int os_t,
-                                 float* y2, int nsplit, void* ws, long ws_bytes, hipStream_t stream);
+                                 act_t* y2, int nsplit, void* ws, long ws_bytes, hipStream_t stream);

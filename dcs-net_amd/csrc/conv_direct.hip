@@ -73,7 +73,7 @@ __device__ __forceinline__ void cconv_direct_body(const ConvArgs& a, int tile_id
     }
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy < a.Hout && ox < a.Wout) {
-        float2* out = a.y + (((long)b * a.Hout + oy) * a.Wout + ox) * a.Cout + co0;
+        act2_t* out = a.y + (((long)b * a.Hout + oy) * a.Wout + ox) * a.Cout + co0;
 #pragma unroll
         for (int i = 0; i < COB; ++i) {
             const float2 bv = a.bias ? a.bias[co0 + i] : make_float2(0.f, 0.f);
@@ -83,7 +83,7 @@ __device__ __forceinline__ void cconv_direct_body(const ConvArgs& a, int tile_id
                 const float ur = vr, ui = vi;
                 vr = fmaf(q[0], ur, fmaf(q[1], ui, q[4])); vi = fmaf(q[2], ur, fmaf(q[3], ui, q[5]));
             }
-            out[i] = make_float2(dcs_act(vr, a.act), dcs_act(vi, a.act));
+            conv::stc(out + i, make_float2(dcs_act(vr, a.act), dcs_act(vi, a.act)));
         }
     }
 }
@@ -109,7 +109,7 @@ constexpr int WG_CO = 8;             // output channels per workgroup (g_Y tile 
 constexpr int WG_TAPS = 13;          // taps per thread: ceil(49 / 4) covers k = 7
 
 struct WgradArgs {
-    const float2* x1; const float2* x2; const float2* gy; float2* slab_w; float2* slab_b;
+    const act2_t* x1; const act2_t* x2; const act2_t* gy; float2* slab_w; float2* slab_b;
     int n_slabs, total_tiles, n_co_chunks;
     ConvArgs c;                      // forward geometry (y/wp/bias unused)
 };
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(TH * TW) void cconv_wgrad_kernel(WgradArgs w) {
             const int oy = oy0 + p / TW, ox = ox0 + p % TW;
             float2 v = make_float2(0.f, 0.f);
             if (oy < a.Hout && ox < a.Wout && co0 + co < a.Cout)
-                v = w.gy[(((long)b * a.Hout + oy) * a.Wout + ox) * a.Cout + co0 + co];
+                v = conv::ldc(w.gy + (((long)b * a.Hout + oy) * a.Wout + ox) * a.Cout + co0 + co);
             gt[p * WG_CO + co] = v;
         }
         __syncthreads();
@@ -231,8 +231,8 @@ int launch_wgrad_reduce(const float2* slab_w, const float2* slab_b, int n_slabs,
 // (the re-layout kernels themselves live in pack_jobs.hip: packjob::DIRECT / packjob::BWD)
 
 // g_x1[b][y][x][c] = sum over the up_f x up_t block of g_Xv[b][..][..][c]; channels >= C1 go to g_x2
-__global__ void upsample_cat_bwd_kernel(const float2* __restrict__ gxv, float2* __restrict__ gx1,
-                                        float2* __restrict__ gx2, int B, int Hin, int Win, int C1, int C2, int up_f,
+__global__ void upsample_cat_bwd_kernel(const act2_t* __restrict__ gxv, act2_t* __restrict__ gx1,
+                                        act2_t* __restrict__ gx2, int B, int Hin, int Win, int C1, int C2, int up_f,
                                         int up_t) {
     const int C = C1 + C2;
     const long n = (long)B * Hin * Win * C;
@@ -246,12 +246,12 @@ __global__ void upsample_cat_bwd_kernel(const float2* __restrict__ gxv, float2* 
         float sr = 0.f, si = 0.f;
         for (int dy = 0; dy < up_f; ++dy)
             for (int dx = 0; dx < up_t; ++dx) {
-                const float2 v = gxv[(((long)b * Hv + y * up_f + dy) * Wv + x * up_t + dx) * C + c];
+                const float2 v = conv::ldc(gxv + (((long)b * Hv + y * up_f + dy) * Wv + x * up_t + dx) * C + c);
                 sr += v.x; si += v.y;
             }
         const long sp = ((long)b * Hin + y) * Win + x;
-        if (c < C1) gx1[sp * C1 + c] = make_float2(sr, si);
-        else        gx2[sp * C2 + (c - C1)] = make_float2(sr, si);
+        if (c < C1) conv::stc(gx1 + sp * C1 + c, make_float2(sr, si));
+        else        conv::stc(gx2 + sp * C2 + (c - C1), make_float2(sr, si));
     }
 }
 
@@ -297,7 +297,7 @@ int launch_direct_multi(ConvArgs* a, int n, hipStream_t stream) {
 }
 
 int launch_direct(ConvArgs& a, hipStream_t stream) {
-    if (dcs_conv_k7_ok(&a, 1)) return dcs_conv_k7_launch(&a, 1, stream);        // the attention convs: conv_k7.hip
+    if (!DCS_ACT_IS_BF16 && dcs_conv_k7_ok(&a, 1)) return dcs_conv_k7_launch(&a, 1, stream);        // the attention convs: conv_k7.hip (fp32 maps)
     if (dcs_conv_enc0_ok(a)) return dcs_conv_enc0_launch(a, stream);            // the first encoder conv: conv_enc0.hip
     if (!conv_geometry(a)) return DCS_ERR_BADARG;
     const int Cin = a.C1 + a.C2;
@@ -322,10 +322,10 @@ int launch_direct(ConvArgs& a, hipStream_t stream) {
     return DCS_OK;
 }
 
-ConvArgs fwd_args(const float* x1, const float* x2, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+ConvArgs fwd_args(const void* x1, const void* x2, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
                   int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t) {
     ConvArgs a{};
-    a.x1 = (const float2*)x1; a.x2 = (const float2*)x2;
+    a.x1 = (const act2_t*)x1; a.x2 = (const act2_t*)x2;
     a.B = B; a.Hin = Hin; a.Win = Win; a.C1 = C1; a.C2 = C2; a.up_f = up_f; a.up_t = up_t; a.zero_ins = 0;
     a.Cout = Cout; a.kh = kh; a.kw = kw; a.sf = sf; a.st = st; a.pad_f = pad_f; a.pad_t = pad_t; a.act = DCS_ACT_NONE;
     a.Hv = Hin * up_f; a.Wv = Win * up_t;
@@ -354,8 +354,11 @@ int wgrad_slabs(const ConvArgs& a, long* wsz_out) {
 
 }  // namespace
 
+#ifndef DCS_ACT_BF16
 int dcs_conv_direct_multi(conv::Args* a, int n, hipStream_t stream) { return launch_direct_multi(a, n, stream); }
+#endif
 
+#ifndef DCS_ACT_BF16
 extern "C" int dcs_pack_conv_weight(const float* w_r, const float* w_i, const float* b_r, const float* b_i, float* wp,
                                     float* bias_out, int Cout, int Cin, int kh, int kw, int transposed, int up_f,
                                     int up_t, dcs_stream_t stream) {
@@ -384,14 +387,18 @@ extern "C" int dcs_pack_conv_weight(const float* w_r, const float* w_i, const fl
         return conv::pack_fold(wp, wp + base_floats(Cout, Cin, kh * kw), Cout, Cin, up_f, up_t, dcs_stream(stream));
     return DCS_OK;
 }
+#endif
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_packed_weight_floats(int Cout, int Cin, int kh, int kw, int up_f, int up_t) {
     if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || up_f < 1 || up_t < 1) return -1;
     long n = base_floats(Cout, Cin, kh * kw);
     if (conv::fold_ok(Cin, Cout, kh, kw, 1, 1, 1, 1, up_f, up_t)) n += conv::fold_floats(Cout, Cin, up_f, up_t);
     return n;
 }
+#endif
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_packed_weight_bwd_floats(int Cout, int Cin, int kh, int kw, int sf, int st, int pad_f, int pad_t,
                                              int up_f, int up_t) {
     if (Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || sf < 1 || st < 1 || up_f < 1 || up_t < 1) return -1;
@@ -401,7 +408,9 @@ extern "C" long dcs_packed_weight_bwd_floats(int Cout, int Cin, int kh, int kw, 
         n += conv::stride_bwd_floats(Cout, Cin, kh, kw, sf, st, pad_f, pad_t);
     return n;
 }
+#endif
 
+#ifndef DCS_ACT_BF16
 extern "C" int dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout, int Cin, int kh, int kw, int sf,
                                         int st, int pad_f, int pad_t, int up_f, int up_t, dcs_stream_t stream) {
     if (!wp || !wp_bwd || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || sf < 1 || st < 1 || up_f < 1 || up_t < 1)
@@ -430,11 +439,12 @@ extern "C" int dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout
         return conv::pack_stride_bwd(wp_bwd, extra, Cout, Cin, kh, kw, sf, st, pad_f, pad_t, s);
     return DCS_OK;
 }
+#endif
 
 // forward launch description shared by the workspace query and the launch itself
 struct FwdPlan { ConvArgs a; int path, ncls, os_f, os_t; conv::Cls cls[4]; };   // path 0: folded classes, 1: plain MFMA, 2: direct
 
-static FwdPlan fwd_plan(const float* x1, const float* x2, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+static FwdPlan fwd_plan(const void* x1, const void* x2, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
                         int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t) {
     FwdPlan p{};
     if (!(C1 & 1) && conv::fold_ok(C1 + C2, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) {
@@ -450,6 +460,7 @@ static FwdPlan fwd_plan(const float* x1, const float* x2, int B, int Hin, int Wi
     return p;
 }
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_cconv2d_fwd_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout,
                                                 int kh, int kw, int sf, int st, int pad_f, int pad_t) {
     if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || up_f < 1 || up_t < 1 || kh < 1 || kw < 1 ||
@@ -461,24 +472,29 @@ extern "C" long dcs_cconv2d_fwd_workspace_bytes(int B, int Hin, int Win, int C1,
     if (p.path == 1) return dcs_conv_mfma_workspace_bytes_plain(p.a);
     return 0;
 }
+#endif
 
-extern "C" int dcs_cconv2d_fwd(const float* x1, const float* x2, const float* wp, const float* bias, float* y,
+extern "C" int DCS_SYM(dcs_cconv2d_fwd_affine)(const act_t* x1, const act_t* x2, const float* wp, const float* bias, const float* coef,
+                                      act_t* y, void* workspace, long workspace_bytes, int B, int Hin, int Win, int C1, int C2,
+                                      int up_f, int up_t, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t,
+                                      int act, dcs_stream_t stream);
+extern "C" int DCS_SYM(dcs_cconv2d_fwd)(const act_t* x1, const act_t* x2, const float* wp, const float* bias, act_t* y,
                                void* workspace, long workspace_bytes, int B, int Hin, int Win, int C1, int C2, int up_f,
                                int up_t, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
                                dcs_stream_t stream) {
-    return dcs_cconv2d_fwd_affine(x1, x2, wp, bias, nullptr, y, workspace, workspace_bytes, B, Hin, Win, C1, C2, up_f, up_t, Cout,
+    return DCS_SYM(dcs_cconv2d_fwd_affine)(x1, x2, wp, bias, nullptr, y, workspace, workspace_bytes, B, Hin, Win, C1, C2, up_f, up_t, Cout,
                                   kh, kw, sf, st, pad_f, pad_t, act, stream);
 }
 
-extern "C" int dcs_cconv2d_fwd_affine(const float* x1, const float* x2, const float* wp, const float* bias, const float* coef,
-                                      float* y, void* workspace, long workspace_bytes, int B, int Hin, int Win, int C1, int C2,
+extern "C" int DCS_SYM(dcs_cconv2d_fwd_affine)(const act_t* x1, const act_t* x2, const float* wp, const float* bias, const float* coef,
+                                      act_t* y, void* workspace, long workspace_bytes, int B, int Hin, int Win, int C1, int C2,
                                       int up_f, int up_t, int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t,
                                       int act, dcs_stream_t stream) {
     if (!wp || !bias || !y) return DCS_ERR_BADARG;
     if (!fwd_geom_ok(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t)) return DCS_ERR_BADARG;
     if (act < DCS_ACT_NONE || act > DCS_ACT_SIGMOID) return DCS_ERR_BADARG;
     FwdPlan p = fwd_plan(x1, x2, B, Hin, Win, C1, C2, up_f, up_t, Cout, kh, kw, sf, st, pad_f, pad_t);
-    p.a.wp = (const float2*)wp; p.a.bias = (const float2*)bias; p.a.y = (float2*)y; p.a.act = act; p.a.coef = coef;
+    p.a.wp = (const float2*)wp; p.a.bias = (const float2*)bias; p.a.y = (act2_t*)y; p.a.act = act; p.a.coef = coef;
     if (p.path == 0)
         return dcs_conv_mfma_launch_classes(p.a, wp + base_floats(Cout, C1 + C2, kh * kw), p.ncls, p.cls, p.os_f, p.os_t,
                                             nullptr, 0, workspace, workspace_bytes, dcs_stream(stream));
@@ -502,6 +518,7 @@ static int fwd_stat_rows(const FwdPlan& p, bool have_ws) {
     return 0;
 }
 
+#ifndef DCS_ACT_BF16
 extern "C" int dcs_cconv2d_fwd_stats_rows(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh,
                                           int kw, int sf, int st, int pad_f, int pad_t) {
     if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || up_f < 1 || up_t < 1 || kh < 1 || kw < 1 ||
@@ -511,12 +528,13 @@ extern "C" int dcs_cconv2d_fwd_stats_rows(int B, int Hin, int Win, int C1, int C
     if (p.a.Hout <= 0 || p.a.Wout <= 0) return -1;
     return fwd_stat_rows(p, true);
 }
+#endif
 
 // dcs_cconv2d_fwd (no activation) that ALSO leaves the training-mode CBN statistics of its raw output: stat =
 // float[Cout][5][stat_rows], column r = one workgroup's partial {S_r, S_i, S_rr, S_ii, S_ri} of (y - bias), fixed order;
 // *rows_used (host int) = the rows actually written (<= stat_rows = dcs_cconv2d_fwd_stats_rows).  Feeds dcs_cbn_fwd_slabs
 // with pivot = bias: the CBN's statistics pass over y (c_network.py:107-114: conv, CBN back to back) disappears.
-extern "C" int dcs_cconv2d_fwd_stats(const float* x1, const float* x2, const float* wp, const float* bias, float* y,
+extern "C" int DCS_SYM(dcs_cconv2d_fwd_stats)(const act_t* x1, const act_t* x2, const float* wp, const float* bias, act_t* y,
                                      float* stat, int stat_rows, int* rows_used, void* workspace, long workspace_bytes, int B,
                                      int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh, int kw, int sf,
                                      int st, int pad_f, int pad_t, dcs_stream_t stream) {
@@ -529,7 +547,7 @@ extern "C" int dcs_cconv2d_fwd_stats(const float* x1, const float* x2, const flo
     const int rows = fwd_stat_rows(p, have_ws);
     if (rows < 1 || rows > stat_rows) return DCS_ERR_BADARG;
     *rows_used = rows;
-    p.a.wp = (const float2*)wp; p.a.bias = (const float2*)bias; p.a.y = (float2*)y; p.a.act = DCS_ACT_NONE; p.a.coef = nullptr;
+    p.a.wp = (const float2*)wp; p.a.bias = (const float2*)bias; p.a.y = (act2_t*)y; p.a.act = DCS_ACT_NONE; p.a.coef = nullptr;
     p.a.stat = stat; p.a.stat_stride = stat_rows;
     if (p.path == 0)
         return dcs_conv_mfma_launch_classes(p.a, wp + base_floats(Cout, C1 + C2, kh * kw), p.ncls, p.cls, p.os_f, p.os_t,
@@ -550,6 +568,7 @@ static bool rconv_ok(int C1r, int C2r, int Coutr) {
     return conv::mfma_ok((C1r + C2r) / 2, Coutr / 2) && !((C1r / 2) & 1);
 }
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_rconv2d_fwd_workspace_bytes(int B, int Hin, int Win, int C1r, int C2r, int up_f, int up_t, int Coutr,
                                                 int kh, int kw, int sf, int st, int pad_f, int pad_t) {
     if (!rconv_ok(C1r, C2r, Coutr) || B <= 0 || Hin <= 0 || Win <= 0) return -1;
@@ -557,7 +576,9 @@ extern "C" long dcs_rconv2d_fwd_workspace_bytes(int B, int Hin, int Win, int C1r
                                 pad_t);
     return dcs_conv_mfma_workspace_bytes_plain(a);
 }
+#endif
 
+#ifndef DCS_ACT_BF16
 extern "C" int dcs_rconv2d_fwd(const float* x1, const float* x2, const float* bm, const float* bias, float* y,
                                void* workspace, long workspace_bytes, int B, int Hin, int Win, int C1r, int C2r, int up_f,
                                int up_t, int Coutr, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act,
@@ -570,11 +591,13 @@ extern "C" int dcs_rconv2d_fwd(const float* x1, const float* x2, const float* bm
     a.wp = nullptr; a.bias = (const float2*)bias; a.y = (float2*)y; a.act = act;
     return dcs_conv_mfma_launch_wide(a, bm, workspace, workspace_bytes, dcs_stream(stream));
 }
+#endif
 
 // Gradient of dcs_rconv2d_fwd's VIRTUAL input (the upsampled concatenation), float[B][Hv][Wv][Cinr]: a stride-1
 // correlation of the zero-inserted g_Y with the caller-packed panel of the flipped, in/out-swapped kernel
 // (B[tap][k = real output channel][n = real input channel]), padding k-1-p.  The block sum over an upsample and the
 // channel split of a concatenation are dcs_upsample_cat_bwd's (complex channel counts Cr/2).
+#ifndef DCS_ACT_BF16
 static conv::Args rconv_dgrad_args(const float* gy, float* gxv, int B, int Hv, int Wv, int Cinr, int Coutr, int kh, int kw,
                                    int sf, int st, int pad_f, int pad_t) {
     ConvArgs a{};
@@ -587,7 +610,9 @@ static conv::Args rconv_dgrad_args(const float* gy, float* gxv, int B, int Hv, i
     a.Hout = Hv; a.Wout = Wv;
     return a;
 }
+#endif
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_rconv2d_bwd_data_workspace_bytes(int B, int Hv, int Wv, int Cinr, int Coutr, int kh, int kw, int sf,
                                                      int st, int pad_f, int pad_t) {
     if (B <= 0 || Hv <= 0 || Wv <= 0 || !rconv_ok(Coutr, 0, Cinr) || kh < 1 || kw < 1 || sf < 1 || st < 1 || pad_f < 0 ||
@@ -597,7 +622,9 @@ extern "C" long dcs_rconv2d_bwd_data_workspace_bytes(int B, int Hv, int Wv, int 
     if (a.Hin <= 0 || a.Win <= 0) return -1;
     return dcs_conv_mfma_workspace_bytes_plain(a);
 }
+#endif
 
+#ifndef DCS_ACT_BF16
 extern "C" int dcs_rconv2d_bwd_data(const float* gy, const float* bm_bwd, float* gxv, void* workspace, long workspace_bytes,
                                     int B, int Hv, int Wv, int Cinr, int Coutr, int kh, int kw, int sf, int st, int pad_f,
                                     int pad_t, dcs_stream_t stream) {
@@ -608,6 +635,7 @@ extern "C" int dcs_rconv2d_bwd_data(const float* gy, const float* bm_bwd, float*
     if (a.Hin <= 0 || a.Win <= 0) return DCS_ERR_BADARG;
     return dcs_conv_mfma_launch_wide(a, bm_bwd, workspace, workspace_bytes, dcs_stream(stream));
 }
+#endif
 
 // data-gradient launch description shared by the workspace query and the launch itself
 struct DgradPlan {
@@ -621,14 +649,14 @@ struct DgradPlan {
     int Hv, Wv, Hout, Wout;
 };
 
-static DgradPlan dgrad_plan(const float* gy, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh,
+static DgradPlan dgrad_plan(const void* gy, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh,
                             int kw, int sf, int st, int pad_f, int pad_t) {
     DgradPlan p{};
     const int Cin = C1 + C2;
     p.Hv = Hin * up_f; p.Wv = Win * up_t;
     p.Hout = (p.Hv + 2 * pad_f - kh) / sf + 1; p.Wout = (p.Wv + 2 * pad_t - kw) / st + 1;
     ConvArgs& a = p.a;
-    a.x1 = (const float2*)gy; a.x2 = nullptr; a.bias = nullptr;
+    a.x1 = (const act2_t*)gy; a.x2 = nullptr; a.bias = nullptr;
     a.B = B; a.Hin = p.Hout; a.Win = p.Wout; a.C1 = Cout; a.C2 = 0; a.Cout = Cin; a.act = DCS_ACT_NONE;
     p.ncls = 1; p.os_f = 1; p.os_t = 1;
     if (!(C1 & 1) && conv::fold_ok(Cin, Cout, kh, kw, sf, st, pad_f, pad_t, up_f, up_t)) {
@@ -674,6 +702,7 @@ static long dgrad_split_bytes(const DgradPlan& p) {
 
 static long align256(long n) { return (n + 255) / 256 * 256; }
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_cconv2d_bwd_data_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
                                                      int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t) {
     if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || up_f < 1 || up_t < 1 || kh < 1 || kw < 1 ||
@@ -683,8 +712,9 @@ extern "C" long dcs_cconv2d_bwd_data_workspace_bytes(int B, int Hin, int Win, in
     if (p.Hout <= 0 || p.Wout <= 0) return -1;
     return align256(p.gxv_bytes) + dgrad_split_bytes(p);     // [g_Xv | split-K slices]
 }
+#endif
 
-extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float* gx1, float* gx2, void* workspace,
+extern "C" int DCS_SYM(dcs_cconv2d_bwd_data)(const act_t* gy, const float* wp_bwd, act_t* gx1, act_t* gx2, void* workspace,
                                     long workspace_bytes, int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
                                     int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t,
                                     dcs_stream_t stream) {
@@ -698,16 +728,16 @@ extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float*
     if (p.Hout <= 0 || p.Wout <= 0) return DCS_ERR_BADARG;
     hipStream_t s = dcs_stream(stream);
     const float* extra = wp_bwd + base_floats(Cin, Cout, taps);
-    float* gxv = gx1;
+    act_t* gxv = gx1;
     if (p.gxv_bytes > 0) {                                  // generic: gradient of the virtual input, then fold it
         if (!workspace || workspace_bytes < p.gxv_bytes) return DCS_ERR_WORKSPACE;
-        gxv = (float*)workspace;
+        gxv = (act_t*)workspace;
     }
     // whatever follows g_Xv in the workspace is split-K scratch (optional: too small just means no slicing)
     const long used = align256(p.gxv_bytes);
     void* ws2 = (workspace && workspace_bytes > used) ? (void*)((char*)workspace + used) : nullptr;
     const long ws2_bytes = ws2 ? workspace_bytes - used : 0;
-    p.a.y = (float2*)gxv;
+    p.a.y = (act2_t*)gxv;
     int rc;
     switch (p.path) {
         case 0:
@@ -732,12 +762,13 @@ extern "C" int dcs_cconv2d_bwd_data(const float* gy, const float* wp_bwd, float*
     const long n = (long)B * Hin * Win * Cin;
     long nb = (n + 255) / 256;
     if (nb > 4096) nb = 4096;
-    DCS_LAUNCH(upsample_cat_bwd_kernel, dim3((int)nb), dim3(256), 0, s, (const float2*)gxv, (float2*)gx1,
-                       (float2*)gx2, B, Hin, Win, C1, C2, up_f, up_t);
+    DCS_LAUNCH(upsample_cat_bwd_kernel, dim3((int)nb), dim3(256), 0, s, (const act2_t*)gxv, (act2_t*)gx1,
+                       (act2_t*)gx2, B, Hin, Win, C1, C2, up_f, up_t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
 
+#ifndef DCS_ACT_BF16
 extern "C" long dcs_cconv2d_bwd_weight_workspace_bytes(int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
                                                        int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t) {
     if (B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || kh < 1 || kw < 1 || sf < 1 || st < 1 ||
@@ -759,8 +790,9 @@ extern "C" long dcs_cconv2d_bwd_weight_workspace_bytes(int B, int Hin, int Win, 
     }
     return bytes;
 }
+#endif
 
-extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const float* gy, float* gw_r, float* gw_i,
+extern "C" int DCS_SYM(dcs_cconv2d_bwd_weight)(const act_t* x1, const act_t* x2, const act_t* gy, float* gw_r, float* gw_i,
                                       float* gb_r, float* gb_i, void* workspace, long workspace_bytes, int B, int Hin,
                                       int Win, int C1, int C2, int up_f, int up_t, int Cout, int kh, int kw, int sf,
                                       int st, int pad_f, int pad_t, int transposed, dcs_stream_t stream) {
@@ -791,12 +823,12 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     long wsz;
     w.n_slabs = wgrad_slabs(w.c, &wsz);
     if (workspace_bytes < (long)w.n_slabs * (wsz + Cout) * (long)sizeof(float2)) return DCS_ERR_WORKSPACE;
-    w.x1 = (const float2*)x1; w.x2 = (const float2*)x2; w.gy = (const float2*)gy;
+    w.x1 = (const act2_t*)x1; w.x2 = (const act2_t*)x2; w.gy = (const act2_t*)gy;
     w.slab_w = (float2*)workspace;
     w.slab_b = w.slab_w + (long)w.n_slabs * wsz;
     w.total_tiles = w.c.tiles_w * w.c.tiles_h * B;
     const int Cin = C1 + C2;
-    w.c.x1 = (const float2*)x1;
+    w.c.x1 = (const act2_t*)x1;
     if (dcs_conv_enc0_wgrad_ok(w.c)) {           // 7x7 1->8 stride 2: taps x pixels on the MFMA units (conv_enc0.hip)
         hipStream_t s = dcs_stream(stream);
         int ns = 0;
@@ -804,6 +836,7 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
         if (rc != DCS_OK) return rc;
         return launch_wgrad_reduce(w.slab_w, w.slab_b, ns, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed, s);
     }
+#ifndef DCS_ACT_BF16                             // (fp32 maps only: the attention convs' operands stay fp32 in either mode)
     if (dcs_conv_wgrad_small_ok(w.c)) {          // 7x7 2->1 / 1->8: pixel-stationary kernel (conv_wgrad_small.hip)
         hipStream_t s = dcs_stream(stream);
         // two resident workgroups per CU.  The 2 -> 1 attention convs run batched (13 problems in one launch inside a
@@ -815,6 +848,7 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
         if (rc != DCS_OK) return rc;
         return launch_wgrad_reduce(w.slab_w, w.slab_b, ns, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed, s);
     }
+#endif
     const int n_ci = (Cin + CHUNK - 1) / CHUNK;
     w.n_co_chunks = (Cout + WG_CO - 1) / WG_CO;
     const size_t lds = ((size_t)CHUNK * w.c.plane + (size_t)TH * TW * WG_CO) * sizeof(float2);
@@ -833,6 +867,7 @@ extern "C" int dcs_cconv2d_bwd_weight(const float* x1, const float* x2, const fl
     return launch_wgrad_reduce(w.slab_w, w.slab_b, w.n_slabs, gw_r, gw_i, gb_r, gb_i, Cout, Cin, kh, kw, transposed, s);
 }
 
+#ifndef DCS_ACT_BF16
 extern "C" int dcs_upsample_cat_bwd(const float* gxv, float* gx1, float* gx2, int B, int Hin, int Win, int C1, int C2,
                                     int up_f, int up_t, dcs_stream_t stream) {
     if (!gxv || !gx1 || B <= 0 || Hin <= 0 || Win <= 0 || C1 <= 0 || C2 < 0 || up_f < 1 || up_t < 1) return DCS_ERR_BADARG;
@@ -845,3 +880,4 @@ extern "C" int dcs_upsample_cat_bwd(const float* gxv, float* gx1, float* gx2, in
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
+#endif

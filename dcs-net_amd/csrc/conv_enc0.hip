@@ -47,28 +47,30 @@ __device__ __forceinline__ void patch_load(const conv::Args& a, const TileDiv& d
     int b, ty, tx;
     tile_split(d, tile, &b, &ty, &tx);
     const int y0 = ty * (2 * TR) - 3, x0 = tx * (2 * TC) - 3;
-    const float2* xb = a.x1 + (long)b * a.Hin * a.Win;
+    const act2_t* xb = a.x1 + (long)b * a.Hin * a.Win;
     if (y0 >= 0 && y0 + PR <= a.Hin && x0 >= 0 && x0 + PC <= a.Win) {                 // (uniform)
-        const float2* org = xb + (long)y0 * a.Win + x0;
+        const act2_t* org = xb + (long)y0 * a.Win + x0;
         const int skip = a.Win - PC;
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int i = t + 256 * k;
-            if (k < NL - 1 || i < PR * PC) pv[k] = org[i + row_of(rows, k) * skip];
+            if (k < NL - 1 || i < PR * PC) pv[k] = conv::ldc(org + i + row_of(rows, k) * skip);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int i = t + 256 * k, r = row_of(rows, k), c = i - r * PC;
             const int y = y0 + r, x = x0 + c;
-            pv[k] = (i < PR * PC && y >= 0 && y < a.Hin && x >= 0 && x < a.Win) ? xb[(long)y * a.Win + x] : make_float2(0.f, 0.f);
+            const bool in_ = i < PR * PC && y >= 0 && y < a.Hin && x >= 0 && x < a.Win;
+            const float2 v_ = conv::ldc(xb + (in_ ? (long)y * a.Win + x : 0));
+            pv[k] = in_ ? v_ : make_float2(0.f, 0.f);
         }
     }
 }
 
 // bias, folded eval-mode CBN, activation and store of one lane's 2 x 4 accumulators (M-tiles h = 0, 1; rows kg*4 + r)
 template <int ACT, bool CHECK, bool STAT>
-__device__ __forceinline__ void store_pair(const conv::Args& a, const f32x4v* acc, float* yp, int ox, float bv, float c_re,
+__device__ __forceinline__ void store_pair(const conv::Args& a, const f32x4v* acc, act_t* yp, int ox, float bv, float c_re,
                                            float c_im, float c_add, int li, float* st) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -84,7 +86,7 @@ __device__ __forceinline__ void store_pair(const conv::Args& a, const f32x4v* ac
                 v = (li & 1) ? fmaf(c_re, pv, fmaf(c_im, v, c_add)) : fmaf(c_re, v, fmaf(c_im, pv, c_add));
             }
             v = ACT < 0 ? dcs_act(v, a.act) : dcs_act(v, ACT);
-            if (!CHECK || ox + h * 16 + r < a.Wout) yp[(h * 16 + r) * 16] = v;
+            if (!CHECK || ox + h * 16 + r < a.Wout) dcs_st1(yp + (h * 16 + r) * 16, v);
         }
 }
 
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256, 4) void cconv_enc0_kernel(conv::Args a, TileDi
             // C/D: col = li, rows kg*4 + r -> pixel (oy0 + py, ox0 + h*16 + kg*4 + r); one row pointer, constant offsets
             const int oy = oy0 + py;
             if (oy < a.Hout) {
-                float* yp = reinterpret_cast<float*>(a.y) + (((long)b * a.Hout + oy) * a.Wout + ox0 + kg * 4) * 16 + li;
+                act_t* yp = reinterpret_cast<act_t*>(a.y) + (((long)b * a.Hout + oy) * a.Wout + ox0 + kg * 4) * 16 + li;
                 if (ox0 + TC <= a.Wout) store_pair<ACT, false, STAT>(a, acc, yp, 0, bv, c_re, c_im, c_add, li, st);
                 else store_pair<ACT, true, STAT>(a, acc, yp, ox0 + kg * 4, bv, c_re, c_im, c_add, li, st);
             }
@@ -230,7 +232,7 @@ constexpr int MT = 7, QPW = 16;                              // M-tiles; pixel q
 constexpr int RED_FLOATS = 3 * MT * 4 * 64, DL_FLOATS = MT * 16 * 16;
 constexpr int WG_SMEM = (RED_FLOATS + DL_FLOATS) * 4 > 2 * PR * PCP * 8 ? (RED_FLOATS + DL_FLOATS) * 4 : 2 * PR * PCP * 8;
 
-__global__ __launch_bounds__(256) void cconv_enc0_wgrad_kernel(conv::Args a, TileDiv d, int ntile, const float* __restrict__ gy,
+__global__ __launch_bounds__(256) void cconv_enc0_wgrad_kernel(conv::Args a, TileDiv d, int ntile, const act_t* __restrict__ gy,
                                                                float2* __restrict__ slab_w, float2* __restrict__ slab_b) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WG_SMEM];
     float2 (*patch)[PR * PCP] = reinterpret_cast<float2 (*)[PR * PCP]>(smem);
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void cconv_enc0_wgrad_kernel(conv::Args a, Til
             // always a load (clamped pixel), zeroed afterwards: as sixteen predicated loads each one sat in its own branch
             // and was waited for with vmcnt(0) before the next was issued
             const bool inb = oy < a.Hout && ox < a.Wout;
-            const float v = gy[(((long)b * a.Hout + (inb ? oy : 0)) * a.Wout + (inb ? ox : 0)) * 16 + li];
+            const float v = dcs_ld1(gy + (((long)b * a.Hout + (inb ? oy : 0)) * a.Wout + (inb ? ox : 0)) * 16 + li);
             gv[q] = inb ? v : 0.f;
         }
         // lane's window origin for quad 0: pixel (2 wave, kg); quad q adds a compile-time offset
@@ -394,7 +396,7 @@ int dcs_conv_enc0_stat_rows(const conv::Args& a0) {
 }
 
 bool dcs_conv_enc0_wgrad_ok(const conv::Args& a) { return enc0_geom(a) && a.x1; }
-int dcs_conv_enc0_wgrad_launch(conv::Args a, const float* gy, float2* slab_w, float2* slab_b, int max_slabs, int* n_used,
+int dcs_conv_enc0_wgrad_launch(conv::Args a, const act_t* gy, float2* slab_w, float2* slab_b, int max_slabs, int* n_used,
                                hipStream_t stream) {
     if (!dcs_conv_enc0_wgrad_ok(a) || !gy || !slab_w || !slab_b || max_slabs < 1) return DCS_ERR_BADARG;
     a.Hout = (a.Hin + 2 * a.pad_f - K7) / 2 + 1;
@@ -417,6 +419,6 @@ int dcs_conv_enc0_wgrad_launch(conv::Args a, const float* gy, float2* slab_w, fl
     return DCS_OK;
 }
 
-#ifdef DCS_ENC0_DIAG
+#if defined(DCS_ENC0_DIAG) && !defined(DCS_ACT_BF16)
 extern "C" int dcs_debug_set_enc0_buffer(void* p) { g_edbg = (long long*)p; return 0; }
 #endif

@@ -191,7 +191,12 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         // VALU busy for ~30 % of a workgroup's life while its MFMA pipe idled).
         constexpr int GU = (PR == 2 && CH == 32) ? DCS_X6_GU32 : (PR == 2 ? DCS_X6_GU16 : 4);
         for (int base = t; base < nslots; base += 256 * GU) {
-            float4 v[GU];
+#if DCS_ACT_IS_BF16
+            typedef uint2 raw_t;                                       // two complex values = 4 bf16, as stored
+#else
+            typedef float4 raw_t;
+#endif
+            raw_t v[GU];
             int spv[GU];
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
@@ -201,17 +206,26 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int idx = base + u * 256;
+#if DCS_ACT_IS_BF16
+                v[u] = make_uint2(0u, 0u);
+#else
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
                 if (spv[u] >= 0) {
                     const int c = ch * CH + 2 * (idx % Q);
-                    const float2* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
-                    v[u] = *reinterpret_cast<const float4*>(src);
+                    const act2_t* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
+                    v[u] = *reinterpret_cast<const raw_t*>(src);
                 }
             }
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int idx = base + u * 256;
                 if (idx >= nslots) continue;
+#if DCS_ACT_IS_BF16
+                // bf16 activations (precision mode 1 only): the stored bits ARE the MFMA operand — no conversion
+                static_assert(PR == 1, "bf16 activations run the bf16-operand kernel");
+                *reinterpret_cast<uint2*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = v[u];
+#else
                 if (PR == 2) {                                         // 2 complex -> 3 planes of 4 bf16 (exact split)
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     float4 r = v[u];
@@ -229,6 +243,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 } else {
                     *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
                 }
+#endif
             }
         }
         __syncthreads();
@@ -345,9 +360,10 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         const bool second = m.ksplit <= 1 && m.y2 != nullptr && n0 >= m.nsplit;      // (a K slice stores raw [pixel][N] tiles)
         const int width = m.ksplit > 1 || m.y2 == nullptr ? m.N : (second ? m.N - m.nsplit : m.nsplit);
         const int col = second ? n0 - m.nsplit : n0;
-        float* yb;
-        if (m.ksplit > 1) yb = m.part + (long)kslice * m.slab_floats + (long)b * a.Hout * a.Wout * m.N;   // raw partial tile
-        else yb = (second ? m.y2 : reinterpret_cast<float*>(a.y)) + (long)b * a.Hout * a.Wout * width;
+        float* pb = nullptr;                                           // a K slice: raw fp32 partial tile
+        act_t* yb = nullptr;
+        if (m.ksplit > 1) pb = m.part + (long)kslice * m.slab_floats + (long)b * a.Hout * a.Wout * m.N;
+        else yb = (second ? m.y2 : reinterpret_cast<act_t*>(a.y)) + (long)b * a.Hout * a.Wout * width;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         float q[12];
 #pragma unroll
@@ -462,8 +478,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     }
                     v.x = dcs_act(v.x, a.act); v.y = dcs_act(v.y, a.act); v.z = dcs_act(v.z, a.act); v.w = dcs_act(v.w, a.act);
                 }
-                if (n0 < m.N && oy < k.Hc && ox < k.Wc)      // 32-bit offsets inside one image (launcher checks the extent)
-                    *reinterpret_cast<float4*>(yb + ((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col) = v;
+                if (n0 < m.N && oy < k.Hc && ox < k.Wc) {    // 32-bit offsets inside one image (launcher checks the extent)
+                    const int off = ((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col;
+                    if (m.ksplit > 1) *reinterpret_cast<float4*>(pb + off) = v;
+                    else dcs_st4(yb + off, v);
+                }
             }
         }
     }
@@ -590,8 +609,8 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (spv[u] >= 0) {
                     const int c = ch * CH + 2 * (idx % Q);
-                    const float2* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
-                    v[u] = *reinterpret_cast<const float4*>(src);
+                    const act2_t* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
+                    v[u] = dcs_ld4(reinterpret_cast<const act_t*>(src));       // (bf16 activations: widened, the kernel computes in fp32)
                 }
             }
 #pragma unroll
@@ -661,10 +680,10 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
     const int n = li;
     const float bv = biasf ? biasf[n] : 0.f;
     const bool second = m.y2 != nullptr && n >= m.nsplit;
-    float* yf = second ? m.y2 : reinterpret_cast<float*>(a.y);
+    act_t* yf = second ? m.y2 : reinterpret_cast<act_t*>(a.y);
     const int width = m.y2 == nullptr ? 16 : (second ? 16 - m.nsplit : m.nsplit);
     const int col = second ? n - m.nsplit : n;
-    float* yb = yf + (long)b * a.Hout * a.Wout * width;
+    act_t* yb = yf + (long)b * a.Hout * a.Wout * width;
     float c_re = 1.f, c_im = 0.f, c_add = 0.f;                        // folded eval-mode CBN (see the 32-column kernel)
     if (a.coef) {
         const float* q = a.coef + 6 * (n >> 1);
@@ -687,7 +706,7 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
                 v = (n & 1) ? fmaf(c_re, pv, fmaf(c_im, v, c_add)) : fmaf(c_re, v, fmaf(c_im, pv, c_add));
             }
             if (oy < k.Hc && ox < k.Wc)
-                yb[((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col] = dcs_act(v, a.act);
+                dcs_st1(yb + ((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col, dcs_act(v, a.act));
         }
     if (stat_row) {
         // column li of 4 row groups (lanes li + 16 g4) x 4 waves: shuffles over g4, then LDS over the waves
@@ -709,8 +728,8 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
 
 // y[p][n] = act(sum_s part[s][p][n] + bias[n]); columns >= nsplit of a cat split go to y2.  One float4 per thread.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long slab_floats,
-                                                            const float* __restrict__ bias, float* __restrict__ y,
-                                                            float* __restrict__ y2, int nsplit, int N, int act,
+                                                            const float* __restrict__ bias, act_t* __restrict__ y,
+                                                            act_t* __restrict__ y2, int nsplit, int N, int act,
                                                             const float* __restrict__ coef) {
     const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
     if (i4 * 4 >= slab_floats) return;
@@ -730,9 +749,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         v.z = fmaf(q[6], u.z, fmaf(q[7], u.w, q[10])); v.w = fmaf(q[8], u.z, fmaf(q[9], u.w, q[11]));
     }
     v.x = dcs_act(v.x, act); v.y = dcs_act(v.y, act); v.z = dcs_act(v.z, act); v.w = dcs_act(v.w, act);
-    if (y2 == nullptr) *reinterpret_cast<float4*>(y + i4 * 4) = v;
-    else if (n < nsplit) *reinterpret_cast<float4*>(y + p * nsplit + n) = v;
-    else *reinterpret_cast<float4*>(y2 + p * (N - nsplit) + (n - nsplit)) = v;
+    if (y2 == nullptr) dcs_st4(y + i4 * 4, v);
+    else if (n < nsplit) dcs_st4(y + p * nsplit + n, v);
+    else dcs_st4(y2 + p * (N - nsplit) + (n - nsplit), v);
 }
 
 // The same slice sum for a layer followed by a training-mode ComplexBatchNorm2d (plain output, no activation): a thread
@@ -740,7 +759,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // the same pass — partial {S_r, S_i, S_rr, S_ii, S_ri} of (y - bias) per workgroup, column blockIdx.x of float[C][5][stride]
 // (conv_common.h Args::stat), fixed order, no atomics.  G = N / 4 column groups, rpi = 256 / G pixel rows per pass.
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ part, int S, long slab_floats,
-                                                                  const float* __restrict__ bias, float* __restrict__ y,
+                                                                  const float* __restrict__ bias, act_t* __restrict__ y,
                                                                   float* __restrict__ stat, int stat_stride, long P, int N,
                                                                   int G, int rpi) {
     __shared__ float red[256 * 10];
@@ -761,7 +780,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
         s[0] += v.x; s[1] += v.y; s[2] = fmaf(v.x, v.x, s[2]); s[3] = fmaf(v.y, v.y, s[3]); s[4] = fmaf(v.x, v.y, s[4]);
         s[5] += v.z; s[6] += v.w; s[7] = fmaf(v.z, v.z, s[7]); s[8] = fmaf(v.w, v.w, s[8]); s[9] = fmaf(v.z, v.w, s[9]);
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        *reinterpret_cast<float4*>(y + o) = v;
+        dcs_st4(y + o, v);
     }
 #pragma unroll
     for (int e = 0; e < 10; ++e) red[e * 256 + t] = s[e];
@@ -814,9 +833,14 @@ template <int WAVES_N, int WM, int WN, int CH>
 int launch_ch(MArgs& m, long npix, hipStream_t stream) {
     // (a caller-packed wide panel — the real-valued convs of DR-Net — is always in the fp32 fragment order)
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(m.c.C1 + m.c.C2, m.ncls == 1 ? m.cls[0].kh * m.cls[0].kw : 0);
+#if DCS_ACT_IS_BF16
+    if (pr != 1) return DCS_ERR_BADARG;
+    return launch_bf<WAVES_N, WM, WN, CH, 1>(m, npix, stream);
+#else
     if (pr == 2) return launch_bf<WAVES_N, WM, WN, CH, 2>(m, npix, stream);
     if (pr == 1) return launch_bf<WAVES_N, WM, WN, CH, 1>(m, npix, stream);
     return launch_bf<WAVES_N, WM, WN, CH, 0>(m, npix, stream);
+#endif
 }
 
 template <int WAVES_N, int WM, int WN>
@@ -911,7 +935,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // the persistent LDS-DMA kernel (conv_pipe.hip) where it applies: the deepest chunk whose two patch buffers fit
     // (fewer, longer work items: one barrier per item), 32 channels only while the buffers leave room for two workgroups
     p->pipe = false;
-    if (!g_force_wide_panel) {
+    if (!g_force_wide_panel && !DCS_ACT_IS_BF16) {
         static const int force_ch = [] { const char* e = getenv("DCS_PIPE_CH"); return e ? atoi(e) : 0; }();
         static const long cap32 = [] { const char* e = getenv("DCS_PIPE_LDS32"); return e ? atol(e) : 76L * 1024; }();
         const int order[3] = {32, 16, 8};
@@ -1012,10 +1036,13 @@ long dcs_conv_mfma_workspace_bytes(const conv::Args& a, int ncls, const conv::Cl
 // extent Hc x Wc, sub-kernel size, padding, panel offset); y2/nsplit: optional column split of the output;
 // ws / ws_bytes: optional split-K scratch (dcs_conv_mfma_workspace_bytes); too small or NULL: the layer runs unsliced
 int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const conv::Cls* cls, int os_f, int os_t,
-                                 float* y2, int nsplit, void* ws, long ws_bytes, hipStream_t stream) {
+                                 act_t* y2, int nsplit, void* ws, long ws_bytes, hipStream_t stream) {
     Plan p;
     long npix;
     if (!make_plan(a, ncls, cls, &p, &npix)) return DCS_ERR_BADARG;
+#if DCS_ACT_IS_BF16
+    if (dcs_conv_precision() != 1) return DCS_ERR_BADARG;     // bf16 activations: bf16 weight panels (dcs_set_conv_precision(1))
+#endif
     if ((long)a.B * a.Hin * a.Win >= (1L << 31)) return DCS_ERR_BADARG;     // source-pixel table holds 32-bit indices
     if ((long)a.Hout * a.Wout * 2 * a.Cout >= (1L << 31)) return DCS_ERR_BADARG;  // 32-bit store offsets inside an image
     const int Cin = a.C1 + a.C2;
@@ -1079,13 +1106,13 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         const int nb = splitk_stat_blocks(P, m.N);
         if (nb < 1 || y2 != nullptr || a.coef || a.act != DCS_ACT_NONE) return DCS_ERR_BADARG;
         DCS_LAUNCH(splitk_reduce_stats_kernel, dim3(nb), dim3(256), 0, stream, (const float*)m.part, m.ksplit, m.slab_floats,
-                   (const float*)a.bias, (float*)a.y, a.stat, a.stat_stride, P, m.N, m.N / 4, 256 / (m.N / 4));
+                   (const float*)a.bias, (act_t*)a.y, a.stat, a.stat_stride, P, m.N, m.N / 4, 256 / (m.N / 4));
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     }
     const long n4 = m.slab_floats / 4;
     DCS_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)m.part,
-                       m.ksplit, m.slab_floats, (const float*)a.bias, (float*)a.y, y2, nsplit, m.N, a.act, a.coef);
+                       m.ksplit, m.slab_floats, (const float*)a.bias, (act_t*)a.y, y2, nsplit, m.N, a.act, a.coef);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -1113,7 +1140,7 @@ int dcs_conv_mfma_launch_wide(conv::Args& a, const float* bm, void* ws, long ws_
 }
 
 // columns >= nsplit of the output go to y2 (g_x1 | g_x2 of a concatenation)
-int dcs_conv_mfma_launch_split(conv::Args& a, const float* bm, float* y2, int nsplit, void* ws, long ws_bytes,
+int dcs_conv_mfma_launch_split(conv::Args& a, const float* bm, act_t* y2, int nsplit, void* ws, long ws_bytes,
                                hipStream_t stream) {
     const conv::Cls c = plain_class(a);
     return dcs_conv_mfma_launch_classes(a, bm, 1, &c, 1, 1, y2, nsplit, ws, ws_bytes, stream);
@@ -1124,6 +1151,6 @@ int dcs_conv_mfma_launch(conv::Args& a, const float* bm, void* ws, long ws_bytes
     return dcs_conv_mfma_launch_classes(a, bm, 1, &c, 1, 1, nullptr, 0, ws, ws_bytes, stream);
 }
 
-#ifdef DCS_FWD_DIAG
+#if defined(DCS_FWD_DIAG) && !defined(DCS_ACT_BF16)
 extern "C" int dcs_debug_set_fwd_buffer(void* p) { g_fdbg = (long long*)p; return 0; }
 #endif

@@ -6,7 +6,7 @@
 struct MArgs {
     conv::Args c;              // c.Hout / c.Wout: FULL output extent (addressing); c.sf / c.st: stride in class space
     const float* bm;
-    float* y2;                 // optional second output: columns >= nsplit go here (g_x1 | g_x2 of a cat)
+    act_t* y2;                 // optional second output: columns >= nsplit go here (g_x1 | g_x2 of a cat)
     int nsplit;
     int twshift;               // log2(TW): tile widths are powers of two
     int TH, TW, N, KG, NT;     // tile shape (TH*TW = pixels per WG), N = 2*Cout, KG = Cin/4, NT = ceil(N/32)

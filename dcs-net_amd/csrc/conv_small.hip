@@ -18,7 +18,7 @@ constexpr int DC = 8;                 // forward output channels = channels of g
 constexpr int DPIX = 10;              // LDS float2 per patch pixel: 8 channels + 2 pad (80-B pitch keeps b128 reads spread)
 
 struct DgArgs {
-    const float2* gy; const float2* wpb; float2* gx;      // wpb: [49][8][1] flipped / conjugated kernel
+    const act2_t* gy; const float2* wpb; act2_t* gx;      // wpb: [49][8][1] flipped / conjugated kernel (act2_t: dcs_common.h)
     int B, Hg, Wg, Hx, Wx, tiles_w, tiles_h;               // g_Y extent, g_X extent, class-space tiling (of the largest class)
     int kh[4], kw[4], fy[4], fx[4], py[4], px[4], Hc[4], Wc[4];   // per class (ry*2 + rx): sub-kernel, first full tap, padding, extent
 };
@@ -48,7 +48,7 @@ __device__ __forceinline__ void dgrad_class(const DgArgs& d, const float2* patch
         }
     const int cy = cy0 + ty, cx = cx0 + tx;
     if (cy < d.Hc[cls] && cx < d.Wc[cls])
-        d.gx[((long)b * d.Hx + 2 * cy + (cls >> 1)) * d.Wx + 2 * cx + (cls & 1)] = make_float2(ar, ai);
+        conv::stc(d.gx + ((long)b * d.Hx + 2 * cy + (cls >> 1)) * d.Wx + 2 * cx + (cls & 1), make_float2(ar, ai));
 }
 
 __global__ __launch_bounds__(TH * TW) void cconv_small_dgrad_s2_kernel(DgArgs d) {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(TH * TW) void cconv_small_dgrad_s2_kernel(DgArgs d)
         const int y = gy0 + iy, x = gx0 + ix;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (y >= 0 && y < d.Hg && x >= 0 && x < d.Wg)
-            v = *reinterpret_cast<const float4*>(d.gy + (((long)b * d.Hg + y) * d.Wg + x) * DC + 2 * q);
+            v = dcs_ld4(reinterpret_cast<const act_t*>(d.gy + (((long)b * d.Hg + y) * d.Wg + x) * DC + 2 * q));
         *reinterpret_cast<float4*>(patch + p * DPIX + 2 * q) = v;
     }
     __syncthreads();
@@ -87,10 +87,10 @@ bool dcs_conv_small_dgrad_ok(int Cin, int Cout, int kh, int kw, int sf, int st, 
     return true;
 }
 
-int dcs_conv_small_dgrad_launch(const float* gy, const float* wp_bwd, float* gx, int B, int Hx, int Wx, int Hg, int Wg,
+int dcs_conv_small_dgrad_launch(const act_t* gy, const float* wp_bwd, act_t* gx, int B, int Hx, int Wx, int Hg, int Wg,
                                 int pad_f, int pad_t, hipStream_t stream) {
     DgArgs d;
-    d.gy = (const float2*)gy; d.wpb = (const float2*)wp_bwd; d.gx = (float2*)gx;
+    d.gy = (const act2_t*)gy; d.wpb = (const float2*)wp_bwd; d.gx = (act2_t*)gx;
     d.B = B; d.Hg = Hg; d.Wg = Wg; d.Hx = Hx; d.Wx = Wx;
     int Hc = 0, Wc = 0;
     for (int ry = 0; ry < 2; ++ry)

@@ -21,11 +21,14 @@ constexpr int CIN = 16, SRT = 8, SCT = 32, HR = SRT + 2, HC = SCT + 2, HCP = HC 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct Up1Args {
-    const float2* x1; const float2* x2; const float2* wt;       // wt: tap-rows panel complex[CIN][ct], tap = dy*3 + dx
+    const void* x1; const void* x2; const float2* wt;           // wt: tap-rows panel complex[CIN][ct], tap = dy*3 + dx
     const float* b_r; const float* b_i; float2* y;
     int Hs, Ws, C1, C2, ct, tiles_w, tiles;
 };
 
+// IT: element type of the two sources — float, or bf16 (unsigned short) where the activations live in bf16
+// (dcs_cconv_up2_single_fwd_h); the result (the network's fp32 mask) and the arithmetic are fp32 either way.
+template <typename IT>
 __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
     __shared__ __attribute__((aligned(16))) float2 tile[CIN][HR * HCP];
     __shared__ float2 wf[4][2][2][CIN];                          // [parity class][a][b][ci]
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
         const int syc = sy < 0 ? 0 : (sy >= p.Hs ? p.Hs - 1 : sy), sxc = sx < 0 ? 0 : (sx >= p.Ws ? p.Ws - 1 : sx);
         const long sp = img + (long)syc * p.Ws + sxc;
         const int c = 2 * q;
-        const float2* src = c < p.C1 ? p.x1 + sp * p.C1 + c : p.x2 + sp * p.C2 + (c - p.C1);
-        const float4 v = *reinterpret_cast<const float4*>(src);
+        const IT* src = c < p.C1 ? (const IT*)p.x1 + (sp * p.C1 + c) * 2 : (const IT*)p.x2 + (sp * p.C2 + (c - p.C1)) * 2;
+        const float4 v = dcs_ld4(src);
         sv[k] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -120,17 +123,30 @@ __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
 // x1 complex[B][Hs][Ws][C1], x2 complex[B][Hs][Ws][C2] (C1 + C2 = 16, both even); wt: the tap-rows panel of
 // dcs_pack_tap_rows (complex[16][ct], ct >= 9, column tap = dy*3 + dx of the CORRELATION kernel); b_r / b_i: the layer's
 // two real bias scalars (both or neither); y complex[B][2 Hs][2 Ws].
-extern "C" int dcs_cconv_up2_single_fwd(const float* x1, const float* x2, const float* wt, const float* b_r, const float* b_i,
-                                        float* y, int B, int Hs, int Ws, int C1, int C2, int ct, dcs_stream_t stream) {
+static int up2_single_impl(const void* x1, const void* x2, bool bf16_in, const float* wt, const float* b_r, const float* b_i,
+                           float* y, int B, int Hs, int Ws, int C1, int C2, int ct, dcs_stream_t stream) {
     if (!x1 || !wt || !y || B <= 0 || B > 65535 || Hs <= 0 || Ws <= 0 || C1 <= 0 || C2 < 0 || C1 + C2 != CIN || (C1 & 1) ||
         (C2 & 1) || ct < 9 || ((C2 > 0) != (x2 != nullptr)) || ((b_r == nullptr) != (b_i == nullptr)))
         return DCS_ERR_BADARG;
     Up1Args p;
-    p.x1 = (const float2*)x1; p.x2 = (const float2*)x2; p.wt = (const float2*)wt; p.b_r = b_r; p.b_i = b_i; p.y = (float2*)y;
+    p.x1 = x1; p.x2 = x2; p.wt = (const float2*)wt; p.b_r = b_r; p.b_i = b_i; p.y = (float2*)y;
     p.Hs = Hs; p.Ws = Ws; p.C1 = C1; p.C2 = C2; p.ct = ct;
     p.tiles_w = (Ws + SCT - 1) / SCT;
     p.tiles = p.tiles_w * ((Hs + SRT - 1) / SRT);
-    DCS_LAUNCH(cconv_up1_kernel, dim3(p.tiles, B), dim3(256), 0, dcs_stream(stream), p);
+    if (bf16_in) DCS_LAUNCH(cconv_up1_kernel<unsigned short>, dim3(p.tiles, B), dim3(256), 0, dcs_stream(stream), p);
+    else DCS_LAUNCH(cconv_up1_kernel<float>, dim3(p.tiles, B), dim3(256), 0, dcs_stream(stream), p);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+extern "C" int dcs_cconv_up2_single_fwd(const float* x1, const float* x2, const float* wt, const float* b_r, const float* b_i,
+                                        float* y, int B, int Hs, int Ws, int C1, int C2, int ct, dcs_stream_t stream) {
+    return up2_single_impl(x1, x2, false, wt, b_r, b_i, y, B, Hs, Ws, C1, C2, ct, stream);
+}
+
+// the two sources in bf16 (activations stored in bf16: BASELINE configs[4]); weights, bias and the result fp32
+extern "C" int dcs_cconv_up2_single_fwd_h(const unsigned short* x1, const unsigned short* x2, const float* wt, const float* b_r,
+                                          const float* b_i, float* y, int B, int Hs, int Ws, int C1, int C2, int ct,
+                                          dcs_stream_t stream) {
+    return up2_single_impl(x1, x2, true, wt, b_r, b_i, y, B, Hs, Ws, C1, C2, ct, stream);
 }

@@ -25,7 +25,7 @@ constexpr int BMP = 128;       // pixels per tile
 
 struct WArgs {
     conv::Args c;
-    const float* gy; float2* slab_w; float* slab_b;
+    const act_t* gy; float2* slab_w; float* slab_b;            // (activation type: dcs_common.h)
     int n_slabs, total_tiles, co_blocks, TH, TW, twshift;
     unsigned cols_magic;       // ceil(2^32 / c.cols): patch pixel index / cols by one multiply-high (patches are < 2^16 pixels)
     // output-parity classes of an upsample-folded conv (blockIdx.z): class pixel (oy, ox) is g_Y pixel
@@ -150,9 +150,9 @@ void cconv_wgrad_mfma_kernel(WArgs w) {
             for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             long sp;
             if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
-                const float2* src = (ci0 < a.C1) ? a.x1 + sp * a.C1 + ci0 : a.x2 + sp * a.C2 + (ci0 - a.C1);
+                const act2_t* src = (ci0 < a.C1) ? a.x1 + sp * a.C1 + ci0 : a.x2 + sp * a.C2 + (ci0 - a.C1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const float4*>(src)[q];
+                for (int q = 0; q < 4; ++q) v[q] = dcs_ld4(reinterpret_cast<const act_t*>(src) + 4 * q);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(patch + px * PIX + q * 4) = v[q];
@@ -167,8 +167,7 @@ void cconv_wgrad_mfma_kernel(WArgs w) {
                 const int oy = oy0 + (p >> w.twshift), ox = ox0 + (p & (w.TW - 1));
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (oy < a.Hout && ox < a.Wout && 2 * cb0 + 4 * q < N1)
-                    v = *reinterpret_cast<const float4*>(w.gy + (((long)b * w.Hy + oy * w.os_f + oo_f) * w.Wy +
-                                                                 ox * w.os_t + oo_t) * N1 + 2 * cb0 + 4 * q);
+                    v = dcs_ld4(w.gy + (((long)b * w.Hy + oy * w.os_f + oo_f) * w.Wy + ox * w.os_t + oo_t) * N1 + 2 * cb0 + 4 * q);
                 *reinterpret_cast<float4*>(gt + p * GP + q * 4) = v;
             }
         }
@@ -181,7 +180,7 @@ void cconv_wgrad_mfma_kernel(WArgs w) {
         // loop invariants they held ~100 registers).
         int tws = w.twshift, twm = w.TW - 1;
         asm volatile("" : "+s"(tws), "+s"(twm));
-        const float* gyb = w.gy + (long)b * w.Hy * w.Wy * N1;
+        const act_t* gyb = w.gy + (long)b * w.Hy * w.Wy * N1;
         const int xlane = lk * a.st * PIX + li;                        // lane part of a patch address (floats)
         const int glane = lk * w.os_t * N1;                            // lane part of a g_Y pixel offset (floats)
         float afr[D][MT];
@@ -196,9 +195,9 @@ void cconv_wgrad_mfma_kernel(WArgs w) {
             const int oy = oy0 + spy, ox = ox0 + spx;                  // scalar; this lane's column is ox + lk
             const bool inb = oy < a.Hout && ox + lk < a.Wout;
             const int soff = ((oy * w.os_f + oo_f) * w.Wy + ox * w.os_t + oo_t) * N1;       // < 2^31 floats inside one image
-            const float* gp = gyb + (inb ? soff + glane : 0);
+            const act_t* gp = gyb + (inb ? soff + glane : 0);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) dst[i] = gp[gcl[i]];          // always a load; masked when consumed
+            for (int i = 0; i < MT; ++i) dst[i] = dcs_ld1(gp + gcl[i]);          // always a load; masked when consumed
         };
         auto xp_of = [&](int ks) -> const float* {
             const int spy = (ks * 4) >> tws, spx = (ks * 4) & twm;     // scalar
@@ -385,6 +384,9 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
     // of the k-step — for BOTH operands (with 8 consecutive pixels per group every read was 2-way conflicted at any pitch).
     constexpr bool CF = DCS_X6_CFMAP;
     const int PIXR = CF ? (a.st == 2 ? PIXE : 24) : PIXE;
+    // NP = 3: fp32 operands split into three bf16 planes, six MFMAs per product (the emulation).  NP = 1 (activations STORED in
+    // bf16, dcs_common.h): the stored bits are the operands — plane 0 only, one MFMA per product, no split anywhere.
+    constexpr int NP = DCS_ACT_IS_BF16 ? 1 : 3;
 
     f32x4 acc[MT][TAPS];
 #pragma unroll
@@ -428,6 +430,18 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         __syncthreads();
         for (int px = t; px < npix; px += 256) {
             const int iy = (int)__umulhi((unsigned)px, w.cols_magic), ix = px - iy * a.cols;
+#if DCS_ACT_IS_BF16
+            uint4 hv[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};      // 8 complex channels = 16 bf16, as stored
+            long sp;
+            if (conv::src_pixel(a, b, vy0 + iy, vx0 + ix, &sp)) {
+                const act2_t* src = (ci0 < a.C1) ? a.x1 + sp * a.C1 + ci0 : a.x2 + sp * a.C2 + (ci0 - a.C1);
+                hv[0] = reinterpret_cast<const uint4*>(src)[0];
+                hv[1] = reinterpret_cast<const uint4*>(src)[1];
+            }
+            *reinterpret_cast<uint4*>(patch + px * PIXR) = hv[0];
+            *reinterpret_cast<uint4*>(patch + px * PIXR + 4) = hv[1];
+            continue;
+#else
             float4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -451,13 +465,14 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                 *reinterpret_cast<bf16x8w*>(patch + px * PIXR + pl * 8) = h0;
                 *reinterpret_cast<bf16x8w*>(patch + px * PIXR + pl * 8 + 4) = h1;
             }
+#endif
         }
         __syncthreads();
         const long long s1 = WDIAG_NOW();
         d_gather += s1 - s0;
         int tws = w.twshift, twm = w.TW - 1;
         asm volatile("" : "+s"(tws), "+s"(twm));
-        const float* gyb = w.gy + (long)b * w.Hy * w.Wy * N1;
+        const act_t* gyb = w.gy + (long)b * w.Hy * w.Wy * N1;
         const int estr = w.os_t * N1;                                  // floats between horizontally adjacent g_Y pixels of the class
         const int nks = npx >> 5;
         // this lane's 8 pixels of k-step ks: tile pixel 32 ks + 8 lk + e, e = 0..7 (one tile row: TW >= 16)
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                 const int ee = CF ? (e < 4 ? e : e + 4) : e;
                 const int off = (rowok && oxb + ee < a.Wout) ? soff + ee * estr : 0;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) dst[i][e] = gyb[off + gcl[i]];
+                for (int i = 0; i < MT; ++i) dst[i][e] = dcs_ld1(gyb + off + gcl[i]);
             }
         };
         load_g(part < nks ? part : nks - 1, raw[0]);
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
             const int py = p8 >> tws, px0 = p8 & twm;
             const bool rowok = oy0 + py < a.Hout;
             // operand A: the three planes of this lane's 8 g_Y values per row tile
-            bf16x8w ap[MT][3];
+            bf16x8w ap[MT][NP];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 float r[8];
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                     for (int e = 0; e < 8; ++e) bsum[i] += r[e];
                 }
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { ap[i][pl][e] = (__bf16)r[e]; r[e] -= (float)ap[i][pl][e]; }
             }
@@ -517,13 +532,13 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
             // MFMAs, every group waited out an LDS round trip (s_waitcnt lgkmcnt(0) after 12 reads, three times per k-step).
             constexpr int TG = DCS_X6_TAP_GROUP;
             constexpr int NG = (TAPS + TG - 1) / TG;
-            bf16x8w bp[2][TG][3];
-            auto read_group = [&](int gidx, bf16x8w (*dst)[3]) {
+            bf16x8w bp[2][TG][NP];
+            auto read_group = [&](int gidx, bf16x8w (*dst)[NP]) {
 #pragma unroll
                 for (int u = 0; u < TG; ++u) {
                     const int tp = gidx * TG + u < TAPS ? gidx * TG + u : TAPS - 1;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < NP; ++pl) {
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (s16x4 __attribute__((address_space(3)))*)(patch + xrow0 + toff[tp] + pl * 8));
                         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -541,14 +556,14 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                 if (DCS_X6_BPIPE) __builtin_amdgcn_sched_barrier(0);
                 constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};         // smallest terms first
 #pragma unroll
-                for (int e = 0; e < 6; ++e)
+                for (int e = (NP == 3 ? 0 : 5); e < 6; ++e)                                   // (NP = 1: the a0 b0 term alone)
 #pragma unroll
                     for (int u = 0; u < TG; ++u)
 #pragma unroll
                         for (int i = 0; i < MT; ++i)
                             if (gi * TG + u < TAPS) {
                                 f32x4& c = acc[i][gi * TG + u < TAPS ? gi * TG + u : 0];
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i][pa[e]], bp[gi & 1][u][pb[e]], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i][pa[e] < NP ? pa[e] : 0], bp[gi & 1][u][pb[e] < NP ? pb[e] : 0], c, 0, 0, 0);
                             }
                 if (DCS_X6_BPIPE) __builtin_amdgcn_sched_barrier(0);
             }
@@ -652,6 +667,7 @@ template <class V> struct X6 {
 
 inline bool wgrad_x6_enabled() {
     static const int e = [] { const char* v = getenv("DCS_WGRAD_X6"); return v ? atoi(v) : 1; }();   // (0: native kernels in every mode)
+    if (DCS_ACT_IS_BF16) return true;        // bf16 activations: the same kernels with ONE plane (operands are the stored bits)
     return e != 0 && dcs_conv_precision() == 2;
 }
 
@@ -888,7 +904,7 @@ void tile_shape_for(const conv::Args& g, int Hc, int Wc, int* TH, int* TW) {
 }
 
 // c: class-space geometry; f: classes; Hy x Wy: full g_Y extent
-int launch_classes(const conv::Args& c, const Fold& f, int Hy, int Wy, const float* gy, float2* slab_w, float* slab_b,
+int launch_classes(const conv::Args& c, const Fold& f, int Hy, int Wy, const act_t* gy, float2* slab_w, float* slab_b,
                    int n_slabs, int TH, int TW, hipStream_t stream) {
     WArgs w;
     w.c = c;
@@ -929,7 +945,7 @@ int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW) {
 }
 
 // slab_w: float2[n_slabs][taps][Cin][Cout]; slab_b: float[n_slabs][2*Cout]
-int dcs_conv_wgrad_mfma_launch(conv::Args& a, const float* gy, float2* slab_w, float* slab_b, int n_slabs,
+int dcs_conv_wgrad_mfma_launch(conv::Args& a, const act_t* gy, float2* slab_w, float* slab_b, int n_slabs,
                                hipStream_t stream) {
     int TH, TW;
     tile_shape_for(a, a.Hout, a.Wout, &TH, &TW);
@@ -965,7 +981,7 @@ long dcs_conv_wgrad_fold_workspace_bytes(const conv::Args& a) {
     return ns * f.ncls * ((long)f.kh * f.kw * (a.C1 + a.C2) * a.Cout + a.Cout) * (long)sizeof(float2);
 }
 
-int dcs_conv_wgrad_fold_run(const conv::Args& a, const float* gy, void* workspace, long workspace_bytes, float* gw_r,
+int dcs_conv_wgrad_fold_run(const conv::Args& a, const act_t* gy, void* workspace, long workspace_bytes, float* gw_r,
                             float* gw_i, float* gb_r, float* gb_i, int transposed, hipStream_t stream) {
     if (!dcs_conv_wgrad_fold_ok(a)) return DCS_ERR_BADARG;
     const Fold f = fold_of(a);

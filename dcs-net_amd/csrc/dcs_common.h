@@ -7,6 +7,77 @@
 
 #define DCS_WAVE 64
 
+// ---- activation storage type -----------------------------------------------------------------------------------------
+// Every source that touches ACTIVATIONS (the [B,H,W,C,2] tensors between layers and their cotangents) is compiled twice
+// (build.py): once with act_t = float — the reference's precision (config.py:70: precision 32), entry points as declared —
+// and once with -DDCS_ACT_BF16, act_t = bf16 in HBM (BASELINE.json configs[4]: bf16 storage, fp32 accumulate / statistics /
+// parameters / optimizer), entry points suffixed _h (DCS_SYM).  Kernels do their arithmetic in fp32 either way: they read
+// through dcs_ld* / ActIn4 and write through dcs_st* / ActOut4, a 16-byte (fp32) or 8-byte (bf16) access per two complex
+// channels.  Small per-sample / per-pixel maps (ca, sa, pooled, statistics, slabs) and every parameter stay fp32.
+#ifdef DCS_ACT_BF16
+typedef unsigned short act_t;                 // bf16 bits
+typedef unsigned int act2_t;                  // one complex value: (re, im) bf16 pair
+#define DCS_SYM(name) name##_h
+#define DCS_ACT_IS_BF16 1
+#else
+typedef float act_t;
+typedef float2 act2_t;
+#define DCS_SYM(name) name
+#define DCS_ACT_IS_BF16 0
+#endif
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float dcs_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short dcs_f32_to_bf16(float v) {       // round to nearest even; NaN stays NaN (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+__device__ __forceinline__ unsigned dcs_pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const bf16x2_ h = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, h);
+}
+// one element / one complex value / two complex values (4 consecutive elements; 16-byte resp. 8-byte aligned)
+__device__ __forceinline__ float dcs_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float dcs_ld1(const unsigned short* p) { return dcs_bf16_to_f32(*p); }
+__device__ __forceinline__ void dcs_st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void dcs_st1(unsigned short* p, float v) { *p = dcs_f32_to_bf16(v); }
+__device__ __forceinline__ float2 dcs_ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 dcs_ld2(const unsigned short* p) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(p);
+    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+}
+__device__ __forceinline__ void dcs_st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void dcs_st2(unsigned short* p, float2 v) { *reinterpret_cast<unsigned*>(p) = dcs_pack_bf16x2(v.x, v.y); }
+__device__ __forceinline__ float4 dcs_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 dcs_ld4(const unsigned short* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void dcs_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void dcs_st4(unsigned short* p, float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(dcs_pack_bf16x2(v.x, v.y), dcs_pack_bf16x2(v.z, v.w));
+}
+// views that index in units of FOUR elements (two complex channels), so kernels written against float4 pointers keep
+// their index arithmetic: `const ActIn4<T> x4 = act_in4(x) + base;  v = x4[i];  y4[i] = o;`
+template <typename T> struct ActIn4 {
+    const T* p;
+    __device__ __forceinline__ float4 operator[](long i) const { return dcs_ld4(p + 4 * i); }
+    __device__ __forceinline__ ActIn4 operator+(long off) const { return ActIn4{p + 4 * off}; }
+};
+template <typename T> struct ActOut4 {
+    T* p;
+    struct Ref {
+        T* q;
+        __device__ __forceinline__ void operator=(float4 v) const { dcs_st4(q, v); }
+    };
+    __device__ __forceinline__ Ref operator[](long i) const { return Ref{p + 4 * i}; }
+    __device__ __forceinline__ ActOut4 operator+(long off) const { return ActOut4{p + 4 * off}; }
+};
+template <typename T> __device__ __forceinline__ ActIn4<T> act_in4(const T* p) { return ActIn4<T>{p}; }
+template <typename T> __device__ __forceinline__ ActOut4<T> act_out4(T* p) { return ActOut4<T>{p}; }
+#endif
+
 // ---- kernel timer (dcs_kernel_timer_*, api.hip) ----------------------------------------------------------------------
 // While a slot is armed every launch of the library goes through hipExtLaunchKernelGGL with a start / stop event pair:
 // the command processor stamps the dispatch itself (what rocprofv3's kernel trace reports), not the stream around it —

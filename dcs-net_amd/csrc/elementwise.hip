@@ -171,7 +171,10 @@ __global__ __launch_bounds__(kThreads) void tapsum_bwd_kernel(const float2* __re
 // g_y that its nine taps read is loaded once (16 unconditional loads of clamped coordinates, masked), every tap is a sum of
 // four of them, the CT tap channels go out as one contiguous run.  The generic kernel above spends ~8 runtime integer
 // divisions and up to four predicated loads per ELEMENT (tap channel): 43 us for 4.7 M elements.
-__global__ __launch_bounds__(kThreads) void tapsum_bwd_3x3_up2_kernel(const float2* __restrict__ gy, float2* __restrict__ gz,
+// OT: element type of gz — float, or bf16 (unsigned short) where the activations live in bf16 (dcs_tapsum_bwd_h: g_y, the
+// cotangent of the fp32 mask, stays fp32).
+template <typename OT>
+__global__ __launch_bounds__(kThreads) void tapsum_bwd_3x3_up2_kernel(const float2* __restrict__ gy, OT* __restrict__ gz,
                                                                        int B, int Hs, int Ws, int CT) {
     const long npx = (long)B * Hs * Ws;
     const long i0 = (long)blockIdx.x * kThreads + threadIdx.x;
@@ -217,20 +220,20 @@ __global__ __launch_bounds__(kThreads) void tapsum_bwd_3x3_up2_kernel(const floa
 #pragma unroll
         for (int tp = 9; tp < 16; ++tp) sm[t][tp] = make_float2(0.f, 0.f);
         __syncthreads();
-        float2* ob = gz + (long)blockIdx.x * kThreads * 16;
+        OT* ob = gz + (long)blockIdx.x * kThreads * 16 * 2;
         const long lim = (npx - (long)blockIdx.x * kThreads) * 16;          // elements of this workgroup that exist
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int e = t + kThreads * k;
-            if (e < lim) ob[e] = sm[e >> 4][e & 15];
+            if (e < lim) dcs_st2(ob + 2 * e, sm[e >> 4][e & 15]);
         }
         return;
     }
     if (i0 >= npx) return;
-    float2* o = gz + i * CT;
+    OT* o = gz + i * CT * 2;
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) o[tp] = acc[tp];
-    for (int tp = 9; tp < CT; ++tp) o[tp] = make_float2(0.f, 0.f);
+    for (int tp = 0; tp < 9; ++tp) dcs_st2(o + 2 * tp, acc[tp]);
+    for (int tp = 9; tp < CT; ++tp) dcs_st2(o + 2 * tp, make_float2(0.f, 0.f));
 }
 }  // namespace
 
@@ -290,9 +293,9 @@ extern "C" int dcs_tapsum_fwd(const float* z, float* y, const float* b_r, const 
 
 extern "C" long dcs_tapsum_bwd_workspace_bytes(void) { return (long)kSumBlocks * 2 * (long)sizeof(double); }
 
-extern "C" int dcs_tapsum_bwd(const float* gy, float* gz, float* gb_r, float* gb_i, void* workspace, long workspace_bytes,
-                              int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t, int pad_f, int pad_t,
-                              dcs_stream_t stream) {
+static int tapsum_bwd_impl(const float* gy, void* gz, bool gz_bf16, float* gb_r, float* gb_i, void* workspace,
+                           long workspace_bytes, int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t, int pad_f,
+                           int pad_t, dcs_stream_t stream) {
     if (!gy || !gz || B <= 0 || Hs <= 0 || Ws <= 0 || kh < 1 || kw < 1 || CT < kh * kw || up_f < 1 || up_t < 1 ||
         pad_f < 0 || pad_t < 0 || ((gb_r == nullptr) != (gb_i == nullptr)))
         return DCS_ERR_BADARG;
@@ -308,13 +311,33 @@ extern "C" int dcs_tapsum_bwd(const float* gy, float* gz, float* gb_r, float* gb
     const long n = (long)B * Hs * Ws * CT;
     if (kh == 3 && kw == 3 && up_f == 2 && up_t == 2 && pad_f == 1 && pad_t == 1 && (long)B * Hs * Ws < (1L << 31) * kThreads) {
         const long npx = (long)B * Hs * Ws;
-        DCS_LAUNCH(tapsum_bwd_3x3_up2_kernel, dim3((unsigned)((npx + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                   dcs_stream(stream), (const float2*)gy, (float2*)gz, B, Hs, Ws, CT);
+        if (gz_bf16)
+            DCS_LAUNCH(tapsum_bwd_3x3_up2_kernel<unsigned short>, dim3((unsigned)((npx + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       dcs_stream(stream), (const float2*)gy, (unsigned short*)gz, B, Hs, Ws, CT);
+        else
+            DCS_LAUNCH(tapsum_bwd_3x3_up2_kernel<float>, dim3((unsigned)((npx + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       dcs_stream(stream), (const float2*)gy, (float*)gz, B, Hs, Ws, CT);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     }
+    if (gz_bf16) return DCS_ERR_BADARG;                                 // (bf16 tap channels: the 3x3 / 2x2-upsample stage only)
     DCS_LAUNCH(tapsum_bwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)gy,
                        (float2*)gz, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+extern "C" int dcs_tapsum_bwd(const float* gy, float* gz, float* gb_r, float* gb_i, void* workspace, long workspace_bytes,
+                              int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t, int pad_f, int pad_t,
+                              dcs_stream_t stream) {
+    return tapsum_bwd_impl(gy, gz, false, gb_r, gb_i, workspace, workspace_bytes, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t,
+                           stream);
+}
+
+// gz in bf16 (activations stored in bf16: BASELINE configs[4]); g_y and the bias gradients fp32
+extern "C" int dcs_tapsum_bwd_h(const float* gy, unsigned short* gz, float* gb_r, float* gb_i, void* workspace,
+                                long workspace_bytes, int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t,
+                                int pad_f, int pad_t, dcs_stream_t stream) {
+    return tapsum_bwd_impl(gy, gz, true, gb_r, gb_i, workspace, workspace_bytes, B, Hs, Ws, CT, kh, kw, up_f, up_t, pad_f, pad_t,
+                           stream);
 }

@@ -135,6 +135,14 @@ class DcsHipError(RuntimeError):
     pass
 
 
+# bf16-activation forms (include/dcsnet_hip.h, last section): the same argument lists as the fp32 entry points they mirror
+for _n in ('dcs_cconv2d_fwd', 'dcs_cconv2d_fwd_affine', 'dcs_cconv2d_fwd_stats', 'dcs_cconv2d_bwd_data', 'dcs_cconv2d_bwd_weight',
+           'dcs_cconv_up2_single_fwd', 'dcs_tapsum_bwd', 'dcs_cbn_fwd', 'dcs_cbn_fwd_slabs', 'dcs_cbn_bwd', 'dcs_cbn_bwd_add',
+           'dcs_channel_attention_fwd', 'dcs_spatial_pool_fwd', 'dcs_attention_apply_fwd', 'dcs_attention_fwd_batched',
+           'dcs_attention_bwd_sa', 'dcs_attention_bwd_x', 'dcs_attention_bwd_batched'):
+    SIGNATURES[_n + '_h'] = SIGNATURES[_n]
+
+
 def load():
     """Load the library once; raises if it has not been built (python dcs-net_amd/build.py)."""
     global _lib

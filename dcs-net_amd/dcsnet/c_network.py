@@ -211,6 +211,9 @@ class C_NETWORK(LightningModule):
         # `enc` serves the first, `enc_skip` the second; with autograd on they are two tensors over one storage, so the
         # two cotangents reach the CBN backward kernels separately and are summed there (F._CbnTwoFn)
         enc = [self._bn(self.initial_batchnorm, e, F.ACT_NONE)]
+        adt = self.activation_dtype
+        if adt != torch.float32:                             # bf16 activation storage (set_activation_dtype): everything between
+            enc[0] = enc[0].to(adt)                          # the initial CBN and the last decoder conv lives in bf16 in HBM
         enc_skip = [None]
         infer = not self.training and not torch.is_grad_enabled()
         for i in range(L):                                   # c_network.py:193-197
@@ -251,7 +254,7 @@ class C_NETWORK(LightningModule):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 skips = self._skip_attentions(enc_skip)
-        z = self.lstm(torch.view_as_complex(lat).view(B, F7 * T7, C7))
+        z = self.lstm(torch.view_as_complex(lat if adt == torch.float32 else lat.float()).view(B, F7 * T7, C7))   # (LSTM + fc: fp32)
         if side is not None:
             # join BEFORE self.fc: the side stream's VALU kernels overlap the LSTM recurrence only (a VALU kernel too), never
             # an MFMA conv kernel — see the packed-fp32 / bf16-MFMA co-residency note in DESIGN.md §3
@@ -266,6 +269,8 @@ class C_NETWORK(LightningModule):
         if dp > 0:
             zr = F.dropout(zr, dp, seed)
         d = zr.view(B, F7, T7, C7, 2)
+        if adt != torch.float32:
+            d = d.to(adt)
 
         if side is None:
             skips = self._skip_attentions(enc_skip)
@@ -323,6 +328,20 @@ class C_NETWORK(LightningModule):
         return F.attention_blocks([enc[L - i] for i in range(L)], params, 7)
 
     batch_skip_attention = True
+    activation_dtype = torch.float32
+
+    def set_activation_dtype(self, dtype):
+        """torch.float32 (the reference: precision 32, config.py:70) or torch.bfloat16 — BASELINE configs[4]: the activations
+        between the initial CBN and the last decoder conv, and their cotangents, live in bf16 in HBM (the _h entry points of
+        include/dcsnet_hip.h); parameters, CBN statistics, accumulators, the attention maps, the LSTM and the mask stay fp32.
+        bf16 storage runs the MFMA convs on bf16 operands: the process-wide conv precision is switched with it."""
+        dtype = {'f32': torch.float32, 'fp32': torch.float32, 'bf16': torch.bfloat16}.get(dtype, dtype)
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise F.DcsHipError(f'activation dtype {dtype}: float32 or bfloat16')
+        self.activation_dtype = dtype
+        if dtype == torch.bfloat16:
+            F.ops.set_conv_precision('bf16')
+        return self
     import os as _os
     overlap_skip_attention = _os.environ.get('DCS_OVERLAP_SKIP', '1') == '1'      # inference only (see forward); 0 disables
 

@@ -734,7 +734,8 @@ class _Up2SingleFn(torch.autograd.Function):
             new = lambda: torch.empty(1, dtype=torch.float32, device=g.device)
             dst = tuple(s_ if s_ is not None else new() for s_ in sk[2:])
             gb = tuple(None if s_ is not None else d for d, s_ in zip(dst, sk[2:]))
-        gz = ops.tapsum((B, Hs, Ws, ctx.ct, 2), (3, 3), (2, 2), (1, 1), backward=True, grad=g.contiguous(), bias_grad=dst)
+        gz = ops.tapsum((B, Hs, Ws, ctx.ct, 2), (3, 3), (2, 2), (1, 1), backward=True, grad=g.contiguous(), bias_grad=dst,
+                        out_dtype=x1.dtype)                  # (bf16 where the activations are stored in bf16)
         gx1 = gx2 = gw_r = gw_i = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             gt_r, gt_i, _, _ = ops.cconv2d_bwd_weight(x1, x2, gz, (ctx.ct, Cin, 1, 1), False, (1, 1), (1, 1), (0, 0))

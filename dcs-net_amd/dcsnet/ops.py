@@ -11,17 +11,29 @@ from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, check, ptr, cur_stream  # noqa: F401
 
 
-def _chk(t, name, dims=None):
+def _chk(t, name, dims=None, act=False):
+    """act=True: an ACTIVATION tensor — float32, or bfloat16 where the activations are stored in bf16 (the _h entry points)."""
     if t is None:
         return
     if not t.is_cuda:
         raise _lib.DcsHipError(f'{name}: expected a CUDA (HIP) tensor; the HIP path has no CPU fallback')
-    if t.dtype != torch.float32:
-        raise _lib.DcsHipError(f'{name}: expected float32, got {t.dtype}')
+    if t.dtype != torch.float32 and not (act and t.dtype == torch.bfloat16):
+        raise _lib.DcsHipError(f'{name}: expected float32{" or bfloat16" if act else ""}, got {t.dtype}')
     if not t.is_contiguous():
         raise _lib.DcsHipError(f'{name}: expected a contiguous tensor')
     if dims is not None and t.dim() != dims:
         raise _lib.DcsHipError(f'{name}: expected {dims} dims, got shape {tuple(t.shape)}')
+
+
+def _sym(name, *acts):
+    """The entry point for these activation tensors: `name` for fp32, `name`_h for bf16 storage; mixing them is an error."""
+    dts = {t.dtype for t in acts if t is not None}
+    if len(dts) > 1:
+        raise _lib.DcsHipError(f'{name}: activation tensors of different dtypes {sorted(str(d) for d in dts)}')
+    bf = dts == {torch.bfloat16}
+    if bf and conv_precision() != 'bf16' and 'conv' in name:
+        raise _lib.DcsHipError(f'{name}: bf16 activations need set_conv_precision("bf16") (bf16 weight panels)')
+    return getattr(_lib.load(), name + ('_h' if bf else ''))
 
 
 CONV_TIMER = None        # set by bench.py: object with begin(flops, tag=None, executed=1.0) -> token / end(token)
@@ -196,8 +208,8 @@ def tap_rows_scatter(gt_r, gt_i, w_shape, outs=None):
 def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=ACT_NONE, coef=None):
     """Complex correlation over the virtual input upsample(cat(x1, x2)); see dcs_cconv2d_fwd.  coef [Cout, 6]: an eval-mode
     CBN's coefficients folded in between bias and activation (dcs_cconv2d_fwd_affine)."""
-    _chk(x1, 'x1', 5)
-    _chk(x2, 'x2', 5)
+    _chk(x1, 'x1', 5, act=True)
+    _chk(x2, 'x2', 5, act=True)
     _chk(wp, 'wp', 4)
     _chk(bias, 'bias', 2)
     B, Hin, Win, C1, _ = x1.shape
@@ -212,7 +224,7 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     Cout = wp.shape[2]
     Hout = (Hin * up[0] + 2 * pad[0] - kh) // stride[0] + 1
     Wout = (Win * up[1] + 2 * pad[1] - kw) // stride[1] + 1
-    y = torch.empty((B, Hout, Wout, Cout, 2), dtype=torch.float32, device=x1.device)
+    y = torch.empty((B, Hout, Wout, Cout, 2), dtype=x1.dtype, device=x1.device)
     lib = _lib.load()
     # split-K scratch for layers with too few output tiles to fill the chip (0 bytes for most geometries)
     nbytes = lib.dcs_cconv2d_fwd_workspace_bytes(B, Hin, Win, C1, C2, up[0], up[1], Cout, kh, kw, stride[0], stride[1],
@@ -229,7 +241,7 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
         _chk(coef, 'coef', 2)
         if tuple(coef.shape) != (Cout, 6):
             raise _lib.DcsHipError(f'cconv2d: coef {tuple(coef.shape)} does not match Cout={Cout}')
-    check(lib.dcs_cconv2d_fwd_affine(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(coef), ptr(y), ptr(ws), nbytes, B, Hin, Win,
+    check(_sym('dcs_cconv2d_fwd_affine', x1, x2)(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(coef), ptr(y), ptr(ws), nbytes, B, Hin, Win,
                                      C1, C2, up[0], up[1], Cout, kh, kw, stride[0], stride[1], pad[0], pad[1], act,
                                      cur_stream()), 'dcs_cconv2d_fwd_affine')
     if ev is not None:
@@ -242,8 +254,8 @@ def cconv2d_stats(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1))
     (dcs_cconv2d_fwd_stats).  Returns (y, stat): stat = (part float[Cout, 5, rows capacity], rows, pivot = bias) for cbn(stat=...),
     or None when this geometry has no statistics epilogue (the plain conv ran: the CBN makes its own statistics pass)."""
     import ctypes
-    _chk(x1, 'x1', 5)
-    _chk(x2, 'x2', 5)
+    _chk(x1, 'x1', 5, act=True)
+    _chk(x2, 'x2', 5, act=True)
     _chk(wp, 'wp', 4)
     _chk(bias, 'bias', 2)
     B, Hin, Win, C1, _ = x1.shape
@@ -261,7 +273,7 @@ def cconv2d_stats(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1))
         raise _lib.DcsHipError(f'cconv2d: packed weight {tuple(wp.shape)} does not match k={ksize}, Cin={C1 + C2}')
     Hout = (Hin * up[0] + 2 * pad[0] - kh) // stride[0] + 1
     Wout = (Win * up[1] + 2 * pad[1] - kw) // stride[1] + 1
-    y = torch.empty((B, Hout, Wout, Cout, 2), dtype=torch.float32, device=x1.device)
+    y = torch.empty((B, Hout, Wout, Cout, 2), dtype=x1.dtype, device=x1.device)
     part = torch.empty((Cout, 5, rows), dtype=torch.float32, device=x1.device)
     nbytes = max(lib.dcs_cconv2d_fwd_workspace_bytes(*geo), 0)
     ws = _workspace(nbytes, x1.device) if nbytes > 0 else None
@@ -270,7 +282,7 @@ def cconv2d_stats(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1))
                            emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and C1 % 2 == 0)
           if CONV_TIMER is not None else None)
     used = ctypes.c_int(0)
-    check(lib.dcs_cconv2d_fwd_stats(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(y), ptr(part), rows, ctypes.byref(used), ptr(ws),
+    check(_sym('dcs_cconv2d_fwd_stats', x1, x2)(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(y), ptr(part), rows, ctypes.byref(used), ptr(ws),
                                     nbytes, *geo, cur_stream()), 'dcs_cconv2d_fwd_stats')
     if ev is not None:
         CONV_TIMER.end(ev)
@@ -338,14 +350,14 @@ def pack_conv_weight_bwd(wp, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1)):
 def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=None):
     """gy [B,Hout,Wout,Cout,2] -> (g_x1, g_x2) for the forward call with x1 [B,Hin,Win,C1,2] (+ x2).
     in_shape = (Hin, Win, Cin_total); wp_bwd from pack_conv_weight_bwd with the same geometry."""
-    _chk(gy, 'gy', 5)
+    _chk(gy, 'gy', 5, act=True)
     _chk(wp_bwd, 'wp_bwd', 4)
     B, Hout, Wout, Cout, _ = gy.shape
     Hin, Win, Cin = in_shape
     C1 = Cin if C1 is None else C1
     C2 = Cin - C1
-    gx1 = torch.empty((B, Hin, Win, C1, 2), dtype=torch.float32, device=gy.device)
-    gx2 = torch.empty((B, Hin, Win, C2, 2), dtype=torch.float32, device=gy.device) if C2 else None
+    gx1 = torch.empty((B, Hin, Win, C1, 2), dtype=gy.dtype, device=gy.device)
+    gx2 = torch.empty((B, Hin, Win, C2, 2), dtype=gy.dtype, device=gy.device) if C2 else None
     lib = _lib.load()
     geo = (B, Hin, Win, C1, C2, up[0], up[1], Cout, ksize[0], ksize[1], stride[0], stride[1], pad[0], pad[1])
     nbytes = lib.dcs_cconv2d_bwd_data_workspace_bytes(*geo)
@@ -355,7 +367,7 @@ def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=Non
     ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * Cin * ksize[0] * ksize[1],
                            executed=_fold_fraction(C1, Cin, Cout, ksize, stride, pad, up), emulated=_emulated(Cout, Cin))
           if CONV_TIMER is not None else None)
-    check(lib.dcs_cconv2d_bwd_data(ptr(gy), ptr(wp_bwd), ptr(gx1), ptr(gx2), ptr(ws), ws.numel() if ws is not None else 0,
+    check(_sym('dcs_cconv2d_bwd_data', gy)(ptr(gy), ptr(wp_bwd), ptr(gx1), ptr(gx2), ptr(ws), ws.numel() if ws is not None else 0,
                                    *geo, cur_stream()), 'dcs_cconv2d_bwd_data')
     if ev is not None:
         CONV_TIMER.end(ev)
@@ -365,9 +377,9 @@ def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=Non
 def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1, 1), transposed=False, outs=None):
     """Gradients in the reference's parameter layout: (gw_r, gw_i, gb_r, gb_i).  `outs`: optional
     pre-existing destinations (e.g. views of a flat gradient bucket) for any of the four."""
-    _chk(x1, 'x1', 5)
-    _chk(x2, 'x2', 5)
-    _chk(gy, 'gy', 5)
+    _chk(x1, 'x1', 5, act=True)
+    _chk(x2, 'x2', 5, act=True)
+    _chk(gy, 'gy', 5, act=True)
     B, Hin, Win, C1, _ = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     Cout = gy.shape[3]
@@ -403,7 +415,7 @@ def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1,
                               executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
                               emulated=_wgrad_emulated(C1, C1 + C2, Cout, ksize))
     try:
-        check(lib.dcs_cconv2d_bwd_weight(ptr(x1), ptr(x2), ptr(gy), ptr(gw_r), ptr(gw_i), ptr(gb_r), ptr(gb_i), ptr(ws),
+        check(_sym('dcs_cconv2d_bwd_weight', x1, x2, gy)(ptr(x1), ptr(x2), ptr(gy), ptr(gw_r), ptr(gw_i), ptr(gb_r), ptr(gb_i), ptr(ws),
                                          ws.numel(), *geo, int(bool(transposed)), cur_stream()), 'dcs_cconv2d_bwd_weight')
     finally:
         if suspend:
@@ -442,7 +454,7 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
     Returns (y, stats [C,8], coef [C,6]).  coef_cached = (stats, coef) of an earlier eval-mode call with the same
     parameters and running statistics: only the apply kernel runs.  stat = (part, rows, pivot) from cconv2d_stats (batch
     statistics only): the partial sums the producing conv left — no statistics pass over x (dcs_cbn_fwd_slabs)."""
-    _chk(x, 'x', 5)
+    _chk(x, 'x', 5, act=True)
     for n, t in (('weight', weight), ('bias', bias), ('running_mean', running_mean), ('running_covar', running_covar)):
         _chk(t, n)
     B, H, W, C, _ = x.shape
@@ -457,7 +469,7 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
             raise _lib.DcsHipError(f'cbn: statistics slabs {tuple(part.shape)} / pivot {tuple(pivot.shape)} do not match C={C}')
         stats = torch.empty((C, 8), dtype=torch.float32, device=x.device)
         coef = torch.empty((C, 6), dtype=torch.float32, device=x.device)
-        check(lib.dcs_cbn_fwd_slabs(ptr(x), ptr(y), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_covar), ptr(stats),
+        check(_sym('dcs_cbn_fwd_slabs', x, y)(ptr(x), ptr(y), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_covar), ptr(stats),
                                     ptr(coef), ptr(part), int(rows), int(part.shape[2]), ptr(pivot), P, C, eps,
                                     -1.0 if momentum is None else momentum, act, float(drop_p), int(seed), ptr(SEED_STATE),
                                     cur_stream()), 'dcs_cbn_fwd_slabs')
@@ -475,7 +487,7 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
     else:
         stats = torch.empty((C, 8), dtype=torch.float32, device=x.device)
         coef = torch.empty((C, 6), dtype=torch.float32, device=x.device)
-    check(lib.dcs_cbn_fwd(ptr(x), ptr(y), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_covar),
+    check(_sym('dcs_cbn_fwd', x, y)(ptr(x), ptr(y), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_covar),
                           ptr(stats), ptr(coef), ptr(ws), ws.numel(), P, C, eps,
                           -1.0 if momentum is None else momentum, mode, act,
                           float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_cbn_fwd')
@@ -487,9 +499,9 @@ def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, see
     """Backward of cbn(): returns (g_x, g_weight [C,3], g_bias [C,2]).  `outs`: optional destinations for
     (g_weight, g_bias).  g_add [B,C,2]: the cotangent is g_out + g_add[b, c] / (H*W) (attention_bwd's g_pooled).
     g_out2: a second cotangent of y (another consumer's), added on the fly."""
-    _chk(x, 'x', 5)
-    _chk(g_out, 'g_out', 5)
-    _chk(g_out2, 'g_out2', 5)
+    _chk(x, 'x', 5, act=True)
+    _chk(g_out, 'g_out', 5, act=True)
+    _chk(g_out2, 'g_out2', 5, act=True)
     if g_out2 is not None and g_out2.shape != g_out.shape:
         raise _lib.DcsHipError(f'cbn_bwd: g_out {tuple(g_out.shape)} vs g_out2 {tuple(g_out2.shape)}')
     B, H, W, C, _ = x.shape
@@ -505,7 +517,7 @@ def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, see
     ws = _workspace(nbytes, x.device)
     if g_add is not None:
         _chk(g_add, 'g_add', 3)
-    check(lib.dcs_cbn_bwd_add(ptr(x), ptr(g_out), ptr(g_x), ptr(weight), ptr(stats), ptr(coef), ptr(g_w), ptr(g_b),
+    check(_sym('dcs_cbn_bwd_add', x, g_out, g_out2)(ptr(x), ptr(g_out), ptr(g_x), ptr(weight), ptr(stats), ptr(coef), ptr(g_w), ptr(g_b),
                               ptr(ws), ws.numel(), P, C, int(bool(use_batch_stats)), act, float(drop_p), int(seed),
                               ptr(SEED_STATE), ptr(g_add), 1.0 / (H * W), H * W, ptr(g_out2), cur_stream()), 'dcs_cbn_bwd_add')
     return g_x, g_w, g_b
@@ -513,7 +525,7 @@ def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, see
 
 def channel_attention(x, w1, w2):
     """x [B,H,W,C,2]; w1 packed [1,C,Ch,2]; w2 packed [1,Ch,C,2] -> (ca [B,C,2], pooled, hidden)."""
-    _chk(x, 'x', 5)
+    _chk(x, 'x', 5, act=True)
     _chk(w1, 'w1')
     _chk(w2, 'w2')
     B, H, W, C, _ = x.shape
@@ -526,28 +538,28 @@ def channel_attention(x, w1, w2):
     if nbytes < 0:
         raise _lib.DcsHipError(f'channel_attention: unsupported channel count C={C}')
     ws = _workspace(nbytes, x.device)
-    check(lib.dcs_channel_attention_fwd(ptr(x), ptr(w1), ptr(w2), ptr(ca), ptr(pooled), ptr(hidden), ptr(ws),
+    check(_sym('dcs_channel_attention_fwd', x)(ptr(x), ptr(w1), ptr(w2), ptr(ca), ptr(pooled), ptr(hidden), ptr(ws),
                                         ws.numel(), B, H * W, C, Ch, cur_stream()), 'dcs_channel_attention_fwd')
     return ca, pooled, hidden
 
 
 def spatial_pool(x, ca=None):
-    _chk(x, 'x', 5)
+    _chk(x, 'x', 5, act=True)
     _chk(ca, 'ca', 3)
     B, H, W, C, _ = x.shape
     pooled = torch.empty((B, H, W, 2, 2), dtype=torch.float32, device=x.device)
-    check(_lib.load().dcs_spatial_pool_fwd(ptr(x), ptr(ca), ptr(pooled), B, H * W, C, cur_stream()),
+    check(_sym('dcs_spatial_pool_fwd', x)(ptr(x), ptr(ca), ptr(pooled), B, H * W, C, cur_stream()),
           'dcs_spatial_pool_fwd')
     return pooled
 
 
 def attention_apply(x, ca=None, sa=None, drop_p=0.0, seed=0, out=None):
-    _chk(x, 'x', 5)
+    _chk(x, 'x', 5, act=True)
     _chk(ca, 'ca', 3)
     _chk(sa, 'sa')
     B, H, W, C, _ = x.shape
     y = torch.empty_like(x) if out is None else out
-    check(_lib.load().dcs_attention_apply_fwd(ptr(x), ptr(ca), ptr(sa), ptr(y), B, H * W, C, float(drop_p),
+    check(_sym('dcs_attention_apply_fwd', x, y)(ptr(x), ptr(ca), ptr(sa), ptr(y), B, H * W, C, float(drop_p),
                                               int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_attention_apply_fwd')
     return y
 
@@ -558,15 +570,15 @@ def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop
     g_conv1_r, g_conv1_i) with the weight gradients in the reference's parameter layout.  split_pool: g_x lacks the
     average pool's broadcast term and an 8th result g_pooled [B,C,2] is returned for the consumer to add
     (cbn_bwd(g_add=...))."""
-    _chk(x, 'x', 5)
-    _chk(g_out, 'g_out', 5)
+    _chk(x, 'x', 5, act=True)
+    _chk(g_out, 'g_out', 5, act=True)
     B, H, W, C, _ = x.shape
     HW = H * W
     Ch = hidden.shape[1]
     dev = x.device
     lib = _lib.load()
     g_pre = torch.empty((B, H, W, 1, 2), dtype=torch.float32, device=dev)
-    check(lib.dcs_attention_bwd_sa(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_pre), B, HW, C, float(drop_p),
+    check(_sym('dcs_attention_bwd_sa', x, g_out)(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_pre), B, HW, C, float(drop_p),
                                    int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_attention_bwd_sa')
     k, pad = (ksize, ksize), (ksize // 2, ksize // 2)
     g_sp, _ = cconv2d_bwd_data(g_pre, pack_conv_weight_bwd(wsa, k, (1, 1), pad), (H, W, 2), k, (1, 1), pad)
@@ -584,7 +596,7 @@ def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop
         raise _lib.DcsHipError(f'attention_bwd: unsupported channel count C={C}')
     ws = _workspace(nbytes, dev)
     g_pooled = new((B, C, 2)) if split_pool else None
-    check(lib.dcs_attention_bwd_x(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_sp), ptr(pooled), ptr(hidden), ptr(w1),
+    check(_sym('dcs_attention_bwd_x', x, g_out)(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_sp), ptr(pooled), ptr(hidden), ptr(w1),
                                   ptr(w2), ptr(g_x), ptr(g0r), ptr(g0i), ptr(g2r), ptr(g2i), ptr(g_pooled), ptr(ws),
                                   ws.numel(), B, HW, C, Ch, float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()),
           'dcs_attention_bwd_x')
@@ -612,7 +624,7 @@ def attention_blocks_fwd(xs, w1s, w2s, wsas, biases):
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     blocks, outs = [], []
     for x, w1, w2, wsa, bias in zip(xs, w1s, w2s, wsas, biases):
-        _chk(x, 'x', 5)
+        _chk(x, 'x', 5, act=True)
         _, H, W, C, _ = x.shape
         Ch = w1.shape[-2]
         o = dict(y=torch.empty_like(x), ca=new(B, C, 2), pooled=new(B, C, 2), hidden=new(B, Ch, 2), sp=new(B, H, W, 2, 2),
@@ -625,7 +637,7 @@ def attention_blocks_fwd(xs, w1s, w2s, wsas, biases):
     if nbytes < 0:
         raise _lib.DcsHipError('attention_blocks_fwd: unsupported block geometry')
     ws = _workspace(nbytes, dev)
-    check(lib.dcs_attention_fwd_batched(n, items, ptr(ws), ws.numel(), B, cur_stream()), 'dcs_attention_fwd_batched')
+    check(_sym('dcs_attention_fwd_batched', *xs)(n, items, ptr(ws), ws.numel(), B, cur_stream()), 'dcs_attention_fwd_batched')
     return outs
 
 
@@ -637,7 +649,7 @@ def attention_blocks_bwd(saved, g_outs, wsa_bwds, fc_outs):
     B, dev = g_outs[0].shape[0], g_outs[0].device
     blocks, res = [], []
     for sv, g, wb, fo in zip(saved, g_outs, wsa_bwds, fc_outs):
-        _chk(g, 'g_out', 5)
+        _chk(g, 'g_out', 5, act=True)
         x = sv['x']
         _, H, W, C, _ = x.shape
         g_pre = torch.empty((B, H, W, 1, 2), dtype=torch.float32, device=dev)
@@ -653,7 +665,7 @@ def attention_blocks_bwd(saved, g_outs, wsa_bwds, fc_outs):
     if nbytes < 0:
         raise _lib.DcsHipError('attention_blocks_bwd: unsupported block geometry')
     ws = _workspace(nbytes, dev)
-    check(lib.dcs_attention_bwd_batched(n, items, ptr(ws), ws.numel(), B, cur_stream()), 'dcs_attention_bwd_batched')
+    check(_sym('dcs_attention_bwd_batched', *g_outs, *[sv['x'] for sv in saved])(n, items, ptr(ws), ws.numel(), B, cur_stream()), 'dcs_attention_bwd_batched')
     return res
 
 
@@ -715,7 +727,7 @@ def complex_upsample(x, up):
     return y
 
 
-def tapsum(z, ksize, up, pad, backward=False, grad=None, bias=None, bias_grad=None):
+def tapsum(z, ksize, up, pad, backward=False, grad=None, bias=None, bias_grad=None, out_dtype=torch.float32):
     """Spatial half of a Cout = 1 conv (dcs_tapsum_fwd / _bwd).  Forward: z [B,Hs,Ws,CT,2] -> y
     [B,Hs*uf,Ws*ut,1,2], plus the layer's bias if bias = (b_r, b_i) (one float each).  backward=True: grad
     [B,Ho,Wo,1,2] -> gz shaped like z (pass z's shape via `z`); bias_grad = (gb_r, gb_i) destinations (written)."""
@@ -730,10 +742,10 @@ def tapsum(z, ksize, up, pad, backward=False, grad=None, bias=None, bias_grad=No
         return y
     _chk(grad, 'grad', 5)
     B, Hs, Ws, CT, _ = z
-    gz = torch.empty((B, Hs, Ws, CT, 2), dtype=torch.float32, device=grad.device)
+    gz = torch.empty((B, Hs, Ws, CT, 2), dtype=out_dtype, device=grad.device)      # (bf16 where the activations are: _h)
     gb_r, gb_i = bias_grad if bias_grad is not None else (None, None)
     ws = _workspace(lib.dcs_tapsum_bwd_workspace_bytes(), grad.device) if gb_r is not None else None
-    check(lib.dcs_tapsum_bwd(ptr(grad), ptr(gz), ptr(gb_r), ptr(gb_i), ptr(ws), 0 if ws is None else ws.numel(), B, Hs, Ws, CT,
+    check(_sym('dcs_tapsum_bwd', gz)(ptr(grad), ptr(gz), ptr(gb_r), ptr(gb_i), ptr(ws), 0 if ws is None else ws.numel(), B, Hs, Ws, CT,
                              ksize[0], ksize[1], up[0], up[1], pad[0], pad[1], cur_stream()), 'dcs_tapsum_bwd')
     return gz
 
@@ -741,13 +753,13 @@ def tapsum(z, ksize, up, pad, backward=False, grad=None, bias=None, bias_grad=No
 def cconv_up2_single(x1, x2, wt, b_r, b_i):
     """3x3 / stride 1 / one output channel over the 2x2 upsample of cat(x1, x2) in one kernel (dcs_cconv_up2_single_fwd).
     wt: tap-rows panel [1, 16, ct, 2] of pack_tap_rows."""
-    _chk(x1, 'x1', 5)
-    _chk(x2, 'x2', 5)
+    _chk(x1, 'x1', 5, act=True)
+    _chk(x2, 'x2', 5, act=True)
     _chk(wt, 'wt', 4)
     B, Hs, Ws, C1, _ = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     y = torch.empty((B, 2 * Hs, 2 * Ws, 1, 2), dtype=torch.float32, device=x1.device)
-    check(_lib.load().dcs_cconv_up2_single_fwd(ptr(x1), ptr(x2), ptr(wt), ptr(b_r), ptr(b_i), ptr(y), B, Hs, Ws, C1, C2,
+    check(_sym('dcs_cconv_up2_single_fwd', x1, x2)(ptr(x1), ptr(x2), ptr(wt), ptr(b_r), ptr(b_i), ptr(y), B, Hs, Ws, C1, C2,
                                                wt.shape[2], cur_stream()), 'dcs_cconv_up2_single_fwd')
     return y
 

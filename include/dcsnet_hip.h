@@ -682,6 +682,83 @@ int dcs_pack_plan_jobs(const void* plan, int* n_jobs, int* n_launches);
 int dcs_pack_plan_run(const void* plan, dcs_stream_t stream);
 int dcs_pack_plan_destroy(void* plan);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * bf16 activation storage (BASELINE.json configs[4]: bf16 activations in HBM, fp32 accumulation / statistics / parameters /
+ * optimizer; the reference itself trains at precision 32: config.py:70, train.py:144 — this is the build's stated
+ * mixed-precision extension).  Every entry point that touches ACTIVATIONS — the float[B][F][T][C][2] tensors between layers
+ * and their cotangents — exists a second time with the suffix _h and those tensors as bf16 (dcs_bf16_t = the upper 16 bits
+ * of an fp32, round-to-nearest-even on store), same argument order and meaning as the fp32 form it mirrors; every other
+ * operand (packed weights, biases, CBN parameters / statistics / coefficients, the per-sample and per-pixel attention maps
+ * ca / sa / pooled / hidden / sp / g_pre / g_sp, split-K and weight-gradient slabs, parameter gradients) stays fp32.
+ * Kernels read bf16, compute in fp32 (MFMA: bf16 operands, fp32 accumulate) and round once on store.  Requires
+ * dcs_set_conv_precision(1) (bf16 weight panels).  Workspace sizes are those of the fp32 queries.
+ * In dcs_attention_item the fields x, y, g_out, g_x are bf16 tensors for the _h batched calls.  dcs_cconv_up2_single_fwd_h
+ * reads bf16 sources and writes the network's fp32 mask; dcs_tapsum_bwd_h reads the fp32 mask cotangent and writes bf16. */
+typedef unsigned short dcs_bf16_t;
+int dcs_cconv2d_fwd_h(const dcs_bf16_t* x1, const dcs_bf16_t* x2, const float* wp, const float* bias, dcs_bf16_t* y,
+                      void* workspace, long workspace_bytes,
+                      int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                      int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act, dcs_stream_t stream);
+int dcs_cconv2d_fwd_affine_h(const dcs_bf16_t* x1, const dcs_bf16_t* x2, const float* wp, const float* bias, const float* coef,
+                             dcs_bf16_t* y, void* workspace, long workspace_bytes,
+                             int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                             int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int act, dcs_stream_t stream);
+int dcs_cconv2d_fwd_stats_h(const dcs_bf16_t* x1, const dcs_bf16_t* x2, const float* wp, const float* bias, dcs_bf16_t* y,
+                            float* stat, int stat_rows, int* rows_used, void* workspace, long workspace_bytes,
+                            int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                            int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, dcs_stream_t stream);
+int dcs_cconv2d_bwd_data_h(const dcs_bf16_t* gy, const float* wp_bwd, dcs_bf16_t* gx1, dcs_bf16_t* gx2,
+                           void* workspace, long workspace_bytes,
+                           int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                           int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, dcs_stream_t stream);
+int dcs_cconv2d_bwd_weight_h(const dcs_bf16_t* x1, const dcs_bf16_t* x2, const dcs_bf16_t* gy,
+                             float* gw_r, float* gw_i, float* gb_r, float* gb_i, void* workspace, long workspace_bytes,
+                             int B, int Hin, int Win, int C1, int C2, int up_f, int up_t,
+                             int Cout, int kh, int kw, int sf, int st, int pad_f, int pad_t, int transposed,
+                             dcs_stream_t stream);
+int dcs_cconv_up2_single_fwd_h(const dcs_bf16_t* x1, const dcs_bf16_t* x2, const float* wt, const float* b_r, const float* b_i,
+                               float* y, int B, int Hs, int Ws, int C1, int C2, int ct, dcs_stream_t stream);
+int dcs_tapsum_bwd_h(const float* gy, dcs_bf16_t* gz, float* gb_r, float* gb_i, void* workspace, long workspace_bytes,
+                     int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t, int pad_f, int pad_t,
+                     dcs_stream_t stream);
+int dcs_cbn_fwd_h(const dcs_bf16_t* x, dcs_bf16_t* y, const float* weight, const float* bias,
+                  float* running_mean, float* running_covar, float* stats_out, float* coef_out,
+                  void* workspace, long workspace_bytes, long P, int C, float eps, float momentum, int use_batch_stats,
+                  int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
+int dcs_cbn_fwd_slabs_h(const dcs_bf16_t* x, dcs_bf16_t* y, const float* weight, const float* bias,
+                        float* running_mean, float* running_covar, float* stats_out, float* coef_out,
+                        const float* part, int rows, int stride, const float* pivot,
+                        long P, int C, float eps, float momentum, int act,
+                        float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
+int dcs_cbn_bwd_h(const dcs_bf16_t* x, const dcs_bf16_t* g_out, dcs_bf16_t* g_x, const float* weight,
+                  const float* stats, const float* coef, float* g_weight, float* g_bias,
+                  void* workspace, long workspace_bytes, long P, int C, int use_batch_stats, int act,
+                  float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
+int dcs_cbn_bwd_add_h(const dcs_bf16_t* x, const dcs_bf16_t* g_out, dcs_bf16_t* g_x, const float* weight, const float* stats,
+                      const float* coef, float* g_weight, float* g_bias, void* workspace, long workspace_bytes,
+                      long P, int C, int use_batch_stats, int act, float drop_p, unsigned long long seed,
+                      const unsigned long long* seed_dev, const float* g_add, float add_scale, long HW,
+                      const dcs_bf16_t* g_out2, dcs_stream_t stream);
+int dcs_channel_attention_fwd_h(const dcs_bf16_t* x, const float* w1, const float* w2,
+                                float* ca_out, float* pooled_out, float* hidden_out,
+                                void* workspace, long workspace_bytes, int B, long HW, int C, int Ch, dcs_stream_t stream);
+int dcs_spatial_pool_fwd_h(const dcs_bf16_t* x, const float* ca, float* pooled, int B, long HW, int C, dcs_stream_t stream);
+int dcs_attention_apply_fwd_h(const dcs_bf16_t* x, const float* ca, const float* sa, dcs_bf16_t* y,
+                              int B, long HW, int C, float drop_p, unsigned long long seed,
+                              const unsigned long long* seed_dev, dcs_stream_t stream);
+int dcs_attention_fwd_batched_h(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
+                                dcs_stream_t stream);
+int dcs_attention_bwd_sa_h(const dcs_bf16_t* x, const dcs_bf16_t* g_out, const float* ca, const float* sa, float* g_pre,
+                           int B, long HW, int C, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                           dcs_stream_t stream);
+int dcs_attention_bwd_x_h(const dcs_bf16_t* x, const dcs_bf16_t* g_out, const float* ca, const float* sa, const float* g_sp,
+                          const float* pooled, const float* hidden, const float* w1, const float* w2,
+                          dcs_bf16_t* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r, float* g_fc2_i, float* g_pooled,
+                          void* workspace, long workspace_bytes, int B, long HW, int C, int Ch,
+                          float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
+int dcs_attention_bwd_batched_h(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
+                                dcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
