@@ -69,7 +69,7 @@ class ConvTimer:
         self._seq = 0
         self._step += 1
 
-    def begin(self, flops, tag=None, executed=1.0, emulated=False):
+    def begin(self, flops, tag=None, executed=1.0, emulated=False, nbytes=0.0):
         """flops: ALGORITHMIC flops of the launch (what the reference computes); executed: the share of them the kernel
         actually issues (< 1 for the upsample-folded decoder launches).  tag: sub-family of the launch ('enc_fwd' =
         forward ComplexConv2d of the encoder stack, the layers BASELINE.json's target names), summed separately as well.
@@ -78,7 +78,7 @@ class ConvTimer:
             return None
         j = self._seq
         self._seq += 1
-        self.flops_by_seq[j] = (flops, executed, tag, bool(emulated))
+        self.flops_by_seq[j] = (flops, executed, tag, bool(emulated), float(nbytes))
         if (j + self._step) % self.stride:
             return None
         from dcsnet import _lib
@@ -114,9 +114,11 @@ class ConvTimer:
                   peak for native launches, bf16 peak / 6 for launches that emulate fp32 by six bf16 MFMAs per product
         pipe_ms   the same for the EXECUTED flops (folded decoder launches issue 6/9 or 4/9 of the taps)
         emu_flops algorithmic flops of the emulated launches."""
-        r = dict(ms=0.0, n=0, flops=0.0, exec=0.0, ceil_ms=0.0, pipe_ms=0.0, emu_flops=0.0)
+        r = dict(ms=0.0, n=0, flops=0.0, exec=0.0, ceil_ms=0.0, pipe_ms=0.0, emu_flops=0.0, bytes=0.0)
         for j, d in sorted(self._read().items()):
-            f, e, tag, emu = self.flops_by_seq[j]
+            f, e, tag, emu, nb = self.flops_by_seq[j]
+            if pred(tag):
+                r['bytes'] += nb
             if pred(tag):
                 peak = PEAK_BF16X6_TFLOPS if emu else PEAK_F32_MFMA_TFLOPS
                 r['ms'] += sorted(d)[len(d) // 2]
@@ -376,10 +378,14 @@ def main():
             print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
     train = args.mode == 'train'
-    B = args.batch or (32 if train else 16)
+    bf16 = args.dtype == 'bf16'
+    # --dtype bf16: BASELINE configs[4]'s per-GPU share — bf16 activations in HBM, B = 64 per GPU in training
+    B = args.batch or ((64 if bf16 else 32) if train else 16)
     T = args.frames or (256 if train else 2000)
     torch.manual_seed(0)
     net = C_NETWORK(config, hparams, 0).to(dev)
+    if bf16:
+        net.set_activation_dtype('bf16')
     noise, noisy, clean = synthetic_stft_batch(B, T, dev, seed=rank)
 
     # DCS_BENCH_TIMER_STRIDE=7 times every 7th launch only (a different residue each step): measured identical to timing
@@ -514,9 +520,13 @@ def main():
                        'STFT frames/sec (forward-only inference: C_NETWORK forward + bound/mask-apply/subtract)'),
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.dtype == 'f32' else 'bf16 conv operands (forward + data gradient), f32 accumulate / weight gradients / storage',
+            'dtype': 'f32' if args.dtype == 'f32' else 'bf16 (activations and cotangents stored in bf16 in HBM, bf16 MFMA operands; fp32 accumulators, CBN statistics, attention maps, LSTM, mask, parameters, gradients, Adam)',
             'data': 'synthetic',
-            'config': {'workload': ('BASELINE configs[2]/[3]: DCS-Net full train step (fwd + SiSNR losses + bwd + grad '
+            'config': {'workload': (f'BASELINE configs[4], per-GPU share: DCS-Net bf16 mixed-precision train step (fwd + SiSNR losses + '
+                                    f'bwd + grad all-reduce + clip 100 + Adam/AMSGrad), complex64 [{B},256,{T}] x (noise, noisy, clean) per '
+                                    'GPU, dropout 0.1/0.2, batch-statistics CBN, random-init weights seed 0 — NOT the headline '
+                                    '(the reference trains at precision 32)' if train and bf16 else
+                                    'BASELINE configs[2]/[3]: DCS-Net full train step (fwd + SiSNR losses + bwd + grad '
                                     'all-reduce + clip 100 + Adam/AMSGrad), complex64 [32,256,256] x (noise, noisy, clean) '
                                     'per GPU, dropout 0.1/0.2, batch-statistics CBN, random-init weights seed 0'
                                     if train else
@@ -565,6 +575,20 @@ def main():
                          # fp32 flop at 2500 TFLOP/s on the emulated one
                          'executed_frac': (conv_pipe_ms / conv_ms if conv_ms > 0 else 0.0)},
         }
+        line['roofline']['algorithmic_gbytes_per_step'] = cs['bytes'] / 1e9
+        if bf16:
+            # BASELINE.md / SURVEY §8(d): with bf16 storage every conv stage sits below the bf16 ridge (310 flop/B) — the family's
+            # roofline is HBM.  achieved = algorithmic bytes (every activation read once and written once at 4 B per complex
+            # value, the weights once) / the launches' measured time; the MFMA figures stay beside it.
+            mf = dict(line['roofline'])
+            gbs = cs['bytes'] / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
+            line['roofline'] = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+                                'traffic': None, 'kernel': mf['kernel'], 'launches_per_step': n_launch,
+                                'kernel_ms_per_step': conv_ms, 'samples_per_launch': mf['samples_per_launch'],
+                                'algorithmic_gbytes_per_step': cs['bytes'] / 1e9, 'measured': mf['measured'],
+                                'mfma': {'achieved': mf['achieved'], 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                         'frac': mf['achieved'] / PEAK_BF16_MFMA_TFLOPS,
+                                         'algorithmic_gflop_per_step': mf['algorithmic_gflop_per_step']}}
         # BASELINE.json's target names the ComplexConv2d ENCODER stack: its forward launches on their own (same pass)
         es = timer.tag_summary('enc_fwd')
         e_ms, e_n, e_fl = es['ms'], es['n'], es['flops']

@@ -235,7 +235,8 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     # (strided forward convs are exactly the encoder's ComplexConv2d stack: tagged for bench.py's encoder roofline)
     ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None,
                            executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
-                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and C1 % 2 == 0)
+                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and C1 % 2 == 0,
+                           nbytes=_conv_bytes(x1, B * Hin * Win * (C1 + C2), B * Hout * Wout * Cout, kh * kw * (C1 + C2) * Cout))
           if CONV_TIMER is not None else None)
     if coef is not None:
         _chk(coef, 'coef', 2)
@@ -279,7 +280,8 @@ def cconv2d_stats(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1))
     ws = _workspace(nbytes, x1.device) if nbytes > 0 else None
     ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None,
                            executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
-                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and C1 % 2 == 0)
+                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and C1 % 2 == 0,
+                           nbytes=_conv_bytes(x1, B * Hin * Win * (C1 + C2), B * Hout * Wout * Cout, kh * kw * (C1 + C2) * Cout))
           if CONV_TIMER is not None else None)
     used = ctypes.c_int(0)
     check(_sym('dcs_cconv2d_fwd_stats', x1, x2)(ptr(x1), ptr(x2), ptr(wp), ptr(bias), ptr(y), ptr(part), rows, ctypes.byref(used), ptr(ws),
@@ -291,6 +293,15 @@ def cconv2d_stats(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1))
 
 import os as _os
 STATS_EPILOGUE = _os.environ.get('DCS_STATS_EPILOGUE', '1') != '0'       # 0 (A/B runs): every training-mode CBN makes its own statistics pass
+
+
+def _conv_bytes(act, n_in, n_out, n_w):
+    """ALGORITHMIC HBM bytes of one conv launch (every activation read once and written once, the weights
+    once): n_in complex values read + n_out written at the activations' storage size (8 B fp32, 4 B bf16), n_w complex
+    weights at the packed panel's size (fp32 8 B; bf16 panels 4 B)."""
+    e = 4.0 if act.dtype == torch.bfloat16 else 8.0
+    w = 4.0 if conv_precision() == 'bf16' else 8.0
+    return e * (n_in + n_out) + w * n_w
 
 
 def _emulated(k_channels, n_channels, taps=0):
@@ -365,7 +376,8 @@ def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=Non
         raise _lib.DcsHipError(f'cconv2d_bwd_data: unsupported geometry {geo}')
     ws = _workspace(nbytes, gy.device) if nbytes else None
     ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * Cin * ksize[0] * ksize[1],
-                           executed=_fold_fraction(C1, Cin, Cout, ksize, stride, pad, up), emulated=_emulated(Cout, Cin))
+                           executed=_fold_fraction(C1, Cin, Cout, ksize, stride, pad, up), emulated=_emulated(Cout, Cin),
+                           nbytes=_conv_bytes(gy, B * Hout * Wout * Cout, B * Hin * Win * Cin, ksize[0] * ksize[1] * Cin * Cout))
           if CONV_TIMER is not None else None)
     check(_sym('dcs_cconv2d_bwd_data', gy)(ptr(gy), ptr(wp_bwd), ptr(gx1), ptr(gx2), ptr(ws), ws.numel() if ws is not None else 0,
                                    *geo, cur_stream()), 'dcs_cconv2d_bwd_data')
@@ -413,7 +425,9 @@ def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1,
     if CONV_TIMER is not None:
         ev = CONV_TIMER.begin(8.0 * B * gy.shape[1] * gy.shape[2] * Cout * (C1 + C2) * ksize[0] * ksize[1],
                               executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
-                              emulated=_wgrad_emulated(C1, C1 + C2, Cout, ksize))
+                              emulated=_wgrad_emulated(C1, C1 + C2, Cout, ksize),
+                              nbytes=(_conv_bytes(x1, B * Hin * Win * (C1 + C2) + B * gy.shape[1] * gy.shape[2] * Cout, 0, 0) +
+                                      8.0 * ksize[0] * ksize[1] * (C1 + C2) * Cout))
     try:
         check(_sym('dcs_cconv2d_bwd_weight', x1, x2, gy)(ptr(x1), ptr(x2), ptr(gy), ptr(gw_r), ptr(gw_i), ptr(gb_r), ptr(gb_i), ptr(ws),
                                          ws.numel(), *geo, int(bool(transposed)), cur_stream()), 'dcs_cconv2d_bwd_weight')
