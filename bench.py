@@ -414,8 +414,10 @@ def main():
 
         def eager_step():
             with torch.no_grad():
-                m_raw = net(noisy)
-                return F.bound_mask_apply_complex(noisy, m_raw, hparams['atan2_eps'])
+                # forward(bound=False) + one kernel for both bound_cRM applications, the multiply and the subtract
+                # (c_network.py:225 + network_functions.py:240-243): the once-bounded mask makes no round trip through HBM
+                d_raw = net(noisy, bound=False)
+                return F.bound2_mask_apply_complex(noisy, d_raw, hparams['atan2_eps'])
         step, setup_steps, queued_step = eager_step, 0, eager_step
         if not args.no_graph:
             for _ in range(2):

@@ -35,12 +35,22 @@ __global__ __launch_bounds__(kThreads) void bound_crm_kernel(const float2* __res
     }
 }
 
+// PRE: Min is the network's RAW last-stage output: the first bound_cRM (c_network.py:225) runs here too, so the predicted
+// mask is bounded twice in this one pass (network_functions.py:240) and the once-bounded mask never makes a round trip
+// through HBM (M1out: optional, for callers that want the network's nominal output as well).
+template <bool PRE>
 __global__ __launch_bounds__(kThreads) void bound_mask_apply_kernel(const float2* __restrict__ Y,
                                                                      const float2* __restrict__ Min,
+                                                                     float2* __restrict__ M1out,
                                                                      float2* __restrict__ Mout, float2* __restrict__ Nh,
                                                                      float2* __restrict__ Sh, long n, float eps) {
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-        const float2 y = Y[i], v = Min[i];
+        const float2 y = Y[i];
+        float2 v = Min[i];
+        if (PRE) {
+            v = bound_one(v.x, v.y, eps);
+            if (M1out) M1out[i] = v;
+        }
         const float2 m = bound_one(v.x, v.y, eps);
         const float nr = y.x * m.x - y.y * m.y;
         const float ni = y.x * m.y + y.y * m.x;
@@ -87,8 +97,11 @@ __device__ __forceinline__ float2 bound_one_bwd(float mr, float mi, float eps, f
 
 // g_Min for M = bound(M_in), N = Y M, S = Y - N with optional cotangents gM, gN, gS (Y may be NULL
 // when only gM is given: plain bound_cRM backward)
+// PRE (see the forward kernel): Min is the raw network output; gM1 = optional cotangent of the once-bounded mask.
+template <bool PRE>
 __global__ __launch_bounds__(kThreads) void bound_mask_apply_bwd_kernel(const float2* __restrict__ Y,
                                                                          const float2* __restrict__ Min,
+                                                                         const float2* __restrict__ gM1,
                                                                          const float2* __restrict__ gM,
                                                                          const float2* __restrict__ gN,
                                                                          const float2* __restrict__ gS,
@@ -103,7 +116,14 @@ __global__ __launch_bounds__(kThreads) void bound_mask_apply_bwd_kernel(const fl
             g.y += y.x * t.y - y.y * t.x;
         }
         const float2 v = Min[i];
-        gMin[i] = bound_one_bwd(v.x, v.y, eps, g);
+        if (PRE) {
+            const float2 m1 = bound_one(v.x, v.y, eps);
+            float2 g1 = bound_one_bwd(m1.x, m1.y, eps, g);
+            if (gM1) { const float2 e = gM1[i]; g1.x += e.x; g1.y += e.y; }
+            gMin[i] = bound_one_bwd(v.x, v.y, eps, g1);
+        } else {
+            gMin[i] = bound_one_bwd(v.x, v.y, eps, g);
+        }
     }
 }
 
@@ -125,8 +145,33 @@ extern "C" int dcs_bound_crm_fwd(const float* M_raw, float* M_out, long n, float
 extern "C" int dcs_bound_mask_apply_fwd(const float* Y, const float* M_in, float* M_out, float* N_hat, float* S_hat,
                                         long n, float eps, dcs_stream_t stream) {
     if (!Y || !M_in || !M_out || !N_hat || !S_hat || n <= 0) return DCS_ERR_BADARG;
-    DCS_LAUNCH(bound_mask_apply_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
-                       (const float2*)Y, (const float2*)M_in, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps);
+    DCS_LAUNCH(bound_mask_apply_kernel<false>, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                       (const float2*)Y, (const float2*)M_in, (float2*)nullptr, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// The network's last bound_cRM (c_network.py:225) and the step function's second one + multiply + subtract
+// (network_functions.py:240-243) in ONE pass over the raw last-stage output D: M1 = bound(D) (optional output, NULL: not
+// stored), M = bound(M1), N_hat = Y M, S_hat = Y - N_hat.
+extern "C" int dcs_bound2_mask_apply_fwd(const float* Y, const float* D_raw, float* M1_out, float* M_out, float* N_hat,
+                                         float* S_hat, long n, float eps, dcs_stream_t stream) {
+    if (!Y || !D_raw || !M_out || !N_hat || !S_hat || n <= 0) return DCS_ERR_BADARG;
+    DCS_LAUNCH(bound_mask_apply_kernel<true>, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                       (const float2*)Y, (const float2*)D_raw, (float2*)M1_out, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// Cotangent of D_raw given any of g_M1 (once-bounded mask), g_M, g_N, g_S.
+extern "C" int dcs_bound2_mask_apply_bwd(const float* Y, const float* D_raw, const float* g_M1, const float* g_M,
+                                         const float* g_N, const float* g_S, float* g_D, long n, float eps,
+                                         dcs_stream_t stream) {
+    if (!D_raw || !g_D || n <= 0) return DCS_ERR_BADARG;
+    if ((g_N || g_S) && !Y) return DCS_ERR_BADARG;
+    DCS_LAUNCH(bound_mask_apply_bwd_kernel<true>, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                       (const float2*)Y, (const float2*)D_raw, (const float2*)g_M1, (const float2*)g_M, (const float2*)g_N,
+                       (const float2*)g_S, (float2*)g_D, n, eps);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -135,8 +180,8 @@ extern "C" int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const
                                         const float* g_S, float* g_Min, long n, float eps, dcs_stream_t stream) {
     if (!M_in || !g_Min || n <= 0) return DCS_ERR_BADARG;
     if ((g_N || g_S) && !Y) return DCS_ERR_BADARG;
-    DCS_LAUNCH(bound_mask_apply_bwd_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
-                       (const float2*)Y, (const float2*)M_in, (const float2*)g_M, (const float2*)g_N,
+    DCS_LAUNCH(bound_mask_apply_bwd_kernel<false>, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                       (const float2*)Y, (const float2*)M_in, (const float2*)nullptr, (const float2*)g_M, (const float2*)g_N,
                        (const float2*)g_S, (float2*)g_Min, n, eps);
     DCS_CHECK_LAUNCH();
     return DCS_OK;

@@ -194,7 +194,10 @@ class C_NETWORK(LightningModule):
         shared += 1
         self._counted = True
 
-    def forward(self, x):
+    def forward(self, x, bound=True):
+        """bound=False (this build's step functions and bench only): return the last stage's RAW output, i.e. skip the final
+        bound_cRM (c_network.py:225) because the caller fuses it with the second bound + mask application
+        (F.bound2_mask_apply_*): same numbers, one pass over the [B,256,T] mask less each way."""
         hp, cfg = self.hparams, self.config
         L = hp['no_of_layers']
         p_conv, p_fc = self.dropout_conv.p, self.dropout_fc.p
@@ -312,7 +315,7 @@ class C_NETWORK(LightningModule):
             else:
                 d = F.dropout(y, dp, seed) if dp > 0 else y
 
-        net_out = F.bound_crm(d.view(B, Fbins, T, 2), hp['atan2_eps'])
+        net_out = F.bound_crm(d.view(B, Fbins, T, 2), hp['atan2_eps']) if bound else d.view(B, Fbins, T, 2)
         return torch.squeeze(torch.view_as_complex(net_out))          # c_network.py:224
 
     def _skip_attentions(self, enc):
@@ -328,6 +331,7 @@ class C_NETWORK(LightningModule):
         return F.attention_blocks([enc[L - i] for i in range(L)], params, 7)
 
     batch_skip_attention = True
+    supports_unbounded_forward = True      # forward(x, bound=False): see forward
     activation_dtype = torch.float32
 
     def set_activation_dtype(self, dtype):

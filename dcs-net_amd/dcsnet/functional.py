@@ -838,6 +838,49 @@ class _BoundMaskApplyPairFn(torch.autograd.Function):
         return None, ops.bound_mask_apply_bwd(Y, M_in, gM, gN, gS, ctx.eps), None
 
 
+class _Bound2MaskApplyPairFn(torch.autograd.Function):
+    """Both bound_cRM applications (the network's own, c_network.py:225, and the step function's, network_functions.py:240)
+    + multiply + subtract over the network's RAW last-stage output in one kernel each way: returns (M, NS) — the
+    twice-bounded mask and the stacked estimates [Y (.) M ; Y - Y (.) M]."""
+
+    @staticmethod
+    def forward(ctx, Y, D_raw, eps):
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(Y, D_raw)
+        _, M, NS = ops.bound2_mask_apply(Y, D_raw, eps, pair=True)
+        return M, NS
+
+    @staticmethod
+    def backward(ctx, gM, gNS):
+        Y, D_raw = ctx.saved_tensors
+        if gM is None and gNS is None:
+            return None, None, None
+        gM = None if gM is None else gM.contiguous()
+        gN = gS = None
+        if gNS is not None:
+            gNS = gNS.contiguous()
+            gN, gS = gNS[0], gNS[1]
+        return None, ops.bound2_mask_apply_bwd(Y, D_raw, None, gM, gN, gS, ctx.eps), None
+
+
+def bound2_mask_apply_pair_complex(Y, D_raw, eps=10e-7):
+    """(bound_cRM(bound_cRM(D_raw)), [Y (.) M ; Y - Y (.) M]) from the network's UNBOUNDED output (C_NETWORK.forward(x,
+    bound=False)); differentiable w.r.t. D_raw."""
+    y = torch.view_as_real(Y.contiguous())
+    d = torch.view_as_real(D_raw.contiguous())
+    M, NS = _Bound2MaskApplyPairFn.apply(y, d, eps)
+    return torch.view_as_complex(M), torch.view_as_complex(NS)
+
+
+def bound2_mask_apply_complex(Y, D_raw, eps=10e-7):
+    """Inference form: (M, N_hat, S_hat) from the network's unbounded output, one kernel (no autograd)."""
+    y = torch.view_as_real(Y.contiguous())
+    d = torch.view_as_real(D_raw.contiguous())
+    _, M, N, S = ops.bound2_mask_apply(y, d, eps)
+    return torch.view_as_complex(M), torch.view_as_complex(N), torch.view_as_complex(S)
+
+
 class _PolarFramesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, Fp, eps):

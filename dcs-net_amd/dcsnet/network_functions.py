@@ -287,12 +287,16 @@ def _complex_step_pair(self, noise_data, noisy_data, clean_data):
     cfg = self.config
     B = noisy_data.shape[0]
     tw = _polar_wave(_stacked(noise_data, clean_data), eps, cfg)
-    mask_out = self(noisy_data)
+    # the network's own bound_cRM and the second one of network_functions.py:240 run as ONE kernel on the raw output when
+    # the module offers it (this build's C_NETWORK: forward(x, bound=False)); any other module gets the two-step form
+    fused = getattr(self, 'supports_unbounded_forward', False)
+    mask_out = self(noisy_data, bound=False) if fused else self(noisy_data)
+    apply_pair = F.bound2_mask_apply_pair_complex if fused else F.bound_mask_apply_pair_complex
     if mask_out.dim() + 1 == noisy_data.dim() and B == 1:          # the B = 1 squeeze quirk (c_network.py:224)
-        mask, NS = F.bound_mask_apply_pair_complex(noisy_data, mask_out.unsqueeze(0), eps)
+        mask, NS = apply_pair(noisy_data, mask_out.unsqueeze(0), eps)
         mask = mask.squeeze(0)
     else:
-        mask, NS = F.bound_mask_apply_pair_complex(noisy_data, mask_out, eps)
+        mask, NS = apply_pair(noisy_data, mask_out, eps)
     ew = _polar_wave(NS.reshape((2 * B,) + tuple(NS.shape[2:])), eps, cfg)
     return {'noise_audio': tw[:B], 'clean_audio': tw[B:], 'predict_noise_mask': mask,
             'predict_noise_audio': ew[:B], 'predict_clean_audio': ew[B:], '_pair': (tw, ew)}

@@ -811,6 +811,35 @@ def bound_mask_apply_pair(Y, M_in, eps=10e-7):
     return M, NS
 
 
+def bound2_mask_apply(Y, D_raw, eps=10e-7, pair=False, keep_m1=False):
+    """Both bound_cRM applications + multiply + subtract over the network's RAW last-stage output (dcs_bound2_mask_apply_fwd).
+    Returns (M1 or None, M, N, S) — or (M1 or None, M, NS) with the two estimates stacked when pair=True."""
+    _chk(Y, 'Y')
+    _chk(D_raw, 'D_raw')
+    if Y.shape != D_raw.shape:
+        raise _lib.DcsHipError(f'bound2_mask_apply: Y {tuple(Y.shape)} vs D {tuple(D_raw.shape)}')
+    M = torch.empty_like(Y)
+    M1 = torch.empty_like(Y) if keep_m1 else None
+    if pair:
+        NS = torch.empty((2,) + tuple(Y.shape), dtype=Y.dtype, device=Y.device)
+        N, S = NS[0], NS[1]
+    else:
+        N, S = torch.empty_like(Y), torch.empty_like(Y)
+    check(_lib.load().dcs_bound2_mask_apply_fwd(ptr(Y), ptr(D_raw), ptr(M1), ptr(M), ptr(N), ptr(S), Y.numel() // 2, eps,
+                                                cur_stream()), 'dcs_bound2_mask_apply_fwd')
+    return (M1, M, NS) if pair else (M1, M, N, S)
+
+
+def bound2_mask_apply_bwd(Y, D_raw, g_M1, g_M, g_N, g_S, eps=10e-7):
+    _chk(D_raw, 'D_raw')
+    for n, t in (('Y', Y), ('g_M1', g_M1), ('g_M', g_M), ('g_N', g_N), ('g_S', g_S)):
+        _chk(t, n)
+    g = torch.empty_like(D_raw)
+    check(_lib.load().dcs_bound2_mask_apply_bwd(ptr(Y), ptr(D_raw), ptr(g_M1), ptr(g_M), ptr(g_N), ptr(g_S), ptr(g),
+                                                D_raw.numel() // 2, eps, cur_stream()), 'dcs_bound2_mask_apply_bwd')
+    return g
+
+
 def bound_mask_apply_bwd(Y, M_in, g_M, g_N, g_S, eps=10e-7):
     """Cotangent of M_in; any of g_M / g_N / g_S (and Y when only g_M is given) may be None."""
     _chk(M_in, 'M_in')

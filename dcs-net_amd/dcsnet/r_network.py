@@ -100,6 +100,21 @@ def _packed(owner, tag, tensors, make):
     return val
 
 
+_CONJ = {}
+
+
+def _conj_vec(device):
+    """(1, -1) on the device: made by device-side fills (a host-to-device copy is not permitted while a stream is being
+    captured into a hipGraph, which is where TrainStep's captured step calls this)."""
+    v = _CONJ.get(device)
+    if v is None:
+        v = torch.ones(2, dtype=torch.float32, device=device)
+        v[1].fill_(-1.0)
+        if not (device.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+            _CONJ[device] = v
+    return v
+
+
 def pack_real_panel(w_corr):
     """Correlation kernel w_corr [Cout_r, Cin_r, kh, kw] -> the MFMA B panel of dcs_rconv2d_fwd (include/dcsnet_hip.h):
     element (tap, kg, nt, lane = 32*kk + j, e) = B[tap][8*kg + 4*kk + e][32*nt + j], B[tap][k][n] = w_corr[n, k, dy, dx]."""
@@ -195,7 +210,7 @@ class _RConvFn(torch.autograd.Function):
                 g1 = gxv
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             cplx = lambda t: None if t is None else t.view(*t.shape[:3], t.shape[3] // 2, 2)
-            conj = torch.tensor([1.0, -1.0], device=gy.device)
+            conj = _conj_vec(gy.device)
             gyc = cplx(gy)
             shape_c = (cout // 2, cin // 2, kh, kw)
             a_r, a_i, ab_r, ab_i = ops.cconv2d_bwd_weight(cplx(x1), cplx(x2), gyc, shape_c, has_bias, (kh, kw), stride, pad, up)

@@ -889,3 +889,31 @@ def test_folded_cbn_epilogue_under_co_resident_bf16_mfma_workgroups(dev):
     for a in out['bf16x6']:
         assert torch.equal(a, out['bf16x6'][0])                       # run-to-run identical
         assert float((a - out['f32'][0]).abs().max()) <= 2e-5 * scale
+
+
+def test_double_bound_mask_application_in_one_kernel(dev):
+    """dcs_bound2_mask_apply_fwd / _bwd (the network's own bound_cRM, c_network.py:225, fused with the step function's second
+    bound + multiply + subtract, network_functions.py:240-243) against the two-kernel chain it replaces — itself pinned to
+    the reference's vectors (test_mask_math_against_reference_vectors): same arithmetic per element, so bit-identical forward,
+    and identical cotangents of the raw output incl. the singular points of atan2."""
+    from dcsnet import functional as F
+    d0 = rand_c((3, 256, 40), 5, 1.5)
+    d0.view(-1)[:4] = torch.tensor([0 + 0j, -1e-6 + 0j, 1e-7 - 1e-7j, -2.0 + 0j])
+    Y = rand_c((3, 256, 40), 6, 0.8).to(dev)
+    gM = torch.view_as_real(rand_c((3, 256, 40), 7)).to(dev)
+    gNS = torch.view_as_real(rand_c((2, 3, 256, 40), 8)).to(dev)
+    outs = []
+    for fused in (False, True):
+        d = d0.clone().to(dev).requires_grad_(True)
+        if fused:
+            M, NS = F.bound2_mask_apply_pair_complex(Y, d, 10e-7)
+        else:
+            M, NS = F.bound_mask_apply_pair_complex(Y, F.bound_crm_complex(d, 10e-7), 10e-7)
+        ((torch.view_as_real(M) * gM).sum() + (torch.view_as_real(NS) * gNS).sum()).backward()
+        outs.append((M.detach(), NS.detach(), d.grad.detach()))
+    for a, b, what in zip(outs[0], outs[1], ('M', 'NS', 'g_D')):
+        assert torch.equal(torch.view_as_real(a), torch.view_as_real(b)), what
+    M, N, S = F.bound2_mask_apply_complex(Y, d0.to(dev), 10e-7)
+    assert torch.equal(torch.view_as_real(M), torch.view_as_real(outs[0][0]))
+    assert torch.equal(torch.view_as_real(N), torch.view_as_real(outs[0][1][0]))
+    assert torch.equal(torch.view_as_real(S), torch.view_as_real(outs[0][1][1]))

@@ -293,3 +293,69 @@ def test_partial_batch_after_capture_runs_eagerly(dev):
     assert torch.allclose(ts_g.bucket.flat, ts_e.bucket.flat, atol=5e-4)
     l1, l2 = ts_g(full), ts_g(full)
     assert l1.data_ptr() != l2.data_ptr()           # each call returns its own loss tensor
+
+
+def test_rnetwork_graph_replayed_train_step_matches_eager(dev):
+    """DR-Net through TrainStep's CAPTURED step (_loss_no_sync hard-coded dtype='complex', so capture always failed
+    for R_NETWORK and fell back to eager with a warning): the graph must really be captured and follow the eager trajectory."""
+    import sys
+    import warnings
+    from dcsnet.config import config, hparams
+    from dcsnet.r_network import R_NETWORK
+    from dcsnet.dp import TrainStep
+    from oracle.seeded_state import fill_state_stream
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    clean, noise = seeded_input(2, 256, 32, 1, 0.1), seeded_input(2, 256, 32, 2, 0.05)
+    batch = (noise.to(dev), (clean + noise).to(dev), clean.to(dev), [0, 1])
+    argv = sys.argv
+    sys.argv = ['train.py', 'drs', '0']
+    try:
+        runs = []
+        for use_graph in (False, True):
+            net = fill_state_stream(R_NETWORK(config, hp, 0), 5).to(dev).train()
+            ts = TrainStep(net, use_graph=use_graph, graph_warmup=2)
+            with warnings.catch_warnings():
+                warnings.simplefilter('error')                      # a capture failure warns: make it fail here
+                losses = [float(ts(batch)) for _ in range(5)]
+            runs.append((losses, ts))
+    finally:
+        sys.argv = argv
+    (eager, _), (graph, ts_g) = runs
+    assert ts_g._graph is not None, 'capture did not happen (fell back to eager)'
+    for a, b in zip(eager, graph):
+        assert abs(a - b) <= 1e-3 * abs(a) + 1e-3, (eager, graph)
+
+
+@pytest.mark.parametrize('graph', [False, True], ids=['eager', 'graph'])
+def test_inference_side_stream_overlap_is_bit_identical(dev, graph):
+    """C_NETWORK.overlap_skip_attention (inference: the batched skip attentions on a side stream beside the LSTM, joined
+    BEFORE the fc conv — profiles/r03_pk_fma_op_sel_hazard.txt) against the single-stream pass, bit for bit, at a shape where
+    the attentions outlast the LSTM (long frequency axis, 8 LSTM steps: the side stream is still busy at the join), eager
+    and captured."""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    net = fill_state(C_NETWORK(config, hparams, 0), 4).to(dev).eval()
+    x = seeded_input(16, 256, 32, seed=9).to(dev)
+    outs = {}
+    for overlap in (False, True):
+        net.overlap_skip_attention = overlap
+
+        def run():
+            with torch.no_grad():
+                return net(x)
+        run(); run()
+        torch.cuda.synchronize()
+        if graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static = run()
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            outs[overlap] = static.clone()
+        else:
+            outs[overlap] = run().clone()
+            torch.cuda.synchronize()
+    assert torch.equal(outs[False], outs[True])
+    assert bool(torch.isfinite(torch.view_as_real(outs[True])).all())
