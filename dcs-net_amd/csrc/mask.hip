@@ -38,15 +38,24 @@ __global__ __launch_bounds__(kThreads) void bound_crm_kernel(const float2* __res
 // PRE: Min is the network's RAW last-stage output: the first bound_cRM (c_network.py:225) runs here too, so the predicted
 // mask is bounded twice in this one pass (network_functions.py:240) and the once-bounded mask never makes a round trip
 // through HBM (M1out: optional, for callers that want the network's nominal output as well).
-template <bool PRE>
+// DROP (with PRE): Min is the last conv's output BEFORE the network's final dropout (c_network.py:221-222): the mask —
+// dcs_dropout_fwd's, hash(seed + *seed_dev, float index) — is applied on the way in, so that pass over the tensor goes too.
+template <bool PRE, bool DROP>
 __global__ __launch_bounds__(kThreads) void bound_mask_apply_kernel(const float2* __restrict__ Y,
                                                                      const float2* __restrict__ Min,
                                                                      float2* __restrict__ M1out,
                                                                      float2* __restrict__ Mout, float2* __restrict__ Nh,
-                                                                     float2* __restrict__ Sh, long n, float eps) {
+                                                                     float2* __restrict__ Sh, long n, float eps,
+                                                                     float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (DROP && seed_dev) seed += seed_dev[0];
+    const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
         const float2 y = Y[i];
         float2 v = Min[i];
+        if (DROP) {
+            v.x *= dcs_keep_scale(seed, (uint64_t)(2 * i), drop_p, inv_keep);
+            v.y *= dcs_keep_scale(seed, (uint64_t)(2 * i + 1), drop_p, inv_keep);
+        }
         if (PRE) {
             v = bound_one(v.x, v.y, eps);
             if (M1out) M1out[i] = v;
@@ -98,14 +107,17 @@ __device__ __forceinline__ float2 bound_one_bwd(float mr, float mi, float eps, f
 // g_Min for M = bound(M_in), N = Y M, S = Y - N with optional cotangents gM, gN, gS (Y may be NULL
 // when only gM is given: plain bound_cRM backward)
 // PRE (see the forward kernel): Min is the raw network output; gM1 = optional cotangent of the once-bounded mask.
-template <bool PRE>
+template <bool PRE, bool DROP>
 __global__ __launch_bounds__(kThreads) void bound_mask_apply_bwd_kernel(const float2* __restrict__ Y,
                                                                          const float2* __restrict__ Min,
                                                                          const float2* __restrict__ gM1,
                                                                          const float2* __restrict__ gM,
                                                                          const float2* __restrict__ gN,
                                                                          const float2* __restrict__ gS,
-                                                                         float2* __restrict__ gMin, long n, float eps) {
+                                                                         float2* __restrict__ gMin, long n, float eps,
+                                                                         float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (DROP && seed_dev) seed += seed_dev[0];
+    const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
         float2 g = gM ? gM[i] : make_float2(0.f, 0.f);
         if (Y && (gN || gS)) {
@@ -115,12 +127,19 @@ __global__ __launch_bounds__(kThreads) void bound_mask_apply_bwd_kernel(const fl
             g.x += y.x * t.x + y.y * t.y;
             g.y += y.x * t.y - y.y * t.x;
         }
-        const float2 v = Min[i];
+        float2 v = Min[i];
+        float kx = 1.f, ky = 1.f;
+        if (DROP) {
+            kx = dcs_keep_scale(seed, (uint64_t)(2 * i), drop_p, inv_keep);
+            ky = dcs_keep_scale(seed, (uint64_t)(2 * i + 1), drop_p, inv_keep);
+            v.x *= kx; v.y *= ky;
+        }
         if (PRE) {
             const float2 m1 = bound_one(v.x, v.y, eps);
             float2 g1 = bound_one_bwd(m1.x, m1.y, eps, g);
             if (gM1) { const float2 e = gM1[i]; g1.x += e.x; g1.y += e.y; }
-            gMin[i] = bound_one_bwd(v.x, v.y, eps, g1);
+            const float2 gd = bound_one_bwd(v.x, v.y, eps, g1);
+            gMin[i] = make_float2(gd.x * kx, gd.y * ky);
         } else {
             gMin[i] = bound_one_bwd(v.x, v.y, eps, g);
         }
@@ -145,8 +164,9 @@ extern "C" int dcs_bound_crm_fwd(const float* M_raw, float* M_out, long n, float
 extern "C" int dcs_bound_mask_apply_fwd(const float* Y, const float* M_in, float* M_out, float* N_hat, float* S_hat,
                                         long n, float eps, dcs_stream_t stream) {
     if (!Y || !M_in || !M_out || !N_hat || !S_hat || n <= 0) return DCS_ERR_BADARG;
-    DCS_LAUNCH(bound_mask_apply_kernel<false>, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
-                       (const float2*)Y, (const float2*)M_in, (float2*)nullptr, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps);
+    DCS_LAUNCH((bound_mask_apply_kernel<false, false>), dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                       (const float2*)Y, (const float2*)M_in, (float2*)nullptr, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps,
+                       0.f, (uint64_t)0, (const uint64_t*)nullptr);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -155,23 +175,35 @@ extern "C" int dcs_bound_mask_apply_fwd(const float* Y, const float* M_in, float
 // (network_functions.py:240-243) in ONE pass over the raw last-stage output D: M1 = bound(D) (optional output, NULL: not
 // stored), M = bound(M1), N_hat = Y M, S_hat = Y - N_hat.
 extern "C" int dcs_bound2_mask_apply_fwd(const float* Y, const float* D_raw, float* M1_out, float* M_out, float* N_hat,
-                                         float* S_hat, long n, float eps, dcs_stream_t stream) {
-    if (!Y || !D_raw || !M_out || !N_hat || !S_hat || n <= 0) return DCS_ERR_BADARG;
-    DCS_LAUNCH(bound_mask_apply_kernel<true>, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
-                       (const float2*)Y, (const float2*)D_raw, (float2*)M1_out, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps);
+                                         float* S_hat, long n, float eps, float drop_p, unsigned long long seed,
+                                         const unsigned long long* seed_dev, dcs_stream_t stream) {
+    if (!Y || !D_raw || !M_out || !N_hat || !S_hat || n <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
+    if (drop_p > 0.f)
+        DCS_LAUNCH((bound_mask_apply_kernel<true, true>), dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                   (const float2*)Y, (const float2*)D_raw, (float2*)M1_out, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps,
+                   drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+    else
+        DCS_LAUNCH((bound_mask_apply_kernel<true, false>), dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                   (const float2*)Y, (const float2*)D_raw, (float2*)M1_out, (float2*)M_out, (float2*)N_hat, (float2*)S_hat, n, eps,
+                   0.f, (uint64_t)0, (const uint64_t*)nullptr);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
 
 // Cotangent of D_raw given any of g_M1 (once-bounded mask), g_M, g_N, g_S.
 extern "C" int dcs_bound2_mask_apply_bwd(const float* Y, const float* D_raw, const float* g_M1, const float* g_M,
-                                         const float* g_N, const float* g_S, float* g_D, long n, float eps,
-                                         dcs_stream_t stream) {
-    if (!D_raw || !g_D || n <= 0) return DCS_ERR_BADARG;
+                                         const float* g_N, const float* g_S, float* g_D, long n, float eps, float drop_p,
+                                         unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
+    if (!D_raw || !g_D || n <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
     if ((g_N || g_S) && !Y) return DCS_ERR_BADARG;
-    DCS_LAUNCH(bound_mask_apply_bwd_kernel<true>, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
-                       (const float2*)Y, (const float2*)D_raw, (const float2*)g_M1, (const float2*)g_M, (const float2*)g_N,
-                       (const float2*)g_S, (float2*)g_D, n, eps);
+    if (drop_p > 0.f)
+        DCS_LAUNCH((bound_mask_apply_bwd_kernel<true, true>), dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                   (const float2*)Y, (const float2*)D_raw, (const float2*)g_M1, (const float2*)g_M, (const float2*)g_N,
+                   (const float2*)g_S, (float2*)g_D, n, eps, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+    else
+        DCS_LAUNCH((bound_mask_apply_bwd_kernel<true, false>), dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+                   (const float2*)Y, (const float2*)D_raw, (const float2*)g_M1, (const float2*)g_M, (const float2*)g_N,
+                   (const float2*)g_S, (float2*)g_D, n, eps, 0.f, (uint64_t)0, (const uint64_t*)nullptr);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
@@ -180,9 +212,9 @@ extern "C" int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const
                                         const float* g_S, float* g_Min, long n, float eps, dcs_stream_t stream) {
     if (!M_in || !g_Min || n <= 0) return DCS_ERR_BADARG;
     if ((g_N || g_S) && !Y) return DCS_ERR_BADARG;
-    DCS_LAUNCH(bound_mask_apply_bwd_kernel<false>, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
+    DCS_LAUNCH((bound_mask_apply_bwd_kernel<false, false>), dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream),
                        (const float2*)Y, (const float2*)M_in, (const float2*)nullptr, (const float2*)g_M, (const float2*)g_N,
-                       (const float2*)g_S, (float2*)g_Min, n, eps);
+                       (const float2*)g_S, (float2*)g_Min, n, eps, 0.f, (uint64_t)0, (const uint64_t*)nullptr);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

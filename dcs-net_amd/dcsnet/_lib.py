@@ -84,8 +84,8 @@ SIGNATURES = {
     'dcs_bound_crm_fwd': (_I, [_P, _P, _L, _F, _P]),
     'dcs_bound_mask_apply_fwd': (_I, [_P, _P, _P, _P, _P, _L, _F, _P]),
     'dcs_bound_mask_apply_bwd': (_I, [_P] * 6 + [_L, _F, _P]),
-    'dcs_bound2_mask_apply_fwd': (_I, [_P] * 6 + [_L, _F, _P]),
-    'dcs_bound2_mask_apply_bwd': (_I, [_P] * 7 + [_L, _F, _P]),
+    'dcs_bound2_mask_apply_fwd': (_I, [_P] * 6 + [_L, _F, _F, _U64, _P, _P]),
+    'dcs_bound2_mask_apply_bwd': (_I, [_P] * 7 + [_L, _F, _F, _U64, _P, _P]),
     'dcs_irfft512_frames': (_I, [_P, _P, _L, _P]),
     'dcs_rfft512_frames': (_I, [_P, _P, _L, _P]),
     'dcs_polar_frames_fwd': (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),

@@ -197,7 +197,8 @@ class C_NETWORK(LightningModule):
     def forward(self, x, bound=True):
         """bound=False (this build's step functions and bench only): return the last stage's RAW output, i.e. skip the final
         bound_cRM (c_network.py:225) because the caller fuses it with the second bound + mask application
-        (F.bound2_mask_apply_*): same numbers, one pass over the [B,256,T] mask less each way."""
+        (F.bound2_mask_apply_*): same numbers, one pass over the [B,256,T] mask less each way.  The last stage's dropout
+        (c_network.py:221-222) is then left to those kernels as well: (p, seed) in self._pending_dropout, (0, 0) in eval."""
         hp, cfg = self.hparams, self.config
         L = hp['no_of_layers']
         p_conv, p_fc = self.dropout_conv.p, self.dropout_fc.p
@@ -312,6 +313,9 @@ class C_NETWORK(LightningModule):
                 d = stage[1]._hip_forward(y, F.ACT_LRELU, 0.0, 0, count=not self._counted, attention=(
                     ca_m.fc[0].conv_r.weight, ca_m.fc[0].conv_i.weight, ca_m.fc[2].conv_r.weight, ca_m.fc[2].conv_i.weight,
                     sa_m.conv1.conv_r.weight, sa_m.conv1.conv_i.weight, sa_m.kernel_size, dp, seed), stat=stat)
+            elif not bound:                                  # the caller's fused bound + apply kernels run this dropout too
+                d = y
+                self.__dict__['_pending_dropout'] = (dp, seed)
             else:
                 d = F.dropout(y, dp, seed) if dp > 0 else y
 

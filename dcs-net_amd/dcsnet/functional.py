@@ -844,32 +844,33 @@ class _Bound2MaskApplyPairFn(torch.autograd.Function):
     twice-bounded mask and the stacked estimates [Y (.) M ; Y - Y (.) M]."""
 
     @staticmethod
-    def forward(ctx, Y, D_raw, eps):
-        ctx.eps = eps
+    def forward(ctx, Y, D_raw, eps, drop_p, seed):
+        ctx.eps, ctx.drop = eps, (float(drop_p), int(seed))
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(Y, D_raw)
-        _, M, NS = ops.bound2_mask_apply(Y, D_raw, eps, pair=True)
+        _, M, NS = ops.bound2_mask_apply(Y, D_raw, eps, pair=True, drop_p=drop_p, seed=seed)
         return M, NS
 
     @staticmethod
     def backward(ctx, gM, gNS):
         Y, D_raw = ctx.saved_tensors
         if gM is None and gNS is None:
-            return None, None, None
+            return None, None, None, None, None
         gM = None if gM is None else gM.contiguous()
         gN = gS = None
         if gNS is not None:
             gNS = gNS.contiguous()
             gN, gS = gNS[0], gNS[1]
-        return None, ops.bound2_mask_apply_bwd(Y, D_raw, None, gM, gN, gS, ctx.eps), None
+        return None, ops.bound2_mask_apply_bwd(Y, D_raw, None, gM, gN, gS, ctx.eps, *ctx.drop), None, None, None
 
 
-def bound2_mask_apply_pair_complex(Y, D_raw, eps=10e-7):
-    """(bound_cRM(bound_cRM(D_raw)), [Y (.) M ; Y - Y (.) M]) from the network's UNBOUNDED output (C_NETWORK.forward(x,
-    bound=False)); differentiable w.r.t. D_raw."""
+def bound2_mask_apply_pair_complex(Y, D_raw, eps=10e-7, drop=(0.0, 0)):
+    """(bound_cRM(bound_cRM(D)), [Y (.) M ; Y - Y (.) M]) from the network's UNBOUNDED output (C_NETWORK.forward(x,
+    bound=False)); differentiable w.r.t. D_raw.  drop = (p, seed): D = dropout(D_raw) with dcs_dropout_fwd's mask, applied
+    inside the same kernels (C_NETWORK.forward(bound=False) in training hands its last dropout over instead of running it)."""
     y = torch.view_as_real(Y.contiguous())
     d = torch.view_as_real(D_raw.contiguous())
-    M, NS = _Bound2MaskApplyPairFn.apply(y, d, eps)
+    M, NS = _Bound2MaskApplyPairFn.apply(y, d, eps, float(drop[0]), int(drop[1]))
     return torch.view_as_complex(M), torch.view_as_complex(NS)
 
 

@@ -291,7 +291,11 @@ def _complex_step_pair(self, noise_data, noisy_data, clean_data):
     # the module offers it (this build's C_NETWORK: forward(x, bound=False)); any other module gets the two-step form
     fused = getattr(self, 'supports_unbounded_forward', False)
     mask_out = self(noisy_data, bound=False) if fused else self(noisy_data)
-    apply_pair = F.bound2_mask_apply_pair_complex if fused else F.bound_mask_apply_pair_complex
+    if fused:
+        drop = self.__dict__.pop('_pending_dropout', (0.0, 0))
+        apply_pair = lambda y_, m_, e_: F.bound2_mask_apply_pair_complex(y_, m_, e_, drop)
+    else:
+        apply_pair = F.bound_mask_apply_pair_complex
     if mask_out.dim() + 1 == noisy_data.dim() and B == 1:          # the B = 1 squeeze quirk (c_network.py:224)
         mask, NS = apply_pair(noisy_data, mask_out.unsqueeze(0), eps)
         mask = mask.squeeze(0)

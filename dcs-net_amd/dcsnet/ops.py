@@ -811,7 +811,7 @@ def bound_mask_apply_pair(Y, M_in, eps=10e-7):
     return M, NS
 
 
-def bound2_mask_apply(Y, D_raw, eps=10e-7, pair=False, keep_m1=False):
+def bound2_mask_apply(Y, D_raw, eps=10e-7, pair=False, keep_m1=False, drop_p=0.0, seed=0):
     """Both bound_cRM applications + multiply + subtract over the network's RAW last-stage output (dcs_bound2_mask_apply_fwd).
     Returns (M1 or None, M, N, S) — or (M1 or None, M, NS) with the two estimates stacked when pair=True."""
     _chk(Y, 'Y')
@@ -826,17 +826,19 @@ def bound2_mask_apply(Y, D_raw, eps=10e-7, pair=False, keep_m1=False):
     else:
         N, S = torch.empty_like(Y), torch.empty_like(Y)
     check(_lib.load().dcs_bound2_mask_apply_fwd(ptr(Y), ptr(D_raw), ptr(M1), ptr(M), ptr(N), ptr(S), Y.numel() // 2, eps,
-                                                cur_stream()), 'dcs_bound2_mask_apply_fwd')
+                                                float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()),
+          'dcs_bound2_mask_apply_fwd')
     return (M1, M, NS) if pair else (M1, M, N, S)
 
 
-def bound2_mask_apply_bwd(Y, D_raw, g_M1, g_M, g_N, g_S, eps=10e-7):
+def bound2_mask_apply_bwd(Y, D_raw, g_M1, g_M, g_N, g_S, eps=10e-7, drop_p=0.0, seed=0):
     _chk(D_raw, 'D_raw')
     for n, t in (('Y', Y), ('g_M1', g_M1), ('g_M', g_M), ('g_N', g_N), ('g_S', g_S)):
         _chk(t, n)
     g = torch.empty_like(D_raw)
     check(_lib.load().dcs_bound2_mask_apply_bwd(ptr(Y), ptr(D_raw), ptr(g_M1), ptr(g_M), ptr(g_N), ptr(g_S), ptr(g),
-                                                D_raw.numel() // 2, eps, cur_stream()), 'dcs_bound2_mask_apply_bwd')
+                                                D_raw.numel() // 2, eps, float(drop_p), int(seed), ptr(SEED_STATE),
+                                                cur_stream()), 'dcs_bound2_mask_apply_bwd')
     return g
 
 

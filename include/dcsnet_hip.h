@@ -508,11 +508,15 @@ int dcs_bound_mask_apply_bwd(const float* Y, const float* M_in, const float* g_M
 /* The network's own bound_cRM (c_network.py:225) AND the step function's second bound + multiply + subtract
  * (network_functions.py:240-243: the predicted mask is bounded twice) in one pass over the RAW last-stage output D:
  * M1 = bound(D) (stored only if M1_out != NULL), M = bound(M1), N_hat = Y (.) M, S_hat = Y - N_hat.  Backward: cotangent
- * of D from any of g_M1, g_M, g_N, g_S (NULL = absent). */
+ * of D from any of g_M1, g_M, g_N, g_S (NULL = absent).  drop_p > 0: D_raw is the last conv's output BEFORE the network's
+ * final dropout (c_network.py:221-222); dcs_dropout_fwd's mask (same seed convention, float index 2i / 2i + 1) is applied
+ * on the way in and to the cotangent on the way out, so the dropout launches of the last stage disappear as well. */
 int dcs_bound2_mask_apply_fwd(const float* Y, const float* D_raw, float* M1_out, float* M_out, float* N_hat, float* S_hat,
-                              long n, float eps, dcs_stream_t stream);
+                              long n, float eps, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                              dcs_stream_t stream);
 int dcs_bound2_mask_apply_bwd(const float* Y, const float* D_raw, const float* g_M1, const float* g_M, const float* g_N,
-                              const float* g_S, float* g_D, long n, float eps, dcs_stream_t stream);
+                              const float* g_S, float* g_D, long n, float eps, float drop_p, unsigned long long seed,
+                              const unsigned long long* seed_dev, dcs_stream_t stream);
 
 /* Waveform synthesis around the inverse FFT of mag_phase_2_wave / torch.istft (network_functions.py:140-150 via
  * :213-221 and :244-247).

@@ -913,6 +913,20 @@ def test_double_bound_mask_application_in_one_kernel(dev):
         outs.append((M.detach(), NS.detach(), d.grad.detach()))
     for a, b, what in zip(outs[0], outs[1], ('M', 'NS', 'g_D')):
         assert torch.equal(torch.view_as_real(a), torch.view_as_real(b)), what
+    # the last stage's dropout handed to the same kernels: identical to running dcs_dropout_fwd first (same mask convention)
+    res = []
+    for inside in (False, True):
+        d = d0.clone().to(dev).requires_grad_(True)
+        if inside:
+            M, NS = F.bound2_mask_apply_pair_complex(Y, d, 10e-7, (0.3, 4242))
+        else:
+            dd = torch.view_as_complex(F.dropout(torch.view_as_real(d), 0.3, 4242))
+            M, NS = F.bound2_mask_apply_pair_complex(Y, dd, 10e-7)
+        ((torch.view_as_real(M) * gM).sum() + (torch.view_as_real(NS) * gNS).sum()).backward()
+        res.append((M.detach(), NS.detach(), d.grad.detach()))
+    for a, b, what in zip(res[0], res[1], ('M', 'NS', 'g_D')):
+        assert torch.equal(torch.view_as_real(a), torch.view_as_real(b)), ('dropout inside', what)
+    assert not torch.equal(torch.view_as_real(res[0][0]), torch.view_as_real(outs[0][0]))      # (the mask did something)
     M, N, S = F.bound2_mask_apply_complex(Y, d0.to(dev), 10e-7)
     assert torch.equal(torch.view_as_real(M), torch.view_as_real(outs[0][0]))
     assert torch.equal(torch.view_as_real(N), torch.view_as_real(outs[0][1][0]))
