@@ -12,45 +12,21 @@
 // per-pixel channel reductions are wavefront shuffles and every global access is a contiguous
 // 16-byte-per-lane stream.
 #include "conv_common.h"
+#include "cbn_geom.h"
 
 namespace {
 
 constexpr int kThreads = 256;
-#ifndef DCS_ATT_RED_IT
-#define DCS_ATT_RED_IT 2          // row passes per reduction workgroup: each pass is loads + cross-lane reductions IN SERIES (~1 us),
-                                  // so eight of them made every decoder block's kernels 16-20 us whatever the tensor size
-#endif
 #ifndef DCS_ATT_APP_IT
 #define DCS_ATT_APP_IT 2          // row passes per streaming workgroup
-#endif
-#ifndef DCS_ATT_SMALL_IT
-#define DCS_ATT_SMALL_IT 256      // row passes of a sample below which the short-chain grids are used
-#endif
-#ifndef DCS_ATT_MAX_CHUNKS
-#define DCS_ATT_MAX_CHUNKS 256
 #endif
 #ifndef DCS_ATT_GRID_CAP
 #define DCS_ATT_GRID_CAP 8192
 #endif
 constexpr int kMaxChunks = DCS_ATT_MAX_CHUNKS;
 
-inline bool att_geom(int C, int* G) {
-    if (C < 2 || (C & 1)) return false;
-    int g = C / 2;
-    if (g > 64 || (g & (g - 1)) != 0) return false;   // lane group must sit inside one wave
-    *G = g;
-    return true;
-}
-
-inline int ca_chunks(long HW, int G) {
-    const int rows_per_iter = kThreads / G;
-    long it = (HW + rows_per_iter - 1) / rows_per_iter;
-    // few passes only where there are few rows to begin with (the train shapes' decoder blocks); large maps keep 8 passes and
-    // 64 chunks (more chunks there cost more in slab traffic than the shorter chains return: inference 4.31 -> 4.43 ms)
-    long nb = it <= DCS_ATT_SMALL_IT ? (it + DCS_ATT_RED_IT - 1) / DCS_ATT_RED_IT : (it + 7) / 8;
-    if (it > DCS_ATT_SMALL_IT && nb > 64) nb = 64;
-    return (int)(nb < 1 ? 1 : (nb > kMaxChunks ? kMaxChunks : nb));
-}
+inline bool att_geom(int C, int* G) { return att::geom(C, G); }
+inline int ca_chunks(long HW, int G) { return att::ca_chunks(HW, G); }
 
 // part[b][chunk][C][2] (double): sum over this chunk's pixels of x[b][p][c]
 __device__ __forceinline__ void ca_pool_kernel_body(const act_t* __restrict__ x, double* __restrict__ part,
@@ -305,6 +281,30 @@ extern "C" int DCS_SYM(dcs_channel_attention_fwd)(const act_t* x, const float* w
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
+
+#ifndef DCS_ACT_BF16
+// The FC half of dcs_channel_attention_fwd alone, for callers whose producer already left the pooling slabs
+// (dcs_cbn_fwd_slabs_pool: the CBN apply kernel pools its own output): part = double[B][chunks][C][2] with
+// chunks = dcs_ca_pool_chunks(HW, C).  Activation-type independent (slabs and maps are fp64 / fp32).
+extern "C" int dcs_ca_pool_chunks(long HW, int C) {
+    int G;
+    if (HW <= 0 || !att_geom(C, &G)) return -1;
+    return ca_chunks(HW, G);
+}
+
+extern "C" int dcs_channel_attention_fc_fwd(const void* part, const float* w1, const float* w2, float* ca_out,
+                                            float* pooled_out, float* hidden_out, int B, long HW, int C, int Ch,
+                                            dcs_stream_t stream) {
+    int G;
+    if (!part || !w1 || !w2 || !ca_out || !pooled_out || !hidden_out) return DCS_ERR_BADARG;
+    if (B <= 0 || B > 65535 || HW <= 0 || !att_geom(C, &G) || Ch <= 0 || Ch > 64) return DCS_ERR_BADARG;
+    const CaFcP fp{(const double*)part, ca_chunks(HW, G), (const float2*)w1, (const float2*)w2, (float2*)ca_out,
+                   (float2*)pooled_out, (float2*)hidden_out, HW, C, Ch};
+    DCS_LAUNCH(ca_fc_kernel, dim3(B), dim3(kThreads), 0, dcs_stream(stream), fp);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+#endif
 
 extern "C" int DCS_SYM(dcs_spatial_pool_fwd)(const act_t* x, const float* ca, float* pooled, int B, long HW, int C,
                                     dcs_stream_t stream) {

@@ -347,6 +347,46 @@ __global__ __launch_bounds__(kThreads) void cbn_apply_kernel(const act_t* __rest
     }
 }
 
+// The decoder stages' CBN + CLReLU is followed at once by a channel attention whose first step is a per-sample average pool
+// of this kernel's OUTPUT (c_network.py:148-150, :219; network_functions.py:135-138): apply and pool in one pass — grid
+// (chunks, B), a workgroup covers rows of ONE sample and leaves the slab double[C][2] of its output sums that ca_fc_kernel
+// (attention.hip) reads (same layout and chunk count as ca_pool_kernel: att::ca_chunks), so that kernel's read of the
+// activation and its launch go.  The sums are taken over the values as STORED (bf16 storage: after rounding).
+__device__ __forceinline__ float stored(float v) { return DCS_ACT_IS_BF16 ? dcs_bf16_to_f32(dcs_f32_to_bf16(v)) : v; }
+
+template <int ACT>
+__global__ __launch_bounds__(kThreads) void cbn_apply_pool_kernel(const act_t* __restrict__ x, act_t* __restrict__ y,
+                                                                   const float* __restrict__ coef, double* __restrict__ part,
+                                                                   long HW, int C, int G) {
+    __shared__ double red[kThreads * 4];
+    const int t = threadIdx.x, g = t % G, r0 = t / G, rpi = kThreads / G;
+    const int b = blockIdx.y, bx = blockIdx.x, gx = gridDim.x;
+    const ActIn4<act_t> x4 = act_in4(x) + (long)b * HW * G;
+    const ActOut4<act_t> y4 = act_out4(y) + (long)b * HW * G;
+    const float* ca = coef + 12 * g;
+    const float a0 = ca[0], a1 = ca[1], a2 = ca[2], a3 = ca[3], c0 = ca[4], c1 = ca[5];
+    const float e0 = ca[6], e1 = ca[7], e2 = ca[8], e3 = ca[9], f0 = ca[10], f1 = ca[11];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (long r = (long)bx * rpi + r0; r < HW; r += (long)gx * rpi) {
+        const float4 v = x4[r * G + g];
+        float4 o;
+        o.x = act_fn<ACT>(fmaf(a0, v.x, fmaf(a1, v.y, c0)));
+        o.y = act_fn<ACT>(fmaf(a2, v.x, fmaf(a3, v.y, c1)));
+        o.z = act_fn<ACT>(fmaf(e0, v.z, fmaf(e1, v.w, f0)));
+        o.w = act_fn<ACT>(fmaf(e2, v.z, fmaf(e3, v.w, f1)));
+        y4[r * G + g] = o;
+        s0 += stored(o.x); s1 += stored(o.y); s2 += stored(o.z); s3 += stored(o.w);
+    }
+    red[t * 4 + 0] = s0; red[t * 4 + 1] = s1; red[t * 4 + 2] = s2; red[t * 4 + 3] = s3;
+    __syncthreads();
+    for (int o = t; o < G * 4; o += kThreads) {
+        const int gg = o / 4, i = o % 4;
+        double a = 0;
+        for (int r = 0; r < rpi; ++r) a += red[(r * G + gg) * 4 + i];
+        part[(((long)b * gx + bx) * C + 2 * gg) * 2 + i] = a;
+    }
+}
+
 }  // namespace
 
 #ifndef DCS_ACT_BF16
@@ -421,6 +461,38 @@ extern "C" int DCS_SYM(dcs_cbn_fwd_slabs)(const act_t* x, act_t* y, const float*
                                  unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
     return cbn_fwd_impl(x, y, weight, bias, running_mean, running_covar, stats_out, coef_out, nullptr, 0, P, C, eps, momentum,
                         3, act, drop_p, seed, seed_dev, stream, part, rows, stride, pivot);
+}
+
+// dcs_cbn_fwd_slabs (batch statistics from the producing conv) whose apply pass also leaves the per-sample pooling slabs of
+// its output for the channel attention that follows: pool_part = double[B][chunks][C][2], chunks = dcs_ca_pool_chunks(HW, C)
+// (consumer: dcs_channel_attention_fc_fwd).  x = [B][HW][C] complex; no dropout (the decoder stage's dropout follows the
+// attention).  Three launches — finalize, apply + pool, FC — where the unfused chain has four and one more read of y.
+extern "C" int DCS_SYM(dcs_cbn_fwd_slabs_pool)(const act_t* x, act_t* y, const float* weight, const float* bias,
+                                               float* running_mean, float* running_covar, float* stats_out, float* coef_out,
+                                               const float* part, int rows, int stride, const float* pivot, void* pool_part,
+                                               long pool_bytes, int B, long HW, int C, float eps, float momentum, int act,
+                                               dcs_stream_t stream) {
+    int G;
+    if (!x || !y || !stats_out || !coef_out || !part || !pivot || !pool_part || B <= 0 || B > 65535 || HW <= 0 ||
+        !att::geom(C, &G) || rows < 1 || stride < rows)
+        return DCS_ERR_BADARG;
+    if ((weight == nullptr) != (bias == nullptr)) return DCS_ERR_BADARG;
+    if (act != DCS_ACT_NONE && act != DCS_ACT_RELU && act != DCS_ACT_LRELU) return DCS_ERR_BADARG;
+    const int nch = att::ca_chunks(HW, G);
+    if (pool_bytes < (long)B * nch * C * 2 * (long)sizeof(double)) return DCS_ERR_WORKSPACE;
+    hipStream_t s = dcs_stream(stream);
+    const long P = (long)B * HW;
+    DCS_LAUNCH((cbn_finalize_kernel<float, float>), dim3(C), dim3(256), 0, s, pivot, part, rows, stride, weight, bias,
+               running_mean, running_covar, stats_out, coef_out, P, C, eps, momentum, 1);
+    DCS_CHECK_LAUNCH();
+#define DCS_CBN_AP(A) DCS_LAUNCH((cbn_apply_pool_kernel<A>), dim3(nch, B), dim3(kThreads), 0, s, x, y, (const float*)coef_out, \
+                                 (double*)pool_part, HW, C, G)
+    if (act == DCS_ACT_RELU) DCS_CBN_AP(DCS_ACT_RELU);
+    else if (act == DCS_ACT_LRELU) DCS_CBN_AP(DCS_ACT_LRELU);
+    else DCS_CBN_AP(DCS_ACT_NONE);
+#undef DCS_CBN_AP
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
 }
 
 #ifndef DCS_ACT_BF16

@@ -48,3 +48,35 @@ inline int stream_grid(long P, int C, const Geom& g) {
 }
 
 }  // namespace cbn
+
+// Channel-attention pooling geometry (attention.hip: ca_pool_kernel, ca_fc_kernel; cbn.hip: the CBN apply kernel that pools
+// its own output): per sample, `chunks` workgroups of 256 threads each sum their pixels' channel values into one slab
+// double[C][2]; G = C / 2 lanes own a pixel.
+#ifndef DCS_ATT_RED_IT
+#define DCS_ATT_RED_IT 2          // row passes per reduction workgroup: each pass is loads + cross-lane reductions IN SERIES (~1 us),
+                                  // so eight of them made every decoder block's kernels 16-20 us whatever the tensor size
+#endif
+#ifndef DCS_ATT_SMALL_IT
+#define DCS_ATT_SMALL_IT 256      // row passes of a sample below which the short-chain grids are used
+#endif
+#ifndef DCS_ATT_MAX_CHUNKS
+#define DCS_ATT_MAX_CHUNKS 256
+#endif
+namespace att {
+inline bool geom(int C, int* G) {
+    if (C < 2 || (C & 1)) return false;
+    const int g = C / 2;
+    if (g > 64 || (g & (g - 1)) != 0) return false;   // lane group must sit inside one wave
+    *G = g;
+    return true;
+}
+inline int ca_chunks(long HW, int G) {
+    const int rows_per_iter = 256 / G;
+    const long it = (HW + rows_per_iter - 1) / rows_per_iter;
+    // few passes only where there are few rows to begin with (the train shapes' decoder blocks); large maps keep 8 passes and
+    // 64 chunks (more chunks there cost more in slab traffic than the shorter chains return: inference 4.31 -> 4.43 ms)
+    long nb = it <= DCS_ATT_SMALL_IT ? (it + DCS_ATT_RED_IT - 1) / DCS_ATT_RED_IT : (it + 7) / 8;
+    if (it > DCS_ATT_SMALL_IT && nb > 64) nb = 64;
+    return (int)(nb < 1 ? 1 : (nb > DCS_ATT_MAX_CHUNKS ? DCS_ATT_MAX_CHUNKS : nb));
+}
+}  // namespace att

@@ -55,6 +55,9 @@ SIGNATURES = {
     'dcs_cbn_workspace_bytes': (_L, [_L, _I]),
     'dcs_cbn_fwd': (_I, [_P] * 9 + [_L, _L, _I, _F, _F, _I, _I, _F, _U64, _P, _P]),
     'dcs_cbn_fwd_slabs': (_I, [_P] * 9 + [_I, _I, _P, _L, _I, _F, _F, _I, _F, _U64, _P, _P]),
+    'dcs_ca_pool_chunks': (_I, [_L, _I]),
+    'dcs_cbn_fwd_slabs_pool': (_I, [_P] * 9 + [_I, _I, _P, _P, _L, _I, _L, _I, _F, _F, _I, _P]),
+    'dcs_channel_attention_fc_fwd': (_I, [_P] * 6 + [_I, _L, _I, _I, _P]),
     'dcs_cbn_bwd_workspace_bytes': (_L, [_L, _I]),
     'dcs_cbn_bwd': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P]),
     'dcs_cbn_bwd_add': (_I, [_P] * 9 + [_L, _L, _I, _I, _I, _F, _U64, _P, _P, _F, _L, _P, _P]),
@@ -139,7 +142,7 @@ class DcsHipError(RuntimeError):
 
 # bf16-activation forms (include/dcsnet_hip.h, last section): the same argument lists as the fp32 entry points they mirror
 for _n in ('dcs_cconv2d_fwd', 'dcs_cconv2d_fwd_affine', 'dcs_cconv2d_fwd_stats', 'dcs_cconv2d_bwd_data', 'dcs_cconv2d_bwd_weight',
-           'dcs_cconv_up2_single_fwd', 'dcs_tapsum_bwd', 'dcs_cbn_fwd', 'dcs_cbn_fwd_slabs', 'dcs_cbn_bwd', 'dcs_cbn_bwd_add',
+           'dcs_cconv_up2_single_fwd', 'dcs_tapsum_bwd', 'dcs_cbn_fwd', 'dcs_cbn_fwd_slabs', 'dcs_cbn_fwd_slabs_pool', 'dcs_cbn_bwd', 'dcs_cbn_bwd_add',
            'dcs_channel_attention_fwd', 'dcs_spatial_pool_fwd', 'dcs_attention_apply_fwd', 'dcs_attention_fwd_batched',
            'dcs_attention_bwd_sa', 'dcs_attention_bwd_x', 'dcs_attention_bwd_batched'):
     SIGNATURES[_n + '_h'] = SIGNATURES[_n]

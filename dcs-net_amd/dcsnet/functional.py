@@ -303,12 +303,17 @@ class _CbnAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
                 fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i, ksize, drop_p, seed, stat=None):
-        a, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, 0.0, 0,
-                                 stat=stat)
         w1, _ = packed_weight(fc0_r, fc0_i, None, None, False)
         w2, _ = packed_weight(fc2_r, fc2_i, None, None, False)
         wsa, zero_bias = packed_weight(c1_r, c1_i, None, None, False)
-        ca, pooled, hidden = ops.channel_attention(a, w1, w2)
+        if stat is not None and use_batch_stats and weight is not None and ops.FUSE_APPLY_POOL:
+            # statistics from the conv, apply + channel pool in one pass, FC: 3 launches (5 for the chain below)
+            a, stats, coef, ca, pooled, hidden = ops.cbn_channel_attention(x, weight, bias, running_mean, running_covar, eps,
+                                                                           momentum, act, stat, w1, w2)
+        else:
+            a, stats, coef = ops.cbn(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act, 0.0, 0,
+                                     stat=stat)
+            ca, pooled, hidden = ops.channel_attention(a, w1, w2)
         sp = ops.spatial_pool(a, ca)
         sa = ops.cconv2d(sp, None, wsa, zero_bias, (ksize, ksize), (1, 1), (ksize // 2, ksize // 2), (1, 1), ACT_SIGMOID)
         out = ops.attention_apply(a, ca, sa, drop_p, seed)

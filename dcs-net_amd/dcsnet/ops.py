@@ -292,6 +292,7 @@ def cconv2d_stats(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1))
 
 
 import os as _os
+FUSE_APPLY_POOL = _os.environ.get('DCS_FUSE_APPLY_POOL', '1') != '0'       # 0 (A/B runs): CBN apply and channel pool as separate launches
 STATS_EPILOGUE = _os.environ.get('DCS_STATS_EPILOGUE', '1') != '0'       # 0 (A/B runs): every training-mode CBN makes its own statistics pass
 
 
@@ -506,6 +507,37 @@ def cbn(x, weight, bias, running_mean, running_covar, eps=1e-5, momentum=0.1, us
                           -1.0 if momentum is None else momentum, mode, act,
                           float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()), 'dcs_cbn_fwd')
     return y, stats, coef
+
+
+def cbn_channel_attention(x, weight, bias, running_mean, running_covar, eps, momentum, act, stat, w1, w2):
+    """A decoder stage's CBN (batch statistics from the producing conv: stat of cconv2d_stats) + activation whose apply pass
+    also pools its output for the channel attention that follows, and that attention's FC (dcs_cbn_fwd_slabs_pool +
+    dcs_channel_attention_fc_fwd: three launches).  Returns (a, stats, coef, ca, pooled, hidden)."""
+    _chk(x, 'x', 5, act=True)
+    for n, t in (('weight', weight), ('bias', bias), ('running_mean', running_mean), ('running_covar', running_covar),
+                 ('w1', w1), ('w2', w2)):
+        _chk(t, n)
+    part, rows, pivot = stat
+    B, H, W, C, _ = x.shape
+    HW = H * W
+    Ch = w1.shape[-2]
+    lib = _lib.load()
+    nch = lib.dcs_ca_pool_chunks(HW, C)
+    if nch < 1 or part.shape[2] < rows or tuple(part.shape[:2]) != (C, 5) or tuple(pivot.shape) != (C, 2):
+        raise _lib.DcsHipError(f'cbn_channel_attention: unsupported C={C} or mismatching statistics slabs {tuple(part.shape)}')
+    dev = x.device
+    a = torch.empty_like(x)
+    new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    stats, coef, ca, pooled, hidden = new(C, 8), new(C, 6), new(B, C, 2), new(B, C, 2), new(B, Ch, 2)
+    nbytes = B * nch * C * 2 * 8
+    ws = _workspace(nbytes, dev)
+    check(_sym('dcs_cbn_fwd_slabs_pool', x, a)(ptr(x), ptr(a), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_covar),
+                                              ptr(stats), ptr(coef), ptr(part), int(rows), int(part.shape[2]), ptr(pivot),
+                                              ptr(ws), ws.numel(), B, HW, C, eps, -1.0 if momentum is None else momentum, act,
+                                              cur_stream()), 'dcs_cbn_fwd_slabs_pool')
+    check(lib.dcs_channel_attention_fc_fwd(ptr(ws), ptr(w1), ptr(w2), ptr(ca), ptr(pooled), ptr(hidden), B, HW, C, Ch,
+                                           cur_stream()), 'dcs_channel_attention_fc_fwd')
+    return a, stats, coef, ca, pooled, hidden
 
 
 def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, seed=0, affine=True, outs=None,

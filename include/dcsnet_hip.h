@@ -267,6 +267,19 @@ int  dcs_cbn_fwd_slabs(const float* x, float* y, const float* weight, const floa
                        long P, int C, float eps, float momentum, int act,
                        float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
 
+/* A decoder stage's tail (c_network.py:148-150, :219: ComplexBatchNorm2d + CLReLU, then a channel attention that starts with a
+ * per-sample average pool of that output): dcs_cbn_fwd_slabs whose apply pass also leaves the pooling slabs of its OUTPUT,
+ * pool_part = double[B][chunks][C][2] with chunks = dcs_ca_pool_chunks(HW, C), and the attention's FC half on those slabs
+ * (dcs_channel_attention_fwd = pool + FC): three launches for CBN + channel attention instead of four, one read of the
+ * activation less.  x = complex[B][HW][C]; no dropout. */
+int dcs_ca_pool_chunks(long HW, int C);
+int dcs_cbn_fwd_slabs_pool(const float* x, float* y, const float* weight, const float* bias,
+                           float* running_mean, float* running_covar, float* stats_out, float* coef_out,
+                           const float* part, int rows, int stride, const float* pivot, void* pool_part, long pool_bytes,
+                           int B, long HW, int C, float eps, float momentum, int act, dcs_stream_t stream);
+int dcs_channel_attention_fc_fwd(const void* pool_part, const float* w1, const float* w2, float* ca_out, float* pooled_out,
+                                 float* hidden_out, int B, long HW, int C, int Ch, dcs_stream_t stream);
+
 /* Backward of dcs_cbn_fwd (closed form of what autograd derives through complexPyTorch's CBN,
  * the activation and the dropout).  g_out: gradient w.r.t. y; g_x: gradient w.r.t. x (may alias
  * g_out); stats/coef: as written by the forward call; g_weight float[C][3], g_bias float[C][2]
@@ -743,6 +756,10 @@ int dcs_cbn_fwd_slabs_h(const dcs_bf16_t* x, dcs_bf16_t* y, const float* weight,
                         const float* part, int rows, int stride, const float* pivot,
                         long P, int C, float eps, float momentum, int act,
                         float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
+int dcs_cbn_fwd_slabs_pool_h(const dcs_bf16_t* x, dcs_bf16_t* y, const float* weight, const float* bias,
+                             float* running_mean, float* running_covar, float* stats_out, float* coef_out,
+                             const float* part, int rows, int stride, const float* pivot, void* pool_part, long pool_bytes,
+                             int B, long HW, int C, float eps, float momentum, int act, dcs_stream_t stream);
 int dcs_cbn_bwd_h(const dcs_bf16_t* x, const dcs_bf16_t* g_out, dcs_bf16_t* g_x, const float* weight,
                   const float* stats, const float* coef, float* g_weight, float* g_bias,
                   void* workspace, long workspace_bytes, long P, int C, int use_batch_stats, int act,

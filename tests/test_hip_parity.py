@@ -931,3 +931,33 @@ def test_double_bound_mask_application_in_one_kernel(dev):
     assert torch.equal(torch.view_as_real(M), torch.view_as_real(outs[0][0]))
     assert torch.equal(torch.view_as_real(N), torch.view_as_real(outs[0][1][0]))
     assert torch.equal(torch.view_as_real(S), torch.view_as_real(outs[0][1][1]))
+
+
+@pytest.mark.parametrize('C,H,W', [(8, 24, 20), (64, 8, 16), (128, 4, 32)])
+def test_cbn_apply_that_pools_for_the_channel_attention(dev, C, H, W):
+    """dcs_cbn_fwd_slabs_pool + dcs_channel_attention_fc_fwd (a decoder stage's CBN + CLReLU + channel attention in three
+    launches) against dcs_cbn_fwd_slabs + dcs_channel_attention_fwd: same activation bit for bit, same pooled means / hidden /
+    ca (the sums are taken in the same chunk geometry and order)."""
+    from dcsnet import ops
+    B, Ch = 3, max(C // 16, 1)
+    g = torch.Generator().manual_seed(C)
+    x1 = torch.randn(B, H // 2, W, 2 * C if False else C, 2, generator=g).to(dev)
+    w_r, w_i = (torch.randn(C, C, 3, 3, generator=g) * 0.1).to(dev), (torch.randn(C, C, 3, 3, generator=g) * 0.1).to(dev)
+    b_r, b_i = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    wp, bias = ops.pack_conv_weight(w_r, w_i, b_r, b_i, True, (2, 1))
+    y, stat = ops.cconv2d_stats(x1, None, wp, bias, (3, 3), (1, 1), (1, 1), (2, 1))
+    assert stat is not None
+    bnw = (torch.randn(C, 3, generator=g) * 0.3 + torch.tensor([1.2, 1.1, 0.1])).to(dev)
+    bnb = torch.randn(C, 2, generator=g).to(dev)
+    rnd = lambda *s: (torch.randn(*s, generator=g) * 0.2).to(dev)
+    w1, _ = ops.pack_conv_weight(rnd(Ch, C, 1, 1), rnd(Ch, C, 1, 1))
+    w2, _ = ops.pack_conv_weight(rnd(C, Ch, 1, 1), rnd(C, Ch, 1, 1))
+    rm0, rc0 = torch.zeros(C, 2, device=dev), torch.ones(C, 3, device=dev)
+    a0, stats0, coef0 = ops.cbn(y, bnw, bnb, rm0, rc0, 1e-5, 0.1, True, ops.ACT_LRELU, stat=stat)
+    ca0, pooled0, hidden0 = ops.channel_attention(a0, w1, w2)
+    rm1, rc1 = torch.zeros(C, 2, device=dev), torch.ones(C, 3, device=dev)
+    a1, stats1, coef1, ca1, pooled1, hidden1 = ops.cbn_channel_attention(y, bnw, bnb, rm1, rc1, 1e-5, 0.1, ops.ACT_LRELU, stat,
+                                                                         w1, w2)
+    for p_, q_, n in ((a1, a0, 'a'), (stats1, stats0, 'stats'), (coef1, coef0, 'coef'), (rm1, rm0, 'running mean'),
+                      (rc1, rc0, 'running covar'), (pooled1, pooled0, 'pooled'), (hidden1, hidden0, 'hidden'), (ca1, ca0, 'ca')):
+        assert torch.equal(p_, q_), n
