@@ -91,6 +91,11 @@ inline int mfma_precision(int Cin, int taps = 0) {
     const int p = dcs_conv_precision();
     return (p == 2 && (Cin % 16) != 0 && !(Cin == 8 && taps == 49)) ? 0 : p;      // (8 channels: only the 7x7 row form)
 }
+// ... of the 16-column kernel (Cout = 8): its bf16 forms (1: bf16 operands, 2: the emulation) need 16-channel k-groups
+inline int mfma_precision16(int Cin) {
+    const int p = dcs_conv_precision();
+    return (Cin % 16) == 0 ? p : 0;
+}
 inline long direct_floats(int Cout, int Cin, int taps) { return (long)taps * Cin * Cout * 2; }
 inline long mfma_floats(int Cout, int Cin, int taps) {      // N = 2*Cout padded to whole 32-column tiles
     // (precision mode 2 keeps three bf16 planes, each half an fp32 panel: 1.5 x)

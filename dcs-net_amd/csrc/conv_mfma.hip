@@ -535,12 +535,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // channels; the lane's 16-byte LDS read is its 8 consecutive bf16 reals of one of the three planes, the B panel is
 // [tap][kg16][plane][64 lanes][8 bf16] (packjob::MFMA, flag 17).  Six MFMAs of 16 cycles per tile and k-group instead
 // of sixteen of 32.
+// PR = 1: bf16 operands (dcs_set_conv_precision(1); activations stored in bf16 need no conversion at all): the same kernel with
+// ONE plane — one MFMA per tile and k-group, B panel [tap][kg16][64 lanes][8 bf16] (packjob::MFMA, flag 18).
 template <int CH, int PR = 0>
 __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     constexpr int NP = PR == 2 ? 3 : 1;
-    constexpr int U8 = PR == 2 ? CH / 16 : CH / 8, PIX = PR == 2 ? 3 * CH + 4 : 2 * CH + 4, Q = CH / 2;
-    static_assert(PR == 0 || (PR == 2 && CH % 16 == 0), "emulated form: 16-channel k-groups");
+    constexpr int U8 = PR != 0 ? CH / 16 : CH / 8, PIX = PR != 0 ? NP * CH + 4 : 2 * CH + 4, Q = CH / 2;
+    static_assert(PR == 0 || CH % 16 == 0, "bf16 forms: 16-channel k-groups");
+    static_assert(!DCS_ACT_IS_BF16 || PR != 2, "bf16 activations: native or bf16-operand form");
     const conv::Args& a = m.c;
     const conv::Cls& k = m.cls[blockIdx.z];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
         pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + g4 * 4;
     }
     const float* bbase = m.bm + k.bm_off + (long)lane * 4;
-    const long b_tap_stride = PR == 2 ? (long)(Cin / 16) * 3 * 256 : (long)(Cin / 8) * 256, b_kg_stride = PR == 2 ? 3 * 256 : 256;
+    const long b_tap_stride = PR != 0 ? (long)(Cin / 16) * NP * 256 : (long)(Cin / 8) * 256, b_kg_stride = PR != 0 ? NP * 256 : 256;
 
     f32x4v acc[2];
     acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -610,14 +613,18 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
                 if (spv[u] >= 0) {
                     const int c = ch * CH + 2 * (idx % Q);
                     const act2_t* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
-                    v[u] = dcs_ld4(reinterpret_cast<const act_t*>(src));       // (bf16 activations: widened, the kernel computes in fp32)
+                    v[u] = dcs_ld4(reinterpret_cast<const act_t*>(src));       // (bf16 activations: widened; PR = 1 narrows exactly again)
                 }
             }
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int idx = base + u * 256;
                 if (idx >= nslots) continue;
-                if (PR == 2) {                                         // 2 complex -> 3 planes of 4 bf16 (exact split)
+                if (PR == 1) {                                         // 2 complex -> 4 bf16 (round to nearest even)
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    const bf16x4 h = {(__bf16)v[u].x, (__bf16)v[u].y, (__bf16)v[u].z, (__bf16)v[u].w};
+                    *reinterpret_cast<bf16x4*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = h;
+                } else if (PR == 2) {                                  // 2 complex -> 3 planes of 4 bf16 (exact split)
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     float4 r = v[u];
                     float* dst = patch + (idx / Q) * PIX + (idx % Q) * 2;
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
             const int tapoff = ((tap / k.kw) * cols + (tap % k.kw)) * PIX;
 #pragma unroll
             for (int g = 0; g < U8; ++g) {
-                if (PR == 2) {
+                if (PR != 0) {
                     float4 af[2][NP];
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
                             af[i][pl] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff + g * 16 + pl * CH);
                     constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
 #pragma unroll
-                    for (int e = 0; e < 6; ++e)
+                    for (int e = (PR == 2 ? 0 : 5); e < 6; ++e)                                // (PR = 1: the a0 b0 term alone)
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
                             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -855,7 +862,7 @@ int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
 template <int CH, int PR = 0>
 int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    const size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH : 2 * CH) + 4 + 1) * sizeof(float);   // patch + source-pixel table
+    const size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH : PR == 1 ? CH : 2 * CH) + 4 + 1) * sizeof(float);   // patch + source-pixel table
     auto fn = cconv_mfma16_kernel<CH, PR>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, 1, m.ncls);
@@ -957,8 +964,8 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
     if (p->pipe) {}
-    else if (2 * a.Cout == 16 && pr == 2 && !(Cin % 32 == 0 && npix * pixw(32) * 4 <= cap32c)) {
-        if (npix * pixw(16) * 4 > 150 * 1024) return false;            // the emulated 16-column kernel has no 8-channel form
+    else if (2 * a.Cout == 16 && conv::mfma_precision16(Cin) != 0 && !(Cin % 32 == 0 && npix * pixw(32) * 4 <= cap32c)) {
+        if (npix * pixw(16) * 4 > 150 * 1024) return false;            // the bf16 forms of the 16-column kernel have no 8-channel form
         p->CH = 16;
     }
     else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= cap32c) p->CH = 32;
@@ -983,9 +990,12 @@ int dcs_conv_mfma_pack(const float* wp_direct, float* bm, int Cout, int Cin, int
     packjob::Job j{};
     j.kind = packjob::MFMA;
     j.Cout = Cout; j.Cin = Cin; j.kh = taps;
-    if (2 * Cout == 16 && conv::mfma_precision(Cin) == 2) {              // 16 columns, three bf16 planes: [tap][kg16][plane][64 lanes][8 bf16]
+    if (2 * Cout == 16 && conv::mfma_precision16(Cin) == 2) {            // 16 columns, three bf16 planes: [tap][kg16][plane][64 lanes][8 bf16]
         j.flag = 17;
         j.total = (long)taps * (Cin / 16) * 64;                          // (a thread writes its element of all three planes)
+    } else if (2 * Cout == 16 && conv::mfma_precision16(Cin) == 1) {     // 16 columns, bf16 operands: one plane
+        j.flag = 18;
+        j.total = (long)taps * (Cin / 16) * 64;
     } else if (2 * Cout == 16) {                                         // 16-column layout of cconv_mfma16_kernel (half the region)
         j.flag = 16;
         j.total = (long)taps * (Cin / 8) * 64;
@@ -1081,9 +1091,17 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
                 a.B, a.Hin, a.Win, a.C1, a.C2, a.Hout, a.Wout, a.Cout, a.kh, a.kw, ncls, p.cand, p.TH, p.TW, p.CH, m.ksplit, p.S,
                 m.cps, g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0), a.coef != nullptr);
     if (m.N == 16 && p.cand == 3 && !g_force_wide_panel) {    // 128 pixels x 16 columns, v_mfma_f32_16x16x4_f32
-        if (conv::mfma_precision(Cin) == 2) {                  // (make_plan chose a 16- or 32-channel chunk)
+        const int pr16 = conv::mfma_precision16(Cin);
+#if !DCS_ACT_IS_BF16
+        if (pr16 == 2) {                                       // (make_plan chose a 16- or 32-channel chunk)
             if (p.CH == 32) return launch16_ch<32, 2>(m, npix, stream);
             if (p.CH == 16) return launch16_ch<16, 2>(m, npix, stream);
+            return DCS_ERR_BADARG;
+        }
+#endif
+        if (pr16 == 1) {
+            if (p.CH == 32) return launch16_ch<32, 1>(m, npix, stream);
+            if (p.CH == 16) return launch16_ch<16, 1>(m, npix, stream);
             return DCS_ERR_BADARG;
         }
         switch (p.CH) {

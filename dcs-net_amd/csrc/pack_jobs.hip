@@ -105,12 +105,12 @@ __device__ __forceinline__ void run_mfma16_split(const Job& jb, int i) {
         const float2 w = wp[(tap * Cin + 16 * kg16 + 4 * kb + q) * Cout + co];
         e[2 * q] = im ? w.y : w.x; e[2 * q + 1] = im ? w.x : -w.y;
     }
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    const int np = jb.flag == 18 ? 1 : 3;          // flag 18: ONE plane (bf16 operands, dcs_set_conv_precision(1)): bm[tap][kg16][lane][8]
+    for (int pl = 0; pl < np; ++pl) {
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) { o[k] = (__bf16)e[k]; e[k] -= (float)o[k]; }
-        bm[(r * 3 + pl) * 64 + (i & 63)] = o;
+        bm[(r * np + pl) * 64 + (i & 63)] = o;
     }
 }
 
@@ -150,7 +150,7 @@ __device__ __forceinline__ void run_mfma_bf16(const Job& jb, int i) {
 
 __device__ __forceinline__ void run_mfma(const Job& jb, int i) {
     if (jb.flag == 16) { run_mfma16(jb, i); return; }
-    if (jb.flag == 17) { run_mfma16_split(jb, i); return; }
+    if (jb.flag == 17 || jb.flag == 18) { run_mfma16_split(jb, i); return; }
     if (jb.flag == 2 || jb.flag == 3) { run_mfma_bf16(jb, i); return; }
     const float2* wp = (const float2*)jb.src0; float4* bm = (float4*)jb.dst0;
     const int Cout = jb.Cout, Cin = jb.Cin;
