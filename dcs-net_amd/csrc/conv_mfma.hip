@@ -65,17 +65,26 @@ long long* g_fdbg = nullptr;
 // TPI > 1 (shallow layers, CH = 8: only U = 2 k-groups per tap): the tap loop advances a whole kernel ROW of TPI = kw taps
 // per iteration — 8 MFMAs per iteration cannot carry the loop's scalar address arithmetic, its waitcnt drain and the
 // B-set copy (enc1 forward: 7 x 2 = 14 k-groups = 56 MFMAs per iteration instead of 8).
-template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI = 1, bool STAT = false>
+// WK > 1 (layers with few output pixels and a long K — enc5 / enc6 / dec0, the latent fc and their data gradients at B = 32):
+// WK waves share ONE output tile and split the K axis between them — wave wk takes the k-groups [wk U / WK, (wk + 1) U / WK)
+// of every chunk and tap — and add their accumulators through LDS in the epilogue (fixed order).  The global split-K these
+// layers ran before wrote fp32 slabs to HBM and needed a reduce launch each; here the tile is 32 pixels, so there are
+// enough workgroups without slicing, the partial sums never leave the CU and the launch goes.
+template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI = 1, bool STAT = false, int WK = 1>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     constexpr bool BF = PR != 0;
     constexpr int NP = PR == 2 ? 3 : 1;                                // bf16 planes per operand
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
-    constexpr int U = BF ? CH / 8 : CH / 4, VU = U * TPI, PIX = BF ? NP * CH + 4 : 2 * CH + 4, Q = CH / 2;
+    constexpr int UALL = BF ? CH / 8 : CH / 4;                         // k-groups per tap and chunk
+    constexpr int U = UALL / WK;                                       // ... of ONE wave
+    static_assert(UALL % WK == 0 && (WK == 1 || TPI == 1), "K split over waves: whole k-groups per wave, tap-at-a-time loop");
+    constexpr int VU = U * TPI, PIX = BF ? NP * CH + 4 : 2 * CH + 4, Q = CH / 2;
     const conv::Args& a = m.c;
     const conv::Cls& k = m.cls[blockIdx.z];
-    // pixels per workgroup = (4 / WAVES_N) * WM * 32 = TH * TW
+    // pixels per workgroup = (4 / (WAVES_N WK)) * WM * 32 = TH * TW
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int wk = wave % WK, wq = wave / WK;
+    const int wm = wq / WAVES_N, wn = wq % WAVES_N;
     const int kk = lane >> 5, li = lane & 31;
 
     const long long d_start = FDIAG_NOW();
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int pi = (wm * WM + i) * 32 + li;
-        pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + kk * 4;
+        pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + kk * 4 + wk * U * 8;   // (+ this wave's k-groups)
     }
     const float* bbase = m.bm + k.bm_off + ((long)nt0 * 64 + lane) * 4;
     const long b_tap_stride = (long)(BF ? m.KG / 2 : m.KG) * m.NT * 256, b_kg_stride = (long)m.NT * 256;
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         if (tp >= ntaps) { tp -= ntaps; ++c; }
         c = c < n_chunks ? c : n_chunks - 1;
         if (PR == 2 && TPI > 1) {
-            unsigned so = (unsigned)((tp * b_tap_stride + (long)(c * U + g) * b_kg_stride) * 4);
+            unsigned so = (unsigned)((tp * b_tap_stride + (long)(c * UALL + wk * U + g) * b_kg_stride) * 4);
             asm volatile("" : "+s"(so));                               // keep the offset where it is used (no hoisting of 49 rows)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     dst[pl][j] = *reinterpret_cast<const float4*>(ubase + so + (unsigned)((pl * b_plane_stride + j * 256) * 4) + lane_off);
             return;
         }
-        const float* bp = bbase + tp * b_tap_stride + (long)(c * U + g) * b_kg_stride;
+        const float* bp = bbase + tp * b_tap_stride + (long)(c * UALL + wk * U + g) * b_kg_stride;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
@@ -382,10 +391,23 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) tsm[((r & 3) + 8 * (r >> 2) + 4 * kk) * TP + li] = acc[i][j][r];
             // (a wave's LDS operations complete in order: no barrier between its own writes and reads)
+            if (WK > 1) __syncthreads();                               // K split: the tile's other K shares are in their waves' tiles
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
+                if (WK > 1 && qq / (4 / WK) != wk) continue;          // each of the WK waves finishes 32 / WK rows of the tile
                 const int row = r8 + 8 * qq;
-                float4 v = *reinterpret_cast<const float4*>(tsm + row * TP + 4 * c4);
+                float4 v;
+                if (WK > 1) {
+                    const float* t0 = patch + (wq * WK) * 32 * TP + row * TP + 4 * c4;
+                    v = *reinterpret_cast<const float4*>(t0);
+#pragma unroll
+                    for (int kq = 1; kq < WK; ++kq) {
+                        const float4 u2 = *reinterpret_cast<const float4*>(t0 + kq * 32 * TP);
+                        v.x += u2.x; v.y += u2.y; v.z += u2.z; v.w += u2.w;
+                    }
+                } else {
+                    v = *reinterpret_cast<const float4*>(tsm + row * TP + 4 * c4);
+                }
                 const int pi = (wm * WM + i) * 32 + row;
                 const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
                 if (STAT && n0 < m.N && oy < k.Hc && ox < k.Wc) {      // moments of the UN-biased value (pivot = bias)
@@ -484,6 +506,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     else dcs_st4(yb + off, v);
                 }
             }
+            if (WK > 1) __syncthreads();                               // (the tiles are rewritten by the next (i, j))
         }
     }
     if (STAT) {
@@ -513,7 +536,8 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
             const int ct = o / 80, e = o % 80, wn_ = ct / WN, j_ = ct % WN;
             float sum = 0.f;
 #pragma unroll
-            for (int wm_ = 0; wm_ < 4 / WAVES_N; ++wm_) sum += comb[((wm_ * WAVES_N + wn_) * WN + j_) * 80 + e];
+            for (int w_ = 0; w_ < 4; ++w_)                              // every wave whose column tiles are these (any wm, any wk)
+                if ((w_ / WK) % WAVES_N == wn_) sum += comb[(w_ * WN + j_) * 80 + e];
             const int c = ((stat_nt0 + ct) * 32 + 4 * (e & 7)) / 2 + e / 40;
             if (c < a.Cout) stat_row[(long)(c * 5 + ((e % 40) >> 3)) * a.stat_stride] = sum;
         }
@@ -802,10 +826,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 
 // (the B-panel re-layout kernel lives in pack_jobs.hip: packjob::MFMA)
 
-struct Plan { int cand, TH, TW, CH, S, cps; long blocks; bool pipe; };
+struct Plan { int cand, TH, TW, CH, S, cps; long blocks; bool pipe; int wk; };
 thread_local bool g_force_wide_panel = false;
 
-template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI, bool STAT = false>
+template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI, bool STAT = false, int WK = 1>
 int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
     size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH + 4 : PR == 1 ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
@@ -814,7 +838,7 @@ int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
 #ifdef DCS_FWD_ONE_PER_CU
     if (lds < 84 * 1024) lds = 84 * 1024;                                            // experiment: one workgroup per CU
 #endif
-    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, PR, TPI, STAT>;
+    auto fn = cconv_mfma_kernel<WAVES_N, WM, WN, CH, PR, TPI, STAT, WK>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     dim3 grid(a.tiles_w * a.tiles_h * a.B, (m.NT / (WAVES_N * WN)) * m.ksplit, m.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
@@ -823,9 +847,17 @@ int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     return DCS_OK;
 }
 
-template <int WAVES_N, int WM, int WN, int CH, int PR>
+template <int WAVES_N, int WM, int WN, int CH, int PR, int WK = 1>
 int launch_bf(MArgs& m, long npix, hipStream_t stream) {
     constexpr bool BF = PR != 0;
+    if constexpr (WK > 1) {                                            // K split over waves: tap-at-a-time loop only
+        if constexpr (((BF ? CH / 8 : CH / 4) % WK) != 0) return DCS_ERR_BADARG;
+        else {
+            const bool stat_ = m.c.stat != nullptr && m.ksplit <= 1;
+            return stat_ ? launch_tpi<WAVES_N, WM, WN, CH, PR, 1, true, WK>(m, npix, stream)
+                         : launch_tpi<WAVES_N, WM, WN, CH, PR, 1, false, WK>(m, npix, stream);
+        }
+    }
     // whole kernel rows per tap-loop iteration for the shallow layers (one class, 7-wide kernel, 128 x 32 tile): native fp32,
     // and the emulated form of the 7 x 7 layer (fully unrolled over its 7 rows)
     constexpr bool ROWS = (PR == 0 || PR == 2) && CH == 8 && WM == 1 && WN == 1;
@@ -836,26 +868,32 @@ int launch_bf(MArgs& m, long npix, hipStream_t stream) {
     return stat ? launch_tpi<WAVES_N, WM, WN, CH, PR, 1, true>(m, npix, stream) : launch_tpi<WAVES_N, WM, WN, CH, PR, 1>(m, npix, stream);
 }
 
-template <int WAVES_N, int WM, int WN, int CH>
+template <int WAVES_N, int WM, int WN, int CH, int WK = 1>
 int launch_ch(MArgs& m, long npix, hipStream_t stream) {
     // (a caller-packed wide panel — the real-valued convs of DR-Net — is always in the fp32 fragment order)
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(m.c.C1 + m.c.C2, m.ncls == 1 ? m.cls[0].kh * m.cls[0].kw : 0);
 #if DCS_ACT_IS_BF16
     if (pr != 1) return DCS_ERR_BADARG;
-    return launch_bf<WAVES_N, WM, WN, CH, 1>(m, npix, stream);
+    return launch_bf<WAVES_N, WM, WN, CH, 1, WK>(m, npix, stream);
 #else
-    if (pr == 2) return launch_bf<WAVES_N, WM, WN, CH, 2>(m, npix, stream);
-    if (pr == 1) return launch_bf<WAVES_N, WM, WN, CH, 1>(m, npix, stream);
-    return launch_bf<WAVES_N, WM, WN, CH, 0>(m, npix, stream);
+    if (pr == 2) return launch_bf<WAVES_N, WM, WN, CH, 2, WK>(m, npix, stream);
+    if (pr == 1) return launch_bf<WAVES_N, WM, WN, CH, 1, WK>(m, npix, stream);
+    return launch_bf<WAVES_N, WM, WN, CH, 0, WK>(m, npix, stream);
 #endif
 }
 
-template <int WAVES_N, int WM, int WN>
+template <int WAVES_N, int WM, int WN, int WK = 1>
 int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
-    switch (p.CH) {
-        case 32: return launch_ch<WAVES_N, WM, WN, 32>(m, npix, stream);
-        case 16: return launch_ch<WAVES_N, WM, WN, 16>(m, npix, stream);
-        default: return launch_ch<WAVES_N, WM, WN, 8>(m, npix, stream);
+    if constexpr (WK > 1) {                                            // (K split over waves: 16- or 32-channel chunks)
+        if (p.CH == 32) return launch_ch<WAVES_N, WM, WN, 32, WK>(m, npix, stream);
+        if constexpr (WK == 2) { if (p.CH == 16) return launch_ch<WAVES_N, WM, WN, 16, WK>(m, npix, stream); }
+        return DCS_ERR_BADARG;
+    } else {
+        switch (p.CH) {
+            case 32: return launch_ch<WAVES_N, WM, WN, 32>(m, npix, stream);
+            case 16: return launch_ch<WAVES_N, WM, WN, 16>(m, npix, stream);
+            default: return launch_ch<WAVES_N, WM, WN, 8>(m, npix, stream);
+        }
     }
 }
 
@@ -871,8 +909,9 @@ int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
     return DCS_OK;
 }
 
-struct Cand { int bm, bn; };
-constexpr Cand kCands[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+struct Cand { int bm, bn, wk; };
+// (pixels, columns, waves along K): the last two are the K-split tiles of the few-pixel layers (cconv_mfma_kernel, WK)
+constexpr Cand kCands[] = {{128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {128, 32, 1}, {32, 64, 2}, {32, 32, 4}};
 
 // tile, chunk depth and K slices for geometry `a` (FULL output extent in Hout/Wout) and its classes
 bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, long* npix_out) {
@@ -921,7 +960,26 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // ... and when even the best tile leaves CUs idle (deep layers at small batch: few pixels, long K), slice K
     // instead: the tile with the best (pixel fit x operand reuse), times enough slices for ~4 workgroups per CU
     int want_s = 1;
-    if (best_useful < split_below) {
+    p->wk = 1;
+    // K split over the waves of a 32-pixel tile first (no slabs, no reduce launch); global slices only where that cannot run
+    static const int wk_on = [] { const char* e = getenv("DCS_MFMA_WK"); return e ? atoi(e) : 1; }();
+    static const long wk_min = [] { const char* e = getenv("DCS_MFMA_WK_MIN"); return e ? atol(e) : 384L; }();
+    if (best_useful < split_below && wk_on && !g_force_wide_panel && 2 * a.Cout >= 32) {
+        for (int i = 4; i < 6 && p->wk == 1; ++i) {
+            if (NT % (kCands[i].bn / 32) != 0) continue;
+            if (Cin % (kCands[i].wk == 4 ? 32 : 16) != 0) continue;         // whole k-groups per wave: 32- (16-) channel chunks
+            // measured per layer at B = 32 (profiles/r03_*_wk_vs_splitk.txt): the 32 x 64 tile wins where one class fills
+            // >= 1.5 workgroups per CU (enc5: 47 -> 38 us incl. the reduce it replaces), the 32 x 32 tile only for 1x1 kernels
+            // (the latent fc and its data gradient: 23 -> 12 us) — with a halo, eight column tiles re-gathering one patch lose
+            // to the sliced 64 x 64 tile (enc6: 30 -> 32 us)
+            if (i == 4 && ncls != 1) continue;
+            if (i == 5 && kh * kw != 1) continue;
+            double eff;
+            const long blocks = blocks_of(i, &eff);
+            if (blocks * eff >= wk_min || i == 5) { best = i; best_blocks = blocks; best_useful = blocks * eff; p->wk = kCands[i].wk; }
+        }
+    }
+    if (p->wk == 1 && best_useful < split_below) {
         const double reuse[4] = {1.0, 0.9, 0.8, 0.7};
         double best_score = -1;
         for (int i = 0; i < 4; ++i) {
@@ -963,7 +1021,14 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // patch words per pixel at chunk depth ch: fp32 2 ch + 4; bf16 ch + 4; three bf16 planes 3 ch + 4
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
+    if (p->wk > 1) p->pipe = false;
     if (p->pipe) {}
+    else if (p->wk > 1) {                                              // K split over waves: the deepest chunk that fits (<= 56 KB)
+        if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 56L * 1024) p->CH = 32;
+        else if (p->wk == 2 && Cin % 16 == 0 && npix * pixw(16) * 4 <= 56L * 1024) p->CH = 16;
+        else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 150L * 1024) p->CH = 32;
+        else return false;
+    }
     else if (2 * a.Cout == 16 && conv::mfma_precision16(Cin) != 0 && !(Cin % 32 == 0 && npix * pixw(32) * 4 <= cap32c)) {
         if (npix * pixw(16) * 4 > 150 * 1024) return false;            // the bf16 forms of the 16-column kernel have no 8-channel form
         p->CH = 16;
@@ -973,7 +1038,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     else if (npix * pixw(8) * 4 <= 150 * 1024) p->CH = 8;
     else return false;
     const int n_chunks = Cin / p->CH;
-    if (2 * a.Cout == 16) want_s = 1;                        // the 16-column kernel does not slice K
+    if (2 * a.Cout == 16 || p->wk > 1) want_s = 1;           // the 16-column kernel does not slice K; nor do the K-split tiles
     int S = want_s < n_chunks ? want_s : n_chunks;
     if (S > 8) S = 8;
     if (S < 1) S = 1;
@@ -1116,6 +1181,8 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         case 0: rc = launch<2, 2, 2>(m, p, npix, stream); break;      // 128 x 128
         case 1: rc = launch<2, 2, 1>(m, p, npix, stream); break;      // 128 x 64
         case 2: rc = launch<2, 1, 1>(m, p, npix, stream); break;      //  64 x 64
+        case 4: rc = launch<2, 1, 1, 2>(m, p, npix, stream); break;   //  32 x 64, two waves along K
+        case 5: rc = launch<1, 1, 1, 4>(m, p, npix, stream); break;   //  32 x 32, four waves along K
         default: rc = launch<1, 1, 1>(m, p, npix, stream); break;     // 128 x 32
     }
     if (rc != DCS_OK || m.ksplit <= 1) return rc;
