@@ -76,8 +76,12 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     constexpr int NP = PR == 2 ? 3 : 1;                                // bf16 planes per operand
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     constexpr int UALL = BF ? CH / 8 : CH / 4;                         // k-groups per tap and chunk
-    constexpr int U = UALL / WK;                                       // ... of ONE wave
-    static_assert(UALL % WK == 0 && (WK == 1 || TPI == 1), "K split over waves: whole k-groups per wave, tap-at-a-time loop");
+    // ... of ONE wave.  TSP (a chunk has fewer k-groups than WK: enc1's 8 channels = ONE bf16 k-group): the waves split the
+    // TAPS instead — wave wk takes taps wk, wk + WK, ... with all k-groups
+    constexpr bool TSP = WK > 1 && (UALL % WK) != 0;
+    constexpr int U = TSP ? UALL : UALL / WK;
+    constexpr int TSTEP = TPI * (TSP ? WK : 1);                         // tap-loop stride
+    static_assert(WK == 1 || TPI == 1, "K split over waves: tap-at-a-time loop");
     constexpr int VU = U * TPI, PIX = BF ? NP * CH + 4 : 2 * CH + 4, Q = CH / 2;
     const conv::Args& a = m.c;
     const conv::Cls& k = m.cls[blockIdx.z];
@@ -117,8 +121,10 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int pi = (wm * WM + i) * 32 + li;
-        pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + kk * 4 + wk * U * 8;   // (+ this wave's k-groups)
+        pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + kk * 4 + (TSP ? 0 : wk * U * 8);   // (+ this wave's k-groups)
     }
+    const int t0 = TSP ? wk : 0;                                       // this wave's first tap
+    const int kgo = TSP ? 0 : wk * U;                                  // ... first k-group
     const float* bbase = m.bm + k.bm_off + ((long)nt0 * 64 + lane) * 4;
     const long b_tap_stride = (long)(BF ? m.KG / 2 : m.KG) * m.NT * 256, b_kg_stride = (long)m.NT * 256;
     const long b_plane_stride = (long)(k.kh * k.kw) * b_tap_stride;    // (PR = 2: planes of this class's panel)
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     const int c_begin = kslice * m.cps;
     const int n_chunks = (c_begin + m.cps) * CH < Cin ? c_begin + m.cps : Cin / CH;     // end of this slice's chunks
     const int nslots = rows * cols * Q;                                // float4 (2 complex) slots of one patch chunk
+    const int tapoff0 = ((t0 / k.kw) * cols + (t0 % k.kw)) * PIX;      // LDS offset of this wave's first tap
 
     // fragment of (chunk c, tap tp, k-group g).  Always a load (past the end it re-reads the last chunk's fragment,
     // which nobody consumes): the tap loop body stays free of branches, so s_waitcnt counts stay exact instead of
@@ -147,10 +154,10 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     auto bload = [&](float4 (*dst)[WN], int c, int tp, int vg) {
         tp += vg / U;
         const int g = vg % U;
-        if (tp >= ntaps) { tp -= ntaps; ++c; }
+        if (tp >= ntaps) { tp = TSP ? t0 : tp - ntaps; ++c; }
         c = c < n_chunks ? c : n_chunks - 1;
         if (PR == 2 && TPI > 1) {
-            unsigned so = (unsigned)((tp * b_tap_stride + (long)(c * UALL + wk * U + g) * b_kg_stride) * 4);
+            unsigned so = (unsigned)((tp * b_tap_stride + (long)(c * UALL + kgo + g) * b_kg_stride) * 4);
             asm volatile("" : "+s"(so));                               // keep the offset where it is used (no hoisting of 49 rows)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     dst[pl][j] = *reinterpret_cast<const float4*>(ubase + so + (unsigned)((pl * b_plane_stride + j * 256) * 4) + lane_off);
             return;
         }
-        const float* bp = bbase + tp * b_tap_stride + (long)(c * UALL + wk * U + g) * b_kg_stride;
+        const float* bp = bbase + tp * b_tap_stride + (long)(c * UALL + kgo + g) * b_kg_stride;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     constexpr int NTAPS_C = INPLACE ? TPI * TPI : 0;
     float4 bcur[VU][NP][WN], bnxt[INPLACE ? 1 : VU][NP][WN];
 #pragma unroll
-    for (int g = 0; g < VU; ++g) bload(bcur[g], c_begin, 0, g);
+    for (int g = 0; g < VU; ++g) bload(bcur[g], c_begin, t0, g);
 
     // source pixel (index into x1 / x2, or -1 for zero) of every patch pixel: the same for all channel chunks
     int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);
@@ -262,11 +269,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + pl * CH);
-        int tapoff = 0;                                                // LDS float offset of the current tap
+            for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + pl * CH + tapoff0);
+        int tapoff = tapoff0;                                          // LDS float offset of the current tap
 #pragma unroll(INPLACE ? TPI : 1)
-        for (int tap = 0; tap < (INPLACE ? NTAPS_C : ntaps); tap += TPI) {
-            const int tap2 = tap + TPI < ntaps ? tap + TPI : tap;      // clamped: the last prefetch re-reads this tap
+        for (int tap = t0; tap < (INPLACE ? NTAPS_C : ntaps); tap += TSTEP) {
+            const int tap2 = tap + TSTEP < ntaps ? tap + TSTEP : tap;  // clamped: the last prefetch re-reads this tap
             const int tapoff2 = ((tap2 / k.kw) * cols + (tap2 % k.kw)) * PIX;
 #pragma unroll
             for (int g = 0; g < VU; ++g) {
@@ -303,11 +310,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 // next tap's fragments (scheduling barriers pin the loads here, ahead of the remaining MFMA groups)
                 __builtin_amdgcn_sched_barrier(0);
                 if (INPLACE) {
-                    bload(bcur[g], ch, tap + TPI, g);
+                    bload(bcur[g], ch, tap + TSTEP, g);
                 } else if (g * LPG < VU) {
 #pragma unroll
                     for (int q = 0; q < LPG; ++q)
-                        if (g * LPG + q < VU) bload(bnxt[INPLACE ? 0 : g * LPG + q], ch, tap + TPI, g * LPG + q);
+                        if (g * LPG + q < VU) bload(bnxt[INPLACE ? 0 : g * LPG + q], ch, tap + TSTEP, g * LPG + q);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -851,12 +858,9 @@ template <int WAVES_N, int WM, int WN, int CH, int PR, int WK = 1>
 int launch_bf(MArgs& m, long npix, hipStream_t stream) {
     constexpr bool BF = PR != 0;
     if constexpr (WK > 1) {                                            // K split over waves: tap-at-a-time loop only
-        if constexpr (((BF ? CH / 8 : CH / 4) % WK) != 0) return DCS_ERR_BADARG;
-        else {
-            const bool stat_ = m.c.stat != nullptr && m.ksplit <= 1;
-            return stat_ ? launch_tpi<WAVES_N, WM, WN, CH, PR, 1, true, WK>(m, npix, stream)
-                         : launch_tpi<WAVES_N, WM, WN, CH, PR, 1, false, WK>(m, npix, stream);
-        }
+        const bool stat_ = m.c.stat != nullptr && m.ksplit <= 1;
+        return stat_ ? launch_tpi<WAVES_N, WM, WN, CH, PR, 1, true, WK>(m, npix, stream)
+                     : launch_tpi<WAVES_N, WM, WN, CH, PR, 1, false, WK>(m, npix, stream);
     }
     // whole kernel rows per tap-loop iteration for the shallow layers (one class, 7-wide kernel, 128 x 32 tile): native fp32,
     // and the emulated form of the 7 x 7 layer (fully unrolled over its 7 rows)
@@ -884,9 +888,12 @@ int launch_ch(MArgs& m, long npix, hipStream_t stream) {
 
 template <int WAVES_N, int WM, int WN, int WK = 1>
 int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
-    if constexpr (WK > 1) {                                            // (K split over waves: 16- or 32-channel chunks)
+    if constexpr (WK > 1) {                                            // (K split over waves: 16- or 32-channel chunks; 8: over the taps)
         if (p.CH == 32) return launch_ch<WAVES_N, WM, WN, 32, WK>(m, npix, stream);
-        if constexpr (WK == 2) { if (p.CH == 16) return launch_ch<WAVES_N, WM, WN, 16, WK>(m, npix, stream); }
+        if constexpr (WK == 2) {
+            if (p.CH == 16) return launch_ch<WAVES_N, WM, WN, 16, WK>(m, npix, stream);
+            if (p.CH == 8) return launch_ch<WAVES_N, WM, WN, 8, WK>(m, npix, stream);
+        }
         return DCS_ERR_BADARG;
     } else {
         switch (p.CH) {
@@ -911,7 +918,8 @@ int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
 
 struct Cand { int bm, bn, wk; };
 // (pixels, columns, waves along K): the last two are the K-split tiles of the few-pixel layers (cconv_mfma_kernel, WK)
-constexpr Cand kCands[] = {{128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {128, 32, 1}, {32, 64, 2}, {32, 32, 4}};
+// and {64, 32, 2}: the LDS-bound 7x7 / 8-channel layer (enc1) — half the tile, so three workgroups share a CU instead of one
+constexpr Cand kCands[] = {{128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {128, 32, 1}, {32, 64, 2}, {32, 32, 4}, {64, 32, 2}};
 
 // tile, chunk depth and K slices for geometry `a` (FULL output extent in Hout/Wout) and its classes
 bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, long* npix_out) {
@@ -964,7 +972,8 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // K split over the waves of a 32-pixel tile first (no slabs, no reduce launch); global slices only where that cannot run
     static const int wk_on = [] { const char* e = getenv("DCS_MFMA_WK"); return e ? atoi(e) : 1; }();
     static const long wk_min = [] { const char* e = getenv("DCS_MFMA_WK_MIN"); return e ? atol(e) : 384L; }();
-    if (best_useful < split_below && wk_on && !g_force_wide_panel && 2 * a.Cout >= 32) {
+    static const long wk_below = [] { const char* e = getenv("DCS_MFMA_WK_BELOW"); return e ? atol(e) : 512L; }();
+    if (best_useful < wk_below && wk_on && !g_force_wide_panel && 2 * a.Cout >= 32) {
         for (int i = 4; i < 6 && p->wk == 1; ++i) {
             if (NT % (kCands[i].bn / 32) != 0) continue;
             if (Cin % (kCands[i].wk == 4 ? 32 : 16) != 0) continue;         // whole k-groups per wave: 32- (16-) channel chunks
@@ -978,6 +987,15 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
             const long blocks = blocks_of(i, &eff);
             if (blocks * eff >= wk_min || i == 5) { best = i; best_blocks = blocks; best_useful = blocks * eff; p->wk = kCands[i].wk; }
         }
+    }
+    // enc1 (8 -> 16 channels, 7x7, stride 2, emulated): a 128-pixel tile's three-plane patch is 87 KB — ONE workgroup per CU,
+    // nothing to overlap its gather with; 64 pixels x 32 columns with the taps split over two waves: 49 KB, three per CU
+    static const int wk_enc1 = [] { const char* e = getenv("DCS_MFMA_WK_ENC1"); return e ? atoi(e) : 1; }();
+    if (wk_on && wk_enc1 && p->wk == 1 && !g_force_wide_panel && NT == 1 && Cin == 8 && kh == 7 && kw == 7 && ncls == 1 &&
+        conv::mfma_precision(Cin, 49) == 2) {
+        double eff;
+        const long blocks = blocks_of(6, &eff);
+        if (blocks * eff >= min_blocks) { best = 6; best_blocks = blocks; best_useful = blocks * eff; p->wk = 2; }
     }
     if (p->wk == 1 && best_useful < split_below) {
         const double reuse[4] = {1.0, 0.9, 0.8, 0.7};
@@ -1024,7 +1042,8 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     if (p->wk > 1) p->pipe = false;
     if (p->pipe) {}
     else if (p->wk > 1) {                                              // K split over waves: the deepest chunk that fits (<= 56 KB)
-        if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 56L * 1024) p->CH = 32;
+        if (best == 6) p->CH = 8;
+        else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 56L * 1024) p->CH = 32;
         else if (p->wk == 2 && Cin % 16 == 0 && npix * pixw(16) * 4 <= 56L * 1024) p->CH = 16;
         else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 150L * 1024) p->CH = 32;
         else return false;
@@ -1183,6 +1202,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         case 2: rc = launch<2, 1, 1>(m, p, npix, stream); break;      //  64 x 64
         case 4: rc = launch<2, 1, 1, 2>(m, p, npix, stream); break;   //  32 x 64, two waves along K
         case 5: rc = launch<1, 1, 1, 4>(m, p, npix, stream); break;   //  32 x 32, four waves along K
+        case 6: rc = launch<1, 1, 1, 2>(m, p, npix, stream); break;   //  64 x 32, two waves along K (taps)
         default: rc = launch<1, 1, 1>(m, p, npix, stream); break;     // 128 x 32
     }
     if (rc != DCS_OK || m.ksplit <= 1) return rc;
