@@ -90,6 +90,23 @@ __device__ __forceinline__ void store_pair(const conv::Args& a, const f32x4v* ac
         }
 }
 
+// one row of partial CBN sums per (persistent) workgroup: over the 4 row groups of a column by shuffles, over the waves in LDS
+__device__ __forceinline__ void stat_rows_out(const conv::Args& a, float* st, float* red, int t, int lane, int wave, int li) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { st[e] += __shfl_xor(st[e], 16, 64); st[e] += __shfl_xor(st[e], 32, 64); }
+    __syncthreads();                                        // every wave is done with the patches
+    if (lane < 16) { red[(wave * 16 + li) * 3] = st[0]; red[(wave * 16 + li) * 3 + 1] = st[1]; red[(wave * 16 + li) * 3 + 2] = st[2]; }
+    __syncthreads();
+    if (t < 40) {                                           // channel c: {S_r, S_i, S_rr, S_ii, S_ri}
+        const int c = t / 5, e = t % 5;
+        const int colx = 2 * c + (e == 1 || e == 3), which = e < 2 ? 0 : (e < 4 ? 1 : 2);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += red[(w * 16 + colx) * 3 + which];
+        a.stat[(long)t * a.stat_stride + blockIdx.x] = sum;
+    }
+}
+
 // Persistent workgroups: tile = blockIdx.x, += gridDim.x.  The NEXT tile's patch is loaded into registers while this
 // tile's MFMAs run (two LDS buffers, one barrier per tile), the B fragments are built once per workgroup.
 // ACT: the activation at compile time, or -1 for a.act at run time.
@@ -193,28 +210,179 @@ __global__ __launch_bounds__(256, 4) void cconv_enc0_kernel(conv::Args a, TileDi
         }
         d_comp += EDIAG_NOW() - e1;
     }
-    if (STAT) {
-        // one row of partial sums per (persistent) workgroup: over the 4 row groups of a column by shuffles, over the waves in LDS
-#pragma unroll
-        for (int e = 0; e < 3; ++e) { st[e] += __shfl_xor(st[e], 16, 64); st[e] += __shfl_xor(st[e], 32, 64); }
-        __syncthreads();                                    // every wave is done with the patches
-        float* red = reinterpret_cast<float*>(patch[0]);
-        if (lane < 16) { red[(wave * 16 + li) * 3] = st[0]; red[(wave * 16 + li) * 3 + 1] = st[1]; red[(wave * 16 + li) * 3 + 2] = st[2]; }
-        __syncthreads();
-        if (t < 40) {                                       // channel c: {S_r, S_i, S_rr, S_ii, S_ri}
-            const int c = t / 5, e = t % 5;
-            const int colx = 2 * c + (e == 1 || e == 3), which = e < 2 ? 0 : (e < 4 ? 1 : 2);
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) sum += red[(w * 16 + colx) * 3 + which];
-            a.stat[(long)t * a.stat_stride + blockIdx.x] = sum;
-        }
-    }
+    if (STAT) stat_rows_out(a, st, reinterpret_cast<float*>(patch[0]), t, lane, wave, li);
 #ifdef DCS_ENC0_DIAG
     if (dbg && t == 0 && blockIdx.x < 4096) {
         long long* q = dbg + blockIdx.x * 8;
         q[0] = d_fill; q[1] = d_comp; q[2] = EDIAG_NOW() - d_start; q[3] = d_n; q[4] = d_start;
         q[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q[6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    }
+#endif
+}
+
+
+// ---- the same layer with bf16 MFMA operands: v_mfma_f32_16x16x32_bf16 ---------------------------------------------------
+// The fp32 MFMA above is 2 x slower per MAC than six bf16 MFMAs on exact three-way splits (conv_common.h precision 2), and
+// the layer is bound by the MFMA pipe (26 x 32 cycles per 16 pixels against 8 us of HBM traffic).  Here K is ordered
+// (kernel row dy, dx, re|im) with dx padded to 8 and dy to 8: 128 = 4 steps of 32, step s = rows 2s, 2s + 1; a lane's eight
+// k of a step = (row 2s + (kg >> 1), dx = 4 (kg & 1) .. + 3, re|im) = FOUR ADJACENT PATCH PIXELS of one plane, 16 contiguous
+// bytes of the LDS patch, which is kept as NPL planes of (re, im) bf16 pairs (the exact split is done once per patch element
+// when it is written).  24 (NPL = 3) or 4 (NPL = 1: bf16 operands) MFMAs of 16 cycles per 16 pixels instead of 26 of 32.
+// Patch row 21 and column 69 (the dy = 7 / dx = 7 padding of the last pixels) are zeros written once.
+// (Measured and dropped: the transposed product D[column][pixel], one 16-byte store per lane and M-tile instead of four 4-byte
+// stores — a lane quad then writes four different 64-byte segments, 26.2 -> 30.5 us.)
+constexpr int PRX = PR + 1, KS = 4;
+
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+
+template <int ACT, bool STAT, int NPL>
+__global__ __launch_bounds__(256, 4) void cconv_enc0b_kernel(conv::Args a, TileDiv d, int ntile, long long* dbg) {
+    const long long d_start = EDIAG_NOW();
+#ifdef DCS_ENC0_DIAG
+    const long long d_rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, one counter for the device (x 24 = 2.4 GHz units)
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned patch[2][NPL][PRX * PCP];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    int tile = blockIdx.x;
+    if (tile >= ntile) return;
+    int rows = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) rows |= ((t + 256 * k) / PC) << (5 * k);
+    float2 pv_[NL];
+    // B fragments: column n = li (co = li >> 1, re | im = li & 1); step s, element e: row 2s + (kg >> 1), dx = 4 (kg & 1) + (e >> 1),
+    // part e & 1.  Every wave holds the same 4 x NPL fragments: wave s builds those of step s (the split of all four in
+    // every wave was 400 VALU instructions x 16 waves per CU: 6 of the kernel's 19 us) and the waves trade them through LDS.
+    uint4 bq[KS][NPL];
+    {
+        const int co = li >> 1, im = li & 1, s = wave;
+        float wv[8];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const int dy = 2 * s + (kg >> 1), dx = 4 * (kg & 1) + e2;
+            const bool ok = dy < K7 && dx < K7;
+            float2 w = a.wp[(ok ? dy * K7 + dx : 0) * a.Cout + co];        // always a load (see the fp32 kernel above)
+            if (!ok) w = make_float2(0.f, 0.f);
+            wv[2 * e2] = im ? w.y : w.x;                                   // x_re: (w_r -> re, w_i -> im)
+            wv[2 * e2 + 1] = im ? w.x : -w.y;                              // x_im: (-w_i -> re, w_r -> im)
+        }
+        patch_load(a, d, tile, t, rows, pv_);                              // (after the weight loads: their wait does not include it)
+        uint4* bx = reinterpret_cast<uint4*>(&patch[1][0][0]);             // (KS * NPL * 64 * 16 B = 12 KB of the 18 KB buffer)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            unsigned h[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                h[e2] = dcs_pack_bf16x2(wv[2 * e2], wv[2 * e2 + 1]);
+                wv[2 * e2] -= __uint_as_float(h[e2] << 16);
+                wv[2 * e2 + 1] -= __uint_as_float(h[e2] & 0xffff0000u);
+            }
+            bx[(s * NPL + pl) * 64 + lane] = make_uint4(h[0], h[1], h[2], h[3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) bq[q][pl] = bx[(q * NPL + pl) * 64 + lane];
+        __syncthreads();
+    }
+    // the padding cells (disjoint from what a fill writes; the first barrier below orders them before any read)
+    for (int i = t; i < 2 * NPL * (PCP + PR); i += 256) {
+        const int c = i % (PCP + PR), q = i / (PCP + PR);
+        (&patch[0][0][0])[q * (PRX * PCP) + (c < PCP ? PR * PCP + c : (c - PCP) * PCP + PC)] = 0u;
+    }
+    const float* biasf = reinterpret_cast<const float*>(a.bias);
+    const float bv = biasf ? biasf[li] : 0.f;
+    float c_re = 1.f, c_im = 0.f, c_add = 0.f;                            // folded eval-mode CBN (conv_mfma.hip)
+    if (a.coef) {
+        const float* q = a.coef + 6 * (li >> 1);
+        if (li & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
+    }
+    int buf = 0;
+    float st[3] = {0.f, 0.f, 0.f};
+    long long d_fill = 0, d_comp = 0, d_n = 0;
+    const long long d_pro = EDIAG_NOW();
+    // this lane's window origin inside a patch row pair: pixel column 2 li + 4 (kg & 1), row kg >> 1
+    const int lane_off = (kg >> 1) * PCP + 2 * li + 4 * (kg & 1);
+#pragma unroll 1
+    for (; tile < ntile; tile += gridDim.x, buf ^= 1) {
+        const long long e0 = EDIAG_NOW();
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = t + 256 * k;
+            if (k < NL - 1 || i < PR * PC) {
+                float2 r = pv_[k];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const unsigned h = dcs_pack_bf16x2(r.x, r.y);
+                    patch[buf][pl][i + row_of(rows, k)] = h;
+                    r.x -= __uint_as_float(h << 16);
+                    r.y -= __uint_as_float(h & 0xffff0000u);
+                }
+            }
+        }
+        __syncthreads();
+        const long long e1 = EDIAG_NOW();
+        d_fill += e1 - e0; ++d_n;
+        // (opaque: the per-element address terms derived from `rows` are otherwise hoisted out of the tile loop and spilled)
+        asm volatile("" : "+v"(rows));
+        if (tile + (int)gridDim.x < ntile) patch_load(a, d, tile + gridDim.x, t, rows, pv_);
+        int b, ty, tx;
+        tile_split(d, tile, &b, &ty, &tx);
+        const int oy0 = ty * TR, ox0 = tx * TC;
+#pragma unroll 1
+        for (int i = 0; i < 4; i += 2) {
+            const int mt = wave * 4 + i;                                   // M-tiles mt (columns 0-15) and mt + 1 (16-31): row mt / 2
+            const int py = mt >> 1;
+            const unsigned* base = &patch[buf][0][0] + (2 * py) * PCP + lane_off;
+            f32x4v acc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+            // A fragments [M-tile][plane]: a tile's registers are re-loaded for the next step as soon as its MFMAs are issued,
+            // under the other tile's MFMAs (a two-deep ring of both tiles spilled at 128 VGPRs)
+            uint4 av[2][NPL];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const uint2* q = reinterpret_cast<const uint2*>(base + pl * (PRX * PCP) + h * 32);
+                    const uint2 lo = q[0], hi = q[1];
+                    av[h][pl] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};      // a0 b2, a1 b1, a2 b0, a0 b1, a1 b0, a0 b0
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int e = (NPL == 3 ? 0 : 5); e < 6; ++e)
+                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, av[h][pa[e]]),
+                                                                         __builtin_bit_cast(bf16x8v, bq[s][pb[e]]), acc[h], 0, 0, 0);
+                    if (s + 1 < KS) {
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl) {
+                            const uint2* q = reinterpret_cast<const uint2*>(base + pl * (PRX * PCP) + h * 32 + (s + 1) * 2 * PCP);
+                            const uint2 lo = q[0], hi = q[1];
+                            av[h][pl] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int oy = oy0 + py;
+            if (oy < a.Hout) {
+                act_t* yp = reinterpret_cast<act_t*>(a.y) + (((long)b * a.Hout + oy) * a.Wout + ox0 + kg * 4) * 16 + li;
+                if (ox0 + TC <= a.Wout) store_pair<ACT, false, STAT>(a, acc, yp, 0, bv, c_re, c_im, c_add, li, st);
+                else store_pair<ACT, true, STAT>(a, acc, yp, ox0 + kg * 4, bv, c_re, c_im, c_add, li, st);
+            }
+        }
+        d_comp += EDIAG_NOW() - e1;
+    }
+    if (STAT) stat_rows_out(a, st, reinterpret_cast<float*>(&patch[0][0][0]), t, lane, wave, li);
+#ifdef DCS_ENC0_DIAG
+    if (dbg && t == 0 && blockIdx.x < 4096) {
+        long long* q = dbg + blockIdx.x * 8;
+        q[0] = d_fill; q[1] = d_comp; q[2] = EDIAG_NOW() - d_start; q[3] = d_n; q[4] = d_rt0 * 24; q[2] = ((long long)__builtin_amdgcn_s_memrealtime() - d_rt0) * 24;
+        q[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q[6] = __builtin_amdgcn_s_getreg((3 << 11) | 20); q[7] = d_pro - d_start;
     }
 #endif
 }
@@ -370,10 +538,22 @@ int dcs_conv_enc0_launch(conv::Args a, hipStream_t stream) {
 #else
     long long* dbgp = nullptr;
 #endif
-    if (a.stat) {
-        if (a.act != DCS_ACT_NONE || a.coef) return DCS_ERR_BADARG;
-        DCS_LAUNCH((cconv_enc0_kernel<DCS_ACT_NONE, true>), dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
+    if (a.stat && (a.act != DCS_ACT_NONE || a.coef)) return DCS_ERR_BADARG;
+    static const int fp32_mfma = [] { const char* e = getenv("DCS_ENC0_F32"); return e ? atoi(e) : 0; }();          // 1: the fp32-MFMA kernel also under precision 1 / 2
+    const int prec = DCS_ACT_IS_BF16 ? 1 : dcs_conv_precision();
+    if (prec != 0 && !fp32_mfma) {
+#define ENC0B(ACT_, STAT_)                                                                                                 \
+        do {                                                                                                               \
+            if (prec == 2) DCS_LAUNCH((cconv_enc0b_kernel<ACT_, STAT_, 3>), dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);  \
+            else DCS_LAUNCH((cconv_enc0b_kernel<ACT_, STAT_, 1>), dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);     \
+        } while (0)
+        if (a.stat) ENC0B(DCS_ACT_NONE, true);
+        else if (a.act == DCS_ACT_NONE) ENC0B(DCS_ACT_NONE, false);
+        else if (a.act == DCS_ACT_RELU) ENC0B(DCS_ACT_RELU, false);
+        else ENC0B(-1, false);
+#undef ENC0B
     }
+    else if (a.stat) DCS_LAUNCH((cconv_enc0_kernel<DCS_ACT_NONE, true>), dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
     else if (a.act == DCS_ACT_NONE) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_NONE>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
     else if (a.act == DCS_ACT_RELU) DCS_LAUNCH(cconv_enc0_kernel<DCS_ACT_RELU>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
     else DCS_LAUNCH(cconv_enc0_kernel<-1>, dim3(grid), dim3(256), 0, stream, a, d, (int)ntile, dbgp);
