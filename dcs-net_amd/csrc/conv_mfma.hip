@@ -1036,6 +1036,11 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     static const long cap32e = [] { const char* e = getenv("DCS_MFMA_LDS_CAP32"); return e ? atol(e) : 32L * 1024; }();
     const long wg_est = best_blocks * (want_s > 1 ? want_s : 1);
     const long cap32c = (pr_for_cap == 2 && wg_est <= 768 && cap32e < 56L * 1024) ? 56L * 1024 : cap32e;
+    // likewise a 16-channel chunk up to 80 KB where at most two workgroups land on a CU (enc2, 16 channels, 5x5 / stride 2:
+    // one 75 KB chunk instead of two gather rounds of 40 KB: 33.7 -> 28.0 us; the same tile split over the taps of two
+    // waves as for enc1: 38.8 us)
+    static const long cap16w = [] { const char* e = getenv("DCS_MFMA_LDS_CAP16W"); return e ? atol(e) : 80L * 1024; }();
+    const long cap16c = (wg_est <= 512 && cap16 < cap16w) ? cap16w : cap16;
     // patch words per pixel at chunk depth ch: fp32 2 ch + 4; bf16 ch + 4; three bf16 planes 3 ch + 4
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
@@ -1053,7 +1058,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
         p->CH = 16;
     }
     else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= cap32c) p->CH = 32;
-    else if (Cin % 16 == 0 && npix * pixw(16) * 4 <= cap16) p->CH = 16;
+    else if (Cin % 16 == 0 && npix * pixw(16) * 4 <= cap16c) p->CH = 16;
     else if (npix * pixw(8) * 4 <= 150 * 1024) p->CH = 8;
     else return false;
     const int n_chunks = Cin / p->CH;
