@@ -1035,7 +1035,10 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // every layer allowed, the inference shapes lose 0.8 %)
     static const long cap32e = [] { const char* e = getenv("DCS_MFMA_LDS_CAP32"); return e ? atol(e) : 32L * 1024; }();
     const long wg_est = best_blocks * (want_s > 1 ? want_s : 1);
-    const long cap32c = (pr_for_cap == 2 && wg_est <= 768 && cap32e < 56L * 1024) ? 56L * 1024 : cap32e;
+    // ... and up to 72 KB where at most two do (enc4: two gather rounds instead of four, 40.3 -> 38.2 us)
+    static const long cap32w2 = [] { const char* e = getenv("DCS_MFMA_LDS_CAP32W2"); return e ? atol(e) : 72L * 1024; }();
+    const long cap32c = (pr_for_cap == 2 && wg_est <= 512 && cap32e < cap32w2) ? cap32w2
+                      : (pr_for_cap == 2 && wg_est <= 768 && cap32e < 56L * 1024) ? 56L * 1024 : cap32e;
     // likewise a 16-channel chunk up to 80 KB where at most two workgroups land on a CU (enc2, 16 channels, 5x5 / stride 2:
     // one 75 KB chunk instead of two gather rounds of 40 KB: 33.7 -> 28.0 us; the same tile split over the taps of two
     // waves as for enc1: 38.8 us)

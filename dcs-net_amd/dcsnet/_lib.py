@@ -67,6 +67,11 @@ SIGNATURES = {
     'dcs_attention_apply_fwd': (_I, [_P, _P, _P, _P, _I, _L, _I, _F, _U64, _P, _P]),
     'dcs_rattention_workspace_bytes': (_L, [_I, _L, _I]),
     'dcs_rattention_fwd': (_I, [_P] * 8 + [_L] + [_I] * 6 + [_P]),
+    'dcs_rattention_train_workspace_bytes': (_L, [_I, _L, _I, _I]),
+    'dcs_rattention_pool_fwd': (_I, [_P] * 8 + [_L] + [_I] * 5 + [_P]),
+    'dcs_rattention_apply_fwd': (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    'dcs_rattention_apply_bwd': (_I, [_P] * 8 + [_L] + [_I] * 4 + [_P]),
+    'dcs_rattention_pool_bwd': (_I, [_P] * 11 + [_I] + [_P, _L] + [_I] * 5 + [_P]),
     'dcs_attention_bwd_sa': (_I, [_P] * 5 + [_I, _L, _I, _F, _U64, _P, _P]),
     'dcs_attention_bwd_workspace_bytes': (_L, [_I, _L, _I, _I]),
     'dcs_attention_bwd_x': (_I, [_P] * 16 + [_L, _I, _L, _I, _I, _F, _U64, _P, _P]),

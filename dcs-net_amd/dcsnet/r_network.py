@@ -32,12 +32,15 @@ behind autograd nodes —
   * enc0 / dec6 / the 7x7 attention convs: the complex conv nodes of the DCS path over weight views of the real
     parameters (autograd maps the gradients back through the pairing);
   * the LSTM recurrence forward + BPTT kernels at hidden size 128, its projections and the Linear as rocBLAS GEMMs.
-In ATen under autograd: the attention blocks' pools / FC / broadcast multiplies (reductions and element-wise ops; the
-fused dcs_rattention_fwd serves inference), dropout, the final sigmoid.
+  * _RAttendFn: an attention block as one node — dcs_rattention_pool_fwd / _apply_fwd and their _bwd twins for the pools, the
+    FC and the broadcast products (first-maximum gradient routing, as torch.max / AdaptiveMaxPool2d), the 7x7 conv through
+    dcs_cconv2d_fwd / _bwd_data / _bwd_weight on the (mean, max) pair as one complex channel.
+In ATen under autograd: dropout, the final sigmoid, and small glue (sigmoid' of the spatial map, weight-gradient views).
 
 Quirks kept (r_network.py): channel attention = sigmoid(fc(max_pool)) only (:23-24); dropout_fc gated by
 hparams['dropout'] (:152) while dropout_conv is not; torch.squeeze drops the batch dimension at B = 1 (:171).
 """
+import os
 import torch
 
 from . import ops
@@ -273,6 +276,73 @@ class _RBnFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None
 
 
+class _RAttendFn(torch.autograd.Function):
+    """The real CBAM pair y = sa (.) ca (.) x (r_network.py:8-42, :155-158) with hand-written gradients: the pools, the FC
+    and the broadcast products through dcs_rattention_{pool,apply}_{fwd,bwd} (csrc/r_attention.hip), the k x k conv through
+    the complex path's entries on the (mean, max) pair read as one complex channel with weights w_mean - j w_max.  The
+    reference differentiates the same graph with autograd; torch.max / AdaptiveMaxPool2d send each maximum's gradient to
+    its first position, and so do the kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w7, k):
+        from . import _lib
+        lib = _lib.load()
+        B, H, W, C = x.shape
+        Ch = w1.shape[0]
+        x = x.contiguous()
+        w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
+        nbytes = lib.dcs_rattention_train_workspace_bytes(B, H * W, C, Ch)
+        if nbytes < 0:
+            raise DcsHipError(f'R_NETWORK attention: unsupported channel count {C}')
+        ws = ops._workspace(nbytes, x.device)
+        dev = x.device
+        ca = torch.empty((B, C), dtype=torch.float32, device=dev)
+        mx = torch.empty((B, C), dtype=torch.float32, device=dev)
+        hid = torch.empty((B, Ch), dtype=torch.float32, device=dev)
+        pooled = torch.empty((B, H, W, 1, 2), dtype=torch.float32, device=dev)
+        _lib.check(lib.dcs_rattention_pool_fwd(_lib.ptr(x), _lib.ptr(w1c), _lib.ptr(w2c), _lib.ptr(ca), _lib.ptr(mx), _lib.ptr(hid),
+                                               _lib.ptr(pooled), _lib.ptr(ws), ws.numel(), B, H, W, C, Ch, _lib.cur_stream()),
+                   'dcs_rattention_pool_fwd')
+        wd = w7.detach()
+        wp, bias = ops.pack_conv_weight(wd[:, 0:1].contiguous(), (-wd[:, 1:2]).contiguous())
+        sa = ops.cconv2d(pooled, None, wp, bias, (k, k), (1, 1), (k // 2, k // 2), (1, 1), F.ACT_SIGMOID)    # [B,H,W,1,2]
+        y = torch.empty_like(x)
+        _lib.check(lib.dcs_rattention_apply_fwd(_lib.ptr(x), _lib.ptr(ca), _lib.ptr(sa), _lib.ptr(y), B, H, W, C,
+                                                _lib.cur_stream()), 'dcs_rattention_apply_fwd')
+        ctx.k = k
+        ctx.save_for_backward(x, w1c, w2c, wp, ca, mx, hid, pooled, sa)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        lib = _lib.load()
+        x, w1, w2, wp, ca, mx, hid, pooled, sa = ctx.saved_tensors
+        k = ctx.k
+        B, H, W, C = x.shape
+        Ch = w1.shape[0]
+        dev = x.device
+        gy = gy.contiguous()
+        ws = ops._workspace(lib.dcs_rattention_train_workspace_bytes(B, H * W, C, Ch), dev)
+        gx = torch.empty_like(x)
+        g_sa = torch.empty_like(sa)
+        g_ca = torch.empty((B, C), dtype=torch.float32, device=dev)
+        _lib.check(lib.dcs_rattention_apply_bwd(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(ca), _lib.ptr(sa), _lib.ptr(gx), _lib.ptr(g_sa),
+                                                _lib.ptr(g_ca), _lib.ptr(ws), ws.numel(), B, H, W, C, _lib.cur_stream()),
+                   'dcs_rattention_apply_bwd')
+        g_u = g_sa * sa * (1.0 - sa)                       # sigmoid on the parts; the imaginary cotangent is zero
+        ksz, one, pad = (k, k), (1, 1), (k // 2, k // 2)
+        g_pooled, _ = ops.cconv2d_bwd_data(g_u, ops.pack_conv_weight_bwd(wp, ksz, one, pad, one), (H, W, 1), ksz, one, pad, one, 1)
+        gw_r, gw_i, _, _ = ops.cconv2d_bwd_weight(pooled, None, g_u, (1, 1, k, k), False, ksz, one, pad, one)
+        g_w7 = torch.cat([gw_r, -gw_i], dim=1)             # conv1.weight [1, 2, k, k] = (w_mean, w_max) = (w_r, -w_i)
+        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+        _lib.check(lib.dcs_rattention_pool_bwd(_lib.ptr(g_pooled), _lib.ptr(g_ca), _lib.ptr(x), _lib.ptr(ca), _lib.ptr(mx),
+                                               _lib.ptr(hid), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(gx), _lib.ptr(gw1), _lib.ptr(gw2),
+                                               1, _lib.ptr(ws), ws.numel(), B, H, W, C, Ch, _lib.cur_stream()),
+                   'dcs_rattention_pool_bwd')
+        return gx, gw1.view_as(w1), gw2.view_as(w2), g_w7, None
+
+
 class R_NETWORK(LightningModule):
     def __init__(self, config, hparams, seed):
         super().__init__()
@@ -447,9 +517,12 @@ class R_NETWORK(LightningModule):
 
     @staticmethod
     def _attend(ca_m, sa_m, x):
-        """sa (.) ca (.) x (r_network.py:155-158 / :166-167) in one C-ABI call: dcs_rattention_fwd."""
+        """sa (.) ca (.) x (r_network.py:155-158 / :166-167): one C-ABI call at inference (dcs_rattention_fwd), one autograd
+        node over the training entries otherwise (_RAttendFn)."""
         if torch.is_grad_enabled() and (x.requires_grad or sa_m.conv1.weight.requires_grad):
-            return R_NETWORK._attend_autograd(ca_m, sa_m, x)
+            if os.environ.get('DCS_RATTENTION_ATEN', '0') == '1':          # (the ATen formulation: a test reference)
+                return R_NETWORK._attend_autograd(ca_m, sa_m, x)
+            return _RAttendFn.apply(x, ca_m.fc[0].weight, ca_m.fc[2].weight, sa_m.conv1.weight, sa_m.kernel_size)
         from . import _lib
         lib = _lib.load()
         B, H, W, C = x.shape

@@ -373,6 +373,30 @@ int  dcs_rattention_fwd(const float* x, const float* w1, const float* w2, const 
                         float* ca_out, float* y, void* workspace, long workspace_bytes,
                         int B, int H, int W, int C, int Ch, int ksize, dcs_stream_t stream);
 
+/* The same block for training (r_network.py:8-42 under loss.backward(): the reference differentiates it with autograd),
+ * as three pieces around the k x k conv, which keeps the complex path's entries (dcs_cconv2d_fwd / _bwd_data / _bwd_weight):
+ *   pool_fwd   ca, and what its backward needs: mx float[B][C] (pooled maxima), hid float[B][Ch] (post-ReLU hidden units);
+ *              pooled float2[B][H][W] = (mean_c, max_c) of ca x as ONE complex channel
+ *   apply_fwd  y = x ca[c] Re(sa[p])                 sa float2[B][H][W]: the conv's complex output
+ *   apply_bwd  g_x = g_y ca sa (OVERWRITES gx);  g_sa float2[B][H][W] = (sum_c g_y x ca, 0);  g_ca float[B][C] = sum_p g_y x sa
+ *   pool_bwd   g_pooled float2[B][H][W] (cotangent of the (mean, max) pair), g_ca float[B][C] or NULL;
+ *              gx: added to (accumulate != 0) or overwritten; gw1 float[Ch][C], gw2 float[C][Ch].
+ * torch.max / AdaptiveMaxPool2d semantics: each maximum's gradient goes to its FIRST position in scan order.
+ * Workspace: dcs_rattention_train_workspace_bytes for every entry that takes one. */
+long dcs_rattention_train_workspace_bytes(int B, long HW, int C, int Ch);
+int  dcs_rattention_pool_fwd(const float* x, const float* w1, const float* w2, float* ca_out, float* mx_out, float* hid_out,
+                             float* pooled, void* workspace, long workspace_bytes, int B, int H, int W, int C, int Ch,
+                             dcs_stream_t stream);
+int  dcs_rattention_apply_fwd(const float* x, const float* ca, const float* sa, float* y, int B, int H, int W, int C,
+                              dcs_stream_t stream);
+int  dcs_rattention_apply_bwd(const float* gy, const float* x, const float* ca, const float* sa, float* gx, float* g_sa,
+                              float* g_ca, void* workspace, long workspace_bytes, int B, int H, int W, int C,
+                              dcs_stream_t stream);
+int  dcs_rattention_pool_bwd(const float* g_pooled, const float* g_ca, const float* x, const float* ca, const float* mx,
+                             const float* hid, const float* w1, const float* w2, float* gx, float* gw1, float* gw2,
+                             int accumulate, void* workspace, long workspace_bytes, int B, int H, int W, int C, int Ch,
+                             dcs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Backward of the fused attention block  out = dropout(sa (.) ca (.) x)  built from the four
  * forward entry points above (channel attention -> spatial pool -> 7x7 conv + sigmoid -> apply).

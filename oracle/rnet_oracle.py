@@ -27,7 +27,8 @@ class RealChannelAttention(nn.Module):
                                 nn.Conv2d(hidden, channels, 1, bias=False))
 
     def forward(self, x):
-        return torch.sigmoid(self.fc(torch.amax(x, dim=(2, 3), keepdim=True)))
+        # AdaptiveMaxPool2d(1) (r_network.py:12,21): its gradient goes to the first maximum (torch.amax would share it among ties)
+        return torch.sigmoid(self.fc(nn.functional.adaptive_max_pool2d(x, 1)))
 
 
 class RealSpatialAttention(nn.Module):

@@ -681,6 +681,39 @@ def test_real_attention_pair(dev, C, hw):
     close(got, want, rel=2e-5)
 
 
+@pytest.mark.parametrize('C,hw,relu_in', [(16, (37, 5), True), (64, (9, 11), False), (256, (2, 32), True), (32, (16, 16), True)])
+def test_real_attention_pair_backward(dev, C, hw, relu_in):
+    """The training node of the DR-Net attention pair (_RAttendFn: dcs_rattention_pool/apply_fwd/_bwd + the complex conv
+    entries) against autograd through the oracle's modules on the CPU (r_network.py:8-42: AdaptiveMaxPool2d and
+    torch.max(dim=1), whose gradients go to the FIRST maximum).  relu_in: a post-ReLU input (exact zeros: ties in the
+    per-pixel channel maximum, two all-zero pixels included) as the skip attentions see it (r_network.py:155-158)."""
+    from oracle.rnet_oracle import RealChannelAttention as OCA, RealSpatialAttention as OSA
+    from dcsnet.r_network import R_NETWORK, RealChannelAttention, RealSpatialAttention
+    torch.manual_seed(C + 1)
+    oca, osa = OCA(C, 16), OSA(7)
+    x = torch.randn(3, C, *hw)
+    if relu_in:
+        x = torch.relu(x)
+        x[0, :, 0, 0] = 0.0
+        x[2, :, -1, -1] = 0.0
+    gy = torch.randn(3, C, *hw)
+    xo = x.clone().requires_grad_(True)
+    z = oca(xo) * xo
+    (osa(z) * z).backward(gy)
+    ca, sa = RealChannelAttention(C, 16), RealSpatialAttention(7)
+    ca.load_state_dict(oca.state_dict()); sa.load_state_dict(osa.state_dict())
+    ca, sa = ca.to(dev), sa.to(dev)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    y = R_NETWORK._attend(ca, sa, xd)
+    assert type(y.grad_fn).__name__ == '_RAttendFnBackward'
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+    close(y.detach(), (osa(z) * z).detach().permute(0, 2, 3, 1), rel=2e-5)
+    close(xd.grad, xo.grad.permute(0, 2, 3, 1), rel=5e-5)
+    close(ca.fc[0].weight.grad, oca.fc[0].weight.grad, rel=5e-5)
+    close(ca.fc[2].weight.grad, oca.fc[2].weight.grad, rel=5e-5)
+    close(sa.conv1.weight.grad, osa.conv1.weight.grad, rel=5e-5)
+
+
 @pytest.mark.parametrize('frames', [(3, 7), (2, 64), (1, 1)])
 def test_fft512_pair(dev, frames):
     """dcs_irfft512_frames / dcs_rfft512_frames (fft512.hip) against torch.fft on the CPU: unnormalised inverse of
