@@ -89,7 +89,7 @@ inline bool mfma_ok(int Cin, int Cout) { return (Cin % 8) == 0 && (Cout % 8) == 
 // iteration there) stay on the fp32 MFMA.  Decides the panel layout (pack) and the kernel (launch) alike.
 inline int mfma_precision(int Cin, int taps = 0) {
     const int p = dcs_conv_precision();
-    return (p == 2 && (Cin % 16) != 0 && !(Cin == 8 && taps == 49)) ? 0 : p;      // (8 channels: only the 7x7 row form)
+    return (p == 2 && (Cin % 16) != 0 && !(Cin == 8 && (taps == 49 || taps == 16))) ? 0 : p;      // (8 channels: only the row forms, 7x7 and 4x4)
 }
 // ... of the 16-column kernel (Cout = 8): its bf16 forms (1: bf16 operands, 2: the emulation) need 16-channel k-groups
 inline int mfma_precision16(int Cin) {

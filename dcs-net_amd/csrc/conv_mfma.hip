@@ -866,6 +866,10 @@ int launch_bf(MArgs& m, long npix, hipStream_t stream) {
     // and the emulated form of the 7 x 7 layer (fully unrolled over its 7 rows)
     constexpr bool ROWS = (PR == 0 || PR == 2) && CH == 8 && WM == 1 && WN == 1;
     const bool stat = m.c.stat != nullptr && m.ksplit <= 1;           // (a sliced launch leaves the statistics to its reduce kernel)
+    // ... and of the 4 x 4 one (dec5's data gradient: the stride-2 fold of the 3 x 3 kernel over 8 channels), 128- or 64-pixel tiles
+    constexpr bool ROWS4 = PR == 2 && CH == 8 && WN == 1;
+    if (ROWS4 && m.ncls == 1 && m.cls[0].kw == 4 && m.cls[0].kh == 4 && !stat)
+        return launch_tpi<WAVES_N, WM, WN, CH, PR, ROWS4 ? 4 : 1>(m, npix, stream);
     if (ROWS && m.ncls == 1 && m.cls[0].kw == 7 && (PR == 2 ? m.cls[0].kh == 7 : (m.cls[0].kh * m.cls[0].kw) % 7 == 0))
         return stat ? launch_tpi<WAVES_N, WM, WN, CH, PR, ROWS ? 7 : 1, true>(m, npix, stream)
                     : launch_tpi<WAVES_N, WM, WN, CH, PR, ROWS ? 7 : 1>(m, npix, stream);
