@@ -923,7 +923,7 @@ int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
 struct Cand { int bm, bn, wk; };
 // (pixels, columns, waves along K): the last two are the K-split tiles of the few-pixel layers (cconv_mfma_kernel, WK)
 // and {64, 32, 2}: the LDS-bound 7x7 / 8-channel layer (enc1) — half the tile, so three workgroups share a CU instead of one
-constexpr Cand kCands[] = {{128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {128, 32, 1}, {32, 64, 2}, {32, 32, 4}, {64, 32, 2}};
+constexpr Cand kCands[] = {{128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {128, 32, 1}, {32, 64, 2}, {32, 32, 4}, {64, 32, 2}, {64, 64, 2}};
 
 // tile, chunk depth and K slices for geometry `a` (FULL output extent in Hout/Wout) and its classes
 bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, long* npix_out) {
@@ -1013,6 +1013,15 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
         }
         want_s = (int)((min_blocks + best_blocks - 1) / best_blocks);
     }
+    // 64 x 64 with the k-groups split over two waves (each wave 64 pixels x 32 columns: every B fragment feeds two MFMA sets,
+    // half the L1 traffic of the 2 x 2 wave layout whose four waves each fetch their own)
+    // (dec1 / dec2 forward and data gradient 78 -> 74 us, dec3 43 -> 41, enc3 / enc4 data gradients -2; not with the statistics
+    // epilogue, whose combine then runs over twice the waves: enc2 / enc3 forward +2 us)
+    static const int wk64 = [] { const char* e = getenv("DCS_MFMA_WK64"); return e ? atoi(e) : 1; }();
+    if (wk64 && best == 2 && p->wk == 1 && want_s == 1 && !a.stat && !g_force_wide_panel && Cin % 16 == 0 &&
+        conv::mfma_precision(Cin, ncls == 1 ? kh * kw : 0) != 0) {
+        best = 7; p->wk = 2;
+    }
     p->cand = best; p->blocks = best_blocks;
     shape(kCands[best].bm, &p->TH, &p->TW);
     const long npix = (long)((p->TH - 1) * a.sf + kh) * ((p->TW - 1) * a.st + kw);
@@ -1053,7 +1062,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
     if (p->wk > 1) p->pipe = false;
     if (p->pipe) {}
-    else if (p->wk > 1) {                                              // K split over waves: the deepest chunk that fits (<= 56 KB)
+    else if (p->wk > 1 && best != 7) {                                              // K split over waves: the deepest chunk that fits (<= 56 KB)
         if (best == 6) p->CH = 8;
         else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 56L * 1024) p->CH = 32;
         else if (p->wk == 2 && Cin % 16 == 0 && npix * pixw(16) * 4 <= 56L * 1024) p->CH = 16;
@@ -1215,6 +1224,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         case 4: rc = launch<2, 1, 1, 2>(m, p, npix, stream); break;   //  32 x 64, two waves along K
         case 5: rc = launch<1, 1, 1, 4>(m, p, npix, stream); break;   //  32 x 32, four waves along K
         case 6: rc = launch<1, 1, 1, 2>(m, p, npix, stream); break;   //  64 x 32, two waves along K (taps)
+        case 7: rc = launch<2, 2, 1, 2>(m, p, npix, stream); break;   //  64 x 64, two waves along K
         default: rc = launch<1, 1, 1>(m, p, npix, stream); break;     // 128 x 32
     }
     if (rc != DCS_OK || m.ksplit <= 1) return rc;
