@@ -198,69 +198,78 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     }
 
     const long long d_loop = FDIAG_NOW();
+    // gather in rounds of GU independent loads per thread (all in flight together), then the LDS stores.  The source
+    // pixel of every patch pixel comes from the table built once above: per slot a shift, an LDS read and one
+    // 64-bit multiply-add (the index arithmetic it replaces — four runtime divisions per slot and chunk — kept the
+    // VALU busy for ~30 % of a workgroup's life while its MFMA pipe idled).
+    constexpr int GU = (PR == 2 && CH == 32) ? DCS_X6_GU32 : (PR == 2 ? DCS_X6_GU16 : 4);
+#if DCS_ACT_IS_BF16
+    typedef uint2 raw_t;                                               // two complex values = 4 bf16, as stored
+#else
+    typedef float4 raw_t;
+#endif
+    auto gissue = [&](raw_t* v, int base, int chx) {                   // the loads of one round: slots base + 256 u of chunk chx
+        int spv[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int idx = base + u * 256;
+            spv[u] = idx < nslots ? spx[idx / Q] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int idx = base + u * 256;
+#if DCS_ACT_IS_BF16
+            v[u] = make_uint2(0u, 0u);
+#else
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+            if (spv[u] >= 0) {
+                const int c = chx * CH + 2 * (idx % Q);
+                const act2_t* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
+                v[u] = *reinterpret_cast<const raw_t*>(src);
+            }
+        }
+    };
+    auto gstore = [&](const raw_t* v, int base) {                      // ... and their LDS stores (operand conversion)
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int idx = base + u * 256;
+            if (idx >= nslots) continue;
+#if DCS_ACT_IS_BF16
+            // bf16 activations (precision mode 1 only): the stored bits ARE the MFMA operand — no conversion
+            static_assert(PR == 1, "bf16 activations run the bf16-operand kernel");
+            *reinterpret_cast<uint2*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = v[u];
+#else
+            if (PR == 2) {                                             // 2 complex -> 3 planes of 4 bf16 (exact split)
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                float4 r = v[u];
+                float* dst = patch + (idx / Q) * PIX + (idx % Q) * 2;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const bf16x4 h = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
+                    *reinterpret_cast<bf16x4*>(dst + pl * CH) = h;
+                    r.x -= (float)h[0]; r.y -= (float)h[1]; r.z -= (float)h[2]; r.w -= (float)h[3];
+                }
+            } else if (BF) {                                           // 2 complex -> 4 bf16 (round to nearest even)
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                const bf16x4 h = {(__bf16)v[u].x, (__bf16)v[u].y, (__bf16)v[u].z, (__bf16)v[u].w};
+                *reinterpret_cast<bf16x4*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = h;
+            } else {
+                *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
+            }
+#endif
+        }
+    };
+    // (Measured and dropped: the first round of the NEXT chunk loaded into registers before this chunk's MFMA loop and stored
+    // after it — +37 VGPRs take the 32-channel instances from three waves per SIMD to two and the first B-fragment wait of
+    // the loop then also waits for the older patch loads: train step 3.950 -> 3.996 ms, inference 3.22 -> 3.37 ms.)
     for (int ch = c_begin; ch < n_chunks; ++ch) {
         const long long g0 = FDIAG_NOW();
         __syncthreads();                                               // previous chunk fully consumed
-        // gather in rounds of GU independent loads per thread (all in flight together), then the LDS stores.  The source
-        // pixel of every patch pixel comes from the table built once above: per slot a shift, an LDS read and one
-        // 64-bit multiply-add (the index arithmetic it replaces — four runtime divisions per slot and chunk — kept the
-        // VALU busy for ~30 % of a workgroup's life while its MFMA pipe idled).
-        constexpr int GU = (PR == 2 && CH == 32) ? DCS_X6_GU32 : (PR == 2 ? DCS_X6_GU16 : 4);
         for (int base = t; base < nslots; base += 256 * GU) {
-#if DCS_ACT_IS_BF16
-            typedef uint2 raw_t;                                       // two complex values = 4 bf16, as stored
-#else
-            typedef float4 raw_t;
-#endif
             raw_t v[GU];
-            int spv[GU];
-#pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int idx = base + u * 256;
-                spv[u] = idx < nslots ? spx[idx / Q] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int idx = base + u * 256;
-#if DCS_ACT_IS_BF16
-                v[u] = make_uint2(0u, 0u);
-#else
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-                if (spv[u] >= 0) {
-                    const int c = ch * CH + 2 * (idx % Q);
-                    const act2_t* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
-                    v[u] = *reinterpret_cast<const raw_t*>(src);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int idx = base + u * 256;
-                if (idx >= nslots) continue;
-#if DCS_ACT_IS_BF16
-                // bf16 activations (precision mode 1 only): the stored bits ARE the MFMA operand — no conversion
-                static_assert(PR == 1, "bf16 activations run the bf16-operand kernel");
-                *reinterpret_cast<uint2*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = v[u];
-#else
-                if (PR == 2) {                                         // 2 complex -> 3 planes of 4 bf16 (exact split)
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                    float4 r = v[u];
-                    float* dst = patch + (idx / Q) * PIX + (idx % Q) * 2;
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const bf16x4 h = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
-                        *reinterpret_cast<bf16x4*>(dst + pl * CH) = h;
-                        r.x -= (float)h[0]; r.y -= (float)h[1]; r.z -= (float)h[2]; r.w -= (float)h[3];
-                    }
-                } else if (BF) {                                       // 2 complex -> 4 bf16 (round to nearest even)
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                    const bf16x4 h = {(__bf16)v[u].x, (__bf16)v[u].y, (__bf16)v[u].z, (__bf16)v[u].w};
-                    *reinterpret_cast<bf16x4*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = h;
-                } else {
-                    *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
-                }
-#endif
-            }
+            gissue(v, base, ch);
+            gstore(v, base);
         }
         __syncthreads();
         const long long g1 = FDIAG_NOW();
