@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // (Measured, no effect: delaying the workgroup in the odd wave slot by 1-3 us so that co-resident workgroups stop gathering
+    // and multiplying in step — dec1 / dec2 / enc3 within +-1 %: the MFMA phase is bound by operand delivery, not by overlap.)
     const int c_begin = kslice * m.cps;
     const int n_chunks = (c_begin + m.cps) * CH < Cin ? c_begin + m.cps : Cin / CH;     // end of this slice's chunks
     const int nslots = rows * cols * Q;                                // float4 (2 complex) slots of one patch chunk
