@@ -360,7 +360,7 @@ extern "C" int DCS_SYM(dcs_cbn_bwd_add)(const act_t* x, const act_t* g_out, act_
                                const unsigned long long* seed_dev, const float* g_add, float add_scale, long HW,
                                const act_t* g_out2, dcs_stream_t stream) {
     cbn::Geom g;
-    if (!x || !g_out || !g_x || !stats || !coef || !workspace || !cbn::geom(P, C, &g)) return DCS_ERR_BADARG;
+    if (!x || !g_out || !stats || !coef || !workspace || !cbn::geom(P, C, &g)) return DCS_ERR_BADARG;   // (g_x NULL: parameter gradients only)
     if (g_add && (C < 2 || HW <= 0 || P % HW != 0)) return DCS_ERR_BADARG;
     if (g_out2 && C == 1 && (P & 1)) return DCS_ERR_BADARG;      // the scalar tail of the one-channel layout reads g_out only
     const act_t* gb = g_out2;
@@ -382,9 +382,10 @@ extern "C" int DCS_SYM(dcs_cbn_bwd_add)(const act_t* x, const act_t* g_out, act_
                            ga, add_scale, HW, gb);                                                                 \
         DCS_LAUNCH(cbn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part,      \
                            g.nblocks, weight, stats, coef, g_weight, g_bias, bcoef, P, C, use_batch_stats);        \
-        DCS_LAUNCH((cbn_bwd_apply_kernel<A, D>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef,    \
-                           stats, (const float*)bcoef, P, C, g.vec_per_row, g.rows_per_iter, drop_p,               \
-                           (uint64_t)seed, (const uint64_t*)seed_dev, ga, add_scale, HW, gb);                      \
+        if (g_x)                                                                                                   \
+            DCS_LAUNCH((cbn_bwd_apply_kernel<A, D>), dim3(grid2), dim3(kThreads), 0, s, x, g_out, g_x, coef,    \
+                               stats, (const float*)bcoef, P, C, g.vec_per_row, g.rows_per_iter, drop_p,           \
+                               (uint64_t)seed, (const uint64_t*)seed_dev, ga, add_scale, HW, gb);                  \
     } while (0)
     if (act == DCS_ACT_RELU) { if (drop) DCS_CBN_BWD(DCS_ACT_RELU, true); else DCS_CBN_BWD(DCS_ACT_RELU, false); }
     else if (act == DCS_ACT_LRELU) { if (drop) DCS_CBN_BWD(DCS_ACT_LRELU, true); else DCS_CBN_BWD(DCS_ACT_LRELU, false); }

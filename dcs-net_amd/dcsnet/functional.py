@@ -190,7 +190,7 @@ class _CbnFn(torch.autograd.Function):
         x, weight, stats, coef = ctx.saved_tensors
         use_batch, act, drop_p, seed, affine = ctx.cfg
         g_x, g_w, g_b = ops.cbn_bwd(x, g_out.contiguous(), weight, stats, coef, use_batch, act, drop_p, seed, affine,
-                                    ctx.sinks)
+                                    ctx.sinks, need_gx=ctx.needs_input_grad[0])
         g_w = None if ctx.sinks[0] is not None else g_w
         g_b = None if ctx.sinks[1] is not None else g_b
         return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None

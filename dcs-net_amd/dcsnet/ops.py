@@ -541,10 +541,11 @@ def cbn_channel_attention(x, weight, bias, running_mean, running_covar, eps, mom
 
 
 def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, seed=0, affine=True, outs=None,
-            g_add=None, g_out2=None):
+            g_add=None, g_out2=None, need_gx=True):
     """Backward of cbn(): returns (g_x, g_weight [C,3], g_bias [C,2]).  `outs`: optional destinations for
     (g_weight, g_bias).  g_add [B,C,2]: the cotangent is g_out + g_add[b, c] / (H*W) (attention_bwd's g_pooled).
-    g_out2: a second cotangent of y (another consumer's), added on the fly."""
+    g_out2: a second cotangent of y (another consumer's), added on the fly.  need_gx = False (the network input's CBN: nothing
+    upstream wants g_x): parameter gradients only, the apply pass is not launched and g_x is None."""
     _chk(x, 'x', 5, act=True)
     _chk(g_out, 'g_out', 5, act=True)
     _chk(g_out2, 'g_out2', 5, act=True)
@@ -552,7 +553,7 @@ def cbn_bwd(x, g_out, weight, stats, coef, use_batch_stats, act, drop_p=0.0, see
         raise _lib.DcsHipError(f'cbn_bwd: g_out {tuple(g_out.shape)} vs g_out2 {tuple(g_out2.shape)}')
     B, H, W, C, _ = x.shape
     P = B * H * W
-    g_x = torch.empty_like(x)
+    g_x = torch.empty_like(x) if need_gx else None
     o = outs or (None, None)
     g_w = (o[0] if o[0] is not None else torch.empty((C, 3), dtype=torch.float32, device=x.device)) if affine else None
     g_b = (o[1] if o[1] is not None else torch.empty((C, 2), dtype=torch.float32, device=x.device)) if affine else None

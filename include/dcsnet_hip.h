@@ -282,7 +282,7 @@ int dcs_channel_attention_fc_fwd(const void* pool_part, const float* w1, const f
 
 /* Backward of dcs_cbn_fwd (closed form of what autograd derives through complexPyTorch's CBN,
  * the activation and the dropout).  g_out: gradient w.r.t. y; g_x: gradient w.r.t. x (may alias
- * g_out); stats/coef: as written by the forward call; g_weight float[C][3], g_bias float[C][2]
+ * g_out; NULL = parameter gradients only: the CBN of the network input, no pass over x for g_x); stats/coef: as written by the forward call; g_weight float[C][3], g_bias float[C][2]
  * (both NULL for affine=False); same act / drop_p / seed as the forward call.
  * use_batch_stats = 0 differentiates the eval-mode (running statistics) normalisation. */
 long dcs_cbn_bwd_workspace_bytes(long P, int C);

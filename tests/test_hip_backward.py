@@ -191,6 +191,25 @@ def test_cbn_backward(dev, C, shape, act, training):
     close(p['bias'].grad, bn.bias.grad, rel=2e-4, what='g_bias')
 
 
+def test_cbn_backward_of_a_network_input_gives_parameter_gradients_only(dev):
+    """The initial CBN (c_network.py:101,191): its input is the data, nothing wants g_x — the backward launches the
+    reduction and the finalize only (dcs_cbn_bwd_add with g_x = NULL) and the parameter gradients are unchanged."""
+    from dcsnet import functional as F
+    bn = fill_state(cpt.ComplexBatchNorm2d(1), seed=3)
+    bn.train(True)
+    x = rand_c((2, 1, 16, 24), 5, 1.2) + (0.3 - 0.5j)
+    rm = torch.view_as_real(bn.running_mean.clone()).to(dev).contiguous()
+    rc = bn.running_covar.clone().to(dev).contiguous()
+    functional_loss(bn(x), 4).backward()
+    p = dev_params(bn, dev)
+    xn = nhwc_leaf(x, dev).detach()                          # no gradient wanted for the input
+    assert not xn.requires_grad
+    y = F.cbn(xn, p['weight'], p['bias'], rm, rc, bn.eps, 0.1, True, F.ACT_NONE)
+    functional_loss(F.from_nhwc(y), 4).backward()
+    close(p['weight'].grad, bn.weight.grad, rel=2e-4, what='g_weight')
+    close(p['bias'].grad, bn.bias.grad, rel=2e-4, what='g_bias')
+
+
 def test_dropout_backward_uses_the_same_mask(dev):
     from dcsnet import functional as F
     x = torch.randn(1 << 16, device=dev, requires_grad=True)
