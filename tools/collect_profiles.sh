@@ -47,4 +47,10 @@ python3 $R/tools/step_sequence.py $(find $out/kt_train -name "*kernel_trace.csv"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/kt_infer -- python3 $R/bench.py --mode infer --no-cpu-baseline --no-native-line --steps 4 --warmup 2 > $out/kt_infer.log 2>&1
 python3 $R/tools/infer_sequence.py $(find $out/kt_infer -name "*kernel_trace.csv" | head -1) > $out/step_sequence_infer.txt
 rm -rf $out/kt_train $out/kt_infer
+echo "[collect] bf16 activation storage at B = 64 (BASELINE.json configs[4], per-GPU share) beside fp32 at the same batch"
+timeout -k 10 400 python3 $R/bench.py --dtype bf16 --batch 64 --no-cpu-baseline > $out/bench_train_bf16_b64.json 2> $out/bench_bf16.log
+timeout -k 10 400 python3 $R/bench.py --batch 64 --no-cpu-baseline > $out/bench_train_f32_b64.json 2> $out/bench_f32_b64.log
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/kt_bf16 -- python3 $R/bench.py --dtype bf16 --batch 64 --no-cpu-baseline --no-native-line --steps 4 --warmup 2 > $out/kt_bf16.log 2>&1
+python3 $R/tools/step_sequence.py $(find $out/kt_bf16 -name "*kernel_trace.csv" | head -1) 6 > $out/step_sequence_train_bf16_b64.txt
+rm -rf $out/kt_bf16
 echo "[collect] done"; ls -la $out
