@@ -528,11 +528,12 @@ def main():
                                     f'bwd + grad all-reduce + clip 100 + Adam/AMSGrad), complex64 [{B},256,{T}] x (noise, noisy, clean) per '
                                     'GPU, dropout 0.1/0.2, batch-statistics CBN, random-init weights seed 0 — NOT the headline '
                                     '(the reference trains at precision 32)' if train and bf16 else
-                                    'BASELINE configs[2]/[3]: DCS-Net full train step (fwd + SiSNR losses + bwd + grad '
-                                    'all-reduce + clip 100 + Adam/AMSGrad), complex64 [32,256,256] x (noise, noisy, clean) '
+                                    ('BASELINE configs[2]/[3]' if (B, T) == (32, 256) else 'BASELINE configs[2] at another batch') +
+                                    ': DCS-Net full train step (fwd + SiSNR losses + bwd + grad '
+                                    f'all-reduce + clip 100 + Adam/AMSGrad), complex64 [{B},256,{T}] x (noise, noisy, clean) '
                                     'per GPU, dropout 0.1/0.2, batch-statistics CBN, random-init weights seed 0'
                                     if train else
-                                    'BASELINE configs[1]: DCS-Net forward-only inference, complex64 [16,256,2000] per GPU '
+                                    f'BASELINE configs[1]: DCS-Net forward-only inference, complex64 [{B},256,{T}] per GPU '
                                     '(4 s / 16 kHz STFT, n_fft 512 hop 32, bins 1..256), random-init weights seed 0'),
                        'world_seen': (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1),
                        'collective_backend': (dist.get_backend() if dist.is_available() and dist.is_initialized() else None),
@@ -541,7 +542,7 @@ def main():
                                     'native: v_mfma_f32_32x32x2_f32' if conv_mode == 'f32' else
                                     'bf16x6: conv forward / data gradient emulate fp32 on v_mfma_f32_32x32x16_bf16 (exact 3-way '
                                     'bf16 split of both operands, 6 cross products, fp32 accumulate; error vs fp64 below the native '
-                                    'MFMA\'s: profiles/*conv_precision.txt); the weight gradients run on the same emulation (cconv_wgrad_x6_kernel), enc0 and the small-channel kernels on the native fp32 pipe / VALU'),
+                                    'MFMA\'s: profiles/*conv_precision.txt); the weight gradients run on the same emulation (cconv_wgrad_x6_kernel), and so does the first encoder conv (v_mfma_f32_16x16x32_bf16); its weight gradient runs on the native fp32 MFMA, the 1-output-channel decoder layer and the 7x7 attention convs on the VALU'),
                        'per_gpu_batch': B, 'frames_per_utterance': T, 'global_batch': B * world,
                        'frames_per_step': B * T * world, 'hip_graph': bool(graphed), 'parallelism': (f'dp{world} (utterance sharding, one flat-bucket gradient all-reduce)' if train
                                        else f'dp{world} (utterance sharding, no collective)')},

@@ -235,7 +235,7 @@ def cconv2d(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1), act=A
     # (strided forward convs are exactly the encoder's ComplexConv2d stack: tagged for bench.py's encoder roofline)
     ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None,
                            executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
-                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and C1 % 2 == 0,
+                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and (C1 % 2 == 0 or C1 + C2 == 1),
                            nbytes=_conv_bytes(x1, B * Hin * Win * (C1 + C2), B * Hout * Wout * Cout, kh * kw * (C1 + C2) * Cout))
           if CONV_TIMER is not None else None)
     if coef is not None:
@@ -280,7 +280,7 @@ def cconv2d_stats(x1, x2, wp, bias, ksize, stride=(1, 1), pad=(0, 0), up=(1, 1))
     ws = _workspace(nbytes, x1.device) if nbytes > 0 else None
     ev = (CONV_TIMER.begin(8.0 * B * Hout * Wout * Cout * (C1 + C2) * kh * kw, 'enc_fwd' if max(stride) > 1 else None,
                            executed=_fold_fraction(C1, C1 + C2, Cout, ksize, stride, pad, up),
-                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and C1 % 2 == 0,
+                           emulated=_emulated(C1 + C2, Cout, kh * kw if tuple(up) == (1, 1) else 0) and (C1 % 2 == 0 or C1 + C2 == 1),
                            nbytes=_conv_bytes(x1, B * Hin * Win * (C1 + C2), B * Hout * Wout * Cout, kh * kw * (C1 + C2) * Cout))
           if CONV_TIMER is not None else None)
     used = ctypes.c_int(0)
@@ -308,8 +308,10 @@ def _conv_bytes(act, n_in, n_out, n_w):
 def _emulated(k_channels, n_channels, taps=0):
     """Whether the MFMA GEMM with K = 2 * k_channels, N = 2 * n_channels runs on the bf16 MFMA in fp32-emulation mode
     (conv::mfma_precision, conv_mfma.hip: 16-channel chunks, 32-column tiles) — for bench.py's instruction accounting."""
+    if conv_precision() == 'bf16x6' and k_channels == 1 and n_channels == 8 and taps == 49:
+        return True                       # the first encoder conv (conv_enc0.hip: cconv_enc0b_kernel, 16x16x32 bf16 MFMAs)
     return (conv_precision() == 'bf16x6' and n_channels % 8 == 0 and
-            (k_channels % 16 == 0 or (k_channels == 8 and taps == 49 and n_channels != 8)))
+            (k_channels % 16 == 0 or (k_channels == 8 and taps in (49, 16) and n_channels != 8)))
 
 
 def _wgrad_emulated(C1, Cin, Cout, ksize):

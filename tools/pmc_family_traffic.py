@@ -51,6 +51,22 @@ out += ['', '# how: tools/collect_profiles.sh + tools/pmc_family_traffic.py — 
         '# 3 steps per pass; KiB -> bytes x1024; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B; MI355X_MICROARCH.md, HBM section).',
         '# calibration: adam must read 105 MB/step (36 B x 2.91 M parameters).',
         '# train step 0 of each pass records the pack plan (per-layer pack launches), so pack_ is above its steady-state value.']
+# MFMA busy fraction of the conv families from the same collection's SQ pass (tools/pmc_mfma_util.py wrote the summary)
+import re
+for mode in ('train', 'infer'):
+    try:
+        txt = open(os.path.join(REPO, 'profiles', f'{tag}_pmc_mfma_util_{mode}.txt')).read()
+    except OSError:
+        continue
+    busy = {}
+    for key, pat in (('fwd_dgrad', r'forward / data gradient\): util ([0-9.]+)'), ('wgrad', r'weight gradient\): util ([0-9.]+)'),
+                     ('all_mfma_kernels', r'all MFMA kernels: util ([0-9.]+)')):
+        m_ = re.search(pat, txt)
+        if m_:
+            busy[key] = float(m_.group(1))
+    if busy:
+        busy['source'] = f'profiles/{tag}_pmc_mfma_util_{mode}.txt (SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES))'
+        res[mode]['mfma_busy'] = busy
 open(os.path.join(REPO, 'profiles', f'{tag}_pmc_hbm_traffic.txt'), 'w').write('\n'.join(out) + '\n')
 json.dump(res, open(os.path.join(REPO, 'profiles', 'traffic.json'), 'w'), indent=1)
 print('\n'.join(out))
