@@ -34,6 +34,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* = 64 FLOP/
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (same guide; AMD's headline figure includes 2:1 sparsity)
 PEAK_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0     # fp32 products emulated by six bf16 MFMAs: the ceiling of that path
 PEAK_HBM_GBS = 8000.0
+SUSTAINED_BF16X6_TFLOPS = 1897.4 / 6.0   # measured: tools/micro/mfma_peak.hip mode 4 (clock 1.845 GHz under bf16 MFMA load)
+SUSTAINED_F32_MFMA_TFLOPS = 154.5       # measured: the same tool, mode 0 (2.39 GHz)
 
 
 def synthetic_stft_batch(B, T, device, seed=0):
@@ -552,6 +554,13 @@ def main():
                                              'launches that emulate fp32 on the bf16 MFMA (six MFMAs per product), 157.3 for native '
                                              'fp32-MFMA launches' if args.dtype == 'f32' else 'dense bf16 MFMA peak'),
                          'frac_vs_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
+                         # what the same pipes SUSTAIN on this part (tools/micro/mfma_peak.hip, profiles/r03_mfma_peak_bf16.txt: a
+                         # bare bf16 MFMA loop runs at 1.845 GHz, 1.90 PFLOP/s -> 316 TFLOP/s of emulated fp32; fp32 MFMA 154.5)
+                         'sustained_peak': ({'bf16x6': SUSTAINED_BF16X6_TFLOPS, 'f32_mfma': SUSTAINED_F32_MFMA_TFLOPS,
+                                             'frac_of_flops_weighted': achieved / (conv_flops / (
+                                                 cs['emu_flops'] / SUSTAINED_BF16X6_TFLOPS +
+                                                 (conv_flops - cs['emu_flops']) / SUSTAINED_F32_MFMA_TFLOPS)) if conv_flops > 0 else None,
+                                             'source': 'profiles/r03_mfma_peak_bf16.txt'} if args.dtype == 'f32' else None),
                          'emulated_share_of_flops': (cs['emu_flops'] / conv_flops if conv_flops > 0 else 0.0),
                          'mfma_busy_pmc': pmc_mfma_busy(args.mode, B, T),
                          'kernel': 'complex conv / convT (dcs_cconv2d_fwd' + (', _bwd_data, _bwd_weight' if train else '')

@@ -55,6 +55,39 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* s
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+
+// ---- the bf16 pipe the emulated ("bf16x6") conv kernels run on: v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16 -------------
+// mode 4: 32x32x16, four accumulators per wave; mode 5: 16x16x32, four accumulators; mode 6: 32x32x16 with TWO waves per SIMD
+// (the conv kernels' usual residency).  Datasheet: 2500 TFLOP/s dense at 2.4 GHz; fp32 emulated by six bf16 MFMAs: 416.7.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void kb(const float* __restrict__ src, float* sink, unsigned long long* clk, int iters) {
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)src[threadIdx.x + 64 * e]; b[e] = (__bf16)src[threadIdx.x + 64 * e + 512]; }
+    f32x16 acc[4];
+    f32x4 acc4[4];
+    for (int i = 0; i < 4; ++i) { for (int r = 0; r < 16; ++r) acc[i][r] = 0.f; for (int r = 0; r < 4; ++r) acc4[i][r] = 0.f; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (MODE == 5) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc4[i], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) { for (int r = 0; r < 16; ++r) s += acc[i][r]; for (int r = 0; r < 4; ++r) s += acc4[i][r]; }
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 int main() {
     const int grid = 256, iters = 20000;          // one 4-wave workgroup per CU: one wave per SIMD
     float *src, *sink; unsigned long long* clk;
@@ -86,6 +119,32 @@ int main() {
         std::sort(ghz.begin(), ghz.end());
         printf("mode %d (%s): %.1f TFLOP/s sustained (last of 3 x %.1f s), best %.1f; in-kernel clock median %.3f GHz\n", mode,
                mode == 0 ? "operands in registers" : mode == 1 ? "ds_read_b128 per 4 MFMAs" : mode == 2 ? "single dependent chain" : "single chain + ds_read_b128 per 4 MFMAs", last, ms * 1e-3, best, ghz[grid / 2]);
+    }
+    for (int mode = 4; mode < 7; ++mode) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        double best = 0, last = 0; float ms = 0;
+        const int launches = 20, g2 = mode == 6 ? 2 * grid : grid;
+        const double flop_per_mfma = mode == 5 ? 16.0 * 16 * 32 * 2 : 32.0 * 32 * 16 * 2;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            for (int l = 0; l < launches; ++l) {
+                if (mode == 5) hipLaunchKernelGGL(kb<5>, dim3(g2), dim3(256), 0, 0, src, sink, clk, iters);
+                else hipLaunchKernelGGL(kb<4>, dim3(g2), dim3(256), 0, 0, src, sink, clk, iters);
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            last = (double)launches * g2 * 4 * iters * 16 * flop_per_mfma / (ms * 1e-3) / 1e12;
+            best = std::max(best, last);
+        }
+        std::vector<unsigned long long> c(2 * grid);
+        hipMemcpy(c.data(), clk, grid * 16, hipMemcpyDeviceToHost);
+        std::vector<double> ghz;
+        for (int i = 0; i < grid; ++i) ghz.push_back((double)c[2 * i] / (double)c[2 * i + 1] * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        printf("mode %d (%s): %.1f TFLOP/s bf16 sustained (last of 3 x %.1f s), best %.1f = %.1f TFLOP/s of fp32 emulated by six MFMAs; in-kernel clock median %.3f GHz\n",
+               mode, mode == 4 ? "v_mfma_f32_32x32x16_bf16, one wave per SIMD" : mode == 5 ? "v_mfma_f32_16x16x32_bf16, one wave per SIMD"
+                                                                                          : "v_mfma_f32_32x32x16_bf16, two waves per SIMD",
+               last, ms * 1e-3, best, last / 6.0, ghz[grid / 2]);
     }
     return 0;
 }
