@@ -6,7 +6,7 @@
 // The conv family is compiled twice (dcs_common.h: act_t): every cross-file function that touches activations gets its own
 // symbol in the bf16 build.  NOT renamed — taken from the once-compiled fp32 objects, whose operands are fp32 in either
 // mode: the 7x7 attention convs (conv_k7.hip, conv_wgrad_small.hip, dcs_conv_direct_multi), the weight packers
-// (conv_pack.hip, pack_jobs.hip), the slab reduces (wgrad_reduce.hip), the pipelined schedule (conv_pipe.hip, fp32 only).
+// (conv_pack.hip, pack_jobs.hip), the slab reduces (wgrad_reduce.hip).
 #ifdef DCS_ACT_BF16
 #define dcs_conv_mfma_stat_rows dcs_conv_mfma_stat_rows_h
 #define dcs_conv_mfma_pack dcs_conv_mfma_pack_h

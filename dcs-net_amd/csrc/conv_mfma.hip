@@ -844,7 +844,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 
 // (the B-panel re-layout kernel lives in pack_jobs.hip: packjob::MFMA)
 
-struct Plan { int cand, TH, TW, CH, S, cps; long blocks; bool pipe; int wk; };
+struct Plan { int cand, TH, TW, CH, S, cps; long blocks; int wk; };
 thread_local bool g_force_wide_panel = false;
 
 template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI, bool STAT = false, int WK = 1>
@@ -1039,20 +1039,6 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // chunk depth: 16 channels whenever the patch stays within ~1/3 of a CU's LDS (2-3 workgroups per CU overlap
     // each other's gathers), 32 only for small patches (occupancy matters more than barrier count there)
     static const long cap16 = [] { const char* e = getenv("DCS_MFMA_LDS_CAP"); return e ? atol(e) : 56L * 1024; }();
-    // the persistent LDS-DMA kernel (conv_pipe.hip) where it applies: the deepest chunk whose two patch buffers fit
-    // (fewer, longer work items: one barrier per item), 32 channels only while the buffers leave room for two workgroups
-    p->pipe = false;
-    if (!g_force_wide_panel && !DCS_ACT_IS_BF16) {
-        static const int force_ch = [] { const char* e = getenv("DCS_PIPE_CH"); return e ? atoi(e) : 0; }();
-        static const long cap32 = [] { const char* e = getenv("DCS_PIPE_LDS32"); return e ? atol(e) : 76L * 1024; }();
-        const int order[3] = {32, 16, 8};
-        for (int i = 0; i < 3 && !p->pipe; ++i) {
-            const int ch = order[i];
-            if (force_ch && ch != force_ch) continue;
-            if (ch == 32 && !force_ch && 2 * npix * 32 * 8 > cap32) continue;
-            if (dcs_conv_pipe_eligible(a, ncls, cls, best, p->TH, p->TW, ch)) { p->CH = ch; p->pipe = true; }
-        }
-    }
     const int pr_for_cap = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     // 32-channel chunks (half the gather rounds, twice the patch): for the emulated kernel also up to 56 KB where the launch
     // puts at most ~3 workgroups on a CU anyway, so the larger patch costs no residency (train shapes: step -1.5 %; with
@@ -1071,9 +1057,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // patch words per pixel at chunk depth ch: fp32 2 ch + 4; bf16 ch + 4; three bf16 planes 3 ch + 4
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
-    if (p->wk > 1) p->pipe = false;
-    if (p->pipe) {}
-    else if (p->wk > 1 && best != 7) {                                              // K split over waves: the deepest chunk that fits (<= 56 KB)
+    if (p->wk > 1 && best != 7) {                                              // K split over waves: the deepest chunk that fits (<= 56 KB)
         if (best == 6) p->CH = 8;
         else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 56L * 1024) p->CH = 32;
         else if (p->wk == 2 && Cin % 16 == 0 && npix * pixw(16) * 4 <= 56L * 1024) p->CH = 16;
@@ -1146,7 +1130,6 @@ int dcs_conv_mfma_stat_rows(const conv::Args& a, int ncls, const conv::Cls* cls,
     if (p.S > 1 && have_ws && !(N & 3)) return splitk_stat_blocks((long)a.B * a.Hout * a.Wout, N);
     int Hc = 0, Wc = 0;
     for (int c = 0; c < ncls; ++c) { Hc = cls[c].Hc > Hc ? cls[c].Hc : Hc; Wc = cls[c].Wc > Wc ? cls[c].Wc : Wc; }
-    if (p.pipe) return 0;
     return ((Wc + p.TW - 1) / p.TW) * ((Hc + p.TH - 1) / p.TH) * a.B * ncls;
 }
 
@@ -1195,7 +1178,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
 #else
     m.dbg = nullptr;
 #endif
-    if (a.stat && (p.pipe || a.coef || a.act != DCS_ACT_NONE || y2 != nullptr)) return DCS_ERR_BADARG;   // raw plain outputs only
+    if (a.stat && (a.coef || a.act != DCS_ACT_NONE || y2 != nullptr)) return DCS_ERR_BADARG;   // raw plain outputs only
     m.ksplit = p.S; m.cps = p.cps; m.part = (float*)ws;
     if (p.S > 1 && (!ws || ws_bytes < (long)p.S * m.slab_floats * (long)sizeof(float) || (m.N & 3) ||
                     (y2 != nullptr && (nsplit & 3)))) {
@@ -1227,8 +1210,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         }
     }
     int rc;
-    if (p.pipe) rc = dcs_conv_pipe_launch(m, p.cand, p.CH, stream);
-    else switch (p.cand) {
+    switch (p.cand) {
         case 0: rc = launch<2, 2, 2>(m, p, npix, stream); break;      // 128 x 128
         case 1: rc = launch<2, 2, 1>(m, p, npix, stream); break;      // 128 x 64
         case 2: rc = launch<2, 1, 1>(m, p, npix, stream); break;      //  64 x 64

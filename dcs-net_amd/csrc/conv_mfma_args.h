@@ -1,5 +1,4 @@
-// conv_mfma_args.h — launch descriptor shared by the two implicit-GEMM complex conv kernels
-// (conv_mfma.hip: one patch per workgroup; conv_pipe.hip: persistent workgroups, LDS-DMA double buffering).
+// conv_mfma_args.h — launch descriptor of the implicit-GEMM complex conv kernels (conv_mfma.hip).
 #pragma once
 #include "conv_common.h"
 
@@ -20,9 +19,3 @@ struct MArgs {
     long slab_floats;          // B * Hout * Wout * N
     long long* dbg;            // diagnostic builds only (-DDCS_FWD_DIAG): per-workgroup phase times (core clocks)
 };
-
-// conv_pipe.hip.  eligible: whether a geometry planned with (cand, CH) can run on the pipelined kernel at all
-// (fp32 operands, 32-column tiles, the chunk does not straddle the two tensors of a concatenation, LDS fits).
-bool dcs_conv_pipe_enabled();
-bool dcs_conv_pipe_eligible(const conv::Args& a, int ncls, const conv::Cls* cls, int cand, int TH, int TW, int CH);
-int dcs_conv_pipe_launch(MArgs& m, int cand, int CH, hipStream_t stream);

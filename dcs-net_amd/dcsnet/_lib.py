@@ -126,8 +126,6 @@ SIGNATURES = {
     'dcs_tap_rows_wgrad_scatter': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dcs_set_conv_precision': (_I, [_I]),
     'dcs_get_conv_precision': (_I, []),
-    'dcs_set_conv_schedule': (_I, [_I]),
-    'dcs_get_conv_schedule': (_I, []),
     'dcs_wgrad_defer_begin': (_I, []),
     'dcs_wgrad_defer_suspend': (_I, [_I]),
     'dcs_wgrad_defer_flush': (_I, [_P]),

@@ -60,16 +60,6 @@ def set_conv_precision(mode):
     pack_plan_drop()
 
 
-def set_conv_schedule(mode):
-    """'classic' (default: one patch per workgroup) or 'pipe' (persistent workgroups, LDS-DMA double buffering) for the
-    fp32 MFMA conv kernels; bit-identical results (dcs_set_conv_schedule)."""
-    check(_lib.load().dcs_set_conv_schedule({'classic': 0, 'pipe': 1}[mode]), 'dcs_set_conv_schedule')
-
-
-def conv_schedule():
-    return 'pipe' if _lib.load().dcs_get_conv_schedule() == 1 else 'classic'
-
-
 def conv_precision():
     return ('f32', 'bf16', 'bf16x6')[_lib.load().dcs_get_conv_precision()]
 

@@ -14,13 +14,12 @@
  *   - Every pointer is a DEVICE pointer BORROWED from the caller.  The library never
  *     allocates, frees or retains caller memory; workspaces are passed in.
  *   - Kernels are enqueued on `stream`; no call synchronises.
- *   - ONE CONTEXT PER PROCESS.  The library is built for the one-process-per-GPU model and keeps five pieces of
+ *   - ONE CONTEXT PER PROCESS.  The library is built for the one-process-per-GPU model and keeps four pieces of
  *     process-global mutable state (each behind its own entry points, each guarded by a mutex, none per stream):
  *       (1) the conv operand precision                         dcs_set_conv_precision / dcs_get_conv_precision
  *       (2) the deferred weight-gradient reduce scope           dcs_wgrad_defer_begin / _suspend / _flush
  *       (3) the pack-plan recorder                              dcs_pack_plan_begin / _end
- *       (4) the conv kernel schedule                            dcs_set_conv_schedule / dcs_get_conv_schedule
- *       (5) the kernel timer's armed slot                       dcs_kernel_timer_begin / _end
+ *       (4) the kernel timer's armed slot                       dcs_kernel_timer_begin / _end
  *     Two training drivers in one process (or two host threads that open scopes concurrently) would see each
  *     other's precision, recorded reduces and recorded packs.  Everything else is stateless: kernels read only
  *     their arguments, so forward / backward calls on different streams of one process are safe as long as they
@@ -696,14 +695,6 @@ int dcs_tap_rows_wgrad_scatter(const float* gt_r, const float* gt_i, float* gw_r
  * packed under one mode are only valid under that mode (the caller re-packs after switching). */
 int dcs_set_conv_precision(int mode);
 int dcs_get_conv_precision(void);
-
-/* Schedule of the fp32 MFMA convolution kernels (forward, data gradient): 0 (default) = one patch per workgroup with a
- * synchronous gather (csrc/conv_mfma.hip), 1 = persistent workgroups with an LDS-DMA double-buffered patch
- * (csrc/conv_pipe.hip; measured at parity or behind, kept as the documented alternative).  Same GEMM, same panels, same accumulation order: the two produce bit-identical results
- * (tests/test_hip_parity.py::test_pipelined_conv_schedule_is_bit_identical); the switch exists for that test and for
- * A/B timing inside one process.  Process-wide; also read once from the environment (DCS_CONV_PIPE=1). */
-int dcs_set_conv_schedule(int mode);
-int dcs_get_conv_schedule(void);
 
 /* Deferred weight-gradient reductions.  dcs_cconv2d_bwd_weight = a partial-slab kernel + a small reduce that writes the
  * parameter layout; nothing reads a weight gradient before the optimizer, so between dcs_wgrad_defer_begin() and

@@ -809,41 +809,6 @@ def test_rnetwork_train_step_against_oracle(dev):
         assert abs(a - b) <= 2e-3 * abs(b) + 1e-3, (got, want)
 
 
-@pytest.mark.parametrize('cin,c2,cout,k,stride,up,HW', [(16, 0, 32, 5, (2, 2), (1, 1), (64, 48)), (64, 0, 128, 3, (2, 1), (1, 1), (16, 32)),
-                                                       (8, 0, 16, 7, (2, 2), (1, 1), (40, 36)), (32, 32, 16, 3, (1, 1), (2, 2), (12, 20)),
-                                                       (64, 64, 64, 3, (1, 1), (2, 1), (5, 32))])
-def test_pipelined_conv_schedule_is_bit_identical(dev, cin, c2, cout, k, stride, up, HW):
-    """csrc/conv_pipe.hip (persistent workgroups, LDS-DMA double-buffered patch, swizzled LDS image, parity planes for
-    stride 2) against csrc/conv_mfma.hip: same GEMM, same panels, same accumulation order -> identical bits, forward and
-    data gradient, incl. cat + upsample folded classes and ragged tiles."""
-    from dcsnet import ops
-    tr = up != (1, 1)
-    Cin = cin + c2
-    g = torch.Generator().manual_seed(cin + cout)
-    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
-    wshape = (Cin, cout, k, k) if tr else (cout, Cin, k, k)
-    wp, bias = ops.pack_conv_weight(rnd(*wshape) * 0.1, rnd(*wshape) * 0.1, rnd(cout), rnd(cout), tr, up)
-    x1 = rnd(3, HW[0], HW[1], cin, 2)
-    x2 = rnd(3, HW[0], HW[1], c2, 2) if c2 else None
-    pad = (k // 2, k // 2)
-    old = ops.conv_schedule()
-    try:
-        res = {}
-        for mode in ('classic', 'pipe'):
-            ops.set_conv_schedule(mode)
-            y = ops.cconv2d(x1, x2, wp, bias, (k, k), stride, pad, up)
-            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(dev)
-            wpb = ops.pack_conv_weight_bwd(wp, (k, k), stride, pad, up)
-            d = ops.cconv2d_bwd_data(gy, wpb, (HW[0], HW[1], Cin), (k, k), stride, pad, up, cin)
-            res[mode] = (y, *d)
-        torch.cuda.synchronize()
-    finally:
-        ops.set_conv_schedule(old)
-    for a, b in zip(res['classic'], res['pipe']):
-        assert (a is None and b is None) or torch.equal(a, b)
-    close(res['pipe'][0], res['classic'][0], rel=0, abs_=0)
-
-
 def _conv_fp64(x, w_r, w_i, b_r, b_i, stride, pad, gy):
     """fp64 complex conv of channels-last x [B,H,W,C,2] with the two-real-layer bias convention of complexPyTorch
     (re: b_r - b_i, im: b_r + b_i) and its gradient with respect to x for the cotangent gy."""

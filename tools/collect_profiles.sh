@@ -26,8 +26,6 @@ for mode in train infer; do
 done
 echo "[collect] sustained fp32 MFMA peak + per-layer conv tables"
 hipcc -O3 --offload-arch=gfx950 $R/tools/micro/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && timeout -k 5 120 /tmp/mfma_peak > $out/mfma_peak.txt
-hipcc -O3 --offload-arch=gfx950 $R/tools/micro/dma_rate.hip -o /tmp/dma_rate 2>/dev/null && timeout -k 5 60 /tmp/dma_rate > $out/dma_rate.txt
-timeout -k 10 300 python3 $R/tools/conv_ab.py 32 256 5 > $out/conv_ab_train.txt 2>/dev/null
 timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 32 256 > $out/conv_layers_train.txt 2>/dev/null
 timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 16 2000 > $out/conv_layers_infer.txt 2>/dev/null
 timeout -k 10 300 python3 $R/tools/conv_layers_bench.py 32 256 f32 > $out/conv_layers_train_native.txt 2>/dev/null

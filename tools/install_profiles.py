@@ -12,7 +12,7 @@ if len(sys.argv) > 2:
 for a, b in (('bench_train_default.json', 'bench_train_default.json'), ('bench_infer.json', 'bench_infer.json'),
              ('train_kernel_stats.csv', 'train_b32_t256_kernel_stats.csv'), ('infer_kernel_stats.csv', 'infer_b16_t2000_kernel_stats.csv')):
     shutil.copy(os.path.join(src, a), os.path.join(dst, f'{tag}_{b}'))
-for a in ('mfma_peak.txt', 'dma_rate.txt', 'conv_ab_train.txt', 'conv_layers_train.txt', 'conv_layers_infer.txt', 'lstm_bench.txt',
+for a in ('mfma_peak.txt', 'conv_layers_train.txt', 'conv_layers_infer.txt', 'lstm_bench.txt',
           'step_sequence_train.txt', 'step_sequence_infer.txt', 'conv_layers_train_native.txt', 'conv_layers_infer_native.txt',
           'conv_precision.txt', 'train_native_kernel_stats.csv', 'infer_native_kernel_stats.csv', 'bench_train_bf16_b64.json',
           'bench_train_f32_b64.json', 'step_sequence_train_bf16_b64.txt'):

@@ -2,7 +2,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1
-fam = [('conv mfma fwd/dgrad', ('cconv_mfma_kernel', 'cconv_mfma16_kernel', 'cconv_pipe_kernel', 'splitk_reduce')),
+fam = [('conv mfma fwd/dgrad', ('cconv_mfma_kernel', 'cconv_mfma16_kernel', 'splitk_reduce')),
        ('small-channel convs', ('cconv_k7', 'cconv_wgrad_small', 'cconv_small_dgrad', 'cconv_up1', 'cconv_enc0', 'tap_rows', 'csum_')), ('conv direct fwd/dgrad', ('cconv_direct_kernel',)),
        ('wgrad mfma', ('cconv_wgrad_mfma', 'cconv_wgrad_x6')), ('wgrad direct', ('cconv_wgrad_kernel',)), ('wgrad reduce', ('wgrad_reduce',)),
        ('weight packs', ('pack_', 'fold_taps')), ('cbn', ('cbn_',)), ('attention', ('att_', 'attention_', 'ca_', 'spatial_pool', 'sa_')),
