@@ -930,7 +930,7 @@ int launch_classes(const conv::Args& c, const Fold& f, int Hy, int Wy, const act
 
 }  // namespace
 
-#ifdef DCS_WGRAD_DIAG
+#if defined(DCS_WGRAD_DIAG) && !defined(DCS_ACT_BF16)
 extern "C" int dcs_debug_set_wgrad_buffer(void* p) { g_wdbg = (long long*)p; return 0; }
 #endif
 

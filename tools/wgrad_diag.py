@@ -1,10 +1,18 @@
-"""Phase times inside the MFMA weight-gradient kernel (needs a diagnostic build:
-DCS_EXTRA_HIPCC_FLAGS=-DDCS_WGRAD_DIAG python dcs-net_amd/build.py).  usage: python tools/wgrad_diag.py [B] [T] [layers]
+"""Phase times inside the MFMA weight-gradient kernel.  Needs a -DDCS_WGRAD_DIAG build of the library:
+  python tools/wgrad_diag.py --build   (here, no GPU: writes dcs-net_amd/lib/diag/libdcsnet_wgraddiag.so), then on the GPU box
+  DCS_LIB_PATH=dcs-net_amd/lib/diag/libdcsnet_wgraddiag.so python tools/wgrad_diag.py [B] [T] [layers]
 Per workgroup (wave 0): gather = tile-loop top -> after the gather's second barrier (incl. waiting for the other waves),
 mfma = the k-step loop, epilogue = slab stores; s_memtime = core clocks, printed as us at 2.4 GHz."""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'dcs-net_amd'))
+if '--build' in sys.argv:
+    import build
+    out = os.path.join(ROOT, 'dcs-net_amd', 'lib', 'diag')
+    os.makedirs(out, exist_ok=True)
+    build.build(flags=build.FLAGS + ['-DDCS_WGRAD_DIAG'], verbose=False, lib=os.path.join(out, 'libdcsnet_wgraddiag.so'),
+                objdir=os.path.join(out, 'obj_wgrad'))
+    sys.exit(0)
 from dcsnet import ops, _lib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
