@@ -227,9 +227,19 @@ class TrainStep:
         if os.environ.get('DCS_WGRAD_DEFER', '1') == '0':       # profiling aid: every reduction as its own kernel
             loss.backward()
             return
+        # the cotangent of the loss is a constant 1: one cached tensor instead of autograd's ones_like fill per step
+        one = self.__dict__.get('_loss_seed')
+        if one is None or one.shape != loss.shape or one.dtype != loss.dtype or one.device != loss.device:
+            if torch.cuda.is_current_stream_capturing():
+                one = None                                  # (made outside a capture only: the three eager warm-up steps do)
+            else:
+                one = self.__dict__['_loss_seed'] = torch.ones_like(loss)
         ops.wgrad_defer_begin()
         try:
-            loss.backward()
+            if one is None:
+                loss.backward()
+            else:
+                loss.backward(gradient=one)
         finally:
             ops.wgrad_defer_flush()
 
