@@ -555,7 +555,8 @@ class _LstmLayerFn(torch.autograd.Function):
                     g_wih[s_].addmm_(g_gx[s_].t(), inp)
             g_inp = None
             if ctx.needs_input_grad[0]:
-                g_inp = torch.addmm(torch.mm(g_gx[0], w_ih[0]), g_gx[1], w_ih[1])
+                g_inp = torch.mm(g_gx[0], w_ih[0])
+                g_inp.addmm_(g_gx[1], w_ih[1])              # (in place: torch.addmm copies its addend first)
             return g_inp, None, None, None, None
         if mfma_ok:
             ops.atb_chunks_acc(g_gx, inp, g_wih, 2, 8 * H, n_in, 8 * H, n_in, NT, CK)
@@ -631,14 +632,17 @@ def complex_lstm(z, real_lstm, imag_lstm):
     B, S, I = z.shape
     sets = (real_lstm, imag_lstm)
     # rows 0..B-1: real parts, rows B..2B-1: imaginary parts; both weight sets see the same input
-    x = torch.view_as_real(z).permute(3, 0, 1, 2).reshape(1, 2 * B * S, I)
-    inp = x.expand(2, -1, -1)
+    # (2-D from the start: indexing a [1, rows, I] tensor costs a zero fill and a copy in the backward of the select)
+    x2 = torch.view_as_real(z).permute(3, 0, 1, 2).reshape(2 * B * S, I)
+    inp = None
     stacked = _stacked_lstm(real_lstm) if torch.is_grad_enabled() else None
     for layer in range(real_lstm.num_layers):
         if stacked is not None:
-            out = _LstmLayerFn.apply(x[0] if layer == 0 else inp, real_lstm.weight_ih_l0, stacked[layer], 2 * B, S)
+            out = _LstmLayerFn.apply(x2 if layer == 0 else inp, real_lstm.weight_ih_l0, stacked[layer], 2 * B, S)
             inp = out.view(2, 2 * B * S, -1)
             continue
+        if inp is None:
+            inp = x2.unsqueeze(0).expand(2, -1, -1)
         w_ih, bias, w_hh = _lstm_layer_operands(sets, layer)
         if not (torch.is_grad_enabled() and (inp.requires_grad or bias.requires_grad or w_ih.requires_grad)):
             # inference: bare projection, the gate biases are added inside the recurrence kernel (baddbmm's bias broadcast was
