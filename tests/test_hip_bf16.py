@@ -78,7 +78,7 @@ def test_conv_forward_data_and_weight_gradient(dev, geom):
     ks, pd = (k, k), (pad, pad)
     y = ops.cconv2d(x1, x2, wp, bias, ks, st, pd, up, ops.ACT_NONE)
     yf = ops.cconv2d(x1f, x2f, wp, bias, ks, st, pd, up, ops.ACT_NONE)
-    if C1 == 1:            # conv_enc0.hip multiplies on the fp32 MFMA in both builds: same accumulators
+    if C1 == 1:            # conv_enc0.hip: the bf16-operand kernel with one plane in both builds (the operands are bf16-representable): same accumulators
         _same_after_rounding(y, yf, 'forward (enc0)')
     else:
         _same_after_rounding(y, yf, 'forward')

@@ -826,7 +826,8 @@ def _conv_fp64(x, w_r, w_i, b_r, b_i, stride, pad, gy):
     return y.detach(), x64.grad, torch.cat((wr.grad.flatten(), wi.grad.flatten()))
 
 
-@pytest.mark.parametrize('geom', [(4, 16, 32, 64, 128, 3, (2, 1)), (2, 48, 40, 16, 32, 5, (2, 2)), (2, 8, 32, 128, 128, 3, (1, 1))])
+@pytest.mark.parametrize('geom', [(4, 16, 32, 64, 128, 3, (2, 1)), (2, 48, 40, 16, 32, 5, (2, 2)), (2, 8, 32, 128, 128, 3, (1, 1)),
+                                  (2, 64, 96, 1, 8, 7, (2, 2))])       # the last: enc0 (conv_enc0.hip, cconv_enc0b_kernel: 16x16x32 bf16 MFMAs)
 def test_f32_emulation_on_the_bf16_mfma_is_at_least_as_accurate_as_the_native_mfma(dev, geom):
     """Precision mode 'bf16x6' (the default): every fp32 operand split exactly into three bf16 terms, six bf16 MFMAs per
     product group, fp32 accumulation (conv_mfma.hip, PR = 2; conv_wgrad_mfma.hip, cconv_wgrad_x6_kernel).  Criterion: distance
