@@ -19,15 +19,17 @@ constexpr int kThreads = 256;
 __device__ __forceinline__ float2 unit_dir(float x, float y) {
     const float h = hypotf(x, y);
     if (h == 0.f) return make_float2(1.f, 0.f);       // atan2(0, 0) = 0
-    return make_float2(x / h, y / h);
+    const float ih = __builtin_amdgcn_rcpf(h);        // (v_rcp_f32 + multiplies instead of IEEE divisions: mask.hip)
+    return make_float2(x * ih, y * ih);
 }
 // d unit_dir(v) / dv applied to a cotangent: (g - u (u.g)) / |v|   (0 at the singular point)
 __device__ __forceinline__ float2 unit_dir_bwd(float x, float y, float2 g) {
     const float h = hypotf(x, y);
     if (h == 0.f) return make_float2(0.f, 0.f);
-    const float ux = x / h, uy = y / h;
+    const float ih = __builtin_amdgcn_rcpf(h);
+    const float ux = x * ih, uy = y * ih;
     const float d = ux * g.x + uy * g.y;
-    return make_float2((g.x - ux * d) / h, (g.y - uy * d) / h);
+    return make_float2((g.x - ux * d) * ih, (g.y - uy * d) * ih);
 }
 
 // grid (ceil(T/32), ceil(Fp/32), B); block 32 x 8
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void polar_frames_bwd_kernel(const float2
             const float2 d = unit_dir(v.x + eps, v.y);
             const float dot = d.x * go.x + d.y * go.y;
             float2 o = unit_dir_bwd(v.x + eps, v.y, make_float2(m * go.x, m * go.y));
-            if (m > 0.f) { o.x += dot * v.x / m; o.y += dot * v.y / m; }
+            if (m > 0.f) { const float im = __builtin_amdgcn_rcpf(m); o.x += dot * v.x * im; o.y += dot * v.y * im; }
             gz[i] = o;
         }
     }
