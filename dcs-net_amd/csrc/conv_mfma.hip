@@ -909,6 +909,9 @@ int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
             if (p.CH == 16) return launch_ch<WAVES_N, WM, WN, 16, WK>(m, npix, stream);
             if (p.CH == 8) return launch_ch<WAVES_N, WM, WN, 8, WK>(m, npix, stream);
         }
+        if constexpr (WK == 4 && WM == 2) {                            // (enc1: the taps over four waves)
+            if (p.CH == 8) return launch_ch<WAVES_N, WM, WN, 8, WK>(m, npix, stream);
+        }
         return DCS_ERR_BADARG;
     } else {
         switch (p.CH) {
@@ -933,8 +936,9 @@ int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
 
 struct Cand { int bm, bn, wk; };
 // (pixels, columns, waves along K): the last two are the K-split tiles of the few-pixel layers (cconv_mfma_kernel, WK)
-// and {64, 32, 2}: the LDS-bound 7x7 / 8-channel layer (enc1) — half the tile, so three workgroups share a CU instead of one
-constexpr Cand kCands[] = {{128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {128, 32, 1}, {32, 64, 2}, {32, 32, 4}, {64, 32, 2}, {64, 64, 2}};
+// and {64, 32, 2} / {64, 32, 4}: the LDS-bound 7x7 / 8-channel layer (enc1) — half the tile, so three workgroups share a CU instead of one;
+// {64, 64, 2}: the un-sliced 64 x 64 launches with each B fragment feeding two MFMA sets
+constexpr Cand kCands[] = {{128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {128, 32, 1}, {32, 64, 2}, {32, 32, 4}, {64, 32, 2}, {64, 64, 2}, {64, 32, 4}};
 
 // tile, chunk depth and K slices for geometry `a` (FULL output extent in Hout/Wout) and its classes
 bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, long* npix_out) {
@@ -1011,6 +1015,11 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
         double eff;
         const long blocks = blocks_of(6, &eff);
         if (blocks * eff >= min_blocks) { best = 6; best_blocks = blocks; best_useful = blocks * eff; p->wk = 2; }
+        // ... or, better, over FOUR waves that each cover all 64 pixels (WM = 2): a B fragment then feeds two MFMA sets — half the
+        // L1 traffic of the two-wave form, whose waves fetch every tap's fragment for one 32-pixel half each (61.7 -> 55.6 us at
+        // the train shapes, 201.7 -> 173.7 us at the inference shapes)
+        static const int enc1_wk4 = [] { const char* e = getenv("DCS_MFMA_ENC1_WK4"); return e ? atoi(e) : 1; }();
+        if (best == 6 && enc1_wk4) { best = 8; p->wk = 4; }
     }
     if (p->wk == 1 && best_useful < split_below) {
         const double reuse[4] = {1.0, 0.9, 0.8, 0.7};
@@ -1058,7 +1067,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
     if (p->wk > 1 && best != 7) {                                              // K split over waves: the deepest chunk that fits (<= 56 KB)
-        if (best == 6) p->CH = 8;
+        if (best == 6 || best == 8) p->CH = 8;
         else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 56L * 1024) p->CH = 32;
         else if (p->wk == 2 && Cin % 16 == 0 && npix * pixw(16) * 4 <= 56L * 1024) p->CH = 16;
         else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 150L * 1024) p->CH = 32;
@@ -1218,6 +1227,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         case 5: rc = launch<1, 1, 1, 4>(m, p, npix, stream); break;   //  32 x 32, four waves along K
         case 6: rc = launch<1, 1, 1, 2>(m, p, npix, stream); break;   //  64 x 32, two waves along K (taps)
         case 7: rc = launch<2, 2, 1, 2>(m, p, npix, stream); break;   //  64 x 64, two waves along K
+        case 8: rc = launch<1, 2, 1, 4>(m, p, npix, stream); break;   //  64 x 32, four waves along K (taps), 64 pixels each
         default: rc = launch<1, 1, 1>(m, p, npix, stream); break;     // 128 x 32
     }
     if (rc != DCS_OK || m.ksplit <= 1) return rc;
