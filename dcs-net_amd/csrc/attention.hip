@@ -110,14 +110,9 @@ __device__ __forceinline__ void ca_fc_kernel_body(const double* __restrict__ par
     }
 }
 
-__device__ __forceinline__ float group_sum(float v, int G) {
-    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float group_max(float v, int G) {
-    for (int o = G >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+// per-pixel reductions over the G lanes of a pixel: DPP inside a row of 16 lanes (dcs_common.h)
+__device__ __forceinline__ float group_sum(float v, int G) { return dcs_group_sum(v, G); }
+__device__ __forceinline__ float group_max(float v, int G) { return dcs_group_max(v, G); }
 
 // pooled[b][p] = { mean_c z , max_c Re z + j max_c Im z },  z = ca[b][c] * x[b][p][c]
 __device__ __forceinline__ void spatial_pool_kernel_body(const act_t* __restrict__ x,

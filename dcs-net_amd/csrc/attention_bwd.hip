@@ -53,18 +53,10 @@ inline int chunks_for(long HW, int G) {
     return (int)(nb < 1 ? 1 : (nb > kMaxChunks ? kMaxChunks : nb));
 }
 
-__device__ __forceinline__ float gsum(float v, int G) {
-    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float gmax(float v, int G) {
-    for (int o = G >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ int gmin_i(int v, int G) {
-    for (int o = G >> 1; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
-}
+// per-pixel reductions over the G lanes of a pixel: DPP inside a row of 16 lanes (dcs_common.h)
+__device__ __forceinline__ float gsum(float v, int G) { return dcs_group_sum(v, G); }
+__device__ __forceinline__ float gmax(float v, int G) { return dcs_group_max(v, G); }
+__device__ __forceinline__ int gmin_i(int v, int G) { return dcs_group_min_i(v, G); }
 
 template <bool DROP>
 __device__ __forceinline__ float4 masked(float4 g, uint64_t seed, uint64_t e, float p, float inv_keep) {

@@ -129,6 +129,35 @@ __device__ __forceinline__ float dcs_dpp_term(float v) {
     // lanes without a valid source (shifted in from outside the row, or masked rows) contribute 0
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
+// All-reduce over the G lanes that share a pixel (G a power of two <= 64, groups aligned to G): the steps inside a row of 16
+// lanes are DPP moves — quad_perm [1,0,3,2] and [2,3,0,1] (xor 1, xor 2), row_half_mirror (lane i <-> 7 - i: the other quad of an
+// 8-lane group, which already holds its own sum), row_mirror (i <-> 15 - i) — one VALU instruction each; only the 32- and 64-lane
+// steps go through the LDS crossbar.  As __shfl_xor (ds_bpermute + s_waitcnt) every step was an LDS operation: the per-pixel
+// channel reductions of the attention kernels ran at half their streaming rate on the 8- and 16-channel maps.
+template <int CTRL>
+__device__ __forceinline__ float dcs_dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dcs_dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+#define DCS_GROUP_REDUCE(NAME, T, MOV, OP)                                                   \
+    __device__ __forceinline__ T NAME(T v, int G) {                                         \
+        if (G >= 2) { const T o = MOV<0xB1>(v); v = OP(v, o); }                             \
+        if (G >= 4) { const T o = MOV<0x4E>(v); v = OP(v, o); }                             \
+        if (G >= 8) { const T o = MOV<0x141>(v); v = OP(v, o); }                            \
+        if (G >= 16) { const T o = MOV<0x140>(v); v = OP(v, o); }                           \
+        if (G >= 32) { const T o = __shfl_xor(v, 16, 64); v = OP(v, o); }                   \
+        if (G >= 64) { const T o = __shfl_xor(v, 32, 64); v = OP(v, o); }                   \
+        return v;                                                                           \
+    }
+__device__ __forceinline__ float dcs_op_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float dcs_op_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ int dcs_op_min_i(int a, int b) { return a < b ? a : b; }
+DCS_GROUP_REDUCE(dcs_group_sum, float, dcs_dpp_mov, dcs_op_add)
+DCS_GROUP_REDUCE(dcs_group_max, float, dcs_dpp_mov, dcs_op_max)
+DCS_GROUP_REDUCE(dcs_group_min_i, int, dcs_dpp_mov_i, dcs_op_min_i)
+#undef DCS_GROUP_REDUCE
+
 __device__ __forceinline__ float dcs_wave_sum_lane63(float v) {
     v += dcs_dpp_term<0x111, 0xf>(v);        // row_shr:1
     v += dcs_dpp_term<0x112, 0xf>(v);        // row_shr:2
