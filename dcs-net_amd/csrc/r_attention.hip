@@ -39,14 +39,9 @@ inline int rstream_grid(long HW, int G, int B) {
     return (int)(nb < 1 ? 1 : nb);
 }
 
-__device__ __forceinline__ float gsum(float v, int G) {
-    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float gmax(float v, int G) {
-    for (int o = G >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+// per-pixel reductions over the G lanes of a pixel: DPP inside a row of 16 lanes (dcs_common.h)
+__device__ __forceinline__ float gsum(float v, int G) { return dcs_group_sum(v, G); }
+__device__ __forceinline__ float gmax(float v, int G) { return dcs_group_max(v, G); }
 
 // part[b][chunk][C]: max over this chunk's pixels
 __global__ __launch_bounds__(kThreads) void r_ca_maxpool_kernel(const float* __restrict__ x, float* __restrict__ part, long HW,
