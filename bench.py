@@ -162,40 +162,66 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def _cpu_infer_sample(T, threads, budget_s, iters=2):
+def _timed_protocol(one, what, budget_s, warmup=3, timed=10):
+    """BASELINE.md "CPU baseline plan": >= 3 warm-up and >= 10 timed repetitions, median — bounded by a wall-clock budget
+    (the default bench.py run has to finish within minutes): when the budget truncates the protocol the note says so.
+    Returns (median seconds per repetition, note)."""
+    t_begin = time.perf_counter()
+    done_w = 0
+    for _ in range(warmup):
+        one()
+        done_w += 1
+        if time.perf_counter() - t_begin > 0.3 * budget_s:
+            break
+    if done_w == 1:
+        print(f'[bench] cpu baseline: {what}: first repetition {time.perf_counter() - t_begin:.1f} s', file=sys.stderr, flush=True)
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > budget_s:
+            break
+    ts.sort()
+    note = f'{len(ts)} timed repetitions after {done_w} warm-up, median'
+    if done_w < warmup or len(ts) < timed:
+        note += f' (protocol is {warmup} + {timed}: truncated by the {budget_s:.0f} s wall-clock budget)'
+        print(f'[bench] cpu baseline: {what}: truncated by the {budget_s:.0f} s budget after {done_w} warm-up + {len(ts)} timed',
+              file=sys.stderr, flush=True)
+    return ts[len(ts) // 2], note
+
+
+def _cpu_infer_sample(Bs, T, threads, budget_s):
     from oracle.cnet_oracle import C_NETWORK_Oracle
     from oracle.nf_oracle import mask_apply_subtract
     from oracle.seeded_state import fill_state, seeded_input
     torch.set_num_threads(threads)
     net = fill_state(C_NETWORK_Oracle({'dropout_conv': 0.0, 'dropout_fc': 0.0}), 0).eval()
-    x = seeded_input(1, 256, T, seed=0, scale=0.1)
-    print(f'[bench] cpu baseline: oracle forward, T={T}, on {torch.get_num_threads()} thread(s) ...', file=sys.stderr, flush=True)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        mask_apply_subtract(x, net(x))
-        first = time.perf_counter() - t0
-        print(f'[bench] cpu baseline: first pass {first:.1f} s', file=sys.stderr, flush=True)
-        n = max(1, min(iters, int(budget_s / max(first, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(n):
+    x = seeded_input(Bs, 256, T, seed=0, scale=0.1)
+    print(f'[bench] cpu baseline: oracle forward, B={Bs}, T={T}, on {torch.get_num_threads()} thread(s) ...', file=sys.stderr, flush=True)
+
+    def one():
+        with torch.no_grad():
             mask_apply_subtract(x, net(x))
-        dt = (time.perf_counter() - t0) / n
-    return T / dt, n
+    dt, note = _timed_protocol(one, f'forward B={Bs} T={T} x{threads}', budget_s)
+    return Bs * T / dt, note
 
 
-def cpu_baseline(T, iters=6):
-    v, n = _cpu_infer_sample(T, host_cores(), 15.0, iters)
+def cpu_baseline(B, T):
+    """configs[1] on the host cores: the GPU run's own batch on all the cores this process may use (identical
+    inputs and batch sizes), and one utterance on ONE thread."""
+    v, note = _cpu_infer_sample(B, T, host_cores(), 75.0)
     cores = torch.get_num_threads()
-    T1 = min(T, 400)                      # one thread: a 400-frame utterance keeps the sample within seconds
-    v1, n1 = _cpu_infer_sample(T1, 1, 8.0, 4)
+    T1 = min(T, 400)                      # one thread: a 400-frame utterance keeps the sample within the budget
+    v1, note1 = _cpu_infer_sample(1, T1, 1, 25.0)
     return {'value': v, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle C_NETWORK eval forward + mask apply, B=1, T={T}, {n} timed passes after 1 warm-up',
+            'sample': f'oracle C_NETWORK eval forward + mask apply, B={B}, T={T}: {note}',
             'single_thread': {'value': v1, 'unit': 'frames/s', 'cores': 1,
-                              'sample': f'the same pass, B=1, T={T1}, {n1} timed pass(es) after 1 warm-up'}}
+                              'sample': f'the same pass, B=1, T={T1}: {note1}'}}
 
 
 def _cpu_train_sample(Bs, T, threads, budget_s):
-    """Oracle train step (forward, SiSNR losses, backward, clip, Adam/AMSGrad) on `threads` host threads; (frames/s, n)."""
+    """Oracle train step (forward, SiSNR losses, backward, clip, Adam/AMSGrad) on `threads` host threads; (frames/s, note)."""
     from oracle.cnet_oracle import C_NETWORK_Oracle
     from oracle.nf_oracle import dcs_train_losses
     from oracle.seeded_state import fill_state, seeded_input
@@ -213,29 +239,21 @@ def _cpu_train_sample(Bs, T, threads, budget_s):
         opt.step()
 
     print(f'[bench] cpu baseline: oracle train step, B={Bs}, on {torch.get_num_threads()} thread(s) ...', file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    one()
-    first = time.perf_counter() - t0
-    print(f'[bench] cpu baseline: first step {first:.1f} s', file=sys.stderr, flush=True)
-    n = max(1, min(12, int(budget_s / max(first, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        one()
-    dt = (time.perf_counter() - t0) / n
-    return Bs * T / dt, n
+    dt, note = _timed_protocol(one, f'train step B={Bs} x{threads}', budget_s)
+    return Bs * T / dt, note
 
 
 def cpu_baseline_train(B, T):
-    """The CPU port beside the GPU number: on all the cores this process may use, and on ONE thread (BASELINE.md's plan)."""
-    Bs = min(B, 2)
-    v, n = _cpu_train_sample(Bs, T, host_cores(), 15.0)
+    """The CPU port beside the GPU number, by BASELINE.md's plan: the GPU run's batch size, >= 3 warm-up and >= 10 timed steps,
+    median, on all the cores this process may use — and on ONE thread (a smaller batch: a B = 32 step on one thread takes
+    about a minute)."""
+    v, note = _cpu_train_sample(B, T, host_cores(), 90.0)
     cores = torch.get_num_threads()
-    v1, n1 = _cpu_train_sample(1, T, 1, 8.0)
+    v1, note1 = _cpu_train_sample(min(B, 2), T, 1, 30.0)
     return {'value': v, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle C_NETWORK train step (fwd + losses + bwd + clip + Adam), B={Bs}, T={T}, '
-                      f'{n} timed steps after 1 warm-up',
+            'sample': f'oracle C_NETWORK train step (fwd + losses + bwd + clip + Adam), B={B}, T={T}: {note}',
             'single_thread': {'value': v1, 'unit': 'frames/s', 'cores': 1,
-                              'sample': f'the same step, B=1, T={T}, {n1} timed step(s) after 1 warm-up'}}
+                              'sample': f'the same step, B={min(B, 2)}, T={T}: {note1}'}}
 
 
 def pmc_traffic(mode, B, T):
@@ -331,6 +349,9 @@ def main():
     ap.add_argument('--no-native-line', action='store_true',
                     help='skip the second measurement with the native fp32 MFMA (default run, one GPU: a child process '
                          'repeats the timed region with --f32-mfma native and its numbers are attached as "native_f32_mfma")')
+    ap.add_argument('--no-sub-lines', action='store_true',
+                    help='skip the child-process measurements of the other BASELINE configs (default run, one GPU, train mode: '
+                         '"infer" = configs[1] and "bf16_b64" = configs[4]\'s per-GPU share are attached to the line)')
     ap.add_argument('--f32-mfma', default='bf16x6', choices=['native', 'bf16x6'],
                     help='how the fp32 MFMA conv forward / data gradient multiplies (--dtype f32 only): native = '
                          'v_mfma_f32_32x32x2_f32; bf16x6 = fp32 emulated on the bf16 MFMA (exact three-way bf16 splits of both '
@@ -617,7 +638,7 @@ def main():
                                'frac_vs_f32_mfma_peak': fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
                               for i, (ms, fl, emu) in enumerate(timer.tag_layers('enc_fwd'))]}
         if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline_train(B, T) if train else cpu_baseline(T)
+            line['cpu_baseline'] = cpu_baseline_train(B, T) if train else cpu_baseline(B, T)
         else:
             line['cpu_baseline'] = None
         line['native_f32_mfma'] = None
@@ -625,7 +646,7 @@ def main():
             # the same timed region on the native fp32 MFMA, in a child process (its own graph, plans and packed panels)
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), '--mode', args.mode, '--steps', str(args.steps), '--warmup',
-                   str(args.warmup), '--f32-mfma', 'native', '--no-cpu-baseline', '--no-native-line']
+                   str(args.warmup), '--f32-mfma', 'native', '--no-cpu-baseline', '--no-native-line', '--no-sub-lines']
             cmd += (['--batch', str(args.batch)] if args.batch else []) + (['--frames', str(args.frames)] if args.frames else [])
             cmd += ['--no-graph'] if args.no_graph else []
             try:
@@ -639,6 +660,32 @@ def main():
                                            'kernel_ms_per_step': nat['roofline']['kernel_ms_per_step']}
             except Exception as e:                              # the headline line must not depend on the second run
                 line['native_f32_mfma'] = {'error': repr(e)[:200]}
+        # The other single-GPU BASELINE configs, each measured by a fresh child process in this same run:
+        # configs[1] (forward-only inference, [16,256,2000]) and configs[4]'s per-GPU share (bf16 storage, B = 64 train step),
+        # each with its own roofline object — so that the driver's one `python bench.py --gpus 1` times all three.
+        line['sub_lines'] = None
+        if (world == 1 and train and args.dtype == 'f32' and conv_mode == 'bf16x6' and not args.no_sub_lines and not args.no_native_line and
+                args.batch is None and args.frames is None):
+            import subprocess
+            line['sub_lines'] = {}
+            common = ['--steps', str(args.steps), '--warmup', str(args.warmup), '--no-cpu-baseline', '--no-native-line',
+                      '--no-sub-lines'] + (['--no-graph'] if args.no_graph else [])
+            for name, extra in (('infer', ['--mode', 'infer']), ('bf16_b64', ['--mode', 'train', '--dtype', 'bf16', '--batch', '64'])):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, capture_output=True,
+                                       text=True, timeout=600)
+                    sub = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+                    rf = sub['roofline']
+                    keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel_ms_per_step', 'launches_per_step',
+                            'executed_frac', 'algorithmic_gflop_per_step', 'algorithmic_gbytes_per_step', 'mfma',
+                            'encoder_stack_forward')
+                    line['sub_lines'][name] = {'metric': sub['metric'], 'value': sub['value'], 'unit': sub['unit'],
+                                               'ms_per_step': sub['ms_per_step'], 'steps': sub['steps'], 'warmup': sub['warmup'],
+                                               'dtype': sub['dtype'].split(' ')[0], 'workload': sub['config']['workload'],
+                                               'hip_graph': sub['config']['hip_graph'],
+                                               'roofline': {k_: rf[k_] for k_ in keep if k_ in rf}}
+                except Exception as e:                          # the headline line must not depend on the extra runs
+                    line['sub_lines'][name] = {'error': repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -31,21 +31,18 @@ ACT_SOURCES = ('cbn.hip', 'cbn_bwd.hip', 'attention.hip', 'attention_bwd.hip', '
 
 
 def _mfma_source_flags():
-    """Sources whose kernels issue MFMAs are compiled WITHOUT the SLP vectoriser: it pairs adjacent scalar fp32 operations
+    """Every source is compiled WITHOUT the SLP vectoriser, except the two named below: it pairs adjacent scalar fp32 operations
     into v_pk_*_f32, and a packed FMA whose low lane takes the HIGH dword of a source pair (op_sel) loses that lane's
     product beside co-resident bf16-MFMA waves on gfx950 (profiles/r03_pk_fma_op_sel_hazard.txt); packed fp32 VALU beside
-    MFMAs is slower than the scalar form anyway (MI355X_MICROARCH.md, cycle constants).  tests/test_host_cpu.py checks the
-    built library's ISA for it."""
+    MFMAs is slower than the scalar form anyway (MI355X_MICROARCH.md, cycle constants).  Round 3 did this for the sources that
+    issue MFMAs and left 97 VALU kernels carrying such pairs, safe only under stream discipline; since round 4 no kernel of
+    the library contains one (same-box A/B of the whole step: profiles/r04_noslp_ab.txt), and tests/test_host_cpu.py scans
+    EVERY kernel of the built library for it."""
     # Where the pairing helps and forms no cross-half selection it stays on: the emulated weight-gradient kernel (its g_Y
     # split is packed: +10 % kernel time without) and lstm.hip, whose recurrence kernels (no MFMA) live beside the MFMA
     # A^T B kernel (+40 % on lstm_rec_bwd without) — measured with tools/compare_sequences.py; the ISA test guards both.
     keep_slp = ('conv_wgrad_mfma.hip', 'lstm.hip')
-    out = {}
-    for f in _sources():
-        with open(os.path.join(CSRC, f)) as fh:
-            if '__builtin_amdgcn_mfma' in fh.read() and f not in keep_slp:
-                out[f] = ['-fno-slp-vectorize']
-    return out
+    return {f: ['-fno-slp-vectorize'] for f in _sources() if f not in keep_slp}
 
 
 def _stamp(paths):

@@ -157,11 +157,13 @@ __device__ __forceinline__ void attention_apply_kernel_body(const act_t* __restr
         const float4 v = x4[r * G + g];
         float2 s = make_float2(1.f, 0.f);
         if (sa) s = sa[(long)b * HW + r];
-        const float z0r = a.x * v.x - a.y * v.y, z0i = a.x * v.y + a.y * v.x;
-        const float z1r = a.z * v.z - a.w * v.w, z1i = a.z * v.w + a.w * v.z;
+        // (explicit fused forms: left to -ffp-contract the fp32 and the bf16-storage builds of this kernel may pick different
+        // associations, and the bf16 build's output must equal the fp32 build's rounded once — tests/test_hip_bf16.py)
+        const float z0r = fmaf(a.x, v.x, -(a.y * v.y)), z0i = fmaf(a.x, v.y, a.y * v.x);
+        const float z1r = fmaf(a.z, v.z, -(a.w * v.w)), z1i = fmaf(a.z, v.w, a.w * v.z);
         float4 o;
-        o.x = s.x * z0r - s.y * z0i; o.y = s.x * z0i + s.y * z0r;
-        o.z = s.x * z1r - s.y * z1i; o.w = s.x * z1i + s.y * z1r;
+        o.x = fmaf(s.x, z0r, -(s.y * z0i)); o.y = fmaf(s.x, z0i, s.y * z0r);
+        o.z = fmaf(s.x, z1r, -(s.y * z1i)); o.w = fmaf(s.x, z1i, s.y * z1r);
         if (DROP) {
             const uint64_t e = (uint64_t)(base + r * G + g) * 4;
             o.x *= dcs_keep_scale(seed, e, drop_p, inv_keep);

@@ -27,6 +27,24 @@
 #ifndef DCS_X6_GU16
 #define DCS_X6_GU16 4
 #endif
+#ifndef DCS_EXP_LOOP
+#define DCS_EXP_LOOP 0      // timing probes of the tap loop (wrong results): 1 no A reads, 2 no B loads, 4 no gather after chunk 0
+#endif
+#ifndef DCS_MFMA_COPY_AT_TOP
+#define DCS_MFMA_COPY_AT_TOP 1
+#endif
+#ifndef DCS_MFMA_LDS_BARRIER
+#define DCS_MFMA_LDS_BARRIER 1
+#endif
+#ifndef DCS_MFMA_XCD_REMAP
+#define DCS_MFMA_XCD_REMAP 1
+#endif
+#ifndef DCS_MFMA_SCALAR_B
+#define DCS_MFMA_SCALAR_B 1
+#endif
+#ifndef DCS_MFMA_EARLY_OPERANDS
+#define DCS_MFMA_EARLY_OPERANDS 0
+#endif
 #ifndef DCS_X6_GU32
 #define DCS_X6_GU32 8       // gather loads in flight per thread at 32-channel chunks of the emulated kernel
 #endif
@@ -84,7 +102,25 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     static_assert(WK == 1 || TPI == 1, "K split over waves: tap-at-a-time loop");
     constexpr int VU = U * TPI, PIX = BF ? NP * CH + 4 : 2 * CH + 4, Q = CH / 2;
     const conv::Args& a = m.c;
-    const conv::Cls& k = m.cls[blockIdx.z];
+    // XCD-aware tile order (Round 4).  The hardware deals workgroups round-robin over the 8 XCDs (workgroup n -> XCD n % 8, each
+    // with its own 4 MB L2) and the two slots of a CU get n and n + 256: in plain (x, y, z) order every XCD saw every
+    // (column tile, class) pair — the whole three-plane B panel (dec1: 9.4 MB) streamed through each 4 MB L2 — and the two
+    // workgroups of a CU read DIFFERENT panels.  Remapped, XCD j owns a contiguous range of the logical order (x fastest): all the
+    // pixel tiles of one or two (column tile, class) pairs, i.e. ~1 MB of B that stays in its L2 and is shared by a CU's
+    // workgroups in L1.  Speed only: any placement gives the same result.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#if DCS_MFMA_XCD_REMAP
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const unsigned n = (bz * gy + by) * gx + bx, xcd = n & 7u, idx = n >> 3, q = total >> 3, r = total & 7u;
+        const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        // (the divisions run through the VALU's reciprocal: hand the quotients back to the scalar unit explicitly)
+        bx = __builtin_amdgcn_readfirstlane(L % gx);
+        by = __builtin_amdgcn_readfirstlane((L / gx) % gy);
+        bz = __builtin_amdgcn_readfirstlane(L / (gx * gy));
+    }
+#endif
+    const conv::Cls& k = m.cls[bz];
     // pixels per workgroup = (4 / (WAVES_N WK)) * WM * 32 = TH * TW
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wk = wave % WK, wq = wave / WK;
@@ -94,16 +130,16 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     const long long d_start = FDIAG_NOW();
     long long d_gather = 0, d_mfma = 0;
     const int tiles_per_img = a.tiles_w * a.tiles_h;
-    const int b = blockIdx.x / tiles_per_img, tile_id = blockIdx.x % tiles_per_img;
+    const int b = bx / tiles_per_img, tile_id = bx % tiles_per_img;
     const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
     const int ny = m.NT / (WAVES_N * WN);
-    const int kslice = blockIdx.y / ny;
-    const int nt0 = ((blockIdx.y % ny) * WAVES_N + wn) * WN;           // first 32-column tile of this wave
+    const int kslice = by / ny;
+    const int nt0 = ((by % ny) * WAVES_N + wn) * WN;           // first 32-column tile of this wave
     // STAT: CBN statistics of the raw output (a.stat, training; unsliced launches only): a row of partial sums per workgroup
     if (oy0 >= k.Hc || ox0 >= k.Wc) {                                  // tile outside this (smaller) class
         if (STAT) {
-            float* const stat_row = a.stat + ((long)blockIdx.z * gridDim.x + blockIdx.x);
-            const int stat_nt0 = (blockIdx.y % ny) * WAVES_N * WN;
+            float* const stat_row = a.stat + ((long)bz * gridDim.x + bx);
+            const int stat_nt0 = (by % ny) * WAVES_N * WN;
             for (int o = t; o < WAVES_N * WN * 80; o += 256) {
                 const int e = o % 80, c = ((stat_nt0 + o / 80) * 32 + 4 * (e & 7)) / 2 + e / 40;
                 if (c < a.Cout) stat_row[(long)(c * 5 + ((e % 40) >> 3)) * a.stat_stride] = 0.f;
@@ -123,8 +159,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         const int pi = (wm * WM + i) * 32 + li;
         pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + kk * 4 + (TSP ? 0 : wk * U * 8);   // (+ this wave's k-groups)
     }
-    const int t0 = TSP ? wk : 0;                                       // this wave's first tap
+    int t0 = TSP ? __builtin_amdgcn_readfirstlane(wk) : 0;             // this wave's first tap (wave-uniform: kept scalar)
+    if (TSP) asm volatile("" : "+s"(t0));
     const int kgo = TSP ? 0 : wk * U;                                  // ... first k-group
+    int kgo_s = __builtin_amdgcn_readfirstlane(kgo);                   // (wave-uniform: the scalar copy for the B addresses;
+    asm volatile("" : "+s"(kgo_s));                                    //  opaque, or the compiler sinks the readfirstlane below the multiplies)
     const float* bbase = m.bm + k.bm_off + ((long)nt0 * 64 + lane) * 4;
     const long b_tap_stride = (long)(BF ? m.KG / 2 : m.KG) * m.NT * 256, b_kg_stride = (long)m.NT * 256;
     const long b_plane_stride = (long)(k.kh * k.kw) * b_tap_stride;    // (PR = 2: planes of this class's panel)
@@ -153,7 +192,9 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     const char* ubase = reinterpret_cast<const char*>(m.bm + k.bm_off) +
                         (size_t)__builtin_amdgcn_readfirstlane(nt0) * 1024;
     const unsigned lane_off = (unsigned)lane * 16u;
+    bool bprobe_first = true;
     auto bload = [&](float4 (*dst)[WN], int c, int tp, int vg) {
+        if ((DCS_EXP_LOOP & 2) && !bprobe_first) return;
         tp += vg / U;
         const int g = vg % U;
         if (tp >= ntaps) { tp = TSP ? t0 : tp - ntaps; ++c; }
@@ -168,6 +209,28 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     dst[pl][j] = *reinterpret_cast<const float4*>(ubase + so + (unsigned)((pl * b_plane_stride + j * 256) * 4) + lane_off);
             return;
         }
+#if DCS_MFMA_SCALAR_B
+        // Round 4: the fragment address is wave-uniform up to the lane's 16 bytes, so it is kept on the SCALAR unit (uniform panel
+        // base + scalar byte offset + one constant lane-offset VGPR).  As per-lane 64-bit pointer arithmetic every tap cost two
+        // v_mad_u64_u32, two v_mul_lo_u32 and ~8 v_lshl_add_u64 (quarter-rate / 64-bit VALU: ~100 issue cycles per tap per wave,
+        // in order with the wave's own MFMAs): the probe that removed the B loads gained 16 % of dec1's forward, most of it this.
+        {
+            const long so = (tp * b_tap_stride + (long)(c * UALL + kgo_s + g) * b_kg_stride) * 4;     // scalar unit throughout
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    typedef __attribute__((address_space(1))) const char gchar_t;       // (the asm would otherwise leave a flat pointer)
+                    typedef float f32x4n __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(1))) const f32x4n gfloat4_t;
+                    gchar_t* sb = (gchar_t*)(ubase + (so + (pl * b_plane_stride + j * 256) * 4));
+                    unsigned lo = lane_off;
+                    asm volatile("" : "+s"(sb), "+v"(lo));             // SGPR pair + 32-bit lane offset in THIS block: global_load v, v_lo, s[base]
+                    dst[pl][j] = __builtin_bit_cast(float4, *(gfloat4_t*)(sb + lo));
+                }
+            return;
+        }
+#endif
         const float* bp = bbase + tp * b_tap_stride + (long)(c * UALL + kgo + g) * b_kg_stride;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
@@ -188,7 +251,16 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     constexpr int NTAPS_C = INPLACE ? TPI * TPI : 0;
     float4 bcur[VU][NP][WN], bnxt[INPLACE ? 1 : VU][NP][WN];
 #pragma unroll
-    for (int g = 0; g < VU; ++g) bload(bcur[g], c_begin, t0, g);
+    for (int g = 0; g < VU; ++g) bload(DCS_MFMA_COPY_AT_TOP && !INPLACE ? bnxt[INPLACE ? 0 : g] : bcur[g], c_begin, t0, g);
+    if (DCS_EXP_LOOP & 2) {
+#pragma unroll
+        for (int g = 0; g < (INPLACE || DCS_MFMA_COPY_AT_TOP ? 0 : VU); ++g)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bnxt[g][pl][j] = bcur[g][pl][j];
+        bprobe_first = false;
+    }
 
     // source pixel (index into x1 / x2, or -1 for zero) of every patch pixel: the same for all channel chunks
     int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);
@@ -246,6 +318,14 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                 float4 r = v[u];
                 float* dst = patch + (idx / Q) * PIX + (idx % Q) * 2;
+#if defined(DCS_EXP_GATHER) && DCS_EXP_GATHER == 1
+                // timing probe (wrong results): the loaded bits stored as they are, 8 bytes per plane — the gather without the
+                // VALU work of the split (what planes written once by the producer would leave: 1.5x the bytes, no conversion)
+                *reinterpret_cast<float2*>(dst) = make_float2(r.x, r.y);
+                *reinterpret_cast<float2*>(dst + CH) = make_float2(r.z, r.w);
+                *reinterpret_cast<float2*>(dst + 2 * CH) = make_float2(r.x, r.w);
+                continue;
+#endif
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     const bf16x4 h = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
@@ -265,15 +345,28 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     // (Measured and dropped: the first round of the NEXT chunk loaded into registers before this chunk's MFMA loop and stored
     // after it — +37 VGPRs take the 32-channel instances from three waves per SIMD to two and the first B-fragment wait of
     // the loop then also waits for the older patch loads: train step 3.950 -> 3.996 ms, inference 3.22 -> 3.37 ms.)
+    // The two barriers of a chunk order LDS traffic only, so they wait on the LDS counter only (Round 4).  __syncthreads() also
+    // drains vmcnt: the B fragments of the next chunk's first tap, requested during the last tap of this chunk, were waited for
+    // right there — one exposed L2 round trip per chunk (dec1: 8 chunks; the probe without B loads ran 16 % faster, and neither
+    // earlier requests, scalar addressing nor an XCD-local tile order recovered any of it).  Now they fly under the gather.
+#if DCS_MFMA_LDS_BARRIER
+#define DCS_CHUNK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define DCS_CHUNK_BARRIER() __syncthreads()
+#endif
     for (int ch = c_begin; ch < n_chunks; ++ch) {
         const long long g0 = FDIAG_NOW();
-        __syncthreads();                                               // previous chunk fully consumed
+        DCS_CHUNK_BARRIER();                                           // previous chunk fully consumed
+#if (defined(DCS_EXP_GATHER) && DCS_EXP_GATHER == 2) || (DCS_EXP_LOOP & 4)
+        // timing probe (wrong results): no gather at all after the first chunk — what a perfectly hidden gather would leave
+        if (ch == c_begin)
+#endif
         for (int base = t; base < nslots; base += 256 * GU) {
             raw_t v[GU];
             gissue(v, base, ch);
             gstore(v, base);
         }
-        __syncthreads();
+        DCS_CHUNK_BARRIER();
         const long long g1 = FDIAG_NOW();
         d_gather += g1 - g0;
         float4 af[2][NP][WM];
@@ -284,6 +377,19 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         int tapoff = tapoff0;                                          // LDS float offset of the current tap
 #pragma unroll(INPLACE ? TPI : 1)
         for (int tap = t0; tap < (INPLACE ? NTAPS_C : ntaps); tap += TSTEP) {
+#if DCS_MFMA_COPY_AT_TOP
+            // Round 4: the prefetched set moves over at the TOP of a tap, not at its end.  At the end, the last tap of a chunk
+            // waited (vmcnt) for the next chunk's first fragments — requested half a tap earlier — BEFORE the gather: one exposed
+            // L2 round trip per chunk.  Now that request flies under the gather's two barriers and its own memory round trip.
+            if (!INPLACE) {
+#pragma unroll
+                for (int g = 0; g < VU; ++g)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) bcur[g][pl][j] = bnxt[INPLACE ? 0 : g][pl][j];
+            }
+#endif
             const int tap2 = tap + TSTEP < ntaps ? tap + TSTEP : tap;  // clamped: the last prefetch re-reads this tap
             const int tapoff2 = ((tap2 / k.kw) * cols + (tap2 % k.kw)) * PIX;
 #pragma unroll
@@ -292,9 +398,23 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                    for (int i = 0; i < WM; ++i)
+                    for (int i = 0; i < WM; ++i) {
+                        if (DCS_EXP_LOOP & 1) { af[(g + 1) & 1][pl][i] = af[g & 1][pl][i]; continue; }
                         af[(g + 1) & 1][pl][i] = *reinterpret_cast<const float4*>(
                             patch + pixoff[i] + pl * CH + (g + 1 < VU ? tapoff + ((g + 1) / U) * PIX + ((g + 1) % U) * 8 : tapoff2));
+                    }
+#if DCS_MFMA_EARLY_OPERANDS
+                // Round 4: both operand streams are issued AHEAD of this k-group's MFMAs.  Left to the scheduler the LDS reads of
+                // the next k-group sank to just before this group's last MFMA (one MFMA = 32 cycles of cover for a ~100-cycle LDS
+                // round trip, every k-group), and the next tap's B fragments were requested after the first k-group's MFMAs, i.e.
+                // U - 1 k-groups before the copy that waits for them (one k-group, ~400 cycles, on the two-wave K-split tiles).
+                if (DCS_MFMA_EARLY_OPERANDS == 1 && !INPLACE && g * LPG < VU) {
+#pragma unroll
+                    for (int q = 0; q < LPG; ++q)
+                        if (g * LPG + q < VU) bload(bnxt[INPLACE ? 0 : g * LPG + q], ch, tap + TSTEP, g * LPG + q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 // MFMAs straight from the ring slot ...
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
@@ -322,14 +442,14 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (INPLACE) {
                     bload(bcur[g], ch, tap + TSTEP, g);
-                } else if (g * LPG < VU) {
+                } else if (DCS_MFMA_EARLY_OPERANDS != 1 && g * LPG < VU) {
 #pragma unroll
                     for (int q = 0; q < LPG; ++q)
                         if (g * LPG + q < VU) bload(bnxt[INPLACE ? 0 : g * LPG + q], ch, tap + TSTEP, g * LPG + q);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!INPLACE) {
+            if (!INPLACE && !DCS_MFMA_COPY_AT_TOP) {
 #pragma unroll
                 for (int g = 0; g < VU; ++g)
 #pragma unroll
@@ -351,7 +471,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #ifdef DCS_FWD_DIAG
     auto diag_out = [&]() {
         if (m.dbg && lane == 0 && wave == 0) {
-            const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const long wg = ((long)bz * gridDim.y + by) * gridDim.x + bx;
             if (wg < 16384) {
                 long long* d = m.dbg + wg * 8;
                 const long long e = FDIAG_NOW();
@@ -531,8 +651,8 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         // lanes c4 + 8 r8 hold the same two channels: sum over r8 through the wave's own transpose tile (in-order LDS), then
         // over the waves that share a column tile (different pixel rows wm) through `comb`, one row of partial sums per workgroup
         float* comb = patch + 4 * 32 * TP;                             // [wave][j][80]
-        float* const stat_row = a.stat + ((long)blockIdx.z * gridDim.x + blockIdx.x);
-        const int stat_nt0 = (blockIdx.y % ny) * WAVES_N * WN;
+        float* const stat_row = a.stat + ((long)bz * gridDim.x + bx);
+        const int stat_nt0 = (by % ny) * WAVES_N * WN;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
 #pragma unroll

@@ -31,7 +31,7 @@ struct Up1Args {
 template <typename IT>
 __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
     __shared__ __attribute__((aligned(16))) float2 tile[CIN][HR * HCP];
-    __shared__ float2 wf[4][2][2][CIN];                          // [parity class][a][b][ci]
+    __shared__ __attribute__((aligned(16))) float4 wf[4][2][2][CIN];     // [parity class][a][b][ci], {w.x, w.y, w.y, w.x}: both broadcasts read a LOW half
     const int t = threadIdx.x, b = blockIdx.y;
     const int m0 = ((int)blockIdx.x / p.tiles_w) * SRT, n0 = ((int)blockIdx.x % p.tiles_w) * SCT;
 
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
                 const float2 w = p.wt[ci * p.ct + dy * 3 + dx];
                 s.x += w.x; s.y += w.y;
             }
-        wf[cls][aa][bb][ci] = s;
+        wf[cls][aa][bb][ci] = make_float4(s.x, s.y, s.y, s.x);
     }
     // haloed source tile, channel-major planes; one float4 (2 channels) per load.  All of a thread's loads are issued
     // before the first LDS write (a load -> wait -> write loop pays one memory round trip per element: 11 per tile)
@@ -83,29 +83,34 @@ __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
 
     const int cls = t >> 6, py = cls >> 1, px = cls & 1;
     const int u = t & 63, m = u >> 3, nq = (u & 7) * 4;
-    v2f acc[4];
+    // two accumulators per output, P += w.x * x and Q += w.y * x, combined at the end (conv_k7.hip: no rotated operand, hence
+    // no cross-half operand selection in the packed FMAs)
+    v2f accp[4], accq[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = v2f{0.f, 0.f};
+    for (int q = 0; q < 4; ++q) { accp[q] = v2f{0.f, 0.f}; accq[q] = v2f{0.f, 0.f}; }
 #pragma unroll 4
     for (int ci = 0; ci < CIN; ++ci) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const float2* row = &tile[ci][(m + a + py) * HCP + nq + px];
-            v2f xv[5], xr[5];
+            v2f xv[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) { const float2 v = row[j]; xv[j] = v2f{v.x, v.y}; xr[j] = v2f{-v.y, v.x}; }
+            for (int j = 0; j < 5; ++j) { const float2 v = row[j]; xv[j] = v2f{v.x, v.y}; }
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
-                const float2 w = wf[cls][a][bb][ci];
-                const v2f wx = v2f{w.x, w.x}, wy = v2f{w.y, w.y};
+                const float4 w = wf[cls][a][bb][ci];
+                const v2f wx = v2f{w.x, w.x}, wy = v2f{w.z, w.z};          // (no cross-half operand selection: dcs_common.h)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    acc[q] = __builtin_elementwise_fma(wx, xv[q + bb], acc[q]);
-                    acc[q] = __builtin_elementwise_fma(wy, xr[q + bb], acc[q]);
+                    accp[q] = __builtin_elementwise_fma(wx, xv[q + bb], accp[q]);
+                    accq[q] = __builtin_elementwise_fma(wy, xv[q + bb], accq[q]);
                 }
             }
         }
     }
+    v2f acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = v2f{accp[q].x - accq[q].y, accp[q].y + accq[q].x};
     const float br = p.b_r ? p.b_r[0] : 0.f, bi = p.b_i ? p.b_i[0] : 0.f;
     const int sy = m0 + m;
     if (sy >= p.Hs) return;

@@ -91,12 +91,12 @@ __device__ __forceinline__ void wgrad_small_body(const SArgs& w, int bid, SmallL
                 for (int dx = 0; dx < KS; ++dx) {
                     const int tp = dy * KS + dx;
                     const float2 x0 = base[dy * COLSP + dx];
-                    const v2f xx = v2f{x0.x, x0.x}, xy = v2f{x0.y, x0.y};
+                    const v2f xx = v2f{x0.x, x0.x}, xy = dcs_bcast2(x0.y);        // (high half broadcast by moves, not by op_sel)
                     acc[tp][0] = __builtin_elementwise_fma(xx, g0v, __builtin_elementwise_fma(xy, g0r, acc[tp][0]));
                     if (MODE == 0) {
                         const float2 x1 = base[PLANE + dy * COLSP + dx];
                         acc[tp][1] = __builtin_elementwise_fma(v2f{x1.x, x1.x}, g0v,
-                                                               __builtin_elementwise_fma(v2f{x1.y, x1.y}, g0r, acc[tp][1]));
+                                                               __builtin_elementwise_fma(dcs_bcast2(x1.y), g0r, acc[tp][1]));
                     } else {
                         acc[tp][1] = __builtin_elementwise_fma(xx, g1v, __builtin_elementwise_fma(xy, g1r, acc[tp][1]));
                     }

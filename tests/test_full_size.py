@@ -139,6 +139,77 @@ def oracle_step():
     return out
 
 
+class _AttentionBackwardSpy:
+    """Records, for every attention block of one EAGER train step, what its backward node received: the block's input and
+    the cotangent of its output (skip attentions: the batched node; decoder attentions: the CBN + attention node, whose
+    attention part starts at the saved activation `a`).  Used by the structural criterion below."""
+
+    def __init__(self):
+        self.skip, self.dec = {}, []
+
+    def __enter__(self):
+        from dcsnet import functional as F
+        self.F = F
+        self._blocks, self._cbn_att = F._AttentionBlocksFn.backward, F._CbnAttentionFn.backward
+        spy = self
+
+        def blocks_bwd(ctx, *g_outs):
+            t = ctx.saved_tensors
+            for i in range(ctx.n):
+                if g_outs[i] is not None:
+                    spy.skip[i] = (t[9 * i].detach().clone(), g_outs[i].detach().clone())
+            return spy._blocks(ctx, *g_outs)
+
+        def cbn_att_bwd(ctx, g_out):
+            spy.dec.append((ctx.saved_tensors[4].detach().clone(), g_out.detach().clone()))      # (a, g_out), stages 5, 4, .. 0
+            return spy._cbn_att(ctx, g_out)
+
+        F._AttentionBlocksFn.backward = staticmethod(blocks_bwd)
+        F._CbnAttentionFn.backward = staticmethod(cbn_att_bwd)
+        return self
+
+    def __exit__(self, *exc):
+        self.F._AttentionBlocksFn.backward = staticmethod(self._blocks)
+        self.F._CbnAttentionFn.backward = staticmethod(self._cbn_att)
+
+    def block_io(self, family, blk):
+        if family == 'skip_attention':
+            return self.skip[blk]
+        assert len(self.dec) == 6, len(self.dec)
+        return self.dec[5 - blk]
+
+
+def _exact_block_gradients(x_hip, g_hip, params, prefix_ca, prefix_sa):
+    """The attention block (channel attention, spatial attention and both applications: c_network.py:53-84, :208-211)
+    re-differentiated in fp64 through the oracle's modules from the HIP path's OWN input and output cotangent
+    (channels-last interleaved [B,H,W,C,2] tensors): {parameter name: exact gradient for those inputs}."""
+    from oracle import cpt_oracle, nf_oracle
+    from oracle.cnet_oracle import ComplexChannelAttention, ComplexSpatialAttention
+    from dcsnet.config import hparams
+    cx = lambda t: torch.view_as_complex(t.detach().cpu().double().contiguous()).permute(0, 3, 1, 2).contiguous()
+    x = cx(x_hip).requires_grad_(True)
+    g = cx(g_hip)
+    cpt_oracle.CDTYPE = nf_oracle.CDTYPE = torch.complex128
+    try:
+        ca = ComplexChannelAttention(x.shape[1], hparams['channel_attention_reduction_ratio']).double()
+        sa = ComplexSpatialAttention(hparams['spatial_attention_kernel_size']).double()
+        ca.load_state_dict({k[len(prefix_ca):]: v.detach().cpu().double() for k, v in params.items() if k.startswith(prefix_ca)})
+        sa.load_state_dict({k[len(prefix_sa):]: v.detach().cpu().double() for k, v in params.items() if k.startswith(prefix_sa)})
+        z = ca(x) * x
+        y = sa(z) * z
+        torch.view_as_real(y).mul(torch.view_as_real(g)).sum().backward()      # pairing of a complex cotangent: sum Re(conj(g) y)
+    finally:
+        cpt_oracle.CDTYPE = nf_oracle.CDTYPE = torch.complex64
+    out = {prefix_ca + n: q.grad.detach() for n, q in ca.named_parameters()}
+    out.update({prefix_sa + n: q.grad.detach() for n, q in sa.named_parameters()})
+    return out
+
+
+# gradients of the eager run that passed the structural criterion: the graph-replayed run may only exceed the per-tensor
+# bound on the SAME tensors, with the same values (its backward does not pass through Python, so it cannot be intercepted)
+_STRUCTURALLY_VALIDATED = {}
+
+
 @pytest.mark.parametrize('use_graph', [False, True])
 def test_train_step_at_bench_size_against_oracle(dev, oracle_step, use_graph):
     """BASELINE configs[2] as `bench.py` runs it (dropout off for comparability), every one of the 222 gradient tensors:
@@ -155,8 +226,13 @@ def test_train_step_at_bench_size_against_oracle(dev, oracle_step, use_graph):
     net.hparams['optim_weight_decay'] = 0.0
     ts = TrainStep(net, use_graph=use_graph, graph_warmup=1)
     batch = (noise.to(dev), noisy.to(dev), clean.to(dev), list(range(TRAIN_B)))
-    for _ in range(3 if use_graph else 1):
-        loss = ts(batch)
+    spy = None
+    if use_graph:
+        for _ in range(3):
+            loss = ts(batch)
+    else:
+        with _AttentionBackwardSpy() as spy:
+            loss = ts(batch)
     torch.cuda.synchronize()
     if use_graph:
         assert ts._graph is not None, 'capture did not happen (fell back to eager)'
@@ -191,15 +267,45 @@ def test_train_step_at_bench_size_against_oracle(dev, oracle_step, use_graph):
         if e_hip > worst[0]:
             worst = (e_hip, n)
     assert len(ratios) >= 170
-    # Per tensor: rel-L2 <= 1.5e-2 vs fp64, with room for ONE cancellation-dominated tensor up to 5e-2.  Measured
-    # (profiles/r03_grad_noise_variants.json, tools/grad_noise_variants.py): across nine numerically equivalent evaluations of
-    # this step by the HIP path (kernel plans, arithmetic modes, statistics kernels) `skip_attention.10.fc.0.conv_i.weight` —
-    # the imaginary part of a 32-term batch sum over ONE hidden unit — lands between 2.9e-3 and 1.94e-2, and the CPU fp32
-    # oracle moves 4x between 1 and 32 threads; tools/skip_att_grad_probe.py re-differentiates that block in fp64 from the HIP
-    # path's own inputs: the block's kernels are exact to 3e-6, its input as close to fp64 as the CPU's (3.3e-7 vs 3.8e-7), and
-    # the exact backward of those inputs is as far from the oracle as the kernels' result (profiles/r03_skip_att_grad_probe.txt):
-    # the distance is the fp32 noise of the cotangent (2e-3 on the CPU path too), amplified by the cancellation.
-    assert len(over) <= 1 and all(('attention' in n and '.fc.' in n) for n, _, _ in over), over
+    # Per tensor: rel-L2 <= 1.5e-2 vs fp64.  A tensor ABOVE that bound (up to 5e-2) must earn it structurally (VERDICT r3
+    # item 6): it has to be a parameter of an attention block — cancellation-dominated batch sums over one hidden unit, whose
+    # distance to the oracle is inherited from the fp32 noise of the cotangent (profiles/r03_grad_noise_variants.json: the same
+    # tensor lands anywhere in 2.9e-3 .. 1.94e-2 across nine numerically equivalent evaluations) — AND the block's backward
+    # kernels must agree to 1e-5 with an fp64 re-differentiation of that block from the HIP path's own input and cotangent
+    # (|hip - exact(block)|; measured 1e-7 .. 3e-6: profiles/r03_skip_att_grad_probe.txt).  A real kernel regression in an
+    # attention FC therefore cannot hide inside the 5e-2: it shows up in |hip - exact(block)|.
+    import re as _re
+    structural = []
+    for n, e_hip, e_f32 in over:
+        mm = _re.match(r'(skip_attention|decoder_attention)\.(\d+)\.', n)
+        assert mm, f'{n}: rel-L2 {e_hip:.2e} vs fp64 (fp32 oracle {e_f32:.2e}) and not an attention-block parameter'
+        g_hip = pd[n].grad.detach().cpu().double()
+        if spy is None:                               # graph replay: the same tensor, the same value as the validated eager run
+            assert n in _STRUCTURALLY_VALIDATED, f'{n}: {e_hip:.2e} vs fp64 in the replayed step, not validated in the eager one'
+            d = float((g_hip - _STRUCTURALLY_VALIDATED[n]).norm() / _STRUCTURALLY_VALIDATED[n].norm())
+            assert d <= 1e-6, (n, d)
+            structural.append((n, e_hip, 'equal to the eager run\'s validated gradient', d))
+            continue
+        family, blk = mm.group(1), int(mm.group(2)) // 2
+        x_blk, g_blk = spy.block_io(family, blk)
+        exact = _exact_block_gradients(x_blk, g_blk, pd, f'{family}.{2 * blk}.', f'{family}.{2 * blk + 1}.')
+        for pn, ge in exact.items():                  # every parameter of that block, not only the loud one
+            d = float((pd[pn].grad.detach().cpu().double() - ge).norm() / ge.norm())
+            assert d <= 1e-5, f'{pn}: |hip - exact(block)| = {d:.2e} (the block\'s kernels, not inherited noise)'
+            if pn == n:
+                structural.append((n, e_hip, '|hip - exact(block)|', d))
+        _STRUCTURALLY_VALIDATED[n] = g_hip
+    if spy is not None:
+        # ... and the criterion itself is exercised on every run, whether or not a tensor came out loud: the two blocks that have
+        # produced the outliers so far (skip attention 5 = skip_attention.10/.11, decoder attention 0), every parameter
+        for family, blk in (('skip_attention', 5), ('decoder_attention', 0)):
+            x_blk, g_blk = spy.block_io(family, blk)
+            exact = _exact_block_gradients(x_blk, g_blk, pd, f'{family}.{2 * blk}.', f'{family}.{2 * blk + 1}.')
+            assert len(exact) == 6, sorted(exact)
+            for pn, ge in exact.items():
+                d = float((pd[pn].grad.detach().cpu().double() - ge).norm() / ge.norm())
+                assert d <= 1e-5, f'{pn}: |hip - exact(block)| = {d:.2e}'
+                structural.append((pn, None, '|hip - exact(block)| (routine check)', d))
     ratios.sort()
     # as accurate as the reference's own fp32 arithmetic: median error ratio ~1, and only a handful of (small,
     # cancellation-dominated attention) tensors noisier than 3x the CPU's fp32
@@ -211,7 +317,8 @@ def test_train_step_at_bench_size_against_oracle(dev, oracle_step, use_graph):
         worst_rel_l2_vs_fp64=worst[0], worst_tensor=worst[1], largest_norm_deviation_vs_fp64=norm_dev[0],
         largest_norm_deviation_tensor=norm_dev[1], median_ratio_hip_error_to_cpu_fp32_error=ratios[len(ratios) // 2],
         p90_ratio=ratios[int(len(ratios) * 0.9)], tensors_above_3x_cpu_fp32_error=[(n, e, f) for n, e, f in loud],
-        bounds='per tensor rel-L2 <= 1.5e-2 (one attention FC tensor up to 5e-2) and norm within 8e-3 of fp64; median ratio <= 1.5; <= 5 tensors above 3x', tensors_above_1p5e_2=over))
+        bounds='per tensor rel-L2 <= 1.5e-2 and norm within 8e-3 of fp64 — above it (<= 5e-2) only attention-block parameters whose block backward matches an fp64 re-differentiation of the block from the HIP path\'s own inputs to 1e-5; median ratio <= 1.5; <= 5 tensors above 3x',
+        tensors_above_1p5e_2=over, structural_checks=structural))
 
 
 def test_complex_lstm_at_inference_sequence_length(dev):

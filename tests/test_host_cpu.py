@@ -266,12 +266,20 @@ def test_stoi_restatement_properties():
         stoi(x, x[:-1], fs)
 
 
-def test_no_cross_half_packed_f32_in_mfma_kernels(tmp_path):
+# Kernels allowed to carry a packed-f32 op with an op_sel bit set.  EMPTY by construction since round 4: every source but
+# two is built without the SLP vectoriser (build.py), the hand-written packed complex MACs (conv_k7.hip, conv_up1.hip,
+# conv_wgrad_small.hip) keep the value they broadcast in the LOW half of a register pair or move it (dcs_bcast2), and the two
+# sources that keep the vectoriser (conv_wgrad_mfma.hip, lstm.hip: it pays there) form no selecting pair.  An entry here needs
+# its reason written next to it.
+PACKED_F32_OP_SEL_ALLOWED = ()
+
+
+def test_no_cross_half_packed_f32_in_any_kernel(tmp_path):
     """Static guard for the gfx950 behaviour pinned in profiles/r03_pk_fma_op_sel_hazard.txt: a v_pk_fma_f32 whose LOW lane
     takes the HIGH dword of a source pair (an op_sel bit set) can lose that lane's product while co-resident waves issue
-    bf16 MFMAs.  No kernel of the built library that issues MFMAs may contain a packed-f32 op with an op_sel bit set (their
-    sources are built without the SLP vectoriser, build.py); the VALU kernels that do contain them never run beside an
-    MFMA kernel (one stream; the inference side stream joins before the fc conv)."""
+    bf16 MFMAs.  Round 3 kept such ops out of the kernels that issue MFMAs themselves and relied on stream discipline for the
+    97 VALU kernels that carried them; since round 4 NO kernel of the built library may contain one, so
+    co-residency — two ranks on one card, a second stream — cannot meet the condition at all."""
     import re
     import struct
     import subprocess
@@ -281,7 +289,7 @@ def test_no_cross_half_packed_f32_in_mfma_kernels(tmp_path):
     from dcsnet import _lib
     data = open(_lib.LIB_PATH, 'rb').read()
     magic = b'__CLANG_OFFLOAD_BUNDLE__'
-    n_obj = n_mfma = 0
+    n_obj = n_kern = n_mfma = 0
     bad = []
     for m in re.finditer(magic, data):
         p = m.start()
@@ -296,20 +304,17 @@ def test_no_cross_half_packed_f32_in_mfma_kernels(tmp_path):
             if 'gfx950' not in triple or size == 0:
                 continue
             blob = data[p + off:p + off + size]
-            if b'v_mfma' not in blob and b'mfma' not in blob:          # (mnemonics are not in the binary; cheap pre-filter on names)
-                pass
             f = tmp_path / f'co{n_obj}.o'
             f.write_bytes(blob)
             n_obj += 1
             asm = subprocess.run([objdump, '-d', '--mcpu=gfx950', str(f)], capture_output=True, text=True, check=True).stdout
             parts = re.split(r'\n[0-9a-f]+ <([^>]+)>:\n', asm)
             for name, body in zip(parts[1::2], parts[2::2]):
-                if 'v_mfma' not in body:
-                    continue
-                n_mfma += 1
+                n_kern += 1
+                n_mfma += 'v_mfma' in body
                 hits = [ln for ln in body.split('\n')
                         if re.search(r'v_pk_(fma|mul|add)_f32', ln) and re.search(r'op_sel:\[[^\]]*1', ln)]
-                if hits:
+                if hits and not any(a in name for a in PACKED_F32_OP_SEL_ALLOWED):
                     bad.append((name, len(hits), hits[0].strip()))
-    assert n_obj > 0 and n_mfma > 20, (n_obj, n_mfma)
-    assert not bad, bad[:5]
+    assert n_obj > 0 and n_kern > 300 and n_mfma > 20, (n_obj, n_kern, n_mfma)
+    assert not bad, f'{len(bad)} kernels carry a packed f32 op with a cross-half operand selection: {bad[:8]}'
