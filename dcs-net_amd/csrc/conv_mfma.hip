@@ -30,6 +30,15 @@
 #ifndef DCS_EXP_LOOP
 #define DCS_EXP_LOOP 0      // timing probes of the tap loop (wrong results): 1 no A reads, 2 no B loads, 4 no gather after chunk 0
 #endif
+#ifndef DCS_MFMA_GATHER_PREFETCH
+#define DCS_MFMA_GATHER_PREFETCH 0      // measured: gather phases of a workgroup halve, its MFMA phases stretch by as much (r04 phase stamps)
+#endif
+#ifndef DCS_MFMA_PROGRESS_PRIO
+#define DCS_MFMA_PROGRESS_PRIO 0      // measured: the two workgroups of a CU finish 7 % apart instead of 25 %, the kernel lasts exactly as long (work-conserving)
+#endif
+#ifndef DCS_MFMA_STAGGER
+#define DCS_MFMA_STAGGER 0
+#endif
 #ifndef DCS_MFMA_COPY_AT_TOP
 #define DCS_MFMA_COPY_AT_TOP 1
 #endif
@@ -118,6 +127,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         bx = __builtin_amdgcn_readfirstlane(L % gx);
         by = __builtin_amdgcn_readfirstlane((L / gx) % gy);
         bz = __builtin_amdgcn_readfirstlane(L / (gx * gy));
+#if DCS_MFMA_STAGGER
+        // experiment: the workgroup in a CU's second slot (hardware ids 256 .. 511, 768 .. ) starts ~one gather late, so that the
+        // two co-resident workgroups alternate gather and MFMA phases instead of running them in lockstep
+        if ((n >> 8) & 1u) __builtin_amdgcn_s_sleep(DCS_MFMA_STAGGER);
+#endif
     }
 #endif
     const conv::Cls& k = m.cls[bz];
@@ -262,13 +276,19 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         bprobe_first = false;
     }
 
-    // source pixel (index into x1 / x2, or -1 for zero) of every patch pixel: the same for all channel chunks
-    int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);
+    // source pixel of every patch pixel, as the element offset of its channel 0 in x1 (spx) and in x2 (spx2) — or -1 for a
+    // zero (padding / inserted zero): the same for all channel chunks.  (Round 4: premultiplied by the channel counts here,
+    // once per workgroup — as a pixel index every gather slot paid a 64-bit multiply-add, a quarter-rate instruction.)
+    const int npatch = rows * cols;
+    int* spx = reinterpret_cast<int*>(patch + npatch * PIX);
+    int* spx2 = spx + npatch;
     const unsigned cols_magic = 0xFFFFFFFFu / (unsigned)cols + 1u;    // ceil(2^32 / cols): exact quotients for p < 2^16
-    for (int p = t; p < rows * cols; p += 256) {
+    for (int p = t; p < npatch; p += 256) {
         const int py = (int)__umulhi((unsigned)p, cols_magic), px = p - py * cols;        // p / cols, p % cols
         long sp;
-        spx[p] = conv::src_pixel(a, b, vy0 + py, vx0 + px, &sp) ? (int)sp : -1;
+        const bool in = conv::src_pixel(a, b, vy0 + py, vx0 + px, &sp);
+        spx[p] = in ? (int)sp * a.C1 * (int)sizeof(act2_t) : -1;       // BYTE offsets (32-bit: the launcher checks the extents)
+        spx2[p] = in ? (int)sp * a.C2 * (int)sizeof(act2_t) : -1;
     }
 
     const long long d_loop = FDIAG_NOW();
@@ -282,66 +302,98 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #else
     typedef float4 raw_t;
 #endif
-    auto gissue = [&](raw_t* v, int base, int chx) {                   // the loads of one round: slots base + 256 u of chunk chx
-        int spv[GU];
+    // Round 4: the gather was the kernel's main VALU consumer — ~60 vector instructions per 16-byte slot, four of them
+    // quarter-rate 64-bit multiply-adds, every load inside its own exec-masked branch, every bf16 conversion a single-operand
+    // v_cvt_pk — about 45 % of the MFMA time of a chunk per wave, and on this part VALU issue and MFMA time of the waves of a
+    // SIMD ADD.  Now: a thread owns a fixed channel pair (256 % Q == 0), so its source base and table
+    // are chosen once per chunk; a slot is a table read, one 64-bit add, an UNCONDITIONAL load (offset clamped, value selected
+    // afterwards), the split as packed conversions (dcs_split_pair) and the LDS stores — ~35 full-rate instructions, no branch.
+    constexpr int PPR = 256 / Q;                                       // patch pixels covered by one pass of the 256 threads
+    const int tq = t % Q, tp0 = t / Q;
+    // a chunk lies in ONE source tensor (make_plan: CH divides C1 when there is a second one), so base and table are
+    // wave-uniform: global_load v, v_offset, s[base] — no 64-bit vector arithmetic at all
+    typedef __attribute__((address_space(1))) const char gsrc_t;
+    // the loads of one round (GU slots per thread: patch pixels pb, pb + PPR, ...) of chunk chx
+    auto gissue = [&](int chx, int pb, int* o, int* pp, raw_t* v) {
+        const bool first = chx * CH < a.C1;
+        gsrc_t* xb = first ? (gsrc_t*)a.x1 : (gsrc_t*)a.x2;
+        asm volatile("" : "+s"(xb));                                   // (an SGPR pair, or the loads get 64-bit vector addresses)
+        const int* tb = first ? spx : spx2;
+        const unsigned cb = (unsigned)((first ? chx * CH : chx * CH - a.C1) + 2 * tq) * (unsigned)sizeof(act2_t);   // this thread's channel pair
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int idx = base + u * 256;
-            spv[u] = idx < nslots ? spx[idx / Q] : -1;
+        for (int u = 0; u < GU; ++u) {                                 // (past the end: the last pixel again — same data, same place)
+            pp[u] = pb + u * PPR < npatch ? pb + u * PPR : npatch - 1;
+            o[u] = tb[pp[u]];
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int idx = base + u * 256;
+            unsigned vo = (unsigned)(o[u] < 0 ? 0 : o[u]) + cb;
+            asm volatile("" : "+v"(vo));
 #if DCS_ACT_IS_BF16
-            v[u] = make_uint2(0u, 0u);
+            typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+            v[u] = __builtin_bit_cast(uint2, *(__attribute__((address_space(1))) const u32x2n*)(xb + vo));
 #else
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            typedef float f32x4g __attribute__((ext_vector_type(4)));
+            v[u] = __builtin_bit_cast(float4, *(__attribute__((address_space(1))) const f32x4g*)(xb + vo));
 #endif
-            if (spv[u] >= 0) {
-                const int c = chx * CH + 2 * (idx % Q);
-                const act2_t* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
-                v[u] = *reinterpret_cast<const raw_t*>(src);
-            }
         }
     };
-    auto gstore = [&](const raw_t* v, int base) {                      // ... and their LDS stores (operand conversion)
+    // ... and their conversion + LDS stores
+    auto gfinish = [&](const int* o, const int* pp, const raw_t* v) {
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int idx = base + u * 256;
-            if (idx >= nslots) continue;
+            // (an LDS-address-space pointer with a 32-bit offset: as a generic float* this was a 64-bit multiply-add per slot)
+            typedef __attribute__((address_space(3))) float lds_f;
+            typedef unsigned nu2 __attribute__((ext_vector_type(2)));            // (native vectors: HIP's structs do not assign into LDS)
+            typedef float nf2 __attribute__((ext_vector_type(2)));
+            typedef float nf4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) nu2 lds_u2;
+            typedef __attribute__((address_space(3))) nf2 lds_f2;
+            typedef __attribute__((address_space(3))) nf4 lds_f4;
+            lds_f* dst = (lds_f*)patch + (__umul24((unsigned)pp[u], (unsigned)PIX) + (unsigned)(tq * (BF ? 2 : 4)));   // (24-bit multiply: full rate)
+            const unsigned keep = o[u] < 0 ? 0u : 0xffffffffu;             // (a mask, not a branch around four moves)
 #if DCS_ACT_IS_BF16
             // bf16 activations (precision mode 1 only): the stored bits ARE the MFMA operand — no conversion
             static_assert(PR == 1, "bf16 activations run the bf16-operand kernel");
-            *reinterpret_cast<uint2*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = v[u];
+            *(lds_u2*)dst = nu2{v[u].x & keep, v[u].y & keep};
 #else
-            if (PR == 2) {                                             // 2 complex -> 3 planes of 4 bf16 (exact split)
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                float4 r = v[u];
-                float* dst = patch + (idx / Q) * PIX + (idx % Q) * 2;
+            float4 r = make_float4(__uint_as_float(__float_as_uint(v[u].x) & keep), __uint_as_float(__float_as_uint(v[u].y) & keep),
+                                   __uint_as_float(__float_as_uint(v[u].z) & keep), __uint_as_float(__float_as_uint(v[u].w) & keep));
 #if defined(DCS_EXP_GATHER) && DCS_EXP_GATHER == 1
-                // timing probe (wrong results): the loaded bits stored as they are, 8 bytes per plane — the gather without the
-                // VALU work of the split (what planes written once by the producer would leave: 1.5x the bytes, no conversion)
-                *reinterpret_cast<float2*>(dst) = make_float2(r.x, r.y);
-                *reinterpret_cast<float2*>(dst + CH) = make_float2(r.z, r.w);
-                *reinterpret_cast<float2*>(dst + 2 * CH) = make_float2(r.x, r.w);
+            if (PR == 2) {     // timing probe (wrong results): the loaded bits stored as they are — the gather without the split
+                *(lds_f2*)dst = nf2{r.x, r.y};
+                *(lds_f2*)(dst + CH) = nf2{r.z, r.w};
+                *(lds_f2*)(dst + 2 * CH) = nf2{r.x, r.w};
                 continue;
+            }
 #endif
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const bf16x4 h = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
-                    *reinterpret_cast<bf16x4*>(dst + pl * CH) = h;
-                    r.x -= (float)h[0]; r.y -= (float)h[1]; r.z -= (float)h[2]; r.w -= (float)h[3];
-                }
+            if (PR == 2) {                                             // 2 complex -> 3 planes of 4 bf16 (exact split)
+                nu2 h0, h1, h2;
+                h0.x = dcs_split_pair(r.x, r.y); h0.y = dcs_split_pair(r.z, r.w);
+                h1.x = dcs_split_pair(r.x, r.y); h1.y = dcs_split_pair(r.z, r.w);
+                h2.x = dcs_pack_bf16x2(r.x, r.y); h2.y = dcs_pack_bf16x2(r.z, r.w);
+                *(lds_u2*)dst = h0;
+                *(lds_u2*)(dst + CH) = h1;
+                *(lds_u2*)(dst + 2 * CH) = h2;
             } else if (BF) {                                           // 2 complex -> 4 bf16 (round to nearest even)
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                const bf16x4 h = {(__bf16)v[u].x, (__bf16)v[u].y, (__bf16)v[u].z, (__bf16)v[u].w};
-                *reinterpret_cast<bf16x4*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = h;
+                *(lds_u2*)dst = nu2{dcs_pack_bf16x2(r.x, r.y), dcs_pack_bf16x2(r.z, r.w)};
             } else {
-                *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
+                *(lds_f4*)dst = nf4{r.x, r.y, r.z, r.w};
             }
 #endif
         }
     };
+    // Round 4: the FIRST round of the next chunk's gather is requested during the LAST tap of this chunk's MFMA loop (behind
+    // that tap's B-fragment requests: vmcnt retires in order, and nothing in the rest of the tap waits on vector memory), so
+    // its memory round trip — the gather is latency-bound: a table read, a load the previous kernel's write-back has pushed
+    // out of L2, then the stores — runs under ~24 MFMAs and the chunk barrier instead of after them.  One round = GU slots per
+    // thread = the whole patch for the tiles of the train shapes.
+    // (32-channel chunks only: their launches hold two workgroups per CU whatever the register count; the GU x 4 held registers
+    // would cost the 16-channel instances their third wave per SIMD)
+    constexpr bool PREFETCH = DCS_MFMA_GATHER_PREFETCH != 0 && CH == 32 && PR == 2 && !INPLACE;
+    int o_pre[GU], pp_pre[GU];
+    raw_t v_pre[GU];
+    bool have_pre = false;
     // (Measured and dropped: the first round of the NEXT chunk loaded into registers before this chunk's MFMA loop and stored
     // after it — +37 VGPRs take the 32-channel instances from three waves per SIMD to two and the first B-fragment wait of
     // the loop then also waits for the older patch loads: train step 3.950 -> 3.996 ms, inference 3.22 -> 3.37 ms.)
@@ -354,6 +406,19 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #else
 #define DCS_CHUNK_BARRIER() __syncthreads()
 #endif
+    // Progress-based wave priority (Round 4).  Phase stamps per workgroup (tools/fwd_diag.py, DCS_FDIAG_DUMP) showed the two
+    // co-resident workgroups of a CU finishing 25 % apart — dec1: 108 k cycles for the one dispatched first, 135 k for the
+    // second: the SIMD arbitrates issue by priority, then AGE, so the older workgroup's waves run nearly unimpeded, the younger
+    // one gets the leftover slots and then runs its last quarter alone on a pipe one wave per SIMD cannot fill; the kernel
+    // lasts as long as the slower one.  A workgroup now lowers its priority as it progresses through its (chunk, tap)
+    // iterations (3 -> 0 in quarters): whichever is ahead yields, both finish together.  (The weight-gradient kernel has done
+    // this per pixel tile since round 2.)
+#if DCS_MFMA_PROGRESS_PRIO
+    const int prio_total = (n_chunks - c_begin) * ((ntaps - t0 + TSTEP - 1) / TSTEP);
+    const int prio_q1 = prio_total / 4, prio_q2 = prio_total / 2, prio_q3 = prio_total - prio_total / 4;
+    int prio_it = 0;
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (int ch = c_begin; ch < n_chunks; ++ch) {
         const long long g0 = FDIAG_NOW();
         DCS_CHUNK_BARRIER();                                           // previous chunk fully consumed
@@ -361,10 +426,18 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         // timing probe (wrong results): no gather at all after the first chunk — what a perfectly hidden gather would leave
         if (ch == c_begin)
 #endif
-        for (int base = t; base < nslots; base += 256 * GU) {
-            raw_t v[GU];
-            gissue(v, base, ch);
-            gstore(v, base);
+        {
+            int pb = tp0;
+            if (PREFETCH && have_pre) {
+                gfinish(o_pre, pp_pre, v_pre);
+                pb += PPR * GU;
+            }
+            for (; pb < npatch; pb += PPR * GU) {
+                int o[GU], pp[GU];
+                raw_t v[GU];
+                gissue(ch, pb, o, pp, v);
+                gfinish(o, pp, v);
+            }
         }
         DCS_CHUNK_BARRIER();
         const long long g1 = FDIAG_NOW();
@@ -377,6 +450,12 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         int tapoff = tapoff0;                                          // LDS float offset of the current tap
 #pragma unroll(INPLACE ? TPI : 1)
         for (int tap = t0; tap < (INPLACE ? NTAPS_C : ntaps); tap += TSTEP) {
+#if DCS_MFMA_PROGRESS_PRIO
+            if (prio_it == prio_q1) __builtin_amdgcn_s_setprio(2);
+            else if (prio_it == prio_q2) __builtin_amdgcn_s_setprio(1);
+            else if (prio_it == prio_q3) __builtin_amdgcn_s_setprio(0);
+            ++prio_it;
+#endif
 #if DCS_MFMA_COPY_AT_TOP
             // Round 4: the prefetched set moves over at the TOP of a tap, not at its end.  At the end, the last tap of a chunk
             // waited (vmcnt) for the next chunk's first fragments — requested half a tap earlier — BEFORE the gather: one exposed
@@ -440,6 +519,10 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     }
                 // next tap's fragments (scheduling barriers pin the loads here, ahead of the remaining MFMA groups)
                 __builtin_amdgcn_sched_barrier(0);
+                if (PREFETCH && g == 0 && tap + TSTEP >= ntaps && ch + 1 < n_chunks) {      // last tap of the chunk, behind its first MFMA group
+                    gissue(ch + 1, tp0, o_pre, pp_pre, v_pre);
+                    have_pre = true;
+                }
                 if (INPLACE) {
                     bload(bcur[g], ch, tap + TSTEP, g);
                 } else if (DCS_MFMA_EARLY_OPERANDS != 1 && g * LPG < VU) {
@@ -467,6 +550,9 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         }
         d_mfma += FDIAG_NOW() - g1;
     }
+#if DCS_MFMA_PROGRESS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const long long d_epi = FDIAG_NOW();
 #ifdef DCS_FWD_DIAG
     auto diag_out = [&]() {
@@ -970,7 +1056,7 @@ thread_local bool g_force_wide_panel = false;
 template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI, bool STAT = false, int WK = 1>
 int launch_tpi(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH + 4 : PR == 1 ? CH + 4 : 2 * CH + 4) + 1) * sizeof(float);   // patch + source-pixel table
+    size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH + 4 : PR == 1 ? CH + 4 : 2 * CH + 4) + 2) * sizeof(float);   // patch + the two source-offset tables
     if (lds < 4 * 32 * 36 * sizeof(float)) lds = 4 * 32 * 36 * sizeof(float);        // the epilogue's four transpose tiles
     if (STAT && lds < (4 * 32 * 36 + 4 * WN * 80) * sizeof(float)) lds = (4 * 32 * 36 + 4 * WN * 80) * sizeof(float);   // + the statistics' combine area
 #ifdef DCS_FWD_ONE_PER_CU
@@ -1029,7 +1115,7 @@ int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
             if (p.CH == 16) return launch_ch<WAVES_N, WM, WN, 16, WK>(m, npix, stream);
             if (p.CH == 8) return launch_ch<WAVES_N, WM, WN, 8, WK>(m, npix, stream);
         }
-        if constexpr (WK == 4 && WM == 2) {                            // (enc1: the taps over four waves)
+        if constexpr (WK == 4 && WM == 2 && WN == 1) {                 // (enc1: the taps over four waves)
             if (p.CH == 8) return launch_ch<WAVES_N, WM, WN, 8, WK>(m, npix, stream);
         }
         return DCS_ERR_BADARG;
@@ -1058,7 +1144,10 @@ struct Cand { int bm, bn, wk; };
 // (pixels, columns, waves along K): the last two are the K-split tiles of the few-pixel layers (cconv_mfma_kernel, WK)
 // and {64, 32, 2} / {64, 32, 4}: the LDS-bound 7x7 / 8-channel layer (enc1) — half the tile, so three workgroups share a CU instead of one;
 // {64, 64, 2}: the un-sliced 64 x 64 launches with each B fragment feeding two MFMA sets
-constexpr Cand kCands[] = {{128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {128, 32, 1}, {32, 64, 2}, {32, 32, 4}, {64, 32, 2}, {64, 64, 2}, {64, 32, 4}};
+// {64, 64, 4} (Round 4): ONE 64 x 64 tile per workgroup, the k-groups of a 32-channel chunk over its four waves — every A and
+// every B fragment feeds two MFMA sets (0.5 KB of operand traffic per MFMA instead of 0.75 KB in the {64, 64, 2} layout)
+constexpr Cand kCands[] = {{128, 128, 1}, {128, 64, 1}, {64, 64, 1}, {128, 32, 1}, {32, 64, 2}, {32, 32, 4}, {64, 32, 2}, {64, 64, 2}, {64, 32, 4},
+                           {64, 64, 4}};
 
 // tile, chunk depth and K slices for geometry `a` (FULL output extent in Hout/Wout) and its classes
 bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, long* npix_out) {
@@ -1161,6 +1250,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     if (wk64 && best == 2 && p->wk == 1 && want_s == 1 && !a.stat && !g_force_wide_panel && Cin % 16 == 0 &&
         conv::mfma_precision(Cin, ncls == 1 ? kh * kw : 0) != 0) {
         best = 7; p->wk = 2;
+        if (wk64 == 2 && Cin % 32 == 0) { best = 9; p->wk = 4; }
     }
     p->cand = best; p->blocks = best_blocks;
     shape(kCands[best].bm, &p->TH, &p->TW);
@@ -1186,7 +1276,10 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // patch words per pixel at chunk depth ch: fp32 2 ch + 4; bf16 ch + 4; three bf16 planes 3 ch + 4
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     auto pixw = [&](int ch) { return (pr == 2 ? 3 * ch : pr == 1 ? ch : 2 * ch) + 4; };
-    if (p->wk > 1 && best != 7) {                                              // K split over waves: the deepest chunk that fits (<= 56 KB)
+    if (best == 9) {
+        if (npix * pixw(32) * 4 > 150L * 1024) return false;
+        p->CH = 32;
+    } else if (p->wk > 1 && best != 7) {                                       // K split over waves: the deepest chunk that fits (<= 56 KB)
         if (best == 6 || best == 8) p->CH = 8;
         else if (Cin % 32 == 0 && npix * pixw(32) * 4 <= 56L * 1024) p->CH = 32;
         else if (p->wk == 2 && Cin % 16 == 0 && npix * pixw(16) * 4 <= 56L * 1024) p->CH = 16;
@@ -1201,6 +1294,12 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     else if (Cin % 16 == 0 && npix * pixw(16) * 4 <= cap16c) p->CH = 16;
     else if (npix * pixw(8) * 4 <= 150 * 1024) p->CH = 8;
     else return false;
+    // a chunk never straddles the two sources of a concatenation (the gather picks ONE source per chunk; the 16-column kernel
+    // selects per slot): a shallower chunk where the first source's channel count asks for it (DR-Net's 8 + 8 complex channels)
+    if (!(2 * a.Cout == 16 && p->cand == 3 && !g_force_wide_panel)) {
+        while (a.C2 > 0 && a.C1 % p->CH != 0 && p->wk == 1 && p->CH > 8) p->CH /= 2;
+        if (a.C2 > 0 && a.C1 % p->CH != 0) return false;
+    }
     const int n_chunks = Cin / p->CH;
     if (2 * a.Cout == 16 || p->wk > 1) want_s = 1;           // the 16-column kernel does not slice K; nor do the K-split tiles
     int S = want_s < n_chunks ? want_s : n_chunks;
@@ -1281,7 +1380,8 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
 #if DCS_ACT_IS_BF16
     if (dcs_conv_precision() != 1) return DCS_ERR_BADARG;     // bf16 activations: bf16 weight panels (dcs_set_conv_precision(1))
 #endif
-    if ((long)a.B * a.Hin * a.Win >= (1L << 31)) return DCS_ERR_BADARG;     // source-pixel table holds 32-bit indices
+    if ((long)a.B * a.Hin * a.Win * (a.C1 > a.C2 ? a.C1 : a.C2) * (long)sizeof(act2_t) >= (1L << 31))
+        return DCS_ERR_BADARG;                                             // the source-offset tables hold 32-bit byte offsets
     if ((long)a.Hout * a.Wout * 2 * a.Cout >= (1L << 31)) return DCS_ERR_BADARG;  // 32-bit store offsets inside an image
     const int Cin = a.C1 + a.C2;
     MArgs m;
@@ -1348,6 +1448,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         case 6: rc = launch<1, 1, 1, 2>(m, p, npix, stream); break;   //  64 x 32, two waves along K (taps)
         case 7: rc = launch<2, 2, 1, 2>(m, p, npix, stream); break;   //  64 x 64, two waves along K
         case 8: rc = launch<1, 2, 1, 4>(m, p, npix, stream); break;   //  64 x 32, four waves along K (taps), 64 pixels each
+        case 9: rc = launch<1, 2, 2, 4>(m, p, npix, stream); break;   //  64 x 64, four waves along K, one tile
         default: rc = launch<1, 1, 1>(m, p, npix, stream); break;     // 128 x 32
     }
     if (rc != DCS_OK || m.ksplit <= 1) return rc;

@@ -31,10 +31,20 @@ __device__ __forceinline__ float dcs_bf16_to_f32(unsigned short h) { return __ui
 __device__ __forceinline__ unsigned short dcs_f32_to_bf16(float v) {       // round to nearest even; NaN stays NaN (v_cvt_pk_bf16_f32)
     return __builtin_bit_cast(unsigned short, (__bf16)v);
 }
-__device__ __forceinline__ unsigned dcs_pack_bf16x2(float lo, float hi) {
+__device__ __forceinline__ unsigned dcs_pack_bf16x2(float lo, float hi) {          // ONE v_cvt_pk_bf16_f32 (nearest even)
     typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-    const bf16x2_ h = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(unsigned, h);
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{lo, hi}, bf16x2_));
+}
+// One step of the exact three-way bf16 split of fp32 values (the "bf16x6" emulation): returns
+// {bf16(a), bf16(b)} in one dword and leaves the residuals a - bf16(a), b - bf16(b) — exact in fp32 — in a and b.  One packed
+// conversion, two unpacks (shift / mask) and two subtractions per pair; element by element the compiler emitted a
+// single-operand v_cvt_pk per value plus the repacking.
+__device__ __forceinline__ unsigned dcs_split_pair(float& a, float& b) {
+    const unsigned u = dcs_pack_bf16x2(a, b);
+    a -= __uint_as_float(u << 16);
+    b -= __uint_as_float(u & 0xffff0000u);
+    return u;
 }
 // one element / one complex value / two complex values (4 consecutive elements; 16-byte resp. 8-byte aligned)
 __device__ __forceinline__ float dcs_ld1(const float* p) { return *p; }

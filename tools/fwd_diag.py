@@ -77,4 +77,8 @@ for name, H, W, C1, C2, Cout, k, st, up in L:
         pairs.setdefault(c_, []).append(w_)
     ex = list(pairs.values())[:3]
     print(f'      WG ids on the first CUs: {ex}')
+    if os.environ.get('DCS_FDIAG_DUMP'):
+        import numpy as np
+        os.makedirs(os.environ['DCS_FDIAG_DUMP'], exist_ok=True)
+        np.save(os.path.join(os.environ['DCS_FDIAG_DUMP'], f'{name}_{what}.npy'), torch.cat([wgid.double()[:, None], d], 1).numpy())
     print(f'      life p5/p50/p95 {q(.05):.1f} {q(.5):.1f} {q(.95):.1f} | start p50/p95/max {us(st_[n // 2]):.1f} {us(st_[int(.95 * (n - 1))]):.1f} {us(st_[-1]):.1f}')
