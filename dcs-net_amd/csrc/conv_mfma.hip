@@ -52,7 +52,7 @@
 #define DCS_MFMA_SCALAR_B 1
 #endif
 #ifndef DCS_MFMA_EARLY_OPERANDS
-#define DCS_MFMA_EARLY_OPERANDS 0
+#define DCS_MFMA_EARLY_OPERANDS 3
 #endif
 #ifndef DCS_X6_GU32
 #define DCS_X6_GU32 8       // gather loads in flight per thread at 32-channel chunks of the emulated kernel
@@ -492,7 +492,8 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     for (int q = 0; q < LPG; ++q)
                         if (g * LPG + q < VU) bload(bnxt[INPLACE ? 0 : g * LPG + q], ch, tap + TSTEP, g * LPG + q);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (DCS_MFMA_EARLY_OPERANDS == 3 && !INPLACE) bload(bnxt[INPLACE ? 0 : g], ch, tap + TSTEP, g);   // this group's slot of the next tap
+                if (DCS_MFMA_EARLY_OPERANDS != 3) __builtin_amdgcn_sched_barrier(0);
 #endif
                 // MFMAs straight from the ring slot ...
 #pragma unroll
@@ -517,6 +518,24 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i][j], 0, 0, 0);
                         }
                     }
+#if DCS_MFMA_EARLY_OPERANDS == 3
+                // Mode 3: the next k-group's A reads and this group's share of the next tap's B loads are written AHEAD of the MFMAs
+                // in the source (so each is requested a whole k-group / a whole tap before its use) and INTERLEAVED with them by the
+                // scheduler — one load behind each MFMA — instead of in one burst in front of them (mode 1: 6 LDS reads + 6 global
+                // loads = ~120 issue cycles before the first MFMA of every k-group: a lone wave ran at 54 % of the pipe, 61 % as
+                // the compiler orders it by itself: profiles/r04_lone_wave.txt).
+                if (!INPLACE) {
+                    constexpr int NM = WM * WN * (PR == 2 ? 6 : (BF ? 1 : 4)), NA = NP * WM, NB = NP * WN;
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA
+                        if (i < NA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // ... one LDS read
+                        else if (i < NA + NB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // ... or one global load
+                    }
+                    if (NM < NA) __builtin_amdgcn_sched_group_barrier(0x100, NA - NM, 0);
+                    if (NM < NA + NB) __builtin_amdgcn_sched_group_barrier(0x020, NA + NB - (NM > NA ? NM : NA), 0);
+                }
+#endif
                 // next tap's fragments (scheduling barriers pin the loads here, ahead of the remaining MFMA groups)
                 __builtin_amdgcn_sched_barrier(0);
                 if (PREFETCH && g == 0 && tap + TSTEP >= ntaps && ch + 1 < n_chunks) {      // last tap of the chunk, behind its first MFMA group
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 }
                 if (INPLACE) {
                     bload(bcur[g], ch, tap + TSTEP, g);
-                } else if (DCS_MFMA_EARLY_OPERANDS != 1 && g * LPG < VU) {
+                } else if (DCS_MFMA_EARLY_OPERANDS != 1 && DCS_MFMA_EARLY_OPERANDS != 3 && g * LPG < VU) {
 #pragma unroll
                     for (int q = 0; q < LPG; ++q)
                         if (g * LPG + q < VU) bload(bnxt[INPLACE ? 0 : g * LPG + q], ch, tap + TSTEP, g * LPG + q);

@@ -454,16 +454,20 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
             float r[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { r[4 * q] = v[q].x; r[4 * q + 1] = v[q].y; r[4 * q + 2] = v[q].z; r[4 * q + 3] = v[q].w; }
+            // the exact three-way split by PAIRS (dcs_split_pair: one packed conversion per pair; element by element the compiler
+            // emitted a single-operand v_cvt_pk per value plus the repacking — Round 4)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                bf16x8w h0, h1;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    h0[e] = (__bf16)r[e]; r[e] -= (float)h0[e];
-                    h1[e] = (__bf16)r[8 + e]; r[8 + e] -= (float)h1[e];
+                uint4 h0, h1;
+                if (pl < 2) {
+                    h0 = make_uint4(dcs_split_pair(r[0], r[1]), dcs_split_pair(r[2], r[3]), dcs_split_pair(r[4], r[5]), dcs_split_pair(r[6], r[7]));
+                    h1 = make_uint4(dcs_split_pair(r[8], r[9]), dcs_split_pair(r[10], r[11]), dcs_split_pair(r[12], r[13]), dcs_split_pair(r[14], r[15]));
+                } else {
+                    h0 = make_uint4(dcs_pack_bf16x2(r[0], r[1]), dcs_pack_bf16x2(r[2], r[3]), dcs_pack_bf16x2(r[4], r[5]), dcs_pack_bf16x2(r[6], r[7]));
+                    h1 = make_uint4(dcs_pack_bf16x2(r[8], r[9]), dcs_pack_bf16x2(r[10], r[11]), dcs_pack_bf16x2(r[12], r[13]), dcs_pack_bf16x2(r[14], r[15]));
                 }
-                *reinterpret_cast<bf16x8w*>(patch + px * PIXR + pl * 8) = h0;
-                *reinterpret_cast<bf16x8w*>(patch + px * PIXR + pl * 8 + 4) = h1;
+                *reinterpret_cast<uint4*>(patch + px * PIXR + pl * 8) = h0;
+                *reinterpret_cast<uint4*>(patch + px * PIXR + pl * 8 + 4) = h1;
             }
 #endif
         }
@@ -518,9 +522,12 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                     for (int e = 0; e < 8; ++e) bsum[i] += r[e];
                 }
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { ap[i][pl][e] = (__bf16)r[e]; r[e] -= (float)ap[i][pl][e]; }
+                for (int pl = 0; pl < NP; ++pl) {                       // (by pairs: dcs_split_pair / one packed conversion for the last plane)
+                    uint4 hp;
+                    if (pl + 1 < NP) hp = make_uint4(dcs_split_pair(r[0], r[1]), dcs_split_pair(r[2], r[3]), dcs_split_pair(r[4], r[5]), dcs_split_pair(r[6], r[7]));
+                    else hp = make_uint4(dcs_pack_bf16x2(r[0], r[1]), dcs_pack_bf16x2(r[2], r[3]), dcs_pack_bf16x2(r[4], r[5]), dcs_pack_bf16x2(r[6], r[7]));
+                    ap[i][pl] = __builtin_bit_cast(bf16x8w, hp);
+                }
             }
             if (j + 1 < 8 / WS) load_g(ks + WS < nks ? ks + WS : nks - 1, raw[(j + 1) & 1]);
             // operand B: lane (row q = li / 4, column quad li % 4) of its 16-lane group addresses pixel 8 lk + q (+ 4)

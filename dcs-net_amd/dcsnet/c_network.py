@@ -204,6 +204,7 @@ class C_NETWORK(LightningModule):
         p_conv, p_fc = self.dropout_conv.p, self.dropout_fc.p
         if x.dim() != 3 or x.dtype != torch.complex64:
             raise F.DcsHipError(f'C_NETWORK.forward expects complex64 [B,F,T], got {x.dtype} {tuple(x.shape)}')
+        self._check_conv_precision()
         B, Fbins, T = x.shape
         if Fbins % (1 << L) or T % 8:
             raise F.DcsHipError(f'F must be a multiple of {1 << L} and T of 8 (config.py:99,105); got F={Fbins}, T={T}')
@@ -348,8 +349,31 @@ class C_NETWORK(LightningModule):
             raise F.DcsHipError(f'activation dtype {dtype}: float32 or bfloat16')
         self.activation_dtype = dtype
         if dtype == torch.bfloat16:
-            F.ops.set_conv_precision('bf16')
+            F.ops._IN_SET_ACTIVATION_DTYPE = True
+            try:
+                F.ops.set_conv_precision('bf16')
+            finally:
+                F.ops._IN_SET_ACTIVATION_DTYPE = False
+        # the conv precision is ONE switch per process (include/dcsnet_hip.h): remember what this network was configured for,
+        # so that forward() can refuse to run under another network's setting instead of silently computing with it
+        self.__dict__['_conv_precision'] = 'bf16' if dtype == torch.bfloat16 else None
         return self
+
+    def _check_conv_precision(self):
+        """bf16 storage needs the process-wide conv precision 'bf16'; fp32 storage must NOT run under it (that is the
+        bf16-operand mode, a different arithmetic, entered only through ops.set_conv_precision('bf16') on purpose — never
+        because another network in the process switched it).  Raises instead of computing with the wrong mode."""
+        want = self.__dict__.get('_conv_precision')
+        have = F.ops.conv_precision()
+        if want == 'bf16' and have != 'bf16':
+            raise F.DcsHipError(f"this network stores activations in bf16 and needs conv precision 'bf16', the process is in "
+                                f"'{have}': another network or caller switched it — call ops.set_conv_precision('bf16') "
+                                f"(one conv precision per process: include/dcsnet_hip.h)")
+        if want is None and have == 'bf16' and not F.ops.BF16_OPERANDS_ON_PURPOSE:
+            raise F.DcsHipError("fp32-storage network under conv precision 'bf16': a bf16-storage network in this process "
+                                "switched the process-wide mode (set_activation_dtype); call ops.set_conv_precision('bf16x6' | "
+                                "'f32') before running this one, or ops.set_conv_precision('bf16') yourself to run "
+                                "bf16 operands on purpose")
     import os as _os
     overlap_skip_attention = _os.environ.get('DCS_OVERLAP_SKIP', '1') == '1'      # inference only (see forward); 0 disables
 

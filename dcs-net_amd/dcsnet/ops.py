@@ -55,9 +55,15 @@ def set_conv_precision(mode):
     are cleared here, a recorded pack plan must be re-recorded by its owner."""
     code = {'f32': 0, 'fp32': 0, 'bf16': 1, 'bf16x6': 2}[mode]
     check(_lib.load().dcs_set_conv_precision(code), 'dcs_set_conv_precision')
+    global BF16_OPERANDS_ON_PURPOSE
+    BF16_OPERANDS_ON_PURPOSE = (code == 1) and not _IN_SET_ACTIVATION_DTYPE
     from . import functional
     functional._pack_cache.clear()
     pack_plan_drop()
+
+
+BF16_OPERANDS_ON_PURPOSE = False       # 'bf16' chosen through set_conv_precision directly (not as a side effect of set_activation_dtype)
+_IN_SET_ACTIVATION_DTYPE = False
 
 
 def conv_precision():

@@ -442,3 +442,25 @@ def test_bf16_train_loss_at_configs4_size_against_the_oracle(dev):
     print(f'loss at [64,256,256]: hip bf16 {loss:.6f}, bf16 oracle {l16:.6f}, fp32 oracle {l32:.6f}')
     _record('train_loss_b64_vs_oracle', dict(hip_bf16=loss, oracle_bf16=l16, oracle_fp32=l32))
     assert abs(loss - l16) <= 5e-4 * abs(l16), (loss, l16, l32)
+
+
+def test_two_networks_of_different_storage_do_not_share_a_precision_silently(dev):
+    """The conv precision is one switch per process (include/dcsnet_hip.h).  set_activation_dtype('bf16') flips it; an
+    fp32-storage network that then runs must RAISE rather than compute on bf16 operands unasked, and a
+    bf16-storage network must raise when someone switched the process back."""
+    from dcsnet import ops, DcsHipError
+    x = seeded_input(1, 256, 16, seed=2).to(dev)
+    ops.set_conv_precision('bf16x6')
+    n32, n16 = _nets(dev)                                  # n16.set_activation_dtype('bf16') switches the process to 'bf16'
+    n32.eval(), n16.eval()
+    try:
+        with torch.no_grad():
+            n16(x)                                         # its own mode: fine
+            with pytest.raises(DcsHipError, match='fp32-storage network under conv precision'):
+                n32(x)
+            ops.set_conv_precision('bf16x6')
+            n32(x)                                         # explicit switch back: fine
+            with pytest.raises(DcsHipError, match="needs conv precision 'bf16'"):
+                n16(x)
+    finally:
+        ops.set_conv_precision('bf16')                     # (the module fixture's mode)
