@@ -37,6 +37,9 @@ struct WArgs {
     long long* dbg;            // diagnostic builds only (-DDCS_WGRAD_DIAG): per-wave phase times (s_memtime ticks)
 };
 
+#ifndef DCS_WG_SETPRIO
+#define DCS_WG_SETPRIO 1      // progress-based wave priority (3 -> 0 over a workgroup's tiles)
+#endif
 #ifndef DCS_WG_RING_BIG
 #define DCS_WG_RING_BIG 2
 #endif
@@ -132,10 +135,14 @@ void cconv_wgrad_mfma_kernel(WArgs w) {
         // workgroup that is ahead yields: its priority falls with the share of its tiles it has finished (100 - 118 us).
         {
             const int q = tiles_done * 4 / my_tiles;
+#if DCS_WG_SETPRIO
             if (q == 0) __builtin_amdgcn_s_setprio(3);
             else if (q == 1) __builtin_amdgcn_s_setprio(2);
             else if (q == 2) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
+#else
+            (void)q;
+#endif
         }
         const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
         const int oy0 = (tile_id / a.tiles_w) * w.TH, ox0 = (tile_id % a.tiles_w) * w.TW;
@@ -418,10 +425,14 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         const long long s0 = WDIAG_NOW();
         {
             const int q = tiles_done * 4 / my_tiles;
+#if DCS_WG_SETPRIO
             if (q == 0) __builtin_amdgcn_s_setprio(3);
             else if (q == 1) __builtin_amdgcn_s_setprio(2);
             else if (q == 2) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
+#else
+            (void)q;
+#endif
         }
         const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
         const int oy0 = (tile_id / a.tiles_w) * w.TH, ox0 = (tile_id % a.tiles_w) * w.TW;

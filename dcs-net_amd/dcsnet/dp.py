@@ -198,6 +198,9 @@ class TrainStep:
         self._graph = self._graph_opt = self._static_batch = self._static_loss = None
         self.use_pack_plan, self._plan = bool(use_pack_plan), None
         self._calls = 0
+        # weight-gradient kernels on a side stream beside the data-gradient chain (functional._CConv2dFn.backward): same kernels,
+        # same results; DCS_WGRAD_SIDE=0 keeps the step on one stream (same-box A/B: profiles/r04_side_stream_ab.txt)
+        self.wgrad_side_stream = os.environ.get('DCS_WGRAD_SIDE', '1') != '0'
         self.comm_events = None        # bench.py sets a list: (start, end) HIP events around every gradient all-reduce
 
     def _step_body(self, batch, batch_idx):
@@ -234,13 +237,23 @@ class TrainStep:
                 one = None                                  # (made outside a capture only: the three eager warm-up steps do)
             else:
                 one = self.__dict__['_loss_seed'] = torch.ones_like(loss)
+        from . import functional
+        side = None
+        if self.wgrad_side_stream:
+            side = self.__dict__.get('_wgrad_side')
+            if side is None or side.device != loss.device:
+                side = self.__dict__['_wgrad_side'] = torch.cuda.Stream(device=loss.device)
         ops.wgrad_defer_begin()
+        functional.WGRAD_SIDE = side
         try:
             if one is None:
                 loss.backward()
             else:
                 loss.backward(gradient=one)
         finally:
+            functional.WGRAD_SIDE = None
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)      # the one join: every weight-gradient kernel is in
             ops.wgrad_defer_flush()
 
     def _eager(self, batch, batch_idx):

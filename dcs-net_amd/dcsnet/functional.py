@@ -4,6 +4,7 @@ Everything here takes / returns channels-last float32 views ``[B,H,W,C,2]`` unle
 "complex" in its name.  Packed weights are cached per parameter version, so inference packs
 once and training re-packs after each optimizer step.
 """
+import os
 import weakref
 
 import torch
@@ -94,6 +95,11 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1), tap_rows=0):
 
 
 ATTENTION_BATCH_MAX = ops.ATTENTION_BATCH_MAX
+WGRAD_SIDE_AFTER_DGRAD = os.environ.get('DCS_WGRAD_SIDE_AFTER_DGRAD', '0') != '0'
+WGRAD_SIDE_FLUSH = os.environ.get('DCS_WGRAD_SIDE_FLUSH', '0') != '0'
+WGRAD_SIDE_LSTM = os.environ.get('DCS_WGRAD_SIDE_LSTM', '0') != '0'
+WGRAD_SIDE_MIN_GFLOP = float(os.environ.get('DCS_WGRAD_SIDE_MIN_GFLOP', '0'))
+WGRAD_SIDE = None      # the side stream the deferred weight-gradient kernels of a train step run on (dp.TrainStep._backward), else None
 sink_hits = 0          # diagnostics: how many parameter gradients were routed to a sink
 
 
@@ -138,13 +144,32 @@ class _CConv2dFn(torch.autograd.Function):
             raise DcsHipError('cconv2d backward: only ACT_NONE / ACT_SIGMOID epilogues are differentiable here')
         gx1 = gx2 = gw_r = gw_i = gb_r = gb_i = None
         need = ctx.needs_input_grad
+        want_w = need[2] or need[3] or need[4] or need[5]
+        # The weight gradient feeds nothing before the optimizer, the data gradient feeds the whole rest of the backward pass:
+        # inside TrainStep's deferred-reduce scope (every result lands in the gradient bucket, slabs and operands are kept
+        # alive until the flush) the weight-gradient kernel goes to a SIDE stream that forks here, BEFORE the data gradient
+        # is queued, and joins once, in front of the flush (dp.TrainStep._backward) — it runs beside this layer's data
+        # gradient and under the launch-bound CBN / attention backward kernels of the next layer, which leave most CUs idle.
+        side = None
+        if (want_w and WGRAD_SIDE is not None and ops.WGRAD_DEFER is not None and gy.is_cuda and
+                8e-9 * gy.shape[0] * gy.shape[1] * gy.shape[2] * w_shape[0] * w_shape[1] * ksize[0] * ksize[1] >= WGRAD_SIDE_MIN_GFLOP and
+                ctx.sinks[0] is not None and ctx.sinks[1] is not None and (not has_bias or (ctx.sinks[2] is not None and ctx.sinks[3] is not None))):
+            side = WGRAD_SIDE
+            if not WGRAD_SIDE_AFTER_DGRAD:
+                side.wait_stream(torch.cuda.current_stream())
         if need[0] or need[1]:
             C1 = x1.shape[3]
             Cin = C1 + (x2.shape[3] if x2 is not None else 0)
             gx1, gx2 = ops.cconv2d_bwd_data(gy, ops.pack_conv_weight_bwd(wp, ksize, stride, pad, up),
                                             (x1.shape[1], x1.shape[2], Cin), ksize, stride, pad, up, C1)
-        if need[2] or need[3] or need[4] or need[5]:
-            g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks)
+        if want_w:
+            if side is not None and WGRAD_SIDE_AFTER_DGRAD:
+                side.wait_stream(torch.cuda.current_stream())
+            if side is not None:
+                with torch.cuda.stream(side):
+                    g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks)
+            else:
+                g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks)
             # gradients written straight into their sink are not handed back to autograd
             gw_r, gw_i, gb_r, gb_i = (None if sk is not None else t for t, sk in zip(g, ctx.sinks))
         return gx1, gx2, gw_r, gw_i, gb_r, gb_i, None, None, None, None, None, None, None
@@ -393,6 +418,15 @@ class _AttentionBlocksFn(torch.autograd.Function):
             full = (*fcs[i], g_c1r, g_c1i)
             grads_x.append(g_x)
             grads_p += [None if s_ is not None else g_ for g_, s_ in zip(full, sk)]
+        # Every decoder stage's weight-gradient kernel is queued on the side stream by now, and every 7x7 attention-conv
+        # problem of the step is recorded: their batched kernel and slab reductions (the first flush: ~100 us) run on the
+        # side stream from here, beside the LSTM and encoder backward, instead of after the last kernel of the step.
+        side = WGRAD_SIDE
+        if side is not None and ops.WGRAD_DEFER is not None and n and gs[0].is_cuda and WGRAD_SIDE_FLUSH:
+            ops.WGRAD_DEFER.append((sps, [r[1] for r in res]))
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.wgrad_defer_flush(partial=True)
         return (None, None, *grads_x, *grads_p)
 
 
@@ -525,6 +559,36 @@ class _LstmLayerFn(torch.autograd.Function):
         H = w_hh.shape[-1]
         NT = B2 * S
         g_pre, b_part = ops.lstm_layer_bwd(g_out.contiguous(), gates, c, w_hh, 2, B2, S, True)
+        g_gx = g_pre.view(2, NT, 8 * H)
+        # The input gradient feeds the rest of the backward pass; the four parameter gradients (three MFMA A^T B launches and
+        # two accumulation passes per layer) feed the optimizer only: inside TrainStep's backward they go to the weight-gradient
+        # side stream, forked here behind the recurrence kernel (operands kept alive until the join, as the conv slabs are).
+        side = WGRAD_SIDE if (WGRAD_SIDE_LSTM and ops.WGRAD_DEFER is not None and g_pre.is_cuda) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            g_inp = None
+            if ctx.needs_input_grad[0]:
+                if inp.dim() == 2:
+                    g_inp = torch.mm(g_gx[0], w_ih[0])
+                    g_inp.addmm_(g_gx[1], w_ih[1])
+                else:
+                    g_inp = torch.bmm(g_gx, w_ih)
+            with torch.cuda.stream(side):
+                _LstmLayerFn._param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT)
+            return g_inp, None, None, None, None
+        _LstmLayerFn._param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT)
+        if inp.dim() == 2:
+            g_inp = None
+            if ctx.needs_input_grad[0]:
+                g_inp = torch.mm(g_gx[0], w_ih[0])
+                g_inp.addmm_(g_gx[1], w_ih[1])              # (in place: torch.addmm copies its addend first)
+            return g_inp, None, None, None, None
+        g_inp = torch.bmm(g_gx, w_ih) if ctx.needs_input_grad[0] else None
+        return g_inp, None, None, None, None
+
+    @staticmethod
+    def _param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT):
+        global sink_hits
         # W_hh gradient per direction d: g_pre[set, (n t), d, :]^T h_prev[set, (n t), d, :] — strided views, no copies
         # (n t) is cut into CK chunks that ride the batch axis (rocBLAS runs a [4H x H] output with K = 4096 on 16
         # workgroups otherwise), summed afterwards in a fixed order
@@ -540,8 +604,10 @@ class _LstmLayerFn(torch.autograd.Function):
                 torch.bmm(a.transpose(1, 2), h, out=part[d])
         # chunk sums of the W_hh products and the per-sequence bias sums, accumulated into the three gradient views by one
         # launch (autograd's spelling: two reductions and three adds)
-        ops.lstm_param_grads(part, b_part.contiguous(), st['weight_hh'][1], st['bias_ih'][1], st['bias_hh'][1], CK, B2, H)
-        g_gx = g_pre.view(2, NT, 8 * H)
+        b_part = b_part.contiguous()
+        ops.lstm_param_grads(part, b_part, st['weight_hh'][1], st['bias_ih'][1], st['bias_hh'][1], CK, B2, H)
+        if ops.WGRAD_DEFER is not None:
+            ops.WGRAD_DEFER.append((part, b_part, g_pre, hprev, inp))       # alive until the flush (side stream)
         g_wih = st['weight_ih'][1]
         sink_hits += 16
         # W_ih gradient g_gx[s]^T inp over the (n t) rows: chunked A^T B on the MFMA pipe (rocBLAS: 25 us per 512 x 2048 x 256)
@@ -553,17 +619,11 @@ class _LstmLayerFn(torch.autograd.Function):
             else:
                 for s_ in range(2):
                     g_wih[s_].addmm_(g_gx[s_].t(), inp)
-            g_inp = None
-            if ctx.needs_input_grad[0]:
-                g_inp = torch.mm(g_gx[0], w_ih[0])
-                g_inp.addmm_(g_gx[1], w_ih[1])              # (in place: torch.addmm copies its addend first)
-            return g_inp, None, None, None, None
+            return
         if mfma_ok:
             ops.atb_chunks_acc(g_gx, inp, g_wih, 2, 8 * H, n_in, 8 * H, n_in, NT, CK)
         else:
             torch.baddbmm(g_wih, g_gx.transpose(1, 2), inp, out=g_wih)  # accumulate in place
-        g_inp = torch.bmm(g_gx, w_ih) if ctx.needs_input_grad[0] else None
-        return g_inp, None, None, None, None
 
 
 class _LstmCombineFn(torch.autograd.Function):
