@@ -299,35 +299,43 @@ struct PoolP { act_t* gx; const float* gpooled; long HW; int G; float inv_hw; in
 
 template <bool DROP>
 __global__ __launch_bounds__(kThreads) void att_bwd_sa_kernel(BwdSaP p, float drop_p, uint64_t seed, const uint64_t* seed_dev) {
+    DCS_PRIO_CRITICAL();
     att_bwd_sa_kernel_body<DROP>(p.x, p.go, p.ca, p.sa, p.gpre, p.HW, p.G, drop_p, seed, seed_dev, blockIdx.x, blockIdx.y, gridDim.x);
 }
 __global__ __launch_bounds__(kThreads) void att_bwd_sa_multi_kernel(Tbl<BwdSaP> t) {
+    DCS_PRIO_CRITICAL();
     const int z = tbl_find(t, blockIdx.x);
     const BwdSaP& p = t.p[z];
     att_bwd_sa_kernel_body<false>(p.x, p.go, p.ca, p.sa, p.gpre, p.HW, p.G, 0.f, 0, nullptr, blockIdx.x - t.x0[z], blockIdx.y, p.nx);
 }
 template <bool DROP>
 __global__ __launch_bounds__(kThreads) void att_bwd_x_kernel(BwdXP p, float drop_p, uint64_t seed, const uint64_t* seed_dev) {
+    DCS_PRIO_CRITICAL();
     att_bwd_x_kernel_body<DROP>(p.x, p.go, p.ca, p.sa, p.gsp, p.gx, p.part, p.HW, p.C, p.G, drop_p, seed, seed_dev, blockIdx.x,
                                 blockIdx.y, gridDim.x);
 }
 __global__ __launch_bounds__(kThreads) void att_bwd_x_multi_kernel(Tbl<BwdXP> t) {
+    DCS_PRIO_CRITICAL();
     const int z = tbl_find(t, blockIdx.x);
     const BwdXP& p = t.p[z];
     att_bwd_x_kernel_body<false>(p.x, p.go, p.ca, p.sa, p.gsp, p.gx, p.part, p.HW, p.C, p.G, 0.f, 0, nullptr, blockIdx.x - t.x0[z],
                                  blockIdx.y, p.nx);
 }
 __global__ __launch_bounds__(kThreads) void ca_bwd_sample_kernel(CaBwdP p) {
+    DCS_PRIO_CRITICAL();
     ca_bwd_sample_kernel_body(p.part, p.nchunks, p.ca, p.hidden, p.w1, p.w2, p.go, p.gh, p.gpooled, p.C, p.Ch, blockIdx.x, 0, 0);
 }
 __global__ __launch_bounds__(kThreads) void ca_bwd_sample_multi_kernel(Tbl<CaBwdP> t) {
+    DCS_PRIO_CRITICAL();
     const CaBwdP& p = t.p[blockIdx.z];
     ca_bwd_sample_kernel_body(p.part, p.nchunks, p.ca, p.hidden, p.w1, p.w2, p.go, p.gh, p.gpooled, p.C, p.Ch, blockIdx.x, 0, 0);
 }
 __global__ __launch_bounds__(kThreads) void att_bwd_pool_kernel(PoolP p) {
+    DCS_PRIO_CRITICAL();
     att_bwd_pool_kernel_body(p.gx, p.gpooled, p.HW, p.G, p.inv_hw, p.nx_pool, p.w, blockIdx.x, blockIdx.y, gridDim.x);
 }
 __global__ __launch_bounds__(kThreads) void att_bwd_pool_multi_kernel(Tbl<PoolP> t) {
+    DCS_PRIO_CRITICAL();
     const int z = tbl_find(t, blockIdx.x);
     const PoolP& p = t.p[z];
     att_bwd_pool_kernel_body(p.gx, p.gpooled, p.HW, p.G, p.inv_hw, p.nx_pool, p.w, blockIdx.x - t.x0[z], blockIdx.y, p.nx);

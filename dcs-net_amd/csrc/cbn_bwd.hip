@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const act_t* _
                                                                    int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                                    const float4* __restrict__ g_add, float add_scale, long HW,
                                                                    const act_t* __restrict__ g2_) {
+    DCS_PRIO_CRITICAL();
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     __shared__ double red[kThreads * 12];
     const int t = threadIdx.x;
@@ -163,6 +164,7 @@ __global__ void cbn_bwd_finalize_kernel(const double* __restrict__ part, int nbl
                                         const float* __restrict__ coef, float* __restrict__ g_weight,
                                         float* __restrict__ g_bias, float* __restrict__ bcoef, long P, int C,
                                         int use_batch_stats) {
+    DCS_PRIO_CRITICAL();
     // one wavefront per channel: lanes stride over the partial slabs, fp64 butterfly, lane 0 finishes
     const int c = blockIdx.x, lane = threadIdx.x;
     // (all of a lane's slab loads in flight at once: see cbn_finalize_kernel)
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const act_t* __
                                                                   int rows_per_iter, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                                   const float4* __restrict__ g_add, float add_scale, long HW,
                                                                   const act_t* __restrict__ g2_) {
+    DCS_PRIO_CRITICAL();
     if (seed_dev) seed += seed_dev[0];   // per-step device-side offset (graph replay safe)
     const int t = threadIdx.x;
     const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;

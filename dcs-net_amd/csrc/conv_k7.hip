@@ -25,6 +25,7 @@ struct K7Table { K7P p[kMaxBatch]; int x0[kMaxBatch + 1]; };
 
 template <int CI, int CO>
 __global__ __launch_bounds__(256) void cconv_k7_kernel(K7Table tb) {
+    DCS_PRIO_CRITICAL();
     __shared__ __attribute__((aligned(16))) float2 tile[CI][ROWS * COLSP];
     __shared__ __attribute__((aligned(16))) float4 wl[K * K * CI * CO];     // {w.x, w.y, w.y, w.x}: both broadcasts read a LOW half
     int z = 0;

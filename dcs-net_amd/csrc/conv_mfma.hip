@@ -99,6 +99,7 @@ long long* g_fdbg = nullptr;
 // enough workgroups without slicing, the partial sums never leave the CU and the launch goes.
 template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI = 1, bool STAT = false, int WK = 1>
 __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
+    DCS_PRIO_CRITICAL();
     constexpr bool BF = PR != 0;
     constexpr int NP = PR == 2 ? 3 : 1;                                // bf16 planes per operand
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
@@ -806,6 +807,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // ONE plane — one MFMA per tile and k-group, B panel [tap][kg16][64 lanes][8 bf16] (packjob::MFMA, flag 18).
 template <int CH, int PR = 0>
 __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
+    DCS_PRIO_CRITICAL();
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     constexpr int NP = PR == 2 ? 3 : 1;
     constexpr int U8 = PR != 0 ? CH / 16 : CH / 8, PIX = PR != 0 ? NP * CH + 4 : 2 * CH + 4, Q = CH / 2;
@@ -1005,6 +1007,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ bias, act_t* __restrict__ y,
                                                             act_t* __restrict__ y2, int nsplit, int N, int act,
                                                             const float* __restrict__ coef) {
+    DCS_PRIO_CRITICAL();
     const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
     if (i4 * 4 >= slab_floats) return;
     float4 v = *reinterpret_cast<const float4*>(part + i4 * 4);
@@ -1036,6 +1039,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
                                                                   const float* __restrict__ bias, act_t* __restrict__ y,
                                                                   float* __restrict__ stat, int stat_stride, long P, int N,
                                                                   int G, int rpi) {
+    DCS_PRIO_CRITICAL();
     __shared__ float red[256 * 10];
     const int t = threadIdx.x, g = t % G, r0 = t / G;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -52,6 +52,7 @@ __device__ __forceinline__ void dgrad_class(const DgArgs& d, const float2* patch
 }
 
 __global__ __launch_bounds__(TH * TW) void cconv_small_dgrad_s2_kernel(DgArgs d) {
+    DCS_PRIO_CRITICAL();
     __shared__ __attribute__((aligned(16))) float2 patch[(TH + 3) * (TW + 3) * DPIX];
     const int cls = blockIdx.y, b = blockIdx.z;
     const int cy0 = (blockIdx.x / d.tiles_w) * TH, cx0 = (blockIdx.x % d.tiles_w) * TW;

@@ -38,7 +38,8 @@ struct WArgs {
 };
 
 #ifndef DCS_WG_SETPRIO
-#define DCS_WG_SETPRIO 1      // progress-based wave priority (3 -> 0 over a workgroup's tiles)
+#define DCS_WG_SETPRIO 0      // progress-based wave priority (3 -> 0 over a workgroup's tiles): off since the kernel runs as the
+                             // BACKGROUND of the backward pass (dcs_common.h, DCS_PRIO_CRITICAL); standalone it measured neutral
 #endif
 #ifndef DCS_WG_RING_BIG
 #define DCS_WG_RING_BIG 2
@@ -699,7 +700,9 @@ int resident_x6(size_t lds) {
             (void)hipGetLastError();
             n = 1;
         }
-        cached = n > 4 ? 4 : n;
+        // (DCS_WGRAD_MAX_PER_CU: experiments with a kernel that leaves room on every CU for the kernels it runs beside)
+        static const int cap = [] { const char* e = getenv("DCS_WGRAD_MAX_PER_CU"); return e ? atoi(e) : 4; }();
+        cached = n > cap ? cap : n;
     }
     return cached;
 }

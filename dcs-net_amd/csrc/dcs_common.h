@@ -225,3 +225,18 @@ hipError_t dcs_ensure_dynamic_lds(const void* fn, size_t bytes);
 // 0: native fp32 MFMA, 1: bf16 operands, 2 (default): fp32 emulated by six bf16 MFMAs on exact three-way operand splits, in the
 // MFMA conv forward / data-gradient GEMMs (dcs_set_conv_precision)
 int dcs_conv_precision();
+
+// Wave priority of kernels on the train step's CRITICAL chain (Round 4).  The weight-gradient kernels run on a side stream
+// beside the data-gradient chain of the backward pass (dcsnet/functional.py, _CConv2dFn.backward); they feed nothing before the
+// optimizer, so they stay at the default priority 0 while every main-stream kernel that can be co-resident with them raises
+// its own: the instruction arbiter of a SIMD then serves the chain's waves first and the weight gradient fills the issue
+// slots and MFMA cycles the chain leaves idle, instead of sharing them evenly (age-based arbitration favours the older —
+// i.e. the weight-gradient — waves, and slowed the launch-bound kernels of the chain 2-3x: profiles/r04_side_stream_ab.txt).
+#ifndef DCS_CRITICAL_PRIO_LEVEL
+#define DCS_CRITICAL_PRIO_LEVEL 3
+#endif
+#if DCS_CRITICAL_PRIO_LEVEL > 0
+#define DCS_PRIO_CRITICAL() __builtin_amdgcn_s_setprio(DCS_CRITICAL_PRIO_LEVEL)
+#else
+#define DCS_PRIO_CRITICAL() ((void)0)
+#endif

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_bwd_kernel(const float* __rest
                                                            const float* __restrict__ gates, const float* __restrict__ cs,
                                                            const float* __restrict__ whh, float* __restrict__ g_pre,
                                                            float* __restrict__ g_bias_part, int S, int seqs_per_set) {
+    DCS_PRIO_CRITICAL();
     constexpr int G4 = 4 * H;
     __shared__ __attribute__((aligned(16))) float gp_s[2][G4];
     const int t = threadIdx.x, u = t >> 2, gate = t & 3, j = gate * H + u;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256) void lstm_combine_fwd_kernel(const float* __re
 }
 // its cotangent: g_o[0] = (g.re | g.im), g_o[1] = (g.im | -g.re)
 __global__ __launch_bounds__(256) void lstm_combine_bwd_kernel(const float2* __restrict__ g, float* __restrict__ g_o, long n) {
+    DCS_PRIO_CRITICAL();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float2 v = g[i];

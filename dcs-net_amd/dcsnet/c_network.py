@@ -19,7 +19,6 @@ callable (layer-by-layer drop-in surface, dcsnet/complexLayers.py).
 """
 import sys
 
-import os
 import torch
 
 from . import functional as F
@@ -251,9 +250,7 @@ class C_NETWORK(LightningModule):
         # dependencies under capture (inference pass 3.46 -> 3.37 ms).  Not in training: with the backward's mirror-image
         # fork the two cross-stream edges cost more than the overlap returns there (step 4.06 -> 4.12 ms, measured).
         side = None
-        train_side = (self.overlap_skip_attention_train and self.training and torch.is_grad_enabled() and
-                      os.environ.get('DCS_OVERLAP_SKIP_TRAIN', '0') != '0')
-        if self.overlap_skip_attention and (infer or train_side) and x.is_cuda:
+        if self.overlap_skip_attention and infer and x.is_cuda:
             cur = torch.cuda.current_stream(x.device)
             side = self.__dict__.get('_side_stream')
             if side is None or side.device != x.device:
@@ -263,7 +260,7 @@ class C_NETWORK(LightningModule):
             with torch.cuda.stream(side):
                 skips = self._skip_attentions(enc_skip)
         z = self.lstm(torch.view_as_complex(lat if adt == torch.float32 else lat.float()).view(B, F7 * T7, C7))   # (LSTM + fc: fp32)
-        if side is not None and not train_side:
+        if side is not None:
             # join BEFORE self.fc: the side stream's VALU kernels overlap the LSTM recurrence only (a VALU kernel too), never
             # an MFMA conv kernel — see the packed-fp32 / bf16-MFMA co-residency note in DESIGN.md §3
             cur.wait_stream(side)
@@ -282,16 +279,6 @@ class C_NETWORK(LightningModule):
 
         if side is None:
             skips = self._skip_attentions(enc_skip)
-        elif train_side:
-            # training (Round 4): the join sits in front of the decoder, so the batched skip attentions run beside the LSTM, the
-            # latent fc and its dropout; autograd replays the mirror image — every backward node runs on its forward's stream,
-            # the engine inserts the cross-stream waits — so the batched attention backward (five launches, 136 us) runs
-            # beside the LSTM backward (240 us of recurrence steps and small GEMMs that leave most CUs idle)
-            cur.wait_stream(side)
-            for t_ in skips:
-                t_.record_stream(cur)
-            for t_ in enc_skip[1:]:
-                t_.record_stream(side)
         for i in range(L):                                   # c_network.py:207-222
             skip = skips[i]
             stat = None
@@ -349,7 +336,6 @@ class C_NETWORK(LightningModule):
         return F.attention_blocks([enc[L - i] for i in range(L)], params, 7)
 
     batch_skip_attention = True
-    overlap_skip_attention_train = True
     supports_unbounded_forward = True      # forward(x, bound=False): see forward
     activation_dtype = torch.float32
 

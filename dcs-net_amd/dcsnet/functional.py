@@ -4,7 +4,6 @@ Everything here takes / returns channels-last float32 views ``[B,H,W,C,2]`` unle
 "complex" in its name.  Packed weights are cached per parameter version, so inference packs
 once and training re-packs after each optimizer step.
 """
-import os
 import weakref
 
 import torch
@@ -95,10 +94,6 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1), tap_rows=0):
 
 
 ATTENTION_BATCH_MAX = ops.ATTENTION_BATCH_MAX
-WGRAD_SIDE_AFTER_DGRAD = os.environ.get('DCS_WGRAD_SIDE_AFTER_DGRAD', '0') != '0'
-WGRAD_SIDE_FLUSH = os.environ.get('DCS_WGRAD_SIDE_FLUSH', '0') != '0'
-WGRAD_SIDE_LSTM = os.environ.get('DCS_WGRAD_SIDE_LSTM', '0') != '0'
-WGRAD_SIDE_MIN_GFLOP = float(os.environ.get('DCS_WGRAD_SIDE_MIN_GFLOP', '0'))
 WGRAD_SIDE = None      # the side stream the deferred weight-gradient kernels of a train step run on (dp.TrainStep._backward), else None
 sink_hits = 0          # diagnostics: how many parameter gradients were routed to a sink
 
@@ -152,19 +147,15 @@ class _CConv2dFn(torch.autograd.Function):
         # gradient and under the launch-bound CBN / attention backward kernels of the next layer, which leave most CUs idle.
         side = None
         if (want_w and WGRAD_SIDE is not None and ops.WGRAD_DEFER is not None and gy.is_cuda and
-                8e-9 * gy.shape[0] * gy.shape[1] * gy.shape[2] * w_shape[0] * w_shape[1] * ksize[0] * ksize[1] >= WGRAD_SIDE_MIN_GFLOP and
                 ctx.sinks[0] is not None and ctx.sinks[1] is not None and (not has_bias or (ctx.sinks[2] is not None and ctx.sinks[3] is not None))):
             side = WGRAD_SIDE
-            if not WGRAD_SIDE_AFTER_DGRAD:
-                side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(torch.cuda.current_stream())
         if need[0] or need[1]:
             C1 = x1.shape[3]
             Cin = C1 + (x2.shape[3] if x2 is not None else 0)
             gx1, gx2 = ops.cconv2d_bwd_data(gy, ops.pack_conv_weight_bwd(wp, ksize, stride, pad, up),
                                             (x1.shape[1], x1.shape[2], Cin), ksize, stride, pad, up, C1)
         if want_w:
-            if side is not None and WGRAD_SIDE_AFTER_DGRAD:
-                side.wait_stream(torch.cuda.current_stream())
             if side is not None:
                 with torch.cuda.stream(side):
                     g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks)
@@ -418,15 +409,6 @@ class _AttentionBlocksFn(torch.autograd.Function):
             full = (*fcs[i], g_c1r, g_c1i)
             grads_x.append(g_x)
             grads_p += [None if s_ is not None else g_ for g_, s_ in zip(full, sk)]
-        # Every decoder stage's weight-gradient kernel is queued on the side stream by now, and every 7x7 attention-conv
-        # problem of the step is recorded: their batched kernel and slab reductions (the first flush: ~100 us) run on the
-        # side stream from here, beside the LSTM and encoder backward, instead of after the last kernel of the step.
-        side = WGRAD_SIDE
-        if side is not None and ops.WGRAD_DEFER is not None and n and gs[0].is_cuda and WGRAD_SIDE_FLUSH:
-            ops.WGRAD_DEFER.append((sps, [r[1] for r in res]))
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                ops.wgrad_defer_flush(partial=True)
         return (None, None, *grads_x, *grads_p)
 
 
@@ -560,22 +542,6 @@ class _LstmLayerFn(torch.autograd.Function):
         NT = B2 * S
         g_pre, b_part = ops.lstm_layer_bwd(g_out.contiguous(), gates, c, w_hh, 2, B2, S, True)
         g_gx = g_pre.view(2, NT, 8 * H)
-        # The input gradient feeds the rest of the backward pass; the four parameter gradients (three MFMA A^T B launches and
-        # two accumulation passes per layer) feed the optimizer only: inside TrainStep's backward they go to the weight-gradient
-        # side stream, forked here behind the recurrence kernel (operands kept alive until the join, as the conv slabs are).
-        side = WGRAD_SIDE if (WGRAD_SIDE_LSTM and ops.WGRAD_DEFER is not None and g_pre.is_cuda) else None
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-            g_inp = None
-            if ctx.needs_input_grad[0]:
-                if inp.dim() == 2:
-                    g_inp = torch.mm(g_gx[0], w_ih[0])
-                    g_inp.addmm_(g_gx[1], w_ih[1])
-                else:
-                    g_inp = torch.bmm(g_gx, w_ih)
-            with torch.cuda.stream(side):
-                _LstmLayerFn._param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT)
-            return g_inp, None, None, None, None
         _LstmLayerFn._param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT)
         if inp.dim() == 2:
             g_inp = None
@@ -606,8 +572,6 @@ class _LstmLayerFn(torch.autograd.Function):
         # launch (autograd's spelling: two reductions and three adds)
         b_part = b_part.contiguous()
         ops.lstm_param_grads(part, b_part, st['weight_hh'][1], st['bias_ih'][1], st['bias_hh'][1], CK, B2, H)
-        if ops.WGRAD_DEFER is not None:
-            ops.WGRAD_DEFER.append((part, b_part, g_pre, hprev, inp))       # alive until the flush (side stream)
         g_wih = st['weight_ih'][1]
         sink_hits += 16
         # W_ih gradient g_gx[s]^T inp over the (n t) rows: chunked A^T B on the MFMA pipe (rocBLAS: 25 us per 512 x 2048 x 256)

@@ -9,7 +9,6 @@ spectrum, 512-point inverse real FFT (csrc/fft512.hip), window / overlap-add / e
 the configured loss pair (csrc/synth.hip).  On PyTorch-ROCm: the non-configured loss types (wSDR, L1, MSE reductions)
 and, for n_fft != 512 only, the inverse FFT (rocFFT via torch.fft.irfft).
 """
-import os
 import sys
 
 import torch
@@ -287,19 +286,7 @@ def _complex_step_pair(self, noise_data, noisy_data, clean_data):
     eps = self.hparams['atan2_eps']
     cfg = self.config
     B = noisy_data.shape[0]
-    # The two target waveforms depend on the batch only (no parameter, no gradient): on the GPU they are synthesised on the
-    # module's side stream beside the first stages of the network and joined in front of the losses (Round 4).
-    side = cur = None
-    if noisy_data.is_cuda and os.environ.get('DCS_OVERLAP_TARGETS', '0') != '0':
-        cur = torch.cuda.current_stream(noisy_data.device)
-        side = self.__dict__.get('_side_stream')
-        if side is None or side.device != noisy_data.device:
-            side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=noisy_data.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            tw = _polar_wave(_stacked(noise_data, clean_data), eps, cfg)
-    else:
-        tw = _polar_wave(_stacked(noise_data, clean_data), eps, cfg)
+    tw = _polar_wave(_stacked(noise_data, clean_data), eps, cfg)
     # the network's own bound_cRM and the second one of network_functions.py:240 run as ONE kernel on the raw output when
     # the module offers it (this build's C_NETWORK: forward(x, bound=False)); any other module gets the two-step form
     fused = getattr(self, 'supports_unbounded_forward', False)
@@ -315,9 +302,6 @@ def _complex_step_pair(self, noise_data, noisy_data, clean_data):
     else:
         mask, NS = apply_pair(noisy_data, mask_out, eps)
     ew = _polar_wave(NS.reshape((2 * B,) + tuple(NS.shape[2:])), eps, cfg)
-    if side is not None:
-        cur.wait_stream(side)
-        tw.record_stream(cur)
     return {'noise_audio': tw[:B], 'clean_audio': tw[B:], 'predict_noise_mask': mask,
             'predict_noise_audio': ew[:B], 'predict_clean_audio': ew[B:], '_pair': (tw, ew)}
 

@@ -448,19 +448,14 @@ def wgrad_defer_begin():
     WGRAD_DEFER = []
 
 
-def wgrad_defer_flush(partial=False):
-    """Run every recorded reduction as one batched launch on the current stream and release the slabs.  partial: the scope
-    stays open (a new recording starts) and the slabs / operands stay alive until the final flush — the caller runs this on
-    a side stream in the middle of backward, so nothing it reads may be recycled before that stream is joined."""
+def wgrad_defer_flush():
+    """Run every recorded reduction as one batched launch on the current stream and release the slabs."""
     global WGRAD_DEFER
     ev = CONV_TIMER.begin(0.0) if CONV_TIMER is not None else None     # the reduces belong to the conv family's time
     try:
         check(_lib.load().dcs_wgrad_defer_flush(cur_stream()), 'dcs_wgrad_defer_flush')
     finally:
-        if not partial:
-            WGRAD_DEFER = None
-    if partial:
-        check(_lib.load().dcs_wgrad_defer_begin(), 'dcs_wgrad_defer_begin')
+        WGRAD_DEFER = None
     if ev is not None:
         CONV_TIMER.end(ev)
 
