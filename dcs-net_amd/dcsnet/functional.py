@@ -94,6 +94,7 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1), tap_rows=0):
 
 
 ATTENTION_BATCH_MAX = ops.ATTENTION_BATCH_MAX
+
 WGRAD_SIDE = None      # the side stream the deferred weight-gradient kernels of a train step run on (dp.TrainStep._backward), else None
 sink_hits = 0          # diagnostics: how many parameter gradients were routed to a sink
 
@@ -158,7 +159,8 @@ class _CConv2dFn(torch.autograd.Function):
         if want_w:
             if side is not None:
                 with torch.cuda.stream(side):
-                    g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks)
+                    g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks,
+                                               immediate=True)
             else:
                 g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks)
             # gradients written straight into their sink are not handed back to autograd

@@ -385,7 +385,7 @@ def cconv2d_bwd_data(gy, wp_bwd, in_shape, ksize, stride, pad, up=(1, 1), C1=Non
     return gx1, gx2
 
 
-def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1, 1), transposed=False, outs=None):
+def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1, 1), transposed=False, outs=None, immediate=False):
     """Gradients in the reference's parameter layout: (gw_r, gw_i, gb_r, gb_i).  `outs`: optional
     pre-existing destinations (e.g. views of a flat gradient bucket) for any of the four."""
     _chk(x1, 'x1', 5, act=True)
@@ -417,7 +417,10 @@ def cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up=(1,
         scope.append((ws, x1, x2, gy))                # a deferred KERNEL (the small-channel one) still reads its inputs at the flush
     else:
         ws = _workspace(nbytes, dev)
-    suspend = scope is not None and not all_out
+    # immediate (the side-stream calls of a train step: functional._CConv2dFn.backward): the slab reduce follows its kernel on
+    # the same stream instead of waiting for the flush — the side stream has slack, the end of the step has none; the slabs
+    # still live until the flush (they are read on a stream that is joined only there)
+    suspend = scope is not None and (not all_out or immediate)
     if suspend:
         lib.dcs_wgrad_defer_suspend(1)
     ev = None
