@@ -245,6 +245,7 @@ class TrainStep:
                 side = self.__dict__['_wgrad_side'] = torch.cuda.Stream(device=loss.device)
         ops.wgrad_defer_begin()
         functional.WGRAD_SIDE = side
+        functional.FLUSH_AT_NEXT_FORK = False
         try:
             if one is None:
                 loss.backward()

@@ -95,6 +95,7 @@ def packed_weight(w_r, w_i, b_r, b_i, transposed, up=(1, 1), tap_rows=0):
 
 ATTENTION_BATCH_MAX = ops.ATTENTION_BATCH_MAX
 
+FLUSH_AT_NEXT_FORK = False   # set by the batched skip-attention backward: the next conv fork also flushes the recorded 7x7 problems
 WGRAD_SIDE = None      # the side stream the deferred weight-gradient kernels of a train step run on (dp.TrainStep._backward), else None
 sink_hits = 0          # diagnostics: how many parameter gradients were routed to a sink
 
@@ -161,6 +162,12 @@ class _CConv2dFn(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks,
                                                immediate=True)
+                    global FLUSH_AT_NEXT_FORK
+                    if FLUSH_AT_NEXT_FORK:
+                        # every 7x7 attention-conv problem of the step is recorded by now (the batched skip attentions came last):
+                        # their one batched kernel and its reductions ride on this fork and run beside the LSTM backward
+                        FLUSH_AT_NEXT_FORK = False
+                        ops.wgrad_defer_flush(partial=True)
             else:
                 g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks)
             # gradients written straight into their sink are not handed back to autograd
@@ -411,6 +418,10 @@ class _AttentionBlocksFn(torch.autograd.Function):
             full = (*fcs[i], g_c1r, g_c1i)
             grads_x.append(g_x)
             grads_p += [None if s_ is not None else g_ for g_, s_ in zip(full, sk)]
+        global FLUSH_AT_NEXT_FORK
+        if WGRAD_SIDE is not None and ops.WGRAD_DEFER is not None:
+            ops.WGRAD_DEFER.append((sps, [r[1] for r in res]))
+            FLUSH_AT_NEXT_FORK = True
         return (None, None, *grads_x, *grads_p)
 
 

@@ -451,14 +451,19 @@ def wgrad_defer_begin():
     WGRAD_DEFER = []
 
 
-def wgrad_defer_flush():
-    """Run every recorded reduction as one batched launch on the current stream and release the slabs."""
+def wgrad_defer_flush(partial=False):
+    """Run every recorded reduction as one batched launch on the current stream and release the slabs.  partial: the scope
+    stays open (a new recording starts) and slabs / operands stay alive until the final flush — the caller runs this on the
+    weight-gradient side stream in the middle of backward, which is joined only in front of the final flush."""
     global WGRAD_DEFER
     ev = CONV_TIMER.begin(0.0) if CONV_TIMER is not None else None     # the reduces belong to the conv family's time
     try:
         check(_lib.load().dcs_wgrad_defer_flush(cur_stream()), 'dcs_wgrad_defer_flush')
     finally:
-        WGRAD_DEFER = None
+        if not partial:
+            WGRAD_DEFER = None
+    if partial:
+        check(_lib.load().dcs_wgrad_defer_begin(), 'dcs_wgrad_defer_begin')
     if ev is not None:
         CONV_TIMER.end(ev)
 
