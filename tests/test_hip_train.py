@@ -359,3 +359,34 @@ def test_inference_side_stream_overlap_is_bit_identical(dev, graph):
             torch.cuda.synchronize()
     assert torch.equal(outs[False], outs[True])
     assert bool(torch.isfinite(torch.view_as_real(outs[True])).all())
+
+
+@pytest.mark.parametrize('graph', [False, True], ids=['eager', 'graph'])
+def test_side_stream_weight_gradients_are_bit_identical(dev, graph):
+    """TrainStep.wgrad_side_stream (Round 4): the weight-gradient kernels and their slab reductions on a side stream beside
+    the data-gradient chain — one fork per conv layer, one join in front of the flush — against the same step on one stream.
+    Same kernels on the same operands, so losses, gradients, parameters and moments agree BIT FOR BIT after several updates
+    with the reference's dropout on (a race on an operand or a slab recycled too early would show as a difference), eager
+    and captured; the batch is large enough for the multi-slab weight-gradient plans."""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    clean, noise = seeded_input(4, 256, 64, 1, 0.1), seeded_input(4, 256, 64, 2, 0.05)
+    batch = (noise.to(dev), (clean + noise).to(dev), clean.to(dev), [0, 1, 2, 3])
+    runs = []
+    for side in (False, True):
+        torch.manual_seed(0)
+        net = fill_state(C_NETWORK(config, dict(hparams), 0), 2).to(dev).train()
+        ts = TrainStep(net, use_graph=graph, graph_warmup=2)
+        ts.wgrad_side_stream = side
+        losses = [float(ts(batch)) for _ in range(5)]
+        torch.cuda.synchronize()
+        runs.append((losses, ts.bucket.flat.clone(), ts.bucket.grad.clone() if hasattr(ts.bucket, 'grad') else None, ts))
+    (l0, p0, g0, ts0), (l1, p1, g1, ts1) = runs
+    if graph:
+        assert ts1._graph is not None, 'capture did not happen (fell back to eager)'
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1)
+    if g0 is not None:
+        assert torch.equal(g0, g1)
+    assert all(torch.isfinite(torch.tensor(l1)))
