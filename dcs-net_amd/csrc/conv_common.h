@@ -24,6 +24,7 @@
 #define dcs_conv_wgrad_mfma_ok dcs_conv_wgrad_mfma_ok_h
 #define dcs_conv_wgrad_mfma_slabs dcs_conv_wgrad_mfma_slabs_h
 #define dcs_conv_wgrad_mfma_launch dcs_conv_wgrad_mfma_launch_h
+#define dcs_conv_wgrad_mfma_planes_bytes dcs_conv_wgrad_mfma_planes_bytes_h
 #define dcs_conv_wgrad_fold_ok dcs_conv_wgrad_fold_ok_h
 #define dcs_conv_wgrad_fold_workspace_bytes dcs_conv_wgrad_fold_workspace_bytes_h
 #define dcs_conv_wgrad_fold_run dcs_conv_wgrad_fold_run_h
@@ -124,7 +125,9 @@ void stride_classes(int Cout, int Cin, int kh, int kw, int sf, int st, int pad_f
 bool dcs_conv_wgrad_mfma_ok(int Cin, int Cout, int kh, int kw, int C1);
 int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW);
 int dcs_conv_wgrad_mfma_launch(conv::Args& a, const act_t* gy, float2* slab_w, float* slab_b, int n_slabs,
-                               hipStream_t stream);
+                               hipStream_t stream, void* planes = nullptr);
+// bytes of the pre-split g_Y (three bf16 planes in A-fragment order) the emulated kernel of this geometry can use, 0 if none
+long dcs_conv_wgrad_mfma_planes_bytes(const conv::Args& a);
 
 // conv_wgrad_mfma.hip: weight gradient of a 3x3 conv over an upsampled input in its folded (per-class, source-
 // resolution) form; kernel + reduce into the parameter layout

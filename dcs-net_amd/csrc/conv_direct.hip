@@ -784,6 +784,8 @@ extern "C" long dcs_cconv2d_bwd_weight_workspace_bytes(int B, int Hin, int Win, 
         if (nm > ns) ns = nm;
     }
     long bytes = (long)ns * (wsz + Cout) * (long)sizeof(float2);
+    if (dcs_conv_wgrad_mfma_ok(C1 + C2, Cout, kh, kw, C1) && !dcs_conv_wgrad_fold_ok(a))
+        bytes = ((bytes + 255) & ~255L) + dcs_conv_wgrad_mfma_planes_bytes(a);      // (the pre-split g_Y behind the slabs)
     if (dcs_conv_wgrad_fold_ok(a)) {
         const long fb = dcs_conv_wgrad_fold_workspace_bytes(a);
         if (fb > bytes) bytes = fb;
@@ -813,7 +815,9 @@ extern "C" int DCS_SYM(dcs_cconv2d_bwd_weight)(const act_t* x1, const act_t* x2,
         float2* slab_w = (float2*)workspace;
         float2* slab_b = slab_w + (long)ns * wsz;
         hipStream_t s = dcs_stream(stream);
-        const int rc = dcs_conv_wgrad_mfma_launch(a, gy, slab_w, (float*)slab_b, ns, s);
+        const long slabs = ((long)ns * (wsz + Cout) * (long)sizeof(float2) + 255) & ~255L, pb = dcs_conv_wgrad_mfma_planes_bytes(a);
+        void* planes = (pb > 0 && workspace_bytes >= slabs + pb) ? (char*)workspace + slabs : nullptr;
+        const int rc = dcs_conv_wgrad_mfma_launch(a, gy, slab_w, (float*)slab_b, ns, s, planes);
         if (rc != DCS_OK) return rc;
         return launch_wgrad_reduce(slab_w, slab_b, ns, gw_r, gw_i, gb_r, gb_i, Cout, C1 + C2, kh, kw, transposed, s);
     }

@@ -35,6 +35,9 @@ struct WArgs {
     int ncls, os_f, os_t, Hy, Wy;
     int pad_f[4], pad_t[4], oo_f[4], oo_t[4];
     long long* dbg;            // diagnostic builds only (-DDCS_WGRAD_DIAG): per-wave phase times (s_memtime ticks)
+    // Round 4: g_Y pre-split into its three bf16 planes in MFMA A-fragment order by gy_planes_kernel (below), or nullptr:
+    // uint4[cls][tile][k-step][plane][2 Cout / 16][64 lanes] — a lane's 16 bytes are its 8 pixels of one (co, re|im) row
+    const uint4* gy_planes;
 };
 
 #ifndef DCS_WG_SETPRIO
@@ -366,8 +369,15 @@ constexpr int PIXE = 28;       // LDS floats per patch pixel: 3 planes x 8 float
 
 // TS (the 7x7 layer with 16 output channels, as in the native kernel): the four waves split the TAPS (13 each) and every
 // wave covers all MT*8 output channels and all pixels.
-template <int KH, int KW, int MT, int WS = 1, bool TS = false>
+// PA (Round 4; plain form only: WS = 1, no tap split): operand A comes PRE-SPLIT from w.gy_planes.  Every workgroup of the
+// same output-channel block — one per 8-channel input chunk: 32 of them at 256 input channels — used to load its g_Y values
+// with 8 masked dword loads per row tile and k-step (64-bit per-lane addresses) and split them into the three planes itself:
+// ~200 of the ~310 vector instructions a wave issued beside the 72 MFMAs of a k-step (valu / MFMA 5.1, MFMA busy 0.35:
+// profiles/r04_a_pmc_wait_states.txt).  Now one pass (gy_planes_kernel) splits g_Y once per layer, edge masks included, and a
+// k-step's operand A is MT x 3 unconditional 16-byte loads at a wave-uniform base.
+template <int KH, int KW, int MT, int WS = 1, bool TS = false, bool PA = false>
 __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
+    static_assert(!PA || (WS == 1 && !TS && !DCS_ACT_IS_BF16), "pre-split g_Y: plain fp32 form only");
     constexpr int TAPS = TS ? (KH * KW + 3) / 4 : KH * KW;          // taps per wave
     constexpr int ALLTAPS = KH * KW;
     constexpr int WCO = TS ? 1 : 4 / WS;                // waves sharing the block's output channels
@@ -492,6 +502,20 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         const int estr = w.os_t * N1;                                  // floats between horizontally adjacent g_Y pixels of the class
         const int nks = npx >> 5;
         // this lane's 8 pixels of k-step ks: tile pixel 32 ks + 8 lk + e, e = 0..7 (one tile row: TW >= 16)
+        // PA: this tile's pre-split g_Y (wave-uniform base; a lane's fragment of (k-step, plane, row block) is one uint4)
+        constexpr int NPA = PA ? NP : 1;
+        uint4 araw[2][MT][NPA];
+        const int nblk = N1 >> 4;
+        const uint4* pa_tile = PA ? w.gy_planes + ((long)cls * w.total_tiles + tl) * nks * (long)(NP * nblk * 64) + lane : nullptr;
+        auto load_a = [&](int ks, uint4 (*dst)[NPA]) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                int mb = __builtin_amdgcn_readfirstlane((co0 + i * 8) >> 3);
+                mb = mb < nblk ? mb : 0;                               // (a block past Cout: its rows are dropped by the epilogue)
+#pragma unroll
+                for (int pl = 0; pl < NPA; ++pl) dst[i][pl] = pa_tile[((long)(ks * NP + pl) * nblk + mb) * 64];
+            }
+        };
         float raw[2][MT][8];
         auto load_g = [&](int ks, float (*dst)[8]) {
             const int p8 = CF ? ks * 32 + 16 * (lk >> 1) + 4 * (lk & 1) : ks * 32 + 8 * lk;     // e < 4: pixels p8 + e; e >= 4: p8 + 8 + (e - 4)
@@ -506,7 +530,8 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                 for (int i = 0; i < MT; ++i) dst[i][e] = dcs_ld1(gyb + off + gcl[i]);
             }
         };
-        load_g(part < nks ? part : nks - 1, raw[0]);
+        if constexpr (PA) load_a(part < nks ? part : nks - 1, araw[0]);
+        else load_g(part < nks ? part : nks - 1, raw[0]);
 #pragma unroll
         for (int j = 0; j < 8 / WS; ++j) {                             // (tiles of up to 256 pixels: tile_shape_for)
             const int ks = part + j * WS;
@@ -516,6 +541,23 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
             const bool rowok = oy0 + py < a.Hout;
             // operand A: the three planes of this lane's 8 g_Y values per row tile
             bf16x8w ap[MT][NP];
+            if constexpr (PA) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) ap[i][pl] = __builtin_bit_cast(bf16x8w, araw[j & 1][i][pl < NPA ? pl : 0]);
+                    if (ci0 == 0) {                                    // bias gradient: the exact value back from its three terms
+                        const uint4 p0 = araw[j & 1][i][0], p1 = araw[j & 1][i][NPA > 1 ? 1 : 0], p2 = araw[j & 1][i][NPA > 2 ? 2 : 0];
+                        const unsigned w0[4] = {p0.x, p0.y, p0.z, p0.w}, w1[4] = {p1.x, p1.y, p1.z, p1.w}, w2[4] = {p2.x, p2.y, p2.z, p2.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bsum[i] += (__uint_as_float(w0[q] << 16) + __uint_as_float(w1[q] << 16)) + __uint_as_float(w2[q] << 16);
+                            bsum[i] += (__uint_as_float(w0[q] & 0xffff0000u) + __uint_as_float(w1[q] & 0xffff0000u)) +
+                                       __uint_as_float(w2[q] & 0xffff0000u);
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 float r[8];
@@ -541,7 +583,10 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
                     ap[i][pl] = __builtin_bit_cast(bf16x8w, hp);
                 }
             }
-            if (j + 1 < 8 / WS) load_g(ks + WS < nks ? ks + WS : nks - 1, raw[(j + 1) & 1]);
+            if (j + 1 < 8 / WS) {
+                if constexpr (PA) load_a(ks + WS < nks ? ks + WS : nks - 1, araw[(j + 1) & 1]);
+                else load_g(ks + WS < nks ? ks + WS : nks - 1, raw[(j + 1) & 1]);
+            }
             // operand B: lane (row q = li / 4, column quad li % 4) of its 16-lane group addresses pixel 8 lk + q (+ 4)
             const int q = li >> 2, p4 = li & 3;
             const int xrow0 = ((py * a.sf) * a.cols + (px0 + q) * a.st) * PIXR + p4 * 2;
@@ -665,6 +710,45 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
 #endif
 }
 
+#if !DCS_ACT_IS_BF16
+// g_Y -> three bf16 planes in the A-fragment order of cconv_wgrad_x6_kernel<..., PA = true> (WArgs::gy_planes): one thread per
+// (class, tile, k-step, 16-row block, lane) reads the lane's 8 pixels of its (co, re|im) row — the access pattern the kernel
+// itself had: the 16 lanes of a group cover 64 contiguous bytes per pixel — masks what lies outside the class extent, splits
+// exactly as the kernel did (dcs_split_pair) and stores three 16-byte fragments.  Same tile / pixel / k-index maps as the kernel.
+__global__ __launch_bounds__(256) void gy_planes_kernel(WArgs w, uint4* __restrict__ out) {
+    const conv::Args& a = w.c;
+    const int cls = blockIdx.z, mb = blockIdx.y, lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+    const int npx = w.TH * w.TW, nks = npx >> 5;
+    const long unit = (long)blockIdx.x * 4 + threadIdx.y;
+    if (unit >= (long)w.total_tiles * nks) return;
+    const int tl = (int)(unit / nks), ks = (int)(unit % nks);
+    const int tiles_per_img = a.tiles_w * a.tiles_h;
+    const int b = tl / tiles_per_img, tile_id = tl % tiles_per_img;
+    const int oy0 = (tile_id / a.tiles_w) * w.TH, ox0 = (tile_id % a.tiles_w) * w.TW;
+    const int N1 = 2 * a.Cout, nblk = N1 >> 4;
+    constexpr bool CF = DCS_X6_CFMAP;
+    const int p8 = CF ? ks * 32 + 16 * (lk >> 1) + 4 * (lk & 1) : ks * 32 + 8 * lk;
+    const int oy = oy0 + (p8 >> w.twshift), oxb = ox0 + (p8 & (w.TW - 1));
+    const float* gyb = w.gy + (long)b * w.Hy * w.Wy * N1 + (mb * 16 + li);
+    const long soff = ((long)(oy * w.os_f + w.oo_f[cls]) * w.Wy + oxb * w.os_t + w.oo_t[cls]) * N1;
+    const int estr = w.os_t * N1;
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ee = CF ? (e < 4 ? e : e + 4) : e;
+        r[e] = (oy < a.Hout && oxb + ee < a.Wout) ? gyb[soff + (long)ee * estr] : 0.f;
+    }
+    uint4* dst = out + ((((long)cls * w.total_tiles + tl) * nks + ks) * 3 * nblk + mb) * 64 + lane;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        uint4 hp;
+        if (pl < 2) hp = make_uint4(dcs_split_pair(r[0], r[1]), dcs_split_pair(r[2], r[3]), dcs_split_pair(r[4], r[5]), dcs_split_pair(r[6], r[7]));
+        else hp = make_uint4(dcs_pack_bf16x2(r[0], r[1]), dcs_pack_bf16x2(r[2], r[3]), dcs_pack_bf16x2(r[4], r[5]), dcs_pack_bf16x2(r[6], r[7]));
+        dst[(long)pl * nblk * 64] = hp;
+    }
+}
+#endif
+
 template <int KH_, int KW_, int MT_, int WS_, bool TS_ = false> struct Variant {
     static constexpr int KH = KH_, KW = KW_, MT = MT_, WS = WS_;
     static constexpr bool TS = TS_;
@@ -690,13 +774,13 @@ inline bool wgrad_x6_enabled() {
     return e != 0 && dcs_conv_precision() == 2;
 }
 
-template <int KH, int KW, int MT, int WS, bool TS>
+template <int KH, int KW, int MT, int WS, bool TS, bool PA = false>
 int resident_x6(size_t lds) {
     static int by_kb[161] = {0};
     int& cached = by_kb[lds / 1024 > 160 ? 160 : lds / 1024];
     if (cached == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cconv_wgrad_x6_kernel<KH, KW, MT, WS, TS>, 256, lds) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cconv_wgrad_x6_kernel<KH, KW, MT, WS, TS, PA>, 256, lds) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 1;
         }
@@ -782,11 +866,26 @@ int launch_x6(WArgs& w, int Cin, hipStream_t stream) {
     const size_t red = TS ? 0 : (size_t)(WS - 1) * (4 / WS) * (MT * KH * KW * 4 + MT) * 64 * sizeof(float);
     if (red > lds) lds = red;
     if (lds > 150 * 1024) return DCS_ERR_BADARG;
-    auto fn = cconv_wgrad_x6_kernel<KH, KW, MT, WS, TS>;
     constexpr int CPBX = TS ? MT * 8 : (4 / WS) * MT * 8;
     w.co_blocks = (a.Cout + CPBX - 1) / CPBX;
     dim3 grid(w.n_slabs, (Cin / CHUNK) * w.co_blocks, w.ncls);
     if (grid.y > 65535) return DCS_ERR_BADARG;
+#if !DCS_ACT_IS_BF16
+    if constexpr (WS == 1 && !TS) {
+        if (w.gy_planes) {                                             // g_Y split once for all input-channel chunks (PA)
+            const long units = (long)w.total_tiles * ((w.TH * w.TW) >> 5);
+            dim3 pgrid((unsigned)((units + 3) / 4), (unsigned)(2 * a.Cout / 16), (unsigned)w.ncls);
+            DCS_LAUNCH(gy_planes_kernel, pgrid, dim3(64, 4), 0, stream, w, const_cast<uint4*>(w.gy_planes));
+            DCS_CHECK_LAUNCH();
+            auto fnp = cconv_wgrad_x6_kernel<KH, KW, MT, WS, TS, true>;
+            if (dcs_ensure_dynamic_lds((const void*)fnp, lds) != hipSuccess) return DCS_ERR_LAUNCH;
+            DCS_LAUNCH(fnp, grid, dim3(256), lds, stream, w);
+            DCS_CHECK_LAUNCH();
+            return DCS_OK;
+        }
+    }
+#endif
+    auto fn = cconv_wgrad_x6_kernel<KH, KW, MT, WS, TS>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
     DCS_LAUNCH(fn, grid, dim3(256), lds, stream, w);
     DCS_CHECK_LAUNCH();
@@ -857,6 +956,8 @@ conv::Args class_args(const conv::Args& a, const Fold& f) {
     return c;
 }
 
+long planes_bytes_for(const conv::Args& c, int ncls, int TH, int TW);
+
 // slabs per class for a class-space geometry `c` (tiling filled in), ncls classes
 int slabs_for(const conv::Args& c, int ncls, int TH, int TW) {
     const long tiles = (long)((c.Wout + TW - 1) / TW) * ((c.Hout + TH - 1) / TH) * c.B;
@@ -877,6 +978,16 @@ int slabs_for(const conv::Args& c, int ncls, int TH, int TW) {
             if (wgrad_x6_enabled() && TW >= 16 && (TH * TW) % 32 == 0) {     // the emulated instance: its own block size / residency
                 cpb = X6<V>::CPB;
                 per_cu = resident_x6<V::KH, V::KW, X6<V>::MT, X6<V>::WS, V::TS>((size_t)rows * cols * PIXE * sizeof(float));
+#if !DCS_ACT_IS_BF16
+                // The pre-split form holds ~40 registers less (four workgroups per CU instead of three).  Planned that way
+                // (DCS_WGRAD_PA_RESIDENCY=1) the kernels alone gain another 7 % (dec1 82 -> 76 us) but the train step LOSES 0.035 ms:
+                // the kernels run on the side stream beside the data gradients, which then find less room (profiles/r04_wgrad_pa.txt).
+                if constexpr (!V::TS && X6<V>::WS == 1) {
+                    static const int pa_res = [] { const char* e = getenv("DCS_WGRAD_PA_RESIDENCY"); return e ? atoi(e) : 0; }();
+                    if (pa_res && planes_bytes_for(c, ncls, TH, TW) > 0)
+                        per_cu = resident_x6<V::KH, V::KW, X6<V>::MT, 1, false, true>((size_t)rows * cols * PIXE * sizeof(float));
+                }
+#endif
             }
         }
         return 0;
@@ -924,11 +1035,30 @@ void tile_shape_for(const conv::Args& g, int Hc, int Wc, int* TH, int* TW) {
     if (patch <= 48 * 1024) *TH *= 2;
 }
 
-// c: class-space geometry; f: classes; Hy x Wy: full g_Y extent
+// bytes of the pre-split g_Y (WArgs::gy_planes) for a class-space geometry, or 0 where the launch would not use it: the plain
+// emulated form (>= 32 output channels, kernel below 7x7) with at least DCS_WGRAD_PA_MIN_CHUNKS input-channel chunks re-reading
+// the same g_Y (the split pass costs a read and 1.5 writes of g_Y; below ~8 chunks the kernels' own split is cheaper)
+long planes_bytes_for(const conv::Args& c, int ncls, int TH, int TW) {
+    if (DCS_ACT_IS_BF16 || !wgrad_x6_enabled() || TW < 16 || (TH * TW) % 32 != 0 || (c.Cout % 8) != 0) return 0;
+    static const int min_chunks = [] { const char* e = getenv("DCS_WGRAD_PA_MIN_CHUNKS"); return e ? atoi(e) : 8; }();
+    if ((c.C1 + c.C2) / CHUNK < min_chunks) return 0;
+    bool ok = false;
+    dispatch(c.kh, c.kw, c.Cout, [&](auto v) {
+        using V = decltype(v);
+        ok = X6<V>::ok && !V::TS && X6<V>::WS == 1;
+        return 0;
+    });
+    if (!ok) return 0;
+    const long tiles = (long)((c.Wout + TW - 1) / TW) * ((c.Hout + TH - 1) / TH) * c.B;
+    return (long)ncls * tiles * ((TH * TW) >> 5) * 3 * (2 * c.Cout / 16) * 64 * (long)sizeof(uint4);
+}
+
+// c: class-space geometry; f: classes; Hy x Wy: full g_Y extent; planes: room for planes_bytes_for(...) bytes, or nullptr
 int launch_classes(const conv::Args& c, const Fold& f, int Hy, int Wy, const act_t* gy, float2* slab_w, float* slab_b,
-                   int n_slabs, int TH, int TW, hipStream_t stream) {
+                   int n_slabs, int TH, int TW, hipStream_t stream, void* planes = nullptr) {
     WArgs w;
     w.c = c;
+    w.gy_planes = (planes && planes_bytes_for(c, f.ncls, TH, TW) > 0) ? (const uint4*)planes : nullptr;
 #ifdef DCS_WGRAD_DIAG
     w.dbg = g_wdbg;
 #else
@@ -967,13 +1097,20 @@ int dcs_conv_wgrad_mfma_slabs(const conv::Args& a, int* TH, int* TW) {
 
 // slab_w: float2[n_slabs][taps][Cin][Cout]; slab_b: float[n_slabs][2*Cout]
 int dcs_conv_wgrad_mfma_launch(conv::Args& a, const act_t* gy, float2* slab_w, float* slab_b, int n_slabs,
-                               hipStream_t stream) {
+                               hipStream_t stream, void* planes) {
     int TH, TW;
     tile_shape_for(a, a.Hout, a.Wout, &TH, &TW);
     Fold f{};
     f.ncls = 1; f.kh = a.kh; f.kw = a.kw; f.os_f = 1; f.os_t = 1;
     f.pad_f[0] = a.pad_f; f.pad_t[0] = a.pad_t;
-    return launch_classes(a, f, a.Hout, a.Wout, gy, slab_w, slab_b, n_slabs, TH, TW, stream);
+    return launch_classes(a, f, a.Hout, a.Wout, gy, slab_w, slab_b, n_slabs, TH, TW, stream, planes);
+}
+
+// bytes of the pre-split g_Y the plain (unfolded) launch of geometry `a` can use (0: none) — behind the slabs in the workspace
+long dcs_conv_wgrad_mfma_planes_bytes(const conv::Args& a) {
+    int TH, TW;
+    tile_shape_for(a, a.Hout, a.Wout, &TH, &TW);
+    return planes_bytes_for(a, 1, TH, TW);
 }
 
 // upsample-folded path: forward geometry `a` (a.Hout / a.Wout set) of a 3x3 stride-1 pad-1 conv over an upsampled input
@@ -999,7 +1136,8 @@ long dcs_conv_wgrad_fold_workspace_bytes(const conv::Args& a) {
     int TH, TW;
     tile_shape_for(c, c.Hout, c.Wout, &TH, &TW);
     const long ns = slabs_for(c, f.ncls, TH, TW);
-    return ns * f.ncls * ((long)f.kh * f.kw * (a.C1 + a.C2) * a.Cout + a.Cout) * (long)sizeof(float2);
+    const long slabs = ns * f.ncls * ((long)f.kh * f.kw * (a.C1 + a.C2) * a.Cout + a.Cout) * (long)sizeof(float2);
+    return ((slabs + 255) & ~255L) + planes_bytes_for(c, f.ncls, TH, TW);       // (+ the pre-split g_Y behind the slabs)
 }
 
 int dcs_conv_wgrad_fold_run(const conv::Args& a, const act_t* gy, void* workspace, long workspace_bytes, float* gw_r,
@@ -1015,7 +1153,9 @@ int dcs_conv_wgrad_fold_run(const conv::Args& a, const act_t* gy, void* workspac
     if (workspace_bytes < (long)ns * f.ncls * (wsz_c + a.Cout) * (long)sizeof(float2)) return DCS_ERR_WORKSPACE;
     float2* slab_w = (float2*)workspace;
     float2* slab_b = slab_w + (long)ns * f.ncls * wsz_c;
-    const int rc = launch_classes(c, f, a.Hout, a.Wout, gy, slab_w, (float*)slab_b, ns, TH, TW, stream);
+    const long slabs = (long)ns * f.ncls * (wsz_c + a.Cout) * (long)sizeof(float2), pb = planes_bytes_for(c, f.ncls, TH, TW);
+    void* planes = (pb > 0 && workspace_bytes >= ((slabs + 255) & ~255L) + pb) ? (char*)workspace + ((slabs + 255) & ~255L) : nullptr;
+    const int rc = launch_classes(c, f, a.Hout, a.Wout, gy, slab_w, (float*)slab_b, ns, TH, TW, stream, planes);
     if (rc != DCS_OK) return rc;
     wreduce::Job j{};                                     // class gradients -> 3x3 parameter (wgrad_reduce.hip)
     j.slab_w = slab_w; j.slab_b = slab_b; j.gw_r = gw_r; j.gw_i = gw_i; j.gb_r = gb_r; j.gb_i = gb_i;

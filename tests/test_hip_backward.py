@@ -67,7 +67,10 @@ def dev_params(mod, dev):
 
 @pytest.mark.parametrize('cin,cout,k,stride,hw', [(1, 8, 7, (2, 2), (40, 36)), (1, 8, 7, (2, 2), (75, 134)), (8, 16, 7, (2, 2), (20, 24)),
                                                    (16, 32, 5, (2, 1), (12, 9)), (64, 128, 3, (2, 1), (8, 16)),
-                                                   (4, 2, 3, (1, 2), (19, 9))])
+                                                   (4, 2, 3, (1, 2), (19, 9)),
+                                                   # >= 8 input-channel chunks: the weight gradient takes g_Y pre-split (gy_planes_kernel,
+                                                   # conv_wgrad_mfma.hip) — ragged tiles, 3x3 and 5x5, 32 .. 128 output channels
+                                                   (128, 64, 3, (1, 1), (9, 37)), (64, 32, 5, (2, 2), (21, 45)), (72, 40, 3, (2, 1), (11, 19))])
 def test_conv2d_backward(dev, cin, cout, k, stride, hw):
     from dcsnet import functional as F
     torch.manual_seed(cin + k)
@@ -101,7 +104,8 @@ def test_first_encoder_conv_weight_gradient_train_size(dev):
         close(p[n].grad, q.grad, rel=3e-4, what=n)     # sums of 524 k fp32 terms in two different orders
 
 
-@pytest.mark.parametrize('c1,c2,cout,up', [(128, 128, 64, (2, 1)), (16, 16, 8, (2, 2)), (8, 8, 1, (2, 2)), (16, 0, 8, (1, 1))])
+@pytest.mark.parametrize('c1,c2,cout,up', [(128, 128, 64, (2, 1)), (16, 16, 8, (2, 2)), (8, 8, 1, (2, 2)), (16, 0, 8, (1, 1)),
+                                           (96, 32, 32, (2, 2)), (64, 64, 128, (2, 1))])
 def test_convtranspose_cat_upsample_backward(dev, c1, c2, cout, up):
     from dcsnet import functional as F
     torch.manual_seed(c1 + cout)

@@ -7,6 +7,10 @@ tag=$1; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag
 mkdir -p $out && cd /tmp && export TMPDIR=/tmp
 echo "[collect] bench train (default flags)"; timeout -k 10 400 python3 $R/bench.py > $out/bench_train_default.json 2> $out/bench_train.log
 echo "[collect] bench infer"; timeout -k 10 400 python3 $R/bench.py --mode infer > $out/bench_infer.json 2> $out/bench_infer.log
+# Kernel statistics and counters are taken with the train step on ONE stream (DCS_WGRAD_SIDE=0): co-scheduled with the side
+# stream's weight gradients a kernel's duration includes the time it shares the card, and bench.py's roofline is priced on the
+# kernels' own durations (its instrumented pass runs on one stream as well).  The shipped two-stream step is traced separately.
+export DCS_WGRAD_SIDE=0
 for mode in train infer; do
   echo "[collect] kernel stats $mode"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$mode -- python3 $R/bench.py --mode $mode --no-cpu-baseline --no-native-line > $out/stats_$mode.log 2>&1
@@ -45,6 +49,12 @@ python3 $R/tools/step_sequence.py $(find $out/kt_train -name "*kernel_trace.csv"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/kt_infer -- python3 $R/bench.py --mode infer --no-cpu-baseline --no-native-line --steps 4 --warmup 2 > $out/kt_infer.log 2>&1
 python3 $R/tools/infer_sequence.py $(find $out/kt_infer -name "*kernel_trace.csv" | head -1) > $out/step_sequence_infer.txt
 rm -rf $out/kt_train $out/kt_infer
+unset DCS_WGRAD_SIDE
+echo "[collect] the shipped two-stream train step: kernel stats and timeline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_side -- python3 $R/bench.py --no-cpu-baseline --no-native-line --no-sub-lines > $out/stats_side.log 2>&1
+cp $(find $out/stats_side -name "*kernel_stats.csv" | head -1) $out/train_side_stream_kernel_stats.csv
+python3 $R/tools/step_timeline.py $(find $out/stats_side -name "*kernel_trace.csv" | head -1) 8 > $out/step_timeline_train.txt
+rm -rf $out/stats_side
 echo "[collect] bf16 activation storage at B = 64 (BASELINE.json configs[4], per-GPU share) beside fp32 at the same batch"
 timeout -k 10 400 python3 $R/bench.py --dtype bf16 --batch 64 --no-cpu-baseline > $out/bench_train_bf16_b64.json 2> $out/bench_bf16.log
 timeout -k 10 400 python3 $R/bench.py --batch 64 --no-cpu-baseline > $out/bench_train_f32_b64.json 2> $out/bench_f32_b64.log

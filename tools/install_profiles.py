@@ -15,7 +15,8 @@ for a, b in (('bench_train_default.json', 'bench_train_default.json'), ('bench_i
 for a in ('mfma_peak.txt', 'conv_layers_train.txt', 'conv_layers_infer.txt', 'lstm_bench.txt',
           'step_sequence_train.txt', 'step_sequence_infer.txt', 'conv_layers_train_native.txt', 'conv_layers_infer_native.txt',
           'conv_precision.txt', 'train_native_kernel_stats.csv', 'infer_native_kernel_stats.csv', 'bench_train_bf16_b64.json',
-          'bench_train_f32_b64.json', 'step_sequence_train_bf16_b64.txt'):
+          'bench_train_f32_b64.json', 'step_sequence_train_bf16_b64.txt', 'train_side_stream_kernel_stats.csv',
+          'step_timeline_train.txt'):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, f'{tag}_{a}'))
 for mode, label in (('train', 'train B=32 T=256'), ('infer', 'infer B=16 T=2000')):
