@@ -783,7 +783,13 @@ class _Up2SingleFn(torch.autograd.Function):
         gz = ops.tapsum((B, Hs, Ws, ctx.ct, 2), (3, 3), (2, 2), (1, 1), backward=True, grad=g.contiguous(), bias_grad=dst,
                         out_dtype=x1.dtype)                  # (bf16 where the activations are stored in bf16)
         gx1 = gx2 = gw_r = gw_i = None
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+        want_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        # train step: the tap-channel weight gradient, its slab reduction and the scatter into the parameter's layout go to the
+        # weight-gradient side stream like every other layer's (forked behind the tap sum, in front of the data gradient)
+        side = WGRAD_SIDE if (want_w and ops.WGRAD_DEFER is not None and g.is_cuda and sk[0] is not None and sk[1] is not None) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        elif want_w:
             gt_r, gt_i, _, _ = ops.cconv2d_bwd_weight(x1, x2, gz, (ctx.ct, Cin, 1, 1), False, (1, 1), (1, 1), (0, 0))
             gw = ops.tap_rows_scatter(gt_r, gt_i, ctx.w_shape, sk[:2])
             if sk[0] is None or sk[1] is None:
@@ -791,6 +797,11 @@ class _Up2SingleFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             gx1, gx2 = ops.cconv2d_bwd_data(gz, ops.pack_conv_weight_bwd(wt, (1, 1)), (Hs, Ws, Cin), (1, 1), (1, 1), (0, 0),
                                             (1, 1), C1)
+        if side is not None:
+            with torch.cuda.stream(side):
+                gt_r, gt_i, _, _ = ops.cconv2d_bwd_weight(x1, x2, gz, (ctx.ct, Cin, 1, 1), False, (1, 1), (1, 1), (0, 0))
+                ops.tap_rows_scatter(gt_r, gt_i, ctx.w_shape, sk[:2])
+            ops.WGRAD_DEFER.append((gt_r, gt_i, gz, x1, x2))      # alive until the join
         return gx1, gx2, gw_r, gw_i, gb[0], gb[1], None
 
 
