@@ -209,7 +209,10 @@ int dcs_rbn_bwd(const float* x, const float* g_out, float* g_x, const float* sta
  * dcs_cconv2d_bwd_weight: gradients of the reference's parameters, in THEIR layout:
  *     gw_r, gw_i: float[Cout][Cin][kh][kw] (transposed=0) or float[Cin][Cout][kh][kw] (transposed=1)
  *     gb_r, gb_i: float[Cout] (NULL for bias-free layers).  x1/x2/geometry as in the forward call.
- *     workspace >= dcs_cconv2d_bwd_weight_workspace_bytes(...) (partial slabs; no atomics). */
+ *     workspace >= dcs_cconv2d_bwd_weight_workspace_bytes(...): the partial slabs (no atomics) and, behind them, the cotangent
+ *     split once into its three bf16 planes for layers of >= 64 input channels in the emulated-fp32 mode (a workspace that
+ *     holds the slabs only is accepted: the kernels then split in place).  The call reads x1 / x2 / gy and the workspace
+ *     until its stream has run it — on a side stream (as dcsnet/dp.py issues it) keep them alive until that stream is joined. */
 long dcs_packed_weight_bwd_floats(int Cout, int Cin, int kh, int kw, int sf, int st, int pad_f, int pad_t,
                                   int up_f, int up_t);
 int  dcs_pack_conv_weight_bwd(const float* wp, float* wp_bwd, int Cout, int Cin, int kh, int kw,
