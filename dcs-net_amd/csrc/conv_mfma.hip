@@ -22,6 +22,7 @@
 #include "pack_jobs.h"
 #include "conv_mfma_args.h"
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 #ifndef DCS_X6_GU16
@@ -50,6 +51,9 @@
 #endif
 #ifndef DCS_MFMA_SCALAR_B
 #define DCS_MFMA_SCALAR_B 1
+#endif
+#ifndef DCS_MFMA_PINGPONG
+#define DCS_MFMA_PINGPONG 1
 #endif
 #ifndef DCS_MFMA_EARLY_OPERANDS
 #define DCS_MFMA_EARLY_OPERANDS 3
@@ -265,8 +269,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
     constexpr bool INPLACE = PR == 2 && TPI > 1;
     constexpr int NTAPS_C = INPLACE ? TPI * TPI : 0;
     float4 bcur[VU][NP][WN], bnxt[INPLACE ? 1 : VU][NP][WN];
+    constexpr bool PP = DCS_MFMA_PINGPONG && !INPLACE && DCS_MFMA_COPY_AT_TOP && DCS_MFMA_EARLY_OPERANDS == 3 && DCS_EXP_LOOP == 0 &&
+                        !DCS_MFMA_GATHER_PREFETCH && WM * WN < 4;         // (2 x 2 tiles per wave: the two bodies spill)
+    float4 bs2[PP ? 2 : 1][PP ? VU : 1][NP][WN];                      // PP: the two B-fragment sets (tap_body, below)
 #pragma unroll
-    for (int g = 0; g < VU; ++g) bload(DCS_MFMA_COPY_AT_TOP && !INPLACE ? bnxt[INPLACE ? 0 : g] : bcur[g], c_begin, t0, g);
+    for (int g = 0; g < VU; ++g) bload(PP ? bs2[0][PP ? g : 0] : (DCS_MFMA_COPY_AT_TOP && !INPLACE ? bnxt[INPLACE ? 0 : g] : bcur[g]), c_begin, t0, g);
     if (DCS_EXP_LOOP & 2) {
 #pragma unroll
         for (int g = 0; g < (INPLACE || DCS_MFMA_COPY_AT_TOP ? 0 : VU); ++g)
@@ -449,8 +456,15 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
             for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + pl * CH + tapoff0);
         int tapoff = tapoff0;                                          // LDS float offset of the current tap
-#pragma unroll(INPLACE ? TPI : 1)
-        for (int tap = t0; tap < (INPLACE ? NTAPS_C : ntaps); tap += TSTEP) {
+        // The tap loop's body (Round 4, ping-pong).  P = which of the two B-fragment sets this tap multiplies from; the other one
+        // receives the next tap's fragments, k-group by k-group, and the roles swap with the tap — no hand-over copy
+        // (VU x NP x WN x 4 moves per tap and wave), and a k-group's fragments are waited for where THAT k-group starts, a
+        // whole tap after their request; the copy at the top of a tap waited for all of them at once, i.e. also for the ones
+        // requested one k-group earlier (the removal probe DCS_EXP_LOOP & 8: dec1 72 -> 64 us).
+        auto tap_body = [&](auto parc, int tap) {
+            constexpr int P = decltype(parc)::value;
+            float4 (*const cur_)[NP][WN] = PP ? bs2[P] : bcur;
+            float4 (*const nxt_)[NP][WN] = PP ? bs2[P ^ 1] : bnxt;
 #if DCS_MFMA_PROGRESS_PRIO
             if (prio_it == prio_q1) __builtin_amdgcn_s_setprio(2);
             else if (prio_it == prio_q2) __builtin_amdgcn_s_setprio(1);
@@ -461,13 +475,16 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
             // Round 4: the prefetched set moves over at the TOP of a tap, not at its end.  At the end, the last tap of a chunk
             // waited (vmcnt) for the next chunk's first fragments — requested half a tap earlier — BEFORE the gather: one exposed
             // L2 round trip per chunk.  Now that request flies under the gather's two barriers and its own memory round trip.
-            if (!INPLACE) {
+            // (DCS_EXP_LOOP & 8: timing probe, wrong results — the hand-over is skipped behind an opaque test, the loads stay)
+            bool do_copy = true;
+            if (DCS_EXP_LOOP & 8) { int z = m.KG; asm volatile("" : "+s"(z)); do_copy = z < 0; }
+            if (!INPLACE && !PP && do_copy) {
 #pragma unroll
                 for (int g = 0; g < VU; ++g)
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                        for (int j = 0; j < WN; ++j) bcur[g][pl][j] = bnxt[INPLACE ? 0 : g][pl][j];
+                        for (int j = 0; j < WN; ++j) cur_[g][pl][j] = nxt_[INPLACE ? 0 : g][pl][j];
             }
 #endif
             const int tap2 = tap + TSTEP < ntaps ? tap + TSTEP : tap;  // clamped: the last prefetch re-reads this tap
@@ -491,9 +508,9 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 if (DCS_MFMA_EARLY_OPERANDS == 1 && !INPLACE && g * LPG < VU) {
 #pragma unroll
                     for (int q = 0; q < LPG; ++q)
-                        if (g * LPG + q < VU) bload(bnxt[INPLACE ? 0 : g * LPG + q], ch, tap + TSTEP, g * LPG + q);
+                        if (g * LPG + q < VU) bload(nxt_[INPLACE ? 0 : g * LPG + q], ch, tap + TSTEP, g * LPG + q);
                 }
-                if (DCS_MFMA_EARLY_OPERANDS == 3 && !INPLACE) bload(bnxt[INPLACE ? 0 : g], ch, tap + TSTEP, g);   // this group's slot of the next tap
+                if (DCS_MFMA_EARLY_OPERANDS == 3 && !INPLACE) bload(nxt_[INPLACE ? 0 : g], ch, tap + TSTEP, g);   // this group's slot of the next tap
                 if (DCS_MFMA_EARLY_OPERANDS != 3) __builtin_amdgcn_sched_barrier(0);
 #endif
                 // MFMAs straight from the ring slot ...
@@ -501,14 +518,14 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        const float4 av = af[g & 1][0][i], bv = bcur[g][0][j];
+                        const float4 av = af[g & 1][0][i], bv = cur_[g][0][j];
                         if (PR == 2) {                                  // a0 b2, a1 b1, a2 b0, a0 b1, a1 b0, a0 b0
                             constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
                             for (int e = 0; e < 6; ++e)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                     __builtin_bit_cast(bf16x8, af[g & 1][pa[e] < NP ? pa[e] : 0][i]),
-                                    __builtin_bit_cast(bf16x8, bcur[g][pb[e] < NP ? pb[e] : 0][j]), acc[i][j], 0, 0, 0);
+                                    __builtin_bit_cast(bf16x8, cur_[g][pb[e] < NP ? pb[e] : 0][j]), acc[i][j], 0, 0, 0);
                         } else if (BF) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
                                                                                 __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
@@ -544,11 +561,11 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     have_pre = true;
                 }
                 if (INPLACE) {
-                    bload(bcur[g], ch, tap + TSTEP, g);
+                    bload(cur_[g], ch, tap + TSTEP, g);
                 } else if (DCS_MFMA_EARLY_OPERANDS != 1 && DCS_MFMA_EARLY_OPERANDS != 3 && g * LPG < VU) {
 #pragma unroll
                     for (int q = 0; q < LPG; ++q)
-                        if (g * LPG + q < VU) bload(bnxt[INPLACE ? 0 : g * LPG + q], ch, tap + TSTEP, g * LPG + q);
+                        if (g * LPG + q < VU) bload(nxt_[INPLACE ? 0 : g * LPG + q], ch, tap + TSTEP, g * LPG + q);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -558,7 +575,7 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                        for (int j = 0; j < WN; ++j) bcur[g][pl][j] = bnxt[INPLACE ? 0 : g][pl][j];
+                        for (int j = 0; j < WN; ++j) cur_[g][pl][j] = nxt_[INPLACE ? 0 : g][pl][j];
             }
             if (VU & 1) {                                               // odd U (bf16, CH = 8): the prefetch landed in set 1
 #pragma unroll
@@ -567,6 +584,29 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                     for (int i = 0; i < WM; ++i) af[0][pl][i] = af[1][pl][i];
             }
             tapoff = tapoff2;
+        };
+        if constexpr (PP) {
+            // two taps per trip, straight-line (the roles of the two sets are compile-time): the loop header — where the compiler
+            // drains vmcnt, it cannot carry counts across the back edge — comes once per PAIR; an odd tap count ends on a single
+            // tap whose prefetch (the next chunk's first tap) landed in set 1 and is handed to set 0, once per chunk
+            int tap = t0;
+#pragma unroll 1
+            for (; tap + TSTEP < ntaps; tap += 2 * TSTEP) {
+                tap_body(std::integral_constant<int, 0>{}, tap);
+                tap_body(std::integral_constant<int, 1>{}, tap + TSTEP);
+            }
+            if (tap < ntaps) {
+                tap_body(std::integral_constant<int, 0>{}, tap);
+#pragma unroll
+                for (int g = 0; g < VU; ++g)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) bs2[0][PP ? g : 0][pl][j] = bs2[PP ? 1 : 0][PP ? g : 0][pl][j];
+            }
+        } else {
+#pragma unroll(INPLACE ? TPI : 1)
+            for (int tap = t0; tap < (INPLACE ? NTAPS_C : ntaps); tap += TSTEP) tap_body(std::integral_constant<int, 0>{}, tap);
         }
         d_mfma += FDIAG_NOW() - g1;
     }
