@@ -934,15 +934,17 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
                     const bf16x4 h = {(__bf16)v[u].x, (__bf16)v[u].y, (__bf16)v[u].z, (__bf16)v[u].w};
                     *reinterpret_cast<bf16x4*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = h;
                 } else if (PR == 2) {                                  // 2 complex -> 3 planes of 4 bf16 (exact split)
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    // (by pairs, as the 32-column kernel's gather: one packed conversion per pair and plane — element by element
+                    // the compiler emitted a single-operand conversion per value plus the repacking)
                     float4 r = v[u];
                     float* dst = patch + (idx / Q) * PIX + (idx % Q) * 2;
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const bf16x4 h = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
-                        *reinterpret_cast<bf16x4*>(dst + pl * CH) = h;
-                        r.x -= (float)h[0]; r.y -= (float)h[1]; r.z -= (float)h[2]; r.w -= (float)h[3];
-                    }
+                    uint2 h0, h1, h2;
+                    h0.x = dcs_split_pair(r.x, r.y); h0.y = dcs_split_pair(r.z, r.w);
+                    h1.x = dcs_split_pair(r.x, r.y); h1.y = dcs_split_pair(r.z, r.w);
+                    h2.x = dcs_pack_bf16x2(r.x, r.y); h2.y = dcs_pack_bf16x2(r.z, r.w);
+                    *reinterpret_cast<uint2*>(dst) = h0;
+                    *reinterpret_cast<uint2*>(dst + CH) = h1;
+                    *reinterpret_cast<uint2*>(dst + 2 * CH) = h2;
                 } else {
                     *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
                 }
