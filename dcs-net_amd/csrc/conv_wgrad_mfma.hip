@@ -359,6 +359,9 @@ typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 #ifndef DCS_X6_CFMAP
 #define DCS_X6_CFMAP 1
 #endif
+#ifndef DCS_X6_FASTLOAD
+#define DCS_X6_FASTLOAD 1
+#endif
 #ifndef DCS_X6_BPIPE
 #define DCS_X6_BPIPE 0       // reads of the next tap group ahead of the current MFMAs: +50 VGPRs, step +0.4 % (measured)
 #endif
@@ -428,6 +431,16 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
         toff[tp] = ((tap / KW) * a.cols + (tap % KW)) * PIXR;
     }
 
+    // byte offsets of this lane's 8 pixels of a k-step's first row(s) from the tile origin, row tile 0 (row tile i: + 64 i bytes)
+    unsigned goff[8];
+    {
+        const int p80 = DCS_X6_CFMAP ? 16 * (lk >> 1) + 4 * (lk & 1) : 8 * lk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pp = p80 + (DCS_X6_CFMAP ? (e < 4 ? e : e + 4) : e);
+            goff[e] = (unsigned)((((pp >> w.twshift) * w.os_f * w.Wy + (pp & (w.TW - 1)) * w.os_t) * N1 + gcol[0]) * 4);
+        }
+    }
     long long d_gather = 0, d_mfma = 0, d_tiles = 0;
     const long long d_start = WDIAG_NOW();
     int tiles_done = 0;
@@ -517,7 +530,26 @@ __global__ __launch_bounds__(256, 2) void cconv_wgrad_x6_kernel(WArgs w) {
             }
         };
         float raw[2][MT][8];
+        // interior tiles (wave-uniform; most of them): the k-step's 8 x MT loads take a wave-uniform base (tile origin + the
+        // k-step's whole rows / half rows) and the per-lane BYTE offsets goff[e] computed once per kernel — no masks, no 64-bit
+        // per-lane addresses (a third of the ~310 vector instructions of a k-step in the in-kernel-split instances)
+        typedef __attribute__((address_space(1))) const char gch_t;
+        typedef __attribute__((address_space(1))) const float gfl_t;
+        gch_t* gy_tile = (gch_t*)(gyb + ((long)(oy0 * w.os_f + oo_f) * w.Wy + ox0 * w.os_t + oo_t) * N1);
         auto load_g = [&](int ks, float (*dst)[8]) {
+            if (DCS_X6_FASTLOAD && !PA && !DCS_ACT_IS_BF16 && interior) {
+                int ksu = __builtin_amdgcn_readfirstlane(ks);
+                gch_t* sb = gy_tile + (long)((((ksu * 32) >> tws) * w.os_f * w.Wy + ((ksu * 32) & twm) * w.os_t) * N1) * 4;
+                asm volatile("" : "+s"(sb));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    unsigned vo = goff[e];
+                    asm volatile("" : "+v"(vo));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) dst[i][e] = *(gfl_t*)(sb + vo + 64 * i);
+                }
+                return;
+            }
             const int p8 = CF ? ks * 32 + 16 * (lk >> 1) + 4 * (lk & 1) : ks * 32 + 8 * lk;     // e < 4: pixels p8 + e; e >= 4: p8 + 8 + (e - 4)
             const int oy = oy0 + (p8 >> tws), oxb = ox0 + (p8 & twm);
             const bool rowok = oy < a.Hout;
