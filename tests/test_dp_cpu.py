@@ -174,6 +174,25 @@ def test_flat_bucket_preserves_values_and_gradient_views():
     assert all(o % 4 == 0 for o in b.offsets)                # float4-aligned slices for the fused kernel
 
 
+def test_train_step_side_stream_switch_and_cpu_backward(monkeypatch):
+    """TrainStep.wgrad_side_stream (the weight-gradient kernels on a side stream of the captured step) is a host-side switch:
+    on by default, off with DCS_WGRAD_SIDE=0, and without a GPU the backward pass neither creates a stream nor opens a
+    deferred-reduce scope (the oracle model's step still runs)."""
+    from dcsnet import functional, ops
+    from dcsnet.dp import TrainStep, TorchAdam
+    monkeypatch.delenv('DCS_WGRAD_SIDE', raising=False)
+    m = _OracleAdapter(seed=2)
+    ts = TrainStep(m, optimizer_cls=TorchAdam)
+    assert ts.wgrad_side_stream is True
+    monkeypatch.setenv('DCS_WGRAD_SIDE', '0')
+    assert TrainStep(_OracleAdapter(seed=2), optimizer_cls=TorchAdam).wgrad_side_stream is False
+    p0 = ts.bucket.params[0]
+    ts.bucket.zero_grad()
+    ts._backward((p0 * p0).sum())
+    assert functional.WGRAD_SIDE is None and ops.WGRAD_DEFER is None and '_wgrad_side' not in ts.__dict__
+    assert torch.allclose(p0.grad, 2 * p0.detach())
+
+
 def test_bench_gpus_flag_launches_its_own_ranks_and_refuses_a_mismatch():
     """`python bench.py --gpus N` with no launcher around it must start N rank processes itself (before any GPU call) and
     relay a line that saw N ranks; under a launcher whose WORLD_SIZE differs from --gpus it must fail, not print a line
