@@ -146,7 +146,12 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_bwd_kernel(const float* __rest
                                                            float* __restrict__ g_bias_part, int S, int seqs_per_set) {
     DCS_PRIO_CRITICAL();
     constexpr int G4 = 4 * H;
-    __shared__ __attribute__((aligned(16))) float gp_s[2][G4];
+    // The four gate blocks of the step's g_pre vector sit H + 4 floats apart (Round 4).  The lanes of a wave carry all four
+    // gates (gate = t & 3), so every 16-byte read of the dot product below has four distinct addresses, one per gate block: at
+    // a pitch of H floats (256 / 512 bytes) they fell on the SAME banks — a four-way conflict on all 16 (32) reads of a step,
+    // SQ_LDS_BANK_CONFLICT at 0.75 of the LDS-active cycles (profiles/r04_a_pmc_wait_states.txt); at H + 4 they are 4 banks apart.
+    constexpr int GS = H + 4;
+    __shared__ __attribute__((aligned(16))) float gp_s[2][4 * GS];
     const int t = threadIdx.x, u = t >> 2, gate = t & 3, j = gate * H + u;
     const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int set = n / seqs_per_set;
@@ -189,13 +194,13 @@ __global__ __launch_bounds__(4 * H) void lstm_rec_bwd_kernel(const float* __rest
         gc_rec = gc * fg;
         const float mine = gate == 0 ? pi : (gate == 1 ? pf : (gate == 2 ? pg : po));
         sb += mine;
-        gp_s[cur][j] = mine;
+        gp_s[cur][gate * GS + u] = mine;
         g_pre[(((long)n * S + tt) * 2 + dir) * G4 + j] = mine;
         c = cp;                                                        // c_{t-1} of this step is c_t of the next one
         act = n_act; cp = n_cp; go = n_go;
         step_barrier();
         v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
-        const float4* g4 = reinterpret_cast<const float4*>(gp_s[cur] + gate * H);
+        const float4* g4 = reinterpret_cast<const float4*>(gp_s[cur] + gate * GS);
 #pragma unroll
         for (int q = 0; q < H / 4; ++q) {
             const float4 gv = g4[q];
