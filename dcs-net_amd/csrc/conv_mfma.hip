@@ -450,12 +450,24 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
         DCS_CHUNK_BARRIER();
         const long long g1 = FDIAG_NOW();
         d_gather += g1 - g0;
-        float4 af[2][NP][WM];
+        // (A fragments as NATIVE 8 x bf16 vectors for the bf16 forms: loaded as HIP's float4 struct and bit-cast for the MFMA, the
+        // tap body's by-reference capture left a third of the fragment loads as `load <8 x bfloat> ... align 4` — pairs of
+        // ds_read2_b32, two instructions and a two-way bank conflict per fragment, instead of one ds_read_b128)
+        float4 af[2][BF ? 1 : NP][BF ? 1 : WM];
+        bf16x8 afb[2][BF ? NP : 1][BF ? WM : 1];
+        typedef __attribute__((address_space(3))) const bf16x8 lds_bf8_t;
+        typedef __attribute__((address_space(3))) const float lds_cf_t;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[0][pl][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + pl * CH + tapoff0);
-        int tapoff = tapoff0;                                          // LDS float offset of the current tap
+            for (int i = 0; i < WM; ++i) {
+                if constexpr (BF) afb[0][pl][i] = *(lds_bf8_t*)((lds_cf_t*)patch + (pixoff[i] + pl * CH + tapoff0));
+                else af[0][pl][i] = *reinterpret_cast<const float4*>(patch + pixoff[i] + pl * CH + tapoff0);
+            }
+        // the current tap as a patch-PIXEL offset; its LDS float offset is formed (x PIX) inside the tap body: carried as the float
+        // offset, the loop's phi hid that it is a multiple of 4 floats and the fragment loads of the first body of a pair were
+        // emitted with `align 4` (see afb above)
+        int tapq = tapoff0 / PIX;
         // The tap loop's body (Round 4, ping-pong).  P = which of the two B-fragment sets this tap multiplies from; the other one
         // receives the next tap's fragments, k-group by k-group, and the roles swap with the tap — no hand-over copy
         // (VU x NP x WN x 4 moves per tap and wave), and a k-group's fragments are waited for where THAT k-group starts, a
@@ -488,7 +500,8 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
             }
 #endif
             const int tap2 = tap + TSTEP < ntaps ? tap + TSTEP : tap;  // clamped: the last prefetch re-reads this tap
-            const int tapoff2 = ((tap2 / k.kw) * cols + (tap2 % k.kw)) * PIX;
+            const int tapq2 = (tap2 / k.kw) * cols + (tap2 % k.kw);
+            const int tapoff = tapq * PIX, tapoff2 = tapq2 * PIX;
 #pragma unroll
             for (int g = 0; g < VU; ++g) {
                 // A fragments of the next iteration into the other register set (taps of a row are adjacent patch columns)
@@ -496,9 +509,14 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                     for (int i = 0; i < WM; ++i) {
-                        if (DCS_EXP_LOOP & 1) { af[(g + 1) & 1][pl][i] = af[g & 1][pl][i]; continue; }
-                        af[(g + 1) & 1][pl][i] = *reinterpret_cast<const float4*>(
-                            patch + pixoff[i] + pl * CH + (g + 1 < VU ? tapoff + ((g + 1) / U) * PIX + ((g + 1) % U) * 8 : tapoff2));
+                        const int aoff = pixoff[i] + pl * CH + (g + 1 < VU ? tapoff + ((g + 1) / U) * PIX + ((g + 1) % U) * 8 : tapoff2);
+                        if constexpr (BF) {
+                            if (DCS_EXP_LOOP & 1) { afb[(g + 1) & 1][pl][i] = afb[g & 1][pl][i]; continue; }
+                            afb[(g + 1) & 1][pl][i] = *(lds_bf8_t*)((lds_cf_t*)patch + aoff);
+                        } else {
+                            if (DCS_EXP_LOOP & 1) { af[(g + 1) & 1][pl][i] = af[g & 1][pl][i]; continue; }
+                            af[(g + 1) & 1][pl][i] = *reinterpret_cast<const float4*>(patch + aoff);
+                        }
                     }
 #if DCS_MFMA_EARLY_OPERANDS
                 // Round 4: both operand streams are issued AHEAD of this k-group's MFMAs.  Left to the scheduler the LDS reads of
@@ -518,16 +536,16 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        const float4 av = af[g & 1][0][i], bv = cur_[g][0][j];
+                        const float4 av = af[g & 1][0][BF ? 0 : i], bv = cur_[g][0][j];
                         if (PR == 2) {                                  // a0 b2, a1 b1, a2 b0, a0 b1, a1 b0, a0 b0
                             constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
                             for (int e = 0; e < 6; ++e)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                    __builtin_bit_cast(bf16x8, af[g & 1][pa[e] < NP ? pa[e] : 0][i]),
+                                    afb[g & 1][pa[e] < NP ? pa[e] : 0][BF ? i : 0],
                                     __builtin_bit_cast(bf16x8, cur_[g][pb[e] < NP ? pb[e] : 0][j]), acc[i][j], 0, 0, 0);
                         } else if (BF) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afb[g & 1][0][BF ? i : 0],
                                                                                 __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
                         } else {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i][j], 0, 0, 0);
@@ -581,9 +599,12 @@ __global__ __launch_bounds__(256) void cconv_mfma_kernel(MArgs m) {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                    for (int i = 0; i < WM; ++i) af[0][pl][i] = af[1][pl][i];
+                    for (int i = 0; i < WM; ++i) {
+                        if constexpr (BF) afb[0][pl][i] = afb[1][pl][i];
+                        else af[0][pl][i] = af[1][pl][i];
+                    }
             }
-            tapoff = tapoff2;
+            tapq = tapq2;
         };
         if constexpr (PP) {
             // two taps per trip, straight-line (the roles of the two sets are compile-time): the loop header — where the compiler
