@@ -318,3 +318,40 @@ def test_no_cross_half_packed_f32_in_any_kernel(tmp_path):
                     bad.append((name, len(hits), hits[0].strip()))
     assert n_obj > 0 and n_kern > 300 and n_mfma > 20, (n_obj, n_kern, n_mfma)
     assert not bad, f'{len(bad)} kernels carry a packed f32 op with a cross-half operand selection: {bad[:8]}'
+
+
+def test_conv_kernel_fragment_loads_stay_whole(tmp_path):
+    """Static guard (Round 4): the emulated forward / data-gradient kernel reads an A fragment with ONE ds_read_b128.  When the
+    tap loop was restructured, the optimiser lost sight of the fragments' 16-byte alignment behind a loop phi and emitted a
+    third of them as pairs of ds_read2_b32 (two instructions, two-way bank conflicts: profiles/r04_conv_probes.txt) — silently,
+    results unchanged.  The instances the two networks launch without a statistics epilogue must hold no ds_read2_b32 at all;
+    the emulated weight-gradient kernel must keep its transposed reads and, in the pre-split form, whole 16-byte g_Y loads."""
+    import re
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'kernel_isa.py')
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump not available')
+    from dcsnet import _lib
+
+    def isa(pattern):
+        out = tmp_path / 'k.isa'
+        subprocess.run([sys.executable, tool, _lib.LIB_PATH, pattern, str(out)], check=True)
+        return {b.split('\n', 1)[0]: b for b in re.split(r'^=== ', out.read_text(), flags=re.M)[1:]}
+
+    fwd = isa('cconv_mfma_kernel<')
+    checked = 0
+    for inst in ('<2, 2, 1, 32, 2, 1, false, 2>', '<2, 2, 1, 16, 2, 1, false, 2>', '<2, 1, 1, 32, 2, 1, false, 1>',
+                 '<2, 1, 1, 32, 2, 1, false, 2>', '<2, 1, 1, 16, 2, 1, false, 1>', '<2, 2, 1, 8, 2, 1, false, 2>'):
+        body = [b for n, b in fwd.items() if 'cconv_mfma_kernel' + inst in n]
+        assert len(body) == 1, inst
+        assert 'v_mfma_f32_32x32x16_bf16' in body[0] and body[0].count('ds_read_b128') >= 20, inst
+        assert body[0].count('ds_read2_b32') == 0, (inst, body[0].count('ds_read2_b32'))
+        checked += 1
+    wg = isa('cconv_wgrad_x6_kernel<2, 3, 2, 1, false, true>')
+    assert len(wg) == 1
+    body = next(iter(wg.values()))
+    assert body.count('ds_read_b64_tr_b16') >= 200 and body.count('global_load_dwordx4') >= 48
+    assert 'global_load_dword ' not in body.replace('global_load_dwordx', 'X')
+    assert checked == 6
