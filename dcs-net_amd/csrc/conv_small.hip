@@ -23,23 +23,26 @@ struct DgArgs {
     int kh[4], kw[4], fy[4], fx[4], py[4], px[4], Hc[4], Wc[4];   // per class (ry*2 + rx): sub-kernel, first full tap, padding, extent
 };
 
+// wsm: the class's sub-kernel, [tap jy * KW + jx][channel pair] as {w0.x, w0.y, w1.x, w1.y}, staged in LDS by the caller.  Read
+// straight from d.wpb (a pointer inside a by-value argument struct: no noalias / readonly information) the wave-uniform weights
+// were VECTOR loads — 196 global_load_dwordx4 per thread in the 4x4 class, 64 lanes x 16 bytes through the L1 for 16 useful bytes:
+// more L1 cycles than the kernel has FMA cycles.  From LDS they are broadcast reads.
 template <int KH, int KW>
-__device__ __forceinline__ void dgrad_class(const DgArgs& d, const float2* patch, int cls, int b, int cy0, int cx0) {
+__device__ __forceinline__ void dgrad_class(const DgArgs& d, const float2* patch, const float4* wsm, int cls, int b, int cy0, int cx0) {
     constexpr int COLS = TW + KW - 1;
     const int t = threadIdx.x, tx = t % TW, ty = t / TW;
     float ar = 0.f, ai = 0.f;
     const float2* base = patch + (ty * COLS + tx) * DPIX;
-    const int fy = d.fy[cls], fx = d.fx[cls];
 #pragma unroll
     for (int jy = 0; jy < KH; ++jy)
 #pragma unroll
         for (int jx = 0; jx < KW; ++jx) {
             const float4* xp = reinterpret_cast<const float4*>(base + (jy * COLS + jx) * DPIX);
-            const float2* wv = d.wpb + ((fy + 2 * jy) * 7 + fx + 2 * jx) * DC;       // wave-uniform
 #pragma unroll
             for (int q = 0; q < DC / 2; ++q) {
                 const float4 xv = xp[q];
-                const float2 w0 = wv[2 * q], w1 = wv[2 * q + 1];
+                const float4 wq = wsm[(jy * KW + jx) * (DC / 2) + q];
+                const float2 w0 = make_float2(wq.x, wq.y), w1 = make_float2(wq.z, wq.w);
                 ar = fmaf(w0.x, xv.x, fmaf(-w0.y, xv.y, ar));
                 ai = fmaf(w0.x, xv.y, fmaf(w0.y, xv.x, ai));
                 ar = fmaf(w1.x, xv.z, fmaf(-w1.y, xv.w, ar));
@@ -54,6 +57,7 @@ __device__ __forceinline__ void dgrad_class(const DgArgs& d, const float2* patch
 __global__ __launch_bounds__(TH * TW) void cconv_small_dgrad_s2_kernel(DgArgs d) {
     DCS_PRIO_CRITICAL();
     __shared__ __attribute__((aligned(16))) float2 patch[(TH + 3) * (TW + 3) * DPIX];
+    __shared__ __attribute__((aligned(16))) float4 wsm[16 * (DC / 2)];
     const int cls = blockIdx.y, b = blockIdx.z;
     const int cy0 = (blockIdx.x / d.tiles_w) * TH, cx0 = (blockIdx.x % d.tiles_w) * TW;
     if (cy0 >= d.Hc[cls] || cx0 >= d.Wc[cls]) return;
@@ -69,11 +73,15 @@ __global__ __launch_bounds__(TH * TW) void cconv_small_dgrad_s2_kernel(DgArgs d)
             v = dcs_ld4(reinterpret_cast<const act_t*>(d.gy + (((long)b * d.Hg + y) * d.Wg + x) * DC + 2 * q));
         *reinterpret_cast<float4*>(patch + p * DPIX + 2 * q) = v;
     }
+    if (threadIdx.x < kh * kw * (DC / 2)) {                            // this class's taps of the flipped 7x7 kernel
+        const int tap = threadIdx.x / (DC / 2), q = threadIdx.x % (DC / 2), jy = tap / kw, jx = tap % kw;
+        wsm[threadIdx.x] = *reinterpret_cast<const float4*>(d.wpb + ((d.fy[cls] + 2 * jy) * 7 + d.fx[cls] + 2 * jx) * DC + 2 * q);
+    }
     __syncthreads();
-    if (kh == 4 && kw == 4) dgrad_class<4, 4>(d, patch, cls, b, cy0, cx0);
-    else if (kh == 4) dgrad_class<4, 3>(d, patch, cls, b, cy0, cx0);
-    else if (kw == 4) dgrad_class<3, 4>(d, patch, cls, b, cy0, cx0);
-    else dgrad_class<3, 3>(d, patch, cls, b, cy0, cx0);
+    if (kh == 4 && kw == 4) dgrad_class<4, 4>(d, patch, wsm, cls, b, cy0, cx0);
+    else if (kh == 4) dgrad_class<4, 3>(d, patch, wsm, cls, b, cy0, cx0);
+    else if (kw == 4) dgrad_class<3, 4>(d, patch, wsm, cls, b, cy0, cx0);
+    else dgrad_class<3, 3>(d, patch, wsm, cls, b, cy0, cx0);
 }
 
 }  // namespace
