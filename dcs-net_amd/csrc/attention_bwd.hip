@@ -190,16 +190,28 @@ __device__ __forceinline__ void ca_bwd_sample_kernel_body(const double* __restri
         go[(long)b * C + c] = g;
     }
     __syncthreads();
-    for (int h = t; h < Ch; h += kThreads) {
-        float ar = 0.f, ai = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float2 w = w2[h * C + c], g = go_s[c];
-            ar += w.x * g.x + w.y * g.y; ai += w.x * g.y - w.y * g.x;
+    // g_h = relu'(h) (.) W2^H g_o: LP lanes per hidden unit share the sum over the C channels (shuffle reduction).  One thread
+    // per hidden unit — Ch <= 16 of the 256 — walked C dependent weight loads on its own: ~3 us of this launch-bound kernel.
+    {
+        int chp = 1;
+        while (chp < Ch) chp <<= 1;
+        const int LP = kThreads / chp > 64 ? 64 : kThreads / chp;       // (a power of two <= 64: the lanes of a unit share a wave)
+        for (int h0 = 0; h0 < Ch; h0 += kThreads / LP) {
+            const int h = h0 + t / LP, sub = t % LP;
+            float ar = 0.f, ai = 0.f;
+            if (h < Ch)
+                for (int c = sub; c < C; c += LP) {
+                    const float2 w = w2[h * C + c], g = go_s[c];
+                    ar += w.x * g.x + w.y * g.y; ai += w.x * g.y - w.y * g.x;
+                }
+            for (int o = LP / 2; o > 0; o >>= 1) { ar += __shfl_xor(ar, o, 64); ai += __shfl_xor(ai, o, 64); }
+            if (h < Ch && sub == 0) {
+                const float2 hv = hidden[(long)b * Ch + h];
+                const float2 g = make_float2(hv.x > 0.f ? ar : 0.f, hv.y > 0.f ? ai : 0.f);
+                gh_s[h] = g;
+                gh[(long)b * Ch + h] = g;
+            }
         }
-        const float2 hv = hidden[(long)b * Ch + h];
-        const float2 g = make_float2(hv.x > 0.f ? ar : 0.f, hv.y > 0.f ? ai : 0.f);
-        gh_s[h] = g;
-        gh[(long)b * Ch + h] = g;
     }
     __syncthreads();
     for (int c = t; c < C; c += kThreads) {
