@@ -513,6 +513,9 @@ def main():
             # roofline is its OWN duration, so the instrumented pass issues the same launches on one stream (co-scheduled, every
             # kernel's duration includes the time it shares the card: `kernel_ms_per_step` would count overlapped time twice)
             side_was, ts.wgrad_side_stream = ts.wgrad_side_stream, False
+        else:
+            # likewise the inference pass: its skip attentions run on a side stream beside the encoder convs and the LSTM
+            side_was, net.overlap_skip_attention = net.overlap_skip_attention, False
         flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         hold = world == 1                  # with a collective inside the step the ranks would hold each other
         for _ in range(max(args.steps, 3 * timer.stride)):      # every launch timed at least three times
@@ -526,7 +529,10 @@ def main():
             torch.cuda.synchronize()
         timer.active = False
         if side_was is not None:
-            ts.wgrad_side_stream = side_was
+            if train:
+                ts.wgrad_side_stream = side_was
+            else:
+                net.overlap_skip_attention = side_was
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -576,7 +582,9 @@ def main():
                                     'MFMA\'s: profiles/*conv_precision.txt); the weight gradients run on the same emulation (cconv_wgrad_x6_kernel), and so does the first encoder conv (v_mfma_f32_16x16x32_bf16); its weight gradient runs on the native fp32 MFMA, the 1-output-channel decoder layer and the 7x7 attention convs on the VALU'),
                        'streams': (('2: the weight-gradient kernels run on a side stream beside the data-gradient chain of the backward '
                                     'pass (one fork per conv layer, one join in front of the slab reductions), all inside the captured graph')
-                                   if train and getattr(ts, 'wgrad_side_stream', False) else 1),
+                                   if train and getattr(ts, 'wgrad_side_stream', False) else
+                                   ('2: the skip attentions run on a side stream beside the encoder convs and the latent LSTM (captured)'
+                                    if not train and getattr(net, 'overlap_skip_attention', False) else 1)),
                        'per_gpu_batch': B, 'frames_per_utterance': T, 'global_batch': B * world,
                        'frames_per_step': B * T * world, 'hip_graph': bool(graphed), 'parallelism': (f'dp{world} (utterance sharding, one flat-bucket gradient all-reduce)' if train
                                        else f'dp{world} (utterance sharding, no collective)')},

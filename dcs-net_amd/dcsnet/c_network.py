@@ -19,6 +19,7 @@ callable (layer-by-layer drop-in surface, dcsnet/complexLayers.py).
 """
 import sys
 
+import os
 import torch
 
 from . import functional as F
@@ -221,6 +222,12 @@ class C_NETWORK(LightningModule):
             enc[0] = enc[0].to(adt)                          # the initial CBN and the last decoder conv lives in bf16 in HBM
         enc_skip = [None]
         infer = not self.training and not torch.is_grad_enabled()
+        # Inference (Round 4): the skip attentions of the first `early` encoder outputs — the large maps: most of the batched
+        # kernels' HBM traffic — start on the side stream as soon as those outputs exist and stream beside the remaining
+        # encoder convs (MFMA-bound); only the small late blocks are left to run beside the LSTM, whose recurrence kernel
+        # doubled in length while it shared the card with all seven (367 vs 175 us at S = 500).
+        early = self.skip_attention_early if (self.overlap_skip_attention and infer and x.is_cuda and self.batch_skip_attention) else 0
+        side = skips_early = None
         for i in range(L):                                   # c_network.py:193-197
             conv, bn = self.encoder[i][0], self.encoder[i][1]
             coef = bn.eval_coef() if infer else None
@@ -230,6 +237,14 @@ class C_NETWORK(LightningModule):
                                               conv.conv_i.bias, False, conv.kernel_size, conv.stride, conv.padding, (1, 1),
                                               coef, F.ACT_RELU))
                 enc_skip.append(enc[-1])
+                if early and i + 1 == early and early < L:
+                    cur = torch.cuda.current_stream(x.device)
+                    side = self.__dict__.get('_side_stream')
+                    if side is None or side.device != x.device:
+                        side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=x.device)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        skips_early = self._skip_attentions(enc_skip, stages=[s_ for s_ in range(L) if L - s_ <= early])
                 continue
             stat = None
             if self.training:                                # batch statistics straight from the conv's epilogue
@@ -249,16 +264,22 @@ class C_NETWORK(LightningModule):
         # per CU (350 us at S = 500): at inference they run on a side stream beside it — the fork / join become graph
         # dependencies under capture (inference pass 3.46 -> 3.37 ms).  Not in training: with the backward's mirror-image
         # fork the two cross-stream edges cost more than the overlap returns there (step 4.06 -> 4.12 ms, measured).
-        side = None
         if self.overlap_skip_attention and infer and x.is_cuda:
             cur = torch.cuda.current_stream(x.device)
-            side = self.__dict__.get('_side_stream')
-            if side is None or side.device != x.device:
-                side = torch.cuda.Stream(device=x.device)
-                self.__dict__['_side_stream'] = side
+            if side is None:
+                side = self.__dict__.get('_side_stream')
+                if side is None or side.device != x.device:
+                    side = torch.cuda.Stream(device=x.device)
+                    self.__dict__['_side_stream'] = side
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                skips = self._skip_attentions(enc_skip)
+                if skips_early is None:
+                    skips = self._skip_attentions(enc_skip)
+                else:
+                    late = self._skip_attentions(enc_skip, stages=[s_ for s_ in range(L) if L - s_ > early])
+                    skips = [None] * L
+                    for s_, t_ in list(skips_early.items()) + list(late.items()):
+                        skips[s_] = t_
         z = self.lstm(torch.view_as_complex(lat if adt == torch.float32 else lat.float()).view(B, F7 * T7, C7))   # (LSTM + fc: fp32)
         if side is not None:
             # join BEFORE self.fc: the side stream's VALU kernels overlap the LSTM recurrence only (a VALU kernel too), never
@@ -323,19 +344,26 @@ class C_NETWORK(LightningModule):
         net_out = F.bound_crm(d.view(B, Fbins, T, 2), hp['atan2_eps']) if bound else d.view(B, Fbins, T, 2)
         return torch.squeeze(torch.view_as_complex(net_out))          # c_network.py:224
 
-    def _skip_attentions(self, enc):
+    def _skip_attentions(self, enc, stages=None):
         """skip_i = sa_i (.) ca_i (.) enc[L - i] for every decoder stage (c_network.py:208-211).  Each depends on one
         encoder output only, so all of them run as one batched set of launches (F.attention_blocks); blocks the batched
-        entry does not cover (spatial kernel != 7) fall back to one launch set per block — same HIP kernels."""
+        entry does not cover (spatial kernel != 7) fall back to one launch set per block — same HIP kernels.
+        stages: a subset of the decoder stages (their encoder outputs must exist) -> {stage: skip}; None: the list of all."""
         L = self.hparams['no_of_layers']
-        mods = [(self.skip_attention[2 * i], self.skip_attention[2 * i + 1]) for i in range(L)]
+        sel = list(range(L)) if stages is None else list(stages)
+        mods = [(self.skip_attention[2 * i], self.skip_attention[2 * i + 1]) for i in sel]
+        if not sel:
+            return {}
         if L > F.ATTENTION_BATCH_MAX or any(sa_m.kernel_size != 7 for _, sa_m in mods) or not self.batch_skip_attention:
-            return [self._attend(ca_m, sa_m, enc[L - i]) for i, (ca_m, sa_m) in enumerate(mods)]
-        params = [(ca_m.fc[0].conv_r.weight, ca_m.fc[0].conv_i.weight, ca_m.fc[2].conv_r.weight, ca_m.fc[2].conv_i.weight,
-                   sa_m.conv1.conv_r.weight, sa_m.conv1.conv_i.weight) for ca_m, sa_m in mods]
-        return F.attention_blocks([enc[L - i] for i in range(L)], params, 7)
+            outs = [self._attend(ca_m, sa_m, enc[L - i]) for i, (ca_m, sa_m) in zip(sel, mods)]
+        else:
+            params = [(ca_m.fc[0].conv_r.weight, ca_m.fc[0].conv_i.weight, ca_m.fc[2].conv_r.weight, ca_m.fc[2].conv_i.weight,
+                       sa_m.conv1.conv_r.weight, sa_m.conv1.conv_i.weight) for ca_m, sa_m in mods]
+            outs = F.attention_blocks([enc[L - i] for i in sel], params, 7)
+        return list(outs) if stages is None else dict(zip(sel, outs))
 
     batch_skip_attention = True
+    skip_attention_early = int(os.environ.get('DCS_SKIP_EARLY', '4'))     # inference: encoder outputs whose skip attentions start early (0: none)
     supports_unbounded_forward = True      # forward(x, bound=False): see forward
     activation_dtype = torch.float32
 
