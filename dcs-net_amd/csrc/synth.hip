@@ -145,6 +145,28 @@ __global__ __launch_bounds__(kThreads) void istft_ola_bwd_kernel(const float* __
     if (n >= 0 && n < Lout) v = scale * w[k] * inv_env[n] * gy[b * Lout + n];
     gf[b * T * n_fft + i] = v;
 }
+
+// The same, four consecutive k per thread (hop, n_fft / 2 and Lout multiples of 4: a thread's four samples n .. n + 3 are aligned
+// and lie together inside or outside the trimmed signal): one float4 load of g_y, w and the envelope, one float4 store, one
+// index division per four elements (the scalar form: 8.4 M threads with a 64-bit division and a dword store each, 17.5 us for
+// 33 MB — Round 4).
+__global__ __launch_bounds__(kThreads) void istft_ola_bwd4_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                   const float* __restrict__ inv_env, float* __restrict__ gf,
+                                                                   int T, int n_fft, int hop, int Lout, float scale) {
+    const int q4 = n_fft >> 2;                                        // float4 per frame
+    const int i = (int)blockIdx.x * kThreads + threadIdx.x;            // (f, k / 4) of one batch item
+    if (i >= T * q4) return;
+    const long b = blockIdx.y;
+    const int f = i / q4, k = (i - f * q4) * 4;
+    const int n = f * hop + k - n_fft / 2;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n >= 0 && n < Lout) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + k), ev = *reinterpret_cast<const float4*>(inv_env + n);
+        const float4 g = *reinterpret_cast<const float4*>(gy + b * Lout + n);
+        v = make_float4(scale * wv.x * ev.x * g.x, scale * wv.y * ev.y * g.y, scale * wv.z * ev.z * g.z, scale * wv.w * ev.w * g.w);
+    }
+    reinterpret_cast<float4*>(gf + b * (long)T * n_fft)[i] = v;
+}
 }  // namespace
 
 extern "C" int dcs_polar_frames_fwd(const float* z, float* out, int B, int F, int Fp, int T, float eps, dcs_stream_t stream) {
@@ -193,8 +215,13 @@ extern "C" int dcs_istft_ola_bwd(const float* g_y, const float* window, const fl
     if (!g_y || !window || !inv_env || !g_frames || !ola_ok(B, T, n_fft, hop)) return DCS_ERR_BADARG;
     const int Lout = hop * (T - 1);
     const long per = (long)T * n_fft;
-    DCS_LAUNCH(istft_ola_bwd_kernel, dim3((unsigned)((per + kThreads - 1) / kThreads), B), dim3(kThreads), 0,
-                       dcs_stream(stream), g_y, window, inv_env, g_frames, T, n_fft, hop, Lout, scale);
+    if (!(hop & 3) && !((n_fft / 2) & 3) && !(Lout & 3) && per / 4 < (1L << 30) &&
+        !(((uintptr_t)g_y | (uintptr_t)window | (uintptr_t)inv_env | (uintptr_t)g_frames) & 15))
+        DCS_LAUNCH(istft_ola_bwd4_kernel, dim3((unsigned)((per / 4 + kThreads - 1) / kThreads), B), dim3(kThreads), 0,
+                           dcs_stream(stream), g_y, window, inv_env, g_frames, T, n_fft, hop, Lout, scale);
+    else
+        DCS_LAUNCH(istft_ola_bwd_kernel, dim3((unsigned)((per + kThreads - 1) / kThreads), B), dim3(kThreads), 0,
+                           dcs_stream(stream), g_y, window, inv_env, g_frames, T, n_fft, hop, Lout, scale);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
