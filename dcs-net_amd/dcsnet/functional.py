@@ -515,6 +515,60 @@ class _LstmRecFn(torch.autograd.Function):
         return g_pre5, g_whh
 
 
+def _project(inp, w_ih, shared, per_set=False):
+    """Input projection of one LSTM layer for both parameter sets, all time steps at once (nn.LSTM's x_t W_ih^T, c_network.py:24-31):
+    shared: inp [M, in] read by both sets -> [M, 2 * 8H] against the stacked weight [2 * 8H, in] (per_set: -> [2, M, 8H], the
+    same rows read once per set); else inp [2, M, in] -> [2, M, 8H].  In-tree fp32 MFMA kernel (dcs_gemm_f32); shapes it does
+    not take go to the library GEMM."""
+    G8, K = w_ih.shape[1], w_ih.shape[2]
+    M = inp.shape[-2]
+    if not (ops.gemm_ok(M, G8, K, 2) and inp.is_contiguous() and w_ih.is_contiguous()):
+        if shared and not per_set:
+            return torch.mm(inp, w_ih.reshape(2 * G8, -1).t())
+        return torch.matmul(inp, w_ih.transpose(1, 2))
+    if shared and not per_set:
+        gx = torch.empty((M, 2 * G8), dtype=torch.float32, device=inp.device)
+        return ops.gemm_f32(inp, w_ih, gx, M, 2 * G8, K, K, K, 2 * G8, True)
+    gx = torch.empty((2, M, G8), dtype=torch.float32, device=inp.device)
+    return ops.gemm_f32(inp, w_ih, gx, M, G8, K, K, K, G8, True, nbatch=2, a_batch=0 if shared else M * K, b_batch=G8 * K,
+                        c_batch=M * G8)
+
+
+def _project_bwd(g_gx, w_ih, shared):
+    """Data gradient of _project: g_gx [2, M, 8H], w_ih [2, 8H, in] -> shared: sum over the sets [M, in] (the two sets are two
+    K segments of one launch); else [2, M, in]."""
+    G8, K = w_ih.shape[1], w_ih.shape[2]
+    M = g_gx.shape[1]
+    if not (ops.gemm_ok(M, K, G8, 2) and g_gx.is_contiguous() and w_ih.is_contiguous()):
+        if shared:
+            g_inp = torch.mm(g_gx[0], w_ih[0])
+            return g_inp.addmm_(g_gx[1], w_ih[1])              # (in place: torch.addmm copies its addend first)
+        return torch.bmm(g_gx, w_ih)
+    if shared:
+        g_inp = torch.empty((M, K), dtype=torch.float32, device=g_gx.device)
+        return ops.gemm_f32(g_gx, w_ih, g_inp, M, K, G8, G8, K, K, False, nseg=2, a_seg=M * G8, b_seg=G8 * K)
+    g_inp = torch.empty((2, M, K), dtype=torch.float32, device=g_gx.device)
+    return ops.gemm_f32(g_gx, w_ih, g_inp, M, K, G8, G8, K, K, False, nbatch=2, a_batch=M * G8, b_batch=G8 * K, c_batch=M * K)
+
+
+class _ProjectFn(torch.autograd.Function):
+    """_project(per_set=True) / _project_bwd under autograd, for LSTM parameters that are not views of a dp.FlatBucket (the
+    weight gradient then goes through torch: not the captured step's path)."""
+
+    @staticmethod
+    def forward(ctx, inp, w_ih):
+        ctx.save_for_backward(inp, w_ih)
+        return _project(inp, w_ih, shared=inp.dim() == 2, per_set=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        inp, w_ih = ctx.saved_tensors
+        g = g.contiguous()
+        g_inp = _project_bwd(g, w_ih, shared=inp.dim() == 2) if ctx.needs_input_grad[0] else None
+        g_w = torch.matmul(g.transpose(1, 2), inp) if ctx.needs_input_grad[1] else None
+        return g_inp, g_w
+
+
 class _LstmLayerFn(torch.autograd.Function):
     """One bidirectional layer of both LSTM parameter sets over STACKED parameters that are views of a
     dp.FlatBucket (st[kind] = (value view, gradient view); weight_ih [2, 8H, in], weight_hh [2, 2, 4H, H],
@@ -531,11 +585,11 @@ class _LstmLayerFn(torch.autograd.Function):
             # first layer: both parameter sets read the SAME rows -> one GEMM against the stacked [2*8H, in] weight; the
             # recurrence takes gx by strides (set stride 8H inside a row), so nothing is expanded or copied
             G8 = w_ih.shape[1]
-            gx = torch.mm(inp, w_ih.reshape(2 * G8, -1).t())                                    # [(n t), (set, dir*4H)]
+            gx = _project(inp, w_ih, shared=True)                                               # [(n t), (set, dir*4H)]
             G4 = G8 // 2
             strides = (G8, S * 2 * G8, 2 * G8)
         else:
-            gx = torch.bmm(inp, w_ih.transpose(1, 2))                                           # (set, n*t, dir*4H)
+            gx = _project(inp, w_ih, shared=False)                                              # (set, n*t, dir*4H)
             G4 = gx.shape[-1] // 2
             strides = (B2 * S * 2 * G4, S * 2 * G4, 2 * G4)
         out, gates, c, hprev = ops.lstm_layer(gx, w_hh, 2, B2, S, strides, need, True,
@@ -556,13 +610,7 @@ class _LstmLayerFn(torch.autograd.Function):
         g_pre, b_part = ops.lstm_layer_bwd(g_out.contiguous(), gates, c, w_hh, 2, B2, S, True)
         g_gx = g_pre.view(2, NT, 8 * H)
         _LstmLayerFn._param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT)
-        if inp.dim() == 2:
-            g_inp = None
-            if ctx.needs_input_grad[0]:
-                g_inp = torch.mm(g_gx[0], w_ih[0])
-                g_inp.addmm_(g_gx[1], w_ih[1])              # (in place: torch.addmm copies its addend first)
-            return g_inp, None, None, None, None
-        g_inp = torch.bmm(g_gx, w_ih) if ctx.needs_input_grad[0] else None
+        g_inp = _project_bwd(g_gx, w_ih, shared=inp.dim() == 2) if ctx.needs_input_grad[0] else None
         return g_inp, None, None, None, None
 
     @staticmethod
@@ -660,8 +708,8 @@ def _lstm_layer_operands(sets, layer):
 
 def complex_lstm(z, real_lstm, imag_lstm):
     """ComplexLSTM.forward (c_network.py:33-47) for two bidirectional batch_first nn.LSTM
-    parameter containers.  Per layer: one batched input-projection GEMM for all time steps
-    (rocBLAS via torch) + one persistent HIP launch for the recurrence of all 4 passes x 2 directions
+    parameter containers.  Per layer: one input-projection GEMM for all time steps
+    (dcs_gemm_f32) + one persistent HIP launch for the recurrence of all 4 passes x 2 directions
     (hand-written BPTT)."""
     if not (real_lstm.bidirectional and real_lstm.batch_first and real_lstm.hidden_size == 64):
         raise DcsHipError('complex_lstm: the HIP path implements the reference geometry '
@@ -678,18 +726,22 @@ def complex_lstm(z, real_lstm, imag_lstm):
             out = _LstmLayerFn.apply(x2 if layer == 0 else inp, real_lstm.weight_ih_l0, stacked[layer], 2 * B, S)
             inp = out.view(2, 2 * B * S, -1)
             continue
-        if inp is None:
-            inp = x2.unsqueeze(0).expand(2, -1, -1)
         w_ih, bias, w_hh = _lstm_layer_operands(sets, layer)
-        if not (torch.is_grad_enabled() and (inp.requires_grad or bias.requires_grad or w_ih.requires_grad)):
+        if not (torch.is_grad_enabled() and ((x2 if layer == 0 else inp).requires_grad or bias.requires_grad or w_ih.requires_grad)):
             # inference: bare projection, the gate biases are added inside the recurrence kernel (baddbmm's bias broadcast was
             # a 27 us pass over gx per layer at [16,256,2000])
-            gx = torch.bmm(inp, w_ih.transpose(1, 2))
-            out = ops.lstm_layer(gx, w_hh.contiguous(), 2, 2 * B, S, (2 * B * S * gx.shape[-1], S * gx.shape[-1], gx.shape[-1]),
-                                 False, bias=(bias.contiguous(), None))[0]
+            if layer == 0:
+                # both sets read the same rows: one launch against the stacked weight, the recurrence takes gx by strides
+                G8 = w_ih.shape[1]
+                gx = _project(x2, w_ih.contiguous(), shared=True)
+                strides = (G8, S * 2 * G8, 2 * G8)
+            else:
+                gx = _project(inp, w_ih.contiguous(), shared=False)
+                strides = (2 * B * S * gx.shape[-1], S * gx.shape[-1], gx.shape[-1])
+            out = ops.lstm_layer(gx, w_hh.contiguous(), 2, 2 * B, S, strides, False, bias=(bias.contiguous(), None))[0]
             inp = out.view(2, 2 * B * S, -1)
             continue
-        gx = torch.baddbmm(bias.unsqueeze(1), inp, w_ih.transpose(1, 2))          # (set, n*t, dir*4H)
+        gx = _ProjectFn.apply(x2 if layer == 0 else inp, w_ih) + bias.unsqueeze(1)             # (set, n*t, dir*4H)
         out = _LstmRecFn.apply(gx.view(2, 2 * B, S, 2, -1), w_hh)                 # [2*2B, S, 2H]
         inp = out.view(2, 2 * B * S, -1)
     o = inp.view(2, 2 * B, S, -1)

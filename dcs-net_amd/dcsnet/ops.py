@@ -1048,6 +1048,29 @@ def atb_chunks_acc(A, B, out, nsets, lda, ldb, M, N, NT, CK, b_shared=False):
     check(lib.dcs_chunk_sum_acc(ptr(part), ptr(out), M * N, 0, nsets, 1, CK, M * N, cur_stream()), 'dcs_chunk_sum_acc')
 
 
+LSTM_GEMM = _os.environ.get('DCS_LSTM_GEMM', '1') != '0'      # 0: the LSTM projections through torch.mm / bmm (rocBLAS), for A/B runs
+# launches above this much work go to the library: the in-tree kernel's 32 x 64 wave tiles are sized for the train shapes
+# (csrc/gemm.hip; same-box: inference pass 2.99 ms with the library's 256 x 256 tiles, 3.06 ms in-tree)
+LSTM_GEMM_MAX_GFLOP = float(_os.environ.get('DCS_LSTM_GEMM_MAX_GFLOP', '1.5'))
+
+
+def gemm_ok(M, N, K, launches=1):
+    """Shapes dcs_gemm_f32 takes and is the faster choice for (the LSTM projections of the train shapes all are); N, K: one
+    launch's columns and contraction length, launches: batches x segments."""
+    return (LSTM_GEMM and M >= 1 and N >= 64 and N % 64 == 0 and K >= 32 and K % 32 == 0
+            and 2e-9 * M * N * K * launches <= LSTM_GEMM_MAX_GFLOP)
+
+
+def gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, b_transposed, nseg=1, a_seg=0, b_seg=0, nbatch=1, a_batch=0, b_batch=0,
+             c_batch=0, a_planes=0, c_planes=0):
+    """C_b = sum_s A_{b,s} op(B_{b,s}) on the fp32 MFMA pipe (include/dcsnet_hip.h: dcs_gemm_f32); strides in floats."""
+    for n, t in (('A', A), ('B', B), ('C', C)):
+        _chk(t, n)
+    check(_lib.load().dcs_gemm_f32(ptr(A), ptr(B), ptr(C), M, N, K, lda, ldb, ldc, 1 if b_transposed else 0, nseg, a_seg,
+                                   b_seg, nbatch, a_batch, b_batch, c_batch, a_planes, c_planes, cur_stream()), 'dcs_gemm_f32')
+    return C
+
+
 def lstm_param_grads(part, b_part, g_whh, g_bih, g_bhh, CK, seqs, H):
     """Accumulate one layer's recurrent-weight and bias gradients from the backward's partial products (in place)."""
     for n, t in (('part', part), ('b_part', b_part), ('g_whh', g_whh), ('g_bih', g_bih), ('g_bhh', g_bhh)):

@@ -475,6 +475,20 @@ int dcs_atb_chunks(const float* A, const float* B, float* part, long a_lo, long 
                    int lda, int ldb, int M, int N, int R, int CK, dcs_stream_t stream);
 int dcs_chunk_sum_acc(const float* part, float* out, long o_lo, long o_hi, int nlo, int nhi, int CK, long MN,
                       dcs_stream_t stream);
+/* dcs_gemm_f32: the LSTM's input projections x_t W_ih^T for all time steps at once, and their data gradients (inside
+ * torch.nn.LSTM in the reference: c_network.py:24-31,43-46) on the fp32 MFMA pipe (exact fp32 products, fixed summation
+ * order: bit-reproducible):
+ *   C_b[m][n] = sum over s < nseg, k < K of A_{b,s}[m][k] * op(B_{b,s})[k][n],  b < nbatch,
+ *   A_{b,s} = A + b * a_batch + s * a_seg (floats; row pitch lda, k contiguous), B_{b,s} likewise with b_transposed != 0:
+ *   B[n][k] (nn.LSTM's weight_ih layout, pitch ldb >= K) or 0: B[k][n] (pitch ldb >= N); C_b = C + b * c_batch, pitch ldc.
+ *   a_planes > 0: A is instead a complex-interleaved float[a_planes][K][2] and row m is part m / a_planes (0 real, 1
+ *   imaginary) of its row m % a_planes — the {re rows | im rows} stacking of ComplexLSTM's input (c_network.py:39-46) read
+ *   in place; c_planes > 0: C is written the same way into float[c_planes][N][2] (the gradient of that stacking).
+ *   N % 64 == 0, K % 32 == 0, any M >= 1 (M <= 2 * planes where planes are used); A, B 16-byte aligned, pitches and
+ *   strides multiples of 4 floats.  DCS_ERR_BADARG otherwise. */
+int dcs_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int b_transposed,
+                 int nseg, long a_seg, long b_seg, int nbatch, long a_batch, long b_batch, long c_batch, int a_planes,
+                 int c_planes, dcs_stream_t stream);
 int dcs_lstm_combine_fwd(const float* o, float* out, long n, dcs_stream_t stream);
 int dcs_lstm_combine_bwd(const float* g, float* g_o, long n, dcs_stream_t stream);
 int dcs_lstm_param_grads(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,

@@ -550,6 +550,62 @@ def test_fused_sisnr_pair_losses_and_guard(dev):
     assert float(skip) == 1.0
 
 
+def test_lstm_projection_gemm(dev):
+    """dcs_gemm_f32 (the LSTM input projections x W_ih^T and their data gradients: inside nn.LSTM in the reference,
+    c_network.py:24-31,43-46) against fp64 matmul: K-contiguous and N-contiguous B, a ragged M, two K segments (the two parameter
+    sets of a shared input), batches, and the {re rows | im rows} stacking read / written in place."""
+    from dcsnet import ops
+    g = torch.Generator().manual_seed(41)
+    f64 = torch.float64
+
+    def run(A, Bm, M, N, K, bt, **kw):
+        C = torch.full(kw.pop('c_shape'), float('nan'), device=dev)
+        ops.gemm_f32(A.to(dev), Bm.to(dev), C, M, N, K, kw.pop('lda', K), kw.pop('ldb', K if bt else N), kw.pop('ldc', N), bt, **kw)
+        return C.cpu()
+
+    # (the shapes cover the three workgroup forms of csrc/gemm.hip and its group sizes 4 / 2 / 1)
+    for M, N, K in ((2048, 1024, 128), (40, 64, 32), (97, 128, 512), (6400, 64, 96), (6401, 64, 64), (4096, 128, 1024)):
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g)
+        want = (A.to(f64) @ W.to(f64).t()).float()
+        close(run(A, W, M, N, K, True, c_shape=(M, N)), want, rel=2e-6, what=f'A W^T {M}x{N}x{K}')
+        close(run(A, W.t().contiguous(), M, N, K, False, c_shape=(M, N)), want, rel=2e-6, what=f'A B {M}x{N}x{K}')
+    # batches: [2][M][K] x [2][N][K]^T; segments: sum over two (A_s, B_s) pairs with B N-contiguous
+    M, N, K = 72, 192, 64
+    A = torch.randn(2, M, K, generator=g)
+    W = torch.randn(2, N, K, generator=g)
+    got = run(A, W, M, N, K, True, c_shape=(2, M, N), nbatch=2, a_batch=M * K, b_batch=N * K, c_batch=M * N)
+    close(got, torch.bmm(A.to(f64), W.to(f64).transpose(1, 2)).float(), rel=2e-6, what='batched')
+    A2 = torch.randn(2, 2048, 512, generator=g)                                   # the layer-1 data gradient's shape
+    W2 = torch.randn(2, 512, 128, generator=g)
+    got = run(A2, W2, 2048, 128, 512, False, c_shape=(2, 2048, 128), nbatch=2, a_batch=2048 * 512, b_batch=512 * 128, c_batch=2048 * 128)
+    close(got, torch.bmm(A2.to(f64), W2.to(f64)).float(), rel=2e-6, what='batched, N-contiguous B')
+    Bn = torch.randn(2, K, N, generator=g)
+    got = run(A, Bn, M, N, K, False, c_shape=(M, N), nseg=2, a_seg=M * K, b_seg=K * N)
+    close(got, torch.bmm(A.to(f64), Bn.to(f64)).sum(0).float(), rel=2e-6, what='two segments')
+    # the stacking of ComplexLSTM's input: rows {re | im} of a complex [R0][K] read in place, and written in place
+    R0, K, N = 36, 128, 64
+    z = torch.randn(R0, K, 2, generator=g)
+    W = torch.randn(N, K, generator=g)
+    x2 = z.permute(2, 0, 1).reshape(2 * R0, K)
+    got = run(z, W, 2 * R0, N, K, True, c_shape=(2 * R0, N), a_planes=R0)
+    close(got, (x2.to(f64) @ W.to(f64).t()).float(), rel=2e-6, what='A read as planes')
+    Gm = torch.randn(2 * R0, K, generator=g)
+    Bn = torch.randn(K, N, generator=g)
+    got = run(Gm, Bn, 2 * R0, N, K, False, c_shape=(R0, N, 2), c_planes=R0)
+    close(got, (Gm.to(f64) @ Bn.to(f64)).float().view(2, R0, N).permute(1, 2, 0), rel=2e-6, what='C written as planes')
+    # two runs give the same bits (fixed summation order); bad shapes are refused
+    A = torch.randn(256, 128, generator=g).to(dev)
+    W = torch.randn(512, 128, generator=g).to(dev)
+    c1 = ops.gemm_f32(A, W, torch.empty(256, 512, device=dev), 256, 512, 128, 128, 128, 512, True)
+    c2 = ops.gemm_f32(A, W, torch.empty(256, 512, device=dev), 256, 512, 128, 128, 128, 512, True)
+    assert torch.equal(c1, c2)
+    with pytest.raises(Exception):
+        ops.gemm_f32(A, W, torch.empty(256, 512, device=dev), 256, 500, 128, 128, 128, 512, True)
+    with pytest.raises(Exception):
+        ops.gemm_f32(A, W, torch.empty(256, 512, device=dev), 256, 512, 100, 128, 128, 512, True)
+
+
 def test_lstm_glue_kernels(dev):
     """dcs_lstm_combine_fwd / _bwd (ComplexLSTM's recombination, c_network.py:43-46) and dcs_lstm_param_grads (chunk sums of
     the recurrent-weight products, per-sequence bias sums) against their torch spellings."""
