@@ -333,6 +333,7 @@ struct AtB {
     const float* A; const float* B; float* part;
     long a_lo, a_hi, b_lo, b_hi;
     int nlo, lda, ldb, M, N, R, CK;
+    int b_es;                                                           // element stride of B along n (2: one part of a complex-interleaved row)
 };
 __global__ __launch_bounds__(256) void atb_chunks_kernel(AtB p) {
     __shared__ float red[3][32][64];                                    // waves 1..3 -> wave 0: 2 tiles x 16 registers x 64 lanes
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(256) void atb_chunks_kernel(AtB p) {
     const int RW = p.R / 4;                                            // rows per wave (even)
     const long r0 = (long)c * p.R + (long)wave * RW + kk;
     const float* ga = p.A + lo * p.a_lo + hi * p.a_hi + r0 * p.lda + m0 + li;
-    const float* hb = p.B + lo * p.b_lo + hi * p.b_hi + r0 * p.ldb + n0 + li;
+    const float* hb = p.B + lo * p.b_lo + hi * p.b_hi + r0 * p.ldb + (n0 + li) * p.b_es;
+    const int b32 = 32 * p.b_es;
     const long ga_step = 2L * p.lda, hb_step = 2L * p.ldb;
     f32x16w acc0, acc1;
 #pragma unroll
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void atb_chunks_kernel(AtB p) {
             const float a_ = ga[ii * ga_step];
             av[u] = ok ? a_ : 0.f;
             b0[u] = hb[ii * hb_step];
-            b1[u] = hb[ii * hb_step + 32];
+            b1[u] = hb[ii * hb_step + b32];
         }
         __builtin_amdgcn_sched_barrier(0);                             // every load issued before the first MFMA waits
 #pragma unroll
@@ -399,15 +401,21 @@ __global__ __launch_bounds__(256) void chunk_sum_acc_kernel(const float* __restr
 }
 }  // namespace
 
-extern "C" int dcs_atb_chunks(const float* A, const float* B, float* part, long a_lo, long a_hi, long b_lo, long b_hi, int nlo,
-                              int nhi, int lda, int ldb, int M, int N, int R, int CK, dcs_stream_t stream) {
-    if (!A || !B || !part || nlo < 1 || nhi < 1 || M < 32 || (M & 31) || N < 64 || (N & 63) || R < 8 || (R & 7) || CK < 1)
+extern "C" int dcs_atb_chunks_strided(const float* A, const float* B, float* part, long a_lo, long a_hi, long b_lo, long b_hi,
+                                      int nlo, int nhi, int lda, int ldb, int b_es, int M, int N, int R, int CK,
+                                      dcs_stream_t stream) {
+    if (!A || !B || !part || nlo < 1 || nhi < 1 || M < 32 || (M & 31) || N < 64 || (N & 63) || R < 8 || (R & 7) || CK < 1 || b_es < 1)
         return DCS_ERR_BADARG;
     if ((long)nlo * nhi * CK > 65535 || N / 64 > 65535) return DCS_ERR_BADARG;
-    AtB p{A, B, part, a_lo, a_hi, b_lo, b_hi, nlo, lda, ldb, M, N, R, CK};
+    AtB p{A, B, part, a_lo, a_hi, b_lo, b_hi, nlo, lda, ldb, M, N, R, CK, b_es};
     DCS_LAUNCH(atb_chunks_kernel, dim3(M / 32, N / 64, nlo * nhi * CK), dim3(256), 0, dcs_stream(stream), p);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+extern "C" int dcs_atb_chunks(const float* A, const float* B, float* part, long a_lo, long a_hi, long b_lo, long b_hi, int nlo,
+                              int nhi, int lda, int ldb, int M, int N, int R, int CK, dcs_stream_t stream) {
+    return dcs_atb_chunks_strided(A, B, part, a_lo, a_hi, b_lo, b_hi, nlo, nhi, lda, ldb, 1, M, N, R, CK, stream);
 }
 
 extern "C" int dcs_chunk_sum_acc(const float* part, float* out, long o_lo, long o_hi, int nlo, int nhi, int CK, long MN,

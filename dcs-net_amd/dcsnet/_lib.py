@@ -109,6 +109,7 @@ SIGNATURES = {
     'dcs_lstm_whh_grad': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'dcs_atb_chunks': (_I, [_P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'dcs_chunk_sum_acc': (_I, [_P, _P, _L, _L, _I, _I, _I, _L, _P]),
+    'dcs_atb_chunks_strided': (_I, [_P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'dcs_gemm_f32': (_I, [_P, _P, _P] + [_I] * 8 + [_L, _L, _I, _L, _L, _L, _I, _I, _P]),
     'dcs_lstm_combine_fwd': (_I, [_P, _P, _L, _P]),
     'dcs_lstm_combine_bwd': (_I, [_P, _P, _L, _P]),

@@ -581,7 +581,19 @@ class _LstmLayerFn(torch.autograd.Function):
         need = inp.requires_grad or anchor.requires_grad
         # the gate biases (b_ih + b_hh, [2 sets, 8H] = [set][dir][4H]) are added inside the recurrence kernel: no add, no
         # bias-broadcast pass over gx
-        if inp.dim() == 2:
+        ctx.planes = 0
+        if inp.is_complex():
+            # first layer, straight from the complex latent [B, S, in]: rows {re | im} of the stacking x2 of complex_lstm are
+            # read in place by the GEMM (and by the weight gradient), the data gradient is written back interleaved
+            zr = torch.view_as_real(inp)
+            G8, K = w_ih.shape[1], w_ih.shape[2]
+            ctx.planes = R0 = zr.shape[0] * zr.shape[1]
+            gx = torch.empty((2 * R0, 2 * G8), dtype=torch.float32, device=inp.device)
+            ops.gemm_f32(zr, w_ih, gx, 2 * R0, 2 * G8, K, K, K, 2 * G8, True, a_planes=R0)
+            inp = zr
+            G4 = G8 // 2
+            strides = (G8, S * 2 * G8, 2 * G8)
+        elif inp.dim() == 2:
             # first layer: both parameter sets read the SAME rows -> one GEMM against the stacked [2*8H, in] weight; the
             # recurrence takes gx by strides (set stride 8H inside a row), so nothing is expanded or copied
             G8 = w_ih.shape[1]
@@ -609,12 +621,20 @@ class _LstmLayerFn(torch.autograd.Function):
         NT = B2 * S
         g_pre, b_part = ops.lstm_layer_bwd(g_out.contiguous(), gates, c, w_hh, 2, B2, S, True)
         g_gx = g_pre.view(2, NT, 8 * H)
-        _LstmLayerFn._param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT)
+        _LstmLayerFn._param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT, planes=ctx.planes)
+        if ctx.planes:
+            g_z = None
+            if ctx.needs_input_grad[0]:
+                G8, K = w_ih.shape[1], w_ih.shape[2]
+                gz = torch.empty(inp.shape, dtype=torch.float32, device=inp.device)               # [B, S, in, 2]
+                ops.gemm_f32(g_gx, w_ih, gz, NT, K, G8, G8, K, K, False, nseg=2, a_seg=NT * G8, b_seg=G8 * K, c_planes=ctx.planes)
+                g_z = torch.view_as_complex(gz)
+            return g_z, None, None, None, None
         g_inp = _project_bwd(g_gx, w_ih, shared=inp.dim() == 2) if ctx.needs_input_grad[0] else None
         return g_inp, None, None, None, None
 
     @staticmethod
-    def _param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT):
+    def _param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT, planes=0):
         global sink_hits
         # W_hh gradient per direction d: g_pre[set, (n t), d, :]^T h_prev[set, (n t), d, :] — strided views, no copies
         # (n t) is cut into CK chunks that ride the batch axis (rocBLAS runs a [4H x H] output with K = 4096 on 16
@@ -636,6 +656,9 @@ class _LstmLayerFn(torch.autograd.Function):
         g_wih = st['weight_ih'][1]
         sink_hits += 16
         # W_ih gradient g_gx[s]^T inp over the (n t) rows: chunked A^T B on the MFMA pipe (rocBLAS: 25 us per 512 x 2048 x 256)
+        if planes:                                                      # inp = the complex latent as float [B, S, in, 2] (checked by the caller)
+            ops.atb_chunks_acc_planes(g_gx, inp, g_wih, 2, 8 * H, 8 * H, inp.shape[-2], planes, 8)
+            return
         n_in = inp.shape[-1]
         mfma_ok = g_wih.is_contiguous() and n_in % 64 == 0 and (8 * H) % 32 == 0 and NT % (8 * CK) == 0 and inp.is_contiguous()
         if inp.dim() == 2:                                              # shared first-layer input: per-set GEMMs, no expand
@@ -718,12 +741,17 @@ def complex_lstm(z, real_lstm, imag_lstm):
     sets = (real_lstm, imag_lstm)
     # rows 0..B-1: real parts, rows B..2B-1: imaginary parts; both weight sets see the same input
     # (2-D from the start: indexing a [1, rows, I] tensor costs a zero fill and a copy in the backward of the select)
-    x2 = torch.view_as_real(z).permute(3, 0, 1, 2).reshape(2 * B * S, I)
     inp = None
     stacked = _stacked_lstm(real_lstm) if torch.is_grad_enabled() else None
+    # the stacking read in place (no x2, no permute in the backward) where the kernels take the shape: whole 8-row chunks of the
+    # weight gradient inside each part (dcs_atb_chunks_strided), a launch the in-tree GEMM is meant for
+    in_place = (stacked is not None and z.is_contiguous() and (B * S) % 64 == 0 and I % 64 == 0
+                and ops.gemm_ok(2 * B * S, 16 * real_lstm.hidden_size, I) and ops.gemm_ok(2 * B * S, I, 8 * real_lstm.hidden_size, 2)
+                and stacked[0]['weight_ih'][0].is_contiguous() and stacked[0]['weight_ih'][1].is_contiguous())
+    x2 = None if in_place else torch.view_as_real(z).permute(3, 0, 1, 2).reshape(2 * B * S, I)
     for layer in range(real_lstm.num_layers):
         if stacked is not None:
-            out = _LstmLayerFn.apply(x2 if layer == 0 else inp, real_lstm.weight_ih_l0, stacked[layer], 2 * B, S)
+            out = _LstmLayerFn.apply((z if in_place else x2) if layer == 0 else inp, real_lstm.weight_ih_l0, stacked[layer], 2 * B, S)
             inp = out.view(2, 2 * B * S, -1)
             continue
         w_ih, bias, w_hh = _lstm_layer_operands(sets, layer)

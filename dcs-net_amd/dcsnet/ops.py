@@ -1071,6 +1071,19 @@ def gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, b_transposed, nseg=1, a_seg=0, b_s
     return C
 
 
+def atb_chunks_acc_planes(A, zr, out, nsets, lda, M, N, R0, CK):
+    """atb_chunks_acc whose shared B is the {re rows | im rows} stacking of a complex-interleaved zr float[R0, N, 2], read in
+    place: out[s] += A[s]^T [zr.re ; zr.im], A: [nsets, 2 * R0, lda-pitched M columns]; CK chunks per part."""
+    for n, t in (('A', A), ('zr', zr), ('out', out)):
+        _chk(t, n)
+    lib = _lib.load()
+    part = torch.empty((nsets * 2 * CK, M, N), dtype=torch.float32, device=A.device)
+    # batches: lo = part (real / imaginary rows), hi = set -> part index (set * 2 + part) * CK + c: 2 CK chunks per set
+    check(lib.dcs_atb_chunks_strided(ptr(A), ptr(zr), ptr(part), R0 * lda, 2 * R0 * lda, 1, 0, 2, nsets, lda, 2 * N, 2, M, N,
+                                     R0 // CK, CK, cur_stream()), 'dcs_atb_chunks_strided')
+    check(lib.dcs_chunk_sum_acc(ptr(part), ptr(out), M * N, 0, nsets, 1, 2 * CK, M * N, cur_stream()), 'dcs_chunk_sum_acc')
+
+
 def lstm_param_grads(part, b_part, g_whh, g_bih, g_bhh, CK, seqs, H):
     """Accumulate one layer's recurrent-weight and bias gradients from the backward's partial products (in place)."""
     for n, t in (('part', part), ('b_part', b_part), ('g_whh', g_whh), ('g_bih', g_bih), ('g_bhh', g_bhh)):

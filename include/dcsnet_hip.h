@@ -475,6 +475,11 @@ int dcs_atb_chunks(const float* A, const float* B, float* part, long a_lo, long 
                    int lda, int ldb, int M, int N, int R, int CK, dcs_stream_t stream);
 int dcs_chunk_sum_acc(const float* part, float* out, long o_lo, long o_hi, int nlo, int nhi, int CK, long MN,
                       dcs_stream_t stream);
+/* dcs_atb_chunks with an element stride b_es along the columns of B (B_b[r][n] = B_b[r * ldb + n * b_es]): b_es = 2, ldb = 2 N,
+ * b_lo = 1 reads the real (lo = 0) and imaginary (lo = 1) parts of a complex-interleaved float[rows][N][2] in place — the
+ * {re rows | im rows} stacking of ComplexLSTM's input (c_network.py:39-46) without its copy. */
+int dcs_atb_chunks_strided(const float* A, const float* B, float* part, long a_lo, long a_hi, long b_lo, long b_hi, int nlo,
+                           int nhi, int lda, int ldb, int b_es, int M, int N, int R, int CK, dcs_stream_t stream);
 /* dcs_gemm_f32: the LSTM's input projections x_t W_ih^T for all time steps at once, and their data gradients (inside
  * torch.nn.LSTM in the reference: c_network.py:24-31,43-46) on the fp32 MFMA pipe (exact fp32 products, fixed summation
  * order: bit-reproducible):

@@ -652,3 +652,12 @@ def test_lstm_glue_kernels(dev):
         out = out0.clone().to(dev)
         ops.atb_chunks_acc(g_pre.to(dev), inp.to(dev), out, 2, 8 * H, n_in, 8 * H, n_in, NT, CK, b_shared=shared)
         close(out, want_w, rel=2e-5, what=f'atb_chunks_acc in={n_in}')
+    # the shared input as the {re rows | im rows} stacking of a complex-interleaved [R0, in, 2], read in place
+    R0, n_in = NT // 2, 128
+    zr = torch.randn(R0, n_in, 2, generator=g)
+    x2 = zr.permute(2, 0, 1).reshape(NT, n_in)
+    out0 = torch.randn(2, 8 * H, n_in, generator=g)
+    want_w = out0 + torch.stack([g_pre[s_].t() @ x2 for s_ in range(2)])
+    out = out0.clone().to(dev)
+    ops.atb_chunks_acc_planes(g_pre.to(dev), zr.to(dev), out, 2, 8 * H, 8 * H, n_in, R0, 8)
+    close(out, want_w, rel=2e-5, what='atb_chunks_acc_planes')

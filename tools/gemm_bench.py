@@ -1,4 +1,4 @@
-"""dcs_gemm_f32 against torch.mm / bmm (rocBLAS) at the LSTM projection shapes of the train step ([32,256,256]: rows 2048, in 128,
+"""dcs_gemm_f32 against torch.mm / bmm (rocBLAS) at the LSTM projection shapes of the train step ([32,256,256]: rows 4096, in 128,
 8H 512) and of the inference pass.  GPU box: python tools/gemm_bench.py [rows]"""
 import os
 import sys
@@ -26,7 +26,7 @@ def timeit(fn, reps=200):
 
 
 def main():
-    M = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     eager = len(sys.argv) > 2 and sys.argv[2] == 'eager'          # a few plain launches of the in-tree kernels (counter passes)
     dev = torch.device('cuda:0')
     K, G8 = 128, 512
