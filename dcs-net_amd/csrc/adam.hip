@@ -84,9 +84,10 @@ __global__ void step_guard_kernel(const float* __restrict__ loss, float* __restr
     skip[0] = (loss[0] != loss[0]) ? 1.f : 0.f;
 }
 __global__ void step_advance_kernel(const float* __restrict__ skip, int* __restrict__ step_dev,
-                                    long long* __restrict__ seed_dev) {
+                                    long long* __restrict__ seed_dev, long long* __restrict__ counters, int n_counters) {
     if (step_dev && !(skip && skip[0] != 0.f)) step_dev[0] += 1;
     if (seed_dev) seed_dev[0] += 1;
+    for (int i = 0; i < n_counters; ++i) counters[i] += 1;      // every forward counts, whatever the guard says (complexLayers: num_batches_tracked)
 }
 }  // namespace
 
@@ -97,9 +98,15 @@ extern "C" int dcs_step_guard(const float* loss, float* skip, dcs_stream_t strea
     return DCS_OK;
 }
 
-extern "C" int dcs_step_advance(const float* skip, int* step_dev, long long* seed_dev, dcs_stream_t stream) {
-    if (!step_dev && !seed_dev) return DCS_ERR_BADARG;
-    DCS_LAUNCH(step_advance_kernel, dim3(1), dim3(1), 0, dcs_stream(stream), skip, step_dev, seed_dev);
+extern "C" int dcs_step_advance_counters(const float* skip, int* step_dev, long long* seed_dev, long long* counters, int n_counters,
+                                         dcs_stream_t stream) {
+    if ((!step_dev && !seed_dev && !counters) || n_counters < 0 || n_counters > 4096 || (n_counters > 0 && !counters)) return DCS_ERR_BADARG;
+    DCS_LAUNCH(step_advance_kernel, dim3(1), dim3(1), 0, dcs_stream(stream), skip, step_dev, seed_dev, counters, n_counters);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+extern "C" int dcs_step_advance(const float* skip, int* step_dev, long long* seed_dev, dcs_stream_t stream) {
+    if (!step_dev && !seed_dev) return DCS_ERR_BADARG;
+    return dcs_step_advance_counters(skip, step_dev, seed_dev, nullptr, 0, stream);
 }

@@ -124,6 +124,7 @@ SIGNATURES = {
     'dcs_kernel_timer_end': (_I, []),
     'dcs_kernel_timer_read': (_I, [_I, _P]),
     'dcs_step_advance': (_I, [_P, _P, _P, _P]),
+    'dcs_step_advance_counters': (_I, [_P, _P, _P, _P, _I, _P]),
     'dcs_pack_tap_rows': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dcs_tap_rows_wgrad_scatter': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dcs_set_conv_precision': (_I, [_I]),

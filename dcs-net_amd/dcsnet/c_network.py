@@ -192,7 +192,10 @@ class C_NETWORK(LightningModule):
             for i, b in enumerate(bns):
                 b._buffers['num_batches_tracked'] = shared[i]
             self.__dict__['_nbt_shared'] = shared
-        shared += 1
+        if self.__dict__.get('_dcs_defer_nbt', False):
+            self.__dict__['_nbt_pending'] = shared       # dp.TrainStep adds the 1 in the step's own counter launch (dcs_step_advance_counters)
+        else:
+            shared += 1
         self._counted = True
 
     def forward(self, x, bound=True):

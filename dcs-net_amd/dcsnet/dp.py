@@ -128,17 +128,19 @@ class FusedAdam:
         self.t = 0
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=bucket.flat.device)
 
-    def step(self, world=1, seed_state=None):
+    def step(self, world=1, seed_state=None, counters=None):
         """One update, unless the bucket's skip flag is set (a NaN loss on some rank: the reference's trainer skips
         the update, c_network.py:257-261) — decided on the device, so the same launches serve a replayed graph.
         `t` counts calls; the update count the bias corrections use is `t_dev` (advances only with a real update).
-        seed_state: the dropout seed offset, advanced in the same launch as `t_dev`."""
+        seed_state: the dropout seed offset, advanced in the same launch as `t_dev`; counters: an int64 tensor whose elements
+        that launch also advances (the network's num_batches_tracked buffers, TrainStep._counted)."""
         b = self.b
         if not b.flat.is_cuda:
             raise _lib.DcsHipError('FusedAdam: expected CUDA (HIP) parameters; the HIP path has no CPU fallback')
         self.t += 1
         lib = _lib.load()
-        check(lib.dcs_step_advance(ptr(b.skip), ptr(self.t_dev), ptr(seed_state), cur_stream()), 'dcs_step_advance')
+        check(lib.dcs_step_advance_counters(ptr(b.skip), ptr(self.t_dev), ptr(seed_state), ptr(counters),
+                                            0 if counters is None else counters.numel(), cur_stream()), 'dcs_step_advance_counters')
         norm = torch.linalg.vector_norm(b.grad).reshape(1) if self.max_norm > 0 else None
         check(lib.dcs_adam_amsgrad_step(ptr(b.flat), ptr(b.grad), ptr(self.m), ptr(self.v), ptr(self.vmax),
                                         ptr(norm), float(self.max_norm), 1.0 / world, b.numel, self.lr,
@@ -159,9 +161,11 @@ class TorchAdam:
         self.opt = torch.optim.Adam(bucket.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                     amsgrad=True)
 
-    def step(self, world=1, seed_state=None):
+    def step(self, world=1, seed_state=None, counters=None):
         if seed_state is not None:
             seed_state += 1
+        if counters is not None:
+            counters += 1
         if float(self.b.skip) != 0.0:             # a NaN loss on some rank: every rank skips (c_network.py:257-261)
             return
         if world > 1:
@@ -203,19 +207,36 @@ class TrainStep:
         self.wgrad_side_stream = os.environ.get('DCS_WGRAD_SIDE', '1') != '0'
         self.comm_events = None        # bench.py sets a list: (start, end) HIP events around every gradient all-reduce
 
+    def _counting(self, on):
+        """While the step's forward runs, the network leaves the `+= 1` of its num_batches_tracked buffers to the optimizer
+        half's counter launch (c_network.C_NETWORK._count_batches); _counted() hands the buffer over exactly once."""
+        if self.bucket.flat.is_cuda:
+            self.net.__dict__['_dcs_defer_nbt'] = bool(on)
+
+    def _counted(self):
+        c = self.net.__dict__.pop('_nbt_pending', None)
+        if c is not None and c.dtype != torch.int64:
+            c += 1                                     # (never the case for the buffers _count_batches makes)
+            return None
+        return c
+
     def _step_body(self, batch, batch_idx):
         """NaN guard of the reference (c_network.py:257-261: training_step returns None, the trainer skips the update).
         With several ranks the decision must be the same everywhere and every rank must still enter the collective:
         a rank whose loss is NaN raises the flag element of the gradient bucket and joins the all-reduce with zero
         gradients; the summed flag makes every rank's optimizer a no-op."""
         self.bucket.zero_grad()
-        loss = self.net.training_step(batch, batch_idx)
+        self._counting(True)
+        try:
+            loss = self.net.training_step(batch, batch_idx)
+        finally:
+            self._counting(False)
         if loss is None:
             self.bucket.skip.fill_(1.0)
         else:
             self._backward(loss)
         world = self.bucket.allreduce(self.comm_events)
-        self.opt.step(world, self.seed_state)
+        self.opt.step(world, self.seed_state, self._counted())
         if loss is None or (world > 1 and float(self.bucket.skip) != 0.0):
             return None
         return loss.detach()
@@ -295,15 +316,17 @@ class TrainStep:
         # the NaN test training_step makes on the host, on the device: flag element of the gradient bucket.  The fused loss
         # assembly writes it in its own launch when handed the flag; any other loss goes through dcs_step_guard.
         self.net._dcs_skip_flag, self.net._dcs_skip_written = self.bucket.skip, False
+        self._counting(True)
         try:
             loss = self._loss_no_sync(batch, 0)
         finally:
             self.net._dcs_skip_flag = None
+            self._counting(False)
         if not self.net._dcs_skip_written:
             check(_lib.load().dcs_step_guard(ptr(loss), ptr(self.bucket.skip), cur_stream()), 'dcs_step_guard')
         self._backward(loss)
         if world == 1:                                 # collectives stay outside the graph
-            self.opt.step(1, self.seed_state)
+            self.opt.step(1, self.seed_state, self._counted())
         return loss
 
     def uncaptured_step(self, batch):
@@ -313,7 +336,7 @@ class TrainStep:
         loss = self._device_step(batch, world)
         if world > 1:
             world = self.bucket.allreduce(self.comm_events)
-            self.opt.step(world, self.seed_state)
+            self.opt.step(world, self.seed_state, self._counted())
         from . import functional
         functional.bump_param_generation()
         return loss
@@ -339,13 +362,14 @@ class TrainStep:
         functional.bump_param_generation()                 # cache entries made during capture live in its pool
         self._graph, self._static_loss, self._graph_world = g, loss.detach(), world
         self._graph_opt = None
+        self._graph_counters = self._counted() if world > 1 else None      # (world 1: the captured optimizer half took them)
         if world > 1:
             # the optimizer half (device-side norm, fused clip + Adam, seed advance) as a second graph replayed after the
             # all-reduce: ~6 eager launches per step otherwise sit between the collective and the next forward
             try:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, capture_error_mode='thread_local'):
-                    self.opt.step(world, self.seed_state)
+                    self.opt.step(world, self.seed_state, self._graph_counters)
                 self._graph_opt = g2
             except Exception as e:                          # noqa: BLE001 - the eager optimizer still works
                 import warnings
@@ -387,7 +411,7 @@ class TrainStep:
             if self._graph_opt is not None:
                 self._graph_opt.replay()
             else:
-                self.opt.step(world, self.seed_state)
+                self.opt.step(world, self.seed_state, self._graph_counters)
         functional.bump_param_generation()     # the replays rewrote parameters and running statistics behind torch's back
         # a NaN loss is returned as such (the caller may test it); the update was skipped on the device
         return self._static_loss.clone()

@@ -686,6 +686,11 @@ int dcs_kernel_timer_begin(int slot);
 int dcs_kernel_timer_end(void);
 int dcs_kernel_timer_read(int slot, float* ms);
 int dcs_step_advance(const float* skip, int* step_dev, long long* seed_dev, dcs_stream_t stream);
+/* dcs_step_advance that also adds 1 to each of n_counters int64 counters (<= 4096), unconditionally: the num_batches_tracked
+ * buffers of the network's ComplexBatchNorm2d layers (complexPyTorch 0.3 counts every training forward) ride the step's own
+ * counter launch instead of one of their own. */
+int dcs_step_advance_counters(const float* skip, int* step_dev, long long* seed_dev, long long* counters, int n_counters,
+                              dcs_stream_t stream);
 
 /* Tap-sum factorisation of a ONE-output-channel stride-1 ComplexConvTranspose2d (the last decoder stage,
  * c_network.py:135-141): y = tapsum(conv1x1(x: Cin -> ct "tap channels")) (dcs_tapsum_fwd).

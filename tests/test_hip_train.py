@@ -121,6 +121,14 @@ def test_graph_replayed_train_step_matches_eager(dev):
     assert int(ts_g.opt.t_dev) == 6 and int(ts_e.opt.t_dev) == 6
     assert int(ts_g.seed_state) == 6
     assert torch.allclose(ts_g.bucket.flat, ts_e.bucket.flat, atol=5e-4)
+    # num_batches_tracked of all fourteen CBNs rides the step's counter launch (dcs_step_advance_counters): one per step, eager
+    # or replayed; a training forward outside the step driver still counts by itself
+    for ts in (ts_e, ts_g):
+        sd = ts.net.state_dict()
+        assert {int(v) for k, v in sd.items() if k.endswith('num_batches_tracked') and
+                (k.startswith('encoder') or k.startswith('initial') or k[:9] in ('decoder.0', 'decoder.5'))} == {6}
+    ts_g.net(batch[1])
+    assert int(ts_g.net.state_dict()['encoder.3.1.num_batches_tracked']) == 7
 
 
 def test_graph_replay_draws_fresh_dropout_masks(dev):
