@@ -118,6 +118,8 @@ SIGNATURES = {
     'dcs_sisnr_pair_bwd': (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     'dcs_crm_fwd': (_I, [_P, _P, _P, _L, _F, _P]),
     'dcs_adam_amsgrad_step': (_I, [_P] * 6 + [_F, _F, _L, _F, _F, _F, _F, _F, _I, _P, _P, _P]),
+    'dcs_adam_amsgrad_step_sumsq': (_I, [_P] * 6 + [_I, _F, _F, _L, _F, _F, _F, _F, _F, _I, _P, _P, _P]),
+    'dcs_grad_sumsq_parts': (_I, [_P, _L, _P, _I, _P, _P, _P, _P, _I, _P]),
     'dcs_step_guard': (_I, [_P, _P, _P]),
     'dcs_stream_hold': (_I, [_P, _I, _P]),
     'dcs_kernel_timer_begin': (_I, [_I]),

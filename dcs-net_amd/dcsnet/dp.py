@@ -127,6 +127,8 @@ class FusedAdam:
         self.vmax = torch.zeros_like(bucket.flat)
         self.t = 0
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=bucket.flat.device)
+        # fp64 partial sums of g^2 (dcs_grad_sumsq_parts); made here, not in step(): a first step under capture would put it in the graph's pool
+        self._parts = torch.empty(512, dtype=torch.float64, device=bucket.flat.device) if bucket.flat.is_cuda else None
 
     def step(self, world=1, seed_state=None, counters=None):
         """One update, unless the bucket's skip flag is set (a NaN loss on some rank: the reference's trainer skips
@@ -139,13 +141,23 @@ class FusedAdam:
             raise _lib.DcsHipError('FusedAdam: expected CUDA (HIP) parameters; the HIP path has no CPU fallback')
         self.t += 1
         lib = _lib.load()
-        check(lib.dcs_step_advance_counters(ptr(b.skip), ptr(self.t_dev), ptr(seed_state), ptr(counters),
-                                            0 if counters is None else counters.numel(), cur_stream()), 'dcs_step_advance_counters')
-        norm = torch.linalg.vector_norm(b.grad).reshape(1) if self.max_norm > 0 else None
-        check(lib.dcs_adam_amsgrad_step(ptr(b.flat), ptr(b.grad), ptr(self.m), ptr(self.v), ptr(self.vmax),
-                                        ptr(norm), float(self.max_norm), 1.0 / world, b.numel, self.lr,
-                                        self.betas[0], self.betas[1], self.eps, self.wd, self.t,
-                                        ptr(self.t_dev), ptr(b.skip), cur_stream()), 'dcs_adam_amsgrad_step')
+        nc = 0 if counters is None else counters.numel()
+        if self.max_norm > 0 and b.numel >= 4:
+            # ||g||^2 as fp64 partial sums + the step's device counters in ONE launch (torch.linalg.vector_norm is a memset and
+            # a reduction, the counters were a third); every Adam workgroup adds the partials up itself
+            check(lib.dcs_grad_sumsq_parts(ptr(b.grad), b.numel, ptr(self._parts), self._parts.numel(), ptr(b.skip), ptr(self.t_dev),
+                                           ptr(seed_state), ptr(counters), nc, cur_stream()), 'dcs_grad_sumsq_parts')
+            check(lib.dcs_adam_amsgrad_step_sumsq(ptr(b.flat), ptr(b.grad), ptr(self.m), ptr(self.v), ptr(self.vmax),
+                                                  ptr(self._parts), self._parts.numel(), float(self.max_norm), 1.0 / world,
+                                                  b.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                                  ptr(self.t_dev), ptr(b.skip), cur_stream()), 'dcs_adam_amsgrad_step_sumsq')
+        else:
+            check(lib.dcs_step_advance_counters(ptr(b.skip), ptr(self.t_dev), ptr(seed_state), ptr(counters), nc, cur_stream()),
+                  'dcs_step_advance_counters')
+            check(lib.dcs_adam_amsgrad_step(ptr(b.flat), ptr(b.grad), ptr(self.m), ptr(self.v), ptr(self.vmax),
+                                            None, 0.0, 1.0 / world, b.numel, self.lr,
+                                            self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                            ptr(self.t_dev), ptr(b.skip), cur_stream()), 'dcs_adam_amsgrad_step')
         # the kernel rewrote the parameters behind torch's version counters: invalidate packed weights
         from . import functional
         functional.bump_param_generation()

@@ -660,6 +660,15 @@ int dcs_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* v
                           const float* grad_norm, float max_norm, float grad_scale, long n,
                           float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                           const int* step_dev, const float* skip, dcs_stream_t stream);
+/* The global gradient norm without ATen's two launches: dcs_grad_sumsq_parts leaves n_parts (<= 1024) fp64 partial sums of g^2
+ * (fixed order: bit-reproducible) and, in the same launch, advances the step's device counters exactly as
+ * dcs_step_advance_counters does (pass null / 0 to leave them alone); dcs_adam_amsgrad_step_sumsq is dcs_adam_amsgrad_step whose
+ * every workgroup adds those partials up itself (||g|| = sqrt(sum)) instead of reading a norm scalar.  g 16-byte aligned, n >= 4. */
+int dcs_grad_sumsq_parts(const float* g, long n, double* parts, int n_parts, const float* skip, int* step_dev, long long* seed_dev,
+                         long long* counters, int n_counters, dcs_stream_t stream);
+int dcs_adam_amsgrad_step_sumsq(float* p, const float* g, float* m, float* v, float* vmax, const double* sumsq_parts, int n_parts,
+                                float max_norm, float grad_scale, long n, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int step, const int* step_dev, const float* skip, dcs_stream_t stream);
 
 /* The NaN-loss guard of c_network.py:257-261 without a host round trip.
  * dcs_step_guard:   *skip = isnan(*loss) ? 1 : 0.  `skip` is meant to be one extra element of the flat gradient
