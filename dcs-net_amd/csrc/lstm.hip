@@ -283,9 +283,23 @@ __global__ __launch_bounds__(256) void lstm_combine_bwd_kernel(const float2* __r
 // parameter gradients of one layer from the partial products the backward left:
 //   g_whh[set][dir][j][k] += sum_c part[dir][set*CK + c][j][k]      (the K-chunked bmm outputs, fixed order)
 //   g_bih[set][q] += s, g_bhh[set][q] += s,  s = sum_n b_part[set][n][q]   (per-sequence bias sums of the BPTT kernel)
+//   g_wih[set][i] += sum_c part_ih[set * CK_ih + c][i], i < MN_ih  (the chunked A^T B outputs of dcs_atb_chunks; optional: ih_blocks > 0)
 __global__ __launch_bounds__(256) void lstm_param_grads_kernel(const float* __restrict__ part, const float* __restrict__ b_part,
                                                                 float* __restrict__ g_whh, float* __restrict__ g_bih,
-                                                                float* __restrict__ g_bhh, int CK, int seqs, int H, int w_blocks) {
+                                                                float* __restrict__ g_bhh, int CK, int seqs, int H, int w_blocks,
+                                                                const float* __restrict__ part_ih, float* __restrict__ g_wih,
+                                                                int CK_ih, long MN_ih, int ih_blocks, int ih_first) {
+    if ((int)blockIdx.x >= ih_first) {                                  // W_ih chunk sums (chunk_sum_acc_kernel's work, same order)
+        const int bx = blockIdx.x - ih_first, s_ = bx / ih_blocks;
+        const long i = (long)(bx % ih_blocks) * 256 + threadIdx.x;
+        if (i >= MN_ih) return;
+        const float* q = part_ih + (long)s_ * CK_ih * MN_ih + i;
+        float a = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < CK_ih; ++c) a += q[(long)c * MN_ih];
+        g_wih[s_ * MN_ih + i] += a;
+        return;
+    }
     const int WH = 4 * H * H, nW = 4 * WH;                             // [2 sets][2 dirs][4H][H]
     if ((int)blockIdx.x < w_blocks) {
         const int i = blockIdx.x * 256 + threadIdx.x;
@@ -449,12 +463,21 @@ extern "C" int dcs_lstm_combine_bwd(const float* g, float* g_o, long n, dcs_stre
     return DCS_OK;
 }
 
-extern "C" int dcs_lstm_param_grads(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,
-                                    int seqs_per_set, int H, dcs_stream_t stream) {
+extern "C" int dcs_lstm_param_grads_ih(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,
+                                       int seqs_per_set, int H, const float* part_ih, float* g_wih, int CK_ih, long MN_ih, int nsets,
+                                       dcs_stream_t stream) {
     if (!part || !b_part || !g_whh || !g_bih || !g_bhh || CK < 1 || seqs_per_set < 1 || H < 1) return DCS_ERR_BADARG;
+    if (part_ih && (!g_wih || CK_ih < 1 || MN_ih < 1 || nsets < 1 || nsets > 64)) return DCS_ERR_BADARG;
     const int w_blocks = (16 * H * H + 255) / 256, b_blocks = H;         // 16 H bias columns, 16 per block
-    DCS_LAUNCH(lstm_param_grads_kernel, dim3(w_blocks + b_blocks), dim3(256), 0, dcs_stream(stream), part, b_part, g_whh, g_bih,
-               g_bhh, CK, seqs_per_set, H, w_blocks);
+    const int ih_blocks = part_ih ? (int)((MN_ih + 255) / 256) : 0;
+    DCS_LAUNCH(lstm_param_grads_kernel, dim3(w_blocks + b_blocks + ih_blocks * (part_ih ? nsets : 0)), dim3(256), 0, dcs_stream(stream),
+               part, b_part, g_whh, g_bih, g_bhh, CK, seqs_per_set, H, w_blocks, part_ih, g_wih, CK_ih, MN_ih, ih_blocks > 0 ? ih_blocks : 1,
+               part_ih ? w_blocks + b_blocks : 0x7fffffff);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+extern "C" int dcs_lstm_param_grads(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,
+                                    int seqs_per_set, int H, dcs_stream_t stream) {
+    return dcs_lstm_param_grads_ih(part, b_part, g_whh, g_bih, g_bhh, CK, seqs_per_set, H, nullptr, nullptr, 0, 0, 0, stream);
 }

@@ -114,6 +114,7 @@ SIGNATURES = {
     'dcs_lstm_combine_fwd': (_I, [_P, _P, _L, _P]),
     'dcs_lstm_combine_bwd': (_I, [_P, _P, _L, _P]),
     'dcs_lstm_param_grads': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'dcs_lstm_param_grads_ih': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _L, _I, _P]),
     'dcs_sisnr_losses_guard_fwd': (_I, [_P, _P, _P, _I, _F, _P, _P]),
     'dcs_sisnr_pair_bwd': (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     'dcs_crm_fwd': (_I, [_P, _P, _P, _L, _F, _P]),

@@ -649,29 +649,27 @@ class _LstmLayerFn(torch.autograd.Function):
                 a = g_pre.as_strided((2 * CK, R, 4 * H), (R * 8 * H, 8 * H, 1), g_pre.storage_offset() + d * 4 * H)
                 h = hprev.as_strided((2 * CK, R, H), (R * 2 * H, 2 * H, 1), hprev.storage_offset() + d * H)
                 torch.bmm(a.transpose(1, 2), h, out=part[d])
-        # chunk sums of the W_hh products and the per-sequence bias sums, accumulated into the three gradient views by one
-        # launch (autograd's spelling: two reductions and three adds)
         b_part = b_part.contiguous()
-        ops.lstm_param_grads(part, b_part, st['weight_hh'][1], st['bias_ih'][1], st['bias_hh'][1], CK, B2, H)
         g_wih = st['weight_ih'][1]
         sink_hits += 16
-        # W_ih gradient g_gx[s]^T inp over the (n t) rows: chunked A^T B on the MFMA pipe (rocBLAS: 25 us per 512 x 2048 x 256)
+        # W_ih gradient g_gx[s]^T inp over the (n t) rows: chunked A^T B on the MFMA pipe (rocBLAS: 25 us per 512 x 2048 x 256);
+        # its chunk sum rides the launch that sums the W_hh products and the per-sequence bias sums into their gradient views
+        # (autograd's spelling: two reductions and three adds — and one more reduction here)
+        ih = None
         if planes:                                                      # inp = the complex latent as float [B, S, in, 2] (checked by the caller)
-            ops.atb_chunks_acc_planes(g_gx, inp, g_wih, 2, 8 * H, 8 * H, inp.shape[-2], planes, 8)
-            return
-        n_in = inp.shape[-1]
-        mfma_ok = g_wih.is_contiguous() and n_in % 64 == 0 and (8 * H) % 32 == 0 and NT % (8 * CK) == 0 and inp.is_contiguous()
-        if inp.dim() == 2:                                              # shared first-layer input: per-set GEMMs, no expand
-            if mfma_ok:
-                ops.atb_chunks_acc(g_gx, inp, g_wih, 2, 8 * H, n_in, 8 * H, n_in, NT, CK, b_shared=True)
-            else:
+            ih = ops.atb_chunks_acc_planes(g_gx, inp, g_wih, 2, 8 * H, 8 * H, inp.shape[-2], planes, 8, reduce=False)
+        else:
+            n_in = inp.shape[-1]
+            if (g_wih.is_contiguous() and n_in % 64 == 0 and (8 * H) % 32 == 0 and NT % (8 * CK) == 0 and inp.is_contiguous()):
+                ih = ops.atb_chunks_acc(g_gx, inp, g_wih, 2, 8 * H, n_in, 8 * H, n_in, NT, CK, b_shared=inp.dim() == 2, reduce=False)
+        ops.lstm_param_grads(part, b_part, st['weight_hh'][1], st['bias_ih'][1], st['bias_hh'][1], CK, B2, H,
+                             ih=None if ih is None else (ih[0], ih[1], g_wih))
+        if ih is None:                                                  # shapes the MFMA kernel does not take
+            if inp.dim() == 2:
                 for s_ in range(2):
                     g_wih[s_].addmm_(g_gx[s_].t(), inp)
-            return
-        if mfma_ok:
-            ops.atb_chunks_acc(g_gx, inp, g_wih, 2, 8 * H, n_in, 8 * H, n_in, NT, CK)
-        else:
-            torch.baddbmm(g_wih, g_gx.transpose(1, 2), inp, out=g_wih)  # accumulate in place
+            else:
+                torch.baddbmm(g_wih, g_gx.transpose(1, 2), inp, out=g_wih)  # accumulate in place
 
 
 class _LstmCombineFn(torch.autograd.Function):

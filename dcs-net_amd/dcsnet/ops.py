@@ -1036,15 +1036,18 @@ def lstm_whh_grad(g_pre, h_prev, NT, CK, H):
     return part
 
 
-def atb_chunks_acc(A, B, out, nsets, lda, ldb, M, N, NT, CK, b_shared=False):
+def atb_chunks_acc(A, B, out, nsets, lda, ldb, M, N, NT, CK, b_shared=False, reduce=True):
     """out[s] (float [M, N], contiguous per set) += A[s]^T B[s] over the NT rows (A: [nsets, NT, lda-pitched M columns],
-    B: [nsets or 1, NT, N]) as CK row chunks on the MFMA pipe + one fixed-order chunk sum."""
+    B: [nsets or 1, NT, N]) as CK row chunks on the MFMA pipe + one fixed-order chunk sum.  reduce=False: the products only;
+    returns (part [nsets * CK, M, N], CK) for a later sum (lstm_param_grads(..., ih=...))."""
     for n, t in (('A', A), ('B', B), ('out', out)):
         _chk(t, n)
     lib = _lib.load()
     part = torch.empty((nsets * CK, M, N), dtype=torch.float32, device=A.device)
     check(lib.dcs_atb_chunks(ptr(A), ptr(B), ptr(part), NT * lda, 0, 0 if b_shared else NT * ldb, 0, nsets, 1, lda, ldb, M, N,
                              NT // CK, CK, cur_stream()), 'dcs_atb_chunks')
+    if not reduce:
+        return part, CK
     check(lib.dcs_chunk_sum_acc(ptr(part), ptr(out), M * N, 0, nsets, 1, CK, M * N, cur_stream()), 'dcs_chunk_sum_acc')
 
 
@@ -1071,7 +1074,7 @@ def gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, b_transposed, nseg=1, a_seg=0, b_s
     return C
 
 
-def atb_chunks_acc_planes(A, zr, out, nsets, lda, M, N, R0, CK):
+def atb_chunks_acc_planes(A, zr, out, nsets, lda, M, N, R0, CK, reduce=True):
     """atb_chunks_acc whose shared B is the {re rows | im rows} stacking of a complex-interleaved zr float[R0, N, 2], read in
     place: out[s] += A[s]^T [zr.re ; zr.im], A: [nsets, 2 * R0, lda-pitched M columns]; CK chunks per part."""
     for n, t in (('A', A), ('zr', zr), ('out', out)):
@@ -1081,15 +1084,26 @@ def atb_chunks_acc_planes(A, zr, out, nsets, lda, M, N, R0, CK):
     # batches: lo = part (real / imaginary rows), hi = set -> part index (set * 2 + part) * CK + c: 2 CK chunks per set
     check(lib.dcs_atb_chunks_strided(ptr(A), ptr(zr), ptr(part), R0 * lda, 2 * R0 * lda, 1, 0, 2, nsets, lda, 2 * N, 2, M, N,
                                      R0 // CK, CK, cur_stream()), 'dcs_atb_chunks_strided')
+    if not reduce:
+        return part, 2 * CK
     check(lib.dcs_chunk_sum_acc(ptr(part), ptr(out), M * N, 0, nsets, 1, 2 * CK, M * N, cur_stream()), 'dcs_chunk_sum_acc')
 
 
-def lstm_param_grads(part, b_part, g_whh, g_bih, g_bhh, CK, seqs, H):
-    """Accumulate one layer's recurrent-weight and bias gradients from the backward's partial products (in place)."""
+def lstm_param_grads(part, b_part, g_whh, g_bih, g_bhh, CK, seqs, H, ih=None):
+    """Accumulate one layer's recurrent-weight and bias gradients from the backward's partial products (in place).
+    ih = (part_ih, CK_ih, g_wih [nsets, M, N]): the input-projection weight gradient's chunk sum in the same launch."""
     for n, t in (('part', part), ('b_part', b_part), ('g_whh', g_whh), ('g_bih', g_bih), ('g_bhh', g_bhh)):
         _chk(t, n)
-    check(_lib.load().dcs_lstm_param_grads(ptr(part), ptr(b_part), ptr(g_whh), ptr(g_bih), ptr(g_bhh), CK, seqs, H,
-                                           cur_stream()), 'dcs_lstm_param_grads')
+    if ih is None:
+        check(_lib.load().dcs_lstm_param_grads(ptr(part), ptr(b_part), ptr(g_whh), ptr(g_bih), ptr(g_bhh), CK, seqs, H,
+                                               cur_stream()), 'dcs_lstm_param_grads')
+        return
+    part_ih, ck_ih, g_wih = ih
+    _chk(part_ih, 'part_ih')
+    _chk(g_wih, 'g_wih', 3)
+    check(_lib.load().dcs_lstm_param_grads_ih(ptr(part), ptr(b_part), ptr(g_whh), ptr(g_bih), ptr(g_bhh), CK, seqs, H, ptr(part_ih),
+                                              ptr(g_wih), ck_ih, g_wih.shape[1] * g_wih.shape[2], g_wih.shape[0], cur_stream()),
+          'dcs_lstm_param_grads_ih')
 
 
 def sisnr_losses_guard(snr_speech, snr_noise, alpha, skip):

@@ -498,6 +498,12 @@ int dcs_lstm_combine_fwd(const float* o, float* out, long n, dcs_stream_t stream
 int dcs_lstm_combine_bwd(const float* g, float* g_o, long n, dcs_stream_t stream);
 int dcs_lstm_param_grads(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,
                          int seqs_per_set, int H, dcs_stream_t stream);
+/* dcs_lstm_param_grads that also sums the chunked input-projection weight gradient (dcs_atb_chunks / _strided outputs):
+ * g_wih float[nsets][MN_ih] += sum over c < CK_ih of part_ih[(set * CK_ih + c)][MN_ih] — dcs_chunk_sum_acc's work in the same
+ * launch (part_ih null: exactly dcs_lstm_param_grads). */
+int dcs_lstm_param_grads_ih(const float* part, const float* b_part, float* g_whh, float* g_bih, float* g_bhh, int CK,
+                            int seqs_per_set, int H, const float* part_ih, float* g_wih, int CK_ih, long MN_ih, int nsets,
+                            dcs_stream_t stream);
 
 /* Stand-alone inverted dropout on a real view (c_network.py:203-204 dropout_fc after the
  * ComplexLinear; c_network.py:221-222 on the last decoder stage, which has no attention to

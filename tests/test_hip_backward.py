@@ -652,6 +652,18 @@ def test_lstm_glue_kernels(dev):
         out = out0.clone().to(dev)
         ops.atb_chunks_acc(g_pre.to(dev), inp.to(dev), out, 2, 8 * H, n_in, 8 * H, n_in, NT, CK, b_shared=shared)
         close(out, want_w, rel=2e-5, what=f'atb_chunks_acc in={n_in}')
+    # the same chunk sum riding dcs_lstm_param_grads' launch (dcs_lstm_param_grads_ih)
+    inp = torch.randn(2, NT, 128, generator=g)
+    out0 = torch.randn(2, 8 * H, 128, generator=g)
+    want_w = out0 + torch.stack([g_pre[s_].t() @ inp[s_] for s_ in range(2)])
+    out = out0.clone().to(dev)
+    part_ih, ck_ih = ops.atb_chunks_acc(g_pre.to(dev), inp.to(dev), out, 2, 8 * H, 128, 8 * H, 128, NT, CK, reduce=False)
+    d = [t.clone().to(dev) for t in (g_whh, g_bih, g_bhh)]
+    ops.lstm_param_grads(part.to(dev), b_part.to(dev), d[0], d[1], d[2], CK, seqs, H, ih=(part_ih, ck_ih, out))
+    close(out, want_w, rel=2e-5, what='g_wih through lstm_param_grads')
+    close(d[0], w_whh, rel=1e-5, what='g_whh (with ih)')
+    close(d[1], g_bih + w_b, rel=1e-5, what='g_bih (with ih)')
+    close(d[2], g_bhh + w_b, rel=1e-5, what='g_bhh (with ih)')
     # the shared input as the {re rows | im rows} stacking of a complex-interleaved [R0, in, 2], read in place
     R0, n_in = NT // 2, 128
     zr = torch.randn(R0, n_in, 2, generator=g)
