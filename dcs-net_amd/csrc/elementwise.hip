@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void tapsum_bwd_kernel(const float2* __re
 // cotangent of the fp32 mask, stays fp32).
 template <typename OT>
 __global__ __launch_bounds__(kThreads) void tapsum_bwd_3x3_up2_kernel(const float2* __restrict__ gy, OT* __restrict__ gz,
-                                                                       int B, int Hs, int Ws, int CT) {
+                                                                       int B, int Hs, int Ws, int CT, double* __restrict__ part) {
     const long npx = (long)B * Hs * Ws;
     const long i0 = (long)blockIdx.x * kThreads + threadIdx.x;
     const long i = i0 < npx ? i0 : npx - 1;                           // (threads past the end shadow the last pixel: barrier below)
@@ -194,6 +194,21 @@ __global__ __launch_bounds__(kThreads) void tapsum_bwd_3x3_up2_kernel(const floa
             const float2 v = gb[(long)oyc * Wo + oxc];
             const bool in = oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
             g[r][c] = in ? v : make_float2(0.f, 0.f);
+        }
+    }
+    if (part != nullptr) {
+        // the bias gradient of the layer is the complex sum of g_y: every output pixel is one of the centre four of exactly one
+        // thread's window, so the sum falls out of the values already loaded (csum_partial_kernel re-read all of g_y for it)
+        __shared__ double red[kThreads / 64][2];
+        const bool own = i0 < npx;
+        double sr = own ? (double)((g[1][1].x + g[1][2].x) + (g[2][1].x + g[2][2].x)) : 0.0;
+        double si = own ? (double)((g[1][1].y + g[1][2].y) + (g[2][1].y + g[2][2].y)) : 0.0;
+        sr = dcs_wave_sum_d(sr); si = dcs_wave_sum_d(si);
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sr; red[threadIdx.x >> 6][1] = si; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kThreads / 64; ++w) { sr += red[w][0]; si += red[w][1]; }
+            part[2 * blockIdx.x] = sr; part[2 * blockIdx.x + 1] = si;
         }
     }
     float2 acc[9];
@@ -256,12 +271,18 @@ __global__ __launch_bounds__(kThreads) void csum_partial_kernel(const float2* __
         part[2 * blockIdx.x] = sr; part[2 * blockIdx.x + 1] = si;
     }
 }
-__global__ __launch_bounds__(64) void csum_bias_final_kernel(const double* __restrict__ part, int nparts, float* __restrict__ gb_r,
-                                                             float* __restrict__ gb_i) {
+__global__ __launch_bounds__(kThreads) void csum_bias_final_kernel(const double* __restrict__ part, int nparts, float* __restrict__ gb_r,
+                                                                   float* __restrict__ gb_i) {
+    __shared__ double red[kThreads / 64][2];
     double sr = 0, si = 0;
-    for (int i = threadIdx.x; i < nparts; i += 64) { sr += part[2 * i]; si += part[2 * i + 1]; }
+    for (int i = threadIdx.x; i < nparts; i += kThreads) { sr += part[2 * i]; si += part[2 * i + 1]; }
     sr = dcs_wave_sum_d(sr); si = dcs_wave_sum_d(si);
-    if (threadIdx.x == 0) { gb_r[0] = (float)(sr + si); gb_i[0] = (float)(si - sr); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sr; red[threadIdx.x >> 6][1] = si; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) { sr += red[w][0]; si += red[w][1]; }
+        gb_r[0] = (float)(sr + si); gb_i[0] = (float)(si - sr);
+    }
 }
 }  // namespace
 
@@ -291,7 +312,8 @@ extern "C" int dcs_tapsum_fwd(const float* z, float* y, const float* b_r, const 
     return DCS_OK;
 }
 
-extern "C" long dcs_tapsum_bwd_workspace_bytes(void) { return (long)kSumBlocks * 2 * (long)sizeof(double); }
+constexpr long kTapSumMaxBlocks = 65536;      // partial sums the fused form may leave (one per workgroup of tapsum_bwd_3x3_up2_kernel)
+extern "C" long dcs_tapsum_bwd_workspace_bytes(void) { return kTapSumMaxBlocks * 2 * (long)sizeof(double); }
 
 static int tapsum_bwd_impl(const float* gy, void* gz, bool gz_bf16, float* gb_r, float* gb_i, void* workspace,
                            long workspace_bytes, int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t, int pad_f,
@@ -299,24 +321,32 @@ static int tapsum_bwd_impl(const float* gy, void* gz, bool gz_bf16, float* gb_r,
     if (!gy || !gz || B <= 0 || Hs <= 0 || Ws <= 0 || kh < 1 || kw < 1 || CT < kh * kw || up_f < 1 || up_t < 1 ||
         pad_f < 0 || pad_t < 0 || ((gb_r == nullptr) != (gb_i == nullptr)))
         return DCS_ERR_BADARG;
-    if (gb_r) {                                              // bias gradients of the Cout = 1 layer: complex sum of gy
-        if (!workspace || workspace_bytes < dcs_tapsum_bwd_workspace_bytes()) return DCS_ERR_WORKSPACE;
+    if (gb_r && (!workspace || workspace_bytes < dcs_tapsum_bwd_workspace_bytes())) return DCS_ERR_WORKSPACE;
+    const bool fast = kh == 3 && kw == 3 && up_f == 2 && up_t == 2 && pad_f == 1 && pad_t == 1 && (long)B * Hs * Ws < (1L << 31) * kThreads;
+    const long fast_blocks = ((long)B * Hs * Ws + kThreads - 1) / kThreads;
+    // bias gradients of the Cout = 1 layer = the complex sum of gy: partial sums out of the 3x3 / 2x2 kernel's own loads where
+    // that kernel runs (one pass over g_y less), from csum_partial_kernel otherwise; one small launch adds them up
+    const bool fused_sum = gb_r && fast && fast_blocks <= kTapSumMaxBlocks;
+    if (gb_r && !fused_sum) {
         const long ny = (long)B * Hs * up_f * Ws * up_t;
         DCS_LAUNCH(csum_partial_kernel, dim3(kSumBlocks), dim3(kThreads), 0, dcs_stream(stream), (const float2*)gy, ny,
                            (double*)workspace);
-        DCS_LAUNCH(csum_bias_final_kernel, dim3(1), dim3(64), 0, dcs_stream(stream), (const double*)workspace,
+        DCS_LAUNCH(csum_bias_final_kernel, dim3(1), dim3(kThreads), 0, dcs_stream(stream), (const double*)workspace,
                            kSumBlocks, gb_r, gb_i);
         DCS_CHECK_LAUNCH();
     }
     const long n = (long)B * Hs * Ws * CT;
-    if (kh == 3 && kw == 3 && up_f == 2 && up_t == 2 && pad_f == 1 && pad_t == 1 && (long)B * Hs * Ws < (1L << 31) * kThreads) {
-        const long npx = (long)B * Hs * Ws;
+    if (fast) {
+        double* part = fused_sum ? (double*)workspace : nullptr;
         if (gz_bf16)
-            DCS_LAUNCH(tapsum_bwd_3x3_up2_kernel<unsigned short>, dim3((unsigned)((npx + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       dcs_stream(stream), (const float2*)gy, (unsigned short*)gz, B, Hs, Ws, CT);
+            DCS_LAUNCH(tapsum_bwd_3x3_up2_kernel<unsigned short>, dim3((unsigned)fast_blocks), dim3(kThreads), 0,
+                       dcs_stream(stream), (const float2*)gy, (unsigned short*)gz, B, Hs, Ws, CT, part);
         else
-            DCS_LAUNCH(tapsum_bwd_3x3_up2_kernel<float>, dim3((unsigned)((npx + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       dcs_stream(stream), (const float2*)gy, (float*)gz, B, Hs, Ws, CT);
+            DCS_LAUNCH(tapsum_bwd_3x3_up2_kernel<float>, dim3((unsigned)fast_blocks), dim3(kThreads), 0,
+                       dcs_stream(stream), (const float2*)gy, (float*)gz, B, Hs, Ws, CT, part);
+        if (fused_sum)
+            DCS_LAUNCH(csum_bias_final_kernel, dim3(1), dim3(kThreads), 0, dcs_stream(stream), (const double*)workspace,
+                       (int)fast_blocks, gb_r, gb_i);
         DCS_CHECK_LAUNCH();
         return DCS_OK;
     }
