@@ -126,6 +126,16 @@ __global__ __launch_bounds__(256) void cbn_finalize_kernel(const PV* __restrict_
                                     long P, int C, float eps, float momentum, int use_batch_stats) {
     __shared__ double wsum[4][5];
     const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // the channel's pivot, running statistics and affine parameters are requested FIRST (uniform addresses): behind the slab sums,
+    // the barrier and the `t != 0` exit they were two more dependent round trips of a kernel that is nothing but round trips
+    const bool run = momentum >= 0.f && running_mean != nullptr;
+    float pv_[2] = {0.f, 0.f}, rm_[2] = {0.f, 0.f}, rc_[3] = {0.f, 0.f, 0.f}, w_[3] = {1.f, 1.f, 0.f}, b_[2] = {0.f, 0.f};
+    if (use_batch_stats) { pv_[0] = dcs_ld1(pivot + 2 * c); pv_[1] = dcs_ld1(pivot + 2 * c + 1); }
+    if (run || !use_batch_stats) {
+        rm_[0] = running_mean[2 * c]; rm_[1] = running_mean[2 * c + 1];
+        rc_[0] = running_covar[3 * c]; rc_[1] = running_covar[3 * c + 1]; rc_[2] = running_covar[3 * c + 2];
+    }
+    if (weight != nullptr) { w_[0] = weight[3 * c]; w_[1] = weight[3 * c + 1]; w_[2] = weight[3 * c + 2]; b_[0] = bias[2 * c]; b_[1] = bias[2 * c + 1]; }
     float mr, mi, Crr, Cii, Cri;
     if (use_batch_stats) {
         double S[5] = {0, 0, 0, 0, 0};
@@ -155,40 +165,36 @@ __global__ __launch_bounds__(256) void cbn_finalize_kernel(const PV* __restrict_
 #pragma unroll
         for (int i = 0; i < 5; ++i) S[i] = wsum[0][i] + wsum[1][i] + wsum[2][i] + wsum[3][i];
         const double n = (double)P;
-        const double kr = use_batch_stats ? (double)dcs_ld1(pivot + 2 * c) : 0.0, ki = use_batch_stats ? (double)dcs_ld1(pivot + 2 * c + 1) : 0.0;
+        const double kr = (double)pv_[0], ki = (double)pv_[1];
         const double dr = S[0] / n, di = S[1] / n;
         mr = (float)(kr + dr);
         mi = (float)(ki + di);
         Crr = (float)(S[2] / n - dr * dr) + eps;
         Cii = (float)(S[3] / n - di * di) + eps;
         Cri = (float)(S[4] / n - dr * di);
-        if (momentum >= 0.f && running_mean != nullptr) {
+        if (run) {
             const float f = momentum;
             const float unb = P > 1 ? (float)(n / (n - 1.0)) : 1.f;
-            running_mean[2 * c] = f * mr + (1.f - f) * running_mean[2 * c];
-            running_mean[2 * c + 1] = f * mi + (1.f - f) * running_mean[2 * c + 1];
-            running_covar[3 * c + 0] = f * Crr * unb + (1.f - f) * running_covar[3 * c + 0];
-            running_covar[3 * c + 1] = f * Cii * unb + (1.f - f) * running_covar[3 * c + 1];
-            running_covar[3 * c + 2] = f * Cri * unb + (1.f - f) * running_covar[3 * c + 2];
+            running_mean[2 * c] = f * mr + (1.f - f) * rm_[0];
+            running_mean[2 * c + 1] = f * mi + (1.f - f) * rm_[1];
+            running_covar[3 * c + 0] = f * Crr * unb + (1.f - f) * rc_[0];
+            running_covar[3 * c + 1] = f * Cii * unb + (1.f - f) * rc_[1];
+            running_covar[3 * c + 2] = f * Cri * unb + (1.f - f) * rc_[2];
         }
     } else {
         if (t != 0) return;
-        mr = running_mean[2 * c];
-        mi = running_mean[2 * c + 1];
-        Crr = running_covar[3 * c + 0] + eps;
-        Cii = running_covar[3 * c + 1] + eps;
-        Cri = running_covar[3 * c + 2];
+        mr = rm_[0];
+        mi = rm_[1];
+        Crr = rc_[0] + eps;
+        Cii = rc_[1] + eps;
+        Cri = rc_[2];
     }
     const float det = Crr * Cii - Cri * Cri;
     const float s = sqrtf(det);
     const float tt = sqrtf(Cii + Crr + 2.f * s);
     const float ist = 1.0f / (s * tt);
     const float Rrr = (Cii + s) * ist, Rii = (Crr + s) * ist, Rri = -Cri * ist;
-    float W0 = 1.f, W1 = 1.f, W2 = 0.f, b0 = 0.f, b1 = 0.f;
-    if (weight != nullptr) {
-        W0 = weight[3 * c]; W1 = weight[3 * c + 1]; W2 = weight[3 * c + 2];
-        b0 = bias[2 * c]; b1 = bias[2 * c + 1];
-    }
+    const float W0 = w_[0], W1 = w_[1], W2 = w_[2], b0 = b_[0], b1 = b_[1];
     const float a0 = W0 * Rrr + W2 * Rri, a1 = W0 * Rri + W2 * Rii;
     const float a2 = W2 * Rrr + W1 * Rri, a3 = W2 * Rri + W1 * Rii;
     float* st = stats_out + 8 * c;

@@ -167,6 +167,14 @@ __global__ void cbn_bwd_finalize_kernel(const double* __restrict__ part, int nbl
     DCS_PRIO_CRITICAL();
     // one wavefront per channel: lanes stride over the partial slabs, fp64 butterfly, lane 0 finishes
     const int c = blockIdx.x, lane = threadIdx.x;
+    // the channel's statistics, coefficients and weights are requested FIRST (every lane, uniform addresses): behind the slab
+    // sums and the `lane != 0` exit they were a second dependent round trip of a kernel that is nothing but round trips
+    const float* st = stats + 8 * c;
+    const float st_[8] = {st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]};
+    const float* co = coef + 6 * c;
+    const float co_[4] = {co[0], co[1], co[2], co[3]};
+    float w_[3] = {1.f, 1.f, 0.f};
+    if (weight) { w_[0] = weight[3 * c]; w_[1] = weight[3 * c + 1]; w_[2] = weight[3 * c + 2]; }
     // (all of a lane's slab loads in flight at once: see cbn_finalize_kernel)
     double S[6] = {0, 0, 0, 0, 0, 0};
     for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
@@ -186,10 +194,8 @@ __global__ void cbn_bwd_finalize_kernel(const double* __restrict__ part, int nbl
     for (int i = 0; i < 6; ++i) S[i] = dcs_wave_sum_d(S[i]);
     if (lane != 0) return;
     const double sgr = S[0], sgi = S[1], N00 = S[2], N01 = S[3], N10 = S[4], N11 = S[5];
-    const float* st = stats + 8 * c;
-    const double mr = st[0], mi = st[1], Rrr = st[2], Rii = st[3], Rri = st[4], Crr = st[5], Cii = st[6], Cri = st[7];
-    double W0 = 1, W1 = 1, W2 = 0;
-    if (weight) { W0 = weight[3 * c]; W1 = weight[3 * c + 1]; W2 = weight[3 * c + 2]; }
+    const double mr = st_[0], mi = st_[1], Rrr = st_[2], Rii = st_[3], Rri = st_[4], Crr = st_[5], Cii = st_[6], Cri = st_[7];
+    const double W0 = w_[0], W1 = w_[1], W2 = w_[2];
     if (g_weight) {
         g_weight[3 * c + 0] = (float)(Rrr * N00 + Rri * N01);
         g_weight[3 * c + 1] = (float)(Rri * N10 + Rii * N11);
@@ -197,8 +203,7 @@ __global__ void cbn_bwd_finalize_kernel(const double* __restrict__ part, int nbl
         g_bias[2 * c + 0] = (float)sgr;
         g_bias[2 * c + 1] = (float)sgi;
     }
-    const float* co = coef + 6 * c;
-    const double a0 = co[0], a1 = co[1], a2 = co[2], a3 = co[3];
+    const double a0 = co_[0], a1 = co_[1], a2 = co_[2], a3 = co_[3];
     double d0 = 0, d1 = 0, d3 = 0, f0 = 0, f1 = 0;
     if (use_batch_stats) {
         const double n = (double)P;
