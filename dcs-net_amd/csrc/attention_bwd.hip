@@ -397,9 +397,11 @@ extern "C" int DCS_SYM(dcs_attention_bwd_x)(const act_t* x, const act_t* g_out, 
                                    int C, int Ch, float drop_p, unsigned long long seed,
                                    const unsigned long long* seed_dev, dcs_stream_t stream) {
     int G;
-    if (!x || !g_out || !ca || !sa || !g_sp || !pooled || !hidden || !w1 || !w2 || !g_x || !g_fc0_r || !g_fc0_i ||
-        !g_fc2_r || !g_fc2_i || !workspace)
-        return DCS_ERR_BADARG;
+    // all four FC destinations null (only with g_pooled): the FC weight gradient is left to dcs_attention_bwd_fc_weights, which
+    // reads the per-sample cotangents this call leaves in `workspace`
+    const bool defer_fc = g_pooled && !g_fc0_r && !g_fc0_i && !g_fc2_r && !g_fc2_i;
+    if (!x || !g_out || !ca || !sa || !g_sp || !pooled || !hidden || !w1 || !w2 || !g_x || !workspace) return DCS_ERR_BADARG;
+    if (!defer_fc && (!g_fc0_r || !g_fc0_i || !g_fc2_r || !g_fc2_i)) return DCS_ERR_BADARG;
     if (B <= 0 || B > 65535 || HW <= 0 || Ch <= 0 || Ch > 64 || C > 128 || !att_geom(C, &G)) return DCS_ERR_BADARG;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
     const int nch = chunks_for(HW, G);
@@ -422,6 +424,7 @@ extern "C" int DCS_SYM(dcs_attention_bwd_x)(const act_t* x, const act_t* g_out, 
                     gpooled, C, Ch};
     DCS_LAUNCH(ca_bwd_sample_kernel, dim3(B), dim3(kThreads), 0, s, cp);
     DCS_CHECK_LAUNCH();
+    if (defer_fc) return DCS_OK;
     CaWeightArgs cw;
     cw.go = go; cw.gh = gh; cw.pooled = (const float2*)pooled; cw.hidden = (const float2*)hidden;
     cw.g_fc0_r = g_fc0_r; cw.g_fc0_i = g_fc0_i; cw.g_fc2_r = g_fc2_r; cw.g_fc2_i = g_fc2_i;
@@ -433,6 +436,30 @@ extern "C" int DCS_SYM(dcs_attention_bwd_x)(const act_t* x, const act_t* g_out, 
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
+
+// The FC weight gradients of a block whose dcs_attention_bwd_x call deferred them (null destinations): the launch nothing downstream
+// waits for, so a two-stream step can queue it beside the data-gradient chain.  `workspace`: the SAME buffer that call was given.
+#ifndef DCS_ACT_BF16
+extern "C" int dcs_attention_bwd_fc_weights(const void* workspace, long workspace_bytes, const float* pooled, const float* hidden,
+                                            float* g_fc0_r, float* g_fc0_i, float* g_fc2_r, float* g_fc2_i, int B, long HW, int C,
+                                            int Ch, dcs_stream_t stream) {
+    int G;
+    if (!workspace || !pooled || !hidden || !g_fc0_r || !g_fc0_i || !g_fc2_r || !g_fc2_i) return DCS_ERR_BADARG;
+    if (B <= 0 || B > 65535 || HW <= 0 || Ch <= 0 || Ch > 64 || C > 128 || !att_geom(C, &G)) return DCS_ERR_BADARG;
+    const long part_bytes = (long)B * chunks_for(HW, G) * C * 2 * (long)sizeof(double);
+    if (workspace_bytes < part_bytes + (2L * B * C + (long)B * Ch) * 8 + 64) return DCS_ERR_WORKSPACE;
+    const float2* go = (const float2*)((const char*)workspace + part_bytes);
+    CaWeightArgs cw;
+    cw.go = go; cw.gh = go + (long)B * C; cw.pooled = (const float2*)pooled; cw.hidden = (const float2*)hidden;
+    cw.g_fc0_r = g_fc0_r; cw.g_fc0_i = g_fc0_i; cw.g_fc2_r = g_fc2_r; cw.g_fc2_i = g_fc2_i;
+    cw.B = B; cw.C = C; cw.Ch = Ch;
+    const int nxw = (C * Ch * kWLanes + kThreads - 1) / kThreads;
+    const PoolP pp{nullptr, nullptr, HW, G, 1.f / (float)HW, 0, nxw, cw};
+    DCS_LAUNCH(att_bwd_pool_kernel, dim3(nxw, 1), dim3(kThreads), 0, dcs_stream(stream), pp);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+#endif
 
 // ---- several attention blocks in one set of launches (backward; see dcs_attention_fwd_batched) ----------------
 static long bwd_item_bytes(const dcs_attention_item& it, int B, int G) {

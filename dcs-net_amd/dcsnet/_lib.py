@@ -75,6 +75,7 @@ SIGNATURES = {
     'dcs_attention_bwd_sa': (_I, [_P] * 5 + [_I, _L, _I, _F, _U64, _P, _P]),
     'dcs_attention_bwd_workspace_bytes': (_L, [_I, _L, _I, _I]),
     'dcs_attention_bwd_x': (_I, [_P] * 16 + [_L, _I, _L, _I, _I, _F, _U64, _P, _P]),
+    'dcs_attention_bwd_fc_weights': (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _P]),
     'dcs_attention_fwd_batched_workspace_bytes': (_L, [_I, _P, _I]),
     'dcs_attention_fwd_batched': (_I, [_I, _P, _P, _L, _I, _P]),
     'dcs_attention_bwd_batched_workspace_bytes': (_L, [_I, _P, _I]),

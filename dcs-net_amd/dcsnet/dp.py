@@ -277,6 +277,7 @@ class TrainStep:
             if side is None or side.device != loss.device:
                 side = self.__dict__['_wgrad_side'] = torch.cuda.Stream(device=loss.device)
         ops.wgrad_defer_begin()
+        del functional.PENDING_SIDE[:]
         functional.WGRAD_SIDE = side
         functional.FLUSH_AT_NEXT_FORK = False
         try:
@@ -286,6 +287,13 @@ class TrainStep:
                 loss.backward(gradient=one)
         finally:
             functional.WGRAD_SIDE = None
+            if functional.PENDING_SIDE:                            # (queued after the last fork: none in the networks of this repo)
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        functional._run_pending_side()
+                else:
+                    functional._run_pending_side()
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)      # the one join: every weight-gradient kernel is in
             ops.wgrad_defer_flush()

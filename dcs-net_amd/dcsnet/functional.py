@@ -4,6 +4,7 @@ Everything here takes / returns channels-last float32 views ``[B,H,W,C,2]`` unle
 "complex" in its name.  Packed weights are cached per parameter version, so inference packs
 once and training re-packs after each optimizer step.
 """
+import os
 import weakref
 
 import torch
@@ -114,6 +115,20 @@ def _sink(p):
     return s
 
 
+DEFER_FC = os.environ.get('DCS_DEFER_FC', '1') != '0'      # 0: the attention blocks' FC weight gradients stay on the main chain (A/B)
+PENDING_SIDE = []          # launches nothing downstream waits for, queued by backward nodes for the next fork of the side stream
+
+
+def _run_pending_side():
+    """Issue the queued launches on the CURRENT stream (the side stream right after a fork, or — dp.TrainStep._backward — whatever
+    is left before the join); their operands stay alive until the join (ops.WGRAD_DEFER)."""
+    while PENDING_SIDE:
+        job = PENDING_SIDE.pop(0)
+        ops.attention_bwd_fc_weights(job)
+        if ops.WGRAD_DEFER is not None:
+            ops.WGRAD_DEFER.append(job)
+
+
 class _CConv2dFn(torch.autograd.Function):
     """dcs_cconv2d_fwd with its hand-written data / weight gradients."""
 
@@ -160,6 +175,7 @@ class _CConv2dFn(torch.autograd.Function):
         if want_w:
             if side is not None:
                 with torch.cuda.stream(side):
+                    _run_pending_side()
                     g = ops.cconv2d_bwd_weight(x1, x2, gy, w_shape, has_bias, ksize, stride, pad, up, transposed, ctx.sinks,
                                                immediate=True)
                     global FLUSH_AT_NEXT_FORK
@@ -352,8 +368,13 @@ class _CbnAttentionFn(torch.autograd.Function):
         x, weight, stats, coef, a, ca, sa, sp, pooled, hidden, w1, w2, wsa = ctx.saved_tensors
         use_batch, act, affine, ksize, drop_p, seed = ctx.cfg
         sk = ctx.sinks
+        # inside TrainStep's two-stream backward the block's FC weight gradients (a launch nothing downstream waits for) are
+        # queued for the side stream: they ride the next conv layer's fork (_run_pending_side)
+        defer = DEFER_FC and WGRAD_SIDE is not None and ops.WGRAD_DEFER is not None and all(s_ is not None for s_ in sk[2:6])
         g = ops.attention_bwd(a, g_out.contiguous(), ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p, seed, sk[2:],
-                              split_pool=True)
+                              split_pool=True, defer_fc=defer)
+        if defer:
+            PENDING_SIDE.append(g[8])
         g_x, g_w, g_b = ops.cbn_bwd(x, g[0], weight, stats, coef, use_batch, act, 0.0, 0, affine, sk[:2], g_add=g[7])
         full = (g_w, g_b, *g[1:7])
         gp = tuple(None if s_ is not None else t for t, s_ in zip(full, sk))

@@ -618,11 +618,12 @@ def attention_apply(x, ca=None, sa=None, drop_p=0.0, seed=0, out=None):
 
 
 def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop_p=0.0, seed=0, outs=None,
-                  split_pool=False):
+                  split_pool=False, defer_fc=False):
     """Backward of the fused attention block.  Returns (g_x, g_fc0_r, g_fc0_i, g_fc2_r, g_fc2_i,
     g_conv1_r, g_conv1_i) with the weight gradients in the reference's parameter layout.  split_pool: g_x lacks the
     average pool's broadcast term and an 8th result g_pooled [B,C,2] is returned for the consumer to add
-    (cbn_bwd(g_add=...))."""
+    (cbn_bwd(g_add=...)).  defer_fc (with split_pool): the FC weight-gradient launch is left out; a 9th result is the job
+    attention_bwd_fc_weights() runs later (it owns the workspace the per-sample cotangents live in)."""
     _chk(x, 'x', 5, act=True)
     _chk(g_out, 'g_out', 5, act=True)
     B, H, W, C, _ = x.shape
@@ -647,15 +648,27 @@ def attention_bwd(x, g_out, ca, sa, sp, pooled, hidden, w1, w2, wsa, ksize, drop
     nbytes = lib.dcs_attention_bwd_workspace_bytes(B, HW, C, Ch)
     if nbytes < 0:
         raise _lib.DcsHipError(f'attention_bwd: unsupported channel count C={C}')
-    ws = _workspace(nbytes, dev)
+    defer_fc = bool(defer_fc and split_pool)
+    # (deferred: a buffer of its own — the cached workspace is the next block's as well)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if defer_fc else _workspace(nbytes, dev)
     g_pooled = new((B, C, 2)) if split_pool else None
+    fcp = (None,) * 4 if defer_fc else (g0r, g0i, g2r, g2i)
     check(_sym('dcs_attention_bwd_x', x, g_out)(ptr(x), ptr(g_out), ptr(ca), ptr(sa), ptr(g_sp), ptr(pooled), ptr(hidden), ptr(w1),
-                                  ptr(w2), ptr(g_x), ptr(g0r), ptr(g0i), ptr(g2r), ptr(g2i), ptr(g_pooled), ptr(ws),
+                                  ptr(w2), ptr(g_x), ptr(fcp[0]), ptr(fcp[1]), ptr(fcp[2]), ptr(fcp[3]), ptr(g_pooled), ptr(ws),
                                   ws.numel(), B, HW, C, Ch, float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()),
           'dcs_attention_bwd_x')
+    if defer_fc:
+        return g_x, g0r, g0i, g2r, g2i, g_c1r, g_c1i, g_pooled, (ws, pooled, hidden, g0r, g0i, g2r, g2i, B, HW, C, Ch)
     if split_pool:
         return g_x, g0r, g0i, g2r, g2i, g_c1r, g_c1i, g_pooled
     return g_x, g0r, g0i, g2r, g2i, g_c1r, g_c1i
+
+
+def attention_bwd_fc_weights(job):
+    """The FC weight gradients attention_bwd(defer_fc=True) left out, on the current stream."""
+    ws, pooled, hidden, g0r, g0i, g2r, g2i, B, HW, C, Ch = job
+    check(_lib.load().dcs_attention_bwd_fc_weights(ptr(ws), ws.numel(), ptr(pooled), ptr(hidden), ptr(g0r), ptr(g0i), ptr(g2r),
+                                                   ptr(g2i), B, HW, C, Ch, cur_stream()), 'dcs_attention_bwd_fc_weights')
 
 
 ATTENTION_BATCH_MAX = 8

@@ -422,6 +422,13 @@ int  dcs_attention_bwd_x(const float* x, const float* g_out, const float* ca, co
                          float* g_x, float* g_fc0_r, float* g_fc0_i, float* g_fc2_r, float* g_fc2_i, float* g_pooled,
                          void* workspace, long workspace_bytes, int B, long HW, int C, int Ch,
                          float drop_p, unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
+/* dcs_attention_bwd_x with all four g_fc* null and g_pooled given leaves the FC weight gradients out (two launches instead of
+ * three); dcs_attention_bwd_fc_weights computes them later from the per-sample cotangents that call left in ITS `workspace` (pass
+ * the same buffer, untouched in between) — nothing downstream waits for them, so a two-stream step queues this launch beside
+ * the data-gradient chain. */
+int dcs_attention_bwd_fc_weights(const void* workspace, long workspace_bytes, const float* pooled, const float* hidden,
+                                 float* g_fc0_r, float* g_fc0_i, float* g_fc2_r, float* g_fc2_i, int B, long HW, int C, int Ch,
+                                 dcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * ComplexLSTM, recurrent half (c_network.py:12-51; built :118-123, called :201).
