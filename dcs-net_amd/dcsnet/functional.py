@@ -642,6 +642,8 @@ class _LstmLayerFn(torch.autograd.Function):
         NT = B2 * S
         g_pre, b_part = ops.lstm_layer_bwd(g_out.contiguous(), gates, c, w_hh, 2, B2, S, True)
         g_gx = g_pre.view(2, NT, 8 * H)
+        # (queued for the side stream like the attention blocks' FC weight gradients — PENDING_SIDE — the two MFMA products and the
+        # reduction of a layer, ~40 us, run beside the encoder's backward and the step is 0.012 ms SLOWER: profiles/r04_side_stream_ab.txt)
         _LstmLayerFn._param_grads(st, inp, hprev, g_pre, b_part, g_gx, B2, S, H, NT, planes=ctx.planes)
         if ctx.planes:
             g_z = None
