@@ -506,7 +506,9 @@ extern "C" int DCS_SYM(dcs_attention_bwd_batched)(int n, const dcs_attention_ite
         double* part = (double*)ws;
         float2* go = (float2*)(ws + (long)B * nch * it.C * 2 * (long)sizeof(double));
         float2* gh = go + (long)B * it.C;
-        float2* gpooled = gh + (long)B * it.Ch;
+        // g_pooled given: the consumer of g_x adds the pool's broadcast term (dcs_cbn_bwd_add), the read-modify-write pass is skipped
+        float2* gpooled = it.g_pooled ? (float2*)it.g_pooled : gh + (long)B * it.Ch;
+        const int nxp = it.g_pooled ? 0 : nxs;
         ws += bwd_item_bytes(it, B, G);
         tsa.p[i] = BwdSaP{(const act_t*)it.x, (const act_t*)it.g_out, it.ca, (const float2*)it.sa, (float2*)it.g_pre, HW, G, nxs};
         tx.p[i] = BwdXP{(const act_t*)it.x, (const act_t*)it.g_out, it.ca, (const float2*)it.sa, (const float4*)it.g_sp, (act_t*)it.g_x, part, HW, it.C, G, nch};
@@ -516,8 +518,8 @@ extern "C" int DCS_SYM(dcs_attention_bwd_batched)(int n, const dcs_attention_ite
         cw.go = go; cw.gh = gh; cw.pooled = (const float2*)it.pooled; cw.hidden = (const float2*)it.hidden;
         cw.g_fc0_r = it.g_fc0_r; cw.g_fc0_i = it.g_fc0_i; cw.g_fc2_r = it.g_fc2_r; cw.g_fc2_i = it.g_fc2_i;
         cw.B = B; cw.C = it.C; cw.Ch = it.Ch;
-        const int nxw = nxs + (it.C * it.Ch * kWLanes + kThreads - 1) / kThreads;
-        tp.p[i] = PoolP{(act_t*)it.g_x, (const float*)gpooled, HW, G, 1.f / (float)HW, nxs, nxw, cw};
+        const int nxw = nxp + (it.C * it.Ch * kWLanes + kThreads - 1) / kThreads;
+        tp.p[i] = PoolP{(act_t*)it.g_x, (const float*)gpooled, HW, G, 1.f / (float)HW, nxp, nxw, cw};
         nx_sa = nxs > nx_sa ? nxs : nx_sa;
         nx_x = nch > nx_x ? nch : nx_x;
         nx_p = nxw > nx_p ? nxw : nx_p;

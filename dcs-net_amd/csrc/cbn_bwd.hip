@@ -51,6 +51,17 @@ __device__ __forceinline__ float2 grad_y(const Chan& k, float xr, float xi, floa
 
 // g_out + scale * (per-sample, per-channel constant): the broadcast half of an average pool's backward, folded into
 // the consumer instead of a read-modify-write pass over g_out (dcs_cbn_bwd_add)
+// sample index r / HW of pixel row r (the per-sample additive term): a float estimate corrected by one either way — exact for
+// r < 2^31 with HW < 2^31 (the 64-bit division it replaces was ~100 instructions per row in two bandwidth-bound kernels)
+__device__ __forceinline__ long sample_of(long r, long HW, float inv_hw) {
+    if (r >= (1L << 31)) return r / HW;
+    const unsigned ru = (unsigned)r, hw = (unsigned)HW;
+    unsigned b = (unsigned)((float)ru * inv_hw);
+    if ((unsigned long long)b * hw > ru) --b;
+    if ((unsigned long long)(b + 1) * hw <= ru) ++b;
+    return (long)b;
+}
+
 __device__ __forceinline__ void add_sample(float4& g, const float4 a, float scale) {
     g.x = fmaf(a.x, scale, g.x); g.y = fmaf(a.y, scale, g.y); g.z = fmaf(a.z, scale, g.z); g.w = fmaf(a.w, scale, g.w);
 }
@@ -116,6 +127,7 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const act_t* _
     }
 
     const int g = t % G, r0 = t / G;
+    const float inv_hw = 1.f / (float)(HW > 0 ? HW : 1);
     const Chan k0 = load_chan(coef, stats, 2 * g), k1 = load_chan(coef, stats, 2 * g + 1);
     // Four row passes per trip, every load unconditional (clamped row; the optional second cotangent and per-sample term
     // read through a valid stand-in pointer and are dropped by a select): as a rolled loop with `if (g2)` / `if (g_add)`
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_reduce_kernel(const act_t* _
             v[u] = x4[rc * G + g];
             gg[u] = g4[rc * G + g];
             h[u] = g2p[rc * G + g];
-            ga[u] = gap[g_add ? (rc / HW) * G + g : 0];
+            ga[u] = gap[g_add ? sample_of(rc, HW, inv_hw) * G + g : 0];
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -338,13 +350,14 @@ __global__ __launch_bounds__(kThreads) void cbn_bwd_apply_kernel(const act_t* __
         return;
     }
     const int g = t % G, r0 = t / G;
+    const float inv_hw = 1.f / (float)(HW > 0 ? HW : 1);
     const Chan k0 = load_chan(coef, stats, 2 * g), k1 = load_chan(coef, stats, 2 * g + 1);
     const BChan b0 = load_bchan(bcoef, 2 * g), b1 = load_bchan(bcoef, 2 * g + 1);
     for (long r = (long)blockIdx.x * rows_per_iter + r0; r < P; r += (long)gridDim.x * rows_per_iter) {
         const float4 v = x4[r * G + g];
         float4 gg = g4[r * G + g];
         if (g2_) { const float4 h = g2[r * G + g]; gg.x += h.x; gg.y += h.y; gg.z += h.z; gg.w += h.w; }
-        if (g_add) add_sample(gg, g_add[(r / HW) * G + g], add_scale);
+        if (g_add) add_sample(gg, g_add[sample_of(r, HW, inv_hw) * G + g], add_scale);
         const uint64_t e = (uint64_t)(r * G + g) * 4;
         const float2 a = grad_x(b0, grad_y<ACT, DROP>(k0, v.x, v.y, gg.x, gg.y, seed, e, drop_p, inv_keep), v.x, v.y);
         const float2 b = grad_x(b1, grad_y<ACT, DROP>(k1, v.z, v.w, gg.z, gg.w, seed, e + 2, drop_p, inv_keep), v.z, v.w);

@@ -25,7 +25,7 @@ class AttentionItem(ctypes.Structure):
     """dcs_attention_item (include/dcsnet_hip.h): one attention block of a batched launch."""
     _fields_ = [(n, _P) for n in ('x', 'w1', 'w2', 'wsa', 'sa_bias', 'ca', 'pooled', 'hidden', 'sp', 'sa', 'y', 'g_out',
                                   'wsa_bwd', 'g_pre', 'g_sp', 'g_x', 'g_fc0_r', 'g_fc0_i', 'g_fc2_r', 'g_fc2_i')] + \
-               [(n, _I) for n in ('H', 'W', 'C', 'Ch')]
+               [(n, _I) for n in ('H', 'W', 'C', 'Ch')] + [('g_pooled', _P)]
 
 
 # name -> (restype, argtypes); must mirror include/dcsnet_hip.h exactly

@@ -268,8 +268,18 @@ class _CbnTwoFn(torch.autograd.Function):
             return (None,) * 12
         if g_a is None:
             g_a, g_b = g_b, None
+        # a skip attention's cotangent may come without its average pool's broadcast term (attention_blocks, _POOL_ADD): the
+        # kernels add g_pooled[b][c] / HW on the fly instead of that block's read-modify-write pass over its g_x
+        g_add = None
+        for g_ in (g_a, g_b):
+            if g_ is not None and _POOL_ADD:
+                hit = _POOL_ADD.pop(g_.data_ptr(), None)
+                if hit is not None:
+                    if g_add is not None:
+                        raise DcsHipError('cbn_two backward: two split pool terms for one stage output')
+                    g_add = hit
         g_x, g_w, g_b_ = ops.cbn_bwd(x, g_a.contiguous(), weight, stats, coef, use_batch, act, drop_p, seed, affine,
-                                     ctx.sinks, g_out2=None if g_b is None else g_b.contiguous())
+                                     ctx.sinks, g_add=g_add, g_out2=None if g_b is None else g_b.contiguous())
         g_w = None if ctx.sinks[0] is not None else g_w
         g_b_ = None if ctx.sinks[1] is not None else g_b_
         return g_x, g_w, g_b_, None, None, None, None, None, None, None, None, None
@@ -278,8 +288,10 @@ class _CbnTwoFn(torch.autograd.Function):
 def cbn_two(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act=ACT_NONE,
             drop_p=0.0, seed=0, stat=None):
     """(y, y') — the same values, for two different consumers (see _CbnTwoFn)."""
-    return _CbnTwoFn.apply(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
-                           drop_p, seed, stat)
+    y, y2 = _CbnTwoFn.apply(x, weight, bias, running_mean, running_covar, eps, momentum, use_batch_stats, act,
+                            drop_p, seed, stat)
+    y2._dcs_adds_pool_term = True         # its backward adds an attention block's pool term itself (_POOL_ADD): attention_blocks may split it off
+    return y, y2
 
 
 def channel_attention(x, fc0_r, fc0_i, fc2_r, fc2_i):
@@ -394,8 +406,9 @@ class _AttentionBlocksFn(torch.autograd.Function):
     Inputs: n, ksize, then x_0..x_{n-1}, then six parameters per block (fc.0 r/i, fc.2 r/i, conv1 r/i)."""
 
     @staticmethod
-    def forward(ctx, n, ksize, *args):
+    def forward(ctx, n, ksize, split, *args):
         xs, params = args[:n], [args[n + 6 * i:n + 6 * i + 6] for i in range(n)]
+        ctx.split = tuple(split)
         w1s, w2s, wsas, biases = [], [], [], []
         for fc0_r, fc0_i, fc2_r, fc2_i, c1_r, c1_i in params:
             w1s.append(packed_weight(fc0_r, fc0_i, None, None, False)[0])
@@ -429,10 +442,16 @@ class _AttentionBlocksFn(torch.autograd.Function):
             sk, (s0, s2) = ctx.sinks[i], ctx.shapes[i]
             new = lambda shape: torch.empty(shape, dtype=torch.float32, device=x.device)
             fcs.append(tuple(sk[j] if sk[j] is not None else new(s0 if j < 2 else s2) for j in range(4)))
-        res = ops.attention_blocks_bwd(saved, gs, wbs, fcs)
+        split = tuple(sp_ and ctx.needs_input_grad[3 + i] for i, sp_ in enumerate(ctx.split))
+        res = ops.attention_blocks_bwd(saved, gs, wbs, fcs, split)
+        if any(split):
+            for (g_x, _, g_pooled), sp_ in zip(res, split):
+                if sp_:
+                    _POOL_ADD[g_x.data_ptr()] = g_pooled
+            torch.autograd.Variable._execution_engine.queue_callback(_pool_add_consumed)
         grads_x, grads_p = [], []
         for i in range(n):
-            g_x, g_pre = res[i]
+            g_x, g_pre, _ = res[i]
             sk = ctx.sinks[i]
             g_c1r, g_c1i, _, _ = ops.cconv2d_bwd_weight(sps[i], None, g_pre, (1, 2, ksize, ksize), False, k, (1, 1), pad,
                                                         outs=(sk[4], sk[5], None, None))
@@ -443,13 +462,29 @@ class _AttentionBlocksFn(torch.autograd.Function):
         if WGRAD_SIDE is not None and ops.WGRAD_DEFER is not None:
             ops.WGRAD_DEFER.append((sps, [r[1] for r in res]))
             FLUSH_AT_NEXT_FORK = True
-        return (None, None, *grads_x, *grads_p)
+        return (None, None, None, *grads_x, *grads_p)
+
+
+SPLIT_SKIP_POOL = os.environ.get('DCS_SPLIT_SKIP_POOL', '1') != '0'     # 0: the skip attentions add their pool term into g_x themselves (A/B)
+_POOL_ADD = {}             # data_ptr of a block's g_x -> its g_pooled [B,C,2], between _AttentionBlocksFn.backward and _CbnTwoFn.backward
+
+
+def _pool_add_consumed():
+    """End of the backward pass: every split-off pool term must have been picked up by its consumer (a silent miss would be a
+    wrong gradient)."""
+    if _POOL_ADD:
+        _POOL_ADD.clear()
+        raise DcsHipError('attention_blocks backward: a split average-pool term was not consumed by a cbn_two backward')
 
 
 def attention_blocks(xs, params, ksize):
-    """params[i] = (fc0_r, fc0_i, fc2_r, fc2_i, conv1_r, conv1_i) of block i; returns the tuple of block outputs."""
+    """params[i] = (fc0_r, fc0_i, fc2_r, fc2_i, conv1_r, conv1_i) of block i; returns the tuple of block outputs.
+    An input that is the second output of cbn_two (marked by it) gets its cotangent WITHOUT the average pool's broadcast term:
+    cbn_two's backward adds it on the fly (one read-modify-write pass over every encoder output's gradient less)."""
     flat = [p for pr in params for p in pr]
-    return _AttentionBlocksFn.apply(len(xs), ksize, *xs, *flat)
+    split = tuple(bool(SPLIT_SKIP_POOL and getattr(x, '_dcs_adds_pool_term', False) and torch.is_grad_enabled() and x.requires_grad)
+                  for x in xs)
+    return _AttentionBlocksFn.apply(len(xs), ksize, split, *xs, *flat)
 
 
 # ---- complex-tensor conveniences for the drop-in layer surface ---------------------------------

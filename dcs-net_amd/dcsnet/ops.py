@@ -707,24 +707,27 @@ def attention_blocks_fwd(xs, w1s, w2s, wsas, biases):
     return outs
 
 
-def attention_blocks_bwd(saved, g_outs, wsa_bwds, fc_outs):
+def attention_blocks_bwd(saved, g_outs, wsa_bwds, fc_outs, split_pool=None):
     """Backward of attention_blocks_fwd.  saved[i]: dict(x, w1, w2, ca, pooled, hidden, sa) of block i; fc_outs[i]: the four
-    FC weight-gradient destinations.  Returns per block (g_x, g_pre); the 7x7 conv's weight gradient is the caller's
-    (cconv2d_bwd_weight(sp, g_pre))."""
+    FC weight-gradient destinations.  Returns per block (g_x, g_pre, g_pooled); the 7x7 conv's weight gradient is the caller's
+    (cconv2d_bwd_weight(sp, g_pre)).  split_pool[i]: block i's g_x lacks the average pool's broadcast term and g_pooled [B,C,2]
+    is returned for the consumer to add (cbn_bwd(g_add=...)); else g_pooled is None."""
     lib = _lib.load()
     B, dev = g_outs[0].shape[0], g_outs[0].device
     blocks, res = [], []
-    for sv, g, wb, fo in zip(saved, g_outs, wsa_bwds, fc_outs):
+    split_pool = split_pool or (False,) * len(saved)
+    for (sv, g, wb, fo), split in zip(zip(saved, g_outs, wsa_bwds, fc_outs), split_pool):
         _chk(g, 'g_out', 5, act=True)
         x = sv['x']
         _, H, W, C, _ = x.shape
         g_pre = torch.empty((B, H, W, 1, 2), dtype=torch.float32, device=dev)
         g_sp = torch.empty((B, H, W, 2, 2), dtype=torch.float32, device=dev)
         g_x = torch.empty_like(x)
+        g_pooled = torch.empty((B, C, 2), dtype=torch.float32, device=dev) if split else None
         blocks.append(dict(x=x, w1=sv['w1'], w2=sv['w2'], ca=sv['ca'], pooled=sv['pooled'], hidden=sv['hidden'], sa=sv['sa'],
                            g_out=g, wsa_bwd=wb, g_pre=g_pre, g_sp=g_sp, g_x=g_x, g_fc0_r=fo[0], g_fc0_i=fo[1], g_fc2_r=fo[2],
-                           g_fc2_i=fo[3], H=H, W=W, C=C, Ch=sv['hidden'].shape[1]))
-        res.append((g_x, g_pre))
+                           g_fc2_i=fo[3], H=H, W=W, C=C, Ch=sv['hidden'].shape[1], **({'g_pooled': g_pooled} if split else {})))
+        res.append((g_x, g_pre, g_pooled))
     items = _attention_items(blocks)
     n = len(blocks)
     nbytes = lib.dcs_attention_bwd_batched_workspace_bytes(n, items, B)

@@ -354,6 +354,8 @@ typedef struct {
     const float* g_out; const float* wsa_bwd; float* g_pre; float* g_sp; float* g_x;
     float* g_fc0_r; float* g_fc0_i; float* g_fc2_r; float* g_fc2_i;
     int H, W, C, Ch;
+    float* g_pooled;       /* backward, optional (ABI 17): complex[B][C] — when given, the average pool's broadcast term is written
+                              there and NOT added into g_x; the consumer of g_x adds g_pooled[b][c] / (H W) (dcs_cbn_bwd_add's g_add) */
 } dcs_attention_item;
 long dcs_attention_fwd_batched_workspace_bytes(int n, const dcs_attention_item* items, int B);
 int dcs_attention_fwd_batched(int n, const dcs_attention_item* items, void* workspace, long workspace_bytes, int B,
