@@ -27,7 +27,7 @@ def _sources():
 # Sources that touch ACTIVATIONS are compiled a second time with -DDCS_ACT_BF16 (csrc/dcs_common.h: act_t = bf16 storage,
 # entry points suffixed _h): BASELINE configs[4]'s bf16 activations in HBM.
 ACT_SOURCES = ('cbn.hip', 'cbn_bwd.hip', 'attention.hip', 'attention_bwd.hip', 'conv_direct.hip', 'conv_mfma.hip',
-               'conv_enc0.hip', 'conv_small.hip', 'conv_wgrad_mfma.hip')
+               'conv_enc0.hip', 'conv_small.hip', 'conv_wgrad_mfma.hip', 'conv_ring.hip')
 
 
 def _mfma_source_flags():

@@ -21,6 +21,7 @@
 #include "conv_common.h"
 #include "pack_jobs.h"
 #include "conv_mfma_args.h"
+#include "conv_ring.h"
 #include <cstdio>
 #include <type_traits>
 #include <cstdlib>
@@ -1136,7 +1137,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 
 // (the B-panel re-layout kernel lives in pack_jobs.hip: packjob::MFMA)
 
-struct Plan { int cand, TH, TW, CH, S, cps; long blocks; int wk; };
+struct Plan { int cand, TH, TW, CH, S, cps; long blocks; int wk; bool ring_on; RingPlan ring; };
 thread_local bool g_force_wide_panel = false;
 
 template <int WAVES_N, int WM, int WN, int CH, int PR, int TPI, bool STAT = false, int WK = 1>
@@ -1245,6 +1246,16 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
         kh = cls[c].kh > kh ? cls[c].kh : kh; kw = cls[c].kw > kw ? cls[c].kw : kw;
     }
     if (Hc <= 0 || Wc <= 0) return false;
+    // Round 5: the producer / consumer kernel (conv_ring.hip) where its 128 x 64 tile fits the layer
+    p->ring_on = false;
+    if (!g_force_wide_panel &&
+        DCS_SYM(dcs_conv_ring_plan)(a, ncls, cls, conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0), &p->ring)) {
+        p->ring_on = true;
+        p->cand = 10; p->TH = p->ring.TH; p->TW = p->ring.TW; p->CH = p->ring.CH; p->S = 1; p->cps = Cin / p->ring.CH;
+        p->blocks = p->ring.wgs; p->wk = 1;
+        *npix_out = p->ring.npix;
+        return true;
+    }
     const int NT = (2 * a.Cout + 31) / 32;
     // tile shape th x tw = bmp pixels: least padding past the class extent first, then the smallest haloed patch
     auto shape = [&](int bmp, int* th, int* tw) {
@@ -1504,6 +1515,7 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
         fprintf(stderr, "[mfma] B %d in %dx%d C %d+%d -> %dx%d Cout %d k %dx%d ncls %d | cand %d tile %dx%d CH %d S %d/%d cps %d prec %d coef %d\n",
                 a.B, a.Hin, a.Win, a.C1, a.C2, a.Hout, a.Wout, a.Cout, a.kh, a.kw, ncls, p.cand, p.TH, p.TW, p.CH, m.ksplit, p.S,
                 m.cps, g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0), a.coef != nullptr);
+    if (p.ring_on) return DCS_SYM(dcs_conv_ring_launch)(m, p.ring, stream);
     if (m.N == 16 && p.cand == 3 && !g_force_wide_panel) {    // 128 pixels x 16 columns, v_mfma_f32_16x16x4_f32
         const int pr16 = conv::mfma_precision16(Cin);
 #if !DCS_ACT_IS_BF16
