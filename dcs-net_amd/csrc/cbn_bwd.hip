@@ -51,8 +51,11 @@ __device__ __forceinline__ float2 grad_y(const Chan& k, float xr, float xi, floa
 
 // g_out + scale * (per-sample, per-channel constant): the broadcast half of an average pool's backward, folded into
 // the consumer instead of a read-modify-write pass over g_out (dcs_cbn_bwd_add)
-// sample index r / HW of pixel row r (the per-sample additive term): a float estimate corrected by one either way — exact for
-// r < 2^31 with HW < 2^31 (the 64-bit division it replaces was ~100 instructions per row in two bandwidth-bound kernels)
+// sample index r / HW of pixel row r (the per-sample additive term): a float estimate corrected by one either way (the 64-bit
+// division it replaces was ~100 instructions per row in two bandwidth-bound kernels).  Precondition: r < 2^31 and at most 2^20
+// samples — the estimate carries ~2^-23 relative error, i.e. less than ONE in absolute terms only while r / HW < 2^22, which is
+// what a single correction step can repair; the host entry rejects larger sample counts (P / HW > 2^20) when a per-sample
+// term is present, rows beyond 2^31 take the exact division.
 __device__ __forceinline__ long sample_of(long r, long HW, float inv_hw) {
     if (r >= (1L << 31)) return r / HW;
     const unsigned ru = (unsigned)r, hw = (unsigned)HW;
@@ -383,6 +386,7 @@ extern "C" int DCS_SYM(dcs_cbn_bwd_add)(const act_t* x, const act_t* g_out, act_
     cbn::Geom g;
     if (!x || !g_out || !stats || !coef || !workspace || !cbn::geom(P, C, &g)) return DCS_ERR_BADARG;   // (g_x NULL: parameter gradients only)
     if (g_add && (C < 2 || HW <= 0 || P % HW != 0)) return DCS_ERR_BADARG;
+    if (g_add && P / HW > (1L << 20)) return DCS_ERR_BADARG;              // sample_of's precondition (above)
     if (g_out2 && C == 1 && (P & 1)) return DCS_ERR_BADARG;      // the scalar tail of the one-channel layout reads g_out only
     const act_t* gb = g_out2;
     const float4* ga = reinterpret_cast<const float4*>(g_add);

@@ -1477,8 +1477,39 @@ int dcs_conv_mfma_launch_classes(conv::Args& a, const float* bm, int ncls, const
 #if DCS_ACT_IS_BF16
     if (dcs_conv_precision() != 1) return DCS_ERR_BADARG;     // bf16 activations: bf16 weight panels (dcs_set_conv_precision(1))
 #endif
-    if ((long)a.B * a.Hin * a.Win * (a.C1 > a.C2 ? a.C1 : a.C2) * (long)sizeof(act2_t) >= (1L << 31))
-        return DCS_ERR_BADARG;                                             // the source-offset tables hold 32-bit byte offsets
+    // The source-offset tables hold 32-bit BYTE offsets from the tensor's base: a source of 2 GiB or more (16 channels in fp32:
+    // B T >= 131072 at F = 128 — e.g. B = 64 at T = 2048) runs as several launches over sub-batches, each with its own base
+    // pointers (samples are independent; the statistics rows of sub-launch s follow those of s - 1).  ADVICE r4: the first form
+    // of the byte tables returned DCS_ERR_BADARG here — a capability the pixel-index tables had had.
+    {
+        const long per_sample = (long)a.Hin * a.Win * (a.C1 > a.C2 ? a.C1 : a.C2) * (long)sizeof(act2_t);
+        if ((long)a.B * per_sample >= (1L << 31)) {
+            if (per_sample >= (1L << 31) || p.S > 1) return DCS_ERR_BADARG;     // (one sample alone; a sliced plan never has this many pixels)
+            const int nb_max = (int)(((1L << 31) - 1) / per_sample);
+            int Hc_ = 0, Wc_ = 0;
+            for (int c = 0; c < ncls; ++c) { Hc_ = cls[c].Hc > Hc_ ? cls[c].Hc : Hc_; Wc_ = cls[c].Wc > Wc_ ? cls[c].Wc : Wc_; }
+            const long rows_per_sample = (long)((Wc_ + p.TW - 1) / p.TW) * ((Hc_ + p.TH - 1) / p.TH) * ncls;
+            const long ypix = (long)a.Hout * a.Wout;
+            const int w1 = y2 != nullptr ? nsplit : 2 * a.Cout, w2 = 2 * a.Cout - nsplit;
+            for (int b0 = 0; b0 < a.B; b0 += nb_max) {
+                conv::Args s_ = a;
+                s_.B = a.B - b0 < nb_max ? a.B - b0 : nb_max;
+                s_.x1 = a.x1 + (long)b0 * a.Hin * a.Win * a.C1;
+                if (a.x2) s_.x2 = a.x2 + (long)b0 * a.Hin * a.Win * a.C2;
+                s_.y = reinterpret_cast<act2_t*>(reinterpret_cast<act_t*>(a.y) + (long)b0 * ypix * w1);
+                act_t* const y2s = y2 != nullptr ? y2 + (long)b0 * ypix * w2 : nullptr;
+                if (a.stat) {
+                    Plan ps;
+                    long nps;
+                    if (!make_plan(s_, ncls, cls, &ps, &nps) || ps.TH != p.TH || ps.TW != p.TW || ps.S > 1) return DCS_ERR_BADARG;
+                    s_.stat = a.stat + rows_per_sample * b0;
+                }
+                const int rc = dcs_conv_mfma_launch_classes(s_, bm, ncls, cls, os_f, os_t, y2s, nsplit, nullptr, 0, stream);
+                if (rc != DCS_OK) return rc;
+            }
+            return DCS_OK;
+        }
+    }
     if ((long)a.Hout * a.Wout * 2 * a.Cout >= (1L << 31)) return DCS_ERR_BADARG;  // 32-bit store offsets inside an image
     const int Cin = a.C1 + a.C2;
     MArgs m;

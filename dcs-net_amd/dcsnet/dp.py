@@ -154,8 +154,11 @@ class FusedAdam:
         else:
             check(lib.dcs_step_advance_counters(ptr(b.skip), ptr(self.t_dev), ptr(seed_state), ptr(counters), nc, cur_stream()),
                   'dcs_step_advance_counters')
+            # a bucket below four elements (dcs_grad_sumsq_parts reads float4s) is still clipped: its norm by torch, handed to the
+            # kernel as a device scalar (this branch used to pass no norm at all and dropped the clipping silently)
+            gn = torch.linalg.vector_norm(b.grad).reshape(1) if self.max_norm > 0 else None
             check(lib.dcs_adam_amsgrad_step(ptr(b.flat), ptr(b.grad), ptr(self.m), ptr(self.v), ptr(self.vmax),
-                                            None, 0.0, 1.0 / world, b.numel, self.lr,
+                                            ptr(gn), float(self.max_norm) if gn is not None else 0.0, 1.0 / world, b.numel, self.lr,
                                             self.betas[0], self.betas[1], self.eps, self.wd, self.t,
                                             ptr(self.t_dev), ptr(b.skip), cur_stream()), 'dcs_adam_amsgrad_step')
         # the kernel rewrote the parameters behind torch's version counters: invalidate packed weights
@@ -277,6 +280,7 @@ class TrainStep:
             if side is None or side.device != loss.device:
                 side = self.__dict__['_wgrad_side'] = torch.cuda.Stream(device=loss.device)
         ops.wgrad_defer_begin()
+        functional._POOL_ADD.clear()                                   # (left over if an earlier backward raised mid-pass: ADVICE r4)
         del functional.PENDING_SIDE[:]
         functional.WGRAD_SIDE = side
         functional.FLUSH_AT_NEXT_FORK = False

@@ -445,6 +445,10 @@ class _AttentionBlocksFn(torch.autograd.Function):
         split = tuple(sp_ and ctx.needs_input_grad[3 + i] for i, sp_ in enumerate(ctx.split))
         res = ops.attention_blocks_bwd(saved, gs, wbs, fcs, split)
         if any(split):
+            # (entries of a backward pass that raised before its end-of-pass callback would survive here, and the caching
+            # allocator reuses addresses: a later cotangent landing on a stale key would get a foreign pool term added.  One
+            # attention_blocks node per backward pass in the networks of this repo: start from an empty table.)
+            _POOL_ADD.clear()
             for (g_x, _, g_pooled), sp_ in zip(res, split):
                 if sp_:
                     _POOL_ADD[g_x.data_ptr()] = g_pooled
@@ -571,14 +575,14 @@ class _LstmRecFn(torch.autograd.Function):
         return g_pre5, g_whh
 
 
-def _project(inp, w_ih, shared, per_set=False):
+def _project(inp, w_ih, shared, per_set=False, train=True):
     """Input projection of one LSTM layer for both parameter sets, all time steps at once (nn.LSTM's x_t W_ih^T, c_network.py:24-31):
     shared: inp [M, in] read by both sets -> [M, 2 * 8H] against the stacked weight [2 * 8H, in] (per_set: -> [2, M, 8H], the
     same rows read once per set); else inp [2, M, in] -> [2, M, 8H].  In-tree fp32 MFMA kernel (dcs_gemm_f32); shapes it does
     not take go to the library GEMM."""
     G8, K = w_ih.shape[1], w_ih.shape[2]
     M = inp.shape[-2]
-    if not (ops.gemm_ok(M, G8, K, 2) and inp.is_contiguous() and w_ih.is_contiguous()):
+    if not (ops.gemm_ok(M, G8, K, 2, train) and inp.is_contiguous() and w_ih.is_contiguous()):
         if shared and not per_set:
             return torch.mm(inp, w_ih.reshape(2 * G8, -1).t())
         return torch.matmul(inp, w_ih.transpose(1, 2))
@@ -595,7 +599,7 @@ def _project_bwd(g_gx, w_ih, shared):
     K segments of one launch); else [2, M, in]."""
     G8, K = w_ih.shape[1], w_ih.shape[2]
     M = g_gx.shape[1]
-    if not (ops.gemm_ok(M, K, G8, 2) and g_gx.is_contiguous() and w_ih.is_contiguous()):
+    if not (ops.gemm_ok(M, K, G8, 2, True) and g_gx.is_contiguous() and w_ih.is_contiguous()):
         if shared:
             g_inp = torch.mm(g_gx[0], w_ih[0])
             return g_inp.addmm_(g_gx[1], w_ih[1])              # (in place: torch.addmm copies its addend first)
@@ -802,7 +806,7 @@ def complex_lstm(z, real_lstm, imag_lstm):
     # the stacking read in place (no x2, no permute in the backward) where the kernels take the shape: whole 8-row chunks of the
     # weight gradient inside each part (dcs_atb_chunks_strided), a launch the in-tree GEMM is meant for
     in_place = (stacked is not None and z.is_contiguous() and (B * S) % 64 == 0 and I % 64 == 0
-                and ops.gemm_ok(2 * B * S, 16 * real_lstm.hidden_size, I) and ops.gemm_ok(2 * B * S, I, 8 * real_lstm.hidden_size, 2)
+                and ops.gemm_ok(2 * B * S, 16 * real_lstm.hidden_size, I, 1, True) and ops.gemm_ok(2 * B * S, I, 8 * real_lstm.hidden_size, 2, True)
                 and stacked[0]['weight_ih'][0].is_contiguous() and stacked[0]['weight_ih'][1].is_contiguous())
     x2 = None if in_place else torch.view_as_real(z).permute(3, 0, 1, 2).reshape(2 * B * S, I)
     for layer in range(real_lstm.num_layers):
@@ -817,10 +821,10 @@ def complex_lstm(z, real_lstm, imag_lstm):
             if layer == 0:
                 # both sets read the same rows: one launch against the stacked weight, the recurrence takes gx by strides
                 G8 = w_ih.shape[1]
-                gx = _project(x2, w_ih.contiguous(), shared=True)
+                gx = _project(x2, w_ih.contiguous(), shared=True, train=False)
                 strides = (G8, S * 2 * G8, 2 * G8)
             else:
-                gx = _project(inp, w_ih.contiguous(), shared=False)
+                gx = _project(inp, w_ih.contiguous(), shared=False, train=False)
                 strides = (2 * B * S * gx.shape[-1], S * gx.shape[-1], gx.shape[-1])
             out = ops.lstm_layer(gx, w_hh.contiguous(), 2, 2 * B, S, strides, False, bias=(bias.contiguous(), None))[0]
             inp = out.view(2, 2 * B * S, -1)

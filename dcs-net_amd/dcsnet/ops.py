@@ -5,6 +5,7 @@ complex, the memory of a torch complex64 [B, C, H, W] tensor in channels_last fo
 function validates device / dtype / contiguity and raises on a non-zero return code; there is
 no eager or CPU fallback.
 """
+import os as _os
 import torch
 
 from . import _lib
@@ -56,13 +57,19 @@ def set_conv_precision(mode):
     code = {'f32': 0, 'fp32': 0, 'bf16': 1, 'bf16x6': 2}[mode]
     check(_lib.load().dcs_set_conv_precision(code), 'dcs_set_conv_precision')
     global BF16_OPERANDS_ON_PURPOSE
-    BF16_OPERANDS_ON_PURPOSE = (code == 1) and not _IN_SET_ACTIVATION_DTYPE
+    if code != 1:
+        BF16_OPERANDS_ON_PURPOSE = False                       # a switch away from 'bf16' ends the choice
+    elif not _IN_SET_ACTIVATION_DTYPE:
+        BF16_OPERANDS_ON_PURPOSE = True                        # chosen by the caller; a later set_activation_dtype('bf16') keeps it
     from . import functional
     functional._pack_cache.clear()
     pack_plan_drop()
 
 
-BF16_OPERANDS_ON_PURPOSE = False       # 'bf16' chosen through set_conv_precision directly (not as a side effect of set_activation_dtype)
+# 'bf16' chosen on purpose: through set_conv_precision directly (not as a side effect of set_activation_dtype), or as the
+# process preset DCS_CONV_PRECISION=1 (csrc/api.hip) — a preset process runs fp32-storage networks on bf16
+# operands because it was asked to, not because another network switched the mode
+BF16_OPERANDS_ON_PURPOSE = _os.environ.get('DCS_CONV_PRECISION', '').strip() == '1'
 _IN_SET_ACTIVATION_DTYPE = False
 
 
@@ -1073,11 +1080,15 @@ LSTM_GEMM = _os.environ.get('DCS_LSTM_GEMM', '1') != '0'      # 0: the LSTM proj
 LSTM_GEMM_MAX_GFLOP = float(_os.environ.get('DCS_LSTM_GEMM_MAX_GFLOP', '1.5'))
 
 
-def gemm_ok(M, N, K, launches=1):
+def gemm_ok(M, N, K, launches=1, train=False):
     """Shapes dcs_gemm_f32 takes and is the faster choice for (the LSTM projections of the train shapes all are); N, K: one
-    launch's columns and contraction length, launches: batches x segments."""
+    launch's columns and contraction length, launches: batches x segments.  train: a launch of a TRAIN step — the work cap does
+    not apply there: a train step's backward runs the weight-gradient MFMA kernels on a side stream (dp.TrainStep), and a library
+    GEMM (or the ATen copy kernels around it) co-resident with them is code the packed-FMA scan of tests/test_host_cpu.py never
+    sees (profiles/r03_pk_fma_op_sel_hazard.txt) — so every train-step GEMM of this shape family stays in-tree,
+    whatever its size (B = 64 in bf16 storage: 2.1 GFLOP per launch)."""
     return (LSTM_GEMM and M >= 1 and N >= 64 and N % 64 == 0 and K >= 32 and K % 32 == 0
-            and 2e-9 * M * N * K * launches <= LSTM_GEMM_MAX_GFLOP)
+            and (train or 2e-9 * M * N * K * launches <= LSTM_GEMM_MAX_GFLOP))
 
 
 def gemm_f32(A, B, C, M, N, K, lda, ldb, ldc, b_transposed, nseg=1, a_seg=0, b_seg=0, nbatch=1, a_batch=0, b_batch=0,

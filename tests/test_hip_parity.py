@@ -200,6 +200,40 @@ def test_conv_edge_shapes_ragged_tiles_and_1x1(dev):
     close(back(y), m(x))
 
 
+def test_conv_source_of_two_gib_and_more_runs_as_sub_batches(dev):
+    """the MFMA conv's source-offset tables hold 32-bit byte offsets; a source tensor of >= 2 GiB (here 16 channels x
+    66 x 512 x 512 pixels in fp32 = 2.07 GiB, forward and data gradient) must still run — as sub-batch launches — and give what
+    the same samples give in a small batch (fp32 accumulation order: the plans may differ), statistics rows included."""
+    from dcsnet import ops
+    B, H, W, C, Cout, k = 66, 512, 512, 16, 16, 3
+    g = torch.Generator().manual_seed(3)
+    w_r, w_i = (torch.randn(Cout, C, k, k, generator=g) * 0.1).to(dev), (torch.randn(Cout, C, k, k, generator=g) * 0.1).to(dev)
+    b_r, b_i = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+    wp, bias = ops.pack_conv_weight(w_r, w_i, b_r, b_i, False, (1, 1))
+    x = torch.empty(B, H, W, C, 2, device=dev)
+    assert x.numel() * 4 >= 2 ** 31
+    for b in range(B):
+        x[b].normal_(generator=None)
+    y, stat = ops.cconv2d_stats(x, None, wp, bias, (k, k), (1, 1), (1, 1), (1, 1))
+    assert stat is not None
+    for sl in (slice(0, 2), slice(B - 2, B), slice(31, 33)):              # first / last sub-batch and (with 64 per launch) across the seam
+        ys = ops.cconv2d(x[sl].contiguous(), None, wp, bias, (k, k), (1, 1), (1, 1), (1, 1))
+        close(y[sl], ys)
+    # the statistics rows cover every sample exactly once: their sums are the moments of the whole output
+    raw = y - torch.stack((b_r - b_i, b_r + b_i), dim=-1)               # (the moments are taken about the effective bias)
+    mom = stat[0][:, :, :stat[1]].double().sum(dim=2)                    # [C, 5]
+    want = torch.stack((raw[..., 0].double().sum(dim=(0, 1, 2)), raw[..., 1].double().sum(dim=(0, 1, 2)),
+                        (raw[..., 0].double() ** 2).sum(dim=(0, 1, 2)), (raw[..., 1].double() ** 2).sum(dim=(0, 1, 2)),
+                        (raw[..., 0].double() * raw[..., 1].double()).sum(dim=(0, 1, 2))), dim=1)
+    close(mom.float(), want.float(), rel=1e-4)
+    del raw, want
+    wpb = ops.pack_conv_weight_bwd(wp, (k, k), (1, 1), (1, 1), (1, 1))
+    gx = ops.cconv2d_bwd_data(y, wpb, (H, W, C), (k, k), (1, 1), (1, 1), (1, 1), C)[0]
+    for sl in (slice(0, 2), slice(B - 2, B)):
+        gs = ops.cconv2d_bwd_data(y[sl].contiguous(), wpb, (H, W, C), (k, k), (1, 1), (1, 1), (1, 1), C)[0]
+        close(gx[sl], gs)
+
+
 def test_complex_linear(dev):
     from dcsnet import functional as F
     torch.manual_seed(6)

@@ -355,3 +355,83 @@ def test_conv_kernel_fragment_loads_stay_whole(tmp_path):
     assert body.count('ds_read_b64_tr_b16') >= 200 and body.count('global_load_dwordx4') >= 48
     assert 'global_load_dword ' not in body.replace('global_load_dwordx', 'X')
     assert checked == 6
+
+
+def test_ring_kernel_load_destinations_are_untouched_until_their_wait(tmp_path):
+    """Static guard for csrc/conv_ring.hip (Round 5): its producer waves issue their patch loads as inline asm (hipcc would
+    otherwise wait vmcnt(0) for an ordinary load beside the LDS-DMA requests in flight and drain the B ring every step) and count
+    them by hand.  hipcc does not know those destination registers are pending: a loop-carried definition or a wait under a
+    branch made it COPY them (v_mov_b64) in front of the hand-written s_waitcnt — garbage on some launches, silently.  Between
+    every such load and the next `s_waitcnt vmcnt` no instruction may name its destination registers."""
+    import re
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'kernel_isa.py')
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('llvm-objdump not available')
+    from dcsnet import _lib
+    out = tmp_path / 'ring.isa'
+    subprocess.run([sys.executable, tool, _lib.LIB_PATH, 'cconv_ring_kernel<', str(out)], check=True)
+    kernels = re.split(r'^=== ', out.read_text(), flags=re.M)[1:]
+    assert len(kernels) >= 8, len(kernels)
+    checked = 0
+    for body in kernels:
+        lines = body.split('\n')
+        name = lines[0]
+        assert 'global_load_lds_dwordx4' in body and 'v_mfma_f32_32x32x16_bf16' in body, name
+        # the steady-state loads: `global_load_dwordx4 v[a:b], vN, s[c:d]` with NO offset / modifiers behind a scalar base and
+        # followed (before any other wait) by the hand-written counted wait
+        for i, ln in enumerate(lines):
+            m = re.search(r'global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[\d+:\d+\]\s*(//.*)?$', ln)
+            if not m:
+                continue
+            lo, hi = int(m.group(1)), int(m.group(2))
+            regs = set(range(lo, hi + 1))
+            for ln2 in lines[i + 1:]:
+                if 's_waitcnt' in ln2 and 'vmcnt' in ln2:
+                    break
+                if 'global_load_dwordx4' in ln2 and re.search(r'global_load_dwordx4 v\[(\d+):(\d+)\]', ln2):
+                    continue                                   # (the next load of the same burst defines its own registers)
+                used = set()
+                for a, b in re.findall(r'v\[(\d+):(\d+)\]', ln2):
+                    used |= set(range(int(a), int(b) + 1))
+                used |= {int(a) for a in re.findall(r'\bv(\d+)\b', ln2)}
+                assert not (used & regs), (name, ln.strip(), ln2.strip())
+            checked += 1
+    assert checked >= 16, checked
+
+
+def test_bf16_operand_flag_follows_explicit_choices_and_the_process_preset():
+    """ADVICE r4 (dcsnet/c_network.py:_check_conv_precision): conv precision 'bf16' counts as chosen ON PURPOSE when the caller set
+    it (ops.set_conv_precision) or the process was preset with DCS_CONV_PRECISION=1 — and a later set_activation_dtype('bf16')
+    (which sets the mode as a side effect) must not take that choice back; only a switch away from 'bf16' does."""
+    import subprocess
+    import sys
+    from dcsnet import ops
+    mode0, flag0 = ops.conv_precision(), ops.BF16_OPERANDS_ON_PURPOSE
+    try:
+        ops.set_conv_precision('bf16x6')
+        assert ops.BF16_OPERANDS_ON_PURPOSE is False
+        ops._IN_SET_ACTIVATION_DTYPE = True                    # as C_NETWORK.set_activation_dtype('bf16') does
+        ops.set_conv_precision('bf16')
+        ops._IN_SET_ACTIVATION_DTYPE = False
+        assert ops.BF16_OPERANDS_ON_PURPOSE is False           # a side effect is not a choice
+        ops.set_conv_precision('bf16')
+        assert ops.BF16_OPERANDS_ON_PURPOSE is True
+        ops._IN_SET_ACTIVATION_DTYPE = True
+        ops.set_conv_precision('bf16')
+        ops._IN_SET_ACTIVATION_DTYPE = False
+        assert ops.BF16_OPERANDS_ON_PURPOSE is True            # ... and does not undo one
+        ops.set_conv_precision('f32')
+        assert ops.BF16_OPERANDS_ON_PURPOSE is False
+    finally:
+        ops._IN_SET_ACTIVATION_DTYPE = False
+        ops.set_conv_precision(mode0)
+        ops.BF16_OPERANDS_ON_PURPOSE = flag0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); from dcsnet import ops; "
+            "print(ops.BF16_OPERANDS_ON_PURPOSE, ops.conv_precision())" % (root, os.path.join(root, 'dcs-net_amd')))
+    for preset, want in (('1', 'True bf16'), ('2', 'False bf16x6')):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DCS_CONV_PRECISION=preset), capture_output=True,
+                           text=True, check=True)
+        assert r.stdout.strip().endswith(want), (preset, r.stdout, r.stderr)
