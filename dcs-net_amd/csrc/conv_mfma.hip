@@ -1278,9 +1278,9 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // candidate workgroup tiles (pixels x columns): the largest whose USEFUL workgroups (workgroups x the share of their
     // pixels inside the map) number >= min_blocks — several per CU, so one workgroup's MFMA phase hides another's
     // patch gather ...
-    static const long min_blocks = [] { const char* e = getenv("DCS_MFMA_MIN_BLOCKS"); return e ? atol(e) : 768L; }();   // (3 per CU; at 1024 the
+    static const long min_blocks = dcs_knob("DCS_MFMA_MIN_BLOCKS", 768L);   // (3 per CU; at 1024 the
     // inference shapes' enc6 / enc3 took the smaller tile: 118 -> 94 us, 224 -> 217 us; the train shapes do not move)
-    static const long split_below = [] { const char* e = getenv("DCS_MFMA_SPLIT_BELOW"); return e ? atol(e) : 512L; }();
+    static const long split_below = dcs_knob("DCS_MFMA_SPLIT_BELOW", 512L);
     int best = -1; long best_blocks = -1; double best_useful = -1;
     for (int i = 0; i < 4; ++i) {
         if (NT % (kCands[i].bn / 32) != 0) continue;
@@ -1295,9 +1295,9 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     int want_s = 1;
     p->wk = 1;
     // K split over the waves of a 32-pixel tile first (no slabs, no reduce launch); global slices only where that cannot run
-    static const int wk_on = [] { const char* e = getenv("DCS_MFMA_WK"); return e ? atoi(e) : 1; }();
-    static const long wk_min = [] { const char* e = getenv("DCS_MFMA_WK_MIN"); return e ? atol(e) : 384L; }();
-    static const long wk_below = [] { const char* e = getenv("DCS_MFMA_WK_BELOW"); return e ? atol(e) : 512L; }();
+    static const int wk_on = (int)dcs_knob("DCS_MFMA_WK", 1);
+    static const long wk_min = dcs_knob("DCS_MFMA_WK_MIN", 384L);
+    static const long wk_below = dcs_knob("DCS_MFMA_WK_BELOW", 512L);
     if (best_useful < wk_below && wk_on && !g_force_wide_panel && 2 * a.Cout >= 32) {
         for (int i = 4; i < 6 && p->wk == 1; ++i) {
             if (NT % (kCands[i].bn / 32) != 0) continue;
@@ -1315,7 +1315,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     }
     // enc1 (8 -> 16 channels, 7x7, stride 2, emulated): a 128-pixel tile's three-plane patch is 87 KB — ONE workgroup per CU,
     // nothing to overlap its gather with; 64 pixels x 32 columns with the taps split over two waves: 49 KB, three per CU
-    static const int wk_enc1 = [] { const char* e = getenv("DCS_MFMA_WK_ENC1"); return e ? atoi(e) : 1; }();
+    static const int wk_enc1 = (int)dcs_knob("DCS_MFMA_WK_ENC1", 1);
     if (wk_on && wk_enc1 && p->wk == 1 && !g_force_wide_panel && NT == 1 && Cin == 8 && kh == 7 && kw == 7 && ncls == 1 &&
         conv::mfma_precision(Cin, 49) == 2) {
         double eff;
@@ -1324,7 +1324,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
         // ... or, better, over FOUR waves that each cover all 64 pixels (WM = 2): a B fragment then feeds two MFMA sets — half the
         // L1 traffic of the two-wave form, whose waves fetch every tap's fragment for one 32-pixel half each (61.7 -> 55.6 us at
         // the train shapes, 201.7 -> 173.7 us at the inference shapes)
-        static const int enc1_wk4 = [] { const char* e = getenv("DCS_MFMA_ENC1_WK4"); return e ? atoi(e) : 1; }();
+        static const int enc1_wk4 = (int)dcs_knob("DCS_MFMA_ENC1_WK4", 1);
         if (best == 6 && enc1_wk4) { best = 8; p->wk = 4; }
     }
     if (p->wk == 1 && best_useful < split_below) {
@@ -1343,7 +1343,7 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     // half the L1 traffic of the 2 x 2 wave layout whose four waves each fetch their own)
     // (dec1 / dec2 forward and data gradient 78 -> 74 us, dec3 43 -> 41, enc3 / enc4 data gradients -2; not with the statistics
     // epilogue, whose combine then runs over twice the waves: enc2 / enc3 forward +2 us)
-    static const int wk64 = [] { const char* e = getenv("DCS_MFMA_WK64"); return e ? atoi(e) : 1; }();
+    static const int wk64 = (int)dcs_knob("DCS_MFMA_WK64", 1);
     if (wk64 && best == 2 && p->wk == 1 && want_s == 1 && !a.stat && !g_force_wide_panel && Cin % 16 == 0 &&
         conv::mfma_precision(Cin, ncls == 1 ? kh * kw : 0) != 0) {
         best = 7; p->wk = 2;
@@ -1354,21 +1354,21 @@ bool make_plan(const conv::Args& a, int ncls, const conv::Cls* cls, Plan* p, lon
     const long npix = (long)((p->TH - 1) * a.sf + kh) * ((p->TW - 1) * a.st + kw);
     // chunk depth: 16 channels whenever the patch stays within ~1/3 of a CU's LDS (2-3 workgroups per CU overlap
     // each other's gathers), 32 only for small patches (occupancy matters more than barrier count there)
-    static const long cap16 = [] { const char* e = getenv("DCS_MFMA_LDS_CAP"); return e ? atol(e) : 56L * 1024; }();
+    static const long cap16 = dcs_knob("DCS_MFMA_LDS_CAP", 56L * 1024);
     const int pr_for_cap = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);
     // 32-channel chunks (half the gather rounds, twice the patch): for the emulated kernel also up to 56 KB where the launch
     // puts at most ~3 workgroups on a CU anyway, so the larger patch costs no residency (train shapes: step -1.5 %; with
     // every layer allowed, the inference shapes lose 0.8 %)
-    static const long cap32e = [] { const char* e = getenv("DCS_MFMA_LDS_CAP32"); return e ? atol(e) : 32L * 1024; }();
+    static const long cap32e = dcs_knob("DCS_MFMA_LDS_CAP32", 32L * 1024);
     const long wg_est = best_blocks * (want_s > 1 ? want_s : 1);
     // ... and up to 72 KB where at most two do (enc4: two gather rounds instead of four, 40.3 -> 38.2 us)
-    static const long cap32w2 = [] { const char* e = getenv("DCS_MFMA_LDS_CAP32W2"); return e ? atol(e) : 72L * 1024; }();
+    static const long cap32w2 = dcs_knob("DCS_MFMA_LDS_CAP32W2", 72L * 1024);
     const long cap32c = (pr_for_cap == 2 && wg_est <= 512 && cap32e < cap32w2) ? cap32w2
                       : (pr_for_cap == 2 && wg_est <= 768 && cap32e < 56L * 1024) ? 56L * 1024 : cap32e;
     // likewise a 16-channel chunk up to 80 KB where at most two workgroups land on a CU (enc2, 16 channels, 5x5 / stride 2:
     // one 75 KB chunk instead of two gather rounds of 40 KB: 33.7 -> 28.0 us; the same tile split over the taps of two
     // waves as for enc1: 38.8 us)
-    static const long cap16w = [] { const char* e = getenv("DCS_MFMA_LDS_CAP16W"); return e ? atol(e) : 80L * 1024; }();
+    static const long cap16w = dcs_knob("DCS_MFMA_LDS_CAP16W", 80L * 1024);
     const long cap16c = (wg_est <= 512 && cap16 < cap16w) ? cap16w : cap16;
     // patch words per pixel at chunk depth ch: fp32 2 ch + 4; bf16 ch + 4; three bf16 planes 3 ch + 4
     const int pr = g_force_wide_panel ? 0 : conv::mfma_precision(Cin, ncls == 1 ? cls[0].kh * cls[0].kw : 0);

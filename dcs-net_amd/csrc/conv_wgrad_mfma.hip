@@ -817,7 +817,7 @@ int resident_x6(size_t lds) {
             n = 1;
         }
         // (DCS_WGRAD_MAX_PER_CU: experiments with a kernel that leaves room on every CU for the kernels it runs beside)
-        static const int cap = [] { const char* e = getenv("DCS_WGRAD_MAX_PER_CU"); return e ? atoi(e) : 4; }();
+        static const int cap = (int)dcs_knob("DCS_WGRAD_MAX_PER_CU", 4);
         cached = n > cap ? cap : n;
     }
     return cached;
@@ -1015,7 +1015,7 @@ int slabs_for(const conv::Args& c, int ncls, int TH, int TW) {
                 // (DCS_WGRAD_PA_RESIDENCY=1) the kernels alone gain another 7 % (dec1 82 -> 76 us) but the train step LOSES 0.035 ms:
                 // the kernels run on the side stream beside the data gradients, which then find less room (profiles/r04_wgrad_pa.txt).
                 if constexpr (!V::TS && X6<V>::WS == 1) {
-                    static const int pa_res = [] { const char* e = getenv("DCS_WGRAD_PA_RESIDENCY"); return e ? atoi(e) : 0; }();
+                    static const int pa_res = (int)dcs_knob("DCS_WGRAD_PA_RESIDENCY", 0);
                     if (pa_res && planes_bytes_for(c, ncls, TH, TW) > 0)
                         per_cu = resident_x6<V::KH, V::KW, X6<V>::MT, 1, false, true>((size_t)rows * cols * PIXE * sizeof(float));
                 }
@@ -1058,7 +1058,7 @@ void tile_shape(int Hc, int Wc, int kh, int sf, int* TH, int* TW) {
 // round trips per pixel.  g: the geometry the launch dispatches on (kh, kw, strides, Cout); Hc x Wc: the (class) extent.
 void tile_shape_for(const conv::Args& g, int Hc, int Wc, int* TH, int* TW) {
     tile_shape(Hc, Wc, g.kh, g.sf, TH, TW);
-    static const int big = [] { const char* e = getenv("DCS_WGRAD_X6_BIG"); return e ? atoi(e) : 1; }();
+    static const int big = (int)dcs_knob("DCS_WGRAD_X6_BIG", 1);
     if (!big || !wgrad_x6_enabled() || *TW < 16 || ((*TH) * (*TW)) % 32 != 0 || (*TH) * (*TW) != 128) return;
     bool ok = false;
     dispatch(g.kh, g.kw, g.Cout, [&](auto v) { ok = X6<decltype(v)>::ok; return 0; });

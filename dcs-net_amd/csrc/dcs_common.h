@@ -217,6 +217,23 @@ __device__ __forceinline__ float dcs_keep_scale(uint64_t seed, uint64_t idx, flo
 
 static inline int dcs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Plan / tuning thresholds (tile-plan cut-offs, LDS caps, slab planning, forced kernel forms): compile-time constants in the shipped
+// library — a configuration nobody tests does not ride an environment variable.  A diagnostic build
+// (tools/exp_build.py <name> <source> -DDCS_PLAN_KNOBS, run with DCS_LIB_PATH) reads them from the environment again: that is
+// what the sweep tools (tools/plan_sweep.sh, tools/bf16_sweep.sh, tools/grad_noise_variants.py) use.  The switches that stay
+// environment variables in the shipped library are the documented ones of INTEGRATION.md §6, each covered by
+// tests/test_switches.py.
+#include <cstdlib>
+static inline long dcs_knob(const char* name, long dflt) {
+#ifdef DCS_PLAN_KNOBS
+    const char* e = getenv(name);
+    return e ? atol(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 // Raise a kernel's dynamic-LDS limit (> 64 KiB) once per (kernel, size high-water mark).  The table makes the
 // call idempotent, so steady-state launches issue no attribute call at all — hipFuncSetAttribute is not
 // permitted while a stream is being captured into a hipGraph, and the eager warm-up steps have already made it.

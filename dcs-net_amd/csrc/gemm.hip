@@ -177,7 +177,7 @@ extern "C" int dcs_gemm_f32(const float* A, const float* B, float* C, int M, int
     // tile count: all its loads are one round trip, and in the step these launches start cold
     const long wg_spatial = (N % 128 == 0) ? (long)((M + 63) / 64) * (N / 128) * nbatch : 0;
     const long wg_split2 = (long)((M + 31) / 32) * (N / 64) * nbatch;
-    static const int force = getenv("DCS_GEMM_FORM") ? atoi(getenv("DCS_GEMM_FORM")) : -1;     // diagnostic: 0 spatial, 1 / 2 split
+    static const int force = (int)dcs_knob("DCS_GEMM_FORM", -1);     // diagnostic: 0 spatial, 1 / 2 split
     int form = (nseg * (K / 32) == 4 && wg_split2 >= 200) ? 2 : wg_spatial >= 200 ? 0 : (wg_split2 >= 200 ? 2 : 1);
     if (force >= 0 && force <= 2 && !(force == 0 && N % 128)) form = force;
     const dim3 grid(form == 0 ? (M + 63) / 64 : (M + 31) / 32, form == 0 ? N / 128 : (form == 2 ? N / 64 : N / 32), nbatch);
