@@ -35,6 +35,12 @@ def _round_complex(z):
     return torch.complex(_bf16(z.real), _bf16(z.imag)) if z.is_complex() else _bf16(z)
 
 
+# What-if switch of the contract (tests/test_oracle.py::test_bf16_contract_gradient_cost_with_fp32_cotangents):
+# cotangents of maps with at most this many pixels (H * W of the stored tensor) stay fp32 on the way back; 0 = the build's
+# contract (every stored tensor's cotangent is rounded to bf16), a huge value = no cotangent is rounded.
+COTANGENT_FP32_MAX_PIXELS = 0
+
+
 class _Store(torch.autograd.Function):
     """A tensor stored in bf16 in HBM: its value is rounded on the way forward, its cotangent on the way back."""
 
@@ -44,6 +50,8 @@ class _Store(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g.dim() >= 2 and g.shape[-2] * g.shape[-1] <= COTANGENT_FP32_MAX_PIXELS:
+            return g
         return _round_complex(g)
 
 
