@@ -59,6 +59,9 @@
 #ifndef DCS_MFMA_EARLY_OPERANDS
 #define DCS_MFMA_EARLY_OPERANDS 3
 #endif
+#ifndef DCS_EXP_M16
+#define DCS_EXP_M16 0       // timing probes of the 16-column kernel (wrong results): 1 no stores, 2 no MFMA loop, 4 no gather, 8 return behind the table
+#endif
 #ifndef DCS_X6_GU32
 #define DCS_X6_GU32 8       // gather loads in flight per thread at 32-channel chunks of the emulated kernel
 #endif
@@ -867,31 +870,54 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // of sixteen of 32.
 // PR = 1: bf16 operands (dcs_set_conv_precision(1); activations stored in bf16 need no conversion at all): the same kernel with
 // ONE plane — one MFMA per tile and k-group, B panel [tap][kg16][64 lanes][8 bf16] (packjob::MFMA, flag 18).
-template <int CH, int PR = 0>
+// FUSE (Round 5): ONE workgroup computes ALL output classes of its pixel tile from one gathered patch.  The parity classes of a
+// conv over an upsampled input (dec5: four classes of 2 x 2 taps) and the residue classes of a strided conv's data gradient
+// (enc1: 4 x 4 .. 3 x 3 taps) read almost the same source pixels — as separate workgroups (blockIdx.z) each built its own
+// source table, gathered and split its own patch and paid its own prologue / epilogue: dec5's forward was 4096 workgroups of
+// 0.8 us of MFMAs each, 16 per CU.  The patch is the union of the classes' windows (origin = the largest padding), a class's
+// taps are offset into it by its own padding, and each class keeps its own two accumulator tiles; statistics rows, output
+// addressing and results are exactly those of the per-class launches.
+template <int CH, int PR = 0, bool FUSE = false>
 __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
     DCS_PRIO_CRITICAL();
     extern __shared__ __attribute__((aligned(16))) float patch[];      // [rows*cols][PIX]
     constexpr int NP = PR == 2 ? 3 : 1;
-    constexpr int U8 = PR != 0 ? CH / 16 : CH / 8, PIX = PR != 0 ? NP * CH + 4 : 2 * CH + 4, Q = CH / 2;
+    // pixel pitch = payload + 8 words: pitch / 4 = 2 (mod 4) keeps the sixteen 16-byte reads of every ds_read_b128 lane group — pixels
+    // li of one tile row, 16-byte piece lane >> 4 — on sixteen different bank quads (the + 4 of the 32-column kernel's pitch suits ITS
+    // lane map; here it was a 56 % conflict rate: profiles/r05_mfma16_probes.txt)
+    constexpr int U8 = PR != 0 ? CH / 16 : CH / 8, PIX = (PR != 0 ? NP * CH : 2 * CH) + 8, Q = CH / 2;
+    constexpr int NC = FUSE ? 4 : 1;                                   // accumulator sets (classes per workgroup)
     static_assert(PR == 0 || CH % 16 == 0, "bf16 forms: 16-channel k-groups");
     static_assert(!DCS_ACT_IS_BF16 || PR != 2, "bf16 activations: native or bf16-operand form");
     const conv::Args& a = m.c;
-    const conv::Cls& k = m.cls[blockIdx.z];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int g4 = lane >> 4, li = lane & 15;
+    const int c_first = FUSE ? 0 : (int)blockIdx.z, n_cls = FUSE ? m.ncls : 1;
 
     const int tiles_per_img = a.tiles_w * a.tiles_h;
     const int b = blockIdx.x / tiles_per_img, tile_id = blockIdx.x % tiles_per_img;
     const int oy0 = (tile_id / a.tiles_w) * m.TH, ox0 = (tile_id % a.tiles_w) * m.TW;
-    float* const stat_row = a.stat ? a.stat + ((long)blockIdx.z * gridDim.x + blockIdx.x) : nullptr;   // (Cout = 8: 40 sums)
-    if (oy0 >= k.Hc || ox0 >= k.Wc) {
-        if (stat_row && t < 40) stat_row[(long)t * a.stat_stride] = 0.f;
+    // the window of the workgroup's classes: origin = the largest padding, extent = the farthest tap of any class
+    int pmf = 0, pmt = 0, ext_f = 0, ext_t = 0, Hc_max = 0, Wc_max = 0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+        if (cc >= n_cls) break;
+        const conv::Cls& kc = m.cls[c_first + cc];
+        pmf = kc.pad_f > pmf ? kc.pad_f : pmf; pmt = kc.pad_t > pmt ? kc.pad_t : pmt;
+        ext_f = kc.kh - kc.pad_f > ext_f ? kc.kh - kc.pad_f : ext_f; ext_t = kc.kw - kc.pad_t > ext_t ? kc.kw - kc.pad_t : ext_t;
+        Hc_max = kc.Hc > Hc_max ? kc.Hc : Hc_max; Wc_max = kc.Wc > Wc_max ? kc.Wc : Wc_max;
+    }
+    if (oy0 >= Hc_max || ox0 >= Wc_max) {                              // tile outside every class
+        if (a.stat && t < 40) {
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc)
+                if (cc < n_cls) a.stat[((long)(c_first + cc) * gridDim.x + blockIdx.x) + (long)t * a.stat_stride] = 0.f;
+        }
         return;
     }
-    const int vy0 = oy0 * a.sf - k.pad_f, vx0 = ox0 * a.st - k.pad_t;
+    const int vy0 = oy0 * a.sf - pmf, vx0 = ox0 * a.st - pmt;
     const int Cin = a.C1 + a.C2;
-    const int ntaps = k.kh * k.kw;
-    const int cols = (m.TW - 1) * a.st + k.kw, rows = (m.TH - 1) * a.sf + k.kh;
+    const int cols = (m.TW - 1) * a.st + pmt + ext_t, rows = (m.TH - 1) * a.sf + pmf + ext_f;
 
     int pixoff[2];
 #pragma unroll
@@ -899,119 +925,211 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
         const int pi = wave * 32 + i * 16 + li;
         pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + g4 * 4;
     }
-    const float* bbase = m.bm + k.bm_off + (long)lane * 4;
     const long b_tap_stride = PR != 0 ? (long)(Cin / 16) * NP * 256 : (long)(Cin / 8) * 256, b_kg_stride = PR != 0 ? NP * 256 : 256;
-
-    f32x4v acc[2];
-    acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    const int n_chunks = Cin / CH;
-    const int nslots = rows * cols * Q;
-
-    auto bload = [&](float4* dst, int c, int tp, int g) {
-        if (tp >= ntaps) { tp = 0; ++c; }
-        c = c < n_chunks ? c : n_chunks - 1;
-        const float* bp = bbase + tp * b_tap_stride + (long)(c * U8 + g) * b_kg_stride;
+    // per class (static indices: the class loops below are unrolled): panel base, tap count, kernel width, window offset
+    // per class (static indices: the class bodies below are instantiated per class): tap count, kernel width, window offset
+    int ntaps_c[NC], kw_c[NC], woff_c[NC];
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const float4*>(bp + pl * 256);
+    for (int cc = 0; cc < NC; ++cc) {
+        const conv::Cls& kc = m.cls[cc < n_cls ? c_first + cc : c_first];
+        ntaps_c[cc] = kc.kh * kc.kw; kw_c[cc] = kc.kw;
+        woff_c[cc] = (pmf - kc.pad_f) * cols + (pmt - kc.pad_t);          // (in patch pixels)
+    }
+    // The B fragment addresses are wave-uniform up to the lane's 16 bytes: panel base (SGPR pair) + a 32-bit scalar byte offset + one
+    // constant lane-offset VGPR (as the 32-column kernel's SCALAR_B).  As per-lane 64-bit pointers every tap paid ~25 scalar and ~20
+    // vector instructions of address arithmetic — 3.8 SALU + 3.6 VALU per 16-cycle MFMA over the whole kernel.
+    typedef __attribute__((address_space(1))) const char gchar_t;
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const f32x4n gfloat4_t;
+    auto uniform_ptr = [](const float* q) -> gchar_t* {               // (wave-uniform by construction: say so to the compiler)
+        const unsigned long long u = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return (gchar_t*)(((unsigned long long)hi << 32) | lo);
     };
-    float4 bring[U8][NP];
-#pragma unroll
-    for (int g = 0; g < U8; ++g) bload(bring[g], 0, 0, g);
+    gchar_t* const pb0 = uniform_ptr(m.bm + m.cls[c_first].bm_off);
+    gchar_t* const pb1 = uniform_ptr(m.bm + m.cls[NC > 1 && n_cls > 1 ? c_first + 1 : c_first].bm_off);
+    gchar_t* const pb2 = uniform_ptr(m.bm + m.cls[NC > 2 && n_cls > 2 ? c_first + 2 : c_first].bm_off);
+    gchar_t* const pb3 = uniform_ptr(m.bm + m.cls[NC > 3 && n_cls > 3 ? c_first + 3 : c_first].bm_off);
+    auto bb = [&](auto iv) -> gchar_t* {
+        constexpr int i = decltype(iv)::value;
+        if constexpr (i == 0) return pb0;
+        else if constexpr (i == 1) return pb1;
+        else if constexpr (i == 2) return pb2;
+        else return pb3;
+    };
+    const unsigned lane_off = (unsigned)lane * 16u;
+    const unsigned tap_stride_b = (unsigned)b_tap_stride * 4u, kg_stride_b = (unsigned)b_kg_stride * 4u;
 
-    int* spx = reinterpret_cast<int*>(patch + rows * cols * PIX);       // source pixel of every patch pixel (see above)
+    f32x4v acc[NC][2];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) { acc[cc][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[cc][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    const int n_chunks = Cin / CH;
+
+    // fragment of (class cc, chunk c, tap tp, k-group g); past a class's last tap: the next class's tap tp - ntaps, past the last
+    // class: the next chunk's — always a load of a valid address (the last ones re-read fragments nobody consumes)
+    auto bload = [&](auto ccv, float4* dst, int c, int tp, int g) {
+        constexpr int cc = decltype(ccv)::value, cn = cc + 1 < NC ? cc + 1 : 0;
+        const int over = tp - ntaps_c[cc];
+        const bool wrap = over >= 0;
+        const bool more = cc + 1 < NC && cc + 1 < n_cls;
+        gchar_t* base = wrap ? (more ? bb(std::integral_constant<int, cn>{}) : pb0) : bb(std::integral_constant<int, cc>{});
+        if (wrap && !more) ++c;
+        if (wrap) {
+            const int nt = more ? ntaps_c[cn] : ntaps_c[0];
+            tp = over < nt ? over : nt - 1;
+        }
+        c = c < n_chunks ? c : n_chunks - 1;
+        base += __builtin_amdgcn_readfirstlane((unsigned)tp * tap_stride_b + (unsigned)(c * U8 + g) * kg_stride_b);
+        unsigned lo = lane_off;
+        asm volatile("" : "+s"(base), "+v"(lo));                       // SGPR pair + 32-bit lane offset: global_load v, v_lo, s[base] offset:...
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_bit_cast(float4, *(gfloat4_t*)(base + lo + pl * 1024));
+    };
+    // B fragments: a ring of RT taps (Round 5).  With one k-group per tap (16-channel chunks) the single-slot ring requested a
+    // tap's fragments 12 MFMAs (192 cycles) before their use — every tap waited out an L2 round trip: the MFMA loop was 31 of the
+    // kernel's 56 us for 6 us of MFMAs (profiles/r05_mfma16_probes.txt).  Slot j holds tap j of a group of RT taps and is refilled,
+    // right after its MFMAs, with tap j of the NEXT group (of the next class behind a class's last group, of the next chunk behind
+    // the last class) — RT - 1 taps of MFMAs ahead of its use, all slot indices static.
+    constexpr int RT = U8 == 1 ? 4 : 2;
+    float4 bring[RT][U8][NP];
+#pragma unroll
+    for (int j = 0; j < RT; ++j)
+#pragma unroll
+        for (int g = 0; g < U8; ++g) bload(std::integral_constant<int, 0>{}, bring[j][g], 0, j, g);
+
+    // source pixel of every patch pixel as the BYTE offset of its channel 0 in x1 (spx) / x2 (spx2), -1: a zero — as in the
+    // 32-column kernel (Round 5: this kernel still had the round-2 gather — a pixel-index table, a 64-bit multiply-add and a
+    // division per slot, every load inside its own branch)
+    const int npatch = rows * cols;
+    int* spx = reinterpret_cast<int*>(patch + npatch * PIX);
+    int* spx2 = spx + npatch;
     const unsigned cols_magic = 0xFFFFFFFFu / (unsigned)cols + 1u;    // ceil(2^32 / cols): exact quotients for p < 2^16
-    for (int p = t; p < rows * cols; p += 256) {
+    for (int p = t; p < npatch; p += 256) {
         const int py = (int)__umulhi((unsigned)p, cols_magic), px = p - py * cols;        // p / cols, p % cols
         long sp;
-        spx[p] = conv::src_pixel(a, b, vy0 + py, vx0 + px, &sp) ? (int)sp : -1;
+        const bool in = conv::src_pixel(a, b, vy0 + py, vx0 + px, &sp);
+        spx[p] = in ? (int)sp * a.C1 * (int)sizeof(act2_t) : -1;
+        spx2[p] = in ? (int)sp * a.C2 * (int)sizeof(act2_t) : -1;
     }
+    // a thread owns a fixed channel pair (256 % Q == 0) and walks the patch pixels tp0, tp0 + PPR, ...: its source tensor, table and
+    // channel offset are fixed per chunk (a 32-channel chunk of dec5 spans BOTH sources of the concatenation: per thread, not
+    // per wave); GU unconditional loads in flight per thread (offset clamped, value masked afterwards)
+    constexpr int PPR = 256 / Q, GU = PR == 2 ? 8 : 4;
+    static_assert(256 % Q == 0, "a thread owns a fixed channel pair");
+    const int tq = t % Q, tp0 = t / Q;
 
+    if (DCS_EXP_M16 & 8) { __syncthreads(); return; }
     for (int ch = 0; ch < n_chunks; ++ch) {
         __syncthreads();
-        constexpr int GU = 4;
-        for (int base = t; base < nslots; base += 256 * GU) {
-            float4 v[GU];
-            int spv[GU];
+        if (!(DCS_EXP_M16 & 4)) {
+            const int c = ch * CH + 2 * tq;
+            const bool first = c < a.C1;
+            const char* const xb = first ? reinterpret_cast<const char*>(a.x1) : reinterpret_cast<const char*>(a.x2);
+            const int* const tb = first ? spx : spx2;
+            const unsigned cb = (unsigned)(first ? c : c - a.C1) * (unsigned)sizeof(act2_t);
+            for (int pb = tp0; pb < npatch; pb += GU * PPR) {
+                int o[GU], pp[GU];
+                float4 v[GU];
 #pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int idx = base + u * 256;
-                spv[u] = idx < nslots ? spx[idx / Q] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int idx = base + u * 256;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (spv[u] >= 0) {
-                    const int c = ch * CH + 2 * (idx % Q);
-                    const act2_t* src = (c < a.C1) ? a.x1 + (long)spv[u] * a.C1 + c : a.x2 + (long)spv[u] * a.C2 + (c - a.C1);
-                    v[u] = dcs_ld4(reinterpret_cast<const act_t*>(src));       // (bf16 activations: widened; PR = 1 narrows exactly again)
+                for (int u = 0; u < GU; ++u) {                          // (past the end: the last pixel again — same data, same place)
+                    pp[u] = pb + u * PPR < npatch ? pb + u * PPR : npatch - 1;
+                    o[u] = tb[pp[u]];
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int idx = base + u * 256;
-                if (idx >= nslots) continue;
-                if (PR == 1) {                                         // 2 complex -> 4 bf16 (round to nearest even)
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                    const bf16x4 h = {(__bf16)v[u].x, (__bf16)v[u].y, (__bf16)v[u].z, (__bf16)v[u].w};
-                    *reinterpret_cast<bf16x4*>(patch + (idx / Q) * PIX + (idx % Q) * 2) = h;
-                } else if (PR == 2) {                                  // 2 complex -> 3 planes of 4 bf16 (exact split)
-                    // (by pairs, as the 32-column kernel's gather: one packed conversion per pair and plane — element by element
-                    // the compiler emitted a single-operand conversion per value plus the repacking)
-                    float4 r = v[u];
-                    float* dst = patch + (idx / Q) * PIX + (idx % Q) * 2;
-                    uint2 h0, h1, h2;
-                    h0.x = dcs_split_pair(r.x, r.y); h0.y = dcs_split_pair(r.z, r.w);
-                    h1.x = dcs_split_pair(r.x, r.y); h1.y = dcs_split_pair(r.z, r.w);
-                    h2.x = dcs_pack_bf16x2(r.x, r.y); h2.y = dcs_pack_bf16x2(r.z, r.w);
-                    *reinterpret_cast<uint2*>(dst) = h0;
-                    *reinterpret_cast<uint2*>(dst + CH) = h1;
-                    *reinterpret_cast<uint2*>(dst + 2 * CH) = h2;
-                } else {
-                    *reinterpret_cast<float4*>(patch + (idx / Q) * PIX + (idx % Q) * 4) = v[u];
+                for (int u = 0; u < GU; ++u)
+                    v[u] = dcs_ld4(reinterpret_cast<const act_t*>(xb + ((unsigned)(o[u] < 0 ? 0 : o[u]) + cb)));   // (bf16 activations: widened)
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const unsigned keep = o[u] < 0 ? 0u : 0xffffffffu;
+                    float4 r = make_float4(__uint_as_float(__float_as_uint(v[u].x) & keep), __uint_as_float(__float_as_uint(v[u].y) & keep),
+                                           __uint_as_float(__float_as_uint(v[u].z) & keep), __uint_as_float(__float_as_uint(v[u].w) & keep));
+                    float* const dst = patch + pp[u] * PIX + tq * (PR != 0 ? 2 : 4);
+                    if (PR == 1) {                                     // 2 complex -> 4 bf16 (round to nearest even; exact on bf16-stored values)
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(dcs_pack_bf16x2(r.x, r.y), dcs_pack_bf16x2(r.z, r.w));
+                    } else if (PR == 2) {                              // 2 complex -> 3 planes of 4 bf16 (exact split)
+                        uint2 h0, h1, h2;
+                        h0.x = dcs_split_pair(r.x, r.y); h0.y = dcs_split_pair(r.z, r.w);
+                        h1.x = dcs_split_pair(r.x, r.y); h1.y = dcs_split_pair(r.z, r.w);
+                        h2.x = dcs_pack_bf16x2(r.x, r.y); h2.y = dcs_pack_bf16x2(r.z, r.w);
+                        *reinterpret_cast<uint2*>(dst) = h0;
+                        *reinterpret_cast<uint2*>(dst + CH) = h1;
+                        *reinterpret_cast<uint2*>(dst + 2 * CH) = h2;
+                    } else {
+                        *reinterpret_cast<float4*>(dst) = r;
+                    }
                 }
             }
         }
         __syncthreads();
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int tapoff = ((tap / k.kw) * cols + (tap % k.kw)) * PIX;
+        // (one call per class with a COMPILE-TIME class index: as a loop with an early exit the compiler kept the class index in
+        // a register and put the per-class arrays in scratch)
+        auto run_class = [&](auto ccv) {
+            constexpr int cc = decltype(ccv)::value;
+            const int ntaps = ntaps_c[cc], kw = kw_c[cc];
+            // the A fragments of tap t + 1 are requested ahead of tap t's MFMAs (two register sets alternating by tap: RT is even),
+            // the tap's patch offset advances incrementally (a division per tap before); a 16-cycle MFMA leaves an LDS round trip
+            // and ~40 scalar instructions per tap nowhere to hide
+            float4 af[2][U8][2][NP];
+            // (carried as a patch-PIXEL offset, multiplied by the constexpr pitch at the use: carried in floats the loop phi hid that it
+            // is a multiple of four and every fragment read became two ds_read2_b32 — the trap of the 32-column kernel's Round 4)
+            int tpix = woff_c[cc], tx = 0;                              // patch pixel / kernel column of the tap whose fragments are requested next
+            auto a_read = [&](int set) {
 #pragma unroll
-            for (int g = 0; g < U8; ++g) {
-                if (PR != 0) {
-                    float4 af[2][NP];
+                for (int g = 0; g < U8; ++g)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int pl = 0; pl < NP; ++pl)
-                            af[i][pl] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tapoff + g * 16 + pl * CH);
-                    constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
+                        for (int pl = 0; pl < (PR != 0 ? NP : 1); ++pl)
+                            af[set][g][i][pl] = *reinterpret_cast<const float4*>(patch + pixoff[i] + tpix * PIX + g * 16 + pl * CH);
+                const bool eol = tx + 1 == kw;                          // (past the last tap: a valid, unused address)
+                tpix += eol ? cols - (kw - 1) : 1;
+                tx = eol ? 0 : tx + 1;
+            };
+            a_read(0);
+            for (int tap0 = 0; tap0 < ntaps; tap0 += RT) {
 #pragma unroll
-                    for (int e = (PR == 2 ? 0 : 5); e < 6; ++e)                                // (PR = 1: the a0 b0 term alone)
+                for (int j = 0; j < RT; ++j) {
+                    const int tap = tap0 + j;
+                    // slot j's next occupant: tap + RT of this class, or — behind this class's last group — tap j of the next one
+                    const int tnext = tap + RT < ntaps ? tap + RT : ntaps + j;
+                    if (tap + 1 < ntaps) a_read((j + 1) & 1);
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, af[i][pa[e] < NP ? pa[e] : 0]),
-                                __builtin_bit_cast(bf16x8, bring[g][pb[e] < NP ? pb[e] : 0]), acc[i], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    bload(bring[g], ch, tap + 1, g);
-                    __builtin_amdgcn_sched_barrier(0);
-                    continue;
+                    for (int g = 0; g < U8; ++g) {
+                        if (tap < ntaps) {
+                            if (PR != 0) {
+                                constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+                                for (int e = (PR == 2 ? 0 : 5); e < 6; ++e)                                // (PR = 1: the a0 b0 term alone)
+#pragma unroll
+                                    for (int i = 0; i < 2; ++i)
+                                        acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                            __builtin_bit_cast(bf16x8, af[j & 1][g][i][pa[e] < NP ? pa[e] : 0]),
+                                            __builtin_bit_cast(bf16x8, bring[j][g][pb[e] < NP ? pb[e] : 0]), acc[cc][i], 0, 0, 0);
+                            } else {
+                                const float4 a0 = af[j & 1][g][0][0], a1 = af[j & 1][g][1][0];
+                                const float4 bv = bring[j][g][0];
+                                acc[cc][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv.x, acc[cc][0], 0, 0, 0);
+                                acc[cc][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv.x, acc[cc][1], 0, 0, 0);
+                                acc[cc][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv.y, acc[cc][0], 0, 0, 0);
+                                acc[cc][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv.y, acc[cc][1], 0, 0, 0);
+                                acc[cc][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv.z, acc[cc][0], 0, 0, 0);
+                                acc[cc][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv.z, acc[cc][1], 0, 0, 0);
+                                acc[cc][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv.w, acc[cc][0], 0, 0, 0);
+                                acc[cc][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[cc][1], 0, 0, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        bload(ccv, bring[j][g], ch, tnext, g);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                const float4 a0 = *reinterpret_cast<const float4*>(patch + pixoff[0] + tapoff + g * 16);
-                const float4 a1 = *reinterpret_cast<const float4*>(patch + pixoff[1] + tapoff + g * 16);
-                const float4 bv = bring[g][0];
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv.x, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv.y, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv.y, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv.z, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv.z, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv.w, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                bload(bring[g], ch, tap + 1, g);                       // same slot, next tap (U8 iterations ahead)
-                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if (!(DCS_EXP_M16 & 2)) run_class(std::integral_constant<int, 0>{});
+        if constexpr (NC > 1 && !(DCS_EXP_M16 & 2)) {
+            if (n_cls > 1) run_class(std::integral_constant<int, 1>{});
+            if (n_cls > 2) run_class(std::integral_constant<int, 2>{});
+            if (n_cls > 3) run_class(std::integral_constant<int, 3>{});
         }
     }
 
@@ -1029,40 +1147,55 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
         const float* q = a.coef + 6 * (n >> 1);
         if (n & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
     }
-    float s1 = 0.f, s2 = 0.f, sri = 0.f;                               // CBN statistics of the raw output (a.stat)
+    auto store_class = [&](auto ccv) {
+        constexpr int cc = decltype(ccv)::value;
+        const conv::Cls& k = m.cls[c_first + cc];
+        float* const stat_row = a.stat ? a.stat + ((long)(c_first + cc) * gridDim.x + blockIdx.x) : nullptr;   // (Cout = 8: 40 sums)
+        float s1 = 0.f, s2 = 0.f, sri = 0.f;                           // CBN statistics of the raw output (a.stat)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pi = wave * 32 + i * 16 + g4 * 4 + r;
-            const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
-            if (stat_row) {                                            // (uniform) moments of the UN-biased value
-                const float raw = (oy < k.Hc && ox < k.Wc) ? acc[i][r] : 0.f;
-                s1 += raw; s2 = fmaf(raw, raw, s2); sri = fmaf(raw, dcs_dpp_term<0xB1, 0xf>(raw), sri);
+            for (int r = 0; r < 4; ++r) {
+                const int pi = wave * 32 + i * 16 + g4 * 4 + r;
+                const int oy = oy0 + (pi >> m.twshift), ox = ox0 + (pi & (m.TW - 1));
+                if (stat_row) {                                        // (uniform) moments of the UN-biased value
+                    const float raw = (oy < k.Hc && ox < k.Wc) ? acc[cc][i][r] : 0.f;
+                    s1 += raw; s2 = fmaf(raw, raw, s2); sri = fmaf(raw, dcs_dpp_term<0xB1, 0xf>(raw), sri);
+                }
+                float v = acc[cc][i][r] + bv;
+                if (a.coef) {
+                    const float pv = dcs_dpp_term<0xB1, 0xf>(v);
+                    v = (n & 1) ? fmaf(c_re, pv, fmaf(c_im, v, c_add)) : fmaf(c_re, v, fmaf(c_im, pv, c_add));
+                }
+#if DCS_EXP_M16 & 1
+                if (oy < k.Hc && ox < k.Wc && v == 123456.f)          // (timing probe: no output stores)
+#else
+                if (oy < k.Hc && ox < k.Wc)
+#endif
+                    dcs_st1(yb + ((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col, dcs_act(v, a.act));
             }
-            float v = acc[i][r] + bv;
-            if (a.coef) {
-                const float pv = dcs_dpp_term<0xB1, 0xf>(v);
-                v = (n & 1) ? fmaf(c_re, pv, fmaf(c_im, v, c_add)) : fmaf(c_re, v, fmaf(c_im, pv, c_add));
-            }
-            if (oy < k.Hc && ox < k.Wc)
-                dcs_st1(yb + ((oy * m.os_f + k.oo_f) * a.Wout + ox * m.os_t + k.oo_t) * width + col, dcs_act(v, a.act));
-        }
-    if (stat_row) {
-        // column li of 4 row groups (lanes li + 16 g4) x 4 waves: shuffles over g4, then LDS over the waves
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); sri += __shfl_xor(sri, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); sri += __shfl_xor(sri, 32, 64);
-        __syncthreads();                                               // every wave is done with the patch
-        if (lane < 16) { patch[(wave * 16 + li) * 3] = s1; patch[(wave * 16 + li) * 3 + 1] = s2; patch[(wave * 16 + li) * 3 + 2] = sri; }
-        __syncthreads();
-        if (t < 40) {                                                  // channel c: {S_r, S_i, S_rr, S_ii, S_ri}
-            const int c = t / 5, e = t % 5;
-            const int colx = 2 * c + (e == 1 || e == 3), which = e < 2 ? 0 : (e < 4 ? 1 : 2);
-            float sum = 0.f;
+        if (stat_row) {
+            // column li of 4 row groups (lanes li + 16 g4) x 4 waves: shuffles over g4, then LDS over the waves
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); sri += __shfl_xor(sri, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); sri += __shfl_xor(sri, 32, 64);
+            __syncthreads();                                           // every wave is done with the patch (and with the previous class's sums)
+            if (lane < 16) { patch[(wave * 16 + li) * 3] = s1; patch[(wave * 16 + li) * 3 + 1] = s2; patch[(wave * 16 + li) * 3 + 2] = sri; }
+            __syncthreads();
+            if (t < 40) {                                              // channel c: {S_r, S_i, S_rr, S_ii, S_ri}
+                const int c = t / 5, e = t % 5;
+                const int colx = 2 * c + (e == 1 || e == 3), which = e < 2 ? 0 : (e < 4 ? 1 : 2);
+                float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) sum += patch[(w * 16 + colx) * 3 + which];
-            stat_row[(long)t * a.stat_stride] = sum;
+                for (int w = 0; w < 4; ++w) sum += patch[(w * 16 + colx) * 3 + which];
+                stat_row[(long)t * a.stat_stride] = sum;
+            }
         }
+    };
+    store_class(std::integral_constant<int, 0>{});
+    if constexpr (NC > 1) {
+        if (n_cls > 1) store_class(std::integral_constant<int, 1>{});
+        if (n_cls > 2) store_class(std::integral_constant<int, 2>{});
+        if (n_cls > 3) store_class(std::integral_constant<int, 3>{});
     }
 }
 
@@ -1215,16 +1348,36 @@ int launch(MArgs& m, const Plan& p, long npix, hipStream_t stream) {
     }
 }
 
-template <int CH, int PR = 0>
-int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
+template <int CH, int PR, bool FUSE>
+int launch16_f(MArgs& m, long npix, hipStream_t stream) {
     const conv::Args& a = m.c;
-    const size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH : PR == 1 ? CH : 2 * CH) + 4 + 1) * sizeof(float);   // patch + source-pixel table
-    auto fn = cconv_mfma16_kernel<CH, PR>;
+    const size_t lds = (size_t)npix * ((PR == 2 ? 3 * CH : PR == 1 ? CH : 2 * CH) + 8 + 2) * sizeof(float);   // patch + the two source-offset tables
+    auto fn = cconv_mfma16_kernel<CH, PR, FUSE>;
     if (dcs_ensure_dynamic_lds((const void*)fn, lds) != hipSuccess) return DCS_ERR_LAUNCH;
-    dim3 grid(a.tiles_w * a.tiles_h * a.B, 1, m.ncls);
+    dim3 grid(a.tiles_w * a.tiles_h * a.B, 1, FUSE ? 1 : m.ncls);
     DCS_LAUNCH(fn, grid, dim3(256), lds, stream, m);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
+}
+
+// all classes of a tile in one workgroup (cconv_mfma16_kernel, FUSE) where the union window's patch keeps two workgroups on a CU
+// (DCS_CLASS_FUSE=0: one workgroup per class, the form of rounds 2-4)
+template <int CH, int PR = 0>
+int launch16_ch(MArgs& m, long npix, hipStream_t stream) {
+    static const int fuse_on = [] { const char* e = getenv("DCS_CLASS_FUSE"); return e ? atoi(e) : 1; }();
+    if (fuse_on && m.ncls > 1) {
+        const conv::Args& a = m.c;
+        int pmf = 0, pmt = 0, ext_f = 0, ext_t = 0;
+        for (int c = 0; c < m.ncls; ++c) {
+            const conv::Cls& k = m.cls[c];
+            pmf = k.pad_f > pmf ? k.pad_f : pmf; pmt = k.pad_t > pmt ? k.pad_t : pmt;
+            ext_f = k.kh - k.pad_f > ext_f ? k.kh - k.pad_f : ext_f; ext_t = k.kw - k.pad_t > ext_t ? k.kw - k.pad_t : ext_t;
+        }
+        const long npix_u = (long)((m.TH - 1) * a.sf + pmf + ext_f) * ((m.TW - 1) * a.st + pmt + ext_t);
+        const long bytes = npix_u * ((PR == 2 ? 3 * CH : PR == 1 ? CH : 2 * CH) + 8 + 2) * (long)sizeof(float);
+        if (bytes <= 80L * 1024) return launch16_f<CH, PR, true>(m, npix_u, stream);
+    }
+    return launch16_f<CH, PR, false>(m, npix, stream);
 }
 
 struct Cand { int bm, bn, wk; };
