@@ -44,6 +44,7 @@ SWITCHES = [
     ('first encoder conv on the fp32 MFMA', {'DCS_ENC0_F32': '1'}, (), False),
     ('cotangent split inside the weight-gradient kernel', {'DCS_WGRAD_PA_MIN_CHUNKS': '999'}, (), False),
     ('producer / consumer conv kernel', {'DCS_CONV_RING': '1', 'DCS_RING_MIN_WG': '1'}, (), False),
+    ('16-column kernel: one workgroup per class', {'DCS_CLASS_FUSE': '0'}, (), False),
     ('one stream', {'DCS_WGRAD_SIDE': '0'}, (), True),
     ('every slab reduction as its own launch', {'DCS_WGRAD_DEFER': '0'}, (), False),
     ('CBN statistics by their own kernels', {'DCS_STATS_EPILOGUE': '0'}, (), False),
