@@ -1,3 +1,5 @@
+# NOTE (round 5): the DCS_MFMA_* thresholds are compile-time constants in the shipped library (csrc/dcs_common.h: dcs_knob).  Sweep with a
+# diagnostic build:  python tools/exp_build.py knobs conv_mfma.hip -DDCS_PLAN_KNOBS ; export DCS_LIB_PATH=$PWD/dcs-net_amd/lib/exp/libdcsnet_hip_knobs.so
 # plan-threshold sweep for the bf16-storage train step at B = 64 (BASELINE configs[4] per-GPU share): one bench run per setting
 out=gpurun_out/$1; mkdir -p $out
 run() { name=$1; shift; env "$@" python bench.py --dtype bf16 --batch 64 --no-cpu-baseline --no-native-line --steps 20 > $out/$name.json 2>/dev/null; python -c "

@@ -1,4 +1,6 @@
-"""How much of a gradient tensor's distance to the fp64 oracle at the bench size is NOISE?  The same train step
+"""NOTE (round 5): the DCS_MFMA_* variants below need a library built with -DDCS_PLAN_KNOBS (tools/exp_build.py; csrc/dcs_common.h: dcs_knob)
+exported through DCS_LIB_PATH; the shipped library ignores those variables.
+How much of a gradient tensor's distance to the fp64 oracle at the bench size is NOISE?  The same train step
 ([32,256,256], dropout off) is evaluated by numerically equivalent variants — the HIP path under different kernel plans /
 arithmetic modes (environment toggles, one process each) and the CPU fp32 oracle with different thread counts (different
 reduction orders) — and every tensor's relative L2 error against the fp64 oracle is listed per variant.
