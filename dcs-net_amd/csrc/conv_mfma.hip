@@ -926,7 +926,6 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
         pixoff[i] = ((((pi >> m.twshift)) * a.sf) * cols + ((pi & (m.TW - 1))) * a.st) * PIX + g4 * 4;
     }
     const long b_tap_stride = PR != 0 ? (long)(Cin / 16) * NP * 256 : (long)(Cin / 8) * 256, b_kg_stride = PR != 0 ? NP * 256 : 256;
-    // per class (static indices: the class loops below are unrolled): panel base, tap count, kernel width, window offset
     // per class (static indices: the class bodies below are instantiated per class): tap count, kernel width, window offset
     int ntaps_c[NC], kw_c[NC], woff_c[NC];
 #pragma unroll
@@ -935,9 +934,10 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
         ntaps_c[cc] = kc.kh * kc.kw; kw_c[cc] = kc.kw;
         woff_c[cc] = (pmf - kc.pad_f) * cols + (pmt - kc.pad_t);          // (in patch pixels)
     }
-    // The B fragment addresses are wave-uniform up to the lane's 16 bytes: panel base (SGPR pair) + a 32-bit scalar byte offset + one
-    // constant lane-offset VGPR (as the 32-column kernel's SCALAR_B).  As per-lane 64-bit pointers every tap paid ~25 scalar and ~20
-    // vector instructions of address arithmetic — 3.8 SALU + 3.6 VALU per 16-cycle MFMA over the whole kernel.
+    // The B fragment addresses are wave-uniform up to the lane's 16 bytes: RUNNING scalar pointers (one per ring slot) + one constant
+    // lane-offset VGPR.  Round 5: computed from scratch per load — class / chunk wrap, clamps, 64-bit multiplies, per-lane 64-bit
+    // pointers — every tap carried ~35 scalar and ~20 vector instructions of bookkeeping: 3.8 SALU + 3.6 VALU per 16-cycle MFMA
+    // over the whole kernel, issue-bound at twice its MFMA time (profiles/r05_mfma16_probes.txt).
     typedef __attribute__((address_space(1))) const char gchar_t;
     typedef float f32x4n __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(1))) const f32x4n gfloat4_t;
@@ -965,37 +965,30 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
     for (int cc = 0; cc < NC; ++cc) { acc[cc][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[cc][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
     const int n_chunks = Cin / CH;
 
-    // fragment of (class cc, chunk c, tap tp, k-group g); past a class's last tap: the next class's tap tp - ntaps, past the last
-    // class: the next chunk's — always a load of a valid address (the last ones re-read fragments nobody consumes)
-    auto bload = [&](auto ccv, float4* dst, int c, int tp, int g) {
-        constexpr int cc = decltype(ccv)::value, cn = cc + 1 < NC ? cc + 1 : 0;
-        const int over = tp - ntaps_c[cc];
-        const bool wrap = over >= 0;
-        const bool more = cc + 1 < NC && cc + 1 < n_cls;
-        gchar_t* base = wrap ? (more ? bb(std::integral_constant<int, cn>{}) : pb0) : bb(std::integral_constant<int, cc>{});
-        if (wrap && !more) ++c;
-        if (wrap) {
-            const int nt = more ? ntaps_c[cn] : ntaps_c[0];
-            tp = over < nt ? over : nt - 1;
-        }
-        c = c < n_chunks ? c : n_chunks - 1;
-        base += __builtin_amdgcn_readfirstlane((unsigned)tp * tap_stride_b + (unsigned)(c * U8 + g) * kg_stride_b);
+    // the fragments of one tap (all k-groups, all planes) from a wave-uniform address
+    auto bfetch = [&](float4 (*dst)[NP], gchar_t* src) {
         unsigned lo = lane_off;
-        asm volatile("" : "+s"(base), "+v"(lo));                       // SGPR pair + 32-bit lane offset: global_load v, v_lo, s[base] offset:...
+        asm volatile("" : "+s"(src), "+v"(lo));                        // SGPR pair + 32-bit lane offset: global_load v, v_lo, s[src] offset:...
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_bit_cast(float4, *(gfloat4_t*)(base + lo + pl * 1024));
+        for (int g = 0; g < U8; ++g)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                dst[g][pl] = __builtin_bit_cast(float4, *(gfloat4_t*)(src + lo + (g * NP + pl) * 1024));
     };
-    // B fragments: a ring of RT taps (Round 5).  With one k-group per tap (16-channel chunks) the single-slot ring requested a
-    // tap's fragments 12 MFMAs (192 cycles) before their use — every tap waited out an L2 round trip: the MFMA loop was 31 of the
-    // kernel's 56 us for 6 us of MFMAs (profiles/r05_mfma16_probes.txt).  Slot j holds tap j of a group of RT taps and is refilled,
-    // right after its MFMAs, with tap j of the NEXT group (of the next class behind a class's last group, of the next chunk behind
-    // the last class) — RT - 1 taps of MFMAs ahead of its use, all slot indices static.
+    // B fragments: a ring of RT taps.  Slot j holds tap j of a group of RT taps of the current class and is refilled, right after
+    // its MFMAs, with tap j of the NEXT group — of the next class behind a class's last group, of the next chunk behind the last
+    // class — RT - 1 taps of MFMAs ahead of its use; all slot indices static.  (With one k-group per tap the single-slot ring of
+    // rounds 2-4 requested a tap's fragments 192 cycles before their use.)
     constexpr int RT = U8 == 1 ? 4 : 2;
     float4 bring[RT][U8][NP];
+    // address of (class base, chunk c, tap tp): tp clamped to the class's taps (a slot past them is never consumed)
+    auto baddr = [&](gchar_t* base, int nt, int c, int tp) -> gchar_t* {
+        tp = tp < nt ? tp : nt - 1;
+        c = c < n_chunks ? c : n_chunks - 1;
+        return base + ((unsigned)tp * tap_stride_b + (unsigned)(c * U8) * kg_stride_b);
+    };
 #pragma unroll
-    for (int j = 0; j < RT; ++j)
-#pragma unroll
-        for (int g = 0; g < U8; ++g) bload(std::integral_constant<int, 0>{}, bring[j][g], 0, j, g);
+    for (int j = 0; j < RT; ++j) bfetch(bring[j], baddr(pb0, ntaps_c[0], 0, j));
 
     // source pixel of every patch pixel as the BYTE offset of its channel 0 in x1 (spx) / x2 (spx2), -1: a zero — as in the
     // 32-column kernel (Round 5: this kernel still had the round-2 gather — a pixel-index table, a 64-bit multiply-add and a
@@ -1064,14 +1057,22 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
         // (one call per class with a COMPILE-TIME class index: as a loop with an early exit the compiler kept the class index in
         // a register and put the per-class arrays in scratch)
         auto run_class = [&](auto ccv) {
-            constexpr int cc = decltype(ccv)::value;
+            constexpr int cc = decltype(ccv)::value, cn = cc + 1 < NC ? cc + 1 : 0;
             const int ntaps = ntaps_c[cc], kw = kw_c[cc];
-            // the A fragments of tap t + 1 are requested ahead of tap t's MFMAs (two register sets alternating by tap: RT is even),
-            // the tap's patch offset advances incrementally (a division per tap before); a 16-cycle MFMA leaves an LDS round trip
-            // and ~40 scalar instructions per tap nowhere to hide
+            // where the slots reload from: this class's tap j + RT, + RT per group ...
+            const bool more = cc + 1 < NC && cc + 1 < n_cls;
+            gchar_t* bp[RT];
+            gchar_t* nb[RT];                                            // ... and, behind the class's last group, tap j of the next class (chunk)
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+                bp[j] = baddr(bb(ccv), ntaps, ch, j + RT);
+                nb[j] = more ? baddr(bb(std::integral_constant<int, cn>{}), ntaps_c[cn], ch, j) : baddr(pb0, ntaps_c[0], ch + 1, j);
+            }
+            // the A fragments of tap t + 1 are requested ahead of tap t's MFMAs (two register sets alternating by tap: RT is even), the
+            // tap's patch offset advances incrementally.  (carried as a patch-PIXEL offset, multiplied by the constexpr pitch at the
+            // use: carried in floats the loop phi hid that it is a multiple of four and every fragment read became two ds_read2_b32 —
+            // the trap of the 32-column kernel's Round 4)
             float4 af[2][U8][2][NP];
-            // (carried as a patch-PIXEL offset, multiplied by the constexpr pitch at the use: carried in floats the loop phi hid that it
-            // is a multiple of four and every fragment read became two ds_read2_b32 — the trap of the 32-column kernel's Round 4)
             int tpix = woff_c[cc], tx = 0;                              // patch pixel / kernel column of the tap whose fragments are requested next
             auto a_read = [&](int set) {
 #pragma unroll
@@ -1090,12 +1091,11 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
 #pragma unroll
                 for (int j = 0; j < RT; ++j) {
                     const int tap = tap0 + j;
-                    // slot j's next occupant: tap + RT of this class, or — behind this class's last group — tap j of the next one
-                    const int tnext = tap + RT < ntaps ? tap + RT : ntaps + j;
                     if (tap + 1 < ntaps) a_read((j + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);                  // (the reads stay AHEAD of this tap's MFMAs: left free they sink to their use)
+                    if (tap < ntaps) {
 #pragma unroll
-                    for (int g = 0; g < U8; ++g) {
-                        if (tap < ntaps) {
+                        for (int g = 0; g < U8; ++g) {
                             if (PR != 0) {
                                 constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
 #pragma unroll
@@ -1118,10 +1118,12 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
                                 acc[cc][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[cc][1], 0, 0, 0);
                             }
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        bload(ccv, bring[j][g], ch, tnext, g);
-                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // slot j's next occupant: tap + RT of this class, or — behind this class's last group — tap j of the next one
+                    bfetch(bring[j], tap + RT < ntaps ? bp[j] : nb[j]);
+                    bp[j] += RT * tap_stride_b;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         };
@@ -1147,6 +1149,10 @@ __global__ __launch_bounds__(256) void cconv_mfma16_kernel(MArgs m) {
         const float* q = a.coef + 6 * (n >> 1);
         if (n & 1) { c_re = q[2]; c_im = q[3]; c_add = q[5]; } else { c_re = q[0]; c_im = q[1]; c_add = q[4]; }
     }
+    // (Measured and dropped, Round 5: the four classes' outputs assembled in an LDS image of the output tile and stored as 16-byte
+    // pieces of whole 2-KB rows instead of 8 dword stores per lane and class that each touch four 64-byte half lines — same box:
+    // dec5 forward 46.5 -> 49.9 us, enc1 data gradient 54.5 -> 57.5 us: the extra barrier pair, LDS round trip and address
+    // arithmetic cost more than the half-line stores, which the L2 merges: profiles/r05_mfma16_probes.txt.)
     auto store_class = [&](auto ccv) {
         constexpr int cc = decltype(ccv)::value;
         const conv::Cls& k = m.cls[c_first + cc];
