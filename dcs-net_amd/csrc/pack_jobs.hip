@@ -217,6 +217,11 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const Job* __restrict__
     run(jobs[lo], (b - blk0[lo]) * 256 + (int)threadIdx.x);
 }
 
+// (Measured and dropped, Round 5: the whole plan in ONE launch — every job carried the chain of producers behind its source
+// (DIRECT <- BWD <- FOLD <- MFMA, at most four deep) and re-derived each panel element it reads from the parameters themselves, so
+// that no job read what another job of the launch wrote.  Bit-identical panels, 4 launches -> 1 — and the step 65 us SLOWER
+// (3.587 vs 3.521 ms, same box, three runs each): an MFMA element of a folded data-gradient panel costs 16 parameter reads and
+// four levels of runtime index divisions instead of 4 panel reads; the level form's launches are cheaper than the recomputation.)
 struct Level { Job* d_jobs = nullptr; int* d_blk0 = nullptr; int nj = 0, nblocks = 0; };
 struct Plan { std::vector<Level> levels; int njobs = 0; };
 
