@@ -219,7 +219,20 @@ class C_NETWORK(LightningModule):
         # every encoder stage output has TWO consumers (the next stage — the LSTM for the last one — and a skip attention):
         # `enc` serves the first, `enc_skip` the second; with autograd on they are two tensors over one storage, so the
         # two cotangents reach the CBN backward kernels separately and are summed there (F._CbnTwoFn)
+        # dp.TrainStep's weight re-layout for this step, left for this point: on its own stream (behind the event recorded when
+        # the step began) beside the initial CBN, joined before the first convolution reads a packed weight
+        fork = self.__dict__.pop('_dcs_pack_fork', None)
+        if fork is not None:
+            cur = torch.cuda.current_stream(x.device)
+            ps = self.__dict__.get('_pack_stream')
+            if ps is None:
+                ps = self.__dict__['_pack_stream'] = torch.cuda.Stream(device=x.device)
+            ps.wait_event(fork[0])
+            with torch.cuda.stream(ps):
+                F.run_pack_plan(fork[1])
         enc = [self._bn(self.initial_batchnorm, e, F.ACT_NONE)]
+        if fork is not None:
+            cur.wait_stream(ps)
         adt = self.activation_dtype
         if adt != torch.float32:                             # bf16 activation storage (set_activation_dtype): everything between
             enc[0] = enc[0].to(adt)                          # the initial CBN and the last decoder conv lives in bf16 in HBM
@@ -368,6 +381,7 @@ class C_NETWORK(LightningModule):
     batch_skip_attention = True
     skip_attention_early = int(os.environ.get('DCS_SKIP_EARLY', '4'))     # inference: encoder outputs whose skip attentions start early (0: none)
     supports_unbounded_forward = True      # forward(x, bound=False): see forward
+    accepts_pack_fork = True               # forward issues dp.TrainStep's pending weight re-layout on a side stream
     activation_dtype = torch.float32
 
     def set_activation_dtype(self, dtype):

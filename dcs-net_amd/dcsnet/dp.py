@@ -201,7 +201,7 @@ class TrainStep:
     set).  The batch is copied into static buffers before each replay; a batch whose shape differs from the captured one
     runs eagerly.  Any capture failure falls back to eager execution, loudly."""
 
-    def __init__(self, net, optimizer_cls=FusedAdam, use_graph=False, graph_warmup=3, use_pack_plan=True):
+    def __init__(self, net, optimizer_cls=FusedAdam, use_graph=False, graph_warmup=3, use_pack_plan=True, pack_fork=True):
         hp = net.hparams
         self.net = net
         self.bucket = FlatBucket(net)
@@ -216,6 +216,7 @@ class TrainStep:
             ops.SEED_STATE = self.seed_state
         self._graph = self._graph_opt = self._static_batch = self._static_loss = None
         self.use_pack_plan, self._plan = bool(use_pack_plan), None
+        self.pack_fork = bool(pack_fork)
         self._calls = 0
         # weight-gradient kernels on a side stream beside the data-gradient chain (functional._CConv2dFn.backward): same kernels,
         # same results; DCS_WGRAD_SIDE=0 keeps the step on one stream (same-box A/B: profiles/r04_side_stream_ab.txt)
@@ -335,7 +336,16 @@ class TrainStep:
         guard).  With world > 1 it stops before the all-reduce (the collective and the optimizer half follow outside)."""
         from . import functional
         if self._plan is not None:
-            functional.run_pack_plan(self._plan)
+            if self.pack_fork and getattr(self.net, 'accepts_pack_fork', False):
+                # the weight re-layout (4 launches, ~70 us, reads only what Adam wrote) on its own stream beside the part of the
+                # step that needs no weights: the target synthesis and the initial CBN.  C_NETWORK.forward issues it — i.e.
+                # AFTER the target kernels in capture order, which is what lets the two branches overlap in a replayed graph
+                # (profiles/r04_side_stream_ab.txt) — and joins before the first convolution.  -20 us / step at B = 32.
+                e0 = torch.cuda.Event()
+                e0.record()
+                self.net.__dict__['_dcs_pack_fork'] = (e0, self._plan)
+            else:
+                functional.run_pack_plan(self._plan)
         self.bucket.zero_grad()
         # the NaN test training_step makes on the host, on the device: flag element of the gradient bucket.  The fused loss
         # assembly writes it in its own launch when handed the flag; any other loss goes through dcs_step_guard.
@@ -346,6 +356,8 @@ class TrainStep:
         finally:
             self.net._dcs_skip_flag = None
             self._counting(False)
+        if self.net.__dict__.pop('_dcs_pack_fork', None) is not None:
+            raise RuntimeError('TrainStep: the step function never reached the network forward; the weight re-layout did not run')
         if not self.net._dcs_skip_written:
             check(_lib.load().dcs_step_guard(ptr(loss), ptr(self.bucket.skip), cur_stream()), 'dcs_step_guard')
         self._backward(loss)

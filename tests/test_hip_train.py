@@ -242,6 +242,32 @@ def test_pack_plan_step_is_bit_identical_to_per_layer_packing(dev):
     assert torch.equal(ts0.bucket.flat, ts1.bucket.flat)
 
 
+@pytest.mark.parametrize('graph', [False, True], ids=['uncaptured', 'graph'])
+def test_weight_relayout_on_its_own_stream_changes_nothing(dev, graph):
+    """dp.TrainStep(pack_fork=True): the step's weight re-layout runs on a side stream beside the target synthesis and the
+    initial CBN and is joined before the first convolution — same parameters, same losses as the in-line order, eager and
+    replayed (dropout on: the two runs draw the same seeds from the same seed state)."""
+    from dcsnet.config import config, hparams
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    clean, noise = seeded_input(2, 256, 32, 1, 0.1), seeded_input(2, 256, 32, 2, 0.05)
+    batch = (noise.to(dev), (clean + noise).to(dev), clean.to(dev), [0, 1])
+    runs = []
+    for fork in (False, True):
+        net = fill_state(C_NETWORK(config, hparams, 0), 2).to(dev).train()
+        ts = TrainStep(net, use_graph=graph, graph_warmup=1, pack_fork=fork)
+        if graph:
+            losses = [float(ts(batch)) for _ in range(5)]
+        else:                                  # the graph's launches issued eagerly (the first call records the plan)
+            losses = [float(ts(batch))] + [float(ts.uncaptured_step(batch)) for _ in range(4)]
+        assert '_dcs_pack_fork' not in net.__dict__
+        assert ('_pack_stream' in net.__dict__) == fork
+        runs.append((losses, ts))
+    (l0, ts0), (l1, ts1) = runs
+    assert l0 == l1
+    assert torch.equal(ts0.bucket.flat, ts1.bucket.flat)
+
+
 def test_graph_replay_skips_the_update_on_a_nan_loss(dev):
     """c_network.py:257-261: a NaN loss skips the update.  Under hipGraph replay there is no host test: the loss's NaN
     flag stays on the device and turns the fused optimizer launch into a no-op (parameters, Adam moments and the

@@ -1,6 +1,7 @@
-# usage: ab_env.sh <outdir-tag> "<ENV assignments for B>"   — per-layer conv bench, default (A) vs the environment variant (B), same box
-set -e
-out=gpurun_out/$1; mkdir -p $out
-python tools/conv_layers_bench.py 32 256 > $out/layers_A.txt 2>&1
-env $2 python tools/conv_layers_bench.py 32 256 > $out/layers_B.txt 2>&1
-for v in A B; do echo "== $v"; grep -E "^(enc|dec|total)" $out/layers_$v.txt | awk '{print $1, $6, $11, $16}' | tr '\n' ';'; echo; done
+# usage: ab_env.sh <VAR=value> [bench args...] — bench.py without (A) and with (B) one environment setting, alternating A B A B on the
+# same box; prints ms/step of each run
+for i in 1 2 3; do
+  a=$(timeout -k 10 300 python bench.py --no-cpu-baseline --no-sub-lines --no-native-line "${@:2}" 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
+  b=$(env "$1" timeout -k 10 300 python bench.py --no-cpu-baseline --no-sub-lines --no-native-line "${@:2}" 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
+  echo "A $a   B($1) $b"
+done
