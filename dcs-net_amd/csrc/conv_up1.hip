@@ -123,6 +123,260 @@ __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
     }
 }
 
+
+// ---- backward: data gradient and weight gradient straight from the cotangent (Round 5) ---------------------------------------------
+// The factored backward wrote the nine tap sums of g_y per source pixel as a 16-channel tensor (67 MB at [32,256,256], 7 of the 16
+// channels padding) and ran a 1x1 MFMA conv and its weight gradient over it: 352 MB of traffic, six launches, 100 us.  Here both
+// kernels stage a haloed 18 x 66 tile of g_y in LDS and form the tap sums of a source pixel s in registers — separable over its 4 x 4
+// window of outputs (rows / columns 2s - 1 .. 2s + 2; tap d covers window indices {2 - d, 3 - d}): 12 + 9 complex adds — then
+//   data:    g_x[s][ci]   = sum_tap conj(w[ci][tap]) T[s][tap]              written once, 16 bytes per lane
+//   weight:  g_w[ci][tap] = sum_s conj(x[s][ci]) T[s][tap],  g_b from sum g_y   per-workgroup partial rows, fixed-order reduce
+// so the traffic is g_y + the gradient (84 MB) and g_y + the sources (84 MB).  A thread owns (source pixel, channel quarter): the
+// four lanes of a pixel cover its 128 bytes, 16 consecutive pixels a wave.  Complex MACs run as packed FMAs over channel PAIRS
+// ({c0, c1} in the two halves) with the tap sum as the broadcast operand: the LDS tile holds every g_y element as {r, r, i, i}, so no
+// packed instruction needs a cross-half operand selection (dcs_common.h).
+constexpr int GC = 2 * SCT + 2;                              // cotangent tile: 2 R + 2 rows (R source rows) x 66 columns
+constexpr int WRT = 2;                                       // source rows per tile of the weight-gradient kernel (one item per thread)
+constexpr int kPartRow = 9 * CIN * 2 + 2;                    // [(tap * 16 + ci) * 2 + part], then sum g_r, sum g_i
+
+struct Up1BwdArgs {
+    const float2* gy; const float2* wt; void* gx1; void* gx2;          // data gradient
+    const void* x1; const void* x2; float* part;                       // weight gradient: part[workgroup][kPartRow]
+    int Hs, Ws, C1, C2, ct, tiles_w, tiles, B;
+};
+
+// g_y tile rows 2 m0 - 1 .. 2 m0 + 16, columns 2 n0 - 1 .. 2 n0 + 64 (zeros outside the image) as {r, r, i, i}; SUM: the
+// thread's share of the sum over the tile's INTERIOR (the outputs this tile owns)
+template <int R> struct GTile { static constexpr int GR = 2 * R + 2, NE = GR * GC, NL = (NE + 255) / 256; };
+// the thread's elements of a tile, loaded (clamped address, value selected afterwards) ...
+template <int R>
+__device__ __forceinline__ void up1_gtile_load(const Up1BwdArgs& p, int b, int m0, int n0, int t, float2 (&v)[GTile<R>::NL]) {
+    const int Ho = 2 * p.Hs, Wo = 2 * p.Ws;
+    const float2* img = p.gy + (long)b * Ho * Wo;
+#pragma unroll
+    for (int k = 0; k < GTile<R>::NL; ++k) {
+        const int i = t + 256 * k, r = i / GC, c = i - r * GC;
+        const int oy = 2 * m0 - 1 + r, ox = 2 * n0 - 1 + c;
+        const bool in = i < GTile<R>::NE && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+        const int oyc = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), oxc = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
+        const float2 g = img[(long)oyc * Wo + oxc];
+        v[k] = in ? g : make_float2(0.f, 0.f);
+    }
+}
+// ... and written to LDS
+template <int R, bool SUM>
+__device__ __forceinline__ void up1_gtile_store(float4* __restrict__ gt, int t, const float2 (&v)[GTile<R>::NL], float& sr, float& si) {
+#pragma unroll
+    for (int k = 0; k < GTile<R>::NL; ++k) {
+        const int i = t + 256 * k, r = i / GC, c = i - r * GC;
+        if (i < GTile<R>::NE) gt[i] = make_float4(v[k].x, v[k].x, v[k].y, v[k].y);
+        if (SUM && i < GTile<R>::NE && r >= 1 && r <= 2 * R && c >= 1 && c <= 2 * SCT) { sr += v[k].x; si += v[k].y; }
+    }
+}
+
+// the nine tap sums of the source pixel whose window starts at tile row 2 m, column 2 n: Tr[dy * 3 + dx] = {Re, Re}, Ti = {Im, Im}
+__device__ __forceinline__ void up1_tapsums(const float4* __restrict__ gt, int m, int n, v2f (&Tr)[9], v2f (&Ti)[9]) {
+    v2f hr[4][3], hi[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float4* row = gt + (2 * m + a) * GC + 2 * n;
+        const float4 g0 = row[0], g1 = row[1], g2 = row[2], g3 = row[3];
+        const v2f r0 = v2f{g0.x, g0.y}, r1 = v2f{g1.x, g1.y}, r2 = v2f{g2.x, g2.y}, r3 = v2f{g3.x, g3.y};
+        const v2f i0 = v2f{g0.z, g0.w}, i1 = v2f{g1.z, g1.w}, i2 = v2f{g2.z, g2.w}, i3 = v2f{g3.z, g3.w};
+        hr[a][0] = r2 + r3; hr[a][1] = r1 + r2; hr[a][2] = r0 + r1;
+        hi[a][0] = i2 + i3; hi[a][1] = i1 + i2; hi[a][2] = i0 + i1;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            Tr[dy * 3 + dx] = hr[2 - dy][dx] + hr[3 - dy][dx];
+            Ti[dy * 3 + dx] = hi[2 - dy][dx] + hi[3 - dy][dx];
+        }
+}
+
+// OT: element type of the gradient — float, or bf16 where the activations live in bf16
+template <typename OT>
+__global__ __launch_bounds__(256) void cconv_up1_bwd_data_kernel(Up1BwdArgs p) {
+    __shared__ __attribute__((aligned(16))) float4 gt[GTile<SRT>::NE];
+    __shared__ __attribute__((aligned(16))) float4 wl[9][CIN / 2];       // [tap][channel pair]: {w_r(c0), w_r(c1), w_i(c0), w_i(c1)}
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int m0 = ((int)blockIdx.x / p.tiles_w) * SRT, n0 = ((int)blockIdx.x % p.tiles_w) * SCT;
+    const int q = t & 3, pl = t >> 2;
+    float2 gv[GTile<SRT>::NL];
+    up1_gtile_load<SRT>(p, b, m0, n0, t, gv);
+    if (t < 9 * (CIN / 2)) {
+        const int tap = t / (CIN / 2), pr = t % (CIN / 2);
+        const float2 w0 = p.wt[(2 * pr) * p.ct + tap], w1 = p.wt[(2 * pr + 1) * p.ct + tap];
+        wl[tap][pr] = make_float4(w0.x, w1.x, w0.y, w1.y);
+    }
+    float sr = 0.f, si = 0.f;
+    up1_gtile_store<SRT, false>(gt, t, gv, sr, si);
+    __syncthreads();
+    v2f wr[9][2], wi[9][2];                                  // this quarter's four channels as two pairs
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const float4 w = wl[tap][2 * q + cp];
+            wr[tap][cp] = v2f{w.x, w.y}; wi[tap][cp] = v2f{w.z, w.w};
+        }
+    const int c0 = 4 * q;
+    OT* const base = c0 < p.C1 ? (OT*)p.gx1 + 2 * c0 : (OT*)p.gx2 + 2 * (c0 - p.C1);
+    const int cs = c0 < p.C1 ? p.C1 : p.C2;
+#pragma unroll 1
+    for (int k = 0; k < SRT * SCT / 64; ++k) {
+        const int pi = k * 64 + pl, m = pi / SCT, n = pi % SCT;
+        v2f Tr[9], Ti[9];
+        up1_tapsums(gt, m, n, Tr, Ti);
+        v2f ar[2] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}}, ai[2] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {                 // conj(w) T = (w_r T_r + w_i T_i) + j (w_r T_i - w_i T_r)
+                ar[cp] = __builtin_elementwise_fma(wr[tap][cp], Tr[tap], ar[cp]);
+                ar[cp] = __builtin_elementwise_fma(wi[tap][cp], Ti[tap], ar[cp]);
+                ai[cp] = __builtin_elementwise_fma(wr[tap][cp], Ti[tap], ai[cp]);
+                ai[cp] = __builtin_elementwise_fma(-wi[tap][cp], Tr[tap], ai[cp]);
+            }
+        const int sy = m0 + m, sx = n0 + n;
+        if (sy < p.Hs && sx < p.Ws) {
+            OT* dst = base + (((long)b * p.Hs + sy) * p.Ws + sx) * cs * 2;
+            dcs_st4(dst, make_float4(ar[0].x, ai[0].x, ar[0].y, ai[0].y));
+            dcs_st4(dst + 4, make_float4(ar[1].x, ai[1].x, ar[1].y, ai[1].y));
+        }
+    }
+}
+
+// IT: element type of the two sources.  Persistent: workgroup w walks tiles w, w + gridDim.x, ... of the B x tiles grid; a tile is
+// WRT = 2 source rows x 32 columns — ONE item per thread, so that the next tile's operands (two g_y elements, two 16-byte source loads)
+// are a dozen registers held across the current tile's arithmetic (with the 8 x 32 tile of the data-gradient kernel the fully unrolled
+// four items took 262 VGPRs: one wave per SIMD, 85 us).
+template <typename IT>
+__global__ __launch_bounds__(256) void cconv_up1_bwd_weight_kernel(Up1BwdArgs p) {
+    __shared__ __attribute__((aligned(16))) float4 gt[GTile<WRT>::NE];
+    __shared__ float red[4][4][74];
+    const int t = threadIdx.x, q = t & 3, pl = t >> 2, lane = t & 63, wave = t >> 6;
+    const int c0 = 4 * q;
+    const IT* const base = c0 < p.C1 ? (const IT*)p.x1 + 2 * c0 : (const IT*)p.x2 + 2 * (c0 - p.C1);
+    const int cs = c0 < p.C1 ? p.C1 : p.C2;
+    v2f wR[9][2], wI[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) { wR[tap][cp] = v2f{0.f, 0.f}; wI[tap][cp] = v2f{0.f, 0.f}; }
+    float sr = 0.f, si = 0.f;
+    const int tiles_h = (p.Hs + WRT - 1) / WRT, tiles = tiles_h * p.tiles_w, total = tiles * p.B;
+    const int m = pl / SCT, n = pl % SCT;
+    float2 gv[GTile<WRT>::NL];
+    float4 xa, xb;
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles, tl = tile - b * tiles;
+        const int m0 = (tl / p.tiles_w) * WRT, n0 = (tl % p.tiles_w) * SCT;
+        up1_gtile_load<WRT>(p, b, m0, n0, t, gv);
+        const int sy = m0 + m, sx = n0 + n;
+        const bool in = sy < p.Hs && sx < p.Ws;
+        const int syc = sy < p.Hs ? sy : p.Hs - 1, sxc = sx < p.Ws ? sx : p.Ws - 1;
+        const IT* src = base + (((long)b * p.Hs + syc) * p.Ws + sxc) * cs * 2;
+        const float4 a0 = dcs_ld4(src), a1 = dcs_ld4(src + 4);
+        xa = in ? a0 : make_float4(0.f, 0.f, 0.f, 0.f);
+        xb = in ? a1 : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    int tile = blockIdx.x;
+    if (tile < total) fetch(tile);
+#pragma unroll 1
+    for (; tile < total; tile += gridDim.x) {
+        __syncthreads();                                     // the previous tile's readers are done
+        up1_gtile_store<WRT, true>(gt, t, gv, sr, si);
+        const float4 x0 = xa, x1 = xb;
+        __syncthreads();
+        if (tile + (int)gridDim.x < total) fetch(tile + gridDim.x);      // in flight during this tile's arithmetic
+        v2f Tr[9], Ti[9];
+        up1_tapsums(gt, m, n, Tr, Ti);
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {                     // conj(x) T = (x_r T_r + x_i T_i) + j (x_r T_i - x_i T_r)
+            const float4 xv = cp ? x1 : x0;
+            const v2f xr = v2f{xv.x, xv.z}, xi = v2f{xv.y, xv.w};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                wR[tap][cp] = __builtin_elementwise_fma(xr, Tr[tap], wR[tap][cp]);
+                wR[tap][cp] = __builtin_elementwise_fma(xi, Ti[tap], wR[tap][cp]);
+                wI[tap][cp] = __builtin_elementwise_fma(xr, Ti[tap], wI[tap][cp]);
+                wI[tap][cp] = __builtin_elementwise_fma(-xi, Tr[tap], wI[tap][cp]);
+            }
+        }
+    }
+    // lanes of one quarter (lane % 4) summed over the wave's 16 pixels, then the four waves in a fixed order
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            float v4[4] = {wR[tap][cp].x, wI[tap][cp].x, wR[tap][cp].y, wI[tap][cp].y};     // (c0: re, im), (c1: re, im)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = v4[j];
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (lane < 4) red[wave][q][(tap * 2 + cp) * 4 + j] = v;
+            }
+        }
+    {
+        float a = sr, c = si;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        if (lane == 0) { red[wave][0][72] = a; red[wave][0][73] = c; }
+    }
+    __syncthreads();
+    float* row = p.part + (long)blockIdx.x * kPartRow;
+    for (int o = t; o < kPartRow; o += 256) {
+        float s;
+        if (o < 9 * CIN * 2) {
+            const int tap = o / (CIN * 2), ci = (o % (CIN * 2)) >> 1, part = o & 1;
+            const int qq = ci >> 2, cp = (ci & 3) >> 1, half = ci & 1, idx = (tap * 2 + cp) * 4 + half * 2 + part;
+            s = red[0][qq][idx] + red[1][qq][idx] + red[2][qq][idx] + red[3][qq][idx];
+        } else {
+            const int idx = 72 + (o - 9 * CIN * 2);
+            s = red[0][0][idx] + red[1][0][idx] + red[2][0][idx] + red[3][0][idx];
+        }
+        row[o] = s;
+    }
+}
+
+// partial rows -> the parameter gradients: g_w[ci][0][ky][kx] (+)= row sums of tap 8 - (ky * 3 + kx) (the correlation kernel is the
+// flipped transposed-conv kernel: dcs_pack_tap_rows), g_b_r = S_r + S_i, g_b_i = S_i - S_r (written).  16 outputs per workgroup,
+// 16 row slices each (a slice's loads are independent: unrolled), combined in a fixed order in fp64.
+constexpr int kFinOut = 16, kFinSl = 256 / kFinOut;
+__global__ __launch_bounds__(256) void cconv_up1_wgrad_final_kernel(const float* __restrict__ part, int nrows, float* __restrict__ gw_r,
+                                                                    float* __restrict__ gw_i, float* __restrict__ gb_r,
+                                                                    float* __restrict__ gb_i, int accumulate) {
+    __shared__ double red[kFinSl][kFinOut];
+    const int t = threadIdx.x, ol = t % kFinOut, sl = t / kFinOut, o = blockIdx.x * kFinOut + ol;
+    double s = 0;
+    if (o < kPartRow) {
+#pragma unroll 8
+        for (int r = sl; r < nrows; r += kFinSl) s += (double)part[(long)r * kPartRow + o];
+    }
+    red[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0) {
+        double a = red[0][ol];
+#pragma unroll
+        for (int k = 1; k < kFinSl; ++k) a += red[k][ol];
+        red[0][ol] = a;
+    }
+    __syncthreads();
+    if (sl != 0 || o >= kPartRow) return;
+    if (o < 9 * CIN * 2) {
+        const int tap = o / (CIN * 2), ci = (o % (CIN * 2)) >> 1, part_ = o & 1;
+        float* dst = (part_ ? gw_i : gw_r) + ci * 9 + (8 - tap);
+        const float v = (float)red[0][ol];
+        if (accumulate) *dst += v; else *dst = v;
+    } else if (o == 9 * CIN * 2 && gb_r) {                   // (both sums live in this workgroup: 288 and 289 share a block of 16)
+        const double Sr = red[0][ol], Si = red[0][ol + 1];
+        gb_r[0] = (float)(Sr + Si); gb_i[0] = (float)(Si - Sr);
+    }
+}
+
 }  // namespace
 
 // x1 complex[B][Hs][Ws][C1], x2 complex[B][Hs][Ws][C2] (C1 + C2 = 16, both even); wt: the tap-rows panel of
@@ -154,4 +408,74 @@ extern "C" int dcs_cconv_up2_single_fwd_h(const unsigned short* x1, const unsign
                                           const float* b_i, float* y, int B, int Hs, int Ws, int C1, int C2, int ct,
                                           dcs_stream_t stream) {
     return up2_single_impl(x1, x2, true, wt, b_r, b_i, y, B, Hs, Ws, C1, C2, ct, stream);
+}
+
+// ---- backward entry points --------------------------------------------------------------------------------------------------------
+static bool up2_bwd_geom_ok(int B, int Hs, int Ws, int C1, int C2) {
+    return B > 0 && B <= 65535 && Hs > 0 && Ws > 0 && C1 > 0 && C2 >= 0 && C1 + C2 == CIN && (C1 % 4) == 0 && (C2 % 4) == 0 &&
+           (long)B * Hs * Ws * CIN * 2 < (1L << 40);
+}
+static void up2_bwd_tiles(Up1BwdArgs& p, int B, int Hs, int Ws, int C1, int C2) {
+    p.Hs = Hs; p.Ws = Ws; p.C1 = C1; p.C2 = C2; p.B = B;
+    p.tiles_w = (Ws + SCT - 1) / SCT;
+    p.tiles = p.tiles_w * ((Hs + SRT - 1) / SRT);
+}
+
+static int up2_single_bwd_data_impl(const float* gy, const float* wt, void* gx1, void* gx2, bool bf16_out, int B, int Hs, int Ws,
+                                    int C1, int C2, int ct, dcs_stream_t stream) {
+    if (!gy || !wt || !gx1 || !up2_bwd_geom_ok(B, Hs, Ws, C1, C2) || ct < 9 || ((C2 > 0) != (gx2 != nullptr))) return DCS_ERR_BADARG;
+    Up1BwdArgs p{};
+    p.gy = (const float2*)gy; p.wt = (const float2*)wt; p.gx1 = gx1; p.gx2 = gx2; p.ct = ct;
+    up2_bwd_tiles(p, B, Hs, Ws, C1, C2);
+    if (bf16_out) DCS_LAUNCH(cconv_up1_bwd_data_kernel<unsigned short>, dim3(p.tiles, B), dim3(256), 0, dcs_stream(stream), p);
+    else DCS_LAUNCH(cconv_up1_bwd_data_kernel<float>, dim3(p.tiles, B), dim3(256), 0, dcs_stream(stream), p);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_cconv_up2_single_bwd_data(const float* gy, const float* wt, float* gx1, float* gx2, int B, int Hs, int Ws, int C1,
+                                             int C2, int ct, dcs_stream_t stream) {
+    return up2_single_bwd_data_impl(gy, wt, gx1, gx2, false, B, Hs, Ws, C1, C2, ct, stream);
+}
+extern "C" int dcs_cconv_up2_single_bwd_data_h(const float* gy, const float* wt, unsigned short* gx1, unsigned short* gx2, int B, int Hs,
+                                               int Ws, int C1, int C2, int ct, dcs_stream_t stream) {
+    return up2_single_bwd_data_impl(gy, wt, gx1, gx2, true, B, Hs, Ws, C1, C2, ct, stream);
+}
+
+constexpr int kUp1WgradMaxGroups = 768;                      // three per CU (the kernel's registers allow three waves per SIMD): all resident
+extern "C" long dcs_cconv_up2_single_bwd_weight_workspace_bytes(void) { return (long)kUp1WgradMaxGroups * kPartRow * (long)sizeof(float); }
+
+static int up2_single_bwd_weight_impl(const float* gy, const void* x1, const void* x2, bool bf16_in, float* gw_r, float* gw_i,
+                                      float* gb_r, float* gb_i, int accumulate, void* workspace, long workspace_bytes, int B, int Hs,
+                                      int Ws, int C1, int C2, dcs_stream_t stream) {
+    if (!gy || !x1 || !gw_r || !gw_i || !up2_bwd_geom_ok(B, Hs, Ws, C1, C2) || ((C2 > 0) != (x2 != nullptr)) ||
+        ((gb_r == nullptr) != (gb_i == nullptr)))
+        return DCS_ERR_BADARG;
+    if (!workspace || workspace_bytes < dcs_cconv_up2_single_bwd_weight_workspace_bytes()) return DCS_ERR_WORKSPACE;
+    Up1BwdArgs p{};
+    p.gy = (const float2*)gy; p.x1 = x1; p.x2 = x2; p.part = (float*)workspace;
+    up2_bwd_tiles(p, B, Hs, Ws, C1, C2);
+    const long total = (long)p.tiles_w * ((Hs + WRT - 1) / WRT) * B;
+    if (total > 0x7fffffffL) return DCS_ERR_BADARG;
+    const int groups = (int)(total < kUp1WgradMaxGroups ? total : kUp1WgradMaxGroups);
+    if (bf16_in) DCS_LAUNCH(cconv_up1_bwd_weight_kernel<unsigned short>, dim3(groups), dim3(256), 0, dcs_stream(stream), p);
+    else DCS_LAUNCH(cconv_up1_bwd_weight_kernel<float>, dim3(groups), dim3(256), 0, dcs_stream(stream), p);
+    DCS_CHECK_LAUNCH();
+    DCS_LAUNCH(cconv_up1_wgrad_final_kernel, dim3((kPartRow + kFinOut - 1) / kFinOut), dim3(256), 0, dcs_stream(stream), (const float*)workspace,
+               groups, gw_r, gw_i, gb_r, gb_i, accumulate);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+extern "C" int dcs_cconv_up2_single_bwd_weight(const float* gy, const float* x1, const float* x2, float* gw_r, float* gw_i, float* gb_r,
+                                               float* gb_i, int accumulate, void* workspace, long workspace_bytes, int B, int Hs,
+                                               int Ws, int C1, int C2, dcs_stream_t stream) {
+    return up2_single_bwd_weight_impl(gy, x1, x2, false, gw_r, gw_i, gb_r, gb_i, accumulate, workspace, workspace_bytes, B, Hs, Ws, C1,
+                                      C2, stream);
+}
+extern "C" int dcs_cconv_up2_single_bwd_weight_h(const float* gy, const unsigned short* x1, const unsigned short* x2, float* gw_r,
+                                                 float* gw_i, float* gb_r, float* gb_i, int accumulate, void* workspace,
+                                                 long workspace_bytes, int B, int Hs, int Ws, int C1, int C2, dcs_stream_t stream) {
+    return up2_single_bwd_weight_impl(gy, x1, x2, true, gw_r, gw_i, gb_r, gb_i, accumulate, workspace, workspace_bytes, B, Hs, Ws, C1,
+                                      C2, stream);
 }

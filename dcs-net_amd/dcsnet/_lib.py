@@ -88,6 +88,9 @@ SIGNATURES = {
     'dcs_complex_upsample_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'dcs_tapsum_fwd': (_I, [_P, _P, _P, _P] + [_I] * 10 + [_P]),
     'dcs_cconv_up2_single_fwd': (_I, [_P] * 6 + [_I] * 6 + [_P]),
+    'dcs_cconv_up2_single_bwd_data': (_I, [_P] * 4 + [_I] * 6 + [_P]),
+    'dcs_cconv_up2_single_bwd_weight_workspace_bytes': (_L, []),
+    'dcs_cconv_up2_single_bwd_weight': (_I, [_P] * 7 + [_I, _P, _L] + [_I] * 5 + [_P]),
     'dcs_tapsum_bwd_workspace_bytes': (_L, []),
     'dcs_tapsum_bwd': (_I, [_P, _P, _P, _P, _P, _L] + [_I] * 10 + [_P]),
     'dcs_bound_crm_fwd': (_I, [_P, _P, _L, _F, _P]),
@@ -152,7 +155,7 @@ class DcsHipError(RuntimeError):
 
 # bf16-activation forms (include/dcsnet_hip.h, last section): the same argument lists as the fp32 entry points they mirror
 for _n in ('dcs_cconv2d_fwd', 'dcs_cconv2d_fwd_affine', 'dcs_cconv2d_fwd_stats', 'dcs_cconv2d_bwd_data', 'dcs_cconv2d_bwd_weight',
-           'dcs_cconv_up2_single_fwd', 'dcs_tapsum_bwd', 'dcs_cbn_fwd', 'dcs_cbn_fwd_slabs', 'dcs_cbn_fwd_slabs_pool', 'dcs_cbn_bwd', 'dcs_cbn_bwd_add',
+           'dcs_cconv_up2_single_fwd', 'dcs_cconv_up2_single_bwd_data', 'dcs_cconv_up2_single_bwd_weight', 'dcs_tapsum_bwd', 'dcs_cbn_fwd', 'dcs_cbn_fwd_slabs', 'dcs_cbn_fwd_slabs_pool', 'dcs_cbn_bwd', 'dcs_cbn_bwd_add',
            'dcs_channel_attention_fwd', 'dcs_spatial_pool_fwd', 'dcs_attention_apply_fwd', 'dcs_attention_fwd_batched',
            'dcs_attention_bwd_sa', 'dcs_attention_bwd_x', 'dcs_attention_bwd_batched'):
     SIGNATURES[_n + '_h'] = SIGNATURES[_n]

@@ -912,7 +912,8 @@ class _Up2SingleFn(torch.autograd.Function):
     def backward(ctx, g):
         x1, x2, wt = ctx.saved_tensors
         B, Hs, Ws, C1, _ = x1.shape
-        Cin = C1 + (x2.shape[3] if x2 is not None else 0)
+        C2 = x2.shape[3] if x2 is not None else 0
+        Cin = C1 + C2
         sk = ctx.sinks
         gb = (None, None)
         dst = None
@@ -920,28 +921,40 @@ class _Up2SingleFn(torch.autograd.Function):
             new = lambda: torch.empty(1, dtype=torch.float32, device=g.device)
             dst = tuple(s_ if s_ is not None else new() for s_ in sk[2:])
             gb = tuple(None if s_ is not None else d for d, s_ in zip(dst, sk[2:]))
-        gz = ops.tapsum((B, Hs, Ws, ctx.ct, 2), (3, 3), (2, 2), (1, 1), backward=True, grad=g.contiguous(), bias_grad=dst,
-                        out_dtype=x1.dtype)                  # (bf16 where the activations are stored in bf16)
+        g = g.contiguous()
         gx1 = gx2 = gw_r = gw_i = None
+        want_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or ctx.bias
+        want_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if C1 % 4 == 0 and C2 % 4 == 0:
+            # Round 5: both gradients straight from the cotangent (conv_up1.hip: tap sums in registers) — no tap-channel tensor, two
+            # kernels + a 5-workgroup reduce instead of six launches.  Train step: the weight / bias gradient goes to the
+            # weight-gradient side stream like every other layer's (forked in front of the data gradient, issued behind it)
+            side = WGRAD_SIDE if (want_w and ops.WGRAD_DEFER is not None and g.is_cuda and sk[0] is not None and sk[1] is not None) else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+            elif want_w:
+                gw = ops.cconv_up2_single_bwd_weight(g, x1, x2, ctx.w_shape, sk[:2], dst)
+                if sk[0] is None or sk[1] is None:
+                    gw_r, gw_i = gw
+            if want_x:
+                gx1, gx2 = ops.cconv_up2_single_bwd_data(g, wt, C1, C2, x1.dtype)
+            if side is not None:
+                with torch.cuda.stream(side):
+                    ops.cconv_up2_single_bwd_weight(g, x1, x2, ctx.w_shape, sk[:2], dst)
+                ops.WGRAD_DEFER.append((g, x1, x2))               # alive until the join
+            return gx1, gx2, gw_r, gw_i, gb[0], gb[1], None
+        # other channel splits: the factored form (tap sums as a tensor, then the 1x1 tap conv's two gradients)
+        gz = ops.tapsum((B, Hs, Ws, ctx.ct, 2), (3, 3), (2, 2), (1, 1), backward=True, grad=g, bias_grad=dst,
+                        out_dtype=x1.dtype)                  # (bf16 where the activations are stored in bf16)
         want_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
-        # train step: the tap-channel weight gradient, its slab reduction and the scatter into the parameter's layout go to the
-        # weight-gradient side stream like every other layer's (forked behind the tap sum, in front of the data gradient)
-        side = WGRAD_SIDE if (want_w and ops.WGRAD_DEFER is not None and g.is_cuda and sk[0] is not None and sk[1] is not None) else None
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-        elif want_w:
+        if want_w:
             gt_r, gt_i, _, _ = ops.cconv2d_bwd_weight(x1, x2, gz, (ctx.ct, Cin, 1, 1), False, (1, 1), (1, 1), (0, 0))
             gw = ops.tap_rows_scatter(gt_r, gt_i, ctx.w_shape, sk[:2])
             if sk[0] is None or sk[1] is None:
                 gw_r, gw_i = gw
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if want_x:
             gx1, gx2 = ops.cconv2d_bwd_data(gz, ops.pack_conv_weight_bwd(wt, (1, 1)), (Hs, Ws, Cin), (1, 1), (1, 1), (0, 0),
                                             (1, 1), C1)
-        if side is not None:
-            with torch.cuda.stream(side):
-                gt_r, gt_i, _, _ = ops.cconv2d_bwd_weight(x1, x2, gz, (ctx.ct, Cin, 1, 1), False, (1, 1), (1, 1), (0, 0))
-                ops.tap_rows_scatter(gt_r, gt_i, ctx.w_shape, sk[:2])
-            ops.WGRAD_DEFER.append((gt_r, gt_i, gz, x1, x2))      # alive until the join
         return gx1, gx2, gw_r, gw_i, gb[0], gb[1], None
 
 

@@ -840,6 +840,41 @@ def cconv_up2_single(x1, x2, wt, b_r, b_i):
     return y
 
 
+def cconv_up2_single_bwd_data(gy, wt, C1, C2, out_dtype=torch.float32):
+    """Data gradient of cconv_up2_single straight from the cotangent gy [B, 2 Hs, 2 Ws, 1, 2] (dcs_cconv_up2_single_bwd_data):
+    -> (gx1 [B,Hs,Ws,C1,2], gx2 [B,Hs,Ws,C2,2] or None) in out_dtype (bf16 where the activations are stored in bf16)."""
+    _chk(gy, 'gy', 5)
+    _chk(wt, 'wt', 4)
+    B, Ho, Wo = gy.shape[:3]
+    Hs, Ws = Ho // 2, Wo // 2
+    gx1 = torch.empty((B, Hs, Ws, C1, 2), dtype=out_dtype, device=gy.device)
+    gx2 = torch.empty((B, Hs, Ws, C2, 2), dtype=out_dtype, device=gy.device) if C2 else None
+    check(_sym('dcs_cconv_up2_single_bwd_data', gx1, gx2)(ptr(gy), ptr(wt), ptr(gx1), ptr(gx2), B, Hs, Ws, C1, C2, wt.shape[2],
+                                                          cur_stream()), 'dcs_cconv_up2_single_bwd_data')
+    return gx1, gx2
+
+
+def cconv_up2_single_bwd_weight(gy, x1, x2, w_shape, outs=None, bias_outs=None):
+    """Weight and bias gradient of cconv_up2_single (dcs_cconv_up2_single_bwd_weight): -> (g_r, g_i) shaped like conv_tran_r/_i.weight
+    [16,1,3,3]; `outs`: optional (g_r, g_i) destinations that are ADDED to (gradient sinks); bias_outs: (gb_r, gb_i) one-float
+    destinations (written) or None."""
+    _chk(gy, 'gy', 5)
+    _chk(x1, 'x1', 5, act=True)
+    _chk(x2, 'x2', 5, act=True)
+    B, Hs, Ws, C1, _ = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    acc = outs is not None and outs[0] is not None and outs[1] is not None
+    g_r = outs[0] if acc else torch.empty(w_shape, dtype=torch.float32, device=gy.device)
+    g_i = outs[1] if acc else torch.empty(w_shape, dtype=torch.float32, device=gy.device)
+    gb_r, gb_i = bias_outs if bias_outs is not None else (None, None)
+    lib = _lib.load()
+    ws = _workspace(lib.dcs_cconv_up2_single_bwd_weight_workspace_bytes(), gy.device)
+    check(_sym('dcs_cconv_up2_single_bwd_weight', x1, x2)(ptr(gy), ptr(x1), ptr(x2), ptr(g_r), ptr(g_i), ptr(gb_r), ptr(gb_i), int(acc),
+                                                            ptr(ws), ws.numel(), B, Hs, Ws, C1, C2, cur_stream()),
+          'dcs_cconv_up2_single_bwd_weight')
+    return g_r, g_i
+
+
 def bound_crm(M, eps=10e-7, out=None):
     """M: float [..., 2] interleaved complex."""
     _chk(M, 'M')

@@ -555,6 +555,22 @@ int dcs_tapsum_bwd(const float* gy, float* gz, float* gb_r, float* gb_i, void* w
 int dcs_cconv_up2_single_fwd(const float* x1, const float* x2, const float* wt, const float* b_r, const float* b_i,
                              float* y, int B, int Hs, int Ws, int C1, int C2, int ct, dcs_stream_t stream);
 
+/* Its backward without the tap-channel tensor (conv_up1.hip, Round 5; C1 and C2 multiples of 4): both kernels form the nine tap sums of
+ * gy (complex[B][2 Hs][2 Ws]) per source pixel in registers from an LDS tile.
+ *   _bwd_data:   gx1 complex[B][Hs][Ws][C1], gx2 complex[B][Hs][Ws][C2] (written) = sum_tap conj(w[ci][tap]) T[tap]
+ *   _bwd_weight: gw_r / gw_i [16][1][3][3] in the PARAMETER layout of conv_tran_r / _i.weight (added to when accumulate != 0, else
+ *                written), gb_r / gb_i the two real bias gradients (written; both or neither); partial rows per workgroup in
+ *                `workspace` (>= dcs_cconv_up2_single_bwd_weight_workspace_bytes()), summed in a fixed order in fp64 by a second
+ *                launch — bit-reproducible, no atomics.
+ * Replaces dcs_tapsum_bwd + dcs_cconv2d_bwd_data + dcs_cconv2d_bwd_weight + dcs_tap_rows_wgrad_scatter for this stage
+ * (reference: the autograd backward of ComplexConvTranspose2d behind cat + upsample, c_network.py:135-141, :214-217). */
+int dcs_cconv_up2_single_bwd_data(const float* gy, const float* wt, float* gx1, float* gx2, int B, int Hs, int Ws, int C1, int C2,
+                                  int ct, dcs_stream_t stream);
+long dcs_cconv_up2_single_bwd_weight_workspace_bytes(void);
+int dcs_cconv_up2_single_bwd_weight(const float* gy, const float* x1, const float* x2, float* gw_r, float* gw_i, float* gb_r,
+                                    float* gb_i, int accumulate, void* workspace, long workspace_bytes, int B, int Hs, int Ws,
+                                    int C1, int C2, dcs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * bound_cRM (network_functions.py:77-88), as called at c_network.py:225:
  *     m = tanh|M| ; phi1 = atan2(Mi, Mr+eps) ; phi2 = atan2(m sin phi1, m cos phi1 + eps)
@@ -810,6 +826,11 @@ int dcs_cconv2d_bwd_weight_h(const dcs_bf16_t* x1, const dcs_bf16_t* x2, const d
                              dcs_stream_t stream);
 int dcs_cconv_up2_single_fwd_h(const dcs_bf16_t* x1, const dcs_bf16_t* x2, const float* wt, const float* b_r, const float* b_i,
                                float* y, int B, int Hs, int Ws, int C1, int C2, int ct, dcs_stream_t stream);
+int dcs_cconv_up2_single_bwd_data_h(const float* gy, const float* wt, dcs_bf16_t* gx1, dcs_bf16_t* gx2, int B, int Hs, int Ws, int C1,
+                                    int C2, int ct, dcs_stream_t stream);
+int dcs_cconv_up2_single_bwd_weight_h(const float* gy, const dcs_bf16_t* x1, const dcs_bf16_t* x2, float* gw_r, float* gw_i,
+                                      float* gb_r, float* gb_i, int accumulate, void* workspace, long workspace_bytes, int B, int Hs,
+                                      int Ws, int C1, int C2, dcs_stream_t stream);
 int dcs_tapsum_bwd_h(const float* gy, dcs_bf16_t* gz, float* gb_r, float* gb_i, void* workspace, long workspace_bytes,
                      int B, int Hs, int Ws, int CT, int kh, int kw, int up_f, int up_t, int pad_f, int pad_t,
                      dcs_stream_t stream);

@@ -155,6 +155,44 @@ def test_single_output_stage(dev, c1, c2, up, hw):
         close(p[n].grad, q.grad, what=n)
 
 
+def test_single_output_stage_direct_backward_equals_the_factored_one(dev):
+    """conv_up1.hip's backward kernels (tap sums of the cotangent in registers: dcs_cconv_up2_single_bwd_data / _bwd_weight) against the
+    factored form they replace (dcs_tapsum_bwd -> 1x1 tap conv data / weight gradient -> scatter) on a ragged multi-tile shape: same
+    sums in another order (2e-5 of the tensor's max-abs, the conv tolerance); accumulation into sinks; bitwise repeatable."""
+    from dcsnet import ops
+    g = torch.Generator().manual_seed(11)
+    B, Hs, Ws, C1, C2 = 3, 21, 70, 8, 8
+    rn = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    x1, x2 = rn(B, Hs, Ws, C1, 2), rn(B, Hs, Ws, C2, 2)
+    w_r, w_i = rn(16, 1, 3, 3) * 0.2, rn(16, 1, 3, 3) * 0.2
+    gy = rn(B, 2 * Hs, 2 * Ws, 1, 2)
+    wt, _ = ops.pack_tap_rows(w_r, w_i, 16)
+    # the factored form
+    gb0 = (torch.empty(1, device=dev), torch.empty(1, device=dev))
+    gz = ops.tapsum((B, Hs, Ws, 16, 2), (3, 3), (2, 2), (1, 1), backward=True, grad=gy, bias_grad=gb0)
+    gt_r, gt_i, _, _ = ops.cconv2d_bwd_weight(x1, x2, gz, (16, 16, 1, 1), False, (1, 1), (1, 1), (0, 0))
+    gw0 = ops.tap_rows_scatter(gt_r, gt_i, (16, 1, 3, 3))
+    gx0 = ops.cconv2d_bwd_data(gz, ops.pack_conv_weight_bwd(wt, (1, 1)), (Hs, Ws, 16), (1, 1), (1, 1), (0, 0), (1, 1), C1)
+    # the direct kernels
+    gx = ops.cconv_up2_single_bwd_data(gy, wt, C1, C2)
+    gb = (torch.empty(1, device=dev), torch.empty(1, device=dev))
+    gw = ops.cconv_up2_single_bwd_weight(gy, x1, x2, (16, 1, 3, 3), None, gb)
+    torch.cuda.synchronize()
+    for a, b_, what in ((gx[0], gx0[0], 'g_x1'), (gx[1], gx0[1], 'g_x2'), (gw[0], gw0[0], 'g_w_r'), (gw[1], gw0[1], 'g_w_i'),
+                        (gb[0], gb0[0], 'g_b_r'), (gb[1], gb0[1], 'g_b_i')):
+        err, scale = float((a - b_).abs().max()), float(b_.abs().max())
+        assert err <= 2e-5 * scale, (what, err, scale)
+    # sinks are added to; a second launch gives the same bits
+    sink = (torch.ones(16, 1, 3, 3, device=dev), torch.full((16, 1, 3, 3), 2.0, device=dev))
+    ops.cconv_up2_single_bwd_weight(gy, x1, x2, (16, 1, 3, 3), sink, None)
+    gw2 = ops.cconv_up2_single_bwd_weight(gy, x1, x2, (16, 1, 3, 3), None, None)
+    gx2_ = ops.cconv_up2_single_bwd_data(gy, wt, C1, C2)
+    torch.cuda.synchronize()
+    assert torch.equal(gw2[0], gw[0]) and torch.equal(gw2[1], gw[1]) and torch.equal(gx2_[0], gx[0]) and torch.equal(gx2_[1], gx[1])
+    assert torch.allclose(sink[0], gw[0] + 1.0, rtol=0, atol=1e-6 * float(gw[0].abs().max()) + 1e-6)
+    assert torch.allclose(sink[1], gw[1] + 2.0, rtol=0, atol=1e-6 * float(gw[1].abs().max()) + 1e-6)
+
+
 def test_complex_linear_backward(dev):
     from dcsnet import functional as F
     torch.manual_seed(8)

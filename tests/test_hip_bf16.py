@@ -191,6 +191,16 @@ def test_last_decoder_stage_reads_bf16_and_writes_the_fp32_mask(dev):
     gz = ops.tapsum((B, Hs, Ws, 16, 2), (3, 3), (2, 2), (1, 1), backward=True, grad=gm, out_dtype=BF)
     gzf = ops.tapsum((B, Hs, Ws, 16, 2), (3, 3), (2, 2), (1, 1), backward=True, grad=gm)
     _same_after_rounding(gz, gzf, 'tap-channel cotangent')
+    # the direct backward kernels (conv_up1.hip): the data gradient written in bf16 = the fp32 kernel's rounded once; the weight
+    # gradient from bf16 sources = the fp32 kernel's on the same (exactly representable) values
+    gx = ops.cconv_up2_single_bwd_data(gm, wt, 8, 8, BF)
+    gxf = ops.cconv_up2_single_bwd_data(gm, wt, 8, 8)
+    _same_after_rounding(gx[0], gxf[0], 'dec6 data gradient (x1)')
+    _same_after_rounding(gx[1], gxf[1], 'dec6 data gradient (x2)')
+    gb, gbf = (torch.empty(1, device=dev), torch.empty(1, device=dev)), (torch.empty(1, device=dev), torch.empty(1, device=dev))
+    gw = ops.cconv_up2_single_bwd_weight(gm, x1, x2, (16, 1, 3, 3), None, gb)
+    gwf = ops.cconv_up2_single_bwd_weight(gm, x1f, x2f, (16, 1, 3, 3), None, gbf)
+    assert torch.equal(gw[0], gwf[0]) and torch.equal(gw[1], gwf[1]) and torch.equal(gb[0], gbf[0]) and torch.equal(gb[1], gbf[1])
 
 
 def _record(key, value):
