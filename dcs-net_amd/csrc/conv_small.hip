@@ -18,70 +18,110 @@ constexpr int DC = 8;                 // forward output channels = channels of g
 constexpr int DPIX = 10;              // LDS float2 per patch pixel: 8 channels + 2 pad (80-B pitch keeps b128 reads spread)
 
 struct DgArgs {
-    const act2_t* gy; const float2* wpb; act2_t* gx;      // wpb: [49][8][1] flipped / conjugated kernel (act2_t: dcs_common.h)
+    const act2_t* gy; act2_t* gx;
     int B, Hg, Wg, Hx, Wx, tiles_w, tiles_h;               // g_Y extent, g_X extent, class-space tiling (of the largest class)
     int kh[4], kw[4], fy[4], fx[4], py[4], px[4], Hc[4], Wc[4];   // per class (ry*2 + rx): sub-kernel, first full tap, padding, extent
 };
 
-// wsm: the class's sub-kernel, [tap jy * KW + jx][channel pair] as {w0.x, w0.y, w1.x, w1.y}, staged in LDS by the caller.  Read
-// straight from d.wpb (a pointer inside a by-value argument struct: no noalias / readonly information) the wave-uniform weights
-// were VECTOR loads — 196 global_load_dwordx4 per thread in the 4x4 class, 64 lanes x 16 bytes through the L1 for 16 useful bytes:
-// more L1 cycles than the kernel has FMA cycles.  From LDS they are broadcast reads.
+// Round 5: a thread owns TWO vertically adjacent class pixels (a workgroup of 256 threads a 16 x 32 tile).  One thread per pixel read
+// a 16-byte patch element AND a 16-byte weight element from LDS per two complex MACs — 3.3 GB of LDS traffic per launch at
+// [32,256,256] (52.5 us).  Now
+//   * the patch lies in LDS as four channel-pair planes [q][row][col] of float4; a thread reads the DP + KH - 1 rows its
+//     windows span once per (tap column, plane), lanes on adjacent columns;
+//   * a complex MAC is two packed FMAs (P += w.x x, Q += w.y x; the weights lie in LDS as {w, w} pairs);
+//   * all of a thread's patch loads are issued before the first LDS write.
+// 52.5 -> 46 us.  Measured on the way (profiles/r05_enc0_dgrad.txt): four pixels per thread at 128 threads (42 KB of LDS per
+// 128 threads: 1.5 waves per SIMD) 63-68 us; the weights as SGPR operands through the scalar cache 68-87 us (scalar loads and LDS
+// reads share lgkmcnt: every step drained both).  Counters of this form: LDS busy 22 us, VALU busy 24 us of the 46 — 886 vector
+// instructions per wave of which 370 are FMAs (the rest: the patch's index arithmetic and stores).
+constexpr int DTH = 16, DTW = 32, DP = 2, DROWS = DTH + 3, DCOLS = DTW + 3;
 template <int KH, int KW>
-__device__ __forceinline__ void dgrad_class(const DgArgs& d, const float2* patch, const float4* wsm, int cls, int b, int cy0, int cx0) {
-    constexpr int COLS = TW + KW - 1;
-    const int t = threadIdx.x, tx = t % TW, ty = t / TW;
-    float ar = 0.f, ai = 0.f;
-    const float2* base = patch + (ty * COLS + tx) * DPIX;
+__device__ __forceinline__ void dgrad_class(const DgArgs& d, const float4* __restrict__ wsm, const float4* __restrict__ planes, int cls,
+                                            int b, int cy0, int cx0) {
+    const int t = threadIdx.x, tx = t % DTW, tg = t / DTW;
+    // two accumulators per pixel, P += w.x * x and Q += w.y * x (packed FMAs on {re, im}; the weights lie in LDS as {w.x, w.x} /
+    // {w.y, w.y} pairs, so no cross-half operand selection: dcs_common.h), combined at the end
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f accp[DP], accq[DP];
 #pragma unroll
-    for (int jy = 0; jy < KH; ++jy)
+    for (int p = 0; p < DP; ++p) { accp[p] = v2f{0.f, 0.f}; accq[p] = v2f{0.f, 0.f}; }
+#pragma unroll 1
+    for (int q = 0; q < DC / 2; ++q)                          // (rolled: fully unrolled the scheduler hoisted all 112 patch reads — 444 VGPRs)
 #pragma unroll
         for (int jx = 0; jx < KW; ++jx) {
-            const float4* xp = reinterpret_cast<const float4*>(base + (jy * COLS + jx) * DPIX);
+            float4 xv[DP + KH - 1];
 #pragma unroll
-            for (int q = 0; q < DC / 2; ++q) {
-                const float4 xv = xp[q];
-                const float4 wq = wsm[(jy * KW + jx) * (DC / 2) + q];
-                const float2 w0 = make_float2(wq.x, wq.y), w1 = make_float2(wq.z, wq.w);
-                ar = fmaf(w0.x, xv.x, fmaf(-w0.y, xv.y, ar));
-                ai = fmaf(w0.x, xv.y, fmaf(w0.y, xv.x, ai));
-                ar = fmaf(w1.x, xv.z, fmaf(-w1.y, xv.w, ar));
-                ai = fmaf(w1.x, xv.w, fmaf(w1.y, xv.z, ai));
+            for (int r = 0; r < DP + KH - 1; ++r) xv[r] = planes[(q * DROWS + DP * tg + r) * DCOLS + tx + jx];
+#pragma unroll
+            for (int jy = 0; jy < KH; ++jy) {
+                const float4 wa = wsm[((jy * KW + jx) * (DC / 2) + q) * 2], wb = wsm[((jy * KW + jx) * (DC / 2) + q) * 2 + 1];
+                const v2f w0x = v2f{wa.x, wa.y}, w0y = v2f{wa.z, wa.w}, w1x = v2f{wb.x, wb.y}, w1y = v2f{wb.z, wb.w};
+#pragma unroll
+                for (int p = 0; p < DP; ++p) {
+                    const float4 x = xv[p + jy];
+                    const v2f x0 = v2f{x.x, x.y}, x1 = v2f{x.z, x.w};
+                    accp[p] = __builtin_elementwise_fma(w0x, x0, accp[p]);
+                    accq[p] = __builtin_elementwise_fma(w0y, x0, accq[p]);
+                    accp[p] = __builtin_elementwise_fma(w1x, x1, accp[p]);
+                    accq[p] = __builtin_elementwise_fma(w1y, x1, accq[p]);
+                }
             }
         }
-    const int cy = cy0 + ty, cx = cx0 + tx;
-    if (cy < d.Hc[cls] && cx < d.Wc[cls])
-        conv::stc(d.gx + ((long)b * d.Hx + 2 * cy + (cls >> 1)) * d.Wx + 2 * cx + (cls & 1), make_float2(ar, ai));
+    float ar[DP], ai[DP];
+#pragma unroll
+    for (int p = 0; p < DP; ++p) { ar[p] = accp[p].x - accq[p].y; ai[p] = accp[p].y + accq[p].x; }
+    const int cx = cx0 + tx;
+#pragma unroll
+    for (int p = 0; p < DP; ++p) {
+        const int cy = cy0 + DP * tg + p;
+        if (cy < d.Hc[cls] && cx < d.Wc[cls])
+            conv::stc(d.gx + ((long)b * d.Hx + 2 * cy + (cls >> 1)) * d.Wx + 2 * cx + (cls & 1), make_float2(ar[p], ai[p]));
+    }
 }
 
-__global__ __launch_bounds__(TH * TW) void cconv_small_dgrad_s2_kernel(DgArgs d) {
+// wpb: [49][8] flipped / conjugated kernel (complex)
+__global__ __launch_bounds__(DTH * DTW / DP) void cconv_small_dgrad_s2_kernel(DgArgs d, const float2* __restrict__ wpb) {
     DCS_PRIO_CRITICAL();
-    __shared__ __attribute__((aligned(16))) float2 patch[(TH + 3) * (TW + 3) * DPIX];
-    __shared__ __attribute__((aligned(16))) float4 wsm[16 * (DC / 2)];
+    __shared__ __attribute__((aligned(16))) float4 planes[(DC / 2) * DROWS * DCOLS];
+    __shared__ __attribute__((aligned(16))) float4 wsm[16 * (DC / 2) * 2];
     const int cls = blockIdx.y, b = blockIdx.z;
-    const int cy0 = (blockIdx.x / d.tiles_w) * TH, cx0 = (blockIdx.x % d.tiles_w) * TW;
+    const int cy0 = (blockIdx.x / d.tiles_w) * DTH, cx0 = (blockIdx.x % d.tiles_w) * DTW;
     if (cy0 >= d.Hc[cls] || cx0 >= d.Wc[cls]) return;
     const int kh = d.kh[cls], kw = d.kw[cls];
-    const int rows = TH + kh - 1, cols = TW + kw - 1;
+    const int rows = DTH + kh - 1, cols = DTW + kw - 1;
     const int gy0 = cy0 - d.py[cls], gx0 = cx0 - d.px[cls];
-    for (int idx = threadIdx.x; idx < rows * cols * (DC / 2); idx += TH * TW) {
+    // every load of the thread first (clamped address, value selected afterwards), then the LDS writes: as a load -> write loop the
+    // 21 elements of a thread went out one memory round trip after the other (~20 us per workgroup)
+    constexpr int NT = DTH * DTW / DP, NE = DROWS * DCOLS * (DC / 2), NL = (NE + NT - 1) / NT;
+    float4 pv[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int idx = threadIdx.x + k * NT;
         const int q = idx % (DC / 2), p = idx / (DC / 2);
-        const int ix = p % cols, iy = p / cols;
+        const int ix = p % DCOLS, iy = p / DCOLS;
         const int y = gy0 + iy, x = gx0 + ix;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < d.Hg && x >= 0 && x < d.Wg)
-            v = dcs_ld4(reinterpret_cast<const act_t*>(d.gy + (((long)b * d.Hg + y) * d.Wg + x) * DC + 2 * q));
-        *reinterpret_cast<float4*>(patch + p * DPIX + 2 * q) = v;
+        const bool in = iy < rows && ix < cols && y >= 0 && y < d.Hg && x >= 0 && x < d.Wg;
+        const int yc = y < 0 ? 0 : (y >= d.Hg ? d.Hg - 1 : y), xc = x < 0 ? 0 : (x >= d.Wg ? d.Wg - 1 : x);
+        const float4 v = dcs_ld4(reinterpret_cast<const act_t*>(d.gy + (((long)b * d.Hg + yc) * d.Wg + xc) * DC + 2 * q));
+        pv[k] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (threadIdx.x < kh * kw * (DC / 2)) {                            // this class's taps of the flipped 7x7 kernel
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int idx = threadIdx.x + k * NT;
+        const int q = idx % (DC / 2), p = idx / (DC / 2);
+        if (idx < NE) planes[(q * DROWS + p / DCOLS) * DCOLS + p % DCOLS] = pv[k];
+    }
+    if (threadIdx.x < kh * kw * (DC / 2)) {                            // this class's taps of the flipped 7x7 kernel (<= 64 x 16 bytes)
         const int tap = threadIdx.x / (DC / 2), q = threadIdx.x % (DC / 2), jy = tap / kw, jx = tap % kw;
-        wsm[threadIdx.x] = *reinterpret_cast<const float4*>(d.wpb + ((d.fy[cls] + 2 * jy) * 7 + d.fx[cls] + 2 * jx) * DC + 2 * q);
+        const float4 w = *reinterpret_cast<const float4*>(wpb + ((d.fy[cls] + 2 * jy) * 7 + d.fx[cls] + 2 * jx) * DC + 2 * q);
+        wsm[2 * threadIdx.x] = make_float4(w.x, w.x, w.y, w.y);
+        wsm[2 * threadIdx.x + 1] = make_float4(w.z, w.z, w.w, w.w);
     }
     __syncthreads();
-    if (kh == 4 && kw == 4) dgrad_class<4, 4>(d, patch, wsm, cls, b, cy0, cx0);
-    else if (kh == 4) dgrad_class<4, 3>(d, patch, wsm, cls, b, cy0, cx0);
-    else if (kw == 4) dgrad_class<3, 4>(d, patch, wsm, cls, b, cy0, cx0);
-    else dgrad_class<3, 3>(d, patch, wsm, cls, b, cy0, cx0);
+    if (kh == 4 && kw == 4) dgrad_class<4, 4>(d, wsm, planes, cls, b, cy0, cx0);
+    else if (kh == 4) dgrad_class<4, 3>(d, wsm, planes, cls, b, cy0, cx0);
+    else if (kw == 4) dgrad_class<3, 4>(d, wsm, planes, cls, b, cy0, cx0);
+    else dgrad_class<3, 3>(d, wsm, planes, cls, b, cy0, cx0);
 }
 
 }  // namespace
@@ -99,7 +139,7 @@ bool dcs_conv_small_dgrad_ok(int Cin, int Cout, int kh, int kw, int sf, int st, 
 int dcs_conv_small_dgrad_launch(const act_t* gy, const float* wp_bwd, act_t* gx, int B, int Hx, int Wx, int Hg, int Wg,
                                 int pad_f, int pad_t, hipStream_t stream) {
     DgArgs d;
-    d.gy = (const act2_t*)gy; d.wpb = (const float2*)wp_bwd; d.gx = (act2_t*)gx;
+    d.gy = (const act2_t*)gy; d.gx = (act2_t*)gx;
     d.B = B; d.Hg = Hg; d.Wg = Wg; d.Hx = Hx; d.Wx = Wx;
     int Hc = 0, Wc = 0;
     for (int ry = 0; ry < 2; ++ry)
@@ -111,10 +151,10 @@ int dcs_conv_small_dgrad_launch(const act_t* gy, const float* wp_bwd, act_t* gx,
             Hc = ay.n > Hc ? ay.n : Hc; Wc = ax.n > Wc ? ax.n : Wc;
         }
     if (Hc <= 0 || Wc <= 0) return DCS_ERR_BADARG;
-    d.tiles_w = (Wc + TW - 1) / TW; d.tiles_h = (Hc + TH - 1) / TH;
+    d.tiles_w = (Wc + DTW - 1) / DTW; d.tiles_h = (Hc + DTH - 1) / DTH;
     dim3 grid(d.tiles_w * d.tiles_h, 4, B);
     if (grid.z > 65535) return DCS_ERR_BADARG;
-    DCS_LAUNCH(cconv_small_dgrad_s2_kernel, grid, dim3(TH * TW), 0, stream, d);
+    DCS_LAUNCH(cconv_small_dgrad_s2_kernel, grid, dim3(DTH * DTW / DP), 0, stream, d, (const float2*)wp_bwd);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }
