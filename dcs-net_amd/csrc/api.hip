@@ -2,7 +2,7 @@
 #include <cstdlib>
 #include "dcs_common.h"
 
-extern "C" int dcs_abi_version(void) { return 17; }
+extern "C" int dcs_abi_version(void) { return 18; }
 
 extern "C" const char* dcs_error_string(int code) {
     switch (code) {

@@ -69,7 +69,11 @@ __device__ __forceinline__ void dgrad_class(const DgArgs& d, const float4* __res
         }
     float ar[DP], ai[DP];
 #pragma unroll
-    for (int p = 0; p < DP; ++p) { ar[p] = accp[p].x - accq[p].y; ai[p] = accp[p].y + accq[p].x; }
+    for (int p = 0; p < DP; ++p) {
+        float px = accp[p].x, py = accp[p].y, qx = accq[p].x, qy = accq[p].y;
+        asm volatile("" : "+v"(px), "+v"(py), "+v"(qx), "+v"(qy));        // scalar combine: as a vector expression it became a v_pk_add_f32
+        ar[p] = px - qy; ai[p] = py + qx;                                  // with a cross-half operand selection (dcs_common.h)
+    }
     const int cx = cx0 + tx;
 #pragma unroll
     for (int p = 0; p < DP; ++p) {
