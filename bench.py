@@ -603,7 +603,9 @@ def main():
                                              'source': 'profiles/r03_mfma_peak_bf16.txt'} if args.dtype == 'f32' else None),
                          'emulated_share_of_flops': (cs['emu_flops'] / conv_flops if conv_flops > 0 else 0.0),
                          'mfma_busy_pmc': pmc_mfma_busy(args.mode, B, T),
-                         'kernel': 'complex conv / convT (dcs_cconv2d_fwd' + (', _bwd_data, _bwd_weight' if train else '')
+                         'kernel': 'complex conv / convT (dcs_cconv2d_fwd' + (
+                             ', _bwd_data, _bwd_weight; the last decoder stage\'s backward dcs_cconv_up2_single_bwd_data / _bwd_weight '
+                             'counted with the flops of the 1x1 tap-conv launches it replaced in round 5' if train else '')
                                    + '), all launches of the timed region',
                          'launches_per_step': n_launch, 'kernel_ms_per_step': conv_ms,
                          'samples_per_launch': timer.samples_per_launch(),

@@ -849,8 +849,15 @@ def cconv_up2_single_bwd_data(gy, wt, C1, C2, out_dtype=torch.float32):
     Hs, Ws = Ho // 2, Wo // 2
     gx1 = torch.empty((B, Hs, Ws, C1, 2), dtype=out_dtype, device=gy.device)
     gx2 = torch.empty((B, Hs, Ws, C2, 2), dtype=out_dtype, device=gy.device) if C2 else None
+    # bench.py's conv family: counted with the flops of the launch it replaces (the factored form's 1x1 tap conv over 16 tap
+    # channels, an emulated-MFMA launch), so that the family's totals stay comparable across rounds
+    ev = (CONV_TIMER.begin(8.0 * B * Hs * Ws * 16 * (C1 + C2), emulated=True,
+                           nbytes=gy.numel() * 4.0 + B * Hs * Ws * (C1 + C2) * 2.0 * gx1.element_size())
+          if CONV_TIMER is not None else None)
     check(_sym('dcs_cconv_up2_single_bwd_data', gx1, gx2)(ptr(gy), ptr(wt), ptr(gx1), ptr(gx2), B, Hs, Ws, C1, C2, wt.shape[2],
                                                           cur_stream()), 'dcs_cconv_up2_single_bwd_data')
+    if ev is not None:
+        CONV_TIMER.end(ev)
     return gx1, gx2
 
 
@@ -869,9 +876,14 @@ def cconv_up2_single_bwd_weight(gy, x1, x2, w_shape, outs=None, bias_outs=None):
     gb_r, gb_i = bias_outs if bias_outs is not None else (None, None)
     lib = _lib.load()
     ws = _workspace(lib.dcs_cconv_up2_single_bwd_weight_workspace_bytes(), gy.device)
+    ev = (CONV_TIMER.begin(8.0 * B * Hs * Ws * 16 * (C1 + C2), emulated=True,            # (as in cconv_up2_single_bwd_data)
+                           nbytes=gy.numel() * 4.0 + B * Hs * Ws * (C1 + C2) * 2.0 * x1.element_size())
+          if CONV_TIMER is not None else None)
     check(_sym('dcs_cconv_up2_single_bwd_weight', x1, x2)(ptr(gy), ptr(x1), ptr(x2), ptr(g_r), ptr(g_i), ptr(gb_r), ptr(gb_i), int(acc),
                                                             ptr(ws), ws.numel(), B, Hs, Ws, C1, C2, cur_stream()),
           'dcs_cconv_up2_single_bwd_weight')
+    if ev is not None:
+        CONV_TIMER.end(ev)
     return g_r, g_i
 
 
