@@ -152,6 +152,124 @@ __global__ __launch_bounds__(kThreads) void bound_mask_apply_bwd_kernel(const fl
     }
 }
 
+// ---- Round 5: mask application fused with the synthesis' polar round trip (train step, configured geometry) --------------------------
+// The step function hands both estimates to mag_phase_2_wave (network_functions.py:244-247): |z| e^{j atan2(z_i, z_r + eps)} with a zero
+// bin appended, frame-major for the inverse FFT (synth.hip, polar_frames).  Run as two kernels the estimates N_hat, S_hat made a
+// round trip through HBM each way (33.5 MB written + read forward; cotangent written + read and the values read again backward, at
+// [32,256,256]).  Here one kernel goes from (Y, raw network output D) to the two frame-major spectra [b] = turn(N_hat),
+// [B + b] = turn(S_hat), and one kernel from their cotangents back to g_D (everything in between recomputed); a 32 x 32 tile
+// is transposed through LDS so that both sides stay coalesced.
+__device__ __forceinline__ float2 polar_turn(float2 z, float eps) {
+    const float m = hypotf(z.x, z.y);
+    const float2 d = unit_dir(z.x + eps, z.y);
+    return make_float2(m * d.x, m * d.y);
+}
+// cotangent of polar_turn's input: (z/|z|) (u.g) + |z| (g - u (u.g)) / |v|,  u = unit(v), v = (z_r + eps, z_i)
+__device__ __forceinline__ float2 polar_turn_bwd(float2 z, float eps, float2 g) {
+    const float m = hypotf(z.x, z.y);
+    const float2 d = unit_dir(z.x + eps, z.y);
+    const float dot = d.x * g.x + d.y * g.y;
+    float2 o = unit_dir_bwd(z.x + eps, z.y, make_float2(m * g.x, m * g.y));
+    if (m > 0.f) { const float im = rcp1(m); o.x += dot * z.x * im; o.y += dot * z.y * im; }
+    return o;
+}
+
+// (Y, D) element -> the twice-bounded mask m and the estimates n = Y m, s = Y - n; DROP: D = dropout(D_raw)
+template <bool DROP>
+__device__ __forceinline__ void apply_one(float2 y, float2 v, long i, float eps, float drop_p, float inv_keep, uint64_t seed,
+                                          float2& vd, float& kx, float& ky, float2& m1, float2& m, float2& n, float2& sh) {
+    kx = 1.f; ky = 1.f;
+    if (DROP) {
+        kx = dcs_keep_scale(seed, (uint64_t)(2 * i), drop_p, inv_keep);
+        ky = dcs_keep_scale(seed, (uint64_t)(2 * i + 1), drop_p, inv_keep);
+    }
+    vd = make_float2(v.x * kx, v.y * ky);
+    m1 = bound_one(vd.x, vd.y, eps);
+    m = bound_one(m1.x, m1.y, eps);
+    n = make_float2(y.x * m.x - y.y * m.y, y.x * m.y + y.y * m.x);
+    sh = make_float2(y.x - n.x, y.y - n.y);
+}
+
+// grid (ceil(T/32), ceil(Fp/32), B); block 32 x 8.  Y, D: complex[B][F][T]; out: complex[2B][T][Fp] (bins >= F are zero);
+// Mout: optional complex[B][F][T] (the twice-bounded mask)
+template <bool DROP>
+__global__ __launch_bounds__(kThreads) void bound2_apply_polar_frames_kernel(const float2* __restrict__ Y, const float2* __restrict__ D,
+                                                                              float2* __restrict__ Mout, float2* __restrict__ out,
+                                                                              int B, int F, int Fp, int T, float eps, float drop_p,
+                                                                              uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    __shared__ float2 tn[32][33], ts[32][33];
+    if (DROP && seed_dev) seed += seed_dev[0];
+    const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+    const long b = blockIdx.z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + ty + 8 * r, t = t0 + tx;
+        float2 on = make_float2(0.f, 0.f), os = on;
+        if (f < F && t < T) {
+            const long i = (b * F + f) * T + t;
+            float2 vd, m1, m, n, sh; float kx, ky;
+            apply_one<DROP>(Y[i], D[i], i, eps, drop_p, inv_keep, seed, vd, kx, ky, m1, m, n, sh);
+            if (Mout) Mout[i] = m;
+            on = polar_turn(n, eps); os = polar_turn(sh, eps);
+        }
+        tn[ty + 8 * r][tx] = on; ts[ty + 8 * r][tx] = os;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r, f = f0 + tx;
+        if (t < T && f < Fp) {
+            out[(b * T + t) * Fp + f] = tn[tx][ty + 8 * r];
+            out[((b + B) * T + t) * Fp + f] = ts[tx][ty + 8 * r];
+        }
+    }
+}
+
+// g: complex[2B][T][Fp] cotangent of the two spectra (herm: as the plain rfft of the cotangent of an unnormalised inverse real FFT's
+// output — every bin but DC and Nyquist counts twice); gM: optional cotangent of the mask; gD: complex[B][F][T]
+template <bool DROP>
+__global__ __launch_bounds__(kThreads) void bound2_apply_polar_frames_bwd_kernel(const float2* __restrict__ Y, const float2* __restrict__ D,
+                                                                                  const float2* __restrict__ g, const float2* __restrict__ gM,
+                                                                                  float2* __restrict__ gD, int B, int F, int Fp, int T,
+                                                                                  float eps, int herm, float drop_p, uint64_t seed,
+                                                                                  const uint64_t* __restrict__ seed_dev) {
+    __shared__ float2 tn[32][33], ts[32][33];
+    if (DROP && seed_dev) seed += seed_dev[0];
+    const float inv_keep = DROP ? 1.f / (1.f - drop_p) : 1.f;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+    const long b = blockIdx.z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r, f = f0 + tx;
+        const bool in = t < T && f < F;
+        tn[tx][ty + 8 * r] = in ? g[(b * T + t) * Fp + f] : make_float2(0.f, 0.f);
+        ts[tx][ty + 8 * r] = in ? g[((b + B) * T + t) * Fp + f] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + ty + 8 * r, t = t0 + tx;
+        if (f < F && t < T) {
+            const long i = (b * F + f) * T + t;
+            const float2 y = Y[i];
+            float2 vd, m1, m, n, sh; float kx, ky;
+            apply_one<DROP>(y, D[i], i, eps, drop_p, inv_keep, seed, vd, kx, ky, m1, m, n, sh);
+            float2 gon = tn[ty + 8 * r][tx], gos = ts[ty + 8 * r][tx];
+            if (herm && f > 0 && f < Fp - 1) { gon.x *= 2.f; gon.y *= 2.f; gos.x *= 2.f; gos.y *= 2.f; }
+            const float2 gn = polar_turn_bwd(n, eps, gon), gs = polar_turn_bwd(sh, eps, gos);
+            const float2 tt = make_float2(gn.x - gs.x, gn.y - gs.y);           // n = Y m, s = Y - n
+            float2 gm = make_float2(y.x * tt.x + y.y * tt.y, y.x * tt.y - y.y * tt.x);       // conj(Y) t
+            if (gM) { const float2 e = gM[i]; gm.x += e.x; gm.y += e.y; }
+            const float2 g1 = bound_one_bwd(m1.x, m1.y, eps, gm);
+            const float2 gd = bound_one_bwd(vd.x, vd.y, eps, g1);
+            gD[i] = make_float2(gd.x * kx, gd.y * ky);
+        }
+    }
+}
+
 inline int ew_grid(long n) {
     long nb = (n + kThreads * 4 - 1) / (kThreads * 4);
     return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
@@ -229,6 +347,42 @@ extern "C" int dcs_crm_fwd(const float* S, const float* Y, float* M, long n, flo
     if (!S || !Y || !M || n <= 0) return DCS_ERR_BADARG;
     DCS_LAUNCH(crm_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, dcs_stream(stream), (const float2*)S,
                        (const float2*)Y, (float2*)M, n, eps);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// (Y, raw last-stage output D) -> the frame-major, polar-turned spectra of both estimates for the synthesis (Round 5; see the kernels).
+// out complex[2B][T][Fp] (rows [0, B): Y (.) M, rows [B, 2B): Y - Y (.) M; Fp >= F, bins >= F zero); M_out: optional.
+extern "C" int dcs_bound2_apply_polar_frames_fwd(const float* Y, const float* D_raw, float* M_out, float* out, int B, int F, int Fp,
+                                                 int T, float eps, float drop_p, unsigned long long seed,
+                                                 const unsigned long long* seed_dev, dcs_stream_t stream) {
+    if (!Y || !D_raw || !out || B <= 0 || B > 65535 || F <= 0 || Fp < F || T <= 0 || !(drop_p >= 0.f && drop_p < 1.f)) return DCS_ERR_BADARG;
+    const dim3 grid((T + 31) / 32, (Fp + 31) / 32, B);
+    if (drop_p > 0.f)
+        DCS_LAUNCH(bound2_apply_polar_frames_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)Y,
+                   (const float2*)D_raw, (float2*)M_out, (float2*)out, B, F, Fp, T, eps, drop_p, (uint64_t)seed, (const uint64_t*)seed_dev);
+    else
+        DCS_LAUNCH(bound2_apply_polar_frames_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)Y,
+                   (const float2*)D_raw, (float2*)M_out, (float2*)out, B, F, Fp, T, eps, 0.f, (uint64_t)0, (const uint64_t*)nullptr);
+    DCS_CHECK_LAUNCH();
+    return DCS_OK;
+}
+
+// g_D from the cotangent g_out of those spectra (complex[2B][T][Fp]; hermitian as in dcs_polar_frames_bwd) and, optionally, g_M
+extern "C" int dcs_bound2_apply_polar_frames_bwd(const float* Y, const float* D_raw, const float* g_out, const float* g_M, float* g_D,
+                                                 int B, int F, int Fp, int T, float eps, int hermitian, float drop_p,
+                                                 unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream) {
+    if (!Y || !D_raw || !g_out || !g_D || B <= 0 || B > 65535 || F <= 0 || Fp < F || T <= 0 || !(drop_p >= 0.f && drop_p < 1.f))
+        return DCS_ERR_BADARG;
+    const dim3 grid((T + 31) / 32, (F + 31) / 32, B);
+    if (drop_p > 0.f)
+        DCS_LAUNCH(bound2_apply_polar_frames_bwd_kernel<true>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)Y,
+                   (const float2*)D_raw, (const float2*)g_out, (const float2*)g_M, (float2*)g_D, B, F, Fp, T, eps, hermitian, drop_p,
+                   (uint64_t)seed, (const uint64_t*)seed_dev);
+    else
+        DCS_LAUNCH(bound2_apply_polar_frames_bwd_kernel<false>, grid, dim3(kThreads), 0, dcs_stream(stream), (const float2*)Y,
+                   (const float2*)D_raw, (const float2*)g_out, (const float2*)g_M, (float2*)g_D, B, F, Fp, T, eps, hermitian, 0.f,
+                   (uint64_t)0, (const uint64_t*)nullptr);
     DCS_CHECK_LAUNCH();
     return DCS_OK;
 }

@@ -98,6 +98,8 @@ SIGNATURES = {
     'dcs_bound_mask_apply_bwd': (_I, [_P] * 6 + [_L, _F, _P]),
     'dcs_bound2_mask_apply_fwd': (_I, [_P] * 6 + [_L, _F, _F, _U64, _P, _P]),
     'dcs_bound2_mask_apply_bwd': (_I, [_P] * 7 + [_L, _F, _F, _U64, _P, _P]),
+    'dcs_bound2_apply_polar_frames_fwd': (_I, [_P] * 4 + [_I] * 4 + [_F, _F, _U64, _P, _P]),
+    'dcs_bound2_apply_polar_frames_bwd': (_I, [_P] * 5 + [_I] * 4 + [_F, _I, _F, _U64, _P, _P]),
     'dcs_irfft512_frames': (_I, [_P, _P, _L, _P]),
     'dcs_rfft512_frames': (_I, [_P, _P, _L, _P]),
     'dcs_polar_frames_fwd': (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),

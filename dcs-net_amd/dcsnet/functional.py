@@ -1170,6 +1170,48 @@ def polar_wave(z, window, inv_env, n_fft, hop, scale, eps):
     return _PolarWaveFn.apply(torch.view_as_real(z.contiguous()), window, inv_env, n_fft, hop, scale, eps)
 
 
+class _Bound2ApplyPolarWaveFn(torch.autograd.Function):
+    """(Y, raw network output D) -> (twice-bounded mask or None, waveforms [2B, L] of Y (.) M and Y - Y (.) M): _Bound2MaskApplyPairFn
+    and _PolarWaveFn as ONE node whose first / last kernel is the fused mask + polar pass (mask.hip, Round 5) — the estimates never
+    exist in HBM; the backward recomputes them from (Y, D)."""
+
+    @staticmethod
+    def forward(ctx, Y, D_raw, window, inv_env, n_fft, hop, scale, eps, drop_p, seed, want_mask):
+        B, Fb, T, _ = Y.shape
+        if Fb + 1 != n_fft // 2 + 1 or n_fft != 512:
+            raise DcsHipError(f'bound2_apply_polar_wave: {Fb} bins, n_fft = {n_fft}: the fused form is built for n_fft = 512')
+        M, comp = ops.bound2_apply_polar_frames(Y, D_raw, Fb + 1, eps, drop_p, seed, want_mask)
+        frames = ops.irfft512(comp)
+        ctx.cfg = (tuple(frames.shape), hop, scale / n_fft, eps, float(drop_p), int(seed))
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(Y, D_raw, window, inv_env)
+        return M, ops.istft_ola(frames, window, inv_env, hop, scale / n_fft)
+
+    @staticmethod
+    def backward(ctx, gM, g):
+        Y, D_raw, window, inv_env = ctx.saved_tensors
+        shape, hop, scale, eps, drop_p, seed = ctx.cfg
+        if g is None and gM is None:
+            return (None,) * 11
+        if g is None:
+            return (None, ops.bound2_mask_apply_bwd(Y, D_raw, None, gM.contiguous(), None, None, eps, drop_p, seed)) + (None,) * 9
+        g_frames = ops.istft_ola(shape, window, inv_env, hop, scale, grad=g.contiguous())
+        G = ops.rfft512(g_frames)                                                     # [2B, T, 257, 2], no scaling
+        gD = ops.bound2_apply_polar_frames(Y, D_raw, Y.shape[1] + 1, eps, drop_p, seed, grad=G,
+                                           g_M=None if gM is None else gM.contiguous(), hermitian=True)
+        return (None, gD) + (None,) * 9
+
+
+def bound2_apply_polar_wave_pair(Y, D_raw, window, inv_env, n_fft, hop, scale, eps=10e-7, drop=(0.0, 0), want_mask=False):
+    """Complex Y, D_raw [B, F, T] -> (M complex [B, F, T] or None, waveforms float [2B, hop (T - 1)]): rows [0, B) the noise
+    estimate Y (.) M, rows [B, 2B) the speech estimate Y - Y (.) M, M = bound_cRM(bound_cRM(dropout(D_raw)))
+    (c_network.py:221-225, network_functions.py:240-247); differentiable w.r.t. D_raw."""
+    y = torch.view_as_real(Y.contiguous())
+    d = torch.view_as_real(D_raw.contiguous())
+    M, wave = _Bound2ApplyPolarWaveFn.apply(y, d, window, inv_env, n_fft, hop, scale, eps, float(drop[0]), int(drop[1]), bool(want_mask))
+    return (None if M is None else torch.view_as_complex(M)), wave
+
+
 class _SiSNRFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, clean, est, eps):

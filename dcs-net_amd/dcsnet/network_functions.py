@@ -291,12 +291,25 @@ def _complex_step_pair(self, noise_data, noisy_data, clean_data):
     # the module offers it (this build's C_NETWORK: forward(x, bound=False)); any other module gets the two-step form
     fused = getattr(self, 'supports_unbounded_forward', False)
     mask_out = self(noisy_data, bound=False) if fused else self(noisy_data)
+    squeezed = mask_out.dim() + 1 == noisy_data.dim() and B == 1           # the B = 1 squeeze quirk (c_network.py:224)
+    if fused and cfg.fft_size == 512:
+        # Round 5: mask application and the synthesis' polar round trip in one kernel each way — the estimates make no round trip
+        # through HBM (F.bound2_apply_polar_wave_pair).  The twice-bounded mask itself is read by the mask-domain losses only
+        # (noise_loss_type 0, 2, 4, 5), never on this path (type 6): it is not stored.
+        drop = self.__dict__.pop('_pending_dropout', (0.0, 0))
+        window = _window_on(cfg, noisy_data.device)
+        scale = float(cfg.fft_size) ** 0.5 if cfg.normalise_stft else 1.0
+        mask, ew = F.bound2_apply_polar_wave_pair(noisy_data, mask_out.unsqueeze(0) if squeezed else mask_out, window,
+                                                  _inv_envelope(window, noisy_data.shape[2], cfg.hop_length), cfg.fft_size,
+                                                  cfg.hop_length, scale, eps, drop, want_mask=False)
+        return {'noise_audio': tw[:B], 'clean_audio': tw[B:], 'predict_noise_mask': mask,
+                'predict_noise_audio': ew[:B], 'predict_clean_audio': ew[B:], '_pair': (tw, ew)}
     if fused:
         drop = self.__dict__.pop('_pending_dropout', (0.0, 0))
         apply_pair = lambda y_, m_, e_: F.bound2_mask_apply_pair_complex(y_, m_, e_, drop)
     else:
         apply_pair = F.bound_mask_apply_pair_complex
-    if mask_out.dim() + 1 == noisy_data.dim() and B == 1:          # the B = 1 squeeze quirk (c_network.py:224)
+    if squeezed:
         mask, NS = apply_pair(noisy_data, mask_out.unsqueeze(0), eps)
         mask = mask.squeeze(0)
     else:

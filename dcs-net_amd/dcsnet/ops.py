@@ -962,6 +962,33 @@ def bound_mask_apply_bwd(Y, M_in, g_M, g_N, g_S, eps=10e-7):
     return g
 
 
+def bound2_apply_polar_frames(Y, D_raw, Fp, eps=10e-7, drop_p=0.0, seed=0, want_mask=False, grad=None, g_M=None, hermitian=False):
+    """dcs_bound2_apply_polar_frames_fwd / _bwd: Y, D_raw float [B,F,T,2].  Forward (grad None): (M or None, out [2B,T,Fp,2]) — the
+    frame-major polar-turned spectra of Y (.) M (rows [0, B)) and Y - Y (.) M (rows [B, 2B)).  With grad [2B,T,Fp,2] (and optionally
+    g_M): the cotangent of D_raw."""
+    _chk(Y, 'Y', 4)
+    _chk(D_raw, 'D_raw', 4)
+    if Y.shape != D_raw.shape:
+        raise _lib.DcsHipError(f'bound2_apply_polar_frames: Y {tuple(Y.shape)} vs D {tuple(D_raw.shape)}')
+    B, F, T, _ = Y.shape
+    lib = _lib.load()
+    if grad is None:
+        out = torch.empty((2 * B, T, Fp, 2), dtype=torch.float32, device=Y.device)
+        M = torch.empty_like(Y) if want_mask else None
+        check(lib.dcs_bound2_apply_polar_frames_fwd(ptr(Y), ptr(D_raw), ptr(M), ptr(out), B, F, Fp, T, eps, float(drop_p), int(seed),
+                                                    ptr(SEED_STATE), cur_stream()), 'dcs_bound2_apply_polar_frames_fwd')
+        return M, out
+    _chk(grad, 'grad', 4)
+    _chk(g_M, 'g_M', 4)
+    if tuple(grad.shape) != (2 * B, T, Fp, 2):
+        raise _lib.DcsHipError(f'bound2_apply_polar_frames: grad {tuple(grad.shape)} for B={B}, T={T}, Fp={Fp}')
+    g = torch.empty_like(D_raw)
+    check(lib.dcs_bound2_apply_polar_frames_bwd(ptr(Y), ptr(D_raw), ptr(grad), ptr(g_M), ptr(g), B, F, Fp, T, eps, int(bool(hermitian)),
+                                                float(drop_p), int(seed), ptr(SEED_STATE), cur_stream()),
+          'dcs_bound2_apply_polar_frames_bwd')
+    return g
+
+
 def polar_frames(z, Fp, eps=10e-7, grad=None, hermitian=False):
     """z: float [B,F,T,2].  Forward (grad None): FRAME-MAJOR [B,T,Fp,2] = |z| unit(z_r+eps, z_i), zero bins F..Fp-1.
     With grad [B,T,Fp,2]: the cotangent of z (hermitian: grad is the plain rfft of an unnormalised irfft's output

@@ -607,6 +607,18 @@ int dcs_bound2_mask_apply_bwd(const float* Y, const float* D_raw, const float* g
                               const float* g_S, float* g_D, long n, float eps, float drop_p, unsigned long long seed,
                               const unsigned long long* seed_dev, dcs_stream_t stream);
 
+/* The same pass fused with the synthesis' polar round trip (mask.hip, Round 5): straight from (Y, D_raw) complex[B][F][T] to the two
+ * frame-major spectra dcs_polar_frames_fwd would make of the estimates — out complex[2B][T][Fp], rows [0, B) from Y (.) M, rows
+ * [B, 2B) from Y - Y (.) M, bins F..Fp-1 zero — so that N_hat / S_hat never exist in HBM (network_functions.py:240-247).
+ * M_out: optional (NULL: the mask is not stored).  _bwd: g_D from the cotangent g_out of `out` (hermitian as in
+ * dcs_polar_frames_bwd) and, optionally, the cotangent g_M of the mask; everything in between is recomputed. */
+int dcs_bound2_apply_polar_frames_fwd(const float* Y, const float* D_raw, float* M_out, float* out, int B, int F, int Fp, int T,
+                                      float eps, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                                      dcs_stream_t stream);
+int dcs_bound2_apply_polar_frames_bwd(const float* Y, const float* D_raw, const float* g_out, const float* g_M, float* g_D,
+                                      int B, int F, int Fp, int T, float eps, int hermitian, float drop_p,
+                                      unsigned long long seed, const unsigned long long* seed_dev, dcs_stream_t stream);
+
 /* Waveform synthesis around the inverse FFT of mag_phase_2_wave / torch.istft (network_functions.py:140-150 via
  * :213-221 and :244-247).
  * dcs_polar_frames_fwd: out = |z| (cos phi + j sin phi), phi = atan2(z_i, z_r + eps), for bins f < F and zeros for

@@ -966,6 +966,45 @@ def test_double_bound_mask_application_in_one_kernel(dev):
     assert torch.equal(torch.view_as_real(S), torch.view_as_real(outs[0][1][1]))
 
 
+@pytest.mark.parametrize('B,T,drop', [(3, 40, (0.0, 0)), (2, 72, (0.3, 4242)), (1, 8, (0.0, 0))])
+def test_mask_application_fused_with_the_polar_round_trip(dev, B, T, drop):
+    """dcs_bound2_apply_polar_frames_fwd / _bwd (network_functions.py:240-247 as one kernel each way inside
+    F.bound2_apply_polar_wave_pair) against the chain it replaces, F.bound2_mask_apply_pair_complex -> F.polar_wave — itself
+    pinned to the reference's vectors.  Same arithmetic per element in the same order: bit-identical waveforms, mask and
+    cotangent of the raw output, incl. the singular points of atan2, ragged tiles (T not a multiple of 32) and the dropout mask."""
+    from dcsnet import functional as F, ops
+    n_fft, hop = 512, 128
+    d0 = rand_c((B, 256, T), 5, 1.5)
+    d0.view(-1)[:4] = torch.tensor([0 + 0j, -1e-6 + 0j, 1e-7 - 1e-7j, -2.0 + 0j])
+    Y = rand_c((B, 256, T), 6, 0.8).to(dev)
+    window = torch.hann_window(n_fft).to(dev)
+    inv_env = ops.istft_envelope(window, T, hop)
+    L = hop * (T - 1)
+    gw = torch.randn(2 * B, L, generator=torch.Generator().manual_seed(9)).to(dev)
+    gM = torch.view_as_real(rand_c((B, 256, T), 7)).to(dev)
+    for with_mask in (False, True):
+        outs = []
+        for fused in (False, True):
+            d = d0.clone().to(dev).requires_grad_(True)
+            if fused:
+                M, wave = F.bound2_apply_polar_wave_pair(Y, d, window, inv_env, n_fft, hop, 1.0, 10e-7, drop, want_mask=with_mask)
+            else:
+                M, NS = F.bound2_mask_apply_pair_complex(Y, d, 10e-7, drop)
+                wave = F.polar_wave(NS.reshape(2 * B, 256, T), window, inv_env, n_fft, hop, 1.0, 10e-7)
+            loss = (wave * gw).sum()
+            if with_mask:
+                loss = loss + (torch.view_as_real(M) * gM).sum()
+            loss.backward()
+            outs.append((wave.detach(), d.grad.detach(), M.detach() if with_mask else None))
+        assert tuple(outs[1][0].shape) == (2 * B, L)
+        assert torch.equal(outs[0][0], outs[1][0]), 'waveforms'
+        assert torch.equal(torch.view_as_real(outs[0][1]), torch.view_as_real(outs[1][1])), 'g_D'
+        if with_mask:
+            assert torch.equal(torch.view_as_real(outs[0][2]), torch.view_as_real(outs[1][2])), 'mask'
+        else:
+            assert M is None
+
+
 @pytest.mark.parametrize('C,H,W', [(8, 24, 20), (64, 8, 16), (128, 4, 32)])
 def test_cbn_apply_that_pools_for_the_channel_attention(dev, C, H, W):
     """dcs_cbn_fwd_slabs_pool + dcs_channel_attention_fc_fwd (a decoder stage's CBN + CLReLU + channel attention in three
