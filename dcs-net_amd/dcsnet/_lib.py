@@ -102,6 +102,8 @@ SIGNATURES = {
     'dcs_bound2_apply_polar_frames_bwd': (_I, [_P] * 5 + [_I] * 4 + [_F, _I, _F, _U64, _P, _P]),
     'dcs_irfft512_frames': (_I, [_P, _P, _L, _P]),
     'dcs_rfft512_frames': (_I, [_P, _P, _L, _P]),
+    'dcs_rfft512_ola_frames': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    'dcs_irfft512_ola_frames': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     'dcs_polar_frames_fwd': (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     'dcs_polar_frames_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     'dcs_istft_envelope': (_I, [_P, _P, _I, _I, _I, _P]),

@@ -1145,23 +1145,25 @@ class _PolarWaveFn(torch.autograd.Function):
         if Fb + 1 != n_fft // 2 + 1:
             raise DcsHipError(f'polar_wave: {Fb} bins + 1 zero bin is not the one-sided spectrum of n_fft = {n_fft}')
         comp = ops.polar_frames(z, Fb + 1, eps)
+        ctx.cfg = ((B, T, n_fft), n_fft, hop, scale / n_fft, eps)
+        ctx.save_for_backward(z, window, inv_env)
+        if n_fft == 512 and ops.irfft512_ola_ok(T, hop):   # inverse FFT + overlap-add in one kernel: the frames stay in LDS
+            return ops.irfft512_ola(comp, window, inv_env, hop, scale / n_fft)
         if n_fft == 512:                                   # hand-written 512-point pair (fft512.hip)
             frames = ops.irfft512(comp)
         else:
             frames = torch.fft.irfft(torch.view_as_complex(comp), n=n_fft, dim=-1, norm='forward')
-        ctx.cfg = (tuple(frames.shape), n_fft, hop, scale / n_fft, eps)
-        ctx.save_for_backward(z, window, inv_env)
         return ops.istft_ola(frames, window, inv_env, hop, scale / n_fft)
 
     @staticmethod
     def backward(ctx, g):
         z, window, inv_env = ctx.saved_tensors
         shape, n_fft, hop, scale, eps = ctx.cfg
-        g_frames = ops.istft_ola(shape, window, inv_env, hop, scale, grad=g.contiguous())
-        if n_fft == 512:
-            G = ops.rfft512(g_frames)                                                 # [B, T, 257, 2], no scaling
+        if n_fft == 512 and not (hop & 1):
+            G = ops.rfft512_ola(g.contiguous(), window, inv_env, shape[1], hop, scale)     # [B, T, 257, 2]; the frames are not stored
         else:
-            G = torch.view_as_real(torch.fft.rfft(g_frames, dim=-1))
+            g_frames = ops.istft_ola(shape, window, inv_env, hop, scale, grad=g.contiguous())
+            G = ops.rfft512(g_frames) if n_fft == 512 else torch.view_as_real(torch.fft.rfft(g_frames, dim=-1))
         return ops.polar_frames(z, z.shape[1] + 1, eps, grad=G, hermitian=True), None, None, None, None, None, None
 
 
@@ -1181,11 +1183,12 @@ class _Bound2ApplyPolarWaveFn(torch.autograd.Function):
         if Fb + 1 != n_fft // 2 + 1 or n_fft != 512:
             raise DcsHipError(f'bound2_apply_polar_wave: {Fb} bins, n_fft = {n_fft}: the fused form is built for n_fft = 512')
         M, comp = ops.bound2_apply_polar_frames(Y, D_raw, Fb + 1, eps, drop_p, seed, want_mask)
-        frames = ops.irfft512(comp)
-        ctx.cfg = (tuple(frames.shape), hop, scale / n_fft, eps, float(drop_p), int(seed))
+        ctx.cfg = ((2 * B, T, n_fft), hop, scale / n_fft, eps, float(drop_p), int(seed))
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(Y, D_raw, window, inv_env)
-        return M, ops.istft_ola(frames, window, inv_env, hop, scale / n_fft)
+        if ops.irfft512_ola_ok(T, hop):
+            return M, ops.irfft512_ola(comp, window, inv_env, hop, scale / n_fft)
+        return M, ops.istft_ola(ops.irfft512(comp), window, inv_env, hop, scale / n_fft)
 
     @staticmethod
     def backward(ctx, gM, g):
@@ -1195,8 +1198,10 @@ class _Bound2ApplyPolarWaveFn(torch.autograd.Function):
             return (None,) * 11
         if g is None:
             return (None, ops.bound2_mask_apply_bwd(Y, D_raw, None, gM.contiguous(), None, None, eps, drop_p, seed)) + (None,) * 9
-        g_frames = ops.istft_ola(shape, window, inv_env, hop, scale, grad=g.contiguous())
-        G = ops.rfft512(g_frames)                                                     # [2B, T, 257, 2], no scaling
+        if hop & 1:
+            G = ops.rfft512(ops.istft_ola(shape, window, inv_env, hop, scale, grad=g.contiguous()))
+        else:
+            G = ops.rfft512_ola(g.contiguous(), window, inv_env, shape[1], hop, scale)     # [2B, T, 257, 2]; the frames are not stored
         gD = ops.bound2_apply_polar_frames(Y, D_raw, Y.shape[1] + 1, eps, drop_p, seed, grad=G,
                                            g_M=None if gM is None else gM.contiguous(), hermitian=True)
         return (None, gD) + (None,) * 9

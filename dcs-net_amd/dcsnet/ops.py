@@ -1007,6 +1007,35 @@ def polar_frames(z, Fp, eps=10e-7, grad=None, hermitian=False):
     return gz
 
 
+def rfft512_ola(gy, window, inv_env, T, hop, scale):
+    """rfft512(istft_ola backward frames of gy) without storing the frames (dcs_rfft512_ola_frames): gy float [B, hop (T - 1)] ->
+    [B, T, 257, 2]."""
+    _chk(gy, 'gy', 2)
+    B, L = gy.shape
+    if L != hop * (T - 1) or window.numel() != 512:
+        raise _lib.DcsHipError(f'rfft512_ola: gy {tuple(gy.shape)} for T={T}, hop={hop}, window {window.numel()}')
+    G = torch.empty((B, T, 257, 2), dtype=torch.float32, device=gy.device)
+    check(_lib.load().dcs_rfft512_ola_frames(ptr(gy), ptr(window), ptr(inv_env), ptr(G), B, T, hop, float(scale), cur_stream()),
+          'dcs_rfft512_ola_frames')
+    return G
+
+
+def irfft512_ola(X, window, inv_env, hop, scale):
+    """istft_ola(irfft512(X)) without storing the frames (dcs_irfft512_ola_frames): X float [B, T, 257, 2] -> [B, hop (T - 1)]."""
+    _chk(X, 'X', 4)
+    B, T = X.shape[:2]
+    if X.shape[-2:] != (257, 2) or window.numel() != 512:
+        raise _lib.DcsHipError(f'irfft512_ola: X {tuple(X.shape)}, window {window.numel()}')
+    y = torch.empty((B, hop * (T - 1)), dtype=torch.float32, device=X.device)
+    check(_lib.load().dcs_irfft512_ola_frames(ptr(X), ptr(window), ptr(inv_env), ptr(y), B, T, hop, float(scale), cur_stream()),
+          'dcs_irfft512_ola_frames')
+    return y
+
+
+def irfft512_ola_ok(T, hop):
+    return T >= 2 and hop in (64, 128, 256)
+
+
 def irfft512(X):
     """X float [..., 257, 2] one-sided spectra -> [..., 512] unnormalised inverse real FFT (dcs_irfft512_frames)."""
     _chk(X, 'X')

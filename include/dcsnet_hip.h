@@ -639,6 +639,14 @@ int dcs_bound2_apply_polar_frames_bwd(const float* Y, const float* D_raw, const 
  *   the one-sided x2 weighting that dcs_polar_frames_bwd(hermitian = 1) applies). */
 int dcs_irfft512_frames(const float* X, float* y, long frames, dcs_stream_t stream);
 int dcs_rfft512_frames(const float* g, float* G, long frames, dcs_stream_t stream);
+/* dcs_rfft512_frames of the frames dcs_istft_ola_bwd would write, read on the fly from g_y float[B][hop (T - 1)] (Round 5: the
+ * windowed cotangent frames are not stored; bit-identical G complex[B * T][257]).  hop even, n_fft = 512. */
+int dcs_rfft512_ola_frames(const float* g_y, const float* window, const float* inv_env, float* G, int B, int T, int hop,
+                           float scale, dcs_stream_t stream);
+/* dcs_istft_ola_fwd(dcs_irfft512_frames(X)) in one kernel — the frames stay in LDS (Round 5; the same sums in the same order, bit-identical
+ * y float[B][hop (T - 1)]).  X complex[B * T][257]; hop in {64, 128, 256}. */
+int dcs_irfft512_ola_frames(const float* X, const float* window, const float* inv_env, float* y, int B, int T, int hop,
+                            float scale, dcs_stream_t stream);
 int dcs_polar_frames_fwd(const float* z, float* out, int B, int F, int Fp, int T, float eps, dcs_stream_t stream);
 int dcs_polar_frames_bwd(const float* z, const float* g_out, float* g_z, int B, int F, int Fp, int T, float eps,
                          int hermitian, dcs_stream_t stream);

@@ -763,6 +763,36 @@ def test_fft512_pair(dev, frames):
     close(ops.rfft512(y.to(dev)), torch.view_as_real(torch.fft.rfft(y, dim=-1)), rel=2e-6)
 
 
+@pytest.mark.parametrize('B,T,hop', [(3, 40, 128), (1, 2, 128), (2, 33, 64)])
+def test_forward_fft_of_the_overlap_add_adjoint_without_the_frames(dev, B, T, hop):
+    """dcs_rfft512_ola_frames (the synthesis backward, network_functions.py:140-150: rfft of the windowed cotangent frames,
+    read on the fly from the cotangent of the waveform) against dcs_istft_ola_bwd + dcs_rfft512_frames: same products in the
+    same order, bit-identical."""
+    from dcsnet import ops
+    g = torch.Generator().manual_seed(B * T + hop)
+    window = torch.hann_window(512).to(dev)
+    inv_env = ops.istft_envelope(window, T, hop)
+    gy = torch.randn(B, hop * (T - 1), generator=g).to(dev)
+    want = ops.rfft512(ops.istft_ola((B, T, 512), window, inv_env, hop, 0.37, grad=gy))
+    got = ops.rfft512_ola(gy, window, inv_env, T, hop, 0.37)
+    assert tuple(got.shape) == (B, T, 257, 2) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize('B,T,hop', [(3, 40, 128), (1, 2, 128), (2, 33, 64), (2, 257, 128), (1, 14, 256), (2, 17, 128)])
+def test_inverse_fft_and_overlap_add_in_one_kernel(dev, B, T, hop):
+    """dcs_irfft512_ola_frames (torch.istft's synthesis behind the inverse FFT, network_functions.py:140-150, the frames staying in
+    LDS) against dcs_irfft512_frames + dcs_istft_ola_fwd: the same sums in the same order, bit-identical — frame counts below,
+    at and above a workgroup's 16 frames, every supported hop."""
+    from dcsnet import ops
+    g = torch.Generator().manual_seed(B * T + hop)
+    window = torch.hann_window(512).to(dev) + 0.01
+    inv_env = ops.istft_envelope(window, T, hop)
+    X = torch.randn(B, T, 257, 2, generator=g).to(dev)
+    want = ops.istft_ola(ops.irfft512(X), window, inv_env, hop, 0.37)
+    got = ops.irfft512_ola(X, window, inv_env, hop, 0.37)
+    assert tuple(got.shape) == (B, hop * (T - 1)) and torch.equal(got, want)
+
+
 def test_rnetwork_gradients_against_reference_vectors(dev, golden_dir):
     """DR-Net training path on the HIP kernels: train-mode forward + backward of R_NETWORK against the gradients of the
     reference's own r_network.py (tests/golden/rnet_grad_vectors.npz — stock torch layers, no stand-in anywhere): the
