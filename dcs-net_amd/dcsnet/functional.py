@@ -1147,7 +1147,7 @@ class _PolarWaveFn(torch.autograd.Function):
         comp = ops.polar_frames(z, Fb + 1, eps)
         ctx.cfg = ((B, T, n_fft), n_fft, hop, scale / n_fft, eps)
         ctx.save_for_backward(z, window, inv_env)
-        if n_fft == 512 and ops.irfft512_ola_ok(T, hop):   # inverse FFT + overlap-add in one kernel: the frames stay in LDS
+        if n_fft == 512 and ops.irfft512_ola_ok(T, hop):   # hop 64 / 128 / 256: inverse FFT + overlap-add in one kernel (not the configured hop = 32)
             return ops.irfft512_ola(comp, window, inv_env, hop, scale / n_fft)
         if n_fft == 512:                                   # hand-written 512-point pair (fft512.hip)
             frames = ops.irfft512(comp)
