@@ -351,12 +351,14 @@ class TrainStep:
         # assembly writes it in its own launch when handed the flag; any other loss goes through dcs_step_guard.
         self.net._dcs_skip_flag, self.net._dcs_skip_written = self.bucket.skip, False
         self._counting(True)
+        unrun = None
         try:
             loss = self._loss_no_sync(batch, 0)
         finally:
             self.net._dcs_skip_flag = None
             self._counting(False)
-        if self.net.__dict__.pop('_dcs_pack_fork', None) is not None:
+            unrun = self.net.__dict__.pop('_dcs_pack_fork', None)          # (never left behind for a later forward, whatever was raised)
+        if unrun is not None:
             raise RuntimeError('TrainStep: the step function never reached the network forward; the weight re-layout did not run')
         if not self.net._dcs_skip_written:
             check(_lib.load().dcs_step_guard(ptr(loss), ptr(self.bucket.skip), cur_stream()), 'dcs_step_guard')
