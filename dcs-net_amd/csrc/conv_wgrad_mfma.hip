@@ -994,7 +994,15 @@ long planes_bytes_for(const conv::Args& c, int ncls, int TH, int TW);
 int slabs_for(const conv::Args& c, int ncls, int TH, int TW) {
     const long tiles = (long)((c.Wout + TW - 1) / TW) * ((c.Hout + TH - 1) / TH) * c.B;
     const long wsz = (long)c.kh * c.kw * (c.C1 + c.C2) * c.Cout;
-    long cap = (96L << 20) / (wsz * ncls * (long)sizeof(float2));
+    // Bytes of partial slabs a layer may write.  Every slab is a full weight gradient written by the kernel and read back by the
+    // reduction — at [32,256,256] 194 + 200 MB per step under the 96 MB budget of rounds 2-4, more than the kernels' operands — and
+    // the kernels run on the side stream beside the data-gradient chain, which pays for that traffic: with 16 MB per layer the
+    // weight-gradient kernels themselves are 2 % slower (fewer, longer workgroups on enc4 .. dec3) and the STEP 1.3 % faster
+    // (3.267 -> 3.224 ms, same box; 8 MB: 3.34).  The optimum moves with the pixel count: 16 MB up to B = 32 (B = 16: -33 us,
+    // bf16 storage B = 32: -16 us), 32 MB at B = 64 (fp32 -14 us, bf16 -8 us; 16 MB loses there): profiles/r05_wgrad_slab_budget.txt.
+    static const long slab_mb_knob = dcs_knob("DCS_WGRAD_SLAB_MB", 0);        // (plan sweeps: a fixed budget instead)
+    const long slab_mb = slab_mb_knob > 0 ? slab_mb_knob : 16L * (c.B > 32 ? c.B : 32) / 32;
+    long cap = (slab_mb << 20) / (wsz * ncls * (long)sizeof(float2));
     if (cap < 1) cap = 1;
     if (cap > 1024) cap = 1024;
     // A workgroup's epilogue writes its whole accumulator set (up to 147 KB), so give each one several pixel
