@@ -763,7 +763,7 @@ def test_fft512_pair(dev, frames):
     close(ops.rfft512(y.to(dev)), torch.view_as_real(torch.fft.rfft(y, dim=-1)), rel=2e-6)
 
 
-@pytest.mark.parametrize('B,T,hop', [(3, 40, 128), (1, 2, 128), (2, 33, 64)])
+@pytest.mark.parametrize('B,T,hop', [(3, 40, 128), (1, 2, 128), (2, 33, 64), (2, 19, 32), (1, 256, 32)])      # (32: the configured hop)
 def test_forward_fft_of_the_overlap_add_adjoint_without_the_frames(dev, B, T, hop):
     """dcs_rfft512_ola_frames (the synthesis backward, network_functions.py:140-150: rfft of the windowed cotangent frames,
     read on the fly from the cotangent of the waveform) against dcs_istft_ola_bwd + dcs_rfft512_frames: same products in the
