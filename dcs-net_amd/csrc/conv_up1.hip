@@ -28,10 +28,21 @@ struct Up1Args {
 
 // IT: element type of the two sources — float, or bf16 (unsigned short) where the activations live in bf16
 // (dcs_cconv_up2_single_fwd_h); the result (the network's fp32 mask) and the arithmetic are fp32 either way.
+//
+// Round 5, second form.  The first one (a wave = one parity class, a thread four outputs of a class row) read five patch elements
+// and two weight elements from LDS per eight complex MACs: its counters said LDS busy 23 us of 41 (42 % conflict cycles on the
+// merged 8-byte reads) and 1260 vector instructions per wave for 512 FMAs.  Now a thread owns a 2 x 2 block of SOURCE pixels,
+// i.e. the 4 x 4 outputs above it (all four parity classes), and a wave four of the sixteen channels: per channel it reads the
+// block's 4 x 4 haloed source window once (eight aligned 16-byte reads) and the sixteen folded weights ({w.x, w.x, w.y, w.y}:
+// broadcast reads whose halves are register pairs as they arrive) for 64 complex MACs — 24 LDS instructions per 128 packed FMAs
+// instead of 56; the four waves' partial sums meet in LDS (over the spent patch) in a fixed order and leave as 32-byte runs.
 template <typename IT>
 __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
-    __shared__ __attribute__((aligned(16))) float2 tile[CIN][HR * HCP];
-    __shared__ __attribute__((aligned(16))) float4 wf[4][2][2][CIN];     // [parity class][a][b][ci], {w.x, w.y, w.y, w.x}: both broadcasts read a LOW half
+    constexpr int TP = HC + 2;                               // row pitch 36 float2: 16-byte aligned rows for the window reads
+    constexpr int PLANE = HR * TP + 12;                      // 372 float2 = 4 (mod 16): the eight channel pairs of a pixel store to distinct bank groups
+    __shared__ __attribute__((aligned(16))) float2 tile[CIN * PLANE];            // [ci][row][col]; reused for the waves' partial sums
+    __shared__ __attribute__((aligned(16))) float4 wf[CIN][4][2][2];             // [ci][parity class][a][b]: {w.x, w.x, w.y, w.y}
+    static_assert(CIN * PLANE >= 4 * 16 * 64 && (PLANE % 2) == 0, "the partial sums of four waves fit over the patch");
     const int t = threadIdx.x, b = blockIdx.y;
     const int m0 = ((int)blockIdx.x / p.tiles_w) * SRT, n0 = ((int)blockIdx.x % p.tiles_w) * SCT;
 
@@ -41,89 +52,125 @@ __global__ __launch_bounds__(256) void cconv_up1_kernel(Up1Args p) {
         // parity 0: a = 0 <- {0}, a = 1 <- {1, 2};  parity 1: a = 0 <- {0, 1}, a = 1 <- {2}
         const int dy_lo = py == 0 ? (aa == 0 ? 0 : 1) : (aa == 0 ? 0 : 2), dy_hi = py == 0 ? (aa == 0 ? 0 : 2) : (aa == 0 ? 1 : 2);
         const int dx_lo = px == 0 ? (bb == 0 ? 0 : 1) : (bb == 0 ? 0 : 2), dx_hi = px == 0 ? (bb == 0 ? 0 : 2) : (bb == 0 ? 1 : 2);
-        float2 s = make_float2(0.f, 0.f);
+        float2 sw = make_float2(0.f, 0.f);
         for (int dy = dy_lo; dy <= dy_hi; ++dy)
             for (int dx = dx_lo; dx <= dx_hi; ++dx) {
                 const float2 w = p.wt[ci * p.ct + dy * 3 + dx];
-                s.x += w.x; s.y += w.y;
+                sw.x += w.x; sw.y += w.y;
             }
-        wf[cls][aa][bb][ci] = make_float4(s.x, s.y, s.y, s.x);
+        wf[ci][cls][aa][bb] = make_float4(sw.x, sw.x, sw.y, sw.y);
     }
     // haloed source tile, channel-major planes; one float4 (2 channels) per load.  All of a thread's loads are issued
-    // before the first LDS write (a load -> wait -> write loop pays one memory round trip per element: 11 per tile)
+    // before the first LDS write (a load -> wait -> write loop pays one memory round trip per element: 11 per tile).
+    // A thread keeps ONE channel pair (256 % 8 == 0) and walks the patch pixels t / 8, t / 8 + 32, ...: source tensor and channel
+    // offset are chosen once, (row, column) advance by carries (per slot: two divisions by constants, the tensor select and a
+    // 64-bit multiply-add before — 440 of the kernel's 1260 vector instructions per wave were this loop's).
+    constexpr int NPIX = HR * HC, NL = (NPIX + 31) / 32;
+    const int q = t & 7, c = 2 * q;
+    const bool first = c < p.C1;
+    const IT* const sbase = first ? (const IT*)p.x1 + 2 * c : (const IT*)p.x2 + 2 * (c - p.C1);
+    const int cs2 = 2 * (first ? p.C1 : p.C2);
     const long img = (long)b * p.Hs * p.Ws;
-    constexpr int NSLOT = HR * HC * (CIN / 2), NL = (NSLOT + 255) / 256;
     float4 sv[NL];
+    {
+        int hr = (t >> 3) / HC, hc = (t >> 3) % HC;
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-        const int i = t + 256 * k;
-        const int q = i % (CIN / 2), px_ = i / (CIN / 2);
-        const int hc = px_ % HC, hr = px_ / HC;
-        const int sy = m0 - 1 + hr, sx = n0 - 1 + hc;
-        // always a load (clamped pixel), zeroed afterwards: predicated, each load sat in its own branch and the eleven of a
-        // thread went out one memory round trip after the other
-        const bool in = i < NSLOT && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
-        const int syc = sy < 0 ? 0 : (sy >= p.Hs ? p.Hs - 1 : sy), sxc = sx < 0 ? 0 : (sx >= p.Ws ? p.Ws - 1 : sx);
-        const long sp = img + (long)syc * p.Ws + sxc;
-        const int c = 2 * q;
-        const IT* src = c < p.C1 ? (const IT*)p.x1 + (sp * p.C1 + c) * 2 : (const IT*)p.x2 + (sp * p.C2 + (c - p.C1)) * 2;
-        const float4 v = dcs_ld4(src);
-        sv[k] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NL; ++k) {
+            const int sy = m0 - 1 + hr, sx = n0 - 1 + hc;
+            const bool in = hr < HR && sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
+            const int syc = sy < 0 ? 0 : (sy >= p.Hs ? p.Hs - 1 : sy), sxc = sx < 0 ? 0 : (sx >= p.Ws ? p.Ws - 1 : sx);
+            const float4 v = dcs_ld4(sbase + (img + (long)syc * p.Ws + sxc) * cs2);
+            sv[k] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            hc += 32;
+            if (hc >= HC) { hc -= HC; hr += 1; }
+        }
     }
+    {
+        int hr = (t >> 3) / HC, hc = (t >> 3) % HC;
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-        const int i = t + 256 * k;
-        if (i >= NSLOT) continue;
-        const int q = i % (CIN / 2), px_ = i / (CIN / 2);
-        const int hc = px_ % HC, hr = px_ / HC;
-        tile[2 * q][hr * HCP + hc] = make_float2(sv[k].x, sv[k].y);
-        tile[2 * q + 1][hr * HCP + hc] = make_float2(sv[k].z, sv[k].w);
+        for (int k = 0; k < NL; ++k) {
+            if (hr < HR) {
+                tile[(2 * q) * PLANE + hr * TP + hc] = make_float2(sv[k].x, sv[k].y);
+                tile[(2 * q + 1) * PLANE + hr * TP + hc] = make_float2(sv[k].z, sv[k].w);
+            }
+            hc += 32;
+            if (hc >= HC) { hc -= HC; hr += 1; }
+        }
     }
     __syncthreads();
 
-    const int cls = t >> 6, py = cls >> 1, px = cls & 1;
-    const int u = t & 63, m = u >> 3, nq = (u & 7) * 4;
-    // two accumulators per output, P += w.x * x and Q += w.y * x, combined at the end (conv_k7.hip: no rotated operand, hence
-    // no cross-half operand selection in the packed FMAs)
-    v2f accp[4], accq[4];
+    const int lane = t & 63, wave = t >> 6, bx = lane & 15, by = lane >> 4;      // block (by, bx): source rows 2 by, 2 by + 1 of the tile
+    // two accumulators per output, P += w.x * x and Q += w.y * x, combined at the end (no cross-half operand selection: dcs_common.h)
+    v2f accp[16], accq[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { accp[q] = v2f{0.f, 0.f}; accq[q] = v2f{0.f, 0.f}; }
-#pragma unroll 4
-    for (int ci = 0; ci < CIN; ++ci) {
+    for (int o = 0; o < 16; ++o) { accp[o] = v2f{0.f, 0.f}; accq[o] = v2f{0.f, 0.f}; }
+#pragma unroll 1
+    for (int cc = 0; cc < CIN / 4; ++cc) {
+        const int ci = wave * (CIN / 4) + cc;
+        v2f xw[4][4];                                        // the block's window: tile rows 2 by .. 2 by + 3, columns 2 bx .. 2 bx + 3
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const float2* row = &tile[ci][(m + a + py) * HCP + nq + px];
-            v2f xv[5];
+        for (int r = 0; r < 4; ++r) {
+            const float4* row = reinterpret_cast<const float4*>(tile + ci * PLANE + (2 * by + r) * TP + 2 * bx);
+            const float4 lo = row[0], hi = row[1];
+            xw[r][0] = v2f{lo.x, lo.y}; xw[r][1] = v2f{lo.z, lo.w}; xw[r][2] = v2f{hi.x, hi.y}; xw[r][3] = v2f{hi.z, hi.w};
+        }
 #pragma unroll
-            for (int j = 0; j < 5; ++j) { const float2 v = row[j]; xv[j] = v2f{v.x, v.y}; }
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const float4 w = wf[cls][a][bb][ci];
-                const v2f wx = v2f{w.x, w.x}, wy = v2f{w.z, w.z};          // (no cross-half operand selection: dcs_common.h)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    accp[q] = __builtin_elementwise_fma(wx, xv[q + bb], accp[q]);
-                    accq[q] = __builtin_elementwise_fma(wy, xv[q + bb], accq[q]);
+                for (int bb = 0; bb < 2; ++bb) {
+                    const float4 w = wf[ci][cls][a][bb];
+                    const v2f wx = v2f{w.x, w.y}, wy = v2f{w.z, w.w};
+#pragma unroll
+                    for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+                        for (int sx = 0; sx < 2; ++sx) {     // output (2 sy + py, 2 sx + px) of the 4 x 4
+                            const int o = (2 * sy + py) * 4 + 2 * sx + px;
+                            const v2f x = xw[sy + a + py][sx + bb + px];
+                            accp[o] = __builtin_elementwise_fma(wx, x, accp[o]);
+                            accq[o] = __builtin_elementwise_fma(wy, x, accq[o]);
+                        }
                 }
-            }
         }
     }
-    v2f acc[4];
+    __syncthreads();                                         // every wave is done with the patch
+    float2* red = tile;                                      // red[wave][o][lane]
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = v2f{accp[q].x - accq[q].y, accp[q].y + accq[q].x};
+    for (int o = 0; o < 16; ++o) {
+        float px_ = accp[o].x, py_ = accp[o].y, qx_ = accq[o].x, qy_ = accq[o].y;
+        asm volatile("" : "+v"(px_), "+v"(py_), "+v"(qx_), "+v"(qy_));          // scalar combine (a vector one becomes a cross-half v_pk_add)
+        red[(wave * 16 + o) * 64 + lane] = make_float2(px_ - qy_, py_ + qx_);
+    }
+    __syncthreads();
+    // thread (wave, lane) finishes output row `wave` of block `lane`: four adjacent outputs, the waves' partial sums in order 0..3
     const float br = p.b_r ? p.b_r[0] : 0.f, bi = p.b_i ? p.b_i[0] : 0.f;
-    const int sy = m0 + m;
-    if (sy >= p.Hs) return;
-    const int Wo = 2 * p.Ws;
-    float2* yrow = p.y + ((long)b * 2 * p.Hs + 2 * sy + py) * Wo;
+    float2 outv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int sx = n0 + nq + q;
-        if (sx < p.Ws) yrow[2 * sx + px] = make_float2(acc[q].x + (br - bi), acc[q].y + (br + bi));
+    for (int c = 0; c < 4; ++c) {
+        const int o = wave * 4 + c;
+        float2 a0 = red[(0 * 16 + o) * 64 + lane];
+        const float2 a1 = red[(1 * 16 + o) * 64 + lane], a2 = red[(2 * 16 + o) * 64 + lane], a3 = red[(3 * 16 + o) * 64 + lane];
+        a0.x = ((a0.x + a1.x) + a2.x) + a3.x; a0.y = ((a0.y + a1.y) + a2.y) + a3.y;
+        outv[c] = make_float2(a0.x + (br - bi), a0.y + (br + bi));
+    }
+    const int sy0 = m0 + 2 * by, sx0 = n0 + 2 * bx;          // the block's first source pixel
+    const int oy = 2 * sy0 + wave, ox = 2 * sx0;
+    if (oy < 2 * p.Hs && sx0 < p.Ws) {
+        float2* yrow = p.y + ((long)b * 2 * p.Hs + oy) * (2 * p.Ws) + ox;
+        if (sx0 + 1 < p.Ws) {
+            *reinterpret_cast<float4*>(yrow) = make_float4(outv[0].x, outv[0].y, outv[1].x, outv[1].y);
+            *reinterpret_cast<float4*>(yrow + 2) = make_float4(outv[2].x, outv[2].y, outv[3].x, outv[3].y);
+        } else {                                             // (an odd source width: the block's second column is outside)
+            *reinterpret_cast<float4*>(yrow) = make_float4(outv[0].x, outv[0].y, outv[1].x, outv[1].y);
+        }
     }
 }
 
+}  // namespace
 
+namespace {
 // ---- backward: data gradient and weight gradient straight from the cotangent (Round 5) ---------------------------------------------
 // The factored backward wrote the nine tap sums of g_y per source pixel as a 16-channel tensor (67 MB at [32,256,256], 7 of the 16
 // channels padding) and ran a 1x1 MFMA conv and its weight gradient over it: 352 MB of traffic, six launches, 100 us.  Here both

@@ -382,6 +382,7 @@ class C_NETWORK(LightningModule):
     skip_attention_early = int(os.environ.get('DCS_SKIP_EARLY', '4'))     # inference: encoder outputs whose skip attentions start early (0: none)
     supports_unbounded_forward = True      # forward(x, bound=False): see forward
     accepts_pack_fork = True               # forward issues dp.TrainStep's pending weight re-layout on a side stream
+    pack_plan_safe = True                  # every packed weight derives from a registered parameter through functional.packed_weight (dp.TrainStep)
     activation_dtype = torch.float32
 
     def set_activation_dtype(self, dtype):

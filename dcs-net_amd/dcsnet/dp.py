@@ -215,7 +215,12 @@ class TrainStep:
             self.seed_state = torch.zeros(1, dtype=torch.int64, device=self.bucket.flat.device)
             ops.SEED_STATE = self.seed_state
         self._graph = self._graph_opt = self._static_batch = self._static_loss = None
-        self.use_pack_plan, self._plan = bool(use_pack_plan), None
+        # The pack plan replays every weight re-layout recorded during the first step from the recorded SOURCE POINTERS: safe only
+        # for a network all of whose packs read registered parameters (stable addresses in the flat bucket) through
+        # functional.packed_weight (destinations kept alive by the plan) — C_NETWORK says so (pack_plan_safe).  R_NETWORK derives its
+        # packed panels from temporaries (paired filters, flipped / sliced copies: r_network.py): replayed, those jobs read and
+        # WRITE freed memory (found in round 5: the second step of the first DR-Net TrainStep of a process differed from later ones).
+        self.use_pack_plan, self._plan = bool(use_pack_plan) and bool(getattr(net, 'pack_plan_safe', False)), None
         self.pack_fork = bool(pack_fork)
         self._calls = 0
         # weight-gradient kernels on a side stream beside the data-gradient chain (functional._CConv2dFn.backward): same kernels,

@@ -361,6 +361,36 @@ def test_rnetwork_graph_replayed_train_step_matches_eager(dev):
         assert abs(a - b) <= 1e-3 * abs(a) + 1e-3, (eager, graph)
 
 
+def test_rnetwork_train_steps_do_not_depend_on_what_ran_before(dev):
+    """Round 5: dp.TrainStep replayed its pack plan for DR-Net as well — whose packed panels derive from temporaries (paired
+    filters, flipped / sliced copies), so the replayed jobs read and wrote freed memory: the second step of the FIRST TrainStep of
+    a process differed from later ones by 1e-3 and the graph / eager comparison above failed once in a full run.  The plan is now
+    used only by networks that declare pack_plan_safe (C_NETWORK): two DR-Net TrainSteps in one process give the same bits."""
+    import sys
+    from dcsnet.config import config, hparams
+    from dcsnet.r_network import R_NETWORK
+    from dcsnet.c_network import C_NETWORK
+    from dcsnet.dp import TrainStep
+    from oracle.seeded_state import fill_state_stream
+    hp = dict(hparams)
+    hp['dropout_conv'], hp['dropout_fc'] = 0.0, 0.0
+    clean, noise = seeded_input(2, 256, 32, 1, 0.1), seeded_input(2, 256, 32, 2, 0.05)
+    batch = (noise.to(dev), (clean + noise).to(dev), clean.to(dev), [0, 1])
+    argv = sys.argv
+    sys.argv = ['train.py', 'drs', '0']
+    try:
+        runs = []
+        for _ in range(3):
+            net = fill_state_stream(R_NETWORK(config, hp, 0), 5).to(dev).train()
+            ts = TrainStep(net, use_graph=False)
+            runs.append([float(ts(batch)) for _ in range(4)])
+            assert ts._plan is None and not ts.use_pack_plan
+    finally:
+        sys.argv = argv
+    assert runs[0] == runs[1] == runs[2], runs
+    assert getattr(C_NETWORK, 'pack_plan_safe', False) and not getattr(R_NETWORK, 'pack_plan_safe', False)
+
+
 @pytest.mark.parametrize('graph', [False, True], ids=['eager', 'graph'])
 def test_inference_side_stream_overlap_is_bit_identical(dev, graph):
     """C_NETWORK.overlap_skip_attention (inference: the batched skip attentions on a side stream beside the LSTM, joined
