@@ -147,12 +147,22 @@ _windows = {}
 
 
 def _window_on(config, device):
-    """The synthesis window on `device`, uploaded once (a per-call host-to-device copy would also be illegal
-    inside a hipGraph capture)."""
-    key = (id(config.window), device)
-    w = _windows.get(key)
-    if w is None:
-        w = _windows[key] = config.window.to(device)
+    """The synthesis window on `device`, uploaded once per window TENSOR (a per-call host-to-device copy would also be illegal
+    inside a hipGraph capture).  The entry holds a weak reference to the host tensor: a recycled id() of a dead window must not
+    serve another config the old one's copy."""
+    import weakref
+    src = config.window
+    if src.device == device:
+        return src
+    key = (id(src), device)
+    ent = _windows.get(key)
+    if ent is not None and ent[0]() is src and ent[2] == src._version:
+        return ent[1]
+    w = src.to(device)
+    if not (device.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+        if len(_windows) > 64:
+            _windows.clear()
+        _windows[key] = (weakref.ref(src), w, src._version)
     return w
 
 
@@ -160,11 +170,17 @@ _envelopes = {}
 
 
 def _inv_envelope(window, T, hop):
-    """1 / squared-window envelope for T frames; depends only on (window, T, hop): computed once (HIP)."""
+    """1 / squared-window envelope for T frames; depends only on (window, T, hop): computed once per device window tensor (HIP).
+    The entry keeps the window alive, so its address cannot be handed to another tensor while the entry exists."""
     key = (window.data_ptr(), T, hop, window.device)
-    env = _envelopes.get(key)
-    if env is None:
-        env = _envelopes[key] = ops.istft_envelope(window, T, hop)
+    ent = _envelopes.get(key)
+    if ent is not None and ent[0] is window and ent[2] == window._version:
+        return ent[1]
+    env = ops.istft_envelope(window, T, hop)
+    if not (window.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if len(_envelopes) > 64:
+            _envelopes.clear()
+        _envelopes[key] = (window, env, window._version)
     return env
 
 
