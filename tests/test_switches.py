@@ -64,3 +64,18 @@ def test_documented_switch_gives_the_same_training_run(base, what, env, attrs, e
     if 'DCS_MFMA_TRACE' in env:
         assert '[mfma]' in err
 
+
+
+def test_no_kernel_reads_memory_nobody_wrote():
+    """tools/nanfill_probe.py: C_NETWORK train steps (bf16 storage, fp32, B = 1; captured) and inference with every torch.empty
+    filled with NaN (torch.utils.deterministic.fill_uninitialized_memory) print exactly what they print without the fill — a kernel
+    that read a buffer element before anything wrote it would turn a loss or a checksum into NaN (round 5: the probe that cleared
+    the kernels when DR-Net's replayed pack plan turned out to read freed memory)."""
+    probe = os.path.join(ROOT, 'tools', 'nanfill_probe.py')
+    outs = []
+    for arg in ([], ['nanfill']):
+        r = subprocess.run([sys.executable, probe, *arg], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (arg, r.stdout[-2000:], r.stderr[-3000:])
+        outs.append([ln for ln in r.stdout.split('\n') if ln.startswith('train') or ln.strip().startswith('eval')])
+    assert len(outs[0]) == 6 and outs[0] == outs[1], outs
+    assert 'nan' not in ' '.join(outs[1]).lower()
